@@ -1,0 +1,40 @@
+# Build of the MI355X path-tracing hot path.
+#   make            host library + HIP library (gfx950) + oracle (+ oracle/_ref when the reference is present)
+#   make host       libtrc_host.so      C++17, CPU only
+#   make hip        libtracer_amd.so    hand-written HIP for gfx950 (hipcc cross-compiles without a GPU)
+#   make oracle     oracle/liboracle.so (test infrastructure, see oracle/README.md)
+ROCM      ?= /opt/rocm
+HIPCC     ?= $(ROCM)/bin/hipcc
+CXX       ?= g++
+LIBDIR    := tracer_amd/lib
+
+# No FMA contraction anywhere: kernel and oracle must round every operation identically.
+CXXFLAGS  := -std=c++17 -O2 -fPIC -Wall -Wextra -ffp-contract=off -Iinclude
+HIPFLAGS  := -std=c++17 -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -Iinclude -Itracer_amd/csrc \
+             -Wall -Wno-unused-function
+
+HOST_SRC  := tracer_amd/host/bvh_builder.cpp tracer_amd/host/scene.cpp tracer_amd/host/mesh.cpp
+HOST_HDR  := tracer_amd/host/host_math.hpp include/tracer_abi.h
+HIP_SRC   := tracer_amd/csrc/trc_abi.hip
+HIP_HDR   := $(wildcard tracer_amd/csrc/*.hpp) include/tracer_abi.h include/trc_detmath.h
+
+.PHONY: all host hip oracle clean
+all: host hip oracle
+
+host: $(LIBDIR)/libtrc_host.so
+hip: $(LIBDIR)/libtracer_amd.so
+oracle:
+	$(MAKE) -C oracle
+
+$(LIBDIR)/libtrc_host.so: $(HOST_SRC) $(HOST_HDR)
+	@mkdir -p $(LIBDIR)
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -lpthread
+
+# RCCL is resolved at run time (dlopen in trc_group_*), so the library loads on boxes without it.
+$(LIBDIR)/libtracer_amd.so: $(HIP_SRC) $(HIP_HDR)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC) -ldl -Wl,-rpath,$(ROCM)/lib
+
+clean:
+	rm -f $(LIBDIR)/*.so
+	$(MAKE) -C oracle clean

@@ -1,0 +1,438 @@
+/*
+ * tracer_abi.h -- the drop-in boundary of the MI355X path-tracing hot path.
+ *
+ * Plain C ABI: extern "C", plain pointers and sizes, no C++/torch types.
+ *
+ * The reference (iaomw/Tracer, RT_Metal) has no FFI; its de-facto boundary is
+ * "flat buffers of POD structs shared by host and shader + one dispatch"
+ * (RT_Metal/Metal/Render.metal:495-509 kernel arguments; host side
+ * RT_Metal/Tracer/AAPLRenderer.mm:702-720,1167-1196).  This header restates
+ * those PODs byte-for-byte (Apple simd rules: float3 = 16 B / align 16,
+ * float2 = 8 / 8, float4x4 = 64 / 16 column-major, packed_float3 = 12 / 4)
+ * and declares the entry points a host would call in place of
+ * `-[AAPLRenderer render:]`.  Every struct cites the reference definition
+ * it mirrors; sizes/offsets are locked by static asserts below.
+ *
+ * Two shared libraries implement it:
+ *   libtracer_amd.so  (HIP, gfx950)  -- trc_*        device path (the product)
+ *   libtrc_host.so    (C++17, CPU)   -- trc_host_*   scene prep + SAH BVH builder
+ */
+#ifndef TRACER_ABI_H
+#define TRACER_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__cplusplus)
+#define TRC_ALIGN(n) alignas(n)
+#else
+#define TRC_ALIGN(n) _Alignas(n)
+#endif
+
+#define TRC_ABI_VERSION 1
+
+/* ------------------------------------------------------------------ */
+/* vector / matrix PODs (Apple simd layout)                            */
+/* ------------------------------------------------------------------ */
+
+/* simd_float2: 8 bytes, align 8 (RT_Metal/Metal/Common.hh:30) */
+typedef struct TRC_ALIGN(8) trc_float2 { float x, y; } trc_float2;
+/* simd_float3: 16 bytes, align 16; 4th lane is padding (Common.hh:29) */
+typedef struct TRC_ALIGN(16) trc_float3 { float x, y, z, _pad; } trc_float3;
+/* simd_float4 (Common.hh:28) */
+typedef struct TRC_ALIGN(16) trc_float4 { float x, y, z, w; } trc_float4;
+/* simd_float4x4: 4 columns, column-major (Common.hh:25) */
+typedef struct TRC_ALIGN(16) trc_float4x4 { trc_float4 columns[4]; } trc_float4x4;
+
+/* ------------------------------------------------------------------ */
+/* enums, with the reference's ordinals                                */
+/* ------------------------------------------------------------------ */
+
+/* RT_Metal/Metal/BVH.hh:6-8 */
+enum trc_PrimitiveType {
+    TRC_PRIM_SPHERE = 0, TRC_PRIM_SQUARE = 1, TRC_PRIM_CUBE = 2,
+    TRC_PRIM_TRIANGLE = 3, TRC_PRIM_BVH = 4, TRC_PRIM_UNKNOW = 5
+};
+/* RT_Metal/Metal/Material.hh:18-20 */
+enum trc_MaterialType {
+    TRC_MAT_DIFFUSE = 0, TRC_MAT_LAMBERT = 1, TRC_MAT_ORENNAYAR = 2,
+    TRC_MAT_PLASTIC = 3, TRC_MAT_METAL = 4, TRC_MAT_GLASS = 5,
+    TRC_MAT_ISOTROPIC = 6, TRC_MAT_DIELECTRIC = 7, TRC_MAT_DEMOFOX = 8,
+    TRC_MAT_PBR = 9, TRC_MAT_NIL = 10
+};
+/* RT_Metal/Metal/Ray.hh:6 */
+enum trc_MediumType { TRC_MEDIUM_NIL = 0, TRC_MEDIUM_HOMOGENEOUS = 1, TRC_MEDIUM_GRIDDENSITY = 2 };
+/* RT_Metal/Metal/Texture.hh:6 */
+enum trc_TextureType { TRC_TEX_CONSTANT = 0, TRC_TEX_CHECKER = 1, TRC_TEX_NOISE = 2, TRC_TEX_IMAGE = 3 };
+
+/* ------------------------------------------------------------------ */
+/* scene PODs                                                          */
+/* ------------------------------------------------------------------ */
+
+/* RT_Metal/Metal/AABB.hh:7-9 -- 32 bytes; empty box = (+FLT_MAX, -FLT_MAX) */
+typedef struct trc_AABB { trc_float3 mini, maxi; } trc_AABB;
+
+/* RT_Metal/Metal/BVH.hh:15-22 -- 64 bytes. Array form: root at index 0,
+ * leaves carry pType in {Sphere,Square,Cube,Triangle} + pIndex, interior
+ * nodes pType == BVH with left/right/parent indices into the same array. */
+typedef struct trc_BVH {
+    uint32_t parent, left, right;
+    uint32_t axis;
+    int32_t  pType;              /* enum trc_PrimitiveType */
+    uint32_t pIndex;
+    uint32_t _pad[2];
+    trc_AABB bBOX;
+} trc_BVH;
+
+/* RT_Metal/Metal/Sphere.hh:6-15 -- 272 bytes */
+typedef struct trc_Sphere {
+    float        radius;
+    uint32_t     _pad0[3];
+    trc_float3   center;
+    trc_float4x4 model_matrix, normal_matrix, inverse_matrix;
+    uint32_t     material;
+    uint32_t     _pad1[3];
+    trc_AABB     boundingBOX;
+} trc_Sphere;
+
+/* RT_Metal/Metal/Square.hh:12-27 -- 272 bytes; axis-aligned rectangle
+ * spanning range_i x range_j on axes (axis_i, axis_j) at axis_k = value_k */
+typedef struct trc_Square {
+    uint8_t      axis_i, axis_j;
+    uint8_t      _pad0[6];
+    trc_float2   range_i, range_j;
+    uint8_t      axis_k;
+    uint8_t      _pad1[3];
+    float        value_k;
+    trc_float4x4 model_matrix, normal_matrix, inverse_matrix;
+    uint32_t     material;
+    uint32_t     _pad2[3];
+    trc_AABB     boundingBOX;
+} trc_Square;
+
+/* RT_Metal/Metal/Cube.hh:6-13 -- 240 bytes; unit box under model_matrix */
+typedef struct trc_Cube {
+    trc_float4x4 model_matrix, normal_matrix, inverse_matrix;
+    trc_AABB     box;
+    uint32_t     material;
+    uint32_t     _pad[3];
+} trc_Cube;
+
+/* RT_Metal/Metal/Triangle.hh:12-18 (device) == Common.hh:32-36 MeshElement
+ * (host) -- 32 bytes, packed */
+typedef struct trc_TriangleVertex {
+    float v[3];
+    float n[3];
+    float uv[2];
+} trc_TriangleVertex;
+
+/* RT_Metal/Metal/Texture.hh:8-13 -- 32 bytes */
+typedef struct trc_TextureInfo {
+    int32_t    type;             /* enum trc_TextureType */
+    uint32_t   textureIndex;
+    uint32_t   _pad[2];
+    trc_float3 albedo;
+} trc_TextureInfo;
+
+/* RT_Metal/Metal/Material.hh:22-40 -- 64 bytes. NOTE (reference behaviour):
+ * BSDF parameters are hard-coded in MicrofacetBXDF.h create*() functions;
+ * eta / roughness are carried but not read by the shading path. */
+typedef struct trc_Material {
+    int32_t  type;               /* enum trc_MaterialType */
+    int32_t  medium;             /* enum trc_MediumType */
+    uint8_t  specular;
+    uint8_t  _pad0[3];
+    float    eta;
+    float    roughness;
+    uint32_t _pad1[3];
+    trc_TextureInfo textureInfo;
+} trc_Material;
+
+/* RT_Metal/Metal/Camera.hh:8-21 -- 176 bytes */
+typedef struct trc_Camera {
+    trc_float3 lookFrom, lookAt, viewUp;
+    float vfov, aspect, aperture, lenRadius;
+    float focus_dist;
+    uint32_t _pad[3];
+    trc_float3 u, v, w;
+    trc_float3 vertical, horizontal, cornerLowLeft;
+} trc_Camera;
+
+/* RT_Metal/Metal/Camera.hh:27-55 -- 96 bytes (per-frame uniforms) */
+typedef struct trc_Complex {
+    trc_float2 tex_size, view_size;
+    float      running_time;
+    uint32_t   frame_count;
+    uint32_t   _pad0[2];
+    trc_AABB   photonBox;
+    trc_float3 photonBoxSize;
+    float      photonInitialRadius;
+    float      photonHashScale;
+    float      totalPhotonSum;
+    uint32_t   framePhotonSum;
+} trc_Complex;
+
+/* Primitive argument table of the kernel (Render.hh:122-130) + materials of
+ * PackageEnv (Render.hh:24-32), as pointers + counts.  All pointers are HOST
+ * pointers; trc_upload_scene copies, the caller keeps ownership. */
+typedef struct trc_scene {
+    const trc_BVH*            bvhList;     uint32_t n_bvh;        /* 2*leaves-1, root at 0 */
+    const trc_Sphere*         sphereList;  uint32_t n_sphere;
+    const trc_Square*         squareList;  uint32_t n_square;
+    const trc_Cube*           cubeList;    uint32_t n_cube;
+    const trc_TriangleVertex* triList;     uint32_t n_vertex;
+    const uint32_t*           idxList;     uint32_t n_index;      /* 3 per triangle */
+    const trc_Material*       materials;   uint32_t n_material;
+} trc_scene;
+
+/* ------------------------------------------------------------------ */
+/* status codes                                                        */
+/* ------------------------------------------------------------------ */
+typedef int32_t trc_status;
+#define TRC_OK                  0
+#define TRC_ERR_INVALID_ARG    -1
+#define TRC_ERR_NO_DEVICE      -2   /* no HIP device / extension unusable: fail loudly */
+#define TRC_ERR_HIP            -3
+#define TRC_ERR_NO_SCENE       -4
+#define TRC_ERR_NO_FRAME       -5   /* trc_resize not called */
+#define TRC_ERR_BVH_INVALID    -6   /* malformed tree (bad index, depth > TRC_MAX_BVH_DEPTH, ...) */
+#define TRC_ERR_UNSUPPORTED    -7
+#define TRC_ERR_RCCL           -8
+#define TRC_ERR_OOM            -9
+
+#define TRC_MAX_BVH_DEPTH      64   /* reference: 32-bit stack_mark (Render.hh:140) */
+
+/* ------------------------------------------------------------------ */
+/* render parameters                                                   */
+/* ------------------------------------------------------------------ */
+enum trc_integrator {
+    TRC_INTEGRATOR_PATH = 0,     /* tracePath, Render.metal:411-492 (the active one, :532) */
+    TRC_INTEGRATOR_MIS  = 1      /* traceMIS,  Render.metal:277-409 */
+};
+
+/* flags */
+#define TRC_FLAG_COLLECT_STATS  1u  /* run the instrumented kernel variant: exact
+                                       N_descend / N_return / leaf-test counters */
+
+typedef struct trc_params {
+    uint32_t spp;                /* samples per pixel this call; the reference does 1 per launch */
+    uint32_t max_depth;          /* 8 (Render.metal:532) */
+    uint32_t integrator;         /* enum trc_integrator */
+    uint32_t frame0;             /* Complex.frame_count of the first sample (running-mean weight) */
+    uint32_t tile_rank;          /* this call renders tiles t with trc_tile_owner(t) == tile_rank ... */
+    uint32_t tile_nranks;        /* ... of tile_nranks (1 => whole frame) */
+    uint32_t flags;
+    uint32_t _reserved;
+} trc_params;
+
+/* Pixel tiles: TRC_TILE x TRC_TILE pixels, row-major tile grid, owner of
+ * tile (tx,ty) among n ranks = (tx + ty) % n. */
+#define TRC_TILE 16
+
+/* One ray / one hit of the Scene::hit test hook (Render.hh:135-252). */
+typedef struct trc_ray {
+    float origin[3];
+    float tmax;                  /* test_t: FLT_MAX for closest hit, distance for shadow rays */
+    float direction[3];          /* normalised on entry like Ray::Ray (Ray.hh:21-23) */
+    uint32_t _pad;
+} trc_ray;
+
+typedef struct trc_hit {
+    int32_t  hit;                /* return value of Scene::hit */
+    int32_t  pType;              /* primitive type of the closest hit, -1 on miss */
+    uint32_t pIndex;             /* index into its primitive list */
+    float    t;
+    float    p[3];
+    float    gn[3];
+    float    sn[3];
+    float    uv[2];
+    uint32_t material;
+    float    PDF;
+    uint32_t n_descend;          /* traversal iterations entered from the parent (Render.hh:155-187) */
+    uint32_t n_return;           /* iterations entered from a child (Render.hh:189-209) */
+    uint32_t n_leaf;             /* primitive hit_test calls */
+} trc_hit;
+
+/* Exact work counters of the render kernels since the last trc_reset_stats.
+ * rays / paths are always counted; the n_* traversal counters only when
+ * TRC_FLAG_COLLECT_STATS was set for the call. */
+typedef struct trc_stats {
+    uint64_t paths;              /* W*H*spp of the tiles rendered */
+    uint64_t rays;               /* Scene::hit invocations (primary + bounce + shadow) */
+    uint64_t shaded;             /* material lookups (S_F / F evaluations' hits) */
+    uint64_t n_descend, n_return;
+    uint64_t n_leaf_sphere, n_leaf_square, n_leaf_cube, n_leaf_triangle;
+    uint64_t n_hit_triangle;     /* triangle tests that hit (+60 B normal/uv fetch) */
+    uint64_t n_hit_cube;         /* cube tests that reach the world transform (228 B vs 100 B) */
+    uint64_t launches;           /* render kernel launches */
+    double   kernel_ms;          /* sum of hipEvent durations of those launches, on the ctx stream */
+} trc_stats;
+
+typedef struct trc_ctx trc_ctx;  /* one per GPU, single-threaded, owns one HIP stream */
+
+/* ------------------------------------------------------------------ */
+/* device path: libtracer_amd.so                                       */
+/* ------------------------------------------------------------------ */
+
+uint32_t    trc_abi_version(void);
+const char* trc_status_string(trc_status s);
+/* last error text of this context (HIP error string etc.), never NULL */
+const char* trc_last_error(const trc_ctx* ctx);
+
+/* replaces device/queue/pipeline creation, AAPLRenderer.mm:129-181 */
+trc_status trc_create(int device, trc_ctx** out);
+void       trc_destroy(trc_ctx* ctx);
+
+/* replaces buffer creation + heap copy, AAPLRenderer.mm:213-246,610-720,1233-1355 */
+trc_status trc_upload_scene(trc_ctx* ctx, const trc_scene* scene);
+/* replaces memcpy(_camera_buffer.contents, ...), AAPLRenderer.mm:1183 */
+trc_status trc_set_camera(trc_ctx* ctx, const trc_Camera* camera);
+/* constant environment radiance used on a miss; stands in for
+ * packageEnv.texHDR.sample (Render.metal:434-439; the HDR blob is missing) */
+trc_status trc_set_environment(trc_ctx* ctx, const float rgb[3]);
+
+/* (re)allocates accum A (RGBA32F) + RNG (RGBA32Uint) for a W x H frame and
+ * zeroes them; replaces texture creation, AAPLRenderer.mm:260-288 */
+trc_status trc_resize(trc_ctx* ctx, uint32_t width, uint32_t height);
+/* deterministic stand-in for fillRNG (AAPLRenderer.mm:296-344, arc4random):
+ * texel(x,y) = 4 successive pcg32 outputs of pcg32_srandom_r(seed, y*W+x),
+ * generated on the device; identical to trc_host_fill_rng. */
+trc_status trc_seed(trc_ctx* ctx, uint64_t seed);
+trc_status trc_upload_rng(trc_ctx* ctx, const uint32_t* rgba /* 4*W*H */);
+trc_status trc_download_rng(trc_ctx* ctx, uint32_t* rgba /* 4*W*H */);
+trc_status trc_upload_accum(trc_ctx* ctx, const float* rgba /* 4*W*H */);
+/* linear radiance running mean, same meaning as textureA/B (Render.metal:540-543) */
+trc_status trc_download_accum(trc_ctx* ctx, float* rgba /* 4*W*H */);
+trc_status trc_clear_accum(trc_ctx* ctx);
+
+/* replaces -[AAPLRenderer render:] + kernelPathTracing dispatch
+ * (AAPLRenderer.mm:1134-1196, Render.metal:495-558); asynchronous on the
+ * context stream; spp samples are fused into one launch with bit-identical
+ * results to spp launches of 1 sample. */
+trc_status trc_render(trc_ctx* ctx, const trc_params* params);
+trc_status trc_synchronize(trc_ctx* ctx);
+
+/* test hook = Scene::hit (Render.hh:135-252) on a batch of rays (host buffers) */
+trc_status trc_trace_rays(trc_ctx* ctx, const trc_ray* rays, size_t n, trc_hit* out, int any_hit);
+
+trc_status trc_get_stats(trc_ctx* ctx, trc_stats* out);   /* synchronises the stream */
+trc_status trc_reset_stats(trc_ctx* ctx);
+
+/* device info for the bench line */
+trc_status trc_device_info(trc_ctx* ctx, char* name, size_t name_len, int* cu_count, size_t* hbm_bytes);
+
+/* --- multi-GPU: pixel tiles sharded over ranks, one RCCL reduce -------- */
+#define TRC_UNIQUE_ID_BYTES 128
+/* rank 0 creates the id, every rank gets the same bytes out-of-band */
+trc_status trc_group_unique_id(uint8_t id[TRC_UNIQUE_ID_BYTES]);
+trc_status trc_group_init(trc_ctx* ctx, const uint8_t id[TRC_UNIQUE_ID_BYTES], int nranks, int rank);
+/* ncclReduce(sum) of the full-frame accum buffer to `root` on the ctx stream:
+ * every rank holds zeros outside its own tiles, so sum == gather */
+trc_status trc_group_reduce_accum(trc_ctx* ctx, int root);
+trc_status trc_group_finalize(trc_ctx* ctx);
+
+/* ------------------------------------------------------------------ */
+/* host path: libtrc_host.so (CPU only)                                */
+/* ------------------------------------------------------------------ */
+
+/* BVH::buildNode, RT_Metal/Metal/BVH.hh:273-314: world AABB of the 8 corners
+ * of `box` under model_matrix -> one leaf record */
+void trc_host_build_node(const trc_AABB* box, const trc_float4x4* model_matrix,
+                         int32_t pType, uint32_t pIndex, trc_BVH* out_leaf);
+/* BVH::buildTree + BVH::make, BVH.hh:35-269: 10-bucket SAH over the n_leaves
+ * leaf records at nodes[0..n_leaves); writes 2*n_leaves-1 nodes (root moved to
+ * index 0); `nodes` must have room for 2*n_leaves-1.  Serial post-order
+ * interior numbering (one legal schedule of the reference's GCD build). */
+trc_status trc_host_build_tree(trc_BVH* nodes, uint32_t n_leaves, uint32_t* out_n_nodes);
+/* depth of the deepest leaf (root = 0); TRC_ERR_BVH_INVALID on malformed trees */
+trc_status trc_host_tree_depth(const trc_BVH* nodes, uint32_t n_nodes, uint32_t* out_depth);
+
+/* MakeCamera / prepareCamera defaults, Tracer.mm:87-125,371-411 */
+void trc_host_make_camera(trc_Camera* out, const float lookFrom[3], const float lookAt[3],
+                          const float viewUp[3], float aperture, float aspect,
+                          float vfov_radians, float focus_dist);
+void trc_host_prepare_camera(trc_Camera* out, float width, float height);
+
+/* deterministic fillRNG stand-in (see trc_seed) */
+void trc_host_fill_rng(uint64_t seed, uint32_t width, uint32_t height, uint32_t* rgba);
+
+/* Scene assembly in the reference's order (AAPLRenderer.mm:213-246,459-468,
+ * 513-610): prepareCubeList (materials 0-2), prepareCornellBox (3-6),
+ * prepareSphereList (7-18), testMaterial (19); leaves = cubes 0..n-2, all
+ * squares, [spheres], [mesh triangles]; then buildTree. */
+typedef struct trc_host_scene trc_host_scene;
+
+enum trc_host_scene_kind {
+    TRC_SCENE_CORNELL          = 0,  /* as shipped: 2 cubes + 7 squares (spheres not in the BVH) */
+    TRC_SCENE_CORNELL_SPHERES  = 1,  /* BASELINE config 2: + the 12 spheres, materials remapped */
+    TRC_SCENE_CORNELL_MESH     = 2   /* + a triangle mesh placed by the reference transform */
+};
+
+/* mesh: optional (NULL for kinds 0/1); positions/normals/uvs as
+ * trc_TriangleVertex + triangle indices in OBJECT space; placement
+ * (AAPLRenderer.mm:513-525,562-572) is applied by the call. */
+trc_status trc_host_scene_create(int32_t kind,
+                                 const trc_TriangleVertex* mesh_vertices, uint32_t n_vertices,
+                                 const uint32_t* mesh_indices, uint32_t n_indices,
+                                 trc_host_scene** out);
+void       trc_host_scene_destroy(trc_host_scene* s);
+/* view of the assembled arrays (valid until destroy) */
+void       trc_host_scene_view(const trc_host_scene* s, trc_scene* out);
+
+/* minimal Wavefront OBJ reader (v / vn / vt / f; polygons fan-triangulated;
+ * smooth normals generated when the file has none), standing in for ModelIO
+ * (AAPLRenderer.mm:474-511).  Returns arrays owned by the mesh handle. */
+typedef struct trc_host_mesh trc_host_mesh;
+trc_status trc_host_mesh_load_obj(const char* path, trc_host_mesh** out);
+/* procedural stand-in for the missing/untravelling assets: a displaced
+ * UV-sphere "ball" with n_lat x n_lon quads (2 triangles each) */
+trc_status trc_host_mesh_make_ball(uint32_t n_lat, uint32_t n_lon, float bump, trc_host_mesh** out);
+/* k x k grid replication (config 4: >= 1 M triangles) */
+trc_status trc_host_mesh_replicate(const trc_host_mesh* src, uint32_t k, float spacing, trc_host_mesh** out);
+void       trc_host_mesh_view(const trc_host_mesh* m, const trc_TriangleVertex** vertices,
+                              uint32_t* n_vertices, const uint32_t** indices, uint32_t* n_indices);
+void       trc_host_mesh_destroy(trc_host_mesh* m);
+
+#ifdef __cplusplus
+}  /* extern "C" */
+#endif
+
+/* ------------------------------------------------------------------ */
+/* layout locks                                 */
+/* ------------------------------------------------------------------ */
+#if defined(__cplusplus)
+#define TRC_SA(c, m) static_assert(c, m)
+#else
+#define TRC_SA(c, m) _Static_assert(c, m)
+#endif
+TRC_SA(sizeof(trc_float2) == 8 && sizeof(trc_float3) == 16 && sizeof(trc_float4x4) == 64, "simd sizes");
+TRC_SA(sizeof(trc_AABB) == 32 && offsetof(trc_AABB, maxi) == 16, "AABB");
+TRC_SA(sizeof(trc_BVH) == 64 && offsetof(trc_BVH, pType) == 16 && offsetof(trc_BVH, pIndex) == 20 &&
+       offsetof(trc_BVH, bBOX) == 32, "BVH");
+TRC_SA(sizeof(trc_Sphere) == 272 && offsetof(trc_Sphere, center) == 16 && offsetof(trc_Sphere, model_matrix) == 32 &&
+       offsetof(trc_Sphere, normal_matrix) == 96 && offsetof(trc_Sphere, inverse_matrix) == 160 &&
+       offsetof(trc_Sphere, material) == 224 && offsetof(trc_Sphere, boundingBOX) == 240, "Sphere");
+TRC_SA(sizeof(trc_Square) == 272 && offsetof(trc_Square, axis_j) == 1 && offsetof(trc_Square, range_i) == 8 &&
+       offsetof(trc_Square, range_j) == 16 && offsetof(trc_Square, axis_k) == 24 &&
+       offsetof(trc_Square, value_k) == 28 && offsetof(trc_Square, model_matrix) == 32 &&
+       offsetof(trc_Square, material) == 224 && offsetof(trc_Square, boundingBOX) == 240, "Square");
+TRC_SA(sizeof(trc_Cube) == 240 && offsetof(trc_Cube, normal_matrix) == 64 && offsetof(trc_Cube, inverse_matrix) == 128 &&
+       offsetof(trc_Cube, box) == 192 && offsetof(trc_Cube, material) == 224, "Cube");
+TRC_SA(sizeof(trc_TriangleVertex) == 32, "TriangleVertex");
+TRC_SA(sizeof(trc_TextureInfo) == 32 && offsetof(trc_TextureInfo, albedo) == 16, "TextureInfo");
+TRC_SA(sizeof(trc_Material) == 64 && offsetof(trc_Material, medium) == 4 && offsetof(trc_Material, specular) == 8 &&
+       offsetof(trc_Material, eta) == 12 && offsetof(trc_Material, roughness) == 16 &&
+       offsetof(trc_Material, textureInfo) == 32, "Material");
+TRC_SA(sizeof(trc_Camera) == 176 && offsetof(trc_Camera, vfov) == 48 && offsetof(trc_Camera, focus_dist) == 64 &&
+       offsetof(trc_Camera, u) == 80 && offsetof(trc_Camera, vertical) == 128 &&
+       offsetof(trc_Camera, cornerLowLeft) == 160, "Camera");
+TRC_SA(sizeof(trc_Complex) == 96 && offsetof(trc_Complex, frame_count) == 20 && offsetof(trc_Complex, photonBox) == 32 &&
+       offsetof(trc_Complex, photonBoxSize) == 64 && offsetof(trc_Complex, photonInitialRadius) == 80 &&
+       offsetof(trc_Complex, framePhotonSum) == 92, "Complex");
+TRC_SA(sizeof(trc_ray) == 32, "trc_ray");
+
+#endif /* TRACER_ABI_H */

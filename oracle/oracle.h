@@ -1,0 +1,72 @@
+/*
+ * oracle.h -- C API of the CPU oracle (TEST INFRASTRUCTURE, not product code).
+ *
+ * The oracle is a scalar, literal CPU restatement of the reference's hot path
+ * (RT_Metal Metal shaders), function for function, quirks included.  Only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it;
+ * the product path (tracer_amd/) never includes, links or calls anything here.
+ *
+ * PARITY PIN STATUS: the reference ships no tests, golden vectors or fixtures
+ * for this path and its Metal/Obj-C++/Swift sources cannot be built or run on
+ * Linux.  The only executable pin is PCG32: the reference's own
+ * vendored RT_Metal/Tracer/pcg_basic.c compiles here (oracle/_ref) and its
+ * outputs are committed as tests/golden/pcg32_kat.json.  Everything else is
+ * pinned by analytic known-answer tests and brute-force cross-checks
+ * (tests/test_oracle_*.py).  Parity against the reference's actual Metal
+ * output is therefore UNPINNED ("parity unpinned" beyond PCG32).
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+
+#include "tracer_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* 1 if built with -DORACLE_USE_LIBM (glibc sinf/cosf/... instead of trc_detmath.h) */
+int orc_uses_libm(void);
+
+/* PCG32: Random.metal:3-26 == pcg_basic.c:42-72 */
+void     orc_pcg32_srandom(uint64_t* state, uint64_t* inc, uint64_t initstate, uint64_t initseq);
+uint32_t orc_pcg32_random(uint64_t* state, uint64_t inc);
+float    orc_randomF(uint64_t* state, uint64_t inc);
+
+/* Scene::hit (Render.hh:135-252) on a batch */
+void orc_trace_rays(const trc_scene* scene, const trc_ray* rays, size_t n, trc_hit* out, int any_hit);
+/* brute force: every leaf of the BVH array tested in array order (cross-check only) */
+void orc_trace_rays_brute(const trc_scene* scene, const trc_ray* rays, size_t n, trc_hit* out);
+
+/* kernelPathTracing (Render.metal:495-558) for the tiles owned by params->tile_rank,
+ * params->spp successive "frames" starting at params->frame0.  rng/accum are the
+ * RGBA32Uint / RGBA32F textures, updated in place.  n_threads row-band workers
+ * (0 = hardware concurrency); results do not depend on n_threads. */
+void orc_render(const trc_scene* scene, const trc_Camera* camera, const float env_rgb[3],
+                uint32_t width, uint32_t height, uint32_t* rng_rgba, float* accum_rgba,
+                const trc_params* params, trc_stats* stats, int n_threads);
+
+/* material entry points (Material.hh:77-146) in the local shading frame */
+void  orc_material_S_F(const trc_Material* m, const float wo[3], const float uv[2], const float uu[2],
+                       float wi_out[3], float f_out[3], float* pdf_out);
+void  orc_material_F(const trc_Material* m, const float wo[3], const float wi[3], const float uv[2],
+                     const float uu[2], float f_out[3], float* pdf_out);
+float orc_material_PDF(const trc_Material* m, const float wo[3], const float wi[3], const float uu[2]);
+
+/* small pieces for known-answer tests */
+void  orc_offset_ray(const float p[3], const float n[3], float out[3]);                 /* Math.hh:57-74 */
+float orc_fr_dielectric(float cosi, float eta);                                          /* BXDF.metal:3-22 */
+void  orc_fr_conductor(float cosi, const float eta[3], const float k[3], float out[3]);  /* BXDF.metal:24-34 */
+float orc_power_heuristic(int nf, float fPdf, int ng, float gPdf);                       /* Sampling.hh:137-140 */
+void  orc_cosine_sample_hemisphere(const float u[2], float out[3]);                      /* Sampling.hh:125-129 */
+float orc_erf(float x);                                                                  /* Math.hh:148-167 */
+float orc_erfinv(float x);                                                               /* Math.hh:118-146 */
+int   orc_aabb_hit_t(const trc_AABB* box, const trc_ray* ray, float tmin, float tmax, float* t_out); /* AABB.hh:92-112 */
+void  orc_cast_ray(const trc_Camera* cam, float s, float t, uint64_t* state, uint64_t inc,
+                   float origin_out[3], float dir_out[3]);                               /* Camera.hh:59-69 */
+/* deterministic math under test (identity wrappers over trc_detmath.h / libm) */
+float orc_math(int fn, float a, float b);   /* 0 sin 1 cos 2 exp 3 log 4 pow 5 asin 6 acos 7 atan2 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

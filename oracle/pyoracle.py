@@ -1,0 +1,113 @@
+"""ctypes loader of the CPU oracle (TEST INFRASTRUCTURE -- see oracle/oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(_HERE))
+from tracer_amd import abi  # noqa: E402  (PODs only; the oracle never calls the product path)
+
+_LIBS = {}
+
+
+def lib(libm=False):
+    key = "liboracle_libm.so" if libm else "liboracle.so"
+    if key not in _LIBS:
+        path = os.path.join(_HERE, key)
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `make oracle`")
+        L = C.CDLL(path)
+        f3 = C.POINTER(C.c_float)
+        L.orc_uses_libm.restype = C.c_int
+        L.orc_pcg32_srandom.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64]
+        L.orc_pcg32_srandom.restype = None
+        L.orc_pcg32_random.argtypes = [C.POINTER(C.c_uint64), C.c_uint64]
+        L.orc_pcg32_random.restype = C.c_uint32
+        L.orc_randomF.argtypes = [C.POINTER(C.c_uint64), C.c_uint64]
+        L.orc_randomF.restype = C.c_float
+        L.orc_trace_rays.argtypes = [C.POINTER(abi.Scene), C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+        L.orc_trace_rays.restype = None
+        L.orc_trace_rays_brute.argtypes = [C.POINTER(abi.Scene), C.c_void_p, C.c_size_t, C.c_void_p]
+        L.orc_trace_rays_brute.restype = None
+        L.orc_render.argtypes = [C.POINTER(abi.Scene), C.POINTER(abi.Camera), f3, C.c_uint32, C.c_uint32,
+                                 C.c_void_p, C.c_void_p, C.POINTER(abi.Params), C.POINTER(abi.Stats), C.c_int]
+        L.orc_render.restype = None
+        L.orc_material_S_F.argtypes = [C.POINTER(abi.Material), f3, f3, f3, f3, f3, f3]
+        L.orc_material_S_F.restype = None
+        L.orc_material_F.argtypes = [C.POINTER(abi.Material), f3, f3, f3, f3, f3, f3]
+        L.orc_material_F.restype = None
+        L.orc_material_PDF.argtypes = [C.POINTER(abi.Material), f3, f3, f3]
+        L.orc_material_PDF.restype = C.c_float
+        L.orc_offset_ray.argtypes = [f3, f3, f3]
+        L.orc_offset_ray.restype = None
+        L.orc_fr_dielectric.argtypes = [C.c_float, C.c_float]
+        L.orc_fr_dielectric.restype = C.c_float
+        L.orc_fr_conductor.argtypes = [C.c_float, f3, f3, f3]
+        L.orc_fr_conductor.restype = None
+        L.orc_power_heuristic.argtypes = [C.c_int, C.c_float, C.c_int, C.c_float]
+        L.orc_power_heuristic.restype = C.c_float
+        L.orc_cosine_sample_hemisphere.argtypes = [f3, f3]
+        L.orc_cosine_sample_hemisphere.restype = None
+        L.orc_erf.argtypes = [C.c_float]
+        L.orc_erf.restype = C.c_float
+        L.orc_erfinv.argtypes = [C.c_float]
+        L.orc_erfinv.restype = C.c_float
+        L.orc_aabb_hit_t.argtypes = [C.POINTER(abi.AABB), C.POINTER(abi.Ray), C.c_float, C.c_float,
+                                     C.POINTER(C.c_float)]
+        L.orc_aabb_hit_t.restype = C.c_int
+        L.orc_cast_ray.argtypes = [C.POINTER(abi.Camera), C.c_float, C.c_float, C.POINTER(C.c_uint64), C.c_uint64,
+                                   f3, f3]
+        L.orc_cast_ray.restype = None
+        L.orc_math.argtypes = [C.c_int, C.c_float, C.c_float]
+        L.orc_math.restype = C.c_float
+        _LIBS[key] = L
+    return _LIBS[key]
+
+
+RAY_DTYPE = np.dtype([("origin", np.float32, 3), ("tmax", np.float32), ("direction", np.float32, 3),
+                      ("_pad", np.uint32)])
+HIT_DTYPE = np.dtype([("hit", np.int32), ("pType", np.int32), ("pIndex", np.uint32), ("t", np.float32),
+                      ("p", np.float32, 3), ("gn", np.float32, 3), ("sn", np.float32, 3), ("uv", np.float32, 2),
+                      ("material", np.uint32), ("PDF", np.float32),
+                      ("n_descend", np.uint32), ("n_return", np.uint32), ("n_leaf", np.uint32)])
+assert RAY_DTYPE.itemsize == C.sizeof(abi.Ray) and HIT_DTYPE.itemsize == C.sizeof(abi.Hit)
+
+
+def make_rays(origins, directions, tmax=None):
+    n = len(origins)
+    rays = np.zeros(n, dtype=RAY_DTYPE)
+    rays["origin"] = origins
+    rays["direction"] = directions
+    rays["tmax"] = np.float32(np.finfo(np.float32).max) if tmax is None else tmax
+    return rays
+
+
+def trace_rays(scene_view, rays, any_hit=False, brute=False, libm=False):
+    hits = np.zeros(len(rays), dtype=HIT_DTYPE)
+    L = lib(libm)
+    if brute:
+        L.orc_trace_rays_brute(C.byref(scene_view), rays.ctypes.data, len(rays), hits.ctypes.data)
+    else:
+        L.orc_trace_rays(C.byref(scene_view), rays.ctypes.data, len(rays), hits.ctypes.data, 1 if any_hit else 0)
+    return hits
+
+
+def render(scene_view, camera, width, height, rng, accum=None, spp=1, max_depth=8, integrator=0, frame0=0,
+           env=(0.0, 0.0, 0.0), tile_rank=0, tile_nranks=1, n_threads=0, libm=False):
+    """kernelPathTracing on the CPU.  rng: (H,W,4) uint32, updated in place.  Returns (accum, stats)."""
+    assert rng.dtype == np.uint32 and rng.shape == (height, width, 4) and rng.flags.c_contiguous
+    if accum is None:
+        accum = np.zeros((height, width, 4), dtype=np.float32)
+    assert accum.dtype == np.float32 and accum.shape == (height, width, 4) and accum.flags.c_contiguous
+    prm = abi.Params(spp=spp, max_depth=max_depth, integrator=integrator, frame0=frame0,
+                     tile_rank=tile_rank, tile_nranks=tile_nranks, flags=abi.FLAG_COLLECT_STATS)
+    stats = abi.Stats()
+    env_c = (C.c_float * 3)(*env)
+    lib(libm).orc_render(C.byref(scene_view), C.byref(camera), env_c, width, height, rng.ctypes.data,
+                         accum.ctypes.data, C.byref(prm), C.byref(stats), n_threads)
+    return accum, stats

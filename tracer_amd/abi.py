@@ -1,0 +1,157 @@
+"""ctypes mirror of include/tracer_abi.h (the drop-in boundary).
+
+Every Structure below restates one POD of the header; sizes are asserted against
+SURVEY.md Appendix A at import time so a drift between the header and this file
+fails loudly.  Reference definitions: RT_Metal/Metal/{AABB,BVH,Sphere,Square,Cube,
+Triangle,Texture,Material,Camera}.hh (see the header for file:line).
+"""
+import ctypes as C
+
+TRC_ABI_VERSION = 1
+TRC_TILE = 16
+TRC_MAX_BVH_DEPTH = 64
+TRC_UNIQUE_ID_BYTES = 128
+
+# enum trc_PrimitiveType (BVH.hh:6-8)
+PRIM_SPHERE, PRIM_SQUARE, PRIM_CUBE, PRIM_TRIANGLE, PRIM_BVH, PRIM_UNKNOW = range(6)
+# enum trc_MaterialType (Material.hh:18-20)
+(MAT_DIFFUSE, MAT_LAMBERT, MAT_ORENNAYAR, MAT_PLASTIC, MAT_METAL, MAT_GLASS,
+ MAT_ISOTROPIC, MAT_DIELECTRIC, MAT_DEMOFOX, MAT_PBR, MAT_NIL) = range(11)
+# enum trc_TextureType (Texture.hh:6)
+TEX_CONSTANT, TEX_CHECKER, TEX_NOISE, TEX_IMAGE = range(4)
+# enum trc_integrator
+INTEGRATOR_PATH, INTEGRATOR_MIS = 0, 1
+# enum trc_host_scene_kind
+SCENE_CORNELL, SCENE_CORNELL_SPHERES, SCENE_CORNELL_MESH = 0, 1, 2
+FLAG_COLLECT_STATS = 1
+
+# status codes
+OK = 0
+ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NO_SCENE, ERR_NO_FRAME = -1, -2, -3, -4, -5
+ERR_BVH_INVALID, ERR_UNSUPPORTED, ERR_RCCL, ERR_OOM = -6, -7, -8, -9
+
+
+class float2(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float)]
+
+
+class float3(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float), ("_pad", C.c_float)]
+
+
+class float4(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float), ("w", C.c_float)]
+
+
+class float4x4(C.Structure):
+    _fields_ = [("columns", float4 * 4)]
+
+
+class AABB(C.Structure):
+    _fields_ = [("mini", float3), ("maxi", float3)]
+
+
+class BVH(C.Structure):
+    _fields_ = [("parent", C.c_uint32), ("left", C.c_uint32), ("right", C.c_uint32), ("axis", C.c_uint32),
+                ("pType", C.c_int32), ("pIndex", C.c_uint32), ("_pad", C.c_uint32 * 2), ("bBOX", AABB)]
+
+
+class Sphere(C.Structure):
+    _fields_ = [("radius", C.c_float), ("_pad0", C.c_uint32 * 3), ("center", float3),
+                ("model_matrix", float4x4), ("normal_matrix", float4x4), ("inverse_matrix", float4x4),
+                ("material", C.c_uint32), ("_pad1", C.c_uint32 * 3), ("boundingBOX", AABB)]
+
+
+class Square(C.Structure):
+    _fields_ = [("axis_i", C.c_uint8), ("axis_j", C.c_uint8), ("_pad0", C.c_uint8 * 6),
+                ("range_i", float2), ("range_j", float2),
+                ("axis_k", C.c_uint8), ("_pad1", C.c_uint8 * 3), ("value_k", C.c_float),
+                ("model_matrix", float4x4), ("normal_matrix", float4x4), ("inverse_matrix", float4x4),
+                ("material", C.c_uint32), ("_pad2", C.c_uint32 * 3), ("boundingBOX", AABB)]
+
+
+class Cube(C.Structure):
+    _fields_ = [("model_matrix", float4x4), ("normal_matrix", float4x4), ("inverse_matrix", float4x4),
+                ("box", AABB), ("material", C.c_uint32), ("_pad", C.c_uint32 * 3)]
+
+
+class TriangleVertex(C.Structure):
+    _fields_ = [("v", C.c_float * 3), ("n", C.c_float * 3), ("uv", C.c_float * 2)]
+
+
+class TextureInfo(C.Structure):
+    _fields_ = [("type", C.c_int32), ("textureIndex", C.c_uint32), ("_pad", C.c_uint32 * 2), ("albedo", float3)]
+
+
+class Material(C.Structure):
+    _fields_ = [("type", C.c_int32), ("medium", C.c_int32), ("specular", C.c_uint8), ("_pad0", C.c_uint8 * 3),
+                ("eta", C.c_float), ("roughness", C.c_float), ("_pad1", C.c_uint32 * 3),
+                ("textureInfo", TextureInfo)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("lookFrom", float3), ("lookAt", float3), ("viewUp", float3),
+                ("vfov", C.c_float), ("aspect", C.c_float), ("aperture", C.c_float), ("lenRadius", C.c_float),
+                ("focus_dist", C.c_float), ("_pad", C.c_uint32 * 3),
+                ("u", float3), ("v", float3), ("w", float3),
+                ("vertical", float3), ("horizontal", float3), ("cornerLowLeft", float3)]
+
+
+class Scene(C.Structure):
+    _fields_ = [("bvhList", C.POINTER(BVH)), ("n_bvh", C.c_uint32),
+                ("sphereList", C.POINTER(Sphere)), ("n_sphere", C.c_uint32),
+                ("squareList", C.POINTER(Square)), ("n_square", C.c_uint32),
+                ("cubeList", C.POINTER(Cube)), ("n_cube", C.c_uint32),
+                ("triList", C.POINTER(TriangleVertex)), ("n_vertex", C.c_uint32),
+                ("idxList", C.POINTER(C.c_uint32)), ("n_index", C.c_uint32),
+                ("materials", C.POINTER(Material)), ("n_material", C.c_uint32)]
+
+
+class Params(C.Structure):
+    _fields_ = [("spp", C.c_uint32), ("max_depth", C.c_uint32), ("integrator", C.c_uint32),
+                ("frame0", C.c_uint32), ("tile_rank", C.c_uint32), ("tile_nranks", C.c_uint32),
+                ("flags", C.c_uint32), ("_reserved", C.c_uint32)]
+
+
+class Ray(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("tmax", C.c_float), ("direction", C.c_float * 3), ("_pad", C.c_uint32)]
+
+
+class Hit(C.Structure):
+    _fields_ = [("hit", C.c_int32), ("pType", C.c_int32), ("pIndex", C.c_uint32), ("t", C.c_float),
+                ("p", C.c_float * 3), ("gn", C.c_float * 3), ("sn", C.c_float * 3), ("uv", C.c_float * 2),
+                ("material", C.c_uint32), ("PDF", C.c_float),
+                ("n_descend", C.c_uint32), ("n_return", C.c_uint32), ("n_leaf", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("shaded", C.c_uint64),
+                ("n_descend", C.c_uint64), ("n_return", C.c_uint64),
+                ("n_leaf_sphere", C.c_uint64), ("n_leaf_square", C.c_uint64),
+                ("n_leaf_cube", C.c_uint64), ("n_leaf_triangle", C.c_uint64),
+                ("n_hit_triangle", C.c_uint64), ("n_hit_cube", C.c_uint64),
+                ("launches", C.c_uint64), ("kernel_ms", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_EXPECTED_SIZES = {float2: 8, float3: 16, float4x4: 64, AABB: 32, BVH: 64, Sphere: 272, Square: 272, Cube: 240,
+                   TriangleVertex: 32, TextureInfo: 32, Material: 64, Camera: 176, Ray: 32, Params: 32}
+for _t, _n in _EXPECTED_SIZES.items():
+    assert C.sizeof(_t) == _n, f"{_t.__name__}: ctypes size {C.sizeof(_t)} != ABI size {_n}"
+
+# every symbol include/tracer_abi.h declares, by library (checked by tests/test_abi_symbols.py)
+DEVICE_SYMBOLS = [
+    "trc_abi_version", "trc_status_string", "trc_last_error", "trc_create", "trc_destroy",
+    "trc_upload_scene", "trc_set_camera", "trc_set_environment", "trc_resize", "trc_seed",
+    "trc_upload_rng", "trc_download_rng", "trc_upload_accum", "trc_download_accum", "trc_clear_accum",
+    "trc_render", "trc_synchronize", "trc_trace_rays", "trc_get_stats", "trc_reset_stats",
+    "trc_device_info", "trc_group_unique_id", "trc_group_init", "trc_group_reduce_accum", "trc_group_finalize",
+]
+HOST_SYMBOLS = [
+    "trc_host_build_node", "trc_host_build_tree", "trc_host_tree_depth", "trc_host_make_camera",
+    "trc_host_prepare_camera", "trc_host_fill_rng", "trc_host_scene_create", "trc_host_scene_destroy",
+    "trc_host_scene_view", "trc_host_mesh_load_obj", "trc_host_mesh_make_ball", "trc_host_mesh_replicate",
+    "trc_host_mesh_view", "trc_host_mesh_destroy",
+]

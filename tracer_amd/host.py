@@ -1,0 +1,196 @@
+"""Host side (CPU): scene assembly + SAH BVH builder, through libtrc_host.so.
+
+Mirrors the reference's host half -- prepareCubeList / prepareCornellBox / prepareSphereList /
+prepareCamera (RT_Metal/Tracer/Tracer.hh:43-47) and BVH::buildNode / buildTree
+(RT_Metal/Metal/BVH.hh:246-314) -- behind the C ABI of include/tracer_abi.h.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_LIB = None
+
+
+def lib_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtrc_host.so")
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `make host` (or __graft_entry__.build())")
+        L = C.CDLL(path)
+        L.trc_host_build_node.argtypes = [C.POINTER(abi.AABB), C.POINTER(abi.float4x4), C.c_int32, C.c_uint32,
+                                          C.POINTER(abi.BVH)]
+        L.trc_host_build_node.restype = None
+        L.trc_host_build_tree.argtypes = [C.POINTER(abi.BVH), C.c_uint32, C.POINTER(C.c_uint32)]
+        L.trc_host_build_tree.restype = C.c_int32
+        L.trc_host_tree_depth.argtypes = [C.POINTER(abi.BVH), C.c_uint32, C.POINTER(C.c_uint32)]
+        L.trc_host_tree_depth.restype = C.c_int32
+        L.trc_host_make_camera.argtypes = [C.POINTER(abi.Camera), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                           C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_float]
+        L.trc_host_make_camera.restype = None
+        L.trc_host_prepare_camera.argtypes = [C.POINTER(abi.Camera), C.c_float, C.c_float]
+        L.trc_host_prepare_camera.restype = None
+        L.trc_host_fill_rng.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.trc_host_fill_rng.restype = None
+        L.trc_host_scene_create.argtypes = [C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                            C.POINTER(C.c_void_p)]
+        L.trc_host_scene_create.restype = C.c_int32
+        L.trc_host_scene_destroy.argtypes = [C.c_void_p]
+        L.trc_host_scene_destroy.restype = None
+        L.trc_host_scene_view.argtypes = [C.c_void_p, C.POINTER(abi.Scene)]
+        L.trc_host_scene_view.restype = None
+        L.trc_host_mesh_load_obj.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.trc_host_mesh_load_obj.restype = C.c_int32
+        L.trc_host_mesh_make_ball.argtypes = [C.c_uint32, C.c_uint32, C.c_float, C.POINTER(C.c_void_p)]
+        L.trc_host_mesh_make_ball.restype = C.c_int32
+        L.trc_host_mesh_replicate.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.POINTER(C.c_void_p)]
+        L.trc_host_mesh_replicate.restype = C.c_int32
+        L.trc_host_mesh_view.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32),
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
+        L.trc_host_mesh_view.restype = None
+        L.trc_host_mesh_destroy.argtypes = [C.c_void_p]
+        L.trc_host_mesh_destroy.restype = None
+        _LIB = L
+    return _LIB
+
+
+def _check(status, what):
+    if status != abi.OK:
+        raise RuntimeError(f"{what} failed with trc_status {status}")
+
+
+class Mesh:
+    """Triangle mesh in object space: 32-byte vertices + u32 triangle indices."""
+
+    def __init__(self, handle):
+        self._h = handle
+        vp, ip = C.c_void_p(), C.c_void_p()
+        nv, ni = C.c_uint32(), C.c_uint32()
+        lib().trc_host_mesh_view(self._h, C.byref(vp), C.byref(nv), C.byref(ip), C.byref(ni))
+        self.vertices_ptr, self.n_vertices = vp.value, nv.value
+        self.indices_ptr, self.n_indices = ip.value, ni.value
+
+    @classmethod
+    def load_obj(cls, path):
+        h = C.c_void_p()
+        _check(lib().trc_host_mesh_load_obj(os.fsencode(path), C.byref(h)), f"trc_host_mesh_load_obj({path})")
+        return cls(h)
+
+    @classmethod
+    def ball(cls, n_lat, n_lon, bump=0.05):
+        h = C.c_void_p()
+        _check(lib().trc_host_mesh_make_ball(n_lat, n_lon, bump, C.byref(h)), "trc_host_mesh_make_ball")
+        return cls(h)
+
+    def replicate(self, k, spacing):
+        h = C.c_void_p()
+        _check(lib().trc_host_mesh_replicate(self._h, k, spacing, C.byref(h)), "trc_host_mesh_replicate")
+        return Mesh(h)
+
+    @property
+    def n_triangles(self):
+        return self.n_indices // 3
+
+    def vertices(self):
+        a = (C.c_float * (8 * self.n_vertices)).from_address(self.vertices_ptr)
+        return np.frombuffer(a, dtype=np.float32).reshape(-1, 8)
+
+    def indices(self):
+        a = (C.c_uint32 * self.n_indices).from_address(self.indices_ptr)
+        return np.frombuffer(a, dtype=np.uint32)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().trc_host_mesh_destroy(self._h)
+            self._h = None
+
+
+class HostScene:
+    """Scene arrays in the reference's layouts + the built BVH (root at index 0)."""
+
+    def __init__(self, kind=abi.SCENE_CORNELL_SPHERES, mesh=None):
+        self._h = C.c_void_p()
+        self._mesh = mesh
+        if mesh is not None:
+            st = lib().trc_host_scene_create(kind, mesh.vertices_ptr, mesh.n_vertices, mesh.indices_ptr,
+                                             mesh.n_indices, C.byref(self._h))
+        else:
+            st = lib().trc_host_scene_create(kind, None, 0, None, 0, C.byref(self._h))
+        _check(st, "trc_host_scene_create")
+        self.view = abi.Scene()
+        lib().trc_host_scene_view(self._h, C.byref(self.view))
+
+    @property
+    def n_leaves(self):
+        return (self.view.n_bvh + 1) // 2
+
+    def bvh(self):
+        return [self.view.bvhList[i] for i in range(self.view.n_bvh)]
+
+    def bvh_array(self):
+        """(n_bvh, 16) uint32 view of the node array (columns: parent,left,right,axis,pType,pIndex,...)"""
+        a = (C.c_uint32 * (16 * self.view.n_bvh)).from_address(C.addressof(self.view.bvhList.contents))
+        return np.frombuffer(a, dtype=np.uint32).reshape(-1, 16)
+
+    def tree_depth(self):
+        d = C.c_uint32()
+        _check(lib().trc_host_tree_depth(self.view.bvhList, self.view.n_bvh, C.byref(d)), "trc_host_tree_depth")
+        return d.value
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().trc_host_scene_destroy(self._h)
+            self._h = None
+
+
+def prepare_camera(width, height):
+    cam = abi.Camera()
+    lib().trc_host_prepare_camera(C.byref(cam), float(width), float(height))
+    return cam
+
+
+def make_camera(look_from, look_at, view_up, aperture, aspect, vfov_radians, focus_dist):
+    cam = abi.Camera()
+    f3 = C.c_float * 3
+    lib().trc_host_make_camera(C.byref(cam), f3(*look_from), f3(*look_at), f3(*view_up), aperture, aspect,
+                               vfov_radians, focus_dist)
+    return cam
+
+
+def fill_rng(seed, width, height):
+    out = np.empty((height, width, 4), dtype=np.uint32)
+    lib().trc_host_fill_rng(seed, width, height, out.ctypes.data)
+    return out
+
+
+def build_tree(leaves):
+    """leaves: list of abi.BVH leaf records -> ctypes array of 2n-1 nodes, root at 0."""
+    n = len(leaves)
+    nodes = (abi.BVH * (2 * n - 1))()
+    for i, leaf in enumerate(leaves):
+        nodes[i] = leaf
+    count = C.c_uint32()
+    _check(lib().trc_host_build_tree(nodes, n, C.byref(count)), "trc_host_build_tree")
+    assert count.value == 2 * n - 1
+    return nodes
+
+
+def build_node(box_min, box_max, ptype, pindex, model=None):
+    box = abi.AABB()
+    box.mini.x, box.mini.y, box.mini.z = box_min
+    box.maxi.x, box.maxi.y, box.maxi.z = box_max
+    m = abi.float4x4()
+    for c in range(4):
+        for r in range(4):
+            v = float(model[r][c]) if model is not None else (1.0 if r == c else 0.0)
+            setattr(m.columns[c], "xyzw"[r], v)
+    out = abi.BVH()
+    lib().trc_host_build_node(C.byref(box), C.byref(m), ptype, pindex, C.byref(out))
+    return out

@@ -1,0 +1,176 @@
+// mesh.cpp -- triangle mesh inputs for the mesh scenes (BASELINE configs 3 and 4).
+//
+// The reference loads its mesh through Apple's ModelIO with 32-byte vertices
+// {float3 position, float3 normal, float2 uv} and adds smooth normals
+// (RT_Metal/Tracer/AAPLRenderer.mm:474-511; vertex layout Common.hh:32-36).  ModelIO does not
+// exist here, so this file provides (a) a minimal Wavefront OBJ reader producing the same
+// 32-byte vertex + u32 index arrays, and (b) procedural meshes used on the GPU box, where the
+// reference's asset files do not travel.
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <new>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "host_math.hpp"
+
+using namespace trc;
+
+struct trc_host_mesh {
+    std::vector<trc_TriangleVertex> vertices;
+    std::vector<uint32_t> indices;
+};
+
+namespace {
+
+// area-weighted smooth normals from the triangles (used when a file carries none)
+void generate_normals(trc_host_mesh& m) {
+    std::vector<trc_float3> acc(m.vertices.size(), f3(0.0f));
+    for (size_t t = 0; t + 2 < m.indices.size(); t += 3) {
+        const uint32_t ia = m.indices[t], ib = m.indices[t + 1], ic = m.indices[t + 2];
+        const trc_float3 a = f3(m.vertices[ia].v[0], m.vertices[ia].v[1], m.vertices[ia].v[2]);
+        const trc_float3 b = f3(m.vertices[ib].v[0], m.vertices[ib].v[1], m.vertices[ib].v[2]);
+        const trc_float3 c = f3(m.vertices[ic].v[0], m.vertices[ic].v[1], m.vertices[ic].v[2]);
+        const trc_float3 fn = cross(b - a, c - a);
+        acc[ia] = acc[ia] + fn; acc[ib] = acc[ib] + fn; acc[ic] = acc[ic] + fn;
+    }
+    for (size_t i = 0; i < m.vertices.size(); ++i) {
+        float len = length(acc[i]);
+        trc_float3 n = len > 0.0f ? acc[i] / len : f3(0, 1, 0);
+        m.vertices[i].n[0] = n.x; m.vertices[i].n[1] = n.y; m.vertices[i].n[2] = n.z;
+    }
+}
+
+int resolve(long idx, size_t count) {   // OBJ indices are 1-based, negative = relative to the end
+    if (idx > 0) return (int)idx - 1;
+    if (idx < 0) return (int)((long)count + idx);
+    return -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+trc_status trc_host_mesh_load_obj(const char* path, trc_host_mesh** out) {
+    if (!path || !out) return TRC_ERR_INVALID_ARG;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return TRC_ERR_INVALID_ARG;
+    trc_host_mesh* m = new (std::nothrow) trc_host_mesh();
+    if (!m) { std::fclose(f); return TRC_ERR_OOM; }
+
+    std::vector<trc_float3> pos, nor;
+    std::vector<trc_float2> tex;
+    std::map<std::tuple<int, int, int>, uint32_t> remap;   // (v, vt, vn) -> unified vertex
+    bool any_normal = false;
+    std::vector<uint32_t> face;
+    char line[4096];
+    while (std::fgets(line, sizeof line, f)) {
+        char* p = line;
+        while (*p == ' ' || *p == '\t') ++p;
+        if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
+            float x = 0, y = 0, z = 0; std::sscanf(p + 2, "%f %f %f", &x, &y, &z); pos.push_back(f3(x, y, z));
+        } else if (p[0] == 'v' && p[1] == 'n') {
+            float x = 0, y = 0, z = 0; std::sscanf(p + 3, "%f %f %f", &x, &y, &z); nor.push_back(f3(x, y, z));
+        } else if (p[0] == 'v' && p[1] == 't') {
+            trc_float2 t; t.x = 0; t.y = 0; std::sscanf(p + 3, "%f %f", &t.x, &t.y); tex.push_back(t);
+        } else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
+            face.clear();
+            p += 2;
+            while (*p) {
+                while (*p == ' ' || *p == '\t') ++p;
+                if (*p == '\0' || *p == '\n' || *p == '\r') break;
+                long vi = std::strtol(p, &p, 10), ti = 0, ni = 0;
+                if (*p == '/') { ++p; if (*p != '/') ti = std::strtol(p, &p, 10); if (*p == '/') { ++p; ni = std::strtol(p, &p, 10); } }
+                const int v = resolve(vi, pos.size()), t = resolve(ti, tex.size()), n = resolve(ni, nor.size());
+                if (v < 0 || v >= (int)pos.size()) { std::fclose(f); delete m; return TRC_ERR_INVALID_ARG; }
+                auto key = std::make_tuple(v, t, n);
+                auto it = remap.find(key);
+                if (it == remap.end()) {
+                    trc_TriangleVertex e;
+                    std::memset(&e, 0, sizeof e);
+                    e.v[0] = pos[v].x; e.v[1] = pos[v].y; e.v[2] = pos[v].z;
+                    if (n >= 0 && n < (int)nor.size()) { e.n[0] = nor[n].x; e.n[1] = nor[n].y; e.n[2] = nor[n].z; any_normal = true; }
+                    if (t >= 0 && t < (int)tex.size()) { e.uv[0] = tex[t].x; e.uv[1] = tex[t].y; }
+                    it = remap.emplace(key, (uint32_t)m->vertices.size()).first;
+                    m->vertices.push_back(e);
+                }
+                face.push_back(it->second);
+            }
+            for (size_t k = 1; k + 1 < face.size(); ++k) {   // fan triangulation
+                m->indices.push_back(face[0]); m->indices.push_back(face[k]); m->indices.push_back(face[k + 1]);
+            }
+        }
+    }
+    std::fclose(f);
+    if (m->indices.empty()) { delete m; return TRC_ERR_INVALID_ARG; }
+    if (!any_normal) generate_normals(*m);
+    *out = m;
+    return TRC_OK;
+}
+
+trc_status trc_host_mesh_make_ball(uint32_t n_lat, uint32_t n_lon, float bump, trc_host_mesh** out) {
+    if (!out || n_lat < 2 || n_lon < 3) return TRC_ERR_INVALID_ARG;
+    trc_host_mesh* m = new (std::nothrow) trc_host_mesh();
+    if (!m) return TRC_ERR_OOM;
+    const double pi = 3.14159265358979323846;
+    for (uint32_t i = 0; i <= n_lat; ++i) {
+        const double theta = pi * i / n_lat;
+        for (uint32_t j = 0; j <= n_lon; ++j) {
+            const double phi = 2 * pi * j / n_lon;
+            const double r = 1.0 + bump * std::sin(7 * theta) * std::sin(5 * phi);
+            trc_TriangleVertex e;
+            std::memset(&e, 0, sizeof e);
+            e.v[0] = (float)(r * std::sin(theta) * std::cos(phi));
+            e.v[1] = (float)(r * std::cos(theta));
+            e.v[2] = (float)(r * std::sin(theta) * std::sin(phi));
+            e.uv[0] = (float)j / n_lon; e.uv[1] = (float)i / n_lat;
+            m->vertices.push_back(e);
+        }
+    }
+    const uint32_t stride = n_lon + 1;
+    for (uint32_t i = 0; i < n_lat; ++i)
+        for (uint32_t j = 0; j < n_lon; ++j) {
+            const uint32_t a = i * stride + j, b = a + 1, c = a + stride, d = c + 1;
+            m->indices.insert(m->indices.end(), {a, b, c});
+            m->indices.insert(m->indices.end(), {b, d, c});
+        }
+    generate_normals(*m);
+    *out = m;
+    return TRC_OK;
+}
+
+trc_status trc_host_mesh_replicate(const trc_host_mesh* src, uint32_t k, float spacing, trc_host_mesh** out) {
+    if (!src || !out || k == 0) return TRC_ERR_INVALID_ARG;
+    trc_host_mesh* m = new (std::nothrow) trc_host_mesh();
+    if (!m) return TRC_ERR_OOM;
+    const size_t nv = src->vertices.size();
+    m->vertices.reserve(nv * k * k);
+    m->indices.reserve(src->indices.size() * k * k);
+    for (uint32_t gy = 0; gy < k; ++gy)
+        for (uint32_t gx = 0; gx < k; ++gx) {
+            const uint32_t base = (uint32_t)m->vertices.size();
+            for (const auto& v : src->vertices) {
+                trc_TriangleVertex e = v;
+                e.v[0] += spacing * gx;
+                e.v[1] += spacing * gy;
+                m->vertices.push_back(e);
+            }
+            for (uint32_t i : src->indices) m->indices.push_back(base + i);
+        }
+    *out = m;
+    return TRC_OK;
+}
+
+void trc_host_mesh_view(const trc_host_mesh* m, const trc_TriangleVertex** vertices, uint32_t* n_vertices,
+                        const uint32_t** indices, uint32_t* n_indices) {
+    if (vertices) *vertices = m->vertices.data();
+    if (n_vertices) *n_vertices = (uint32_t)m->vertices.size();
+    if (indices) *indices = m->indices.data();
+    if (n_indices) *n_indices = (uint32_t)m->indices.size();
+}
+
+void trc_host_mesh_destroy(trc_host_mesh* m) { delete m; }
+
+}  // extern "C"

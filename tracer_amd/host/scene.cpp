@@ -1,0 +1,336 @@
+// scene.cpp -- host scene construction with the reference's constants and ordering.
+//
+//   cubes + materials 0-2      RT_Metal/Tracer/Tracer.mm:174-243  (prepareCubeList)
+//   Cornell squares + mat 3-6  Tracer.mm:245-304                  (prepareCornellBox)
+//   spheres + materials 7-18   Tracer.mm:306-369                  (prepareSphereList)
+//   material 19                RT_Metal/Tracer/AAPLRenderer.mm:233-242 (testMaterial)
+//   leaves and tree            AAPLRenderer.mm:454-468,546-610
+//   mesh placement             AAPLRenderer.mm:513-525,560-573
+//   camera                     Tracer.mm:87-125,371-411
+//   RNG texture                AAPLRenderer.mm:296-344 (arc4random -> deterministic per-pixel PCG32)
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "host_math.hpp"
+
+using namespace trc;
+
+struct trc_host_scene {
+    std::vector<trc_BVH> bvh;
+    std::vector<trc_Sphere> spheres;
+    std::vector<trc_Square> squares;
+    std::vector<trc_Cube> cubes;
+    std::vector<trc_TriangleVertex> vertices;
+    std::vector<uint32_t> indices;
+    std::vector<trc_Material> materials;
+};
+
+namespace {
+
+trc_Material make_material(int32_t type) {
+    trc_Material m;
+    std::memset(&m, 0, sizeof(m));
+    m.type = type;
+    m.medium = TRC_MEDIUM_NIL;
+    m.specular = 0;
+    m.eta = 0.0f;
+    m.roughness = 1.0f;                       // Material.hh:30
+    m.textureInfo.type = TRC_TEX_CONSTANT;
+    m.textureInfo.albedo = f3(0.0f);
+    return m;
+}
+
+// Tracer.mm:127-153
+trc_Square make_square(uint8_t axis_i, float i0, float i1, uint8_t axis_j, float j0, float j1,
+                       uint8_t axis_k, float k, uint32_t material) {
+    trc_Square r;
+    std::memset(&r, 0, sizeof(r));
+    r.axis_i = axis_i; r.axis_j = axis_j; r.axis_k = axis_k;
+    r.range_i.x = i0; r.range_i.y = i1;
+    r.range_j.x = j0; r.range_j.y = j1;
+    r.value_k = k;
+    const float delta = 1.0f / 512.0f;        // SquarePadding, Square.hh:7-9
+    trc_float3 a = f3(0.0f), b = f3(0.0f);
+    set(a, axis_i, i0); set(a, axis_j, j0); set(a, axis_k, k - delta);
+    set(b, axis_i, i1); set(b, axis_j, j1); set(b, axis_k, k + delta);
+    r.boundingBOX = box_of(a, b);
+    r.model_matrix = identity4x4();
+    r.material = material;
+    return r;
+}
+
+// Tracer.mm:155-163 + the T*R*S set-up of prepareCubeList
+trc_Cube make_cube(uint32_t material, trc_float4x4 translate, trc_float4x4 rotate, trc_float4x4 scale) {
+    trc_Cube r;
+    std::memset(&r, 0, sizeof(r));
+    r.box = box_of(f3(0, 0, 0), f3(1, 1, 1));
+    r.material = material;
+    r.model_matrix = mul(mul(translate, rotate), scale);
+    r.inverse_matrix = inverse(r.model_matrix);
+    r.normal_matrix = transpose(r.inverse_matrix);
+    return r;
+}
+
+// Tracer.mm:165-172 -- radius inflated by 1e-4, AABB not (quirk B-13)
+trc_Sphere make_sphere(float radius, trc_float3 c, uint32_t material) {
+    trc_Sphere s;
+    std::memset(&s, 0, sizeof(s));
+    s.radius = radius + 0.0001f;
+    s.center = c;
+    s.boundingBOX = box_of(c - f3(radius), c + f3(radius));
+    s.model_matrix = identity4x4();
+    s.material = material;
+    return s;
+}
+
+void prepare_cube_list(trc_host_scene& s) {
+    const float pi = (float)M_PI;
+    trc_Material metal = make_material(TRC_MAT_METAL);
+    metal.textureInfo.albedo = f3(0.8f, 0.85f, 0.88f);
+    metal.specular = 1;
+    const uint32_t metal_index = (uint32_t)s.materials.size();
+    s.materials.push_back(metal);
+    s.cubes.push_back(make_cube(metal_index, translation4x4(265, 1, 295),
+                                rotation4x4((float)(M_PI * 15 / 180), f3(0, 1, 0)), scale4x4(165, 330, 165)));
+
+    trc_Material white = make_material(TRC_MAT_GLASS);
+    white.textureInfo.albedo = f3(1, 1, 1);
+    white.eta = 0.01f;
+    s.materials.push_back(white);
+    // the smaller cube uses material 19 (testMaterial), Tracer.mm:208-209
+    s.cubes.push_back(make_cube(19, translation4x4(130, 1, 65),
+                                rotation4x4((float)(-0.1 * M_PI), f3(0, 1, 0)), scale4x4(165, 165, 165)));
+
+    trc_Material density = make_material(TRC_MAT_NIL);
+    density.medium = TRC_MEDIUM_GRIDDENSITY;
+    density.textureInfo.albedo = f3(1, 1, 1);
+    const uint32_t density_index = (uint32_t)s.materials.size();
+    s.materials.push_back(density);
+    // density container: present in the cube list, never inserted in the BVH (AAPLRenderer.mm:459)
+    s.cubes.push_back(make_cube(density_index, translation4x4(0, 200, 65),
+                                rotation4x4(0.0f * pi, f3(0, 1, 0)), scale4x4(200, 200, 80)));
+}
+
+void prepare_cornell_box(trc_host_scene& s) {
+    trc_Material light = make_material(TRC_MAT_DIFFUSE);
+    light.textureInfo.albedo = f3(11.0f);
+    const uint32_t light_index = (uint32_t)s.materials.size();
+    s.materials.push_back(light);
+
+    trc_Material red = make_material(TRC_MAT_LAMBERT);
+    red.textureInfo.albedo = f3(0.65f, 0.05f, 0.05f);
+    const uint32_t red_index = (uint32_t)s.materials.size();
+    s.materials.push_back(red);
+
+    trc_Material green = make_material(TRC_MAT_LAMBERT);
+    green.textureInfo.albedo = f3(0.05f, 0.65f, 0.05f);
+    const uint32_t green_index = (uint32_t)s.materials.size();
+    s.materials.push_back(green);
+
+    trc_Material white = make_material(TRC_MAT_LAMBERT);
+    white.textureInfo.type = TRC_TEX_CHECKER;
+    white.textureInfo.albedo = f3(0.73f);
+    const uint32_t white_index = (uint32_t)s.materials.size();
+    s.materials.push_back(white);
+
+    // list order fixes the indices the integrators hard-code (squareList[5], [6] are the lights)
+    s.squares.push_back(make_square(1, 0, 555, 2, 0, 555, 0, -245, green_index));            // 0 left
+    s.squares.push_back(make_square(1, 0, 555, 2, 0, 555, 0, 800, red_index));               // 1 right
+    s.squares.push_back(make_square(0, -245, 800, 2, 0, 555, 1, 555, white_index));          // 2 top
+    s.squares.push_back(make_square(0, -245, 800, 1, 0, 555, 2, 555, white_index));          // 3 back
+    s.squares.push_back(make_square(0, -245, 800, 2, 0, 555, 1, 0, white_index));            // 4 bottom
+    s.squares.push_back(make_square(0, 400, 555, 2, 200, 355, 1, (float)(555 - 0.1), light_index));  // 5 light
+    s.squares.push_back(make_square(1, 200, 300, 2, 200, 300, 0, -300, light_index));        // 6 little light
+}
+
+void prepare_sphere_list(trc_host_scene& s, bool remap_materials) {
+    // Reference material types here (Dielectric, Demofox) make Material::S_F return 0
+    // (Material.hh:143-144), i.e. black absorbers.  BASELINE config 2 remaps them to the
+    // supported lobes so every BSDF of the path is exercised; albedos are kept.
+    static const int32_t bottom_row[6] = {TRC_MAT_LAMBERT, TRC_MAT_PLASTIC, TRC_MAT_METAL,
+                                          TRC_MAT_GLASS, TRC_MAT_LAMBERT, TRC_MAT_PLASTIC};
+    static const int32_t top_row[5] = {TRC_MAT_METAL, TRC_MAT_GLASS, TRC_MAT_PLASTIC,
+                                       TRC_MAT_METAL, TRC_MAT_LAMBERT};
+
+    trc_Material glass = make_material(remap_materials ? TRC_MAT_GLASS : TRC_MAT_DIELECTRIC);
+    glass.textureInfo.albedo = f3(1.0f);
+    glass.textureInfo.type = remap_materials ? TRC_TEX_CONSTANT : TRC_TEX_NOISE;
+    glass.eta = 1.5f;
+    uint32_t index = (uint32_t)s.materials.size();
+    s.materials.push_back(glass);
+    s.spheres.push_back(make_sphere(64, f3(200, 250, 200), index));
+
+    for (int i = 0; i < 6; ++i) {
+        trc_Material specu = make_material(remap_materials ? bottom_row[i] : TRC_MAT_DEMOFOX);
+        specu.textureInfo.albedo = f3(0.9f, 0.25f, 0.25f);
+        index = (uint32_t)s.materials.size();
+        s.materials.push_back(specu);
+        s.spheres.push_back(make_sphere(40, f3(0.0f + 100.0f * (5 - i), 50, 50), index));
+    }
+    for (int i = 0; i < 5; ++i) {
+        trc_Material gloss = make_material(remap_materials ? top_row[i] : TRC_MAT_DEMOFOX);
+        gloss.textureInfo.albedo = f3(1.0f);
+        index = (uint32_t)s.materials.size();
+        s.materials.push_back(gloss);
+        s.spheres.push_back(make_sphere(40, f3(-10.0f + 150.0f * i, 500, 400), index));
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+void trc_host_make_camera(trc_Camera* camera, const float lookFrom[3], const float lookAt[3],
+                          const float viewUp[3], float aperture, float aspect,
+                          float vfov, float focus_dist) {
+    std::memset(camera, 0, sizeof(*camera));
+    const trc_float3 from = f3(lookFrom[0], lookFrom[1], lookFrom[2]);
+    const trc_float3 at = f3(lookAt[0], lookAt[1], lookAt[2]);
+    const trc_float3 up = f3(viewUp[0], viewUp[1], viewUp[2]);
+    camera->lookFrom = from; camera->lookAt = at; camera->viewUp = up;
+    camera->aperture = aperture; camera->aspect = aspect; camera->vfov = vfov;
+    camera->focus_dist = focus_dist;
+    camera->lenRadius = aperture / 2;
+    const float halfHeight = std::tan(vfov / 2);      // vfov already in radians (Tracer.mm:107)
+    const float halfWidth = aspect * halfHeight;
+    const trc_float3 w = normalize(from - at);
+    const trc_float3 u = normalize(cross(up, w));
+    const trc_float3 v = cross(w, u);
+    camera->u = u; camera->v = v; camera->w = w;
+    const trc_float3 vertical = v * (2 * halfHeight * focus_dist);
+    const trc_float3 horizontal = u * (2 * halfWidth * focus_dist);
+    camera->vertical = vertical;
+    camera->horizontal = horizontal;
+    camera->cornerLowLeft = from - vertical / 2.0f - horizontal / 2.0f - w * focus_dist;
+}
+
+// prepareCamera with zero rotation / zero wasd offset (Tracer.mm:371-411)
+void trc_host_prepare_camera(trc_Camera* out, float width, float height) {
+    const float from[3] = {278, 278, -800}, at[3] = {278, 278, 278}, up[3] = {0, 1, 0};
+    trc_host_make_camera(out, from, at, up, 0.0f, width / height, (float)(45 * (M_PI / 180)), 10.0f);
+}
+
+// PCG32 (RT_Metal/Tracer/pcg_basic.c:42-72)
+static inline uint32_t pcg32_next(uint64_t& state, uint64_t inc) {
+    uint64_t old = state;
+    state = old * 6364136223846793005ULL + inc;
+    uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+    uint32_t rot = (uint32_t)(old >> 59u);
+    return (xorshifted >> rot) | (xorshifted << ((0u - rot) & 31));
+}
+
+void trc_host_fill_rng(uint64_t seed, uint32_t width, uint32_t height, uint32_t* rgba) {
+    const uint64_t n = (uint64_t)width * height;
+    for (uint64_t p = 0; p < n; ++p) {
+        // pcg32_srandom_r(rng, seed, seq = pixel index)
+        uint64_t state = 0, inc = (p << 1u) | 1u;
+        pcg32_next(state, inc);
+        state += seed;
+        pcg32_next(state, inc);
+        for (int c = 0; c < 4; ++c) rgba[4 * p + c] = pcg32_next(state, inc);
+    }
+}
+
+trc_status trc_host_scene_create(int32_t kind, const trc_TriangleVertex* mesh_vertices, uint32_t n_vertices,
+                                 const uint32_t* mesh_indices, uint32_t n_indices, trc_host_scene** out) {
+    if (!out) return TRC_ERR_INVALID_ARG;
+    if (kind < TRC_SCENE_CORNELL || kind > TRC_SCENE_CORNELL_MESH) return TRC_ERR_INVALID_ARG;
+    if (kind == TRC_SCENE_CORNELL_MESH && (!mesh_vertices || !mesh_indices || n_indices < 3 || n_indices % 3))
+        return TRC_ERR_INVALID_ARG;
+    trc_host_scene* s = new (std::nothrow) trc_host_scene();
+    if (!s) return TRC_ERR_OOM;
+
+    const bool with_spheres = (kind == TRC_SCENE_CORNELL_SPHERES);
+    prepare_cube_list(*s);                     // materials 0-2
+    prepare_cornell_box(*s);                   // materials 3-6
+    prepare_sphere_list(*s, with_spheres);     // materials 7-18
+    trc_Material test = make_material(TRC_MAT_GLASS);   // material 19
+    test.medium = TRC_MEDIUM_HOMOGENEOUS;
+    test.textureInfo.albedo = f3(1, 1, 1);
+    test.specular = 1;
+    test.eta = 1.5f;
+    s->materials.push_back(test);
+
+    std::vector<trc_BVH> leaves;
+    trc_BVH leaf;
+    // all cubes but the last (density container), AAPLRenderer.mm:459-462
+    for (uint32_t i = 0; i + 1 < s->cubes.size(); ++i) {
+        trc_host_build_node(&s->cubes[i].box, &s->cubes[i].model_matrix, TRC_PRIM_CUBE, i, &leaf);
+        leaves.push_back(leaf);
+    }
+    for (uint32_t i = 0; i < s->squares.size(); ++i) {
+        trc_host_build_node(&s->squares[i].boundingBOX, &s->squares[i].model_matrix, TRC_PRIM_SQUARE, i, &leaf);
+        leaves.push_back(leaf);
+    }
+    if (with_spheres) {
+        // the commented-out loop of AAPLRenderer.mm:454-457, from i = 0 (BASELINE config 2)
+        for (uint32_t i = 0; i < s->spheres.size(); ++i) {
+            trc_host_build_node(&s->spheres[i].boundingBOX, &s->spheres[i].model_matrix, TRC_PRIM_SPHERE, i, &leaf);
+            leaves.push_back(leaf);
+        }
+    }
+    if (kind == TRC_SCENE_CORNELL_MESH) {
+        s->vertices.assign(mesh_vertices, mesh_vertices + n_vertices);
+        s->indices.assign(mesh_indices, mesh_indices + n_indices);
+        for (uint32_t i = 0; i < n_indices; ++i)
+            if (mesh_indices[i] >= n_vertices) { delete s; return TRC_ERR_INVALID_ARG; }
+
+        trc_AABB mesh_box = empty_box();
+        for (auto& e : s->vertices) mesh_box = box_grow(mesh_box, f3(e.v[0], e.v[1], e.v[2]));
+        const trc_float3 centroid = box_centroid(mesh_box);
+        const float max_dim = get(box_diagonal(mesh_box), box_max_extent(mesh_box));
+        const double mesh_scale = 300.0 / max_dim;
+        trc_float3 mesh_offset = f3(278.0f) - centroid;
+        mesh_offset.y = (float)(180 - mesh_box.mini.y * mesh_scale);
+        // each vertex transformed ONCE (the reference transforms per referencing triangle, B-14)
+        for (auto& e : s->vertices) {
+            e.v[0] = (float)(e.v[0] * mesh_scale);
+            e.v[1] = (float)(e.v[1] * mesh_scale);
+            e.v[2] = (float)(e.v[2] * -mesh_scale);
+            e.n[2] *= -1;
+            e.v[0] += mesh_offset.x;
+            e.v[1] += mesh_offset.y;
+            e.v[2] += mesh_offset.z;
+            e.v[0] += -200;
+        }
+        const trc_float4x4 ident = identity4x4();
+        const uint32_t n_tri = n_indices / 3;
+        leaves.reserve(leaves.size() + n_tri);
+        for (uint32_t t = 0; t < n_tri; ++t) {
+            const trc_TriangleVertex& a = s->vertices[s->indices[3 * t]];
+            const trc_TriangleVertex& b = s->vertices[s->indices[3 * t + 1]];
+            const trc_TriangleVertex& c = s->vertices[s->indices[3 * t + 2]];
+            trc_AABB box;
+            box.maxi = f3(std::max({a.v[0], b.v[0], c.v[0]}), std::max({a.v[1], b.v[1], c.v[1]}),
+                          std::max({a.v[2], b.v[2], c.v[2]}));
+            box.mini = f3(std::min({a.v[0], b.v[0], c.v[0]}), std::min({a.v[1], b.v[1], c.v[1]}),
+                          std::min({a.v[2], b.v[2], c.v[2]}));
+            trc_host_build_node(&box, &ident, TRC_PRIM_TRIANGLE, t, &leaf);
+            leaves.push_back(leaf);
+        }
+    }
+
+    const uint32_t n_leaves = (uint32_t)leaves.size();
+    s->bvh.resize(2 * (size_t)n_leaves - 1);
+    std::copy(leaves.begin(), leaves.end(), s->bvh.begin());
+    uint32_t n_nodes = 0;
+    trc_status st = trc_host_build_tree(s->bvh.data(), n_leaves, &n_nodes);
+    if (st != TRC_OK) { delete s; return st; }
+    *out = s;
+    return TRC_OK;
+}
+
+void trc_host_scene_destroy(trc_host_scene* s) { delete s; }
+
+void trc_host_scene_view(const trc_host_scene* s, trc_scene* out) {
+    out->bvhList = s->bvh.data();           out->n_bvh = (uint32_t)s->bvh.size();
+    out->sphereList = s->spheres.data();    out->n_sphere = (uint32_t)s->spheres.size();
+    out->squareList = s->squares.data();    out->n_square = (uint32_t)s->squares.size();
+    out->cubeList = s->cubes.data();        out->n_cube = (uint32_t)s->cubes.size();
+    out->triList = s->vertices.data();      out->n_vertex = (uint32_t)s->vertices.size();
+    out->idxList = s->indices.data();       out->n_index = (uint32_t)s->indices.size();
+    out->materials = s->materials.data();   out->n_material = (uint32_t)s->materials.size();
+}
+
+}  // extern "C"
