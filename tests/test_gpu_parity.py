@@ -1,0 +1,220 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+
+Bar: BIT-EXACT for everything -- hit identity (pType, pIndex), t, the whole HitRecord, traversal
+counters, RNG state and the radiance accumulator (both sides use IEEE binary32 without FMA
+contraction and include/trc_detmath.h for transcendentals, so no tolerance is needed).
+"""
+import numpy as np
+import pytest
+
+from conftest import camera_rays, random_rays
+from oracle import pyoracle as po
+from tracer_amd import abi, host
+
+pytestmark = pytest.mark.gpu
+
+HIT_FIELDS = ["hit", "pType", "pIndex", "t", "p", "gn", "sn", "uv", "material", "PDF"]
+COUNTER_FIELDS = ["n_descend", "n_return", "n_leaf"]
+
+
+def assert_hits_equal(dev, ref, counters=True):
+    for f in HIT_FIELDS + (COUNTER_FIELDS if counters else []):
+        a, b = dev[f], ref[f]
+        same = (a.view(np.uint32) == b.view(np.uint32)) if a.dtype == np.float32 else (a == b)
+        if a.dtype == np.float32:   # NaN payloads aside, require identical bits; allow NaN==NaN
+            same = same | (np.isnan(a) & np.isnan(b))
+        assert same.all(), f"field {f}: {np.count_nonzero(~same)} mismatches, first at {np.argwhere(~same)[0]}"
+
+
+@pytest.mark.parametrize("scene_name", ["cornell", "cornell_spheres", "ball_mesh_scene"])
+def test_trace_rays_closest_hit_bit_exact(gpu, request, scene_name):
+    scene = request.getfixturevalue(scene_name)
+    gpu.upload_scene(scene.view)
+    rays = np.concatenate([random_rays(60000, 11), random_rays(60000, 12, inside_only=True),
+                           camera_rays(host.prepare_camera(320, 180), 320, 180)])
+    dev = gpu.trace_rays(rays)
+    ref = po.trace_rays(scene.view, rays)
+    assert ref["hit"].mean() > 0.3
+    assert_hits_equal(dev, ref)
+
+
+@pytest.mark.parametrize("scene_name", ["cornell_spheres", "ball_mesh_scene"])
+def test_trace_rays_any_hit_bit_exact(gpu, request, scene_name):
+    """Shadow-ray mode (Render.hh:244): early exit on the first accepted primitive."""
+    scene = request.getfixturevalue(scene_name)
+    gpu.upload_scene(scene.view)
+    rays = random_rays(80000, 21, inside_only=True)
+    rays["tmax"] = np.random.RandomState(5).uniform(50, 900, len(rays)).astype(np.float32)
+    dev = gpu.trace_rays(rays, any_hit=True)
+    ref = po.trace_rays(scene.view, rays, any_hit=True)
+    assert 0.05 < ref["hit"].mean() < 0.98
+    # any-hit only promises the boolean + counters; the record of the accepted primitive is also identical
+    assert_hits_equal(dev, ref)
+
+
+def test_trace_rays_degenerate_directions(gpu, cornell_spheres):
+    """Axis-parallel rays: 1/0 = inf and 0*inf = NaN inside the slab test (SURVEY B-10)."""
+    gpu.upload_scene(cornell_spheres.view)
+    o = np.array([[278, 278, -800], [278, 278, 100], [100, 300, 300], [0, 0, 0], [555, 554.9, 277.5]], np.float32)
+    dirs = np.array([[0, 0, 1], [0, 1, 0], [1, 0, 0], [0, -1, 0], [-1, 0, 0], [0, 0, -1]], np.float32)
+    O = np.repeat(o, len(dirs), 0)
+    D = np.tile(dirs, (len(o), 1))
+    from tracer_amd.dtypes import make_rays
+    rays = make_rays(O, D)
+    assert_hits_equal(gpu.trace_rays(rays), po.trace_rays(cornell_spheres.view, rays))
+
+
+def _render_both(gpu, scene, W, H, spp, integrator, seed=0x5EED0000, env=(0.0, 0.0, 0.0), frame0=0, max_depth=8):
+    cam = host.prepare_camera(W, H)
+    gpu.upload_scene(scene.view)
+    gpu.set_camera(cam)
+    gpu.set_environment(env)
+    gpu.resize(W, H)
+    gpu.seed(seed)
+    gpu.reset_stats()
+    gpu.render(spp=spp, integrator=integrator, frame0=frame0, max_depth=max_depth, collect_stats=True)
+    dev_acc, dev_rng, dev_stats = gpu.download_accum(), gpu.download_rng(), gpu.stats()
+    rng = host.fill_rng(seed, W, H)
+    ref_acc, ref_stats = po.render(scene.view, cam, W, H, rng, spp=spp, integrator=integrator, env=env,
+                                   frame0=frame0, max_depth=max_depth)
+    return dev_acc, dev_rng, dev_stats, ref_acc, rng, ref_stats
+
+
+STAT_FIELDS = ["paths", "rays", "shaded", "n_descend", "n_return", "n_leaf_sphere", "n_leaf_square", "n_leaf_cube",
+               "n_leaf_triangle", "n_hit_triangle", "n_hit_cube"]
+
+
+def assert_frames_equal(dev_acc, dev_rng, dev_stats, ref_acc, ref_rng, ref_stats):
+    assert np.array_equal(dev_rng, ref_rng), "RNG texture differs"
+    bad = dev_acc.view(np.uint32) != ref_acc.view(np.uint32)
+    assert not bad.any(), (f"accumulator differs in {np.count_nonzero(bad.any(axis=2))} pixels; first "
+                           f"{np.argwhere(bad)[0]} dev={dev_acc[tuple(np.argwhere(bad)[0][:2])]} "
+                           f"ref={ref_acc[tuple(np.argwhere(bad)[0][:2])]}")
+    for f in STAT_FIELDS:
+        assert getattr(dev_stats, f) == getattr(ref_stats, f), f"stat {f}: {getattr(dev_stats, f)} != {getattr(ref_stats, f)}"
+
+
+@pytest.mark.parametrize("scene_name,integrator,W,H,spp", [
+    ("cornell", abi.INTEGRATOR_PATH, 160, 90, 8),
+    ("cornell_spheres", abi.INTEGRATOR_PATH, 160, 90, 16),
+    ("cornell_spheres", abi.INTEGRATOR_MIS, 160, 90, 8),
+    ("cornell_spheres", abi.INTEGRATOR_PATH, 97, 61, 4),       # ragged: partial tiles on both edges
+    ("ball_mesh_scene", abi.INTEGRATOR_PATH, 128, 72, 8),
+    ("ball_mesh_scene", abi.INTEGRATOR_MIS, 128, 72, 4),
+])
+def test_render_bit_exact(gpu, request, scene_name, integrator, W, H, spp):
+    scene = request.getfixturevalue(scene_name)
+    out = _render_both(gpu, scene, W, H, spp, integrator)
+    assert out[3][..., :3].max() > 0, "oracle image is black: the test would be vacuous"
+    assert_frames_equal(*out)
+
+
+def test_render_with_sky_environment(gpu, cornell_spheres):
+    """constant environment (0.5, 0.7, 1.0): the miss branch of tracePath (Render.metal:434-439)"""
+    assert_frames_equal(*_render_both(gpu, cornell_spheres, 96, 54, 8, abi.INTEGRATOR_PATH, env=(0.5, 0.7, 1.0)))
+
+
+def test_seed_matches_host_fill(gpu):
+    gpu.resize(131, 77)
+    gpu.seed(1234567)
+    assert np.array_equal(gpu.download_rng(), host.fill_rng(1234567, 131, 77))
+
+
+def test_spp_fusion_equals_per_frame_launches(gpu, cornell_spheres):
+    """One launch of spp samples == spp launches of 1 sample (the reference's 1 spp/frame progressive loop)."""
+    W, H, spp = 96, 64, 6
+    cam = host.prepare_camera(W, H)
+    gpu.upload_scene(cornell_spheres.view)
+    gpu.set_camera(cam)
+    gpu.set_environment((0, 0, 0))
+    gpu.resize(W, H)
+    gpu.seed(77)
+    gpu.render(spp=spp)
+    fused_acc, fused_rng = gpu.download_accum(), gpu.download_rng()
+    gpu.clear_accum()
+    gpu.seed(77)
+    for f in range(spp):
+        gpu.render(spp=1, frame0=f)
+    assert np.array_equal(gpu.download_rng(), fused_rng)
+    assert np.array_equal(gpu.download_accum().view(np.uint32), fused_acc.view(np.uint32))
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 8])
+def test_tile_shards_compose_the_single_gpu_frame(gpu, cornell_spheres, nranks):
+    """Rank r renders tiles (tx+ty)%N==r into a zero frame; the SUM over ranks (what the RCCL reduce
+    computes) is bit-identical to the 1-GPU frame because per-pixel RNG streams depend on (x,y,seed) only."""
+    W, H, spp = 112, 80, 4
+    cam = host.prepare_camera(W, H)
+    gpu.upload_scene(cornell_spheres.view)
+    gpu.set_camera(cam)
+    gpu.set_environment((0.1, 0.1, 0.1))
+    gpu.resize(W, H)
+    gpu.seed(9)
+    gpu.render(spp=spp)
+    full = gpu.download_accum()
+    total = np.zeros_like(full)
+    for r in range(nranks):
+        gpu.clear_accum()
+        gpu.seed(9)
+        gpu.render(spp=spp, tile_rank=r, tile_nranks=nranks)
+        part = gpu.download_accum()
+        ty, tx = np.mgrid[0:H, 0:W] // abi.TRC_TILE
+        mine = ((tx + ty) % nranks) == r
+        assert not part[~mine].any(), "a rank wrote outside its tiles"
+        total += part
+    assert np.array_equal(total.view(np.uint32), full.view(np.uint32))
+
+
+def test_full_size_tile_subsample_matches_oracle(gpu, cornell_spheres):
+    """BASELINE config 2 at full size (1920x1080x64spp): the oracle renders 1 tile in 64 (every tile with
+    (tx+ty)%64==0, ~32k pixels, 2 M paths); those pixels must be bit-identical in the full GPU frame."""
+    W, H, spp = 1920, 1080, 64
+    cam = host.prepare_camera(W, H)
+    gpu.upload_scene(cornell_spheres.view)
+    gpu.set_camera(cam)
+    gpu.set_environment((0, 0, 0))
+    gpu.resize(W, H)
+    gpu.seed(0x5EED0000)
+    gpu.reset_stats()
+    gpu.render(spp=spp)
+    dev = gpu.download_accum()
+    st = gpu.stats()
+    assert st.paths == W * H * spp
+    rng = host.fill_rng(0x5EED0000, W, H)
+    ref, _ = po.render(cornell_spheres.view, cam, W, H, rng, spp=spp, tile_rank=0, tile_nranks=64)
+    ty, tx = np.mgrid[0:H, 0:W] // abi.TRC_TILE
+    mine = ((tx + ty) % 64) == 0
+    assert mine.sum() > 20000
+    assert np.array_equal(dev[mine].view(np.uint32), ref[mine].view(np.uint32))
+    # size-independent properties of the full frame: finite, alpha 1, deterministic
+    assert np.isfinite(dev).all() and (dev[..., 3] == 1.0).all()
+    gpu.clear_accum()
+    gpu.seed(0x5EED0000)
+    gpu.render(spp=spp)
+    assert np.array_equal(gpu.download_accum().view(np.uint32), dev.view(np.uint32))
+
+
+def test_error_paths(gpu, cornell):
+    from tracer_amd.device import Tracer, TracerError
+    t = Tracer(0)
+    try:
+        with pytest.raises(TracerError) as e:
+            t.render(spp=1)
+        assert e.value.status == abi.ERR_NO_SCENE
+        t.upload_scene(cornell.view)
+        with pytest.raises(TracerError) as e:
+            t.render(spp=1)
+        assert e.value.status == abi.ERR_NO_FRAME
+        # malformed tree: child index out of range
+        import ctypes as C
+        nodes = (abi.BVH * cornell.view.n_bvh)()
+        C.memmove(nodes, cornell.view.bvhList, C.sizeof(nodes))
+        nodes[0].left = 10_000
+        bad = abi.Scene()
+        C.memmove(C.byref(bad), C.byref(cornell.view), C.sizeof(bad))
+        bad.bvhList = C.cast(nodes, C.POINTER(abi.BVH))
+        with pytest.raises(TracerError) as e:
+            t.upload_scene(bad)
+        assert e.value.status == abi.ERR_BVH_INVALID
+    finally:
+        t.close()

@@ -1,0 +1,457 @@
+// dev_bsdf.hpp -- BSDF evaluation / sampling on the device, in the local shading frame (z = normal).
+//
+// Reference (RT_Metal/Metal/): Sampling.hh:18-203, BXDF.hh:24-81, BXDF.metal:3-34,
+// MatteBXDF.hh:6-22, MicrofacetBXDF.h:7-586, Texture.hh:17-43, Material.hh:77-146.
+// The reference hard-codes every lobe parameter in its create*() functions
+// (MicrofacetBXDF.h:438-455,514-530,576-586); they are compile-time constants here, so the
+// material switch carries no per-material parameter loads beyond type + albedo.
+#pragma once
+
+#include "dev_vec.hpp"
+
+namespace trcdev {
+
+// ---------------------------------------------------------------- Sampling.hh
+TRC_DEV void coordinate_system(const F3 a, F3& b, F3& c) {          // Sampling.hh:18-34
+    if (fabsf(a.x) > fabsf(a.y)) b = f3(-a.z, 0, a.x);
+    else b = f3(0, a.z, -a.y);
+    b = normalize(b);
+    c = cross(a, b);
+}
+TRC_DEV F2 concentric_sample_disk(const F2 u) {                      // Sampling.hh:79-99
+    F2 uo; uo.x = 2.f * u.x - 1; uo.y = 2.f * u.y - 1;
+    F2 r0; r0.x = 0; r0.y = 0;
+    if (uo.x == 0 && uo.y == 0) return r0;
+    const float PiOver2 = kPi / 2.0f, PiOver4 = kPi / 4.0f;
+    float theta, r;
+    if (fabsf(uo.x) > fabsf(uo.y)) { r = uo.x; theta = PiOver4 * (uo.y / uo.x); }
+    else { r = uo.y; theta = PiOver2 - PiOver4 * (uo.x / uo.y); }
+    float s, c;
+    dm_sincosf(theta, &s, &c);
+    F2 out; out.x = r * c; out.y = r * s;
+    return out;
+}
+TRC_DEV F3 cosine_sample_hemisphere(const F2 u) {                    // Sampling.hh:125-129
+    F2 d = concentric_sample_disk(u);
+    float z = sqrtf(fmaxf(0.0f, 1.0f - d.x * d.x - d.y * d.y));
+    return f3(d.x, d.y, z);
+}
+TRC_DEV float power_heuristic(int nf, float fPdf, int ng, float gPdf) {   // Sampling.hh:137-140
+    float f = nf * fPdf, g = ng * gPdf;
+    return (f * f) / (f * f + g * g);
+}
+// Sampling.hh:148-203
+TRC_DEV float cos_theta(F3 w) { return w.z; }
+TRC_DEV float cos2_theta(F3 w) { return w.z * w.z; }
+TRC_DEV float abs_cos_theta(F3 w) { return fabsf(w.z); }
+TRC_DEV float sin2_theta(F3 w) { return fmaxf(0.0f, 1.0f - cos2_theta(w)); }
+TRC_DEV float sin_theta(F3 w) { return sqrtf(sin2_theta(w)); }
+TRC_DEV float tan_theta(F3 v) {
+    float temp = 1 - v.z * v.z;
+    if (temp <= 0.0f || v.z == 0.0f) return 0.0f;
+    return sqrtf(temp) / v.z;
+}
+TRC_DEV float tan2_theta(F3 v) {
+    float zz = v.z * v.z;
+    float temp = 1 - zz;
+    if (temp <= 0.0f || zz == 0.0f) return 0.0f;
+    return temp / zz;
+}
+TRC_DEV float cos_phi(F3 w) { float s = sin_theta(w); return (s == 0) ? 1 : clampf(w.x / s, -1.0f, 1.0f); }
+TRC_DEV float sin_phi(F3 w) { float s = sin_theta(w); return (s == 0) ? 0 : clampf(w.y / s, -1.0f, 1.0f); }
+TRC_DEV float cos2_phi(F3 w) { float r = cos_phi(w); return r * r; }
+TRC_DEV float sin2_phi(F3 w) { float r = sin_phi(w); return r * r; }
+TRC_DEV float sqr(float v) { return v * v; }
+
+// ---------------------------------------------------------------- Math.hh:118-167
+TRC_DEV float erf_inv(float x) {
+    float w, p;
+    x = clampf(x, -.99999f, .99999f);
+    w = -dm_logf((1 - x) * (1 + x));
+    if (w < 5) {
+        w = w - 2.5f;
+        p = 2.81022636e-08f;
+        p = 3.43273939e-07f + p * w;
+        p = -3.5233877e-06f + p * w;
+        p = -4.39150654e-06f + p * w;
+        p = 0.00021858087f + p * w;
+        p = -0.00125372503f + p * w;
+        p = -0.00417768164f + p * w;
+        p = 0.246640727f + p * w;
+        p = 1.50140941f + p * w;
+    } else {
+        w = sqrtf(w) - 3;
+        p = -0.000200214257f;
+        p = 0.000100950558f + p * w;
+        p = 0.00134934322f + p * w;
+        p = -0.00367342844f + p * w;
+        p = 0.00573950773f + p * w;
+        p = -0.0076224613f + p * w;
+        p = 0.00943887047f + p * w;
+        p = 1.00167406f + p * w;
+        p = 2.83297682f + p * w;
+    }
+    return p * x;
+}
+TRC_DEV float erf_approx(float x) {
+    const float a1 = 0.254829592f, a2 = -0.284496736f, a3 = 1.421413741f, a4 = -1.453152027f, a5 = 1.061405429f;
+    const float p = 0.3275911f;
+    int sign = 1;
+    if (x < 0) sign = -1;
+    x = fabsf(x);
+    float t = 1 / (1 + p * x);
+    float y = 1 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * dm_expf(-x * x);
+    return sign * y;
+}
+
+// ---------------------------------------------------------------- BXDF.hh / BXDF.metal
+TRC_DEV F3 reflect(F3 wo, F3 n) { return -wo + 2 * dot(wo, n) * n; }             // BXDF.hh:24-26
+TRC_DEV bool refract(F3 wo, F3 n, float eta, F3& wi) {                            // BXDF.hh:28-41 (cos from wo.z, B-6)
+    float cosThetaI = wo.z;
+    float sin2ThetaI = fmaxf(0.0f, 1.0f - cosThetaI * cosThetaI);
+    float sin2ThetaT = eta * eta * sin2ThetaI;
+    if (sin2ThetaT >= 1) return false;
+    float cosThetaT = sqrtf(1 - sin2ThetaT);
+    wi = eta * -wo + (eta * cosThetaI - cosThetaT) * n;
+    return true;
+}
+TRC_DEV float fr_dielectric(float cosi, float eta) {                              // BXDF.metal:3-22
+    cosi = clampf(cosi, -1.0f, 1.0f);
+    bool entering = cosi > 0.f;
+    if (!entering) { eta = 1 / eta; cosi = -cosi; }
+    float sin2Theta_i = 1 - cosi * cosi;
+    float sin2Theta_t = sin2Theta_i / sqr(eta);
+    if (sin2Theta_t >= 1) return 1.f;
+    float cosTheta_t = sqrtf(fmaxf(0.0f, 1 - sin2Theta_t));
+    float r_parl = (eta * cosi - cosTheta_t) / (eta * cosi + cosTheta_t);
+    float r_perp = (cosi - eta * cosTheta_t) / (cosi + eta * cosTheta_t);
+    return (r_parl * r_parl + r_perp * r_perp) / 2;
+}
+TRC_DEV F3 fr_conductor(float cosi, F3 eta, F3 k) {                               // BXDF.metal:24-34
+    F3 tmp = (eta * eta + k * k) * cosi * cosi;
+    F3 Rparl2 = (tmp - (2.f * eta * cosi) + f3(1)) / (tmp + (2.f * eta * cosi) + f3(1));
+    F3 tmp_f = eta * eta + k * k;
+    F3 Rperp2 = (tmp_f - (2.f * eta * cosi) + f3(cosi * cosi)) / (tmp_f + (2.f * eta * cosi) + f3(cosi * cosi));
+    return 0.5f * (Rparl2 + Rperp2);
+}
+
+// Fresnel policies
+struct FrCond {   // BXDF.hh:59-70; MetalMaterial: eta = (0.18, 0.15, 0.81), k = 1 (MicrofacetBXDF.h:445-449)
+    TRC_DEV static F3 eval(float cosThetaI) { return fr_conductor(fabsf(cosThetaI), f3(0.18f, 0.15f, 0.81f), f3(1.0f)); }
+};
+struct FrDiel15 { // BXDF.hh:72-81 with eta = 1.5 (Plastic, Glass reflection)
+    TRC_DEV static F3 eval(float cosThetaI) { return f3(fr_dielectric(cosThetaI, 1.5f)); }
+};
+
+// ---------------------------------------------------------------- microfacet distributions
+// alpha is already clamped to >= 0.001 by the constructors (MicrofacetBXDF.h:164,306-309)
+// roughness pairs as types (float literals must match the reference's exactly)
+struct Alpha_01_02 { TRC_DEV static float x() { return 0.01f; } TRC_DEV static float y() { return 0.02f; } };
+struct Alpha_01_10 { TRC_DEV static float x() { return 0.01f; } TRC_DEV static float y() { return 0.1f; } };
+struct Alpha_01_01 { TRC_DEV static float x() { return 0.01f; } TRC_DEV static float y() { return 0.01f; } };
+
+template <class Alpha>
+struct BeckmannD {                                                   // MicrofacetBXDF.h:137-290
+    TRC_DEV static float ax() { return fmaxf(0.001f, Alpha::x()); }
+    TRC_DEV static float ay() { return fmaxf(0.001f, Alpha::y()); }
+
+    TRC_DEV static float lambda(F3 w) {
+        float absTanTheta = fabsf(tan_theta(w));
+        if (is_inf(absTanTheta)) return 0.;
+        float alpha = sqrtf(cos2_phi(w) * ax() * ax() + sin2_phi(w) * ay() * ay());
+        float a = 1 / (alpha * absTanTheta);
+        if (a >= 1.6f) return 0;
+        return (1 - 1.259f * a + 0.396f * a * a) / (3.535f * a + 2.181f * a * a);
+    }
+    TRC_DEV static float D(F3 wh) {
+        float tan2Theta = tan2_theta(wh);
+        if (is_inf(tan2Theta)) return 0.;
+        float cos4Theta = cos2_theta(wh) * cos2_theta(wh);
+        return dm_expf(-tan2Theta * (cos2_phi(wh) / (ax() * ax()) + sin2_phi(wh) / (ay() * ay()))) /
+               (kPi * ax() * ay() * cos4Theta);
+    }
+    TRC_DEV static float G1(F3 w) { return 1 / (1 + lambda(w)); }
+    TRC_DEV static float G(F3 wo, F3 wi) { return 1 / (1 + lambda(wo) + lambda(wi)); }
+    TRC_DEV static float pdf(F3 wo, F3 wh) { return D(wh) * G1(wo) * fabsf(dot(wo, wh)) / abs_cos_theta(wo); }
+
+    TRC_DEV static void sample11(float cosThetaI, float U1, float U2, float& slope_x, float& slope_y) {
+        if (cosThetaI > .9999f) {
+            float r = sqrtf(-dm_logf(1.0f - U1));
+            float sinPhi, cosPhi;
+            dm_sincosf(2 * kPi * U2, &sinPhi, &cosPhi);
+            slope_x = r * cosPhi;
+            slope_y = r * sinPhi;
+            return;
+        }
+        float sinThetaI = sqrtf(fmaxf(0.0f, 1.0f - cosThetaI * cosThetaI));
+        float tanThetaI = sinThetaI / cosThetaI;
+        float cotThetaI = 1 / tanThetaI;
+        float a = -1, c = erf_approx(cotThetaI);
+        float sample_x = fmaxf(U1, 1e-6f);
+        float thetaI = dm_acosf(cosThetaI);
+        float fit = 1 + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
+        float b = c - (1 + c) * dm_powf(1 - sample_x, fit);
+        const float SQRT_PI_INV = 1.f / sqrtf(kPi);
+        float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * dm_expf(-cotThetaI * cotThetaI));
+        int it = 0;
+        while (++it < 10) {
+            if (!(b >= a && b <= c)) b = 0.5f * (a + c);
+            float invErf = erf_inv(b);
+            float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * dm_expf(-invErf * invErf)) - sample_x;
+            float derivative = normalization * (1 - invErf * tanThetaI);
+            if (fabsf(value) < 1e-5f) break;
+            if (value > 0) c = b; else a = b;
+            b -= value / derivative;
+        }
+        slope_x = erf_inv(b);
+        slope_y = erf_inv(2.0f * fmaxf(U2, 1e-6f) - 1.0f);
+    }
+    TRC_DEV static F3 sample_wh(F3 wo, F2 u) {
+        const bool flip = wo.z < 0;
+        const F3 wi = flip ? -wo : wo;
+        F3 wiStretched = normalize(f3(ax() * wi.x, ay() * wi.y, wi.z));
+        float slope_x, slope_y;
+        sample11(cos_theta(wiStretched), u.x, u.y, slope_x, slope_y);
+        float tmp = cos_phi(wiStretched) * slope_x - sin_phi(wiStretched) * slope_y;
+        slope_y = sin_phi(wiStretched) * slope_x + cos_phi(wiStretched) * slope_y;
+        slope_x = tmp;
+        slope_x = ax() * slope_x;
+        slope_y = ay() * slope_y;
+        F3 wh = normalize(f3(-slope_x, -slope_y, 1.f));
+        return flip ? -wh : wh;
+    }
+};
+
+template <class Alpha>
+struct TrowbridgeReitzD {                                            // MicrofacetBXDF.h:292-434
+    TRC_DEV static float ax() { return fmaxf(0.001f, Alpha::x()); }
+    TRC_DEV static float ay() { return fmaxf(0.001f, Alpha::y()); }
+
+    TRC_DEV static float D(F3 wh) {
+        float tan2Theta = tan2_theta(wh);
+        if (is_inf(tan2Theta)) return 0.;
+        const float cos4Theta = cos2_theta(wh) * cos2_theta(wh);
+        if (cos4Theta < 1e-16f) return 0;
+        float e = (cos2_phi(wh) / sqr(ax()) + sin2_phi(wh) / sqr(ay())) * tan2Theta;
+        return 1 / (kPi * ax() * ay() * sqr(1 + e) * cos4Theta);
+    }
+    TRC_DEV static float lambda(F3 w) {
+        float tan2Theta = tan2_theta(w);
+        if (is_inf(tan2Theta)) return 0.;
+        float alpha2 = sqr(cos_phi(w) * ax()) + sqr(sin_phi(w) * ay());
+        return 0.5f * (sqrtf(1 + alpha2 * tan2Theta) - 1);
+    }
+    TRC_DEV static float G1(F3 w) { return 1 / (1 + lambda(w)); }
+    TRC_DEV static float G(F3 wo, F3 wi) { return 1 / (1 + lambda(wo) + lambda(wi)); }
+    TRC_DEV static float pdf(F3 wo, F3 wh) { return D(wh) * G1(wo) * fabsf(dot(wo, wh) / cos_theta(wo)); }
+
+    TRC_DEV static void sample11(float cosTheta, float U1, float U2, float& slope_x, float& slope_y) {
+        if (cosTheta > .9999f) {
+            float r = sqrtf(U1 / (1 - U1));
+            float phi = 6.28318530718f * U2;
+            float s, c;
+            dm_sincosf(phi, &s, &c);
+            slope_x = r * c;
+            slope_y = r * s;
+            return;
+        }
+        float sinTheta = sqrtf(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
+        float tanTheta = sinTheta / cosTheta;
+        float a = 1 / tanTheta;
+        float G1 = 2 / (1 + sqrtf(1.f + 1.f / (a * a)));
+        float A = 2 * U1 / G1 - 1;
+        float tmp = 1.f / (A * A - 1.f);
+        if (tmp > 1e10f) tmp = 1e10f;
+        float B = tanTheta;
+        float D = sqrtf(fmaxf(B * B * tmp * tmp - (A * A - B * B) * tmp, 0.0f));
+        float slope_x_1 = B * tmp - D;
+        float slope_x_2 = B * tmp + D;
+        slope_x = (A < 0 || slope_x_2 > 1.f / tanTheta) ? slope_x_1 : slope_x_2;
+        float S;
+        if (U2 > 0.5f) { S = 1.f; U2 = 2.f * (U2 - .5f); }
+        else { S = -1.f; U2 = 2.f * (.5f - U2); }
+        float z = (U2 * (U2 * (U2 * 0.27385f - 0.73369f) + 0.46341f)) /
+                  (U2 * (U2 * (U2 * 0.093073f + 0.309420f) - 1.000000f) + 0.597999f);
+        slope_y = S * z * sqrtf(1.f + slope_x * slope_x);
+    }
+    TRC_DEV static F3 sample_wh(F3 wo, F2 u) {
+        const bool flip = wo.z < 0;
+        const F3 wi = flip ? -wo : wo;
+        F3 wiStretched = normalize(f3(ax() * wi.x, ay() * wi.y, wi.z));
+        float slope_x, slope_y;
+        sample11(cos_theta(wiStretched), u.x, u.y, slope_x, slope_y);
+        float tmp = cos_phi(wiStretched) * slope_x - sin_phi(wiStretched) * slope_y;
+        slope_y = sin_phi(wiStretched) * slope_x + cos_phi(wiStretched) * slope_y;
+        slope_x = tmp;
+        slope_x = ax() * slope_x;
+        slope_y = ay() * slope_y;
+        F3 wh = normalize(f3(-slope_x, -slope_y, 1.f));
+        return flip ? -wh : wh;
+    }
+};
+
+// ---------------------------------------------------------------- lobes
+struct Lambert {                                                     // MatteBXDF.hh:6-22 (F folds in the cosine)
+    TRC_DEV static float F(F3, F3 wi) { return wi.z / kPi; }
+    TRC_DEV static float pdf(F3 wo, F3 wi) { return wo.z * wi.z > 0 ? fabsf(wi.z) / kPi : 0; }
+    TRC_DEV static float S_F(F3 wo, F3& wi, F2 uu, float& pdf_out) {
+        wi = cosine_sample_hemisphere(uu);
+        pdf_out = pdf(wo, wi);
+        return wi.z / kPi;
+    }
+};
+
+template <class Dist, class Fr>
+struct MicroRefl {                                                   // MicrofacetBXDF.h:7-62
+    TRC_DEV static F3 F(float R, F3 wo, F3 wi) {
+        float cosThetaO = abs_cos_theta(wo), cosThetaI = abs_cos_theta(wi);
+        if (cosThetaI == 0 || cosThetaO == 0) return f3(0);
+        F3 wh = wi + wo;
+        if (wh.x == 0 && wh.y == 0 && wh.z == 0) return f3(0);
+        wh = normalize(wh);
+        // Faceforward(wh, (0,0,1)): dot(wh,(0,0,1)) is evaluated like the oracle does
+        const float d001 = wh.x * 0.0f + wh.y * 0.0f + wh.z * 1.0f;
+        const F3 whf = (d001 < 0.f) ? -wh : wh;
+        F3 Fres = Fr::eval(dot(wi, whf));
+        return f3(R) * Dist::D(wh) * Dist::G(wo, wi) * Fres / (4 * cosThetaI * cosThetaO);
+    }
+    TRC_DEV static float pdf(F3 wo, F3 wi) {
+        if (wo.z * wi.z <= 0) return 0;
+        F3 wh = normalize(wo + wi);
+        return Dist::pdf(wo, wh) / (4 * dot(wo, wh));
+    }
+    TRC_DEV static F3 S_F(float R, F3 wo, F3& wi, F2 uu, float& pdf_out) {
+        if (wo.z == 0) return f3(0);
+        F3 wh = Dist::sample_wh(wo, uu);
+        if (dot(wo, wh) <= 0) return f3(0);
+        wi = reflect(wo, wh);
+        if (wo.z * wi.z <= 0) return f3(0);
+        pdf_out = Dist::pdf(wo, wh) / (4 * dot(wo, wh));
+        return F(R, wo, wi);
+    }
+};
+
+// MicrofacetBXDF.h:64-135 as instantiated by GlassMaterial (:541): T = 0.98, etaA = 1, etaB = 1.5,
+// mode = Importance (factor 1), and its own Fresnel is FresnelDielectric(etaA = 1.0) (:81).
+template <class Dist>
+struct MicroTransGlass {
+    TRC_DEV static F3 F(F3 wo, F3 wi) {
+        const float etaA = 1.0f, etaB = 1.5f;
+        if (wo.z * wi.z > 0) return f3(0);
+        float cosThetaO = cos_theta(wo), cosThetaI = cos_theta(wi);
+        if (cosThetaI == 0 || cosThetaO == 0) return f3(0);
+        float eta = cos_theta(wo) > 0 ? (etaB / etaA) : (etaA / etaB);
+        F3 wh = normalize(wo + wi * eta);
+        if (wh.z < 0) wh = -wh;
+        if (dot(wo, wh) * dot(wi, wh) > 0) return f3(0);
+        F3 Fres = f3(fr_dielectric(dot(wo, wh), etaA));
+        float sqrtDenom = dot(wo, wh) + eta * dot(wi, wh);
+        float factor = 1;
+        return (f3(1.0f) - Fres) * f3(0.98f) *
+               fabsf(Dist::D(wh) * Dist::G(wo, wi) * eta * eta * fabsf(dot(wi, wh)) * fabsf(dot(wo, wh)) * factor * factor /
+                     (cosThetaI * cosThetaO * sqrtDenom * sqrtDenom));
+    }
+    TRC_DEV static float pdf(F3 wo, F3 wi) {
+        const float etaA = 1.0f, etaB = 1.5f;
+        if (wo.z * wi.z > 0) return 0;
+        float eta = cos_theta(wo) > 0 ? (etaB / etaA) : (etaA / etaB);
+        F3 wh = normalize(wo + wi * eta);
+        if (dot(wo, wh) * dot(wi, wh) > 0) return 0;
+        float sqrtDenom = dot(wo, wh) + eta * dot(wi, wh);
+        float dwh_dwi = fabsf((eta * eta * dot(wi, wh)) / (sqrtDenom * sqrtDenom));
+        return Dist::pdf(wo, wh) * dwh_dwi;
+    }
+    TRC_DEV static F3 S_F(F3 wo, F3& wi, F2 uu, float& pdf_out) {
+        const float etaA = 1.0f, etaB = 1.5f;
+        if (wo.z == 0) return f3(0);
+        F3 wh = Dist::sample_wh(wo, uu);
+        if (dot(wo, wh) < 0) return f3(0);
+        float eta = cos_theta(wo) > 0 ? (etaA / etaB) : (etaB / etaA);
+        if (!refract(wo, wh, eta, wi)) return f3(0);
+        pdf_out = pdf(wo, wi);
+        return F(wo, wi);
+    }
+};
+
+// composites (MicrofacetBXDF.h:436-586)
+typedef MicroRefl<TrowbridgeReitzD<Alpha_01_02>, FrCond> MetalLobe;       // alpha (0.01, 0.02), R = 1
+typedef MicroRefl<BeckmannD<Alpha_01_10>, FrDiel15> PlasticLobe;         // alpha (0.01, 0.1),  R = 1
+typedef MicroRefl<BeckmannD<Alpha_01_01>, FrDiel15> GlassReflLobe;        // alpha (0.01, 0.01), R = kr = 0.98
+typedef MicroTransGlass<BeckmannD<Alpha_01_01>> GlassTransLobe;
+
+// material types (Material.hh:18-20) and texture types (Texture.hh:6) by ordinal
+constexpr int kMatDiffuse = 0, kMatLambert = 1, kMatPlastic = 3, kMatMetal = 4, kMatGlass = 5;
+constexpr int kTexConstant = 0, kTexChecker = 1;
+
+TRC_DEV F3 texture_value(int tex_type, F3 albedo, F2 uv) {           // Texture.hh:17-43
+    if (tex_type == kTexChecker) {
+        float s, c, s2, c2;
+        dm_sincosf(8 * kPi * uv.x, &s, &c);
+        dm_sincosf(kPi / 2 + 4 * kPi * uv.y, &s2, &c2);
+        float sines = s * c2;
+        return albedo * (0.5f * (sines < 0 ? 0.0f : 1.0f) + 0.5f);
+    }
+    // Constant; Image with a null texture and Noise resolve to albedo (see oracle/oracle.cpp texture_value)
+    return (tex_type >= 0 && tex_type <= 3) ? albedo : f3(1.0f);
+}
+
+// Material::S_F, Material.hh:124-146.  bxPDF must be pre-set to 0 by the caller (B-3).
+TRC_DEV F3 material_S_F(int type, F3 color, F3 wo, F3& wi, F2 uu, float& pdf) {
+    switch (type) {
+        case kMatLambert:
+            return color * f3(Lambert::S_F(wo, wi, uu, pdf));
+        case kMatMetal:
+            return color * MetalLobe::S_F(1.0f, wo, wi, uu, pdf);
+        case kMatPlastic: {                                          // PlasticMaterial::S_F, :497-511
+            F2 u2 = uu;
+            if (u2.x < 0.5f) {
+                u2.x *= 2;
+                return color * (f3(0.35f, 0.12f, 0.48f) * Lambert::S_F(wo, wi, u2, pdf));
+            }
+            u2.x -= 0.5f; u2.x *= 2.0f;
+            return color * (f3(0.2f) * PlasticLobe::S_F(1.0f, wo, wi, u2, pdf));
+        }
+        case kMatGlass: {                                            // GlassMaterial::S_F, :564-573
+            const float ratio = 0.25f;
+            F2 u2 = uu;
+            if (uu.x < ratio) { u2.x = uu.x / ratio; return color * GlassReflLobe::S_F(0.98f, wo, wi, u2, pdf); }
+            u2.x = (uu.x - ratio) / (1.0f - ratio);
+            return color * GlassTransLobe::S_F(wo, wi, u2, pdf);
+        }
+        default:
+            return f3(0);
+    }
+}
+
+// Material::F, Material.hh:77-99 (pdf = bx.PDF, value = color * bx.F)
+TRC_DEV F3 material_F(int type, F3 color, F3 wo, F3 wi, F2 uu, float& pdf) {
+    switch (type) {
+        case kMatLambert:
+            pdf = Lambert::pdf(wo, wi);
+            return color * f3(Lambert::F(wo, wi));
+        case kMatMetal:
+            pdf = MetalLobe::pdf(wo, wi);
+            return color * MetalLobe::F(1.0f, wo, wi);
+        case kMatPlastic:                                            // PlasticMaterial::F/PDF, :469-495
+            if (uu.x < 0.5f) {
+                pdf = Lambert::pdf(wo, wi);
+                return color * (f3(0.35f, 0.12f, 0.48f) * Lambert::F(wo, wi));
+            }
+            pdf = PlasticLobe::pdf(wo, wi);
+            return color * (f3(0.2f) * PlasticLobe::F(1.0f, wo, wi));
+        case kMatGlass: {                                            // GlassMaterial::F/PDF, :543-562
+            const float ratio = 0.25f;
+            if (uu.x < ratio) {
+                pdf = ratio * GlassReflLobe::pdf(wo, wi);
+                return color * GlassReflLobe::F(0.98f, wo, wi);
+            }
+            pdf = (1 - ratio) * GlassTransLobe::pdf(wo, wi);
+            return color * GlassTransLobe::F(wo, wi);
+        }
+        default:
+            pdf = 0;
+            return f3(0);
+    }
+}
+
+}  // namespace trcdev

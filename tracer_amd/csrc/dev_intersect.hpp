@@ -1,0 +1,383 @@
+// dev_intersect.hpp -- ray/box, ray/primitive tests and the BVH traversal on the device.
+//
+// Reference functions restated here (RT_Metal/Metal/):
+//   AABB::hit / hit_t            AABB.hh:73-112
+//   AABB::hit(ray,range,record)  AABB.hh:114-209   (used by Cube)
+//   Sphere::hit_test             Sphere.hh:33-78
+//   Square::hit_test / sample    Square.hh:40-113
+//   Cube::hit_test               Cube.hh:17-47
+//   Triangle::hit_test           Triangle.hh:31-85
+//   Scene::hit                   Render.hh:135-252
+//
+// Traversal design (MI355X): the reference walks parent pointers with a 32-bit "visit the
+// sibling later" bitmask and spends one loop iteration per level on the way back up.  Here the
+// deferred sibling is pushed on a per-lane short stack in LDS (column layout: entry e of lane l
+// at stack[e * 256 + l], so a wavefront's push/pop is one conflict-free ds_write/ds_read_b32),
+// which removes every upward iteration while visiting boxes and primitives in EXACTLY the
+// reference's order -- near child first by hit_t, far child later WITHOUT re-testing its box
+// (Render.hh:171-174,204-208) -- so closest-hit ties resolve identically.  The upward
+// iterations the reference would have executed are still COUNTED (exactly) in the
+// instrumented build, because the roofline's algorithmic bytes are defined on them.
+#pragma once
+
+#include "dev_scene.hpp"
+#include "dev_vec.hpp"
+
+namespace trcdev {
+
+constexpr int kBlock = 256;   // threads per workgroup = one 16x16 pixel tile = 4 wavefronts of 8x8
+
+struct Ray {
+    F3 o, d, inv;     // inv = 1.0 / direction, computed once per ray (AABB.hh:75,94 recompute it per box)
+};
+TRC_DEV Ray make_ray(F3 o, F3 dir) {     // Ray::Ray normalises (Ray.hh:21-23)
+    Ray r; r.o = o; r.d = normalize(dir); r.inv = f3(1.0f) / r.d; return r;
+}
+TRC_DEV F3 point_at(const Ray& r, float t) { return r.o + r.d * t; }
+
+struct HitRec {       // HitRecord.hh:9-30 (live fields) + the primitive tag
+    float t;
+    F3 p, gn, sn;
+    F2 uv;
+    uint32_t material;
+    float PDF;
+    uint32_t tag;
+};
+TRC_DEV void hit_init(HitRec& h) {
+    h.t = 0; h.p = f3(0); h.gn = f3(0); h.sn = f3(0); h.uv.x = 0; h.uv.y = 0; h.material = 0; h.PDF = 0; h.tag = kTagNone;
+}
+TRC_DEV void check_face(HitRec& h, const Ray& ray) {   // HitRecord.hh:26-29
+    bool f = dot(ray.d, h.gn) <= 0;
+    h.sn = f ? h.gn : -h.gn;
+}
+
+struct TravCounters {   // only live in instrumented kernels
+    uint32_t rays, shaded, n_descend, n_return, leaf[4], hit_triangle, hit_cube;
+};
+TRC_DEV void counters_zero(TravCounters& c) {
+    c.rays = c.shaded = c.n_descend = c.n_return = 0; c.leaf[0] = c.leaf[1] = c.leaf[2] = c.leaf[3] = 0;
+    c.hit_triangle = c.hit_cube = 0;
+}
+
+// scene accessor: `small` points at the LDS copy (or the global blob) of nodes+analytic prims+materials
+struct SceneRef {
+    const uint32_t* small_base;
+    const uint32_t* blob;
+    uint32_t off_nodes, off_spheres, off_squares, off_cubes, off_materials, off_tripos, off_triattr;
+};
+TRC_DEV float4 ld4(const uint32_t* p) { return *reinterpret_cast<const float4*>(p); }
+
+// ---------------------------------------------------------------- boxes
+TRC_DEV bool box_hit(F3 mn, F3 mx, const Ray& r, float rx, float ry) {      // AABB.hh:73-90
+    F3 ts = (mn - r.o) * r.inv;
+    F3 te = (mx - r.o) * r.inv;
+    float tmin = fmax3(fminf(ts.x, te.x), fminf(ts.y, te.y), fminf(ts.z, te.z));
+    float tmax = fmin3(fmaxf(ts.x, te.x), fmaxf(ts.y, te.y), fmaxf(ts.z, te.z));
+    tmin = fmaxf(tmin, rx);
+    tmax = fminf(tmax, ry);
+    return !(tmax < tmin || tmax < 0);
+}
+TRC_DEV bool box_hit_t(F3 mn, F3 mx, const Ray& r, float rx, float ry, float& t) {   // AABB.hh:92-112
+    F3 ts = (mn - r.o) * r.inv;
+    F3 te = (mx - r.o) * r.inv;
+    float tmin = fmax3(fminf(ts.x, te.x), fminf(ts.y, te.y), fminf(ts.z, te.z));
+    float tmax = fmin3(fmaxf(ts.x, te.x), fmaxf(ts.y, te.y), fmaxf(ts.z, te.z));
+    tmin = fmaxf(tmin, rx);
+    tmax = fminf(tmax, ry);
+    if (tmax < tmin || tmax < 0) return false;
+    t = (tmin < 0) ? tmax : tmin;
+    return true;
+}
+
+// Math.hh:51-55: gamma(3) with MachineEpsilon = FLT_EPSILON * 0.5 (unparenthesised macro)
+TRC_DEV float box_pad() { return 1 + 2 * ((3 * FLT_EPSILON * 0.5f) / (1 - 3 * FLT_EPSILON * 0.5f)); }
+
+// AABB.hh:114-209: object-space box test of Cube; o/d are the object-space ray (d normalised)
+TRC_DEV bool box_hit_record(F3 mini, F3 maxi, F3 o, F3 d, float range_y, float& out_t, F3& out_gn, F3& out_p, F2& out_uv) {
+    float tmin = -FLT_MAX;
+    float tmax = range_y;
+    uint32_t axisPick = 0;
+    const F3 ddd = o - mini, bbb = o - maxi;
+    const float pad = box_pad();
+    const bool inside = (ddd.x > 0 && ddd.y > 0 && ddd.z > 0) && (bbb.x < 0 && bbb.y < 0 && bbb.z < 0);
+#pragma unroll
+    for (uint32_t i = 0; i < 3; ++i) {
+        float oi = comp(o, i), di = comp(d, i);
+        float min_bound = (comp(mini, i) - oi) / di;
+        float max_bound = (comp(maxi, i) - oi) / di;
+        float ts = fminf(max_bound, min_bound);
+        float te = fmaxf(max_bound, min_bound);
+        te *= pad;
+        if (inside) {
+            tmin = fmaxf(ts, tmin);
+            if (te < tmax) { tmax = te; axisPick = i; }
+        } else {
+            tmax = fminf(te, tmax);
+            if (ts > tmin) { tmin = ts; axisPick = i; }
+        }
+        if (tmax < tmin || tmax < 0) return false;
+    }
+    const float dpick = comp(d, axisPick);
+    const float t = inside ? tmax : tmin;
+    out_t = t;
+    F3 gn = f3(0);
+    set_comp(gn, axisPick, inside ? (dpick > 0 ? 1.0f : -1.0f) : (dpick > 0 ? -1.0f : 1.0f));
+    out_gn = gn;
+    F3 hitPoint = o + d * t;
+    F3 p = hitPoint;
+    set_comp(p, axisPick, inside ? (dpick > 0 ? comp(maxi, axisPick) : comp(mini, axisPick))
+                                 : (dpick > 0 ? comp(mini, axisPick) : comp(maxi, axisPick)));
+    out_p = p;
+    uint32_t ax = axisPick + 1; ax = ax >= 3 ? ax - 3 : ax;
+    uint32_t ay = axisPick + 2; ay = ay >= 3 ? ay - 3 : ay;
+    out_uv.x = comp(hitPoint, ax);
+    out_uv.y = comp(hitPoint, ay);
+    return true;
+}
+
+// ---------------------------------------------------------------- primitives
+TRC_DEV F2 sphere_uv(F3 p) {    // Sphere.hh:19-31
+    float phi = dm_atan2f(p.z, p.x);
+    float theta = dm_asinf(p.y);
+    F2 uv;
+    uv.x = 1 - (phi + kPi) / (2 * kPi);
+    uv.y = (theta + kPi2) / kPi;
+    return uv;
+}
+
+template <bool EAGER_UV>
+TRC_DEV bool sphere_hit_test(const SceneRef& S, uint32_t index, const Ray& ray, float rx, float& ry, HitRec& rec) {
+    const uint32_t* sp = S.small_base + S.off_spheres + index * kSphereDwords;
+    const float4 cr = ld4(sp);
+    const F3 center = f3(cr.x, cr.y, cr.z);
+    const float radius = cr.w;
+    F3 oc = ray.o - center;
+    float a = dot(ray.d, ray.d);
+    float half_b = dot(oc, ray.d);
+    float c = dot(oc, oc) - radius * radius;
+    float discriminant = half_b * half_b - a * c;
+    if (discriminant <= 0) return false;
+    float root = sqrtf(discriminant);
+    float temp = (-half_b - root) / a;
+    if (!(temp < ry && temp > rx)) {
+        temp = (-half_b + root) / a;
+        if (!(temp < ry && temp > rx)) return false;
+    }
+    rec.t = temp;
+    rec.p = point_at(ray, temp);
+    rec.gn = (rec.p - center) / radius;
+    check_face(rec, ray);
+    if (EAGER_UV) rec.uv = sphere_uv(rec.gn);    // the render kernel derives it lazily from gn
+    rec.material = sp[4];
+    ry = temp;
+    return true;
+}
+
+TRC_DEV bool square_hit_test(const SceneRef& S, uint32_t index, const Ray& ray, float rx, float& ry, HitRec& rec) {
+    const uint32_t* sq = S.small_base + S.off_squares + index * kSquareDwords;
+    const float4 rg = ld4(sq);          // range_i.x, range_i.y, range_j.x, range_j.y
+    const float4 kx = ld4(sq + 4);      // value_k, 1/area, axes, material
+    const uint32_t axes = __float_as_uint(kx.z);
+    const uint32_t axis_i = axes & 3u, axis_j = (axes >> 2) & 3u, axis_k = (axes >> 4) & 3u;
+    const float value_k = kx.x;
+    float t = (value_k - comp(ray.o, axis_k)) / comp(ray.d, axis_k);
+    if (is_inf(t) || is_nan(t)) return false;
+    if (t < rx || t > ry) return false;
+    float a = comp(ray.o, axis_i) + t * comp(ray.d, axis_i);
+    if (a < rg.x || a > rg.y) return false;
+    float b = comp(ray.o, axis_j) + t * comp(ray.d, axis_j);
+    if (b < rg.z || b > rg.w) return false;
+    rec.uv.x = (a - rg.x) / (rg.y - rg.x);
+    rec.uv.y = (b - rg.z) / (rg.w - rg.z);
+    rec.t = t;
+    F3 gn = f3(0);
+    set_comp(gn, axis_k, 1.0f);
+    rec.gn = gn;
+    check_face(rec, ray);
+    rec.gn = rec.sn;
+    set_comp(rec.p, axis_k, value_k);
+    set_comp(rec.p, axis_i, a);
+    set_comp(rec.p, axis_j, b);
+    ry = t;
+    rec.PDF = kx.y;
+    rec.material = __float_as_uint(kx.w);
+    return true;
+}
+
+struct LightSample { F3 p, n; float areaPDF; uint32_t material; };
+// Math.hh:57-74 (Ray Tracing Gems ch. 6)
+TRC_DEV F3 offset_ray(const F3 p, const F3 n) {
+    const float origin = 1.0f / 32.0f, float_scale = 1.0f / 65536.0f, int_scale = 256.0f;
+    int32_t of_x = (int32_t)(int_scale * n.x), of_y = (int32_t)(int_scale * n.y), of_z = (int32_t)(int_scale * n.z);
+    float pix = __int_as_float(__float_as_int(p.x) + ((p.x < 0) ? -of_x : of_x));
+    float piy = __int_as_float(__float_as_int(p.y) + ((p.y < 0) ? -of_y : of_y));
+    float piz = __int_as_float(__float_as_int(p.z) + ((p.z < 0) ? -of_z : of_z));
+    return f3(fabsf(p.x) < origin ? p.x + float_scale * n.x : pix,
+              fabsf(p.y) < origin ? p.y + float_scale * n.y : piy,
+              fabsf(p.z) < origin ? p.z + float_scale * n.z : piz);
+}
+// Square.hh:40-58
+TRC_DEV void square_sample(const SceneRef& S, uint32_t index, F2 u, F3 pos, LightSample& lsr) {
+    const uint32_t* sq = S.small_base + S.off_squares + index * kSquareDwords;
+    const float4 rg = ld4(sq);
+    const float4 kx = ld4(sq + 4);
+    const uint32_t axes = __float_as_uint(kx.z);
+    const uint32_t axis_i = axes & 3u, axis_j = (axes >> 2) & 3u, axis_k = (axes >> 4) & 3u;
+    F3 p = f3(0);
+    set_comp(p, axis_k, kx.x);
+    set_comp(p, axis_i, rg.x + u.x * (rg.y - rg.x));
+    set_comp(p, axis_j, rg.z + u.y * (rg.w - rg.z));
+    F3 n = f3(0);
+    set_comp(n, axis_k, 1.0f);
+    F3 w = normalize(pos - p);
+    set_comp(n, axis_k, copysignf(1.0f, dot(w, n)));
+    lsr.n = n;
+    lsr.p = offset_ray(p, n);
+    lsr.areaPDF = kx.y;
+    lsr.material = __float_as_uint(kx.w);
+}
+
+template <bool STATS>
+TRC_DEV bool cube_hit_test(const SceneRef& S, uint32_t index, const Ray& ray, float& ry, HitRec& rec, TravCounters& cnt) {
+    const uint32_t* cb = S.small_base + S.off_cubes + index * kCubeDwords;
+    // inverse matrix columns c0..c3 (xyz each)
+    const float4 i0 = ld4(cb), i1 = ld4(cb + 4), i2 = ld4(cb + 8);
+    const F3 ic0 = f3(i0.x, i0.y, i0.z), ic1 = f3(i0.w, i1.x, i1.y), ic2 = f3(i1.z, i1.w, i2.x), ic3 = f3(i2.y, i2.z, i2.w);
+    F3 origin = ((ic0 * ray.o.x + ic1 * ray.o.y) + ic2 * ray.o.z) + ic3;
+    F3 direction = (ic0 * ray.d.x + ic1 * ray.d.y) + ic2 * ray.d.z;
+    direction = normalize(direction);                       // Ray(origin.xyz, direction.xyz), Cube.hh:23
+    // layout: [0,12) inverse, [12,24) model, [24,33) normal c0..c2, [33,39) box min/max, [39] material
+    const F3 mini = f3(__uint_as_float(cb[33]), __uint_as_float(cb[34]), __uint_as_float(cb[35]));
+    const F3 maxi = f3(__uint_as_float(cb[36]), __uint_as_float(cb[37]), __uint_as_float(cb[38]));
+    float t_obj; F3 gn_obj, p_obj; F2 uv;
+    if (!box_hit_record(mini, maxi, origin, direction, ry, t_obj, gn_obj, p_obj, uv)) return false;
+    if (STATS) cnt.hit_cube++;
+    const float4 m0 = ld4(cb + 12), m1 = ld4(cb + 16), m2 = ld4(cb + 20);
+    const F3 mc0 = f3(m0.x, m0.y, m0.z), mc1 = f3(m0.w, m1.x, m1.y), mc2 = f3(m1.z, m1.w, m2.x), mc3 = f3(m2.y, m2.z, m2.w);
+    F3 p = ((mc0 * p_obj.x + mc1 * p_obj.y) + mc2 * p_obj.z) + mc3;
+    float t = length(ray.o - p);                            // distance(ray.origin, p), Cube.hh:32
+    if (t >= ry) return false;
+    ry = t;
+    const float4 n0 = ld4(cb + 24), n1 = ld4(cb + 28);
+    const F3 nc0 = f3(n0.x, n0.y, n0.z), nc1 = f3(n0.w, n1.x, n1.y), nc2 = f3(n1.z, n1.w, __uint_as_float(cb[32]));
+    rec.t = t;
+    rec.p = p;
+    rec.gn = normalize((nc0 * gn_obj.x + nc1 * gn_obj.y) + nc2 * gn_obj.z);
+    check_face(rec, ray);
+    rec.uv = uv;
+    rec.material = cb[39];
+    // rec.PDF keeps its previous value: the reference copies an uninitialised field here (Cube.hh:21,45)
+    return true;
+}
+
+template <bool STATS>
+TRC_DEV bool triangle_hit_test(const SceneRef& S, uint32_t index, const Ray& ray, float rx, float& ry, HitRec& rec, TravCounters& cnt) {
+    const uint32_t* tp = S.blob + S.off_tripos + (size_t)index * kTriPosDwords;
+    const float4 a4 = ld4(tp), b4 = ld4(tp + 4), c4 = ld4(tp + 8);
+    const F3 v0 = f3(a4.x, a4.y, a4.z), v1 = f3(b4.x, b4.y, b4.z), v2 = f3(c4.x, c4.y, c4.z);
+    F3 v0v1 = v1 - v0;
+    F3 v0v2 = v2 - v0;
+    F3 pvec = cross(ray.d, v0v2);
+    float det = dot(v0v1, pvec);
+    if (fabsf(det) < FLT_EPSILON) return false;
+    float invDet = 1 / det;
+    F3 tvec = ray.o - v0;
+    float u = dot(tvec, pvec) * invDet;
+    if (u < 0 || u > 1) return false;
+    F3 qvec = cross(tvec, v0v1);
+    float v = dot(ray.d, qvec) * invDet;
+    if (v < 0 || (u + v) > 1) return false;
+    float w = 1.0f - u - v;
+    float t = dot(v0v2, qvec) * invDet;
+    if (t > ry || t < rx) return false;
+    if (STATS) cnt.hit_triangle++;
+    rec.p = (u * v1 + v * v2) + w * v0;
+    ry = t;
+    rec.t = t;
+    const uint32_t* ta = S.blob + S.off_triattr + (size_t)index * kTriAttrDwords;
+    const float4 q0 = ld4(ta), q1 = ld4(ta + 4), q2 = ld4(ta + 8), q3 = ld4(ta + 12);
+    const F3 n0 = f3(q0.x, q0.y, q0.z), n1 = f3(q0.w, q1.x, q1.y), n2 = f3(q1.z, q1.w, q2.x);
+    rec.gn = (u * n1 + v * n2) + w * n0;                    // unnormalised (B-5)
+    rec.uv.x = (u * q2.w + v * q3.y) + w * q2.y;            // uv0 = q2.yz, uv1 = q2.w q3.x, uv2 = q3.yz
+    rec.uv.y = (u * q3.x + v * q3.z) + w * q2.z;
+    check_face(rec, ray);
+    rec.material = 19;                                      // hard-coded, Triangle.hh:82
+    return true;
+}
+
+// ---------------------------------------------------------------- Scene::hit
+// `stack` is this lane's column of the workgroup stack (entry e at stack[e * kBlock]); `lvstack`
+// (STATS only) holds the level of the node that deferred each entry.
+template <bool STATS, bool ANY, bool EAGER_UV>
+TRC_DEV bool scene_hit(const SceneRef& S, const F3 root_min, const F3 root_max, const Ray& ray, HitRec& rec, const float test_t,
+                       uint32_t* stack, uint32_t* lvstack, TravCounters& cnt) {
+    if (STATS) cnt.rays++;
+    const float rx = FLT_MIN;
+    float ry = test_t;
+    if (!box_hit(root_min, root_max, ray, rx, ry))
+        return false;
+
+    uint32_t tag = kTagInterior << kTagIndexBits;   // root
+    uint32_t sp = 0;
+    int32_t level = 0;        // level of the interior node being expanded / parent level of a leaf
+    for (;;) {
+        int32_t ret_start;    // level at which the reference's first upward iteration would run
+        if ((tag >> kTagIndexBits) == kTagInterior) {
+            const uint32_t* np = S.small_base + S.off_nodes + (size_t)(tag & kTagIndexMask) * kNodeDwords;
+            const float4 q0 = ld4(np), q1 = ld4(np + 4), q2 = ld4(np + 8), q3 = ld4(np + 12);
+            if (STATS) cnt.n_descend++;
+            float t_left = ry, t_right = ry;
+            const bool left_test = box_hit_t(f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), ray, rx, ry, t_left);
+            const bool right_test = box_hit_t(f3(q1.z, q1.w, q2.x), f3(q2.y, q2.z, q2.w), ray, rx, ry, t_right);
+            if (left_test || right_test) {
+                const uint32_t tagL = __float_as_uint(q3.z), tagR = __float_as_uint(q3.w);
+                const bool left_first = t_left < t_right;            // Render.hh:174 (literal, also when only one hit)
+                const uint32_t first = left_first ? tagL : tagR;
+                if (left_test && right_test) {
+                    stack[sp * kBlock] = left_first ? tagR : tagL;    // Render.hh:171-172: visit the other one later
+                    if (STATS) lvstack[sp * kBlock] = (uint32_t)level;
+                    sp++;
+                }
+                tag = first;
+                if ((first >> kTagIndexBits) == kTagInterior) level += 1;
+                continue;
+            }
+            ret_start = level - 1;
+        } else {
+            const uint32_t type = tag >> kTagIndexBits, index = tag & kTagIndexMask;
+            bool ok;
+            if (type == 1u) {
+                if (STATS) cnt.leaf[1]++;
+                ok = square_hit_test(S, index, ray, rx, ry, rec);
+            } else if (type == 0u) {
+                if (STATS) cnt.leaf[0]++;
+                ok = sphere_hit_test<EAGER_UV>(S, index, ray, rx, ry, rec);
+            } else if (type == 2u) {
+                if (STATS) cnt.leaf[2]++;
+                ok = cube_hit_test<STATS>(S, index, ray, ry, rec, cnt);
+            } else {
+                if (STATS) cnt.leaf[3]++;
+                ok = triangle_hit_test<STATS>(S, index, ray, rx, ry, rec, cnt);
+            }
+            if (ok) rec.tag = tag;
+            if (ANY && ry < test_t) return true;                      // Render.hh:244
+            ret_start = level;
+        }
+        // pop the next deferred sibling
+        if (sp == 0) {
+            if (STATS) cnt.n_return += (uint32_t)(ret_start + 1);
+            break;
+        }
+        sp--;
+        tag = stack[sp * kBlock];
+        if (STATS) {
+            const int32_t ls = (int32_t)lvstack[sp * kBlock];
+            cnt.n_return += (uint32_t)(ret_start - ls + 1);
+            level = ls;
+        }
+        if ((tag >> kTagIndexBits) == kTagInterior) level += 1;       // (only meaningful under STATS)
+    }
+    return ry < test_t;
+}
+
+}  // namespace trcdev

@@ -1,0 +1,833 @@
+// trc_abi.hip -- kernels and the C ABI of libtracer_amd.so (gfx950 only).
+//
+// Replaces, for the path-tracing hot path, the reference's Metal host glue
+// (-[AAPLRenderer render:] AAPLRenderer.mm:1134-1196) and kernelPathTracing
+// (RT_Metal/Metal/Render.metal:495-558).  See include/tracer_abi.h for the boundary and
+// DESIGN.md for the data layout and kernel design.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "tracer_abi.h"
+#include "dev_integrator.hpp"
+
+using namespace trcdev;
+
+// ======================================================================= kernels
+extern __shared__ __attribute__((aligned(16))) uint32_t trc_smem[];
+
+struct KScene {
+    DScene sc;
+    float root_box[6];
+};
+
+struct KRender {
+    KScene ks;
+    DCamera cam;
+    float ambient[3];
+    DFrame fr;
+    uint32_t spp, max_depth, frame0, _pad;
+    const uint32_t* tiles;              // tx | ty << 16, one per workgroup
+    unsigned long long* stats;          // kStatCount counters
+};
+
+struct KTrace {
+    KScene ks;
+    const trc_ray* rays;
+    trc_hit* hits;
+    uint32_t n;
+};
+
+// cooperative copy of the small scene part into LDS; returns the base the accessors use
+template <bool LDS>
+__device__ __forceinline__ const uint32_t* stage_scene(const DScene& sc) {
+    if (LDS) {
+        const uint4* src = reinterpret_cast<const uint4*>(sc.blob);
+        uint4* dst = reinterpret_cast<uint4*>(trc_smem);
+        const uint32_t n16 = sc.small_dwords >> 2;
+        for (uint32_t i = threadIdx.x; i < n16; i += kBlock) dst[i] = src[i];
+        __syncthreads();
+        return trc_smem;
+    }
+    return sc.blob;
+}
+
+__device__ __forceinline__ SceneRef make_scene_ref(const DScene& sc, const uint32_t* small_base) {
+    SceneRef S;
+    S.small_base = small_base;
+    S.blob = sc.blob;
+    S.off_nodes = sc.off_nodes; S.off_spheres = sc.off_spheres; S.off_squares = sc.off_squares;
+    S.off_cubes = sc.off_cubes; S.off_materials = sc.off_materials;
+    S.off_tripos = sc.off_tripos; S.off_triattr = sc.off_triattr;
+    return S;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// deterministic stand-in for fillRNG (AAPLRenderer.mm:296-344): texel p = 4 outputs of
+// pcg32_srandom_r(seed, p)
+__global__ void __launch_bounds__(256) k_seed(uint32_t* rng, uint32_t n_pixels, uint64_t seed) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pixels) return;
+    Pcg r;
+    r.state = 0;
+    r.inc = ((uint64_t)p << 1u) | 1u;
+    pcg_next(r);
+    r.state += seed;
+    pcg_next(r);
+    uint4 out;
+    out.x = pcg_next(r); out.y = pcg_next(r); out.z = pcg_next(r); out.w = pcg_next(r);
+    reinterpret_cast<uint4*>(rng)[p] = out;
+}
+
+// kernelPathTracing, Render.metal:495-558.  One lane per pixel, one workgroup per 16x16 tile
+// (4 wavefronts of 8x8 pixels), all `spp` samples fused: RNG texel and accumulator are read and
+// written ONCE per pixel instead of once per sample (64 B/pixel/sample in the reference).
+template <bool LDS, bool STATS, int INTEGRATOR>
+__global__ void __launch_bounds__(kBlock) k_render(const KRender kp) {
+    const DScene& sc = kp.ks.sc;
+    const uint32_t* small_base = stage_scene<LDS>(sc);
+    uint32_t* stack_base = trc_smem + (LDS ? sc.small_dwords : 0u);
+    uint32_t* stack = stack_base + threadIdx.x;
+    uint32_t* lvstack = stack + sc.stack_depth * kBlock;
+
+    const uint32_t tile = kp.tiles[blockIdx.x];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t px = (tile & 0xFFFFu) * TRC_TILE + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t py = (tile >> 16) * TRC_TILE + (wave >> 1) * 8u + (lane >> 3);
+    const uint32_t W = kp.fr.width, H = kp.fr.height;
+    const bool active = px < W && py < H;
+
+    uint32_t n_rays = 0, n_shaded = 0, n_paths = 0;
+    TravCounters cnt;
+    counters_zero(cnt);
+
+    if (active) {
+        PathCtx cx;
+        cx.S = make_scene_ref(sc, small_base);
+        cx.root_min = f3(kp.ks.root_box[0], kp.ks.root_box[1], kp.ks.root_box[2]);
+        cx.root_max = f3(kp.ks.root_box[3], kp.ks.root_box[4], kp.ks.root_box[5]);
+        cx.sh.mats = small_base + sc.off_materials;
+        cx.ambient = f3(kp.ambient[0], kp.ambient[1], kp.ambient[2]);
+        cx.stack = stack;
+        cx.lvstack = lvstack;
+        cx.max_depth = kp.max_depth;
+
+        const size_t pix = (size_t)py * W + px;
+        uint4 texel = reinterpret_cast<const uint4*>(kp.fr.rng)[pix];       // r, g, b, a
+        float4 acc = reinterpret_cast<const float4*>(kp.fr.accum)[pix];
+        F3 cached = f3(acc.x, acc.y, acc.z);
+        const float u = (float)px / (float)W;                               // no sub-pixel jitter (B-2)
+        const float v = (float)py / (float)H;
+
+        for (uint32_t s = 0; s < kp.spp; ++s) {
+            // pcg32_t rng = { rng_inc, rng_state } aggregate-initialises {state, inc}: the two 64-bit
+            // words trade roles every frame (Render.metal:516-519,545-557, B-1)
+            Pcg rng;
+            rng.state = ((uint64_t)texel.z << 32) | texel.w;
+            rng.inc = ((uint64_t)texel.x << 32) | texel.y;
+            const uint32_t frame = kp.frame0 + s;
+            Ray ray = cast_ray(kp.cam, u, v, rng);
+            F3 color = (INTEGRATOR == TRC_INTEGRATOR_MIS) ? trace_mis<STATS>(cx, ray, rng, cnt, n_rays, n_shaded)
+                                                          : trace_path<STATS>(cx, ray, rng, cnt, n_rays, n_shaded);
+            const bool bad = is_inf(color.x) || is_nan(color.x) || is_inf(color.y) || is_nan(color.y) ||
+                             is_inf(color.z) || is_nan(color.z);
+            if (bad) color = f3(0);
+            cached = (cached * (float)frame + color) / (float)(frame + 1);  // running mean, :540-541
+            texel.y = (uint32_t)rng.state; texel.x = (uint32_t)(rng.state >> 32);
+            texel.w = (uint32_t)rng.inc;   texel.z = (uint32_t)(rng.inc >> 32);
+            n_paths++;
+        }
+        float4 out; out.x = cached.x; out.y = cached.y; out.z = cached.z; out.w = 1.0f;
+        reinterpret_cast<float4*>(kp.fr.accum)[pix] = out;
+        reinterpret_cast<uint4*>(kp.fr.rng)[pix] = texel;
+    }
+
+    // exact work counters: wave reduction, one 64-bit atomic per wave and counter
+    uint32_t r_paths = wave_sum(n_paths), r_rays = wave_sum(n_rays), r_shaded = wave_sum(n_shaded);
+    if (lane == 0) {
+        atomicAdd(&kp.stats[kStatPaths], (unsigned long long)r_paths);
+        atomicAdd(&kp.stats[kStatRays], (unsigned long long)r_rays);
+        atomicAdd(&kp.stats[kStatShaded], (unsigned long long)r_shaded);
+    }
+    if (STATS) {
+        uint32_t v[8] = {cnt.n_descend, cnt.n_return, cnt.leaf[0], cnt.leaf[1], cnt.leaf[2], cnt.leaf[3],
+                         cnt.hit_triangle, cnt.hit_cube};
+        const int slot[8] = {kStatDescend, kStatReturn, kStatLeafSphere, kStatLeafSquare, kStatLeafCube,
+                             kStatLeafTriangle, kStatHitTriangle, kStatHitCube};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uint32_t r = wave_sum(v[i]);
+            if (lane == 0) atomicAdd(&kp.stats[slot[i]], (unsigned long long)r);
+        }
+    }
+}
+
+// Scene::hit test hook: one lane per ray, full HitRecord + per-ray traversal counters
+template <bool LDS, bool ANY>
+__global__ void __launch_bounds__(kBlock) k_trace(const KTrace kp) {
+    const DScene& sc = kp.ks.sc;
+    const uint32_t* small_base = stage_scene<LDS>(sc);
+    uint32_t* stack = trc_smem + (LDS ? sc.small_dwords : 0u) + threadIdx.x;
+    uint32_t* lvstack = stack + sc.stack_depth * kBlock;
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= kp.n) return;
+    const trc_ray in = kp.rays[i];
+    SceneRef S = make_scene_ref(sc, small_base);
+    Ray ray = make_ray(f3(in.origin[0], in.origin[1], in.origin[2]), f3(in.direction[0], in.direction[1], in.direction[2]));
+    HitRec rec;
+    hit_init(rec);
+    TravCounters cnt;
+    counters_zero(cnt);
+    const bool h = scene_hit<true, ANY, true>(S, f3(kp.ks.root_box[0], kp.ks.root_box[1], kp.ks.root_box[2]),
+                                                 f3(kp.ks.root_box[3], kp.ks.root_box[4], kp.ks.root_box[5]), ray, rec, in.tmax, stack, lvstack, cnt);
+    trc_hit o;
+    memset(&o, 0, sizeof o);
+    o.hit = h ? 1 : 0;
+    o.pType = -1;
+    if (h) {
+        o.pType = (int32_t)(rec.tag >> kTagIndexBits);
+        o.pIndex = rec.tag & kTagIndexMask;
+        o.t = rec.t;
+        o.p[0] = rec.p.x; o.p[1] = rec.p.y; o.p[2] = rec.p.z;
+        o.gn[0] = rec.gn.x; o.gn[1] = rec.gn.y; o.gn[2] = rec.gn.z;
+        o.sn[0] = rec.sn.x; o.sn[1] = rec.sn.y; o.sn[2] = rec.sn.z;
+        o.uv[0] = rec.uv.x; o.uv[1] = rec.uv.y;
+        o.material = rec.material;
+        o.PDF = rec.PDF;
+    }
+    o.n_descend = cnt.n_descend;
+    o.n_return = cnt.n_return;
+    o.n_leaf = cnt.leaf[0] + cnt.leaf[1] + cnt.leaf[2] + cnt.leaf[3];
+    kp.hits[i] = o;
+}
+
+// ======================================================================= host side
+namespace {
+
+// RCCL entry points, resolved at run time so the library loads where RCCL is absent
+struct IdBlob { char internal[TRC_UNIQUE_ID_BYTES]; };   // ncclUniqueId, passed by value
+struct Rccl {
+    void* handle = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, IdBlob, int) = nullptr;
+    int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+
+bool load_rccl(Rccl& r, std::string& err) {
+    if (r.handle) return true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (r.handle) break;
+    }
+    if (!r.handle) { err = std::string("dlopen(librccl) failed: ") + dlerror(); return false; }
+    r.GetUniqueId = (int (*)(void*))dlsym(r.handle, "ncclGetUniqueId");
+    r.CommInitRank = (int (*)(void**, int, IdBlob, int))dlsym(r.handle, "ncclCommInitRank");
+    r.Reduce = (int (*)(const void*, void*, size_t, int, int, int, void*, hipStream_t))dlsym(r.handle, "ncclReduce");
+    r.CommDestroy = (int (*)(void*))dlsym(r.handle, "ncclCommDestroy");
+    r.GetErrorString = (const char* (*)(int))dlsym(r.handle, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.Reduce || !r.CommDestroy) { err = "librccl: missing symbols"; return false; }
+    return true;
+}
+Rccl g_rccl;
+
+}  // namespace
+
+struct trc_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    std::string error;
+
+    // scene
+    bool has_scene = false;
+    KScene ks{};
+    uint32_t* d_blob = nullptr;
+    size_t blob_bytes = 0;
+    bool lds_scene = false;
+
+    bool has_camera = false;
+    DCamera cam{};
+    float ambient[3] = {0, 0, 0};
+
+    // frame
+    uint32_t width = 0, height = 0;
+    uint32_t* d_rng = nullptr;
+    float* d_accum = nullptr;
+
+    // tiles for (nranks, rank)
+    uint32_t* d_tiles = nullptr;
+    uint32_t n_tiles = 0, tiles_nranks = 0, tiles_rank = 0;
+
+    // stats
+    unsigned long long* d_stats = nullptr;
+    uint64_t launches = 0;
+    double kernel_ms = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // per-launch event pairs not yet read
+    std::vector<hipEvent_t> event_pool;
+
+    // RCCL
+    void* comm = nullptr;
+    int nranks = 1, rank = 0;
+    float* d_reduce_recv = nullptr;
+};
+
+namespace {
+
+trc_status fail(trc_ctx* ctx, trc_status s, const std::string& msg) {
+    if (ctx) ctx->error = msg;
+    return s;
+}
+#define HIP_TRY(ctx, expr)                                                                 \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? TRC_ERR_OOM : TRC_ERR_HIP,         \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                \
+    } while (0)
+
+hipEvent_t get_event(trc_ctx* ctx) {
+    if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+// drains finished per-launch event pairs into kernel_ms (call after a stream sync)
+void collect_events(trc_ctx* ctx) {
+    for (auto& pr : ctx->pending) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) ctx->kernel_ms += ms;
+        ctx->event_pool.push_back(pr.first);
+        ctx->event_pool.push_back(pr.second);
+    }
+    ctx->pending.clear();
+}
+
+inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+
+// Repack the reference arrays into the device layout (dev_scene.hpp) and validate the tree.
+trc_status build_blob(trc_ctx* ctx, const trc_scene* s, std::vector<uint32_t>& blob, KScene& ks) {
+    if (!s || !s->bvhList || s->n_bvh < 3 || (s->n_bvh & 1u) == 0) return fail(ctx, TRC_ERR_INVALID_ARG, "scene: need >= 2 leaves (n_bvh odd, >= 3)");
+    if (!s->materials || s->n_material == 0) return fail(ctx, TRC_ERR_INVALID_ARG, "scene: no materials");
+    if (s->n_index % 3) return fail(ctx, TRC_ERR_INVALID_ARG, "scene: n_index not a multiple of 3");
+    const trc_BVH* nodes = s->bvhList;
+    const uint32_t n = s->n_bvh;
+    if (nodes[0].pType != TRC_PRIM_BVH) return fail(ctx, TRC_ERR_BVH_INVALID, "bvh: root is not an interior node");
+    const uint32_t n_tri = s->n_index / 3;
+
+    // BFS over interior nodes: compact ids, depth, validation
+    std::vector<uint32_t> interior_id(n, 0xFFFFFFFFu), order, depth_of(n, 0);
+    order.reserve(n / 2 + 1);
+    order.push_back(0);
+    interior_id[0] = 0;
+    uint32_t visited = 1, max_leaf_depth = 0;
+    for (size_t h = 0; h < order.size(); ++h) {
+        const uint32_t i = order[h];
+        const uint32_t kids[2] = {nodes[i].left, nodes[i].right};
+        if (kids[0] == kids[1]) return fail(ctx, TRC_ERR_BVH_INVALID, "bvh: left == right");
+        for (uint32_t c : kids) {
+            if (c == 0 || c >= n) return fail(ctx, TRC_ERR_BVH_INVALID, "bvh: child index out of range");
+            if (++visited > n) return fail(ctx, TRC_ERR_BVH_INVALID, "bvh: cycle");
+            depth_of[c] = depth_of[i] + 1;
+            const int32_t t = nodes[c].pType;
+            if (t == TRC_PRIM_BVH) {
+                if (interior_id[c] != 0xFFFFFFFFu) return fail(ctx, TRC_ERR_BVH_INVALID, "bvh: node reached twice");
+                interior_id[c] = (uint32_t)order.size();
+                order.push_back(c);
+            } else {
+                max_leaf_depth = std::max(max_leaf_depth, depth_of[c]);
+                const uint32_t pi = nodes[c].pIndex;
+                const uint32_t limit = t == TRC_PRIM_SPHERE ? s->n_sphere : t == TRC_PRIM_SQUARE ? s->n_square
+                                     : t == TRC_PRIM_CUBE ? s->n_cube : t == TRC_PRIM_TRIANGLE ? n_tri : 0;
+                if (t < 0 || t > TRC_PRIM_TRIANGLE || pi >= limit)
+                    return fail(ctx, TRC_ERR_BVH_INVALID, "bvh: leaf with bad primitive type/index");
+                if (pi > kTagIndexMask) return fail(ctx, TRC_ERR_UNSUPPORTED, "bvh: primitive index exceeds 29 bits");
+            }
+        }
+    }
+    if (visited != n) return fail(ctx, TRC_ERR_BVH_INVALID, "bvh: unreachable nodes");
+    if (max_leaf_depth > TRC_MAX_BVH_DEPTH) return fail(ctx, TRC_ERR_BVH_INVALID, "bvh: deeper than TRC_MAX_BVH_DEPTH");
+    for (uint32_t t = 0; t < s->n_index; ++t)
+        if (s->idxList[t] >= s->n_vertex) return fail(ctx, TRC_ERR_INVALID_ARG, "scene: triangle index out of range");
+    // materials referenced by primitives
+    auto bad_mat = [&](uint32_t m) { return m >= s->n_material; };
+    for (uint32_t i = 0; i < s->n_sphere; ++i) if (bad_mat(s->sphereList[i].material)) return fail(ctx, TRC_ERR_INVALID_ARG, "sphere material out of range");
+    for (uint32_t i = 0; i < s->n_square; ++i) if (bad_mat(s->squareList[i].material)) return fail(ctx, TRC_ERR_INVALID_ARG, "square material out of range");
+    for (uint32_t i = 0; i < s->n_cube; ++i) if (bad_mat(s->cubeList[i].material)) return fail(ctx, TRC_ERR_INVALID_ARG, "cube material out of range");
+    if (n_tri && s->n_material <= 19) return fail(ctx, TRC_ERR_INVALID_ARG, "triangles use material 19 (Triangle.hh:82): need >= 20 materials");
+
+    const uint32_t n_interior = (uint32_t)order.size();
+    DScene sc{};
+    auto align4 = [](uint32_t v) { return (v + 3u) & ~3u; };
+    sc.off_nodes = 0;
+    sc.off_spheres = align4(sc.off_nodes + n_interior * kNodeDwords);
+    sc.off_squares = align4(sc.off_spheres + s->n_sphere * kSphereDwords);
+    sc.off_cubes = align4(sc.off_squares + s->n_square * kSquareDwords);
+    sc.off_materials = align4(sc.off_cubes + s->n_cube * kCubeDwords);
+    sc.small_dwords = align4(sc.off_materials + s->n_material * kMaterialDwords);
+    sc.off_tripos = sc.small_dwords;
+    const uint64_t total = (uint64_t)sc.off_tripos + (uint64_t)n_tri * kTriPosDwords + (uint64_t)n_tri * kTriAttrDwords;
+    if (total > 0xFFFFFFF0ull) return fail(ctx, TRC_ERR_UNSUPPORTED, "scene too large for 32-bit dword offsets");
+    sc.off_triattr = sc.off_tripos + n_tri * kTriPosDwords;
+    sc.n_nodes = n_interior; sc.n_spheres = s->n_sphere; sc.n_squares = s->n_square; sc.n_cubes = s->n_cube;
+    sc.n_materials = s->n_material; sc.n_triangles = n_tri;
+    sc.stack_depth = std::max(1u, max_leaf_depth);
+    blob.assign((size_t)total, 0u);
+
+    auto tag_of = [&](uint32_t c) -> uint32_t {
+        if (nodes[c].pType == TRC_PRIM_BVH) return (kTagInterior << kTagIndexBits) | interior_id[c];
+        return ((uint32_t)nodes[c].pType << kTagIndexBits) | nodes[c].pIndex;
+    };
+    for (uint32_t k = 0; k < n_interior; ++k) {
+        const trc_BVH& nd = nodes[order[k]];
+        const trc_AABB& L = nodes[nd.left].bBOX;
+        const trc_AABB& R = nodes[nd.right].bBOX;
+        uint32_t* q = &blob[sc.off_nodes + (size_t)k * kNodeDwords];
+        q[0] = f2u(L.mini.x); q[1] = f2u(L.mini.y); q[2] = f2u(L.mini.z); q[3] = f2u(L.maxi.x);
+        q[4] = f2u(L.maxi.y); q[5] = f2u(L.maxi.z); q[6] = f2u(R.mini.x); q[7] = f2u(R.mini.y);
+        q[8] = f2u(R.mini.z); q[9] = f2u(R.maxi.x); q[10] = f2u(R.maxi.y); q[11] = f2u(R.maxi.z);
+        q[12] = 0; q[13] = 0; q[14] = tag_of(nd.left); q[15] = tag_of(nd.right);
+    }
+    for (uint32_t i = 0; i < s->n_sphere; ++i) {
+        const trc_Sphere& sp = s->sphereList[i];
+        uint32_t* q = &blob[sc.off_spheres + (size_t)i * kSphereDwords];
+        q[0] = f2u(sp.center.x); q[1] = f2u(sp.center.y); q[2] = f2u(sp.center.z); q[3] = f2u(sp.radius);
+        q[4] = sp.material;
+    }
+    for (uint32_t i = 0; i < s->n_square; ++i) {
+        const trc_Square& sq = s->squareList[i];
+        if (sq.axis_i > 2 || sq.axis_j > 2 || sq.axis_k > 2) return fail(ctx, TRC_ERR_INVALID_ARG, "square axis out of range");
+        uint32_t* q = &blob[sc.off_squares + (size_t)i * kSquareDwords];
+        q[0] = f2u(sq.range_i.x); q[1] = f2u(sq.range_i.y); q[2] = f2u(sq.range_j.x); q[3] = f2u(sq.range_j.y);
+        // Square::area() = 2*i*j and aeraPDF() = 1/area (Square.hh:31-38), evaluated once here in binary32
+        const float di = sq.range_i.y - sq.range_i.x, dj = sq.range_j.y - sq.range_j.x;
+        const float area = 2 * di * dj;
+        const float pdf = 1 / area;
+        q[4] = f2u(sq.value_k); q[5] = f2u(pdf);
+        q[6] = (uint32_t)sq.axis_i | ((uint32_t)sq.axis_j << 2) | ((uint32_t)sq.axis_k << 4);
+        q[7] = sq.material;
+    }
+    for (uint32_t i = 0; i < s->n_cube; ++i) {
+        const trc_Cube& cb = s->cubeList[i];
+        uint32_t* q = &blob[sc.off_cubes + (size_t)i * kCubeDwords];
+        auto put_cols = [&](uint32_t* dst, const trc_float4x4& m, int ncols) {
+            for (int c = 0; c < ncols; ++c) { dst[3 * c] = f2u(m.columns[c].x); dst[3 * c + 1] = f2u(m.columns[c].y); dst[3 * c + 2] = f2u(m.columns[c].z); }
+        };
+        put_cols(q, cb.inverse_matrix, 4);
+        put_cols(q + 12, cb.model_matrix, 4);
+        put_cols(q + 24, cb.normal_matrix, 3);
+        q[33] = f2u(cb.box.mini.x); q[34] = f2u(cb.box.mini.y); q[35] = f2u(cb.box.mini.z);
+        q[36] = f2u(cb.box.maxi.x); q[37] = f2u(cb.box.maxi.y); q[38] = f2u(cb.box.maxi.z);
+        q[39] = cb.material;
+    }
+    for (uint32_t i = 0; i < s->n_material; ++i) {
+        const trc_Material& m = s->materials[i];
+        uint32_t* q = &blob[sc.off_materials + (size_t)i * kMaterialDwords];
+        q[0] = (uint32_t)m.type; q[1] = (uint32_t)m.textureInfo.type;
+        q[2] = f2u(m.textureInfo.albedo.x); q[3] = f2u(m.textureInfo.albedo.y); q[4] = f2u(m.textureInfo.albedo.z);
+    }
+    for (uint32_t t = 0; t < n_tri; ++t) {
+        const trc_TriangleVertex* v[3] = {&s->triList[s->idxList[3 * t]], &s->triList[s->idxList[3 * t + 1]],
+                                          &s->triList[s->idxList[3 * t + 2]]};
+        uint32_t* p = &blob[sc.off_tripos + (size_t)t * kTriPosDwords];
+        uint32_t* a = &blob[sc.off_triattr + (size_t)t * kTriAttrDwords];
+        for (int k = 0; k < 3; ++k) {
+            p[4 * k] = f2u(v[k]->v[0]); p[4 * k + 1] = f2u(v[k]->v[1]); p[4 * k + 2] = f2u(v[k]->v[2]);
+            a[3 * k] = f2u(v[k]->n[0]); a[3 * k + 1] = f2u(v[k]->n[1]); a[3 * k + 2] = f2u(v[k]->n[2]);
+            a[9 + 2 * k] = f2u(v[k]->uv[0]); a[10 + 2 * k] = f2u(v[k]->uv[1]);
+        }
+    }
+    ks.sc = sc;
+    const trc_AABB& rb = nodes[0].bBOX;
+    ks.root_box[0] = rb.mini.x; ks.root_box[1] = rb.mini.y; ks.root_box[2] = rb.mini.z;
+    ks.root_box[3] = rb.maxi.x; ks.root_box[4] = rb.maxi.y; ks.root_box[5] = rb.maxi.z;
+    return TRC_OK;
+}
+
+// tiles owned by `rank` of `nranks`, ordered so that the workgroups one XCD receives
+// (blockIdx % 8 under round-robin dispatch) cover a contiguous image region
+std::vector<uint32_t> make_tiles(uint32_t W, uint32_t H, uint32_t nranks, uint32_t rank) {
+    const uint32_t tw = (W + TRC_TILE - 1) / TRC_TILE, th = (H + TRC_TILE - 1) / TRC_TILE;
+    std::vector<uint32_t> mine;
+    for (uint32_t ty = 0; ty < th; ++ty)
+        for (uint32_t tx = 0; tx < tw; ++tx)
+            if ((tx + ty) % nranks == rank) mine.push_back(tx | (ty << 16));
+    const uint32_t n = (uint32_t)mine.size(), chunk = (n + 7) / 8;
+    std::vector<uint32_t> out;
+    out.reserve(n);
+    for (uint32_t j = 0; j < chunk; ++j)
+        for (uint32_t x = 0; x < 8; ++x) {
+            const uint32_t idx = x * chunk + j;
+            if (idx < n) out.push_back(mine[idx]);
+        }
+    return out;
+}
+
+size_t dyn_lds_bytes(const trc_ctx* ctx, bool stats) {
+    const DScene& sc = ctx->ks.sc;
+    size_t dwords = (ctx->lds_scene ? sc.small_dwords : 0u) + (size_t)sc.stack_depth * kBlock * (stats ? 2u : 1u);
+    return dwords * 4;
+}
+
+template <bool LDS>
+void launch_render(trc_ctx* ctx, const KRender& kp, bool stats, uint32_t integrator, size_t lds) {
+    dim3 grid(ctx->n_tiles), block(kBlock);
+    if (integrator == TRC_INTEGRATOR_MIS) {
+        if (stats) hipLaunchKernelGGL((k_render<LDS, true, TRC_INTEGRATOR_MIS>), grid, block, lds, ctx->stream, kp);
+        else hipLaunchKernelGGL((k_render<LDS, false, TRC_INTEGRATOR_MIS>), grid, block, lds, ctx->stream, kp);
+    } else {
+        if (stats) hipLaunchKernelGGL((k_render<LDS, true, TRC_INTEGRATOR_PATH>), grid, block, lds, ctx->stream, kp);
+        else hipLaunchKernelGGL((k_render<LDS, false, TRC_INTEGRATOR_PATH>), grid, block, lds, ctx->stream, kp);
+    }
+}
+
+}  // namespace
+
+// ======================================================================= C ABI
+extern "C" {
+
+uint32_t trc_abi_version(void) { return TRC_ABI_VERSION; }
+
+const char* trc_status_string(trc_status s) {
+    switch (s) {
+        case TRC_OK: return "ok";
+        case TRC_ERR_INVALID_ARG: return "invalid argument";
+        case TRC_ERR_NO_DEVICE: return "no usable HIP device";
+        case TRC_ERR_HIP: return "HIP runtime error";
+        case TRC_ERR_NO_SCENE: return "no scene uploaded";
+        case TRC_ERR_NO_FRAME: return "no frame allocated (trc_resize)";
+        case TRC_ERR_BVH_INVALID: return "invalid BVH";
+        case TRC_ERR_UNSUPPORTED: return "unsupported";
+        case TRC_ERR_RCCL: return "RCCL error";
+        case TRC_ERR_OOM: return "out of memory";
+        default: return "unknown status";
+    }
+}
+
+const char* trc_last_error(const trc_ctx* ctx) { return ctx ? ctx->error.c_str() : "null context"; }
+
+trc_status trc_create(int device, trc_ctx** out) {
+    if (!out) return TRC_ERR_INVALID_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return TRC_ERR_NO_DEVICE;
+    if (device < 0 || device >= count) return TRC_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return TRC_ERR_NO_DEVICE;
+    trc_ctx* ctx = new (std::nothrow) trc_ctx();
+    if (!ctx) return TRC_ERR_OOM;
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_stats, sizeof(unsigned long long) * kStatCount) != hipSuccess ||
+        hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * kStatCount, ctx->stream) != hipSuccess) {
+        trc_destroy(ctx);
+        return TRC_ERR_HIP;
+    }
+    *out = ctx;
+    return TRC_OK;
+}
+
+void trc_destroy(trc_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
+    collect_events(ctx);
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    (void)hipFree(ctx->d_blob); (void)hipFree(ctx->d_rng); (void)hipFree(ctx->d_accum);
+    (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_stats); (void)hipFree(ctx->d_reduce_recv);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+trc_status trc_upload_scene(trc_ctx* ctx, const trc_scene* scene) {
+    if (!ctx) return TRC_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<uint32_t> blob;
+    KScene ks{};
+    trc_status st = build_blob(ctx, scene, blob, ks);
+    if (st != TRC_OK) return st;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_blob) { (void)hipFree(ctx->d_blob); ctx->d_blob = nullptr; }
+    ctx->has_scene = false;
+    ctx->blob_bytes = blob.size() * 4;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_blob, ctx->blob_bytes));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_blob, blob.data(), ctx->blob_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ks.sc.blob = ctx->d_blob;
+    ctx->ks = ks;
+    // whole small part + both stacks of the instrumented kernel must fit the LDS budget
+    const size_t small_bytes = (size_t)ks.sc.small_dwords * 4;
+    ctx->lds_scene = small_bytes <= kLdsSceneBytes;
+    ctx->has_scene = true;
+    return TRC_OK;
+}
+
+trc_status trc_set_camera(trc_ctx* ctx, const trc_Camera* c) {
+    if (!ctx || !c) return TRC_ERR_INVALID_ARG;
+    DCamera& d = ctx->cam;
+    const trc_float3* src[6] = {&c->lookFrom, &c->u, &c->v, &c->vertical, &c->horizontal, &c->cornerLowLeft};
+    float* dst[6] = {d.lookFrom, d.u, d.v, d.vertical, d.horizontal, d.cornerLowLeft};
+    for (int i = 0; i < 6; ++i) { dst[i][0] = src[i]->x; dst[i][1] = src[i]->y; dst[i][2] = src[i]->z; }
+    d.lenRadius = c->lenRadius;
+    ctx->has_camera = true;
+    return TRC_OK;
+}
+
+trc_status trc_set_environment(trc_ctx* ctx, const float rgb[3]) {
+    if (!ctx || !rgb) return TRC_ERR_INVALID_ARG;
+    ctx->ambient[0] = rgb[0]; ctx->ambient[1] = rgb[1]; ctx->ambient[2] = rgb[2];
+    return TRC_OK;
+}
+
+trc_status trc_resize(trc_ctx* ctx, uint32_t width, uint32_t height) {
+    if (!ctx || width == 0 || height == 0 || width > 65535u * TRC_TILE || height > 65535u * TRC_TILE) return TRC_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(ctx->d_rng); (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_reduce_recv);
+    ctx->d_rng = nullptr; ctx->d_accum = nullptr; ctx->d_tiles = nullptr; ctx->d_reduce_recv = nullptr;
+    ctx->n_tiles = 0; ctx->tiles_nranks = 0;
+    ctx->width = ctx->height = 0;
+    const size_t n = (size_t)width * height;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_rng, n * 16));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_accum, n * 16));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_rng, 0, n * 16, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_accum, 0, n * 16, ctx->stream));
+    ctx->width = width; ctx->height = height;
+    return TRC_OK;
+}
+
+trc_status trc_seed(trc_ctx* ctx, uint64_t seed) {
+    if (!ctx) return TRC_ERR_INVALID_ARG;
+    if (!ctx->d_rng) return fail(ctx, TRC_ERR_NO_FRAME, "trc_seed before trc_resize");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = ctx->width * ctx->height;
+    hipLaunchKernelGGL(k_seed, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_rng, n, seed);
+    HIP_TRY(ctx, hipGetLastError());
+    return TRC_OK;
+}
+
+static trc_status copy_frame(trc_ctx* ctx, void* dev, void* host, bool to_device) {
+    if (!ctx || !host) return TRC_ERR_INVALID_ARG;
+    if (!dev) return fail(ctx, TRC_ERR_NO_FRAME, "frame buffers not allocated (trc_resize)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)ctx->width * ctx->height * 16;
+    if (to_device) HIP_TRY(ctx, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    else HIP_TRY(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TRC_OK;
+}
+trc_status trc_upload_rng(trc_ctx* ctx, const uint32_t* rgba) { return copy_frame(ctx, ctx ? ctx->d_rng : nullptr, (void*)rgba, true); }
+trc_status trc_download_rng(trc_ctx* ctx, uint32_t* rgba) { return copy_frame(ctx, ctx ? ctx->d_rng : nullptr, rgba, false); }
+trc_status trc_upload_accum(trc_ctx* ctx, const float* rgba) { return copy_frame(ctx, ctx ? ctx->d_accum : nullptr, (void*)rgba, true); }
+trc_status trc_download_accum(trc_ctx* ctx, float* rgba) { return copy_frame(ctx, ctx ? ctx->d_accum : nullptr, rgba, false); }
+
+trc_status trc_clear_accum(trc_ctx* ctx) {
+    if (!ctx) return TRC_ERR_INVALID_ARG;
+    if (!ctx->d_accum) return fail(ctx, TRC_ERR_NO_FRAME, "trc_clear_accum before trc_resize");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_accum, 0, (size_t)ctx->width * ctx->height * 16, ctx->stream));
+    return TRC_OK;
+}
+
+trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
+    if (!ctx || !p) return TRC_ERR_INVALID_ARG;
+    if (!ctx->has_scene) return fail(ctx, TRC_ERR_NO_SCENE, "trc_render before trc_upload_scene");
+    if (!ctx->d_accum) return fail(ctx, TRC_ERR_NO_FRAME, "trc_render before trc_resize");
+    if (!ctx->has_camera) return fail(ctx, TRC_ERR_INVALID_ARG, "trc_render before trc_set_camera");
+    const uint32_t nranks = p->tile_nranks ? p->tile_nranks : 1;
+    if (p->tile_rank >= nranks) return fail(ctx, TRC_ERR_INVALID_ARG, "tile_rank >= tile_nranks");
+    if (p->integrator > TRC_INTEGRATOR_MIS) return fail(ctx, TRC_ERR_INVALID_ARG, "unknown integrator");
+    if (p->integrator == TRC_INTEGRATOR_MIS && ctx->ks.sc.n_squares < 7)
+        return fail(ctx, TRC_ERR_INVALID_ARG, "traceMIS samples squareList[5] and [6] (Render.metal:320-324)");
+    if (p->spp == 0) return TRC_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    if (!ctx->d_tiles || ctx->tiles_nranks != nranks || ctx->tiles_rank != p->tile_rank) {
+        std::vector<uint32_t> tiles = make_tiles(ctx->width, ctx->height, nranks, p->tile_rank);
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_tiles); ctx->d_tiles = nullptr;
+        ctx->n_tiles = (uint32_t)tiles.size();
+        if (ctx->n_tiles) {
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tiles, tiles.size() * 4));
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->d_tiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        ctx->tiles_nranks = nranks; ctx->tiles_rank = p->tile_rank;
+    }
+    if (ctx->n_tiles == 0) return TRC_OK;
+
+    const bool stats = (p->flags & TRC_FLAG_COLLECT_STATS) != 0;
+    const size_t lds = dyn_lds_bytes(ctx, stats);
+    if (lds > 160 * 1024) return fail(ctx, TRC_ERR_UNSUPPORTED, "traversal stack exceeds the 160 KB LDS of a CU");
+
+    KRender kp{};
+    kp.ks = ctx->ks;
+    kp.cam = ctx->cam;
+    kp.ambient[0] = ctx->ambient[0]; kp.ambient[1] = ctx->ambient[1]; kp.ambient[2] = ctx->ambient[2];
+    kp.fr.rng = ctx->d_rng; kp.fr.accum = ctx->d_accum; kp.fr.width = ctx->width; kp.fr.height = ctx->height;
+    kp.spp = p->spp; kp.max_depth = p->max_depth; kp.frame0 = p->frame0;
+    kp.tiles = ctx->d_tiles;
+    kp.stats = ctx->d_stats;
+
+    hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);
+    if (!e0 || !e1) return fail(ctx, TRC_ERR_HIP, "hipEventCreate failed");
+    HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+    if (ctx->lds_scene) launch_render<true>(ctx, kp, stats, p->integrator, lds);
+    else launch_render<false>(ctx, kp, stats, p->integrator, lds);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+    ctx->pending.emplace_back(e0, e1);
+    ctx->launches++;
+    return TRC_OK;
+}
+
+trc_status trc_synchronize(trc_ctx* ctx) {
+    if (!ctx) return TRC_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    collect_events(ctx);
+    return TRC_OK;
+}
+
+trc_status trc_trace_rays(trc_ctx* ctx, const trc_ray* rays, size_t n, trc_hit* out, int any_hit) {
+    if (!ctx || (n && (!rays || !out))) return TRC_ERR_INVALID_ARG;
+    if (!ctx->has_scene) return fail(ctx, TRC_ERR_NO_SCENE, "trc_trace_rays before trc_upload_scene");
+    if (n == 0) return TRC_OK;
+    if (n > 0x7FFFFFFFu) return fail(ctx, TRC_ERR_INVALID_ARG, "too many rays in one call");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    trc_ray* d_rays = nullptr; trc_hit* d_hits = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d_rays, n * sizeof(trc_ray)));
+    if (hipMalloc((void**)&d_hits, n * sizeof(trc_hit)) != hipSuccess) { (void)hipFree(d_rays); return fail(ctx, TRC_ERR_OOM, "hipMalloc hits"); }
+    trc_status st = TRC_OK;
+    do {
+        if (hipMemcpyAsync(d_rays, rays, n * sizeof(trc_ray), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { st = fail(ctx, TRC_ERR_HIP, "H2D rays"); break; }
+        KTrace kp{};
+        kp.ks = ctx->ks; kp.rays = d_rays; kp.hits = d_hits; kp.n = (uint32_t)n;
+        const size_t lds = dyn_lds_bytes(ctx, true);
+        dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+        if (ctx->lds_scene) {
+            if (any_hit) hipLaunchKernelGGL((k_trace<true, true>), grid, block, lds, ctx->stream, kp);
+            else hipLaunchKernelGGL((k_trace<true, false>), grid, block, lds, ctx->stream, kp);
+        } else {
+            if (any_hit) hipLaunchKernelGGL((k_trace<false, true>), grid, block, lds, ctx->stream, kp);
+            else hipLaunchKernelGGL((k_trace<false, false>), grid, block, lds, ctx->stream, kp);
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { st = fail(ctx, TRC_ERR_HIP, std::string("k_trace launch: ") + hipGetErrorString(e)); break; }
+        if (hipMemcpyAsync(out, d_hits, n * sizeof(trc_hit), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { st = fail(ctx, TRC_ERR_HIP, "D2H hits"); break; }
+        e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { st = fail(ctx, TRC_ERR_HIP, std::string("k_trace: ") + hipGetErrorString(e)); break; }
+    } while (0);
+    (void)hipFree(d_rays); (void)hipFree(d_hits);
+    return st;
+}
+
+trc_status trc_get_stats(trc_ctx* ctx, trc_stats* out) {
+    if (!ctx || !out) return TRC_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    unsigned long long h[kStatCount];
+    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    collect_events(ctx);
+    std::memset(out, 0, sizeof *out);
+    out->paths = h[kStatPaths]; out->rays = h[kStatRays]; out->shaded = h[kStatShaded];
+    out->n_descend = h[kStatDescend]; out->n_return = h[kStatReturn];
+    out->n_leaf_sphere = h[kStatLeafSphere]; out->n_leaf_square = h[kStatLeafSquare];
+    out->n_leaf_cube = h[kStatLeafCube]; out->n_leaf_triangle = h[kStatLeafTriangle];
+    out->n_hit_triangle = h[kStatHitTriangle]; out->n_hit_cube = h[kStatHitCube];
+    out->launches = ctx->launches;
+    out->kernel_ms = ctx->kernel_ms;
+    return TRC_OK;
+}
+
+trc_status trc_reset_stats(trc_ctx* ctx) {
+    if (!ctx) return TRC_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    collect_events(ctx);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * kStatCount, ctx->stream));
+    ctx->launches = 0;
+    ctx->kernel_ms = 0.0;
+    return TRC_OK;
+}
+
+trc_status trc_device_info(trc_ctx* ctx, char* name, size_t name_len, int* cu_count, size_t* hbm_bytes) {
+    if (!ctx) return TRC_ERR_INVALID_ARG;
+    hipDeviceProp_t prop;
+    HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    if (name && name_len) { std::snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName); }
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    return TRC_OK;
+}
+
+// ----------------------------------------------------------------------- multi-GPU (RCCL over xGMI)
+trc_status trc_group_unique_id(uint8_t id[TRC_UNIQUE_ID_BYTES]) {
+    if (!id) return TRC_ERR_INVALID_ARG;
+    std::string err;
+    if (!load_rccl(g_rccl, err)) return TRC_ERR_RCCL;
+    IdBlob blob;
+    std::memset(&blob, 0, sizeof blob);
+    if (g_rccl.GetUniqueId(&blob) != 0) return TRC_ERR_RCCL;
+    std::memcpy(id, &blob, TRC_UNIQUE_ID_BYTES);
+    return TRC_OK;
+}
+
+trc_status trc_group_init(trc_ctx* ctx, const uint8_t id[TRC_UNIQUE_ID_BYTES], int nranks, int rank) {
+    if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return TRC_ERR_INVALID_ARG;
+    std::string err;
+    if (!load_rccl(g_rccl, err)) return fail(ctx, TRC_ERR_RCCL, err);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->comm) { g_rccl.CommDestroy(ctx->comm); ctx->comm = nullptr; }
+    IdBlob blob;
+    std::memcpy(&blob, id, TRC_UNIQUE_ID_BYTES);
+    int rc = g_rccl.CommInitRank(&ctx->comm, nranks, blob, rank);
+    if (rc != 0) {
+        ctx->comm = nullptr;
+        return fail(ctx, TRC_ERR_RCCL, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
+    }
+    ctx->nranks = nranks; ctx->rank = rank;
+    return TRC_OK;
+}
+
+trc_status trc_group_reduce_accum(trc_ctx* ctx, int root) {
+    if (!ctx) return TRC_ERR_INVALID_ARG;
+    if (!ctx->comm) return fail(ctx, TRC_ERR_RCCL, "trc_group_reduce_accum before trc_group_init");
+    if (!ctx->d_accum) return fail(ctx, TRC_ERR_NO_FRAME, "no frame");
+    if (root < 0 || root >= ctx->nranks) return TRC_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t count = (size_t)ctx->width * ctx->height * 4;
+    // ncclFloat = 7, ncclSum = 0; in place on the root (sendbuff == recvbuff is allowed)
+    int rc = g_rccl.Reduce(ctx->d_accum, ctx->d_accum, count, 7, 0, root, ctx->comm, ctx->stream);
+    if (rc != 0) return fail(ctx, TRC_ERR_RCCL, std::string("ncclReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
+    return TRC_OK;
+}
+
+trc_status trc_group_finalize(trc_ctx* ctx) {
+    if (!ctx) return TRC_ERR_INVALID_ARG;
+    if (ctx->comm) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        g_rccl.CommDestroy(ctx->comm);
+        ctx->comm = nullptr;
+    }
+    ctx->nranks = 1; ctx->rank = 0;
+    return TRC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,190 @@
+"""Device side: the HIP path tracer behind the C ABI (libtracer_amd.so, gfx950).
+
+`Tracer` plays the role of the reference's AAPLRenderer for the path-tracing path
+(RT_Metal/Tracer/AAPLRenderer.hh:7-14: init / render); every method is one trc_* call of
+include/tracer_abi.h.  There is NO CPU fallback: a missing library or a missing GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_LIB = None
+
+
+class TracerError(RuntimeError):
+    def __init__(self, what, status, detail=""):
+        super().__init__(f"{what}: trc_status {status}" + (f" ({detail})" if detail else ""))
+        self.status = status
+
+
+def lib_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtracer_amd.so")
+
+
+def lib():
+    """Load libtracer_amd.so (fails loudly when the HIP extension has not been built)."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: the HIP extension is not built "
+                               f"(run `make hip` or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(path)
+        vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
+        L.trc_abi_version.restype = u32
+        L.trc_status_string.argtypes = [i32]
+        L.trc_status_string.restype = C.c_char_p
+        L.trc_last_error.argtypes = [vp]
+        L.trc_last_error.restype = C.c_char_p
+        L.trc_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.trc_destroy.argtypes = [vp]
+        L.trc_destroy.restype = None
+        L.trc_upload_scene.argtypes = [vp, C.POINTER(abi.Scene)]
+        L.trc_set_camera.argtypes = [vp, C.POINTER(abi.Camera)]
+        L.trc_set_environment.argtypes = [vp, C.POINTER(C.c_float)]
+        L.trc_resize.argtypes = [vp, u32, u32]
+        L.trc_seed.argtypes = [vp, u64]
+        for name in ("trc_upload_rng", "trc_download_rng", "trc_upload_accum", "trc_download_accum"):
+            getattr(L, name).argtypes = [vp, vp]
+        L.trc_clear_accum.argtypes = [vp]
+        L.trc_render.argtypes = [vp, C.POINTER(abi.Params)]
+        L.trc_synchronize.argtypes = [vp]
+        L.trc_trace_rays.argtypes = [vp, vp, C.c_size_t, vp, C.c_int]
+        L.trc_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
+        L.trc_reset_stats.argtypes = [vp]
+        L.trc_device_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
+        L.trc_group_unique_id.argtypes = [C.POINTER(C.c_uint8)]
+        L.trc_group_init.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int, C.c_int]
+        L.trc_group_reduce_accum.argtypes = [vp, C.c_int]
+        L.trc_group_finalize.argtypes = [vp]
+        for name in abi.DEVICE_SYMBOLS:
+            f = getattr(L, name)
+            if name not in ("trc_abi_version", "trc_status_string", "trc_last_error", "trc_destroy"):
+                f.restype = i32
+        if L.trc_abi_version() != abi.TRC_ABI_VERSION:
+            raise RuntimeError("libtracer_amd.so ABI version mismatch")
+        _LIB = L
+    return _LIB
+
+
+def group_unique_id():
+    buf = (C.c_uint8 * abi.TRC_UNIQUE_ID_BYTES)()
+    st = lib().trc_group_unique_id(buf)
+    if st != abi.OK:
+        raise TracerError("trc_group_unique_id", st)
+    return bytes(buf)
+
+
+class Tracer:
+    """One context per GPU (single-threaded, one HIP stream)."""
+
+    def __init__(self, device=0):
+        self._L = lib()
+        self._h = C.c_void_p()
+        st = self._L.trc_create(device, C.byref(self._h))
+        if st != abi.OK:
+            self._h = None
+            raise TracerError(f"trc_create(device={device})", st, self._L.trc_status_string(st).decode())
+        self.width = self.height = 0
+
+    def _check(self, st, what):
+        if st != abi.OK:
+            raise TracerError(what, st, self._L.trc_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.trc_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # --- scene / camera / frame -------------------------------------------------
+    def upload_scene(self, scene_view):
+        self._check(self._L.trc_upload_scene(self._h, C.byref(scene_view)), "trc_upload_scene")
+
+    def set_camera(self, camera):
+        self._check(self._L.trc_set_camera(self._h, C.byref(camera)), "trc_set_camera")
+
+    def set_environment(self, rgb):
+        self._check(self._L.trc_set_environment(self._h, (C.c_float * 3)(*rgb)), "trc_set_environment")
+
+    def resize(self, width, height):
+        self._check(self._L.trc_resize(self._h, width, height), "trc_resize")
+        self.width, self.height = width, height
+
+    def seed(self, seed):
+        self._check(self._L.trc_seed(self._h, seed), "trc_seed")
+
+    def upload_rng(self, rng):
+        assert rng.dtype == np.uint32 and rng.shape == (self.height, self.width, 4) and rng.flags.c_contiguous
+        self._check(self._L.trc_upload_rng(self._h, rng.ctypes.data), "trc_upload_rng")
+
+    def download_rng(self):
+        out = np.empty((self.height, self.width, 4), dtype=np.uint32)
+        self._check(self._L.trc_download_rng(self._h, out.ctypes.data), "trc_download_rng")
+        return out
+
+    def upload_accum(self, accum):
+        assert accum.dtype == np.float32 and accum.shape == (self.height, self.width, 4) and accum.flags.c_contiguous
+        self._check(self._L.trc_upload_accum(self._h, accum.ctypes.data), "trc_upload_accum")
+
+    def download_accum(self):
+        out = np.empty((self.height, self.width, 4), dtype=np.float32)
+        self._check(self._L.trc_download_accum(self._h, out.ctypes.data), "trc_download_accum")
+        return out
+
+    def clear_accum(self):
+        self._check(self._L.trc_clear_accum(self._h), "trc_clear_accum")
+
+    # --- the hot path --------------------------------------------------------------
+    def render(self, spp=1, max_depth=8, integrator=abi.INTEGRATOR_PATH, frame0=0, tile_rank=0, tile_nranks=1,
+               collect_stats=False):
+        prm = abi.Params(spp=spp, max_depth=max_depth, integrator=integrator, frame0=frame0, tile_rank=tile_rank,
+                         tile_nranks=tile_nranks, flags=abi.FLAG_COLLECT_STATS if collect_stats else 0)
+        self._check(self._L.trc_render(self._h, C.byref(prm)), "trc_render")
+
+    def synchronize(self):
+        self._check(self._L.trc_synchronize(self._h), "trc_synchronize")
+
+    def trace_rays(self, rays, any_hit=False):
+        """rays: structured array with the layout of trc_ray -> structured array of trc_hit."""
+        from .dtypes import HIT_DTYPE, RAY_DTYPE
+        assert rays.dtype == RAY_DTYPE and rays.flags.c_contiguous
+        hits = np.zeros(len(rays), dtype=HIT_DTYPE)
+        self._check(self._L.trc_trace_rays(self._h, rays.ctypes.data, len(rays), hits.ctypes.data,
+                                           1 if any_hit else 0), "trc_trace_rays")
+        return hits
+
+    def stats(self):
+        s = abi.Stats()
+        self._check(self._L.trc_get_stats(self._h, C.byref(s)), "trc_get_stats")
+        return s
+
+    def reset_stats(self):
+        self._check(self._L.trc_reset_stats(self._h), "trc_reset_stats")
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cu, mem = C.c_int(), C.c_size_t()
+        self._check(self._L.trc_device_info(self._h, name, 256, C.byref(cu), C.byref(mem)), "trc_device_info")
+        return {"name": name.value.decode(), "cu_count": cu.value, "hbm_bytes": mem.value}
+
+    # --- multi-GPU -------------------------------------------------------------------
+    def group_init(self, unique_id, nranks, rank):
+        buf = (C.c_uint8 * abi.TRC_UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        self._check(self._L.trc_group_init(self._h, buf, nranks, rank), "trc_group_init")
+
+    def group_reduce_accum(self, root=0):
+        self._check(self._L.trc_group_reduce_accum(self._h, root), "trc_group_reduce_accum")
+
+    def group_finalize(self):
+        self._check(self._L.trc_group_finalize(self._h), "trc_group_finalize")
