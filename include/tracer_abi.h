@@ -27,11 +27,8 @@
 extern "C" {
 #endif
 
-#if defined(__cplusplus)
-#define TRC_ALIGN(n) alignas(n)
-#else
-#define TRC_ALIGN(n) _Alignas(n)
-#endif
+/* gcc / clang / hipcc, C and C++ alike */
+#define TRC_ALIGN(n) __attribute__((aligned(n)))
 
 #define TRC_ABI_VERSION 1
 
