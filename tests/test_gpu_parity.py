@@ -218,3 +218,28 @@ def test_error_paths(gpu, cornell):
         assert e.value.status == abi.ERR_BVH_INVALID
     finally:
         t.close()
+
+
+def test_committed_golden_frames(gpu):
+    """tests/golden/frames.npz (made by tests/golden/make_frame_fixtures.py): accumulator, RNG texture
+    and work counters, bit for bit."""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_frame_fixtures as fx
+    frames = np.load(os.path.join(ROOT, "tests", "golden", "frames.npz"))
+    for name, (kind, integ, W, H, spp, seed, env) in fx.CASES.items():
+        scene = host.HostScene(kind)
+        gpu.upload_scene(scene.view)
+        gpu.set_camera(host.prepare_camera(W, H))
+        gpu.set_environment(env)
+        gpu.resize(W, H)
+        gpu.seed(seed)
+        gpu.reset_stats()
+        gpu.render(spp=spp, integrator=integ, collect_stats=True)
+        assert np.array_equal(gpu.download_accum().view(np.uint32), frames[name + "_accum"].view(np.uint32)), name
+        assert np.array_equal(gpu.download_rng(), frames[name + "_rng"]), name
+        st = gpu.stats()
+        counts = [st.paths, st.rays, st.shaded, st.n_descend, st.n_return, st.n_leaf_sphere, st.n_leaf_square, st.n_leaf_cube]
+        assert counts == list(frames[name + "_counts"]), name

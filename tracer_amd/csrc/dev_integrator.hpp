@@ -70,136 +70,155 @@ struct PathCtx {
     uint32_t max_depth;
 };
 
-// Render.metal:411-492
-template <bool STATS>
-TRC_DEV F3 trace_path(const PathCtx& cx, Ray ray, Pcg& rng, TravCounters& cnt, uint32_t& n_rays, uint32_t& n_shaded) {
+// ---------------------------------------------------------------- path state machine
+// The reference runs, per pixel and per frame, castRay -> tracePath/traceMIS (a bounce loop around
+// Scene::hit).  Executed literally on a 64-wide wavefront, every lane waits for the longest path of the
+// wave in every sample (measured: 14.6 % VALU lane utilisation).  Here each lane is a small state
+// machine that performs ONE Scene::hit per iteration of a single flat loop and immediately starts its
+// next sample when a path ends (path regeneration), so lanes stay busy until their pixel's samples
+// are exhausted.  Per-path arithmetic and RNG consumption are exactly the reference's.
+struct PathState {
+    Ray ray;
     HitRec rec;
-    hit_init(rec);
-    F3 ratio = f3(1.0f);
-    F3 color = f3(0.0f);
-    int depth = (int)cx.max_depth;
-    n_rays++;
-    bool hitted = scene_hit<STATS, false, false>(cx.S, cx.root_min, cx.root_max, ray, rec, FLT_MAX, cx.stack, cx.lvstack, cnt);
-    do {
-        if (!hitted) { color = color + ratio * cx.ambient; break; }
-        const int mtype = mat_type(cx.sh, rec.material);
-        if (mtype == kMatDiffuse) {                                   // emitter, :441-445
-            F3 le = mat_albedo(cx.sh, rec.material);
-            float w = dot(-ray.d, -rec.gn);
-            return ratio * le * fabsf(w);
-        }
-        F2 uu; uu.x = pcg_float(rng); uu.y = pcg_float(rng);          // sample2D, :447
-        const F3 hit_origin = rec.p;
-        F3 _origin = offset_ray(rec.p, rec.sn);
-        F3 nx, ny;
-        coordinate_system(rec.sn, nx, ny);
-        F3 minus_d = -ray.d;
-        F3 wo = f3(dot(nx, minus_d), dot(ny, minus_d), dot(rec.sn, minus_d));   // wts * (-dir)
-        F3 wi = f3(0);
-        float bxPDF = 0;                                              // uninitialised in the reference (B-3)
-        n_shaded++;
-        F3 attenuation = material_S_F(mtype, hit_color(cx.sh, rec), wo, wi, uu, bxPDF);
-        if (bxPDF <= 0) break;
-        F3 wiw = (nx * wi.x + ny * wi.y) + rec.sn * wi.z;             // stw * wi
-        if (wi.z < 0) ray = make_ray(offset_ray(hit_origin, -rec.sn), wiw);   // transmission
-        else ray = make_ray(_origin, wiw);
-        ratio = ratio * (attenuation / fmaxf(FLT_EPSILON, bxPDF));
-        {   // Russian roulette on luminance, :479-485
-            float p = rgb_to_y(ratio);
-            if (pcg_float(rng) > p) break;
-            ratio = ratio * (1.0f / p);
-        }
-        n_rays++;
-        hitted = scene_hit<STATS, false, false>(cx.S, cx.root_min, cx.root_max, ray, rec, FLT_MAX, cx.stack, cx.lvstack, cnt);
-    } while ((--depth) > 0);
-    return color;
+    F3 ratio, color;
+    F3 scat_attenuation;     // traceMIS: BxRecord carried from the BSDF sample to the next hit (:364-365,395-401)
+    float scat_bxPDF;
+    int depth_left;          // bounce rays the do-while may still trace (Render.metal:406,489)
+    bool primary;            // the ray in flight is the camera ray
+};
+
+TRC_DEV void path_begin(PathState& ps, const Ray& camera_ray, uint32_t max_depth) {
+    ps.ray = camera_ray;
+    hit_init(ps.rec);
+    ps.ratio = f3(1.0f);
+    ps.color = f3(0.0f);
+    ps.scat_attenuation = f3(0.0f);
+    ps.scat_bxPDF = 1.0f;
+    ps.depth_left = (int)max_depth;
+    ps.primary = true;
 }
 
-// Render.metal:277-409.  Lights are literally squareList[5] and [6] (:320-324, B-12).
+// What happens between two Scene::hit calls of tracePath (Render.metal:432-489).  Returns true when the
+// path is finished; `result` is then the sample's radiance.
 template <bool STATS>
-TRC_DEV F3 trace_mis(const PathCtx& cx, Ray ray, Pcg& rng, TravCounters& cnt, uint32_t& n_rays, uint32_t& n_shaded) {
-    HitRec rec;
-    hit_init(rec);
-    F3 scat_attenuation = f3(0);
-    float scat_bxPDF = 1.0f;
-    F3 ratio = f3(1.0f);
-    F3 color = f3(0.0f);
-    int depth = (int)cx.max_depth;
-    n_rays++;
-    bool hitted = scene_hit<STATS, false, false>(cx.S, cx.root_min, cx.root_max, ray, rec, FLT_MAX, cx.stack, cx.lvstack, cnt);
-    do {
-        if (!hitted) { color = color + ratio * cx.ambient; break; }
-        const int mtype = mat_type(cx.sh, rec.material);
-        if (mtype == kMatDiffuse) {
-            F3 le = mat_albedo(cx.sh, rec.material);
-            float w = dot(-ray.d, -rec.gn);
-            return ratio * le * fabsf(w);
-        }
-        LightSample lsr;
-        F2 uu; uu.x = pcg_float(rng); uu.y = pcg_float(rng);
-        const F3 hit_origin = rec.p;
-        F3 _origin = offset_ray(rec.p, rec.sn);
-        if (pcg_float(rng) < 0.5f) square_sample(cx.S, 5, uu, _origin, lsr);
-        else square_sample(cx.S, 6, uu, _origin, lsr);
-        F3 _dir = lsr.p - _origin;
-        F3 _nor = normalize(_dir);
-        F3 nx, ny;
-        coordinate_system(rec.sn, nx, ny);
-        const float _tr = 1.0f;
-        const float _dis = length(_dir);
-        const Ray _ray = make_ray(_origin, _nor);
-        HitRec shr;
-        hit_init(shr);
-        n_rays++;
-        const bool blocked = scene_hit<STATS, true, false>(cx.S, cx.root_min, cx.root_max, _ray, shr, _dis, cx.stack, cx.lvstack, cnt);
-        const F3 minus_d = -ray.d;
-        const F3 base_color = hit_color(cx.sh, rec);
-        if (!blocked) {                                               // light sampling, :339-356
-            F3 wo = f3(dot(nx, minus_d), dot(ny, minus_d), dot(rec.sn, minus_d));
-            F3 wi = f3(dot(nx, _ray.d), dot(ny, _ray.d), dot(rec.sn, _ray.d));
-            float bxPDF = 0;
-            n_shaded++;
-            F3 weight = material_F(mtype, base_color, wo, wi, uu, bxPDF);
-            float cosOnLight = fabsf(dot(lsr.n, -_nor));
-            F3 Li = mat_albedo(cx.sh, lsr.material);
-            weight = weight * (Li * cosOnLight);
-            float dist2 = _dis * _dis;
-            float liPDF = dist2 * lsr.areaPDF / cosOnLight;
-            weight = weight * power_heuristic(1, liPDF, 1, bxPDF);
-            color = color + _tr * ratio * weight / liPDF;
-        }
-        // BXDF sampling, :358-378
-        F3 wi = f3(0);
-        float bxPDF = 0;
-        F3 wo = f3(dot(nx, minus_d), dot(ny, minus_d), dot(rec.sn, minus_d));
-        n_shaded++;
-        scat_attenuation = material_S_F(mtype, base_color, wo, wi, uu, bxPDF);
-        scat_bxPDF = bxPDF;
-        if (bxPDF <= 0) break;
-        F3 wiw = (nx * wi.x + ny * wi.y) + rec.sn * wi.z;
-        if (wi.z < 0) ray = make_ray(offset_ray(hit_origin, -rec.sn), wiw);
-        else ray = make_ray(_origin, wiw);
-        ratio = ratio * (scat_attenuation / scat_bxPDF);
-        {
-            float p = rgb_to_y(ratio);
-            if (pcg_float(rng) > p) break;
-            ratio = ratio * (1.0f / p);
-        }
-        n_rays++;
-        hitted = scene_hit<STATS, false, false>(cx.S, cx.root_min, cx.root_max, ray, rec, FLT_MAX, cx.stack, cx.lvstack, cnt);
+TRC_DEV bool path_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, uint32_t& n_shaded, F3& result) {
+    if (!ps.primary) {                                               // } while ((--depth) > 0), :489
+        if (--ps.depth_left <= 0) { result = ps.color; return true; }
+    }
+    ps.primary = false;
+    if (!hitted) { result = ps.color + ps.ratio * cx.ambient; return true; }        // :434-439
+    HitRec& rec = ps.rec;
+    const int mtype = mat_type(cx.sh, rec.material);
+    if (mtype == kMatDiffuse) {                                      // emitter, :441-445
+        F3 le = mat_albedo(cx.sh, rec.material);
+        float w = dot(-ps.ray.d, -rec.gn);
+        result = ps.ratio * le * fabsf(w);
+        return true;
+    }
+    F2 uu; uu.x = pcg_float(rng); uu.y = pcg_float(rng);             // sample2D, :447
+    const F3 hit_origin = rec.p;
+    F3 _origin = offset_ray(rec.p, rec.sn);
+    F3 nx, ny;
+    coordinate_system(rec.sn, nx, ny);
+    F3 minus_d = -ps.ray.d;
+    F3 wo = f3(dot(nx, minus_d), dot(ny, minus_d), dot(rec.sn, minus_d));   // wts * (-dir)
+    F3 wi = f3(0);
+    float bxPDF = 0;                                                 // uninitialised in the reference (B-3)
+    n_shaded++;
+    F3 attenuation = material_S_F(mtype, hit_color(cx.sh, rec), wo, wi, uu, bxPDF);
+    if (bxPDF <= 0) { result = ps.color; return true; }
+    F3 wiw = (nx * wi.x + ny * wi.y) + rec.sn * wi.z;                // stw * wi
+    if (wi.z < 0) ps.ray = make_ray(offset_ray(hit_origin, -rec.sn), wiw);   // transmission
+    else ps.ray = make_ray(_origin, wiw);
+    ps.ratio = ps.ratio * (attenuation / fmaxf(FLT_EPSILON, bxPDF));
+    {   // Russian roulette on luminance, :479-485
+        float p = rgb_to_y(ps.ratio);
+        if (pcg_float(rng) > p) { result = ps.color; return true; }
+        ps.ratio = ps.ratio * (1.0f / p);
+    }
+    return false;
+}
+
+// Same for traceMIS (Render.metal:298-406).  Lights are literally squareList[5] and [6] (:320-324, B-12).
+// The shadow ray (any-hit Scene::hit) is traced here, inside the step.
+template <bool STATS>
+TRC_DEV bool mis_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, TravCounters& cnt, uint32_t& n_rays,
+                      uint32_t& n_shaded, F3& result) {
+    HitRec& rec = ps.rec;
+    if (!ps.primary) {
         if (hitted && mat_type(cx.sh, rec.material) == kMatDiffuse) {   // MIS-weighted emitter hit, :390-404
             F3 Li = mat_albedo(cx.sh, rec.material);
-            float cosOnLight = dot(-ray.d, rec.sn);
-            F3 weight = scat_attenuation * Li * cosOnLight;
-            F3 d = rec.p - ray.o;
+            float cosOnLight = dot(-ps.ray.d, rec.sn);
+            F3 weight = ps.scat_attenuation * Li * cosOnLight;
+            F3 d = rec.p - ps.ray.o;
             float dist2 = dot(d, d);
             float lightPDF = rec.PDF * dist2 / cosOnLight;
-            weight = weight * power_heuristic(1, scat_bxPDF, 1, lightPDF);
-            color = color + ratio * weight / scat_bxPDF;
-            break;
+            weight = weight * power_heuristic(1, ps.scat_bxPDF, 1, lightPDF);
+            result = ps.color + ps.ratio * weight / ps.scat_bxPDF;
+            return true;
         }
-    } while ((--depth) > 0);
-    return color;
+        if (--ps.depth_left <= 0) { result = ps.color; return true; }   // } while ((--depth) > 0), :406
+    }
+    ps.primary = false;
+    if (!hitted) { result = ps.color + ps.ratio * cx.ambient; return true; }
+    const int mtype = mat_type(cx.sh, rec.material);
+    if (mtype == kMatDiffuse) {
+        F3 le = mat_albedo(cx.sh, rec.material);
+        float w = dot(-ps.ray.d, -rec.gn);
+        result = ps.ratio * le * fabsf(w);
+        return true;
+    }
+    LightSample lsr;
+    F2 uu; uu.x = pcg_float(rng); uu.y = pcg_float(rng);
+    const F3 hit_origin = rec.p;
+    F3 _origin = offset_ray(rec.p, rec.sn);
+    if (pcg_float(rng) < 0.5f) square_sample(cx.S, 5, uu, _origin, lsr);
+    else square_sample(cx.S, 6, uu, _origin, lsr);
+    F3 _dir = lsr.p - _origin;
+    F3 _nor = normalize(_dir);
+    F3 nx, ny;
+    coordinate_system(rec.sn, nx, ny);
+    const float _tr = 1.0f;
+    const float _dis = length(_dir);
+    const Ray _ray = make_ray(_origin, _nor);
+    HitRec shr;
+    hit_init(shr);
+    n_rays++;
+    const bool blocked = scene_hit<STATS, true, false>(cx.S, cx.root_min, cx.root_max, _ray, shr, _dis, cx.stack, cx.lvstack, cnt);
+    const F3 minus_d = -ps.ray.d;
+    const F3 base_color = hit_color(cx.sh, rec);
+    if (!blocked) {                                                  // light sampling, :339-356
+        F3 wo = f3(dot(nx, minus_d), dot(ny, minus_d), dot(rec.sn, minus_d));
+        F3 wi = f3(dot(nx, _ray.d), dot(ny, _ray.d), dot(rec.sn, _ray.d));
+        float bxPDF = 0;
+        n_shaded++;
+        F3 weight = material_F(mtype, base_color, wo, wi, uu, bxPDF);
+        float cosOnLight = fabsf(dot(lsr.n, -_nor));
+        F3 Li = mat_albedo(cx.sh, lsr.material);
+        weight = weight * (Li * cosOnLight);
+        float dist2 = _dis * _dis;
+        float liPDF = dist2 * lsr.areaPDF / cosOnLight;
+        weight = weight * power_heuristic(1, liPDF, 1, bxPDF);
+        ps.color = ps.color + _tr * ps.ratio * weight / liPDF;
+    }
+    // BXDF sampling, :358-378
+    F3 wi = f3(0);
+    float bxPDF = 0;
+    F3 wo = f3(dot(nx, minus_d), dot(ny, minus_d), dot(rec.sn, minus_d));
+    n_shaded++;
+    ps.scat_attenuation = material_S_F(mtype, base_color, wo, wi, uu, bxPDF);
+    ps.scat_bxPDF = bxPDF;
+    if (bxPDF <= 0) { result = ps.color; return true; }
+    F3 wiw = (nx * wi.x + ny * wi.y) + rec.sn * wi.z;
+    if (wi.z < 0) ps.ray = make_ray(offset_ray(hit_origin, -rec.sn), wiw);
+    else ps.ray = make_ray(_origin, wiw);
+    ps.ratio = ps.ratio * (ps.scat_attenuation / ps.scat_bxPDF);
+    {
+        float p = rgb_to_y(ps.ratio);
+        if (pcg_float(rng) > p) { result = ps.color; return true; }
+        ps.ratio = ps.ratio * (1.0f / p);
+    }
+    return false;
 }
 
 }  // namespace trcdev

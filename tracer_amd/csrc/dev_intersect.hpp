@@ -320,9 +320,28 @@ TRC_DEV bool scene_hit(const SceneRef& S, const F3 root_min, const F3 root_max, 
     uint32_t tag = kTagInterior << kTagIndexBits;   // root
     uint32_t sp = 0;
     int32_t level = 0;        // level of the interior node being expanded / parent level of a leaf
-    for (;;) {
-        int32_t ret_start;    // level at which the reference's first upward iteration would run
-        if ((tag >> kTagIndexBits) == kTagInterior) {
+    bool done = false;
+    // pops the next deferred sibling, or ends the traversal; `ret_start` = level at which the
+    // reference's first upward ("came from child") iteration would run -- only counted, never executed
+    auto pop_or_finish = [&](int32_t ret_start) {
+        if (sp == 0) {
+            if (STATS) cnt.n_return += (uint32_t)(ret_start + 1);
+            done = true;
+            return;
+        }
+        sp--;
+        tag = stack[sp * kBlock];
+        if (STATS) {
+            const int32_t ls = (int32_t)lvstack[sp * kBlock];
+            cnt.n_return += (uint32_t)(ret_start - ls + 1);
+            level = ls;
+            if ((tag >> kTagIndexBits) == kTagInterior) level += 1;
+        }
+    };
+    while (!done) {
+        // (1) descend: expand interior nodes until this lane holds a leaf (or runs out of work); the whole
+        //     wavefront does box tests here, leaf tests are batched in (2)
+        while (!done && (tag >> kTagIndexBits) == kTagInterior) {
             const uint32_t* np = S.small_base + S.off_nodes + (size_t)(tag & kTagIndexMask) * kNodeDwords;
             const float4 q0 = ld4(np), q1 = ld4(np + 4), q2 = ld4(np + 8), q3 = ld4(np + 12);
             if (STATS) cnt.n_descend++;
@@ -332,18 +351,20 @@ TRC_DEV bool scene_hit(const SceneRef& S, const F3 root_min, const F3 root_max, 
             if (left_test || right_test) {
                 const uint32_t tagL = __float_as_uint(q3.z), tagR = __float_as_uint(q3.w);
                 const bool left_first = t_left < t_right;            // Render.hh:174 (literal, also when only one hit)
-                const uint32_t first = left_first ? tagL : tagR;
                 if (left_test && right_test) {
                     stack[sp * kBlock] = left_first ? tagR : tagL;    // Render.hh:171-172: visit the other one later
                     if (STATS) lvstack[sp * kBlock] = (uint32_t)level;
                     sp++;
                 }
-                tag = first;
-                if ((first >> kTagIndexBits) == kTagInterior) level += 1;
-                continue;
+                tag = left_first ? tagL : tagR;
+                if (STATS && (tag >> kTagIndexBits) == kTagInterior) level += 1;
+            } else {
+                pop_or_finish(level - 1);
             }
-            ret_start = level - 1;
-        } else {
+        }
+        if (done) break;
+        // (2) leaf
+        {
             const uint32_t type = tag >> kTagIndexBits, index = tag & kTagIndexMask;
             bool ok;
             if (type == 1u) {
@@ -361,21 +382,8 @@ TRC_DEV bool scene_hit(const SceneRef& S, const F3 root_min, const F3 root_max, 
             }
             if (ok) rec.tag = tag;
             if (ANY && ry < test_t) return true;                      // Render.hh:244
-            ret_start = level;
+            pop_or_finish(level);
         }
-        // pop the next deferred sibling
-        if (sp == 0) {
-            if (STATS) cnt.n_return += (uint32_t)(ret_start + 1);
-            break;
-        }
-        sp--;
-        tag = stack[sp * kBlock];
-        if (STATS) {
-            const int32_t ls = (int32_t)lvstack[sp * kBlock];
-            cnt.n_return += (uint32_t)(ret_start - ls + 1);
-            level = ls;
-        }
-        if ((tag >> kTagIndexBits) == kTagInterior) level += 1;       // (only meaningful under STATS)
     }
     return ry < test_t;
 }

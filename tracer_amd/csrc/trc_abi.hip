@@ -131,23 +131,43 @@ __global__ void __launch_bounds__(kBlock) k_render(const KRender kp) {
         const float u = (float)px / (float)W;                               // no sub-pixel jitter (B-2)
         const float v = (float)py / (float)H;
 
-        for (uint32_t s = 0; s < kp.spp; ++s) {
+        // flat loop: one Scene::hit per iteration; a finished path immediately regenerates the next sample
+        PathState ps;
+        Pcg rng;
+        uint32_t s = 0;
+        bool alive = kp.spp > 0;
+        if (alive) {
             // pcg32_t rng = { rng_inc, rng_state } aggregate-initialises {state, inc}: the two 64-bit
             // words trade roles every frame (Render.metal:516-519,545-557, B-1)
-            Pcg rng;
             rng.state = ((uint64_t)texel.z << 32) | texel.w;
             rng.inc = ((uint64_t)texel.x << 32) | texel.y;
-            const uint32_t frame = kp.frame0 + s;
-            Ray ray = cast_ray(kp.cam, u, v, rng);
-            F3 color = (INTEGRATOR == TRC_INTEGRATOR_MIS) ? trace_mis<STATS>(cx, ray, rng, cnt, n_rays, n_shaded)
-                                                          : trace_path<STATS>(cx, ray, rng, cnt, n_rays, n_shaded);
-            const bool bad = is_inf(color.x) || is_nan(color.x) || is_inf(color.y) || is_nan(color.y) ||
-                             is_inf(color.z) || is_nan(color.z);
-            if (bad) color = f3(0);
-            cached = (cached * (float)frame + color) / (float)(frame + 1);  // running mean, :540-541
-            texel.y = (uint32_t)rng.state; texel.x = (uint32_t)(rng.state >> 32);
-            texel.w = (uint32_t)rng.inc;   texel.z = (uint32_t)(rng.inc >> 32);
-            n_paths++;
+            path_begin(ps, cast_ray(kp.cam, u, v, rng), kp.max_depth);
+        }
+        while (alive) {
+            n_rays++;
+            const bool hitted = scene_hit<STATS, false, false>(cx.S, cx.root_min, cx.root_max, ps.ray, ps.rec, FLT_MAX,
+                                                               cx.stack, cx.lvstack, cnt);
+            F3 color;
+            const bool finished = (INTEGRATOR == TRC_INTEGRATOR_MIS)
+                                      ? mis_step<STATS>(cx, ps, hitted, rng, cnt, n_rays, n_shaded, color)
+                                      : path_step<STATS>(cx, ps, hitted, rng, n_shaded, color);
+            if (finished) {
+                const bool bad = is_inf(color.x) || is_nan(color.x) || is_inf(color.y) || is_nan(color.y) ||
+                                 is_inf(color.z) || is_nan(color.z);
+                if (bad) color = f3(0);                                         // :537-538
+                const uint32_t frame = kp.frame0 + s;
+                cached = (cached * (float)frame + color) / (float)(frame + 1);  // running mean, :540-541
+                texel.y = (uint32_t)rng.state; texel.x = (uint32_t)(rng.state >> 32);
+                texel.w = (uint32_t)rng.inc;   texel.z = (uint32_t)(rng.inc >> 32);
+                n_paths++;
+                if (++s == kp.spp) {
+                    alive = false;
+                } else {
+                    rng.state = ((uint64_t)texel.z << 32) | texel.w;
+                    rng.inc = ((uint64_t)texel.x << 32) | texel.y;
+                    path_begin(ps, cast_ray(kp.cam, u, v, rng), kp.max_depth);
+                }
+            }
         }
         float4 out; out.x = cached.x; out.y = cached.y; out.z = cached.z; out.w = 1.0f;
         reinterpret_cast<float4*>(kp.fr.accum)[pix] = out;
