@@ -146,7 +146,7 @@ DEVICE_SYMBOLS = [
     "trc_abi_version", "trc_status_string", "trc_last_error", "trc_create", "trc_destroy",
     "trc_upload_scene", "trc_set_camera", "trc_set_environment", "trc_resize", "trc_seed",
     "trc_upload_rng", "trc_download_rng", "trc_upload_accum", "trc_download_accum", "trc_clear_accum",
-    "trc_render", "trc_synchronize", "trc_trace_rays", "trc_get_stats", "trc_reset_stats",
+    "trc_render", "trc_synchronize", "trc_trace_rays", "trc_get_stats", "trc_reset_stats", "trc_debug_profile",
     "trc_device_info", "trc_group_unique_id", "trc_group_init", "trc_group_reduce_accum", "trc_group_finalize",
 ]
 HOST_SYMBOLS = [

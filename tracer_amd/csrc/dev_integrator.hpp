@@ -101,7 +101,7 @@ TRC_DEV void path_begin(PathState& ps, const Ray& camera_ray, uint32_t max_depth
 // What happens between two Scene::hit calls of tracePath (Render.metal:432-489).  Returns true when the
 // path is finished; `result` is then the sample's radiance.
 template <bool STATS>
-TRC_DEV bool path_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, uint32_t& n_shaded, F3& result) {
+TRC_DEV bool path_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, TravCounters& cnt, uint32_t& n_shaded, F3& result) {
     if (!ps.primary) {                                               // } while ((--depth) > 0), :489
         if (--ps.depth_left <= 0) { result = ps.color; return true; }
     }
@@ -125,6 +125,13 @@ TRC_DEV bool path_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, 
     F3 wi = f3(0);
     float bxPDF = 0;                                                 // uninitialised in the reference (B-3)
     n_shaded++;
+    prof<STATS>(cnt, kProfShade);
+    if (STATS) {
+        if (mtype == kMatLambert) prof<STATS>(cnt, kProfLambert);
+        else if (mtype == kMatMetal) prof<STATS>(cnt, kProfMetal);
+        else if (mtype == kMatPlastic) prof<STATS>(cnt, kProfPlastic);
+        else if (mtype == kMatGlass) prof<STATS>(cnt, kProfGlass);
+    }
     F3 attenuation = material_S_F(mtype, hit_color(cx.sh, rec), wo, wi, uu, bxPDF);
     if (bxPDF <= 0) { result = ps.color; return true; }
     F3 wiw = (nx * wi.x + ny * wi.y) + rec.sn * wi.z;                // stw * wi

@@ -144,14 +144,16 @@ __global__ void __launch_bounds__(kBlock) k_render(const KRender kp) {
             path_begin(ps, cast_ray(kp.cam, u, v, rng), kp.max_depth);
         }
         while (alive) {
+            prof<STATS>(cnt, kProfLoop);
             n_rays++;
             const bool hitted = scene_hit<STATS, false, false>(cx.S, cx.root_min, cx.root_max, ps.ray, ps.rec, FLT_MAX,
                                                                cx.stack, cx.lvstack, cnt);
             F3 color;
             const bool finished = (INTEGRATOR == TRC_INTEGRATOR_MIS)
                                       ? mis_step<STATS>(cx, ps, hitted, rng, cnt, n_rays, n_shaded, color)
-                                      : path_step<STATS>(cx, ps, hitted, rng, n_shaded, color);
+                                      : path_step<STATS>(cx, ps, hitted, rng, cnt, n_shaded, color);
             if (finished) {
+                prof<STATS>(cnt, kProfFinish);
                 const bool bad = is_inf(color.x) || is_nan(color.x) || is_inf(color.y) || is_nan(color.y) ||
                                  is_inf(color.z) || is_nan(color.z);
                 if (bad) color = f3(0);                                         // :537-538
@@ -190,6 +192,13 @@ __global__ void __launch_bounds__(kBlock) k_render(const KRender kp) {
         for (int i = 0; i < 8; ++i) {
             uint32_t r = wave_sum(v[i]);
             if (lane == 0) atomicAdd(&kp.stats[slot[i]], (unsigned long long)r);
+        }
+        for (int i = 0; i < kProfCount; ++i) {       // divergence profile: lanes and wavefronts per site
+            uint32_t rl = wave_sum(cnt.prof_lane[i]), rw = wave_sum(cnt.prof_wave[i]);
+            if (lane == 0) {
+                atomicAdd(&kp.stats[kStatCount + 2 * i], (unsigned long long)rl);
+                atomicAdd(&kp.stats[kStatCount + 2 * i + 1], (unsigned long long)rw);
+            }
         }
     }
 }
@@ -552,8 +561,8 @@ trc_status trc_create(int device, trc_ctx** out) {
     if (!ctx) return TRC_ERR_OOM;
     ctx->device = device;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void**)&ctx->d_stats, sizeof(unsigned long long) * kStatCount) != hipSuccess ||
-        hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * kStatCount, ctx->stream) != hipSuccess) {
+        hipMalloc((void**)&ctx->d_stats, sizeof(unsigned long long) * (kStatCount + 2 * kProfCount)) != hipSuccess ||
+        hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * (kStatCount + 2 * kProfCount), ctx->stream) != hipSuccess) {
         trc_destroy(ctx);
         return TRC_ERR_HIP;
     }
@@ -775,12 +784,23 @@ trc_status trc_get_stats(trc_ctx* ctx, trc_stats* out) {
     return TRC_OK;
 }
 
+// developer diagnostic: (lanes, wavefronts) that executed each ProfSite of the instrumented kernels
+trc_status trc_debug_profile(trc_ctx* ctx, uint64_t* out, uint32_t n_pairs) {
+    if (!ctx || !out) return TRC_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    unsigned long long h[kStatCount + 2 * kProfCount];
+    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t i = 0; i < n_pairs && i < (uint32_t)kProfCount; ++i) { out[2 * i] = h[kStatCount + 2 * i]; out[2 * i + 1] = h[kStatCount + 2 * i + 1]; }
+    return TRC_OK;
+}
+
 trc_status trc_reset_stats(trc_ctx* ctx) {
     if (!ctx) return TRC_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     collect_events(ctx);
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * kStatCount, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * (kStatCount + 2 * kProfCount), ctx->stream));
     ctx->launches = 0;
     ctx->kernel_ms = 0.0;
     return TRC_OK;

@@ -55,6 +55,7 @@ def lib():
         L.trc_trace_rays.argtypes = [vp, vp, C.c_size_t, vp, C.c_int]
         L.trc_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
         L.trc_reset_stats.argtypes = [vp]
+        L.trc_debug_profile.argtypes = [vp, C.POINTER(C.c_uint64), u32]
         L.trc_device_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
         L.trc_group_unique_id.argtypes = [C.POINTER(C.c_uint8)]
         L.trc_group_init.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int, C.c_int]
@@ -168,6 +169,17 @@ class Tracer:
         s = abi.Stats()
         self._check(self._L.trc_get_stats(self._h, C.byref(s)), "trc_get_stats")
         return s
+
+    PROFILE_SITES = ["loop", "box_step", "square", "sphere", "cube", "triangle", "shade", "lambert", "metal",
+                     "plastic", "glass", "path_end"]
+
+    def debug_profile(self):
+        """{site: (lanes, wavefronts, lanes/(64*wavefronts))} of the instrumented kernels."""
+        n = len(self.PROFILE_SITES)
+        buf = (C.c_uint64 * (2 * n))()
+        self._check(self._L.trc_debug_profile(self._h, buf, n), "trc_debug_profile")
+        return {s: (buf[2 * i], buf[2 * i + 1], buf[2 * i] / (64.0 * buf[2 * i + 1]) if buf[2 * i + 1] else 0.0)
+                for i, s in enumerate(self.PROFILE_SITES)}
 
     def reset_stats(self):
         self._check(self._L.trc_reset_stats(self._h), "trc_reset_stats")
