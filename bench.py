@@ -51,7 +51,7 @@ def cpu_baseline(scene, cam, budget_s=20.0):
     rate = st.rays / dt
     full_rays_est = st.rays * 256
     nranks = 256
-    while nranks > 8 and (full_rays_est / (nranks // 2)) / rate < budget_s:
+    while nranks > 1 and (full_rays_est / (nranks // 2)) / rate < budget_s:
         nranks //= 2
     if nranks != 256:
         rng = host.fill_rng(SEED, W, H)
@@ -62,6 +62,32 @@ def cpu_baseline(scene, cam, budget_s=20.0):
     return {"value": round(st.rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": f"oracle/liboracle.so (scalar C++ restatement), tiles (tx+ty)%{nranks}==0 of the same "
                       f"1920x1080x64spp frame: {st.paths} paths, {st.rays} rays in {dt:.2f} s on {cores} threads"}
+
+
+def cpu_rt_weekend():
+    """BASELINE config 1: the reference's RT_Weekend CPU path (C++ restatement, oracle/cpu_baseline.cpp)
+    on the Cornell box at 400x400x16 spp, all host cores, row bands like main.swift:77-87."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "cpu_baseline")
+    if not os.path.exists(exe):
+        return None
+    out = subprocess.check_output([exe, "--scene", "cornell", "--width", "400", "--height", "400", "--spp", "16"],
+                                  text=True, timeout=600)
+    r = json.loads(out.strip().splitlines()[-1])
+    return {"value": r["mrays_per_s"], "unit": "Mrays/s", "cores": r["threads"], "kind": "port",
+            "sample": f"RT_Weekend recursive tracer restated in C++ (linear-scan HittableList), RT_Nextweek Cornell "
+                      f"box 400x400x16spp: {r['rays']} rays in {r['seconds']:.2f} s, {r['mpaths_per_s']} Mpaths/s"}
+
+
+def pmc_traffic(world):
+    """HBM bytes per launch from rocprofv3 PMC passes (profiles/*/traffic.json, produced by
+    tools/tools_pmc.sh + tools/tools_traffic.py with the gfx950 FETCH_SIZE x2 correction); None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
+    if not files or world != 1:
+        return None
+    t = json.load(open(files[-1]))
+    return t.get("hbm_bytes_per_launch")
 
 
 def main():
@@ -165,13 +191,14 @@ def main():
                        "tiles": f"16x16 px, owner (tx+ty)%{world}", "device": info["name"],
                        "compose": "ncclReduce(sum) of the RGBA32F frame to rank 0" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(world),
                          "kernel": "k_render", "kernel_ms": round(kernel_ms, 3),
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "bytes_per_ray": round(bytes_per_launch / max(1, rays_per_launch), 1)},
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scene, cam)
+            line["cpu_rt_weekend"] = cpu_rt_weekend()
         print(json.dumps(line), flush=True)
 
     if world > 1:
