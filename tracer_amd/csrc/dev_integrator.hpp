@@ -148,7 +148,7 @@ TRC_DEV bool path_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, 
 
 // Same for traceMIS (Render.metal:298-406).  Lights are literally squareList[5] and [6] (:320-324, B-12).
 // The shadow ray (any-hit Scene::hit) is traced here, inside the step.
-template <bool STATS>
+template <bool ALL_LDS, bool STATS>
 TRC_DEV bool mis_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, TravCounters& cnt, uint32_t& n_rays,
                       uint32_t& n_shaded, F3& result) {
     HitRec& rec = ps.rec;
@@ -191,7 +191,7 @@ TRC_DEV bool mis_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, T
     HitRec shr;
     hit_init(shr);
     n_rays++;
-    const bool blocked = scene_hit<STATS, true, false>(cx.S, cx.root_min, cx.root_max, _ray, shr, _dis, cx.stack, cx.lvstack, cnt);
+    const bool blocked = scene_hit<ALL_LDS, STATS, true, false>(cx.S, cx.root_min, cx.root_max, _ray, shr, _dis, cx.stack, cx.lvstack, cnt);
     const F3 minus_d = -ps.ray.d;
     const F3 base_color = hit_color(cx.sh, rec);
     if (!blocked) {                                                  // light sampling, :339-356

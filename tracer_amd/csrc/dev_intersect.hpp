@@ -73,13 +73,26 @@ TRC_DEV void prof(TravCounters& c, int site) {
     }
 }
 
-// scene accessor: `small` points at the LDS copy (or the global blob) of nodes+analytic prims+materials
+// scene accessor: `small_base` is the LDS copy of the blob prefix (analytic prims, materials, top fat nodes)
 struct SceneRef {
     const uint32_t* small_base;
     const uint32_t* blob;
     uint32_t off_nodes, off_spheres, off_squares, off_cubes, off_materials, off_tripos, off_triattr;
+    uint32_t n_lds_nodes;
 };
 TRC_DEV float4 ld4(const uint32_t* p) { return *reinterpret_cast<const float4*>(p); }
+
+// fat-node fetch: LDS for the staged top of the tree, global memory below it.  ALL_LDS = whole tree staged.
+template <bool ALL_LDS>
+TRC_DEV void load_node(const SceneRef& S, uint32_t idx, float4& q0, float4& q1, float4& q2, float4& q3) {
+    if (ALL_LDS || idx < S.n_lds_nodes) {
+        const uint32_t* np = S.small_base + S.off_nodes + idx * kNodeDwords;
+        q0 = ld4(np); q1 = ld4(np + 4); q2 = ld4(np + 8); q3 = ld4(np + 12);
+    } else {
+        const uint32_t* np = S.blob + S.off_nodes + (size_t)idx * kNodeDwords;
+        q0 = ld4(np); q1 = ld4(np + 4); q2 = ld4(np + 8); q3 = ld4(np + 12);
+    }
+}
 
 // ---------------------------------------------------------------- boxes
 TRC_DEV bool box_hit(F3 mn, F3 mx, const Ray& r, float rx, float ry) {      // AABB.hh:73-90
@@ -322,7 +335,7 @@ TRC_DEV bool triangle_hit_test(const SceneRef& S, uint32_t index, const Ray& ray
 // ---------------------------------------------------------------- Scene::hit
 // `stack` is this lane's column of the workgroup stack (entry e at stack[e * kBlock]); `lvstack`
 // (STATS only) holds the level of the node that deferred each entry.
-template <bool STATS, bool ANY, bool EAGER_UV>
+template <bool ALL_LDS, bool STATS, bool ANY, bool EAGER_UV>
 TRC_DEV bool scene_hit(const SceneRef& S, const F3 root_min, const F3 root_max, const Ray& ray, HitRec& rec, const float test_t,
                        uint32_t* stack, uint32_t* lvstack, TravCounters& cnt) {
     if (STATS) cnt.rays++;
@@ -356,8 +369,8 @@ TRC_DEV bool scene_hit(const SceneRef& S, const F3 root_min, const F3 root_max, 
         // (1) descend: expand interior nodes until this lane holds a leaf (or runs out of work); the whole
         //     wavefront does box tests here, leaf tests are batched in (2)
         while (!done && (tag >> kTagIndexBits) == kTagInterior) {
-            const uint32_t* np = S.small_base + S.off_nodes + (size_t)(tag & kTagIndexMask) * kNodeDwords;
-            const float4 q0 = ld4(np), q1 = ld4(np + 4), q2 = ld4(np + 8), q3 = ld4(np + 12);
+            float4 q0, q1, q2, q3;
+            load_node<ALL_LDS>(S, tag & kTagIndexMask, q0, q1, q2, q3);
             if (STATS) cnt.n_descend++;
             prof<STATS>(cnt, kProfDescend);
             float t_left = ry, t_right = ry;

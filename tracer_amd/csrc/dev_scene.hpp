@@ -19,8 +19,11 @@
 //   triangle positions 48 B : v0, v1, v2 as float4 (what a TEST reads)
 //   triangle attributes 64 B: n0 n1 n2 (9), uv0 uv1 uv2 (6)  (read only on an accepted hit)
 //
-// Small scenes (everything but triangles <= kLdsSceneBytes) are staged into LDS by each
-// workgroup; traversal then never touches HBM/L2 after the first few hundred cycles.
+// Blob order: spheres, squares, cubes, materials, fat nodes (BFS), triangle positions, triangle
+// attributes.  Every workgroup stages the PREFIX that fits kLdsSceneBytes into LDS: always the
+// analytic primitives + materials, then as many fat nodes as fit -- the whole tree for the Cornell
+// scenes (traversal never touches L2/HBM), the top levels of the tree (BFS prefix, ~550 nodes) for
+// mesh scenes, whose deeper nodes and triangles come from global memory (L2 / Infinity Cache).
 #pragma once
 
 #include <stdint.h>
@@ -42,12 +45,12 @@ constexpr uint32_t kTagNone = 0xFFFFFFFFu;
 
 constexpr uint32_t kLdsSceneBytes = 40 * 1024;   // staged-scene budget per workgroup
 
-// Offsets are in dwords from `blob`.  Section order: nodes, spheres, squares, cubes, materials
-// (the "small" part, `small_dwords` long), then triangle positions and attributes.
+// Offsets are in dwords from `blob`.
 struct DScene {
     const uint32_t* blob;
     uint32_t off_nodes, off_spheres, off_squares, off_cubes, off_materials, off_tripos, off_triattr;
-    uint32_t small_dwords;
+    uint32_t lds_dwords;      // staged prefix: prims + materials + the first n_lds_nodes fat nodes
+    uint32_t n_lds_nodes;
     uint32_t n_nodes, n_spheres, n_squares, n_cubes, n_materials, n_triangles;
     uint32_t stack_depth;     // max pending siblings = tree depth (checked <= TRC_MAX_BVH_DEPTH)
 };

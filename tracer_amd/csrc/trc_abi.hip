@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -45,18 +46,14 @@ struct KTrace {
     uint32_t n;
 };
 
-// cooperative copy of the small scene part into LDS; returns the base the accessors use
-template <bool LDS>
+// cooperative copy of the blob prefix (prims, materials, top fat nodes) into LDS
 __device__ __forceinline__ const uint32_t* stage_scene(const DScene& sc) {
-    if (LDS) {
-        const uint4* src = reinterpret_cast<const uint4*>(sc.blob);
-        uint4* dst = reinterpret_cast<uint4*>(trc_smem);
-        const uint32_t n16 = sc.small_dwords >> 2;
-        for (uint32_t i = threadIdx.x; i < n16; i += kBlock) dst[i] = src[i];
-        __syncthreads();
-        return trc_smem;
-    }
-    return sc.blob;
+    const uint4* src = reinterpret_cast<const uint4*>(sc.blob);
+    uint4* dst = reinterpret_cast<uint4*>(trc_smem);
+    const uint32_t n16 = sc.lds_dwords >> 2;
+    for (uint32_t i = threadIdx.x; i < n16; i += kBlock) dst[i] = src[i];
+    __syncthreads();
+    return trc_smem;
 }
 
 __device__ __forceinline__ SceneRef make_scene_ref(const DScene& sc, const uint32_t* small_base) {
@@ -66,6 +63,7 @@ __device__ __forceinline__ SceneRef make_scene_ref(const DScene& sc, const uint3
     S.off_nodes = sc.off_nodes; S.off_spheres = sc.off_spheres; S.off_squares = sc.off_squares;
     S.off_cubes = sc.off_cubes; S.off_materials = sc.off_materials;
     S.off_tripos = sc.off_tripos; S.off_triattr = sc.off_triattr;
+    S.n_lds_nodes = sc.n_lds_nodes;
     return S;
 }
 
@@ -97,8 +95,8 @@ __global__ void __launch_bounds__(256) k_seed(uint32_t* rng, uint32_t n_pixels, 
 template <bool LDS, bool STATS, int INTEGRATOR>
 __global__ void __launch_bounds__(kBlock) k_render(const KRender kp) {
     const DScene& sc = kp.ks.sc;
-    const uint32_t* small_base = stage_scene<LDS>(sc);
-    uint32_t* stack_base = trc_smem + (LDS ? sc.small_dwords : 0u);
+    const uint32_t* small_base = stage_scene(sc);
+    uint32_t* stack_base = trc_smem + sc.lds_dwords;
     uint32_t* stack = stack_base + threadIdx.x;
     uint32_t* lvstack = stack + sc.stack_depth * kBlock;
 
@@ -146,11 +144,11 @@ __global__ void __launch_bounds__(kBlock) k_render(const KRender kp) {
         while (alive) {
             prof<STATS>(cnt, kProfLoop);
             n_rays++;
-            const bool hitted = scene_hit<STATS, false, false>(cx.S, cx.root_min, cx.root_max, ps.ray, ps.rec, FLT_MAX,
+            const bool hitted = scene_hit<LDS, STATS, false, false>(cx.S, cx.root_min, cx.root_max, ps.ray, ps.rec, FLT_MAX,
                                                                cx.stack, cx.lvstack, cnt);
             F3 color;
             const bool finished = (INTEGRATOR == TRC_INTEGRATOR_MIS)
-                                      ? mis_step<STATS>(cx, ps, hitted, rng, cnt, n_rays, n_shaded, color)
+                                      ? mis_step<LDS, STATS>(cx, ps, hitted, rng, cnt, n_rays, n_shaded, color)
                                       : path_step<STATS>(cx, ps, hitted, rng, cnt, n_shaded, color);
             if (finished) {
                 prof<STATS>(cnt, kProfFinish);
@@ -207,8 +205,8 @@ __global__ void __launch_bounds__(kBlock) k_render(const KRender kp) {
 template <bool LDS, bool ANY>
 __global__ void __launch_bounds__(kBlock) k_trace(const KTrace kp) {
     const DScene& sc = kp.ks.sc;
-    const uint32_t* small_base = stage_scene<LDS>(sc);
-    uint32_t* stack = trc_smem + (LDS ? sc.small_dwords : 0u) + threadIdx.x;
+    const uint32_t* small_base = stage_scene(sc);
+    uint32_t* stack = trc_smem + sc.lds_dwords + threadIdx.x;
     uint32_t* lvstack = stack + sc.stack_depth * kBlock;
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= kp.n) return;
@@ -219,7 +217,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(const KTrace kp) {
     hit_init(rec);
     TravCounters cnt;
     counters_zero(cnt);
-    const bool h = scene_hit<true, ANY, true>(S, f3(kp.ks.root_box[0], kp.ks.root_box[1], kp.ks.root_box[2]),
+    const bool h = scene_hit<LDS, true, ANY, true>(S, f3(kp.ks.root_box[0], kp.ks.root_box[1], kp.ks.root_box[2]),
                                                  f3(kp.ks.root_box[3], kp.ks.root_box[4], kp.ks.root_box[5]), ray, rec, in.tmax, stack, lvstack, cnt);
     trc_hit o;
     memset(&o, 0, sizeof o);
@@ -403,13 +401,27 @@ trc_status build_blob(trc_ctx* ctx, const trc_scene* s, std::vector<uint32_t>& b
     const uint32_t n_interior = (uint32_t)order.size();
     DScene sc{};
     auto align4 = [](uint32_t v) { return (v + 3u) & ~3u; };
-    sc.off_nodes = 0;
-    sc.off_spheres = align4(sc.off_nodes + n_interior * kNodeDwords);
+    sc.off_spheres = 0;
     sc.off_squares = align4(sc.off_spheres + s->n_sphere * kSphereDwords);
     sc.off_cubes = align4(sc.off_squares + s->n_square * kSquareDwords);
     sc.off_materials = align4(sc.off_cubes + s->n_cube * kCubeDwords);
-    sc.small_dwords = align4(sc.off_materials + s->n_material * kMaterialDwords);
-    sc.off_tripos = sc.small_dwords;
+    sc.off_nodes = align4(sc.off_materials + s->n_material * kMaterialDwords);
+    if ((uint64_t)sc.off_nodes * 4 + kNodeDwords * 4 > kLdsSceneBytes)
+        return fail(ctx, TRC_ERR_UNSUPPORTED, "analytic primitives + materials exceed the LDS staging budget");
+    // LDS per workgroup = staged prefix + traversal stack; keep 4 workgroups per CU resident (measured on
+    // MI355X: occupancy beats top-of-tree staging -- 8/16/24/40/64 KB staged on the 1 M-triangle scene gave
+    // 1826/1553/1155/1165/666 Mrays/s), so nodes are staged only into what the stack leaves of ~38 KB.
+    const uint32_t stack_dwords = std::max(1u, max_leaf_depth) * kBlock;
+    uint32_t budget_dwords = (38u * 1024u / 4u > stack_dwords) ? 38u * 1024u / 4u - stack_dwords : 0u;
+    budget_dwords = std::min(budget_dwords, kLdsSceneBytes / 4);
+    if (const char* e = std::getenv("TRC_LDS_BUDGET_KB")) {          // tuning knob: staged bytes vs occupancy
+        const long kb = std::atol(e);
+        if (kb > 0 && kb <= 128) budget_dwords = (uint32_t)kb * 256u;
+    }
+    budget_dwords = std::max(budget_dwords, sc.off_nodes + kNodeDwords);
+    sc.n_lds_nodes = std::min<uint32_t>(n_interior, (budget_dwords - sc.off_nodes) / kNodeDwords);
+    sc.lds_dwords = sc.off_nodes + sc.n_lds_nodes * kNodeDwords;
+    sc.off_tripos = align4(sc.off_nodes + n_interior * kNodeDwords);
     const uint64_t total = (uint64_t)sc.off_tripos + (uint64_t)n_tri * kTriPosDwords + (uint64_t)n_tri * kTriAttrDwords;
     if (total > 0xFFFFFFF0ull) return fail(ctx, TRC_ERR_UNSUPPORTED, "scene too large for 32-bit dword offsets");
     sc.off_triattr = sc.off_tripos + n_tri * kTriPosDwords;
@@ -509,7 +521,7 @@ std::vector<uint32_t> make_tiles(uint32_t W, uint32_t H, uint32_t nranks, uint32
 
 size_t dyn_lds_bytes(const trc_ctx* ctx, bool stats) {
     const DScene& sc = ctx->ks.sc;
-    size_t dwords = (ctx->lds_scene ? sc.small_dwords : 0u) + (size_t)sc.stack_depth * kBlock * (stats ? 2u : 1u);
+    size_t dwords = sc.lds_dwords + (size_t)sc.stack_depth * kBlock * (stats ? 2u : 1u);
     return dwords * 4;
 }
 
@@ -599,9 +611,7 @@ trc_status trc_upload_scene(trc_ctx* ctx, const trc_scene* scene) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ks.sc.blob = ctx->d_blob;
     ctx->ks = ks;
-    // whole small part + both stacks of the instrumented kernel must fit the LDS budget
-    const size_t small_bytes = (size_t)ks.sc.small_dwords * 4;
-    ctx->lds_scene = small_bytes <= kLdsSceneBytes;
+    ctx->lds_scene = ks.sc.n_lds_nodes == ks.sc.n_nodes;      // whole tree staged in LDS
     ctx->has_scene = true;
     return TRC_OK;
 }
