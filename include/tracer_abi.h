@@ -173,6 +173,27 @@ typedef struct trc_Complex {
     uint32_t   framePhotonSum;
 } trc_Complex;
 
+/* RT_Metal/Metal/Photon.hh:12-28 -- 80 bytes (SPPM photon, persists across frames up to 8 steps) */
+typedef struct trc_PhotonRecord {
+    trc_float3 flux, normal, position, direction;
+    uint8_t    step;
+    uint8_t    active;
+    uint8_t    _pad[14];
+} trc_PhotonRecord;
+
+/* RT_Metal/Metal/Photon.hh:30-53 -- 112 bytes (SPPM visible point of one pixel) */
+typedef struct trc_CameraRecord {
+    trc_float3 ratio, position, direction;
+    uint8_t    valid;
+    uint8_t    _pad0[15];
+    trc_float3 alternative, flux;
+    float      radius;
+    uint32_t   photonCount;
+    uint32_t   _pad1[2];
+} trc_CameraRecord;
+
+#define TRC_PHOTON_HASHN 512      /* PHOTON_HASHN, RT_Metal/Metal/Common.hh:4: 512x512 photons and hash cells */
+
 /* Primitive argument table of the kernel (Render.hh:122-130) + materials of
  * PackageEnv (Render.hh:24-32), as pointers + counts.  All pointers are HOST
  * pointers; trc_upload_scene copies, the caller keeps ownership. */
@@ -327,6 +348,21 @@ trc_status trc_debug_profile(trc_ctx* ctx, uint64_t* out, uint32_t n_pairs);
 /* device info for the bench line */
 trc_status trc_device_info(trc_ctx* ctx, char* name, size_t name_len, int* cu_count, size_t* hbm_bytes);
 
+/* --- SPPM pass (RT_Metal/Metal/Photon.metal, host sequencing AAPLRenderer.mm:860-1086) ------------
+ * Uses the scene / camera / frame (canvas RNG + accumulator) of the context. */
+/* allocates the 512x512 photon records, photon RNG texture (seeded like trc_seed), per-pixel camera
+ * records and the hash grids; resets Complex (frame_count = 0, totalPhotonSum = 0) */
+trc_status trc_sppm_init(trc_ctx* ctx, uint64_t photon_seed);
+/* n_frames x `photon:` (AAPLRenderer.mm:1077-1086): frame 0 runs photonPrepare (camera records, their
+ * bounding box, hash scale, initial radius), every frame photonWork (odd frames re-run the camera pass,
+ * photon bounce, hashing, mark/count grid, photon sum, progressive refine into the accumulator) */
+trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames);
+/* any pointer may be NULL.  mark: 4 floats per cell as texturePhotonMark (x, y of the winning photon,
+ * cell x, y; -1 when empty), count: 1 float per cell as texturePhotonCount */
+trc_status trc_sppm_download(trc_ctx* ctx, trc_CameraRecord* camera_records /* W*H */,
+                             trc_PhotonRecord* photon_records /* 512*512 */, float* mark /* 512*512*4 */,
+                             float* count /* 512*512 */, trc_Complex* complex);
+
 /* --- multi-GPU: pixel tiles sharded over ranks, one RCCL reduce -------- */
 #define TRC_UNIQUE_ID_BYTES 128
 /* rank 0 creates the id, every rank gets the same bytes out-of-band */
@@ -436,5 +472,12 @@ TRC_SA(sizeof(trc_Complex) == 96 && offsetof(trc_Complex, frame_count) == 20 && 
        offsetof(trc_Complex, photonBoxSize) == 64 && offsetof(trc_Complex, photonInitialRadius) == 80 &&
        offsetof(trc_Complex, framePhotonSum) == 92, "Complex");
 TRC_SA(sizeof(trc_ray) == 32, "trc_ray");
+TRC_SA(sizeof(trc_PhotonRecord) == 80 && offsetof(trc_PhotonRecord, normal) == 16 && offsetof(trc_PhotonRecord, position) == 32 &&
+       offsetof(trc_PhotonRecord, direction) == 48 && offsetof(trc_PhotonRecord, step) == 64 &&
+       offsetof(trc_PhotonRecord, active) == 65, "PhotonRecord");
+TRC_SA(sizeof(trc_CameraRecord) == 112 && offsetof(trc_CameraRecord, position) == 16 && offsetof(trc_CameraRecord, direction) == 32 &&
+       offsetof(trc_CameraRecord, valid) == 48 && offsetof(trc_CameraRecord, alternative) == 64 &&
+       offsetof(trc_CameraRecord, flux) == 80 && offsetof(trc_CameraRecord, radius) == 96 &&
+       offsetof(trc_CameraRecord, photonCount) == 100, "CameraRecord");
 
 #endif /* TRACER_ABI_H */

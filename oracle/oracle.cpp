@@ -1158,6 +1158,307 @@ void render_pixel(const trc_scene& prims, const trc_Camera* camera, const Env& e
     texel[0] = rr; texel[1] = gg; texel[2] = bb; texel[3] = aa;
 }
 
+// ================================================================ SPPM (Photon.metal, Photon.hh)
+// Photon.hh:57-69
+inline float ph_mod(float x, float y) { return x - y * floorf(x / y); }
+// Photon.hh:71-89: float-only Lehmer-style hash of a cell index into [0, N*N)
+inline float ph_hash(const V3 idx, const float HashScale, const float BufInfo) {
+    const float HashNum = BufInfo * BufInfo;
+    float n[4] = {idx.x, idx.y, idx.z, idx.x + idx.y - idx.z};
+    const float q[4] = {1225.0f, 1585.0f, 2457.0f, 2098.0f};
+    const float r[4] = {1112.0f, 367.0f, 92.0f, 265.0f};
+    const float a[4] = {3423.0f, 2646.0f, 1707.0f, 1999.0f};
+    const float m[4] = {4194287.0f, 4194277.0f, 4194191.0f, 4194167.0f};
+    float nm[4];
+    for (int k = 0; k < 4; ++k) {
+        float nk = n[k] * 4194304.0f / HashScale;
+        float beta = floorf(nk / q[k]);
+        float pk = a[k] * (nk - beta * q[k]) - beta * r[k];
+        float sgn = (-pk > 0.0f) ? 1.0f : ((-pk < 0.0f) ? -1.0f : 0.0f);      // sign(-p)
+        beta = (sgn + 1.0f) * 0.5f * m[k];
+        nk = pk + beta;
+        nm[k] = nk / m[k];
+    }
+    float d = ((nm[0] * 1.0f + nm[1] * -1.0f) + nm[2] * 1.0f) + nm[3] * -1.0f;   // dot(n/m, (1,-1,1,-1))
+    float fr = d - floorf(d);                                                       // fract
+    return floorf(fr * HashNum);
+}
+// Sampling.hh:55-60
+inline V3 UniformSampleHemisphere(const V2& u) {
+    float z = u[0];
+    float r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+    float phi = 2 * PI_F * u[1];
+    return v3(r * m_cos(phi), r * m_sin(phi), z);
+}
+
+struct CamRec {     // Photon.hh:30-53
+    V3 ratio = v3(1), position = v3(0), direction = v3(0);
+    bool valid = false;
+    V3 alternative = v3(0), flux = v3(0);
+    float radius = 0;
+    uint32_t photonCount = 0;
+    void reset() { ratio = v3(1); position = v3(0); direction = v3(0); valid = false; flux = v3(0); radius = 0; photonCount = 0; }
+};
+struct PhoRec {     // Photon.hh:12-28
+    V3 flux = v3(1), normal = v3(0), position = v3(0), direction = v3(0);
+    uint8_t step = 0;
+    bool active = false;
+    void reset() { flux = v3(1); step = 0; active = false; }
+};
+
+// Photon.metal:3-92
+bool traceCameraRecord(int depth, Ray& ray, RandomSampler& xsampler, CamRec& cr, const Env& env, Scene& scene) {
+    HitRecord hitRecord;
+    cr.valid = false;
+    V3 ratio = v3(1.0f);
+    bool hitted = scene.hit(ray, hitRecord, FLT_MAX);
+    do {
+        if (!hitted) { cr.alternative = ratio * env.ambient; return false; }
+        const trc_Material& material = env.materials[hitRecord.material];
+        if (material.type == TRC_MAT_DIFFUSE) {
+            V3 le = v3(material.textureInfo.albedo);
+            float w = dot(-ray.direction, -hitRecord.gn);
+            cr.alternative = ratio * le * fabsf(w);
+            return false;
+        }
+        if (!material.specular) {
+            cr.valid = true; cr.ratio = ratio; cr.position = hitRecord.p; cr.direction = ray.direction;
+            return true;
+        }
+        V3 nx, ny;
+        CoordinateSystem(hitRecord.sn, nx, ny);
+        V3 wi = v3(0); float bxPDF = 0;
+        V3 minus_d = -ray.direction;
+        V3 wo = v3(dot(nx, minus_d), dot(ny, minus_d), dot(hitRecord.sn, minus_d));
+        V2 uu = xsampler.sample2D();
+        V3 attenuation = Material_S_F(material, wo, wi, hitRecord.uv, uu, bxPDF);
+        if (bxPDF <= 0) break;
+        V3 pn = hitRecord.sn * copysignf(1.0f, wi.z);
+        V3 _origin = offset_ray(hitRecord.p, pn);
+        ray.update(_origin, (nx * wi.x + ny * wi.y) + hitRecord.sn * wi.z);
+        ratio = ratio * (attenuation / fmaxf(FLT_EPSILON, bxPDF));
+        if (std::isinf(ratio.x) || std::isinf(ratio.y) || std::isinf(ratio.z) ||
+            std::isnan(ratio.x) || std::isnan(ratio.y) || std::isnan(ratio.z)) ratio = v3(1.0f);
+        hitted = scene.hit(ray, hitRecord, FLT_MAX);
+    } while ((--depth) > 0);
+    cr.alternative = v3(0);
+    return false;
+}
+
+// Photon.metal:220-285
+void tracePhotonRecord(Ray& ray, RandomSampler& xsampler, PhoRec& pr, const Env& env, Scene& scene) {
+    HitRecord hitRecord;
+    V3 ratio = v3(1.0f);
+    bool hitted = scene.hit(ray, hitRecord, FLT_MAX);
+    const trc_Material& material = env.materials[hitRecord.material];
+    if (!hitted || material.type == TRC_MAT_DIFFUSE) { pr.reset(); return; }
+    V3 nx, ny;
+    CoordinateSystem(hitRecord.sn, nx, ny);
+    V3 wi = v3(0); float bxPDF = 0;
+    V3 minus_d = -ray.direction;
+    V3 wo = v3(dot(nx, minus_d), dot(ny, minus_d), dot(hitRecord.sn, minus_d));
+    V2 uu = xsampler.sample2D();
+    V3 attenuation = Material_S_F(material, wo, wi, hitRecord.uv, uu, bxPDF);
+    if (bxPDF <= 0) { pr.reset(); return; }
+    ratio = ratio * (attenuation / fmaxf(FLT_EPSILON, bxPDF));
+    {
+        float p = RGBToY(ratio);
+        if (xsampler.random() > p) { pr.reset(); return; }
+        ratio = ratio * (1.0f / p);
+    }
+    V3 pn = hitRecord.sn * copysignf(1.0f, wi.z);
+    pr.position = offset_ray(hitRecord.p, pn);
+    pr.normal = pn;
+    pr.direction = (nx * wi.x + ny * wi.y) + hitRecord.sn * wi.z;
+    pr.flux = pr.flux * ratio;
+    pr.step += 1;
+    pr.active = !material.specular;
+}
+
+struct SppmState {
+    uint32_t W = 0, H = 0;
+    std::vector<CamRec> cam;
+    std::vector<PhoRec> pho;
+    std::vector<uint32_t> photon_rng;        // 512*512*4
+    std::vector<int32_t> mark;               // winning photon index per cell, -1 = empty
+    std::vector<uint32_t> count;
+    // Complex (Camera.hh:27-55)
+    uint32_t frame_count = 0;
+    V3 box_min = v3(0), box_max = v3(0), box_size = v3(0);
+    float initial_radius = 0, hash_scale = 0, total_photon_sum = 0;
+    uint32_t frame_photon_sum = 0;
+};
+const uint32_t kHashN = TRC_PHOTON_HASHN;
+
+inline pcg32_t toRNG(const uint32_t* t) {          // Render.hh:96-107 (same word swap as the path kernel, B-1)
+    uint64_t rng_state = ((uint64_t)t[0] << 32) | t[1];
+    uint64_t rng_inc = ((uint64_t)t[2] << 32) | t[3];
+    return pcg32_t{rng_inc, rng_state};
+}
+inline void exRNG(const pcg32_t& rng, uint32_t* t) {   // Render.hh:109-120
+    t[0] = (uint32_t)(rng.state >> 32); t[1] = (uint32_t)rng.state;
+    t[2] = (uint32_t)(rng.inc >> 32);   t[3] = (uint32_t)rng.inc;
+}
+
+// kernelCameraRecording, Photon.metal:96-167
+void sppm_camera_pass(SppmState& st, const trc_scene& prims, const trc_Camera* camera, const Env& env, uint32_t* canvas_rng) {
+    Scene scene{prims, nullptr};
+    for (uint32_t y = 0; y < st.H; ++y)
+        for (uint32_t x = 0; x < st.W; ++x) {
+            uint32_t* texel = canvas_rng + 4 * ((size_t)y * st.W + x);
+            pcg32_t rng = toRNG(texel);
+            float u = (float)x / (float)st.W, v = (float)y / (float)st.H;
+            RandomSampler rs{&rng};
+            Ray ray = castRay(camera, u, v, &rs);
+            CamRec& slot = st.cam[(size_t)y * st.W + x];
+            CamRec cr = slot;
+            int depth = 8;
+            if (st.frame_count == 0) { cr.reset(); depth = 3; }
+            traceCameraRecord(depth, ray, rs, cr, env, scene);
+            slot = cr;
+            exRNG(rng, texel);
+        }
+}
+
+// kernelCameraReducing + kernelPhotonParams + kernelPhotonRadius, Photon.metal:169-218,357-384
+void sppm_prepare_params(SppmState& st) {
+    V3 lo = v3(FLT_MAX), hi = v3(-FLT_MAX);        // AABB over the valid camera records (min/max are exact)
+    for (const CamRec& c : st.cam)
+        if (c.valid) {
+            lo = v3(fminf(lo.x, c.position.x), fminf(lo.y, c.position.y), fminf(lo.z, c.position.z));
+            hi = v3(fmaxf(hi.x, c.position.x), fmaxf(hi.y, c.position.y), fmaxf(hi.z, c.position.z));
+        }
+    st.box_min = lo; st.box_max = hi;
+    st.box_size = hi - lo;
+    st.initial_radius = dot(st.box_size, v3(1.0f / 3.0f));
+    st.initial_radius *= 2.5f / (1 << 12);
+    st.box_min = st.box_min - v3(st.initial_radius);
+    st.box_max = st.box_max + v3(st.initial_radius);
+    st.hash_scale = 1.0f / (st.initial_radius * 1.5f);
+    for (CamRec& c : st.cam) c.radius = st.initial_radius;
+}
+
+// kernelPhotonRecording, Photon.metal:286-355
+void sppm_photon_pass(SppmState& st, const trc_scene& prims, const Env& env) {
+    Scene scene{prims, nullptr};
+    for (uint32_t idx = 0; idx < kHashN * kHashN; ++idx) {
+        PhoRec pc = st.pho[idx];
+        uint32_t* texel = &st.photon_rng[4 * (size_t)idx];
+        pcg32_t rng = toRNG(texel);
+        RandomSampler rs{&rng};
+        Ray ray;
+        bool check = (st.frame_count == 0) || (pc.step == 0) || (pc.step == 8);
+        if (check) {   // ray from the light source
+            pc.reset();
+            LightSampleRecord lsr;
+            V2 uu = rs.sample2D();
+            V3 _origin = v3(450, 250, 250);
+            if (rs.random() < 1) square_sample(prims.squareList[5], uu, _origin, lsr);
+            else square_sample(prims.squareList[6], uu, _origin, lsr);
+            pc.flux = v3(env.materials[lsr.material].textureInfo.albedo) * 100000.0f;
+            V3 nx, ny;
+            CoordinateSystem(lsr.n, nx, ny);
+            uu = rs.sample2D();
+            V3 h = UniformSampleHemisphere(uu);
+            ray = Ray(lsr.p, (nx * h.x + ny * h.y) + lsr.n * h.z);
+        } else {
+            ray = Ray(pc.position, pc.direction);
+        }
+        tracePhotonRecord(ray, rs, pc, env, scene);
+        st.pho[idx] = pc;
+        exRNG(rng, texel);
+    }
+}
+
+// kernelPhotonHashing + the point raster PhotonMarkVS/FS + kernelPhotonSumming, Photon.metal:386-496.
+// Raster semantics: a point at the integer corner (hx, hy) lands in texel (hx-1, hy-1) -- the texel
+// kernelPhotonRefine reads back (:556-558); the last primitive in API order wins the mark (= the
+// highest photon index), the count blends additively; inactive photons are clipped (z = -1).
+void sppm_hash_pass(SppmState& st) {
+    std::fill(st.mark.begin(), st.mark.end(), -1);
+    std::fill(st.count.begin(), st.count.end(), 0u);
+    for (uint32_t idx = 0; idx < kHashN * kHashN; ++idx) {
+        const PhoRec& p = st.pho[idx];
+        V3 HashIndex = (p.position - st.box_min) * st.hash_scale;
+        HashIndex = v3(floorf(HashIndex.x), floorf(HashIndex.y), floorf(HashIndex.z));
+        float hashed = ph_hash(HashIndex, st.hash_scale, (float)kHashN);
+        float hx = ph_mod(hashed, (float)kHashN), hy = floorf(hashed / (float)kHashN);
+        if (!p.active) continue;
+        float tx = hx - 1.0f, ty = hy - 1.0f;
+        if (!(tx >= 0.0f && tx < (float)kHashN && ty >= 0.0f && ty < (float)kHashN)) continue;
+        uint32_t cell = (uint32_t)ty * kHashN + (uint32_t)tx;
+        st.mark[cell] = std::max(st.mark[cell], (int32_t)idx);
+        st.count[cell] += 1;
+    }
+    uint32_t sum = 0;
+    for (uint32_t c : st.count) if (c > 0) sum += std::max(1u, c);
+    st.frame_photon_sum += sum;
+}
+
+// kernelPhotonRefine, Photon.metal:498-623
+void sppm_refine_pass(SppmState& st, float* accum) {
+    const float fN = (float)kHashN;
+    for (size_t i = 0; i < (size_t)st.W * st.H; ++i) {
+        CamRec& c = st.cam[i];
+        float* px = accum + 4 * i;
+        const float frame = (float)st.frame_count, frame1 = (float)(st.frame_count + 1);
+        V3 cache = v3(px[0], px[1], px[2]);
+        if (!c.valid) {
+            V3 result = (cache * frame + c.alternative) / frame1;
+            px[0] = result.x; px[1] = result.y; px[2] = result.z; px[3] = 1.0f;
+            continue;
+        }
+        V3 QueryPosition = c.position, QueryDirection = c.direction, QueryFlux = c.flux, QueryReflectance = c.ratio;
+        float QueryRadius = c.radius;
+        uint32_t QueryPhotonCount = c.photonCount;
+        V3 BBoxMin = st.box_min;
+        float HashScale = st.hash_scale;
+        V3 RangeMin = vabs(QueryPosition - v3(QueryRadius) - BBoxMin) * HashScale;
+        V3 RangeMax = vabs(QueryPosition + v3(QueryRadius) - BBoxMin) * HashScale;
+        V3 _Flux = v3(0); uint32_t _PhotonCount = 0;
+        for (int iz = (int)RangeMin.z; iz <= (int)RangeMax.z; iz++)
+            for (int iy = (int)RangeMin.y; iy <= (int)RangeMax.y; iy++)
+                for (int ix = (int)RangeMin.x; ix <= (int)RangeMax.x; ix++) {
+                    V3 hashIndex = v3((float)ix, (float)iy, (float)iz);
+                    float hashed = ph_hash(hashIndex, HashScale, fN);
+                    float hx = ph_mod(hashed, fN) - 1.0f, hy = floorf(hashed / fN) - 1.0f;
+                    // _marksHashGrid.read((uint2)(hx, hy)): out-of-range reads return 0 -> photon (0,0), count 0
+                    int32_t winner; float Correction;
+                    if (hx >= 0.0f && hx < fN && hy >= 0.0f && hy < fN) {
+                        uint32_t cell = (uint32_t)hy * kHashN + (uint32_t)hx;
+                        winner = st.mark[cell];
+                        Correction = (float)st.count[cell];
+                        if (winner < 0) continue;                                    // PhotonIndex2D.x < 0
+                    } else { winner = 0; Correction = 0.0f; }
+                    const PhoRec& ph = st.pho[(size_t)winner];
+                    V3 _RangeMin = hashIndex / HashScale + BBoxMin;
+                    V3 _RangeMax = (hashIndex + v3(1.0f)) / HashScale + BBoxMin;
+                    if ((_RangeMin.x < ph.position.x) && (ph.position.x < _RangeMax.x) &&
+                        (_RangeMin.y < ph.position.y) && (ph.position.y < _RangeMax.y) &&
+                        (_RangeMin.z < ph.position.z) && (ph.position.z < _RangeMax.z)) {
+                        float d = length(ph.position - QueryPosition);
+                        if ((d < QueryRadius) && (-dot(QueryDirection, ph.direction) > 0.001f)) {
+                            _Flux = _Flux + ph.flux * Correction;
+                            _PhotonCount = (uint32_t)((float)_PhotonCount + Correction);
+                        }
+                    }
+                }
+        _Flux = _Flux * (QueryReflectance / 3.141592f);
+        const float alpha = 0.8f;
+        float g = fminf(((float)QueryPhotonCount + (float)_PhotonCount * alpha) / (float)(QueryPhotonCount + _PhotonCount), 1.0f);
+        QueryRadius = QueryRadius * sqrtf(g);
+        QueryPhotonCount = (uint32_t)((float)QueryPhotonCount + (float)_PhotonCount * alpha);
+        QueryFlux = (QueryFlux + _Flux) * g;
+        c.flux = QueryFlux; c.radius = QueryRadius; c.photonCount = QueryPhotonCount;
+        float TotalPhotonNum = st.total_photon_sum;
+        TotalPhotonNum += (float)st.frame_photon_sum;
+        V3 color = QueryFlux / (QueryRadius * QueryRadius * 3.141592f * TotalPhotonNum);
+        V3 result = (cache * frame + color) / frame1;
+        if (std::isnan(result.x) || std::isnan(result.y) || std::isnan(result.z)) result = v3(0);
+        px[0] = result.x; px[1] = result.y; px[2] = result.z; px[3] = 1.0f;
+    }
+}
+
 inline void fill_hit(trc_hit& o, bool hit, const HitRecord& rec, float tmax_after, uint32_t nd, uint32_t nr, uint32_t nl) {
     memset(&o, 0, sizeof o);
     o.hit = hit ? 1 : 0;
@@ -1317,5 +1618,80 @@ float orc_math(int fn, float a, float b) {
         default: return 0.0f;
     }
 }
+
+// ---------------------------------------------------------------- SPPM C API
+struct orc_sppm { SppmState st; };
+
+orc_sppm* orc_sppm_create(uint32_t W, uint32_t H, uint64_t photon_seed) {
+    orc_sppm* s = new orc_sppm();
+    s->st.W = W; s->st.H = H;
+    s->st.cam.resize((size_t)W * H);
+    s->st.pho.resize((size_t)kHashN * kHashN);
+    s->st.photon_rng.resize((size_t)kHashN * kHashN * 4);
+    s->st.mark.assign((size_t)kHashN * kHashN, -1);
+    s->st.count.assign((size_t)kHashN * kHashN, 0);
+    for (uint64_t p = 0; p < (uint64_t)kHashN * kHashN; ++p) {      // same as trc_host_fill_rng
+        pcg32_t r; pcg32_srandom_r(&r, photon_seed, p);
+        for (int c = 0; c < 4; ++c) s->st.photon_rng[4 * p + c] = pcg32_random_r(&r);
+    }
+    return s;
+}
+void orc_sppm_destroy(orc_sppm* s) { delete s; }
+
+// `photon:` (AAPLRenderer.mm:1077-1086) for n_frames frames
+void orc_sppm_frames(orc_sppm* s, const trc_scene* scene, const trc_Camera* camera, const float env_rgb[3],
+                     uint32_t* canvas_rng, float* accum, uint32_t n_frames) {
+    SppmState& st = s->st;
+    Env env{scene->materials, v3(env_rgb[0], env_rgb[1], env_rgb[2])};
+    for (uint32_t f = 0; f < n_frames; ++f) {
+        if (st.frame_count == 0) {              // photonPrepare (view != nil)
+            sppm_camera_pass(st, *scene, camera, env, canvas_rng);
+            sppm_prepare_params(st);
+        }
+        if (st.frame_count % 2) sppm_camera_pass(st, *scene, camera, env, canvas_rng);   // photonPrepare:nil
+        sppm_photon_pass(st, *scene, env);
+        sppm_hash_pass(st);
+        sppm_refine_pass(st, accum);
+        st.total_photon_sum += (float)st.frame_photon_sum;      // completion handler, :1031-1036
+        st.frame_photon_sum = 0;
+        st.frame_count += 1;
+    }
+}
+
+void orc_sppm_download(const orc_sppm* s, trc_CameraRecord* cam, trc_PhotonRecord* pho, float* mark, float* count,
+                       trc_Complex* cx) {
+    const SppmState& st = s->st;
+    auto put = [](trc_float3& d, const V3& v) { d.x = v.x; d.y = v.y; d.z = v.z; d._pad = 0; };
+    if (cam) for (size_t i = 0; i < st.cam.size(); ++i) {
+        const CamRec& c = st.cam[i]; trc_CameraRecord& o = cam[i];
+        memset(&o, 0, sizeof o);
+        put(o.ratio, c.ratio); put(o.position, c.position); put(o.direction, c.direction);
+        o.valid = c.valid; put(o.alternative, c.alternative); put(o.flux, c.flux);
+        o.radius = c.radius; o.photonCount = c.photonCount;
+    }
+    if (pho) for (size_t i = 0; i < st.pho.size(); ++i) {
+        const PhoRec& p = st.pho[i]; trc_PhotonRecord& o = pho[i];
+        memset(&o, 0, sizeof o);
+        put(o.flux, p.flux); put(o.normal, p.normal); put(o.position, p.position); put(o.direction, p.direction);
+        o.step = p.step; o.active = p.active;
+    }
+    if (mark) for (size_t c = 0; c < st.mark.size(); ++c) {
+        if (st.mark[c] < 0) { mark[4 * c] = mark[4 * c + 1] = mark[4 * c + 2] = mark[4 * c + 3] = -1.0f; }
+        else {
+            mark[4 * c] = (float)(st.mark[c] % kHashN); mark[4 * c + 1] = (float)(st.mark[c] / kHashN);
+            mark[4 * c + 2] = (float)(c % kHashN); mark[4 * c + 3] = (float)(c / kHashN);
+        }
+    }
+    if (count) for (size_t c = 0; c < st.count.size(); ++c) count[c] = (float)st.count[c];
+    if (cx) {
+        memset(cx, 0, sizeof *cx);
+        cx->frame_count = st.frame_count;
+        put(cx->photonBox.mini, st.box_min); put(cx->photonBox.maxi, st.box_max); put(cx->photonBoxSize, st.box_size);
+        cx->photonInitialRadius = st.initial_radius; cx->photonHashScale = st.hash_scale;
+        cx->totalPhotonSum = st.total_photon_sum; cx->framePhotonSum = st.frame_photon_sum;
+        cx->tex_size.x = cx->view_size.x = (float)st.W; cx->tex_size.y = cx->view_size.y = (float)st.H;
+    }
+}
+float orc_photon_hash(const float idx[3], float hash_scale) { return ph_hash(v3a(idx), hash_scale, (float)kHashN); }
 
 }  // extern "C"

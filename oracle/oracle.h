@@ -63,6 +63,16 @@ float orc_erfinv(float x);                                                      
 int   orc_aabb_hit_t(const trc_AABB* box, const trc_ray* ray, float tmin, float tmax, float* t_out); /* AABB.hh:92-112 */
 void  orc_cast_ray(const trc_Camera* cam, float s, float t, uint64_t* state, uint64_t inc,
                    float origin_out[3], float dir_out[3]);                               /* Camera.hh:59-69 */
+/* SPPM pass (Photon.metal 3-623; host sequencing AAPLRenderer.mm:860-1086), single-threaded */
+typedef struct orc_sppm orc_sppm;
+orc_sppm* orc_sppm_create(uint32_t width, uint32_t height, uint64_t photon_seed);
+void      orc_sppm_destroy(orc_sppm* s);
+void      orc_sppm_frames(orc_sppm* s, const trc_scene* scene, const trc_Camera* camera, const float env_rgb[3],
+                          uint32_t* canvas_rng, float* accum, uint32_t n_frames);
+void      orc_sppm_download(const orc_sppm* s, trc_CameraRecord* cam, trc_PhotonRecord* pho, float* mark,
+                            float* count, trc_Complex* complex);
+float     orc_photon_hash(const float idx[3], float hash_scale);                         /* Photon.hh:71-89 */
+
 /* deterministic math under test (identity wrappers over trc_detmath.h / libm) */
 float orc_math(int fn, float a, float b);   /* 0 sin 1 cos 2 exp 3 log 4 pow 5 asin 6 acos 7 atan2 */
 

@@ -63,6 +63,18 @@ def lib(libm=False):
         L.orc_cast_ray.argtypes = [C.POINTER(abi.Camera), C.c_float, C.c_float, C.POINTER(C.c_uint64), C.c_uint64,
                                    f3, f3]
         L.orc_cast_ray.restype = None
+        L.orc_sppm_create.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64]
+        L.orc_sppm_create.restype = C.c_void_p
+        L.orc_sppm_destroy.argtypes = [C.c_void_p]
+        L.orc_sppm_destroy.restype = None
+        L.orc_sppm_frames.argtypes = [C.c_void_p, C.POINTER(abi.Scene), C.POINTER(abi.Camera), f3, C.c_void_p,
+                                      C.c_void_p, C.c_uint32]
+        L.orc_sppm_frames.restype = None
+        L.orc_sppm_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.POINTER(abi.Complex)]
+        L.orc_sppm_download.restype = None
+        L.orc_photon_hash.argtypes = [f3, C.c_float]
+        L.orc_photon_hash.restype = C.c_float
         L.orc_math.argtypes = [C.c_int, C.c_float, C.c_float]
         L.orc_math.restype = C.c_float
         _LIBS[key] = L
@@ -111,3 +123,41 @@ def render(scene_view, camera, width, height, rng, accum=None, spp=1, max_depth=
     lib(libm).orc_render(C.byref(scene_view), C.byref(camera), env_c, width, height, rng.ctypes.data,
                          accum.ctypes.data, C.byref(prm), C.byref(stats), n_threads)
     return accum, stats
+
+
+CAMREC_DTYPE = np.dtype([("ratio", np.float32, 4), ("position", np.float32, 4), ("direction", np.float32, 4),
+                         ("valid", np.uint8), ("_pad0", np.uint8, 15), ("alternative", np.float32, 4),
+                         ("flux", np.float32, 4), ("radius", np.float32), ("photonCount", np.uint32),
+                         ("_pad1", np.uint32, 2)])
+PHOTON_DTYPE = np.dtype([("flux", np.float32, 4), ("normal", np.float32, 4), ("position", np.float32, 4),
+                         ("direction", np.float32, 4), ("step", np.uint8), ("active", np.uint8), ("_pad", np.uint8, 14)])
+assert CAMREC_DTYPE.itemsize == 112 and PHOTON_DTYPE.itemsize == 80
+
+
+class Sppm:
+    """SPPM pass on the CPU oracle (Photon.metal); canvas rng / accum are updated in place."""
+
+    def __init__(self, width, height, photon_seed):
+        self.W, self.H = width, height
+        self._h = lib().orc_sppm_create(width, height, photon_seed)
+
+    def frames(self, scene_view, camera, rng, accum, n_frames=1, env=(0.0, 0.0, 0.0)):
+        assert rng.dtype == np.uint32 and rng.shape == (self.H, self.W, 4) and rng.flags.c_contiguous
+        assert accum.dtype == np.float32 and accum.shape == (self.H, self.W, 4) and accum.flags.c_contiguous
+        lib().orc_sppm_frames(self._h, C.byref(scene_view), C.byref(camera), (C.c_float * 3)(*env), rng.ctypes.data,
+                              accum.ctypes.data, n_frames)
+
+    def download(self):
+        n = abi.PHOTON_HASHN
+        cam = np.zeros(self.W * self.H, dtype=CAMREC_DTYPE)
+        pho = np.zeros(n * n, dtype=PHOTON_DTYPE)
+        mark = np.zeros((n, n, 4), dtype=np.float32)
+        count = np.zeros((n, n), dtype=np.float32)
+        cx = abi.Complex()
+        lib().orc_sppm_download(self._h, cam.ctypes.data, pho.ctypes.data, mark.ctypes.data, count.ctypes.data, C.byref(cx))
+        return cam, pho, mark, count, cx
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_sppm_destroy(self._h)
+            self._h = None

@@ -1,0 +1,74 @@
+"""GPU parity of the SPPM pass (Photon.metal, BASELINE config 5) against the CPU oracle: camera records,
+photon records, the mark/count hash grids, Complex, the canvas RNG texture and the refined frame -- bit for bit.
+The reference's point-raster "last writer wins" is deterministic here (highest photon index = last primitive
+in API order), so no statistical tolerance is needed."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tracer_amd import abi, host
+
+pytestmark = pytest.mark.gpu
+
+CAM_FIELDS = ["ratio", "position", "direction", "valid", "alternative", "flux", "radius", "photonCount"]
+PHO_FIELDS = ["flux", "normal", "position", "direction", "step", "active"]
+
+
+def bits_equal(a, b):
+    if a.dtype == np.float32:
+        return np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    return np.array_equal(a, b)
+
+
+def run_both(gpu, scene, W, H, n_frames, canvas_seed=5, photon_seed=77):
+    cam = host.prepare_camera(W, H)
+    gpu.upload_scene(scene.view)
+    gpu.set_camera(cam)
+    gpu.set_environment((0.0, 0.0, 0.0))
+    gpu.resize(W, H)
+    gpu.seed(canvas_seed)
+    gpu.sppm_init(photon_seed)
+    gpu.sppm_frames(n_frames)
+    dev = gpu.sppm_download()
+    dev_acc, dev_rng = gpu.download_accum(), gpu.download_rng()
+    rng = host.fill_rng(canvas_seed, W, H)
+    acc = np.zeros((H, W, 4), np.float32)
+    s = po.Sppm(W, H, photon_seed)
+    s.frames(scene.view, cam, rng, acc, n_frames)
+    return dev, dev_acc, dev_rng, s.download(), acc, rng
+
+
+@pytest.mark.parametrize("n_frames", [1, 4])
+def test_sppm_bit_exact(gpu, cornell_spheres, n_frames):
+    (dcam, dpho, dmark, dcount, dcx), dacc, drng, (ocam, opho, omark, ocount, ocx), oacc, orng = run_both(
+        gpu, cornell_spheres, 96, 54, n_frames)
+    assert ocam["valid"].mean() > 0.3 and opho["active"].mean() > 0.1 and (ocount > 0).sum() > 1000
+    for f in ["frame_count", "photonInitialRadius", "photonHashScale", "totalPhotonSum", "framePhotonSum"]:
+        assert getattr(dcx, f) == getattr(ocx, f), f
+    for ax in "xyz":
+        assert getattr(dcx.photonBox.mini, ax) == getattr(ocx.photonBox.mini, ax)
+        assert getattr(dcx.photonBox.maxi, ax) == getattr(ocx.photonBox.maxi, ax)
+    for f in PHO_FIELDS:
+        assert bits_equal(dpho[f], opho[f]), f"photon {f}"
+    assert np.array_equal(dcount, ocount) and np.array_equal(dmark, omark)
+    for f in CAM_FIELDS:
+        assert bits_equal(dcam[f], ocam[f]), f"camera record {f}"
+    assert np.array_equal(drng, orng)
+    assert np.array_equal(dacc.view(np.uint32), oacc.view(np.uint32))
+    assert oacc[..., :3].max() > 0
+
+
+def test_sppm_mesh_scene(gpu, ball_mesh_scene):
+    (dcam, dpho, dmark, dcount, dcx), dacc, drng, (ocam, opho, omark, ocount, ocx), oacc, orng = run_both(
+        gpu, ball_mesh_scene, 64, 40, 2)
+    assert np.array_equal(dcount, ocount) and np.array_equal(dmark, omark)
+    for f in PHO_FIELDS:
+        assert bits_equal(dpho[f], opho[f]), f
+    assert np.array_equal(dacc.view(np.uint32), oacc.view(np.uint32))
+
+
+def test_sppm_requires_init(gpu, cornell_spheres):
+    from tracer_amd.device import TracerError
+    gpu.resize(32, 32)               # releases any SPPM state
+    with pytest.raises(TracerError):
+        gpu.sppm_frames(1)

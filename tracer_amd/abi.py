@@ -97,6 +97,27 @@ class Camera(C.Structure):
                 ("vertical", float3), ("horizontal", float3), ("cornerLowLeft", float3)]
 
 
+class PhotonRecord(C.Structure):
+    _fields_ = [("flux", float3), ("normal", float3), ("position", float3), ("direction", float3),
+                ("step", C.c_uint8), ("active", C.c_uint8), ("_pad", C.c_uint8 * 14)]
+
+
+class CameraRecord(C.Structure):
+    _fields_ = [("ratio", float3), ("position", float3), ("direction", float3),
+                ("valid", C.c_uint8), ("_pad0", C.c_uint8 * 15), ("alternative", float3), ("flux", float3),
+                ("radius", C.c_float), ("photonCount", C.c_uint32), ("_pad1", C.c_uint32 * 2)]
+
+
+class Complex(C.Structure):
+    _fields_ = [("tex_size", float2), ("view_size", float2), ("running_time", C.c_float),
+                ("frame_count", C.c_uint32), ("_pad0", C.c_uint32 * 2), ("photonBox", AABB),
+                ("photonBoxSize", float3), ("photonInitialRadius", C.c_float), ("photonHashScale", C.c_float),
+                ("totalPhotonSum", C.c_float), ("framePhotonSum", C.c_uint32)]
+
+
+PHOTON_HASHN = 512
+
+
 class Scene(C.Structure):
     _fields_ = [("bvhList", C.POINTER(BVH)), ("n_bvh", C.c_uint32),
                 ("sphereList", C.POINTER(Sphere)), ("n_sphere", C.c_uint32),
@@ -137,7 +158,8 @@ class Stats(C.Structure):
 
 
 _EXPECTED_SIZES = {float2: 8, float3: 16, float4x4: 64, AABB: 32, BVH: 64, Sphere: 272, Square: 272, Cube: 240,
-                   TriangleVertex: 32, TextureInfo: 32, Material: 64, Camera: 176, Ray: 32, Params: 32}
+                   TriangleVertex: 32, TextureInfo: 32, Material: 64, Camera: 176, Ray: 32, Params: 32,
+                   PhotonRecord: 80, CameraRecord: 112, Complex: 96}
 for _t, _n in _EXPECTED_SIZES.items():
     assert C.sizeof(_t) == _n, f"{_t.__name__}: ctypes size {C.sizeof(_t)} != ABI size {_n}"
 
@@ -147,6 +169,7 @@ DEVICE_SYMBOLS = [
     "trc_upload_scene", "trc_set_camera", "trc_set_environment", "trc_resize", "trc_seed",
     "trc_upload_rng", "trc_download_rng", "trc_upload_accum", "trc_download_accum", "trc_clear_accum",
     "trc_render", "trc_synchronize", "trc_trace_rays", "trc_get_stats", "trc_reset_stats", "trc_debug_profile",
+    "trc_sppm_init", "trc_sppm_frames", "trc_sppm_download",
     "trc_device_info", "trc_group_unique_id", "trc_group_init", "trc_group_reduce_accum", "trc_group_finalize",
 ]
 HOST_SYMBOLS = [

@@ -26,6 +26,7 @@ struct Shade {            // what the integrators need from the material table
 };
 TRC_DEV int mat_type(const Shade& sh, uint32_t m) { return (int)sh.mats[m * kMaterialDwords]; }
 TRC_DEV int mat_tex(const Shade& sh, uint32_t m) { return (int)sh.mats[m * kMaterialDwords + 1]; }
+TRC_DEV bool mat_specular(const Shade& sh, uint32_t m) { return sh.mats[m * kMaterialDwords + 5] != 0u; }
 TRC_DEV F3 mat_albedo(const Shade& sh, uint32_t m) {
     const uint32_t* p = sh.mats + m * kMaterialDwords;
     return f3(__uint_as_float(p[2]), __uint_as_float(p[3]), __uint_as_float(p[4]));

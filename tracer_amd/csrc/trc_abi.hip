@@ -16,62 +16,7 @@
 #include <string>
 #include <vector>
 
-#include "tracer_abi.h"
-#include "dev_integrator.hpp"
-
-using namespace trcdev;
-
-// ======================================================================= kernels
-extern __shared__ __attribute__((aligned(16))) uint32_t trc_smem[];
-
-struct KScene {
-    DScene sc;
-    float root_box[6];
-};
-
-struct KRender {
-    KScene ks;
-    DCamera cam;
-    float ambient[3];
-    DFrame fr;
-    uint32_t spp, max_depth, frame0, _pad;
-    const uint32_t* tiles;              // tx | ty << 16, one per workgroup
-    unsigned long long* stats;          // kStatCount counters
-};
-
-struct KTrace {
-    KScene ks;
-    const trc_ray* rays;
-    trc_hit* hits;
-    uint32_t n;
-};
-
-// cooperative copy of the blob prefix (prims, materials, top fat nodes) into LDS
-__device__ __forceinline__ const uint32_t* stage_scene(const DScene& sc) {
-    const uint4* src = reinterpret_cast<const uint4*>(sc.blob);
-    uint4* dst = reinterpret_cast<uint4*>(trc_smem);
-    const uint32_t n16 = sc.lds_dwords >> 2;
-    for (uint32_t i = threadIdx.x; i < n16; i += kBlock) dst[i] = src[i];
-    __syncthreads();
-    return trc_smem;
-}
-
-__device__ __forceinline__ SceneRef make_scene_ref(const DScene& sc, const uint32_t* small_base) {
-    SceneRef S;
-    S.small_base = small_base;
-    S.blob = sc.blob;
-    S.off_nodes = sc.off_nodes; S.off_spheres = sc.off_spheres; S.off_squares = sc.off_squares;
-    S.off_cubes = sc.off_cubes; S.off_materials = sc.off_materials;
-    S.off_tripos = sc.off_tripos; S.off_triattr = sc.off_triattr;
-    S.n_lds_nodes = sc.n_lds_nodes;
-    return S;
-}
-
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+#include "trc_ctx.hpp"
 
 // deterministic stand-in for fillRNG (AAPLRenderer.mm:296-344): texel p = 4 outputs of
 // pcg32_srandom_r(seed, p)
@@ -274,58 +219,9 @@ Rccl g_rccl;
 
 }  // namespace
 
-struct trc_ctx {
-    int device = -1;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    std::string error;
-
-    // scene
-    bool has_scene = false;
-    KScene ks{};
-    uint32_t* d_blob = nullptr;
-    size_t blob_bytes = 0;
-    bool lds_scene = false;
-
-    bool has_camera = false;
-    DCamera cam{};
-    float ambient[3] = {0, 0, 0};
-
-    // frame
-    uint32_t width = 0, height = 0;
-    uint32_t* d_rng = nullptr;
-    float* d_accum = nullptr;
-
-    // tiles for (nranks, rank)
-    uint32_t* d_tiles = nullptr;
-    uint32_t n_tiles = 0, tiles_nranks = 0, tiles_rank = 0;
-
-    // stats
-    unsigned long long* d_stats = nullptr;
-    uint64_t launches = 0;
-    double kernel_ms = 0.0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // per-launch event pairs not yet read
-    std::vector<hipEvent_t> event_pool;
-
-    // RCCL
-    void* comm = nullptr;
-    int nranks = 1, rank = 0;
-    float* d_reduce_recv = nullptr;
-};
-
 namespace {
 
-trc_status fail(trc_ctx* ctx, trc_status s, const std::string& msg) {
-    if (ctx) ctx->error = msg;
-    return s;
-}
-#define HIP_TRY(ctx, expr)                                                                 \
-    do {                                                                                   \
-        hipError_t e_ = (expr);                                                            \
-        if (e_ != hipSuccess)                                                              \
-            return fail(ctx, e_ == hipErrorOutOfMemory ? TRC_ERR_OOM : TRC_ERR_HIP,         \
-                        std::string(#expr) + ": " + hipGetErrorString(e_));                \
-    } while (0)
+inline trc_status fail(trc_ctx* ctx, trc_status st, const std::string& msg) { return trc_fail(ctx, st, msg); }
 
 hipEvent_t get_event(trc_ctx* ctx) {
     if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
@@ -481,6 +377,7 @@ trc_status build_blob(trc_ctx* ctx, const trc_scene* s, std::vector<uint32_t>& b
         uint32_t* q = &blob[sc.off_materials + (size_t)i * kMaterialDwords];
         q[0] = (uint32_t)m.type; q[1] = (uint32_t)m.textureInfo.type;
         q[2] = f2u(m.textureInfo.albedo.x); q[3] = f2u(m.textureInfo.albedo.y); q[4] = f2u(m.textureInfo.albedo.z);
+        q[5] = m.specular ? 1u : 0u;
     }
     for (uint32_t t = 0; t < n_tri; ++t) {
         const trc_TriangleVertex* v[3] = {&s->triList[s->idxList[3 * t]], &s->triList[s->idxList[3 * t + 1]],
@@ -519,11 +416,30 @@ std::vector<uint32_t> make_tiles(uint32_t W, uint32_t H, uint32_t nranks, uint32
     return out;
 }
 
-size_t dyn_lds_bytes(const trc_ctx* ctx, bool stats) {
+}  // namespace
+
+size_t trc_dyn_lds_bytes(const trc_ctx* ctx, bool stats) {
     const DScene& sc = ctx->ks.sc;
     size_t dwords = sc.lds_dwords + (size_t)sc.stack_depth * kBlock * (stats ? 2u : 1u);
     return dwords * 4;
 }
+
+trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank) {
+    if (ctx->d_tiles && ctx->tiles_nranks == nranks && ctx->tiles_rank == rank) return TRC_OK;
+    std::vector<uint32_t> tiles = make_tiles(ctx->width, ctx->height, nranks, rank);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(ctx->d_tiles); ctx->d_tiles = nullptr;
+    ctx->n_tiles = (uint32_t)tiles.size();
+    if (ctx->n_tiles) {
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tiles, tiles.size() * 4));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_tiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    ctx->tiles_nranks = nranks; ctx->tiles_rank = rank;
+    return TRC_OK;
+}
+
+namespace {
 
 template <bool LDS>
 void launch_render(trc_ctx* ctx, const KRender& kp, bool stats, uint32_t integrator, size_t lds) {
@@ -587,6 +503,7 @@ void trc_destroy(trc_ctx* ctx) {
     if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
+    trc_sppm_release(ctx);
     collect_events(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     (void)hipFree(ctx->d_blob); (void)hipFree(ctx->d_rng); (void)hipFree(ctx->d_accum);
@@ -639,6 +556,7 @@ trc_status trc_resize(trc_ctx* ctx, uint32_t width, uint32_t height) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     (void)hipFree(ctx->d_rng); (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_reduce_recv);
     ctx->d_rng = nullptr; ctx->d_accum = nullptr; ctx->d_tiles = nullptr; ctx->d_reduce_recv = nullptr;
+    trc_sppm_release(ctx);          // per-pixel camera records depend on the frame size
     ctx->n_tiles = 0; ctx->tiles_nranks = 0;
     ctx->width = ctx->height = 0;
     const size_t n = (size_t)width * height;
@@ -696,22 +614,11 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
     if (p->spp == 0) return TRC_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
-    if (!ctx->d_tiles || ctx->tiles_nranks != nranks || ctx->tiles_rank != p->tile_rank) {
-        std::vector<uint32_t> tiles = make_tiles(ctx->width, ctx->height, nranks, p->tile_rank);
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        (void)hipFree(ctx->d_tiles); ctx->d_tiles = nullptr;
-        ctx->n_tiles = (uint32_t)tiles.size();
-        if (ctx->n_tiles) {
-            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tiles, tiles.size() * 4));
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->d_tiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        }
-        ctx->tiles_nranks = nranks; ctx->tiles_rank = p->tile_rank;
-    }
+    { trc_status ts = trc_ensure_tiles(ctx, nranks, p->tile_rank); if (ts != TRC_OK) return ts; }
     if (ctx->n_tiles == 0) return TRC_OK;
 
     const bool stats = (p->flags & TRC_FLAG_COLLECT_STATS) != 0;
-    const size_t lds = dyn_lds_bytes(ctx, stats);
+    const size_t lds = trc_dyn_lds_bytes(ctx, stats);
     if (lds > 160 * 1024) return fail(ctx, TRC_ERR_UNSUPPORTED, "traversal stack exceeds the 160 KB LDS of a CU");
 
     KRender kp{};
@@ -757,7 +664,7 @@ trc_status trc_trace_rays(trc_ctx* ctx, const trc_ray* rays, size_t n, trc_hit* 
         if (hipMemcpyAsync(d_rays, rays, n * sizeof(trc_ray), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { st = fail(ctx, TRC_ERR_HIP, "H2D rays"); break; }
         KTrace kp{};
         kp.ks = ctx->ks; kp.rays = d_rays; kp.hits = d_hits; kp.n = (uint32_t)n;
-        const size_t lds = dyn_lds_bytes(ctx, true);
+        const size_t lds = trc_dyn_lds_bytes(ctx, true);
         dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
         if (ctx->lds_scene) {
             if (any_hit) hipLaunchKernelGGL((k_trace<true, true>), grid, block, lds, ctx->stream, kp);

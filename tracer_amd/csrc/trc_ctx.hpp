@@ -1,0 +1,129 @@
+// trc_ctx.hpp -- pieces shared by the translation units of libtracer_amd.so (trc_abi.hip, trc_sppm.hip):
+// kernel-side scene staging helpers, the context struct and the error helpers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "tracer_abi.h"
+#include "dev_integrator.hpp"
+
+using namespace trcdev;
+
+// ======================================================================= kernels
+extern __shared__ __attribute__((aligned(16))) uint32_t trc_smem[];
+
+struct KScene {
+    DScene sc;
+    float root_box[6];
+};
+
+struct KRender {
+    KScene ks;
+    DCamera cam;
+    float ambient[3];
+    DFrame fr;
+    uint32_t spp, max_depth, frame0, _pad;
+    const uint32_t* tiles;              // tx | ty << 16, one per workgroup
+    unsigned long long* stats;          // kStatCount counters
+};
+
+struct KTrace {
+    KScene ks;
+    const trc_ray* rays;
+    trc_hit* hits;
+    uint32_t n;
+};
+
+// cooperative copy of the blob prefix (prims, materials, top fat nodes) into LDS
+__device__ __forceinline__ const uint32_t* stage_scene(const DScene& sc) {
+    const uint4* src = reinterpret_cast<const uint4*>(sc.blob);
+    uint4* dst = reinterpret_cast<uint4*>(trc_smem);
+    const uint32_t n16 = sc.lds_dwords >> 2;
+    for (uint32_t i = threadIdx.x; i < n16; i += kBlock) dst[i] = src[i];
+    __syncthreads();
+    return trc_smem;
+}
+
+__device__ __forceinline__ SceneRef make_scene_ref(const DScene& sc, const uint32_t* small_base) {
+    SceneRef S;
+    S.small_base = small_base;
+    S.blob = sc.blob;
+    S.off_nodes = sc.off_nodes; S.off_spheres = sc.off_spheres; S.off_squares = sc.off_squares;
+    S.off_cubes = sc.off_cubes; S.off_materials = sc.off_materials;
+    S.off_tripos = sc.off_tripos; S.off_triattr = sc.off_triattr;
+    S.n_lds_nodes = sc.n_lds_nodes;
+    return S;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+
+// ======================================================================= context
+struct SppmState;   // trc_sppm.hip
+
+struct trc_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    std::string error;
+
+    // scene
+    bool has_scene = false;
+    KScene ks{};
+    uint32_t* d_blob = nullptr;
+    size_t blob_bytes = 0;
+    bool lds_scene = false;
+
+    bool has_camera = false;
+    DCamera cam{};
+    float ambient[3] = {0, 0, 0};
+
+    // frame
+    uint32_t width = 0, height = 0;
+    uint32_t* d_rng = nullptr;
+    float* d_accum = nullptr;
+
+    // tiles for (nranks, rank)
+    uint32_t* d_tiles = nullptr;
+    uint32_t n_tiles = 0, tiles_nranks = 0, tiles_rank = 0;
+
+    // stats
+    unsigned long long* d_stats = nullptr;
+    uint64_t launches = 0;
+    double kernel_ms = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // per-launch event pairs not yet read
+    std::vector<hipEvent_t> event_pool;
+
+    // RCCL
+    void* comm = nullptr;
+    int nranks = 1, rank = 0;
+    float* d_reduce_recv = nullptr;
+
+    SppmState* sppm = nullptr;       // trc_sppm.hip
+};
+
+
+inline trc_status trc_fail(trc_ctx* ctx, trc_status s, const std::string& msg) {
+    if (ctx) ctx->error = msg;
+    return s;
+}
+#define HIP_TRY(ctx, expr)                                                                 \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return trc_fail(ctx, e_ == hipErrorOutOfMemory ? TRC_ERR_OOM : TRC_ERR_HIP,     \
+                            std::string(#expr) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+// tiles owned by `rank` of `nranks` (XCD-aware order) uploaded into ctx->d_tiles; shared by render and SPPM
+trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank);
+size_t trc_dyn_lds_bytes(const trc_ctx* ctx, bool stats);
+void trc_sppm_release(trc_ctx* ctx);   // frees ctx->sppm (no-op when absent)

@@ -56,6 +56,9 @@ def lib():
         L.trc_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
         L.trc_reset_stats.argtypes = [vp]
         L.trc_debug_profile.argtypes = [vp, C.POINTER(C.c_uint64), u32]
+        L.trc_sppm_init.argtypes = [vp, u64]
+        L.trc_sppm_frames.argtypes = [vp, u32]
+        L.trc_sppm_download.argtypes = [vp, vp, vp, vp, vp, C.POINTER(abi.Complex)]
         L.trc_device_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
         L.trc_group_unique_id.argtypes = [C.POINTER(C.c_uint8)]
         L.trc_group_init.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int, C.c_int]
@@ -189,6 +192,26 @@ class Tracer:
         cu, mem = C.c_int(), C.c_size_t()
         self._check(self._L.trc_device_info(self._h, name, 256, C.byref(cu), C.byref(mem)), "trc_device_info")
         return {"name": name.value.decode(), "cu_count": cu.value, "hbm_bytes": mem.value}
+
+    # --- SPPM pass (Photon.metal) -----------------------------------------------------
+    def sppm_init(self, photon_seed):
+        self._check(self._L.trc_sppm_init(self._h, photon_seed), "trc_sppm_init")
+
+    def sppm_frames(self, n_frames=1):
+        self._check(self._L.trc_sppm_frames(self._h, n_frames), "trc_sppm_frames")
+
+    def sppm_download(self):
+        """(camera records, photon records, mark grid, count grid, Complex) in the reference's layouts"""
+        from .dtypes import CAMREC_DTYPE, PHOTON_DTYPE
+        n = abi.PHOTON_HASHN
+        cam = np.zeros(self.width * self.height, dtype=CAMREC_DTYPE)
+        pho = np.zeros(n * n, dtype=PHOTON_DTYPE)
+        mark = np.zeros((n, n, 4), dtype=np.float32)
+        count = np.zeros((n, n), dtype=np.float32)
+        cx = abi.Complex()
+        self._check(self._L.trc_sppm_download(self._h, cam.ctypes.data, pho.ctypes.data, mark.ctypes.data,
+                                              count.ctypes.data, C.byref(cx)), "trc_sppm_download")
+        return cam, pho, mark, count, cx
 
     # --- multi-GPU -------------------------------------------------------------------
     def group_init(self, unique_id, nranks, rank):

@@ -20,3 +20,12 @@ def make_rays(origins, directions, tmax=None):
     rays["direction"] = directions
     rays["tmax"] = np.float32(np.finfo(np.float32).max) if tmax is None else tmax
     return rays
+
+
+CAMREC_DTYPE = np.dtype([("ratio", np.float32, 4), ("position", np.float32, 4), ("direction", np.float32, 4),
+                         ("valid", np.uint8), ("_pad0", np.uint8, 15), ("alternative", np.float32, 4),
+                         ("flux", np.float32, 4), ("radius", np.float32), ("photonCount", np.uint32),
+                         ("_pad1", np.uint32, 2)])
+PHOTON_DTYPE = np.dtype([("flux", np.float32, 4), ("normal", np.float32, 4), ("position", np.float32, 4),
+                         ("direction", np.float32, 4), ("step", np.uint8), ("active", np.uint8), ("_pad", np.uint8, 14)])
+assert CAMREC_DTYPE.itemsize == C.sizeof(abi.CameraRecord) and PHOTON_DTYPE.itemsize == C.sizeof(abi.PhotonRecord)
