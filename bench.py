@@ -90,12 +90,30 @@ def pmc_traffic(world):
     return t.get("hbm_bytes_per_launch")
 
 
+def _with_c_stdout_on_stderr(fn):
+    """Run fn() with file descriptor 1 pointing at stderr, flushing C stdio before restoring it."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    sys.stdout.flush()
+    libc.fflush(None)
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        fn()
+    finally:
+        libc.fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-group", action="store_true",
+                    help="exercise the gloo rendezvous + RCCL compose path even with one rank (plumbing check)")
     args = ap.parse_args()
 
     import torch  # plumbing only: rendezvous / barrier / max-over-ranks; loaded first so ONE HIP runtime is used
@@ -108,10 +126,12 @@ def main():
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     dist = None
-    if world > 1:
+    grouped = world > 1 or args.force_group
+    if grouped:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        _with_c_stdout_on_stderr(lambda: dist.init_process_group("gloo", rank=rank, world_size=world))
 
     from tracer_amd import abi, host
     from tracer_amd.device import Tracer, group_unique_id
@@ -123,10 +143,17 @@ def main():
     trc.set_camera(cam)
     trc.set_environment((0.0, 0.0, 0.0))
     trc.resize(W, H)
-    if world > 1:
+    if grouped:
         ids = [group_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
-        trc.group_init(ids[0], world, rank)
+
+        def init_comm():
+            trc.group_init(ids[0], world, rank)
+            trc.clear_accum()
+            trc.group_reduce_accum(0)        # first collective: RCCL finishes its lazy set-up here
+            trc.synchronize()
+        # RCCL prints a version banner through C stdio on fd 1; keep stdout clean for the single JSON line
+        _with_c_stdout_on_stderr(init_comm)
 
     def barrier():
         trc.synchronize()
@@ -136,12 +163,12 @@ def main():
             dist.barrier()
 
     def step(collect_stats=False):
-        if world > 1:
+        if grouped:
             trc.clear_accum()            # non-owned tiles must be zero for the sum-compose
         trc.seed(SEED)
         trc.render(spp=SPP, max_depth=DEPTH, integrator=abi.INTEGRATOR_PATH, frame0=0, tile_rank=rank,
                    tile_nranks=world, collect_stats=collect_stats)
-        if world > 1:
+        if grouped:
             trc.group_reduce_accum(0)
 
     # exact algorithmic work of ONE step on this rank (instrumented kernel, untimed)
@@ -189,7 +216,7 @@ def main():
                        "integrator": "tracePath", "rays_per_step": int(rays_total / args.steps),
                        "paths_per_step": W * H * SPP, "mpaths_per_s": round(W * H * SPP * args.steps / dt_max / 1e6, 2),
                        "tiles": f"16x16 px, owner (tx+ty)%{world}", "device": info["name"],
-                       "compose": "ncclReduce(sum) of the RGBA32F frame to rank 0" if world > 1 else "none"},
+                       "compose": "ncclReduce(sum) of the RGBA32F frame to rank 0" if grouped else "none"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(world),
                          "kernel": "k_render", "kernel_ms": round(kernel_ms, 3),
@@ -200,12 +227,16 @@ def main():
             line["cpu_baseline"] = cpu_baseline(scene, cam)
             line["cpu_rt_weekend"] = cpu_rt_weekend()
         print(json.dumps(line), flush=True)
+    sys.stdout.flush()
 
-    if world > 1:
-        trc.group_finalize()
-        dist.barrier()
-        dist.destroy_process_group()
-    trc.close()
+    def teardown():
+        if grouped:
+            trc.group_finalize()
+            dist.barrier()
+            dist.destroy_process_group()
+        trc.close()
+    _with_c_stdout_on_stderr(teardown)
+    os.dup2(2, 1)       # anything native code still prints at exit goes to stderr, after the JSON line
 
 
 if __name__ == "__main__":

@@ -243,3 +243,24 @@ def test_committed_golden_frames(gpu):
         st = gpu.stats()
         counts = [st.paths, st.rays, st.shaded, st.n_descend, st.n_return, st.n_leaf_sphere, st.n_leaf_square, st.n_leaf_cube]
         assert counts == list(frames[name + "_counts"]), name
+
+
+def test_rccl_group_single_rank_roundtrip(gpu, cornell_spheres):
+    """trc_group_* with a 1-rank communicator: ncclGetUniqueId / ncclCommInitRank / ncclReduce(sum, root 0) /
+    ncclCommDestroy resolve and run (RCCL is dlopen'ed); a 1-rank sum-reduce must leave the frame unchanged."""
+    from tracer_amd.device import group_unique_id
+    W, H = 64, 48
+    gpu.upload_scene(cornell_spheres.view)
+    gpu.set_camera(host.prepare_camera(W, H))
+    gpu.resize(W, H)
+    gpu.seed(3)
+    gpu.render(spp=2)
+    before = gpu.download_accum()
+    uid = group_unique_id()
+    assert len(uid) == abi.TRC_UNIQUE_ID_BYTES and any(uid)
+    gpu.group_init(uid, 1, 0)
+    gpu.group_reduce_accum(0)
+    gpu.synchronize()
+    after = gpu.download_accum()
+    gpu.group_finalize()
+    assert np.array_equal(before.view(np.uint32), after.view(np.uint32))

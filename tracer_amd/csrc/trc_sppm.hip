@@ -43,6 +43,7 @@ struct KSppm {
     uint32_t* mark;          // winning photon index + 1 per cell, 0 = empty
     uint32_t* count;
     DComplex* cx;
+    unsigned long long* stats;   // ctx counters: rays += Scene::hit calls of the camera and photon passes
 };
 
 // order-preserving float <-> uint mapping for atomicMin/atomicMax
@@ -112,7 +113,8 @@ __device__ __forceinline__ SppmCtx make_sppm_ctx(const KSppm& kp, const uint32_t
     return cx;
 }
 template <bool ALL_LDS>
-__device__ __forceinline__ bool sppm_hit(const SppmCtx& cx, const Ray& ray, HitRec& rec) {
+__device__ __forceinline__ bool sppm_hit(const SppmCtx& cx, const Ray& ray, HitRec& rec, uint32_t& n_rays) {
+    n_rays++;
     TravCounters cnt;    // dead in non-instrumented instantiations
     return scene_hit<ALL_LDS, false, false, false>(cx.S, cx.root_min, cx.root_max, ray, rec, FLT_MAX, cx.stack, cx.lvstack, cnt);
 }
@@ -126,7 +128,8 @@ __global__ void __launch_bounds__(kBlock) k_sppm_camera(const KSppm kp) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t px = (tile & 0xFFFFu) * TRC_TILE + (wave & 1u) * 8u + (lane & 7u);
     const uint32_t py = (tile >> 16) * TRC_TILE + (wave >> 1) * 8u + (lane >> 3);
-    if (px >= kp.W || py >= kp.H) return;
+    uint32_t n_rays = 0;
+    if (px < kp.W && py < kp.H) {
     const size_t pix = (size_t)py * kp.W + px;
 
     Pcg rng = to_rng(reinterpret_cast<const uint4*>(kp.canvas_rng)[pix]);
@@ -148,7 +151,7 @@ __global__ void __launch_bounds__(kBlock) k_sppm_camera(const KSppm kp) {
         HitRec rec;
         hit_init(rec);
         F3 ratio = f3(1.0f);
-        bool hitted = sppm_hit<ALL_LDS>(cx, ray, rec);
+        bool hitted = sppm_hit<ALL_LDS>(cx, ray, rec, n_rays);
         bool finished = false;
         do {
             if (!hitted) { cr_alternative = ratio * cx.ambient; finished = true; break; }
@@ -176,7 +179,7 @@ __global__ void __launch_bounds__(kBlock) k_sppm_camera(const KSppm kp) {
             ray = make_ray(_origin, (nx * wi.x + ny * wi.y) + rec.sn * wi.z);
             ratio = ratio * (attenuation / fmaxf(FLT_EPSILON, bxPDF));
             if (is_inf(ratio.x) || is_inf(ratio.y) || is_inf(ratio.z) || is_nan(ratio.x) || is_nan(ratio.y) || is_nan(ratio.z)) ratio = f3(1.0f);
-            hitted = sppm_hit<ALL_LDS>(cx, ray, rec);
+            hitted = sppm_hit<ALL_LDS>(cx, ray, rec, n_rays);
         } while ((--depth) > 0);
         if (!finished) cr_alternative = f3(0);
     }
@@ -191,6 +194,9 @@ __global__ void __launch_bounds__(kBlock) k_sppm_camera(const KSppm kp) {
         atomicMin(&kp.cx->key_min[1], f2key(cr_position.y)); atomicMax(&kp.cx->key_max[1], f2key(cr_position.y));
         atomicMin(&kp.cx->key_min[2], f2key(cr_position.z)); atomicMax(&kp.cx->key_max[2], f2key(cr_position.z));
     }
+    }
+    const uint32_t r = wave_sum(n_rays);
+    if (lane == 0 && r) atomicAdd(&kp.stats[kStatRays], (unsigned long long)r);
 }
 
 // kernelPhotonParams, Photon.metal:357-372
@@ -221,8 +227,8 @@ template <bool ALL_LDS>
 __global__ void __launch_bounds__(kBlock) k_sppm_photon(const KSppm kp) {
     const uint32_t* small_base = stage_scene(kp.ks.sc);
     const SppmCtx cx = make_sppm_ctx(kp, small_base);
-    const uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
-    if (idx >= kHashN * kHashN) return;
+    const uint32_t idx = blockIdx.x * kBlock + threadIdx.x;     // grid covers exactly 512*512 photons
+    uint32_t n_rays = 0;
     trc_PhotonRecord& slot = kp.pho_rec[idx];
     F3 flux = ld3(slot.flux), normal = ld3(slot.normal), position = ld3(slot.position), direction = ld3(slot.direction);
     uint32_t step = slot.step;
@@ -251,7 +257,7 @@ __global__ void __launch_bounds__(kBlock) k_sppm_photon(const KSppm kp) {
         HitRec rec;
         hit_init(rec);
         F3 ratio = f3(1.0f);
-        const bool hitted = sppm_hit<ALL_LDS>(cx, ray, rec);
+        const bool hitted = sppm_hit<ALL_LDS>(cx, ray, rec, n_rays);
         const int mtype = mat_type(cx.sh, rec.material);
         bool alive = hitted && mtype != kMatDiffuse;
         F3 nx = f3(0), ny = f3(0), wi = f3(0);
@@ -284,6 +290,8 @@ __global__ void __launch_bounds__(kBlock) k_sppm_photon(const KSppm kp) {
     st3(slot.flux, flux); st3(slot.normal, normal); st3(slot.position, position); st3(slot.direction, direction);
     slot.step = (uint8_t)step; slot.active = active ? 1 : 0;
     reinterpret_cast<uint4*>(kp.photon_rng)[idx] = ex_rng(rng);
+    const uint32_t r = wave_sum(n_rays);
+    if ((threadIdx.x & 63u) == 0 && r) atomicAdd(&kp.stats[kStatRays], (unsigned long long)r);
 }
 
 // kernelPhotonHashing + point raster (PhotonMarkVS/FS), Photon.metal:386-456
@@ -475,6 +483,7 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
     kp.tiles = ctx->d_tiles;
     kp.canvas_rng = ctx->d_rng; kp.accum = ctx->d_accum; kp.photon_rng = s->d_photon_rng;
     kp.cam_rec = s->d_cam; kp.pho_rec = s->d_pho; kp.mark = s->d_mark; kp.count = s->d_count; kp.cx = s->d_cx;
+    kp.stats = ctx->d_stats;
     const size_t lds = trc_dyn_lds_bytes(ctx, false);
     const uint32_t np = s->W * s->H, nph = kHashN * kHashN;
     const bool all_lds = ctx->lds_scene;
