@@ -235,8 +235,6 @@ enum trc_integrator {
 /* flags */
 #define TRC_FLAG_COLLECT_STATS  1u  /* run the instrumented kernel variant: exact
                                        N_descend / N_return / leaf-test counters */
-#define TRC_FLAG_SIMPLE_KERNEL  2u  /* force the one-path-per-lane kernel instead of the LDS ray-pool
-                                       kernel (same results bit for bit; used by tests and A/B timing) */
 
 typedef struct trc_params {
     uint32_t spp;                /* samples per pixel this call; the reference does 1 per launch */

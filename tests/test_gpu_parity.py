@@ -264,57 +264,3 @@ def test_rccl_group_single_rank_roundtrip(gpu, cornell_spheres):
     after = gpu.download_accum()
     gpu.group_finalize()
     assert np.array_equal(before.view(np.uint32), after.view(np.uint32))
-
-
-@pytest.mark.parametrize("scene_name,W,H,spp,env", [
-    ("cornell", 160, 90, 8, (0.0, 0.0, 0.0)),
-    ("cornell_spheres", 160, 90, 16, (0.0, 0.0, 0.0)),
-    ("cornell_spheres", 97, 61, 5, (0.5, 0.7, 1.0)),        # ragged tiles + miss branch
-    ("cornell_spheres", 24, 16, 3, (0.0, 0.0, 0.0)),        # fewer pixels than pool slots
-])
-def test_pool_kernel_bit_exact(gpu, request, scene_name, W, H, spp, env):
-    """The LDS ray-pool kernel (default for tracePath on LDS-resident scenes) against the oracle AND against the
-    one-path-per-lane kernel: frame, RNG texture and the always-on counters."""
-    scene = request.getfixturevalue(scene_name)
-    cam = host.prepare_camera(W, H)
-    gpu.upload_scene(scene.view)
-    gpu.set_camera(cam)
-    gpu.set_environment(env)
-    gpu.resize(W, H)
-    outs = []
-    for simple in (False, True):
-        gpu.clear_accum()
-        gpu.seed(99)
-        gpu.reset_stats()
-        gpu.render(spp=spp, simple_kernel=simple)
-        st = gpu.stats()
-        outs.append((gpu.download_accum(), gpu.download_rng(), (st.paths, st.rays, st.shaded)))
-    rng = host.fill_rng(99, W, H)
-    ref, rst = po.render(scene.view, cam, W, H, rng, spp=spp, env=env)
-    for acc, r, counts in outs:
-        assert np.array_equal(r, rng)
-        assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32))
-        assert counts == (rst.paths, rst.rays, rst.shaded)
-
-
-def test_pool_kernel_progressive_frames_and_shards(gpu, cornell_spheres):
-    """frame0 > 0 (running mean over an existing accumulator) and tile sharding through the pool kernel."""
-    W, H = 80, 48
-    cam = host.prepare_camera(W, H)
-    gpu.upload_scene(cornell_spheres.view)
-    gpu.set_camera(cam)
-    gpu.set_environment((0, 0, 0))
-    gpu.resize(W, H)
-    gpu.seed(5)
-    gpu.render(spp=3)
-    gpu.render(spp=2, frame0=3)
-    a = gpu.download_accum()
-    rng = host.fill_rng(5, W, H)
-    ref, _ = po.render(cornell_spheres.view, cam, W, H, rng, spp=5)
-    assert np.array_equal(a.view(np.uint32), ref.view(np.uint32))
-    total = np.zeros_like(a)
-    for r in range(3):
-        gpu.clear_accum(); gpu.seed(5)
-        gpu.render(spp=5, tile_rank=r, tile_nranks=3)
-        total += gpu.download_accum()
-    assert np.array_equal(total.view(np.uint32), ref.view(np.uint32))

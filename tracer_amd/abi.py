@@ -24,7 +24,6 @@ INTEGRATOR_PATH, INTEGRATOR_MIS = 0, 1
 # enum trc_host_scene_kind
 SCENE_CORNELL, SCENE_CORNELL_SPHERES, SCENE_CORNELL_MESH = 0, 1, 2
 FLAG_COLLECT_STATS = 1
-FLAG_SIMPLE_KERNEL = 2
 
 # status codes
 OK = 0

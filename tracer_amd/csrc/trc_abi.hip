@@ -17,7 +17,6 @@
 #include <vector>
 
 #include "trc_ctx.hpp"
-#include "dev_pool.hpp"
 
 // deterministic stand-in for fillRNG (AAPLRenderer.mm:296-344): texel p = 4 outputs of
 // pcg32_srandom_r(seed, p)
@@ -144,203 +143,6 @@ __global__ void __launch_bounds__(kBlock) k_render(const KRender kp) {
                 atomicAdd(&kp.stats[kStatCount + 2 * i + 1], (unsigned long long)rw);
             }
         }
-    }
-}
-
-// The wavefront's pixel supply for the pool kernel: positions of the current 16x16 tile, refilled from the
-// global tile queue.  All members are wave-uniform.
-struct PixelSupply {
-    uint32_t cur_tile, cur_pos;
-    bool tiles_left;
-};
-
-// End of a sample for the lanes with `ended` (Render.metal:537-557), then the next sample of the pixel or the
-// next pixel of the supply, camera ray and root test.  Must be called in wave-uniform control flow.
-// `fresh` lanes own no pixel yet (no accumulation).  Sets next_phase for the `ended` lanes.
-__device__ __forceinline__ void pool_finish_regen(const KRender& kp, const PathCtx& cx, PixelSupply& ps, uint32_t* sl,
-                                                  bool ended, bool fresh, F3 color, Pcg rng, uint32_t meta,
-                                                  PoolCounters& pc, uint32_t& next_phase) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t W = kp.fr.width, H = kp.fr.height;
-    uint32_t pix = 0;
-    uint4 texel = make_uint4(0, 0, 0, 0);      // r, g, b, a
-    bool need_pixel = false;
-    if (ended) {
-        if (fresh) {
-            need_pixel = true;
-        } else {
-            pix = sl[SL_SN + 3];
-            const bool bad = is_inf(color.x) || is_nan(color.x) || is_inf(color.y) || is_nan(color.y) ||
-                             is_inf(color.z) || is_nan(color.z);
-            if (bad) color = f3(0);
-            uint32_t s_done = meta & 0xFFFFu;
-            const uint32_t frame = kp.frame0 + s_done;
-            float4* apx = reinterpret_cast<float4*>(kp.fr.accum) + pix;
-            const float4 acc = *apx;
-            const F3 cached = (f3(acc.x, acc.y, acc.z) * (float)frame + color) / (float)(frame + 1);
-            float4 out; out.x = cached.x; out.y = cached.y; out.z = cached.z; out.w = 1.0f;
-            *apx = out;
-            // write-back of the generator: (r,g) <- state, (b,a) <- inc (Render.metal:545-557)
-            texel.y = (uint32_t)rng.state; texel.x = (uint32_t)(rng.state >> 32);
-            texel.w = (uint32_t)rng.inc;   texel.z = (uint32_t)(rng.inc >> 32);
-            pc.paths++;
-            s_done++;
-            meta = (meta & ~0xFFFFu) | s_done;
-            if (s_done == kp.spp) {
-                reinterpret_cast<uint4*>(kp.fr.rng)[pix] = texel;
-                need_pixel = true;
-            }
-        }
-    }
-    bool done = false;
-    while (__ballot(need_pixel)) {
-        if (ps.cur_pos >= TRC_TILE * TRC_TILE) {
-            uint32_t t = 0;
-            if (ps.tiles_left && lane == 0) t = atomicAdd(kp.queue, 1u);
-            t = __builtin_amdgcn_readfirstlane(t);
-            if (!ps.tiles_left || t >= kp.n_tiles) { ps.tiles_left = false; if (need_pixel) done = true; need_pixel = false; break; }
-            ps.cur_tile = kp.tiles[t];
-            ps.cur_pos = 0;
-        }
-        const unsigned long long m = __ballot(need_pixel);
-        const uint32_t r = mbcnt64(m);
-        const uint32_t avail = TRC_TILE * TRC_TILE - ps.cur_pos;
-        const uint32_t want = (uint32_t)__popcll(m);
-        if (need_pixel && r < avail) {
-            const uint32_t sub = ps.cur_pos + r, l = sub & 63u, w = sub >> 6;
-            const uint32_t px = (ps.cur_tile & 0xFFFFu) * TRC_TILE + (w & 1u) * 8u + (l & 7u);
-            const uint32_t py = (ps.cur_tile >> 16) * TRC_TILE + (w >> 1) * 8u + (l >> 3);
-            if (px < W && py < H) {
-                pix = py * W + px;
-                texel = reinterpret_cast<const uint4*>(kp.fr.rng)[pix];
-                meta = 0;
-                need_pixel = false;
-            }
-        }
-        ps.cur_pos += want < avail ? want : avail;
-    }
-    if (ended) {
-        if (done) {
-            next_phase = PP_DONE;
-        } else {
-            // pcg32_t rng = { rng_inc, rng_state }: the two 64-bit words trade roles every frame (B-1)
-            Pcg g;
-            g.state = ((uint64_t)texel.z << 32) | texel.w;
-            g.inc = ((uint64_t)texel.x << 32) | texel.y;
-            const uint32_t py = pix / W, px = pix - py * W;
-            const float u = (float)px / (float)W, v = (float)py / (float)H;      // no jitter (B-2)
-            const Ray ray = cast_ray(kp.cam, u, v, g);
-            meta = (meta & 0xFFFFu) | ((kp.max_depth & 0xFFu) << 16) | META_PRIMARY;
-            st4(sl + SL_RATIO, 1.0f, 1.0f, 1.0f, meta);
-            pool_store_rng(sl, g);
-            sl[SL_SN + 3] = pix;
-            next_phase = pool_start_ray(cx, sl, ray, pc);
-        }
-    }
-}
-
-// kernelPathTracing with the LDS ray pool of dev_pool.hpp (tracePath, scene fully staged in LDS, depth <= 8).
-// Persistent workgroups; each wavefront owns kPoolSlots path slots and pulls 16x16 pixel tiles from a global
-// queue.  Pixel state (RNG texel, accumulator) lives in HBM and is touched once per pixel (RNG) / once per
-// sample (running mean), exactly the reference's access pattern.
-__global__ void __launch_bounds__(kBlock) k_render_pool(const KRender kp) {
-    const DScene& sc = kp.ks.sc;
-    const uint32_t* small_base = stage_scene(sc);
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t* pool = trc_smem + sc.lds_dwords + wave * (kPoolSlots * kSlotDwords);
-    uint32_t* phase_of = trc_smem + sc.lds_dwords + 4u * (kPoolSlots * kSlotDwords) + wave * kPoolSlots;
-    uint32_t* list = trc_smem + sc.lds_dwords + 4u * (kPoolSlots * kSlotDwords) + 4u * kPoolSlots + wave * kPoolSlots;
-
-    PathCtx cx;
-    cx.S = make_scene_ref(sc, small_base);
-    cx.root_min = f3(kp.ks.root_box[0], kp.ks.root_box[1], kp.ks.root_box[2]);
-    cx.root_max = f3(kp.ks.root_box[3], kp.ks.root_box[4], kp.ks.root_box[5]);
-    cx.sh.mats = small_base + sc.off_materials;
-    cx.ambient = f3(kp.ambient[0], kp.ambient[1], kp.ambient[2]);
-    cx.stack = nullptr; cx.lvstack = nullptr;
-    cx.max_depth = kp.max_depth;
-
-    PoolCounters pc; pc.rays = 0; pc.shaded = 0; pc.paths = 0;
-    uint32_t prof_rounds = 0, prof_lanes = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < kPoolK; ++k) {               // every slot starts in R as "fresh": it asks for a pixel
-        if (lane + 64u * k < kPoolSlots) {
-            phase_of[lane + 64u * k] = PP_R;
-            pool[(lane + 64u * k) * kSlotDwords + SL_RATIO + 3] = META_FRESH;
-        }
-    }
-    PixelSupply ps; ps.cur_tile = 0; ps.cur_pos = TRC_TILE * TRC_TILE; ps.tiles_left = true;
-
-    for (;;) {
-        // ---- phase census of the wavefront's slots (lane l is "home" of slots l, l+64, ...)
-        uint32_t ph[kPoolK];
-#pragma unroll
-        for (uint32_t k = 0; k < kPoolK; ++k) ph[k] = (lane + 64u * k < kPoolSlots) ? phase_of[lane + 64u * k] : (uint32_t)PP_DONE;
-        uint32_t best = PP_DONE, best_n = 0;
-#pragma unroll
-        for (uint32_t p = 0; p < PP_DONE; ++p) {
-            uint32_t n = 0;
-#pragma unroll
-            for (uint32_t k = 0; k < kPoolK; ++k) n += (uint32_t)__popcll(__ballot(ph[k] == p));
-            if (n > best_n) { best_n = n; best = p; }
-        }
-        if (best_n == 0) break;                            // every slot is PP_DONE
-        // ---- list of ALL slots in phase `best`
-        uint32_t base = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < kPoolK; ++k) {
-            const unsigned long long m = __ballot(ph[k] == best);
-            if (ph[k] == best) list[base + mbcnt64(m)] = lane + 64u * k;
-            base += (uint32_t)__popcll(m);
-        }
-        if (lane == best) { prof_rounds++; prof_lanes += best_n; }      // lane p keeps the tally of phase p
-
-        if (best == PP_T) {
-            pool_phase_T(cx, pool, phase_of, list, best_n);
-            continue;
-        }
-        for (uint32_t first = 0; first < best_n; first += 64u) {        // drain the list, 64 slots at a time
-            const bool have = first + lane < best_n;
-            const uint32_t slot = have ? list[first + lane] : 0u;
-            uint32_t* sl = pool + slot * kSlotDwords;
-            uint32_t next_phase = best;
-            if (best == PP_L) {
-                pool_phase_L(cx, sl, have, next_phase);
-            } else {
-                PoolPath p;
-                bool ended = false, fresh = false;
-                F3 result = f3(0.0f);
-                if (have) {
-                    pool_load_path(sl, p);
-                    if (best == PP_R) {
-                        fresh = (p.meta & META_FRESH) != 0u;
-                        if (fresh) ended = true;
-                        else pool_resolve(cx, sl, p, pc, ended, result, next_phase);
-                    } else {                                           // PP_M: the BSDF types one after the other
-                        F2 uu; uu.x = __uint_as_float(sl[SL_UV + 2]); uu.y = __uint_as_float(sl[SL_UV + 3]);
-                        const int mtype = (int)((p.meta >> 26) & 7u);
-                        if (mtype == kMatMetal) ended = pool_shade<kMatMetal>(cx, sl, p, uu, pc, next_phase);
-                        else if (mtype == kMatPlastic) ended = pool_shade<kMatPlastic>(cx, sl, p, uu, pc, next_phase);
-                        else ended = pool_shade<kMatGlass>(cx, sl, p, uu, pc, next_phase);
-                    }
-                } else {
-                    p.rng.state = p.rng.inc = 0; p.meta = 0;
-                }
-                pool_finish_regen(kp, cx, ps, sl, have && ended, fresh, result, p.rng, p.meta, pc, next_phase);
-            }
-            if (have) phase_of[slot] = next_phase;
-        }
-    }
-
-    const uint32_t r_paths = wave_sum(pc.paths), r_rays = wave_sum(pc.rays), r_shaded = wave_sum(pc.shaded);
-    if (lane == 0) {
-        atomicAdd(&kp.stats[kStatPaths], (unsigned long long)r_paths);
-        atomicAdd(&kp.stats[kStatRays], (unsigned long long)r_rays);
-        atomicAdd(&kp.stats[kStatShaded], (unsigned long long)r_shaded);
-    }
-    if (lane < PP_DONE) {       // batch census per phase (trc_debug_profile: lanes, batches)
-        atomicAdd(&kp.stats[kStatCount + 2 * lane], (unsigned long long)prof_lanes);
-        atomicAdd(&kp.stats[kStatCount + 2 * lane + 1], (unsigned long long)prof_rounds);
     }
 }
 
@@ -688,14 +490,10 @@ trc_status trc_create(int device, trc_ctx** out) {
     ctx->device = device;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void**)&ctx->d_stats, sizeof(unsigned long long) * (kStatCount + 2 * kProfCount)) != hipSuccess ||
-        hipMalloc((void**)&ctx->d_queue, 64) != hipSuccess ||
         hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * (kStatCount + 2 * kProfCount), ctx->stream) != hipSuccess) {
         trc_destroy(ctx);
         return TRC_ERR_HIP;
     }
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { trc_destroy(ctx); return TRC_ERR_HIP; }
-    ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     *out = ctx;
     return TRC_OK;
 }
@@ -709,7 +507,7 @@ void trc_destroy(trc_ctx* ctx) {
     collect_events(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     (void)hipFree(ctx->d_blob); (void)hipFree(ctx->d_rng); (void)hipFree(ctx->d_accum);
-    (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_stats); (void)hipFree(ctx->d_reduce_recv); (void)hipFree(ctx->d_queue);
+    (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_stats); (void)hipFree(ctx->d_reduce_recv);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -830,32 +628,12 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
     kp.fr.rng = ctx->d_rng; kp.fr.accum = ctx->d_accum; kp.fr.width = ctx->width; kp.fr.height = ctx->height;
     kp.spp = p->spp; kp.max_depth = p->max_depth; kp.frame0 = p->frame0;
     kp.tiles = ctx->d_tiles;
-    kp.queue = ctx->d_queue;
-    kp.n_tiles = ctx->n_tiles;
     kp.stats = ctx->d_stats;
 
     hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);
     if (!e0 || !e1) return fail(ctx, TRC_ERR_HIP, "hipEventCreate failed");
-    // LDS ray-pool kernel: tracePath on a fully LDS-staged scene whose tree fits the per-slot stack
-    const size_t pool_lds = ((size_t)ctx->ks.sc.lds_dwords + 4u * kPoolSlots * kSlotDwords + 8u * kPoolSlots) * 4u;
-    const bool use_pool = !stats && !(p->flags & TRC_FLAG_SIMPLE_KERNEL) && p->integrator == TRC_INTEGRATOR_PATH &&
-                          ctx->lds_scene && ctx->ks.sc.stack_depth <= kPoolStack && ctx->ks.sc.n_triangles == 0 &&
-                          p->spp <= 0xFFFFu && p->max_depth <= 0xFFu && pool_lds <= 160u * 1024u;
-    if (use_pool) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_pool),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, 4, ctx->stream));
-    }
     HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
-    if (use_pool) {
-        const uint32_t per_cu = std::max<uint32_t>(1u, (uint32_t)((150u * 1024u) / pool_lds));
-        const uint32_t grid = std::min<uint32_t>((uint32_t)ctx->cu_count * per_cu, (ctx->n_tiles + 3u) / 4u);
-        hipLaunchKernelGGL(k_render_pool, dim3(std::max(1u, grid)), dim3(kBlock), pool_lds, ctx->stream, kp);
-    } else if (ctx->lds_scene) launch_render<true>(ctx, kp, stats, p->integrator, lds);
+    if (ctx->lds_scene) launch_render<true>(ctx, kp, stats, p->integrator, lds);
     else launch_render<false>(ctx, kp, stats, p->integrator, lds);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));

@@ -27,9 +27,7 @@ struct KRender {
     float ambient[3];
     DFrame fr;
     uint32_t spp, max_depth, frame0, _pad;
-    const uint32_t* tiles;              // tx | ty << 16, one per workgroup (or per queue entry)
-    uint32_t* queue;                    // pool kernel: next tile of the list (zeroed before every launch)
-    uint32_t n_tiles, _pad2;
+    const uint32_t* tiles;              // tx | ty << 16, one per workgroup
     unsigned long long* stats;          // kStatCount counters
 };
 
@@ -95,8 +93,6 @@ struct trc_ctx {
 
     // tiles for (nranks, rank)
     uint32_t* d_tiles = nullptr;
-    uint32_t* d_queue = nullptr;
-    int cu_count = 0;
     uint32_t n_tiles = 0, tiles_nranks = 0, tiles_rank = 0;
 
     // stats
