@@ -486,8 +486,15 @@ struct Scene {
         uint32_t nd = 0, nr = 0, nl = 0;
         V2 range_t = V2{FLT_MIN, test_t};
         bool result_early = false;
+        // A ray with a NaN / infinite component (randomF == 1.0 makes BeckmannSample11 / TrowbridgeReitzSample11
+        // produce inf -> NaN directions, SURVEY B-4) MISSES the scene.  Metal's fast-math min/max on NaN are
+        // unspecified (B-10); with NaN-ignoring min/max such a ray would "hit" every box and walk the whole
+        // tree (1.3 s for one lane on a 1 M-triangle scene).  The sample's radiance is NaN -> 0 either way.
+        const float finite_probe = fabsf(ray.origin.x) + fabsf(ray.origin.y) + fabsf(ray.origin.z) +
+                                   fabsf(ray.direction.x) + fabsf(ray.direction.y) + fabsf(ray.direction.z);
+        const bool ray_ok = finite_probe < INFINITY;
 
-        if (aabb_hit(bvhList[the_index].bBOX, ray, range_t)) {
+        if (ray_ok && aabb_hit(bvhList[the_index].bBOX, ray, range_t)) {
             do {   // travel in bvh
                 uint32_t selected_index = UINT_MAX;
                 uint32_t left_index = bvhList[the_index].left;

@@ -341,6 +341,10 @@ TRC_DEV bool scene_hit(const SceneRef& S, const F3 root_min, const F3 root_max, 
     if (STATS) cnt.rays++;
     const float rx = FLT_MIN;
     float ry = test_t;
+    // a ray with a NaN / infinite component misses the scene (same rule as oracle/oracle.cpp Scene::hit: B-4/B-10);
+    // without it NaN-ignoring min/max make such a ray "hit" every box of the tree
+    const float finite_probe = fabsf(ray.o.x) + fabsf(ray.o.y) + fabsf(ray.o.z) + fabsf(ray.d.x) + fabsf(ray.d.y) + fabsf(ray.d.z);
+    if (!(finite_probe < __builtin_inff())) return false;
     if (!box_hit(root_min, root_max, ray, rx, ry))
         return false;
 
