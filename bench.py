@@ -223,7 +223,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "bytes_per_ray": round(bytes_per_launch / max(1, rays_per_launch), 1)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # CPU baselines: rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(scene, cam)
             line["cpu_rt_weekend"] = cpu_rt_weekend()
         print(json.dumps(line), flush=True)

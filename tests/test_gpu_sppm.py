@@ -72,3 +72,30 @@ def test_sppm_requires_init(gpu, cornell_spheres):
     gpu.resize(32, 32)               # releases any SPPM state
     with pytest.raises(TracerError):
         gpu.sppm_frames(1)
+
+
+def test_sppm_through_a_one_rank_communicator(gpu, cornell_spheres):
+    """With a communicator the pass takes the multi-GPU route (tile-sharded camera/refine, photon range,
+    ncclAllReduce(min/max) of the bound keys, ncclAllGather of the photon records).  One rank must reproduce the
+    plain single-GPU result bit for bit."""
+    from tracer_amd.device import group_unique_id
+    W, H, n_frames = 80, 48, 3
+    cam = host.prepare_camera(W, H)
+    outs = []
+    for grouped in (False, True):
+        gpu.upload_scene(cornell_spheres.view)
+        gpu.set_camera(cam)
+        gpu.set_environment((0.0, 0.0, 0.0))
+        gpu.resize(W, H)
+        gpu.seed(11)
+        if grouped:
+            gpu.group_init(group_unique_id(), 1, 0)
+        gpu.sppm_init(21)
+        gpu.sppm_frames(n_frames)
+        dcam, dpho, dmark, dcount, dcx = gpu.sppm_download()
+        outs.append((gpu.download_accum(), dpho.copy(), dmark.copy(), dcount.copy(), dcx.totalPhotonSum))
+        if grouped:
+            gpu.group_finalize()
+    a, b = outs
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+    assert a[1].tobytes() == b[1].tobytes() and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and a[4] == b[4]

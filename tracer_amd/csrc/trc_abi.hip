@@ -188,34 +188,6 @@ __global__ void __launch_bounds__(kBlock) k_trace(const KTrace kp) {
 // ======================================================================= host side
 namespace {
 
-// RCCL entry points, resolved at run time so the library loads where RCCL is absent
-struct IdBlob { char internal[TRC_UNIQUE_ID_BYTES]; };   // ncclUniqueId, passed by value
-struct Rccl {
-    void* handle = nullptr;
-    int (*GetUniqueId)(void*) = nullptr;
-    int (*CommInitRank)(void**, int, IdBlob, int) = nullptr;
-    int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
-    int (*CommDestroy)(void*) = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
-};
-
-bool load_rccl(Rccl& r, std::string& err) {
-    if (r.handle) return true;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) {
-        r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (r.handle) break;
-    }
-    if (!r.handle) { err = std::string("dlopen(librccl) failed: ") + dlerror(); return false; }
-    r.GetUniqueId = (int (*)(void*))dlsym(r.handle, "ncclGetUniqueId");
-    r.CommInitRank = (int (*)(void**, int, IdBlob, int))dlsym(r.handle, "ncclCommInitRank");
-    r.Reduce = (int (*)(const void*, void*, size_t, int, int, int, void*, hipStream_t))dlsym(r.handle, "ncclReduce");
-    r.CommDestroy = (int (*)(void*))dlsym(r.handle, "ncclCommDestroy");
-    r.GetErrorString = (const char* (*)(int))dlsym(r.handle, "ncclGetErrorString");
-    if (!r.GetUniqueId || !r.CommInitRank || !r.Reduce || !r.CommDestroy) { err = "librccl: missing symbols"; return false; }
-    return true;
-}
-Rccl g_rccl;
 
 }  // namespace
 
@@ -417,6 +389,31 @@ std::vector<uint32_t> make_tiles(uint32_t W, uint32_t H, uint32_t nranks, uint32
 }
 
 }  // namespace
+
+Rccl g_rccl;
+
+bool trc_load_rccl(std::string& err) {
+    Rccl& r = g_rccl;
+    if (r.handle) return true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (r.handle) break;
+    }
+    if (!r.handle) { err = std::string("dlopen(librccl) failed: ") + dlerror(); return false; }
+    r.GetUniqueId = (int (*)(void*))dlsym(r.handle, "ncclGetUniqueId");
+    r.CommInitRank = (int (*)(void**, int, IdBlob, int))dlsym(r.handle, "ncclCommInitRank");
+    r.Reduce = (int (*)(const void*, void*, size_t, int, int, int, void*, hipStream_t))dlsym(r.handle, "ncclReduce");
+    r.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(r.handle, "ncclAllReduce");
+    r.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(r.handle, "ncclAllGather");
+    r.CommDestroy = (int (*)(void*))dlsym(r.handle, "ncclCommDestroy");
+    r.GetErrorString = (const char* (*)(int))dlsym(r.handle, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.Reduce || !r.AllReduce || !r.AllGather || !r.CommDestroy) {
+        err = "librccl: missing symbols";
+        return false;
+    }
+    return true;
+}
 
 size_t trc_dyn_lds_bytes(const trc_ctx* ctx, bool stats) {
     const DScene& sc = ctx->ks.sc;
@@ -737,7 +734,7 @@ trc_status trc_device_info(trc_ctx* ctx, char* name, size_t name_len, int* cu_co
 trc_status trc_group_unique_id(uint8_t id[TRC_UNIQUE_ID_BYTES]) {
     if (!id) return TRC_ERR_INVALID_ARG;
     std::string err;
-    if (!load_rccl(g_rccl, err)) return TRC_ERR_RCCL;
+    if (!trc_load_rccl(err)) return TRC_ERR_RCCL;
     IdBlob blob;
     std::memset(&blob, 0, sizeof blob);
     if (g_rccl.GetUniqueId(&blob) != 0) return TRC_ERR_RCCL;
@@ -748,7 +745,7 @@ trc_status trc_group_unique_id(uint8_t id[TRC_UNIQUE_ID_BYTES]) {
 trc_status trc_group_init(trc_ctx* ctx, const uint8_t id[TRC_UNIQUE_ID_BYTES], int nranks, int rank) {
     if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return TRC_ERR_INVALID_ARG;
     std::string err;
-    if (!load_rccl(g_rccl, err)) return fail(ctx, TRC_ERR_RCCL, err);
+    if (!trc_load_rccl(err)) return fail(ctx, TRC_ERR_RCCL, err);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->comm) { g_rccl.CommDestroy(ctx->comm); ctx->comm = nullptr; }
     IdBlob blob;

@@ -123,6 +123,23 @@ inline trc_status trc_fail(trc_ctx* ctx, trc_status s, const std::string& msg) {
                             std::string(#expr) + ": " + hipGetErrorString(e_));            \
     } while (0)
 
+// RCCL entry points, resolved at run time (dlopen) so the library loads where RCCL is absent
+struct IdBlob { char internal[TRC_UNIQUE_ID_BYTES]; };   // ncclUniqueId, passed by value
+struct Rccl {
+    void* handle = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, IdBlob, int) = nullptr;
+    int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+extern Rccl g_rccl;
+bool trc_load_rccl(std::string& err);
+// ncclDataType_t / ncclRedOp_t ordinals (rccl.h:448-466)
+constexpr int kNcclUint8 = 1, kNcclUint32 = 3, kNcclFloat = 7, kNcclSum = 0, kNcclMax = 2, kNcclMin = 3;
+
 // tiles owned by `rank` of `nranks` (XCD-aware order) uploaded into ctx->d_tiles; shared by render and SPPM
 trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank);
 size_t trc_dyn_lds_bytes(const trc_ctx* ctx, bool stats);

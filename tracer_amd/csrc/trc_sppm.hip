@@ -33,7 +33,7 @@ struct KSppm {
     KScene ks;
     DCamera cam;
     float ambient[3];
-    uint32_t W, H, frame_count, _pad;
+    uint32_t W, H, frame_count, photon_first;   // photon_first: first photon index of this rank's range
     const uint32_t* tiles;
     uint32_t* canvas_rng;
     float* accum;
@@ -227,7 +227,7 @@ template <bool ALL_LDS>
 __global__ void __launch_bounds__(kBlock) k_sppm_photon(const KSppm kp) {
     const uint32_t* small_base = stage_scene(kp.ks.sc);
     const SppmCtx cx = make_sppm_ctx(kp, small_base);
-    const uint32_t idx = blockIdx.x * kBlock + threadIdx.x;     // grid covers exactly 512*512 photons
+    const uint32_t idx = kp.photon_first + blockIdx.x * kBlock + threadIdx.x;     // grid covers exactly this rank's photon range
     uint32_t n_rays = 0;
     trc_PhotonRecord& slot = kp.pho_rec[idx];
     F3 flux = ld3(slot.flux), normal = ld3(slot.normal), position = ld3(slot.position), direction = ld3(slot.direction);
@@ -322,8 +322,13 @@ __global__ void __launch_bounds__(256) k_sppm_sum(const uint32_t* count, DComple
 
 // kernelPhotonRefine, Photon.metal:498-623
 __global__ void __launch_bounds__(256) k_sppm_refine(const KSppm kp) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= kp.W * kp.H) return;
+    // one workgroup per 16x16 tile of this rank (same tile list as the camera pass)
+    const uint32_t tile = kp.tiles[blockIdx.x];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t qx = (tile & 0xFFFFu) * TRC_TILE + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t qy = (tile >> 16) * TRC_TILE + (wave >> 1) * 8u + (lane >> 3);
+    if (qx >= kp.W || qy >= kp.H) return;
+    const uint32_t i = qy * kp.W + qx;
     trc_CameraRecord& c = kp.cam_rec[i];
     float4* px = reinterpret_cast<float4*>(kp.accum) + i;
     const float4 cached = *px;
@@ -474,19 +479,32 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
     if (ctx->ks.sc.n_squares < 7) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "SPPM emits photons from squareList[5] (Photon.metal:316-320)");
     if (s->W != ctx->width || s->H != ctx->height) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "frame resized after trc_sppm_init");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    { trc_status ts = trc_ensure_tiles(ctx, 1, 0); if (ts != TRC_OK) return ts; }
+    // Multi-GPU: with a communicator (trc_group_init) rank r traces the camera records and refines
+    // the pixels of ITS tiles, and bounces ITS photon index range; the camera-record AABB is all-reduced
+    // (min/max on order-preserving keys: exact) and the photon records are all-gathered every frame so that
+    // every rank hashes the full photon set.  All of it is deterministic: N ranks == 1 rank, bit for bit.
+    const bool grouped = ctx->comm != nullptr;
+    const uint32_t nranks = grouped ? (uint32_t)ctx->nranks : 1u, rank = grouped ? (uint32_t)ctx->rank : 0u;
+    const uint32_t np = s->W * s->H, nph = kHashN * kHashN;
+    if (nph % (nranks * kBlock)) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "512*512 photons must split evenly over the ranks");
+    const uint32_t chunk = nph / nranks;
+    { trc_status ts = trc_ensure_tiles(ctx, nranks, rank); if (ts != TRC_OK) return ts; }
+    if (ctx->n_tiles == 0) return TRC_OK;
 
     KSppm kp{};
     kp.ks = ctx->ks; kp.cam = ctx->cam;
     kp.ambient[0] = ctx->ambient[0]; kp.ambient[1] = ctx->ambient[1]; kp.ambient[2] = ctx->ambient[2];
     kp.W = s->W; kp.H = s->H;
+    kp.photon_first = rank * chunk;
     kp.tiles = ctx->d_tiles;
     kp.canvas_rng = ctx->d_rng; kp.accum = ctx->d_accum; kp.photon_rng = s->d_photon_rng;
     kp.cam_rec = s->d_cam; kp.pho_rec = s->d_pho; kp.mark = s->d_mark; kp.count = s->d_count; kp.cx = s->d_cx;
     kp.stats = ctx->d_stats;
     const size_t lds = trc_dyn_lds_bytes(ctx, false);
-    const uint32_t np = s->W * s->H, nph = kHashN * kHashN;
     const bool all_lds = ctx->lds_scene;
+    auto rccl_fail = [&](const char* what, int rc) {
+        return trc_fail(ctx, TRC_ERR_RCCL, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
+    };
     auto camera_pass = [&]() {
         if (all_lds) hipLaunchKernelGGL((k_sppm_camera<true>), dim3(ctx->n_tiles), dim3(kBlock), lds, ctx->stream, kp);
         else hipLaunchKernelGGL((k_sppm_camera<false>), dim3(ctx->n_tiles), dim3(kBlock), lds, ctx->stream, kp);
@@ -495,17 +513,29 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
         kp.frame_count = s->frame_count;
         if (s->frame_count == 0) {                      // photonPrepare, AAPLRenderer.mm:860-947
             camera_pass();
+            if (grouped) {
+                DComplex* cx = s->d_cx;
+                int rc = g_rccl.AllReduce(cx->key_min, cx->key_min, 3, kNcclUint32, kNcclMin, ctx->comm, ctx->stream);
+                if (rc) return rccl_fail("ncclAllReduce(min)", rc);
+                rc = g_rccl.AllReduce(cx->key_max, cx->key_max, 3, kNcclUint32, kNcclMax, ctx->comm, ctx->stream);
+                if (rc) return rccl_fail("ncclAllReduce(max)", rc);
+            }
             hipLaunchKernelGGL(k_sppm_params, dim3(1), dim3(64), 0, ctx->stream, s->d_cx);
             hipLaunchKernelGGL(k_sppm_radius, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, s->d_cam, np, s->d_cx);
         }
         if (s->frame_count % 2) camera_pass();          // photonWork re-runs the camera pass on odd frames, :953-955
-        if (all_lds) hipLaunchKernelGGL((k_sppm_photon<true>), dim3(nph / kBlock), dim3(kBlock), lds, ctx->stream, kp);
-        else hipLaunchKernelGGL((k_sppm_photon<false>), dim3(nph / kBlock), dim3(kBlock), lds, ctx->stream, kp);
+        if (all_lds) hipLaunchKernelGGL((k_sppm_photon<true>), dim3(chunk / kBlock), dim3(kBlock), lds, ctx->stream, kp);
+        else hipLaunchKernelGGL((k_sppm_photon<false>), dim3(chunk / kBlock), dim3(kBlock), lds, ctx->stream, kp);
+        if (grouped) {                                  // every rank needs every photon for hashing + refine
+            int rc = g_rccl.AllGather(s->d_pho + (size_t)rank * chunk, s->d_pho, (size_t)chunk * sizeof(trc_PhotonRecord),
+                                      kNcclUint8, ctx->comm, ctx->stream);
+            if (rc) return rccl_fail("ncclAllGather(photons)", rc);
+        }
         HIP_TRY(ctx, hipMemsetAsync(s->d_mark, 0, (size_t)nph * 4, ctx->stream));     // loadAction clear, :785-790
         HIP_TRY(ctx, hipMemsetAsync(s->d_count, 0, (size_t)nph * 4, ctx->stream));
         hipLaunchKernelGGL(k_sppm_hash, dim3(nph / 256), dim3(256), 0, ctx->stream, s->d_pho, s->d_mark, s->d_count, s->d_cx);
         hipLaunchKernelGGL(k_sppm_sum, dim3(nph / 256), dim3(256), 0, ctx->stream, s->d_count, s->d_cx);
-        hipLaunchKernelGGL(k_sppm_refine, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, kp);
+        hipLaunchKernelGGL(k_sppm_refine, dim3(ctx->n_tiles), dim3(256), 0, ctx->stream, kp);
         hipLaunchKernelGGL(k_sppm_end_frame, dim3(1), dim3(64), 0, ctx->stream, s->d_cx);
         HIP_TRY(ctx, hipGetLastError());
         s->frame_count += 1;
