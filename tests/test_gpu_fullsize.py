@@ -1,0 +1,116 @@
+"""BASELINE configs 3, 4, 5 at full frame size (1920x1080) on the GPU, checked against the oracle on a
+subsample and through size-independent properties.  The reference's OBJ assets do not travel to the GPU box:
+procedural stand-ins of the same triangle counts are used."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tracer_amd import abi, host
+
+pytestmark = pytest.mark.gpu
+W, H = 1920, 1080
+
+
+def _tile_mask(nranks):
+    ty, tx = np.mgrid[0:H, 0:W] // abi.TRC_TILE
+    return ((tx + ty) % nranks) == 0
+
+
+def _check_subsample(gpu, scene, integrator, spp, nranks, seed=0xC0FFEE):
+    cam = host.prepare_camera(W, H)
+    gpu.upload_scene(scene.view)
+    gpu.set_camera(cam)
+    gpu.set_environment((0.0, 0.0, 0.0))
+    gpu.resize(W, H)
+    gpu.seed(seed)
+    gpu.reset_stats()
+    gpu.render(spp=spp, integrator=integrator)
+    dev = gpu.download_accum()
+    st = gpu.stats()
+    assert st.paths == W * H * spp and st.rays >= st.paths
+    assert np.isfinite(dev).all() and (dev[..., 3] == 1.0).all() and (dev[..., :3] >= 0).all()
+    ref, rst = po.render(scene.view, cam, W, H, host.fill_rng(seed, W, H), spp=spp, integrator=integrator,
+                         tile_rank=0, tile_nranks=nranks)
+    mine = _tile_mask(nranks)
+    assert mine.sum() > 5000 and rst.rays > 0
+    assert np.array_equal(dev[mine].view(np.uint32), ref[mine].view(np.uint32))
+    return dev
+
+
+def test_config3_mesh_mis_full_frame(gpu):
+    """config 3: Cornell + a 46.8k-triangle mesh (coatball.obj's size), traceMIS; 1 tile in 128 re-rendered by the oracle"""
+    scene = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.ball(153, 153, 0.08))
+    assert scene.view.n_index // 3 == 46818
+    _check_subsample(gpu, scene, abi.INTEGRATOR_MIS, 8, 128)
+
+
+def test_config4_million_triangles_full_frame(gpu):
+    """config 4: >= 1 M triangles (BVH far beyond L2), tracePath; hits on the mesh must exist in the checked tiles"""
+    mesh = host.Mesh.ball(60, 60, 0.08).replicate(12, 2.4)
+    assert mesh.n_triangles >= 1_000_000
+    scene = host.HostScene(abi.SCENE_CORNELL_MESH, mesh)
+    assert scene.tree_depth() <= abi.TRC_MAX_BVH_DEPTH
+    _check_subsample(gpu, scene, abi.INTEGRATOR_PATH, 4, 128)
+    # Scene::hit on the big tree: primary rays, bit-exact incl. traversal counters
+    from conftest import camera_rays
+    rays = camera_rays(host.prepare_camera(W, H), W, H, step=12)
+    dev = gpu.trace_rays(rays)
+    ref = po.trace_rays(scene.view, rays)
+    assert (ref["pType"] == abi.PRIM_TRIANGLE).sum() > 100
+    for f in ("hit", "pType", "pIndex", "n_descend", "n_return", "n_leaf"):
+        assert np.array_equal(dev[f], ref[f]), f
+    assert np.array_equal(dev["t"].view(np.uint32), ref["t"].view(np.uint32))
+
+
+def test_config5_sppm_full_frame(gpu, cornell_spheres):
+    """config 5: SPPM at 1080p, 2 frames, the whole pass against the (single-threaded) oracle"""
+    cam = host.prepare_camera(W, H)
+    gpu.upload_scene(cornell_spheres.view)
+    gpu.set_camera(cam)
+    gpu.set_environment((0.0, 0.0, 0.0))
+    gpu.resize(W, H)
+    gpu.seed(8)
+    gpu.sppm_init(9)
+    gpu.sppm_frames(2)
+    dcam, dpho, dmark, dcount, dcx = gpu.sppm_download()
+    dacc = gpu.download_accum()
+    rng = host.fill_rng(8, W, H)
+    acc = np.zeros((H, W, 4), np.float32)
+    s = po.Sppm(W, H, 9)
+    s.frames(cornell_spheres.view, cam, rng, acc, 2)
+    ocam, opho, omark, ocount, ocx = s.download()
+    assert dcx.totalPhotonSum == ocx.totalPhotonSum and dcx.photonInitialRadius == ocx.photonInitialRadius
+    assert np.array_equal(dcount, ocount) and np.array_equal(dmark, omark)
+    assert dpho.tobytes() == opho.tobytes()
+    assert np.array_equal(dcam["radius"].view(np.uint32), ocam["radius"].view(np.uint32))
+    assert np.array_equal(dcam["photonCount"], ocam["photonCount"])
+    assert np.array_equal(dacc.view(np.uint32), acc.view(np.uint32))
+    assert np.array_equal(gpu.download_rng(), rng)
+
+
+def test_edge_sizes_and_empty_inputs(gpu, cornell):
+    """1x1 frame, zero samples, an empty ray batch, and a frame larger than 4K (size-independent properties)"""
+    from tracer_amd.dtypes import RAY_DTYPE
+    gpu.upload_scene(cornell.view)
+    assert len(gpu.trace_rays(np.zeros(0, dtype=RAY_DTYPE))) == 0
+    gpu.set_camera(host.prepare_camera(1, 1))
+    gpu.resize(1, 1)
+    gpu.seed(1)
+    gpu.render(spp=0)                                   # no-op
+    assert not gpu.download_accum().any()
+    gpu.render(spp=3)
+    ref, _ = po.render(cornell.view, host.prepare_camera(1, 1), 1, 1, host.fill_rng(1, 1, 1), spp=3)
+    assert np.array_equal(gpu.download_accum().view(np.uint32), ref.view(np.uint32))
+    BW, BH = 4100, 2310                                 # ragged on both axes, 9.5 M pixels
+    cam = host.prepare_camera(BW, BH)
+    gpu.set_camera(cam)
+    gpu.resize(BW, BH)
+    gpu.seed(2)
+    gpu.reset_stats()
+    gpu.render(spp=1)
+    big = gpu.download_accum()
+    assert gpu.stats().paths == BW * BH and np.isfinite(big).all() and (big[..., 3] == 1).all()
+    ref, _ = po.render(cornell.view, cam, BW, BH, host.fill_rng(2, BW, BH), spp=1, tile_rank=0, tile_nranks=97)
+    ty, tx = np.mgrid[0:BH, 0:BW] // abi.TRC_TILE
+    mine = ((tx + ty) % 97) == 0
+    assert np.array_equal(big[mine].view(np.uint32), ref[mine].view(np.uint32))
