@@ -339,11 +339,12 @@ trc_status trc_trace_rays(trc_ctx* ctx, const trc_ray* rays, size_t n, trc_hit* 
 
 trc_status trc_get_stats(trc_ctx* ctx, trc_stats* out);   /* synchronises the stream */
 trc_status trc_reset_stats(trc_ctx* ctx);
-/* developer diagnostic (divergence profile of the instrumented kernels): out[2*i] = lanes,
- * out[2*i+1] = wavefronts that executed site i since the last trc_reset_stats; sites: 0 loop
- * iteration, 1 box step, 2 square, 3 sphere, 4 cube, 5 triangle, 6 shade, 7 Lambert, 8 Metal,
- * 9 Plastic, 10 Glass, 11 path end */
-trc_status trc_debug_profile(trc_ctx* ctx, uint64_t* out, uint32_t n_pairs);
+/* developer diagnostic (divergence / cycle profile of the instrumented kernels), per site i since the
+ * last trc_reset_stats: out[3*i] = lanes, out[3*i+1] = wavefronts that executed the site, out[3*i+2] =
+ * shader-clock cycles those wavefronts spent inside it; sites: 0 loop iteration, 1 box step, 2 square,
+ * 3 sphere, 4 cube, 5 triangle, 6 shade, 7 cosine lobe, 8 Metal, 9 Beckmann sampling,
+ * 10 Beckmann lobe evaluation (Plastic specular + Glass), 11 path end */
+trc_status trc_debug_profile(trc_ctx* ctx, uint64_t* out, uint32_t n_sites);
 
 /* device info for the bench line */
 trc_status trc_device_info(trc_ctx* ctx, char* name, size_t name_len, int* cu_count, size_t* hbm_bytes);

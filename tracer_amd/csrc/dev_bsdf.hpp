@@ -7,6 +7,7 @@
 // material switch carries no per-material parameter loads beyond type + albedo.
 #pragma once
 
+#include "dev_prof.hpp"
 #include "dev_vec.hpp"
 
 namespace trcdev {
@@ -147,15 +148,18 @@ struct FrDiel15 { // BXDF.hh:72-81 with eta = 1.5 (Plastic, Glass reflection)
 // alpha is already clamped to >= 0.001 by the constructors (MicrofacetBXDF.h:164,306-309)
 // roughness pairs as types (float literals must match the reference's exactly)
 struct Alpha_01_02 { TRC_DEV static float x() { return 0.01f; } TRC_DEV static float y() { return 0.02f; } };
-struct Alpha_01_10 { TRC_DEV static float x() { return 0.01f; } TRC_DEV static float y() { return 0.1f; } };
-struct Alpha_01_01 { TRC_DEV static float x() { return 0.01f; } TRC_DEV static float y() { return 0.01f; } };
 
-template <class Alpha>
-struct BeckmannD {                                                   // MicrofacetBXDF.h:137-290
-    TRC_DEV static float ax() { return fmaxf(0.001f, Alpha::x()); }
-    TRC_DEV static float ay() { return fmaxf(0.001f, Alpha::y()); }
+// Beckmann distribution, MicrofacetBXDF.h:137-290.  The roughness pair is a run-time value (not a template
+// parameter) on purpose: Plastic's specular lobe (0.01, 0.1) and Glass's reflection and transmission lobes
+// (0.01, 0.01) then run the SAME instructions, so a wavefront holding lanes of several of these lobes executes
+// the expensive visible-normal sampling (a Newton iteration over erf^-1 / exp) once instead of once per lobe.
+struct Beckmann {
+    float alpha_x, alpha_y;
+    TRC_DEV static Beckmann make(float x, float y) { Beckmann d; d.alpha_x = fmaxf(0.001f, x); d.alpha_y = fmaxf(0.001f, y); return d; }
+    TRC_DEV float ax() const { return alpha_x; }
+    TRC_DEV float ay() const { return alpha_y; }
 
-    TRC_DEV static float lambda(F3 w) {
+    TRC_DEV float lambda(F3 w) const {
         float absTanTheta = fabsf(tan_theta(w));
         if (is_inf(absTanTheta)) return 0.;
         float alpha = sqrtf(cos2_phi(w) * ax() * ax() + sin2_phi(w) * ay() * ay());
@@ -163,16 +167,16 @@ struct BeckmannD {                                                   // Microfac
         if (a >= 1.6f) return 0;
         return (1 - 1.259f * a + 0.396f * a * a) / (3.535f * a + 2.181f * a * a);
     }
-    TRC_DEV static float D(F3 wh) {
+    TRC_DEV float D(F3 wh) const {
         float tan2Theta = tan2_theta(wh);
         if (is_inf(tan2Theta)) return 0.;
         float cos4Theta = cos2_theta(wh) * cos2_theta(wh);
         return dm_expf(-tan2Theta * (cos2_phi(wh) / (ax() * ax()) + sin2_phi(wh) / (ay() * ay()))) /
                (kPi * ax() * ay() * cos4Theta);
     }
-    TRC_DEV static float G1(F3 w) { return 1 / (1 + lambda(w)); }
-    TRC_DEV static float G(F3 wo, F3 wi) { return 1 / (1 + lambda(wo) + lambda(wi)); }
-    TRC_DEV static float pdf(F3 wo, F3 wh) { return D(wh) * G1(wo) * fabsf(dot(wo, wh)) / abs_cos_theta(wo); }
+    TRC_DEV float G1(F3 w) const { return 1 / (1 + lambda(w)); }
+    TRC_DEV float G(F3 wo, F3 wi) const { return 1 / (1 + lambda(wo) + lambda(wi)); }
+    TRC_DEV float pdf(F3 wo, F3 wh) const { return D(wh) * G1(wo) * fabsf(dot(wo, wh)) / abs_cos_theta(wo); }
 
     TRC_DEV static void sample11(float cosThetaI, float U1, float U2, float& slope_x, float& slope_y) {
         if (cosThetaI > .9999f) {
@@ -206,7 +210,7 @@ struct BeckmannD {                                                   // Microfac
         slope_x = erf_inv(b);
         slope_y = erf_inv(2.0f * fmaxf(U2, 1e-6f) - 1.0f);
     }
-    TRC_DEV static F3 sample_wh(F3 wo, F2 u) {
+    TRC_DEV F3 sample_wh(F3 wo, F2 u) const {
         const bool flip = wo.z < 0;
         const F3 wi = flip ? -wo : wo;
         F3 wiStretched = normalize(f3(ax() * wi.x, ay() * wi.y, wi.z));
@@ -331,11 +335,39 @@ struct MicroRefl {                                                   // Microfac
     }
 };
 
+// MicrofacetReflection over a run-time Beckmann distribution with FresnelDielectric(1.5): Plastic's specular
+// lobe (R = 1) and Glass's reflection lobe (R = kr = 0.98).  Same expressions as MicroRefl above.
+struct BeckRefl {
+    TRC_DEV static F3 F(const Beckmann& d, float R, F3 wo, F3 wi) {
+        float cosThetaO = abs_cos_theta(wo), cosThetaI = abs_cos_theta(wi);
+        if (cosThetaI == 0 || cosThetaO == 0) return f3(0);
+        F3 wh = wi + wo;
+        if (wh.x == 0 && wh.y == 0 && wh.z == 0) return f3(0);
+        wh = normalize(wh);
+        const float d001 = wh.x * 0.0f + wh.y * 0.0f + wh.z * 1.0f;
+        const F3 whf = (d001 < 0.f) ? -wh : wh;
+        F3 Fres = FrDiel15::eval(dot(wi, whf));
+        return f3(R) * d.D(wh) * d.G(wo, wi) * Fres / (4 * cosThetaI * cosThetaO);
+    }
+    TRC_DEV static float pdf(const Beckmann& d, F3 wo, F3 wi) {
+        if (wo.z * wi.z <= 0) return 0;
+        F3 wh = normalize(wo + wi);
+        return d.pdf(wo, wh) / (4 * dot(wo, wh));
+    }
+    // S_F after wh = d.sample_wh(wo, u) (MicrofacetBXDF.h:36-48); pdf_out untouched on the zero returns
+    TRC_DEV static F3 finish(const Beckmann& d, float R, F3 wo, F3 wh, F3& wi, float& pdf_out) {
+        if (dot(wo, wh) <= 0) return f3(0);
+        wi = reflect(wo, wh);
+        if (wo.z * wi.z <= 0) return f3(0);
+        pdf_out = d.pdf(wo, wh) / (4 * dot(wo, wh));
+        return F(d, R, wo, wi);
+    }
+};
+
 // MicrofacetBXDF.h:64-135 as instantiated by GlassMaterial (:541): T = 0.98, etaA = 1, etaB = 1.5,
 // mode = Importance (factor 1), and its own Fresnel is FresnelDielectric(etaA = 1.0) (:81).
-template <class Dist>
-struct MicroTransGlass {
-    TRC_DEV static F3 F(F3 wo, F3 wi) {
+struct BeckTransGlass {
+    TRC_DEV static F3 F(const Beckmann& d, F3 wo, F3 wi) {
         const float etaA = 1.0f, etaB = 1.5f;
         if (wo.z * wi.z > 0) return f3(0);
         float cosThetaO = cos_theta(wo), cosThetaI = cos_theta(wi);
@@ -348,10 +380,10 @@ struct MicroTransGlass {
         float sqrtDenom = dot(wo, wh) + eta * dot(wi, wh);
         float factor = 1;
         return (f3(1.0f) - Fres) * f3(0.98f) *
-               fabsf(Dist::D(wh) * Dist::G(wo, wi) * eta * eta * fabsf(dot(wi, wh)) * fabsf(dot(wo, wh)) * factor * factor /
+               fabsf(d.D(wh) * d.G(wo, wi) * eta * eta * fabsf(dot(wi, wh)) * fabsf(dot(wo, wh)) * factor * factor /
                      (cosThetaI * cosThetaO * sqrtDenom * sqrtDenom));
     }
-    TRC_DEV static float pdf(F3 wo, F3 wi) {
+    TRC_DEV static float pdf(const Beckmann& d, F3 wo, F3 wi) {
         const float etaA = 1.0f, etaB = 1.5f;
         if (wo.z * wi.z > 0) return 0;
         float eta = cos_theta(wo) > 0 ? (etaB / etaA) : (etaA / etaB);
@@ -359,25 +391,116 @@ struct MicroTransGlass {
         if (dot(wo, wh) * dot(wi, wh) > 0) return 0;
         float sqrtDenom = dot(wo, wh) + eta * dot(wi, wh);
         float dwh_dwi = fabsf((eta * eta * dot(wi, wh)) / (sqrtDenom * sqrtDenom));
-        return Dist::pdf(wo, wh) * dwh_dwi;
+        return d.pdf(wo, wh) * dwh_dwi;
     }
-    TRC_DEV static F3 S_F(F3 wo, F3& wi, F2 uu, float& pdf_out) {
+    // S_F after wh = d.sample_wh(wo, u) (MicrofacetBXDF.h:117-133)
+    TRC_DEV static F3 finish(const Beckmann& d, F3 wo, F3 wh, F3& wi, float& pdf_out) {
         const float etaA = 1.0f, etaB = 1.5f;
-        if (wo.z == 0) return f3(0);
-        F3 wh = Dist::sample_wh(wo, uu);
         if (dot(wo, wh) < 0) return f3(0);
         float eta = cos_theta(wo) > 0 ? (etaA / etaB) : (etaB / etaA);
         if (!refract(wo, wh, eta, wi)) return f3(0);
-        pdf_out = pdf(wo, wi);
-        return F(wo, wi);
+        pdf_out = pdf(d, wo, wi);
+        return F(d, wo, wi);
     }
 };
 
+// Tail of S_F for the three Beckmann lobes after wh = d.sample_wh(wo, u): MicrofacetReflection::S_F
+// (MicrofacetBXDF.h:36-48 -> PDF :50-57, F :15-34) and MicrofacetTransmission::S_F (:117-133 -> PDF :100-115,
+// F :83-98).  Written in three phases so that reflection and transmission lanes of a wavefront share the
+// expensive part: (A) per-lobe geometry and the lobe's early-outs, (B) D, Lambda and the dielectric Fresnel
+// term -- one instruction stream for all lanes, (C) per-lobe combination.  Every expression is the
+// reference's, evaluated on the same operands in the same order; D(-w) == D(w) bit for bit (w enters only
+// through squares), which is why transmission needs one D.  pdf_out is left untouched on the early-outs.
+TRC_DEV F3 beckmann_finish(const Beckmann& d, bool refl, float R, F3 wo, F3 wh, F3& wi_out, float& pdf_out) {
+    const float etaA = 1.0f, etaB = 1.5f;
+    bool live;                    // got past the early-outs of S_F: pdf_out will be written
+    bool pdf_live = false;        // ... with a non-trivial value
+    bool f_live = false;          // F reaches its D * G * Fresnel expression
+    F3 wi = wi_out, whA = wh, whB = wh;
+    float eta = 0, fres_cos = 0, fres_eta = 1.5f;
+    // ---- (A)
+    if (refl) {
+        live = !(dot(wo, wh) <= 0);
+        if (live) { wi = reflect(wo, wh); live = !(wo.z * wi.z <= 0); }
+        if (live) {
+            pdf_live = true;
+            const float cosThetaO = abs_cos_theta(wo), cosThetaI = abs_cos_theta(wi);
+            F3 sum = wi + wo;
+            f_live = !(cosThetaI == 0 || cosThetaO == 0) && !(sum.x == 0 && sum.y == 0 && sum.z == 0);
+            if (f_live) {
+                whB = normalize(sum);
+                const float d001 = whB.x * 0.0f + whB.y * 0.0f + whB.z * 1.0f;      // Faceforward(wh, (0,0,1))
+                const F3 whf = (d001 < 0.f) ? -whB : whB;
+                fres_cos = dot(wi, whf);
+                fres_eta = 1.5f;
+            }
+        }
+    } else {
+        live = !(dot(wo, wh) < 0);
+        if (live) live = refract(wo, wh, cos_theta(wo) > 0 ? (etaA / etaB) : (etaB / etaA), wi);
+        if (live) {
+            eta = cos_theta(wo) > 0 ? (etaB / etaA) : (etaA / etaB);
+            const bool same_side = wo.z * wi.z > 0;
+            whA = normalize(wo + wi * eta);
+            const bool backfacing = dot(wo, whA) * dot(wi, whA) > 0;               // same truth value for -whA
+            pdf_live = !same_side && !backfacing;
+            whB = whA;
+            if (whB.z < 0) whB = -whB;
+            f_live = pdf_live && !(cos_theta(wi) == 0 || cos_theta(wo) == 0);
+            fres_cos = dot(wo, whB);
+            fres_eta = etaA;
+        }
+    }
+    // ---- (B)
+    float D_A = 0, D_B = 0, lam_o = 0, lam_i = 0, fres = 0;
+    if (pdf_live) {
+        lam_o = d.lambda(wo);
+        D_A = d.D(whA);
+        D_B = D_A;
+        if (refl && f_live) D_B = d.D(whB);
+        if (f_live) {
+            lam_i = d.lambda(wi);
+            fres = fr_dielectric(fres_cos, fres_eta);
+        }
+    }
+    // ---- (C)
+    F3 out = f3(0);
+    if (live) {
+        wi_out = wi;
+        const float G1 = 1 / (1 + lam_o);
+        const float G = 1 / (1 + lam_o + lam_i);
+        if (refl) {
+            const float dist_pdf = D_A * G1 * fabsf(dot(wo, wh)) / abs_cos_theta(wo);
+            pdf_out = dist_pdf / (4 * dot(wo, wh));
+            if (f_live) {
+                const float cosThetaO = abs_cos_theta(wo), cosThetaI = abs_cos_theta(wi);
+                out = f3(R) * D_B * G * f3(fres) / (4 * cosThetaI * cosThetaO);
+            }
+        } else {
+            float p = 0;
+            if (pdf_live) {
+                const float sqrtDenom = dot(wo, whA) + eta * dot(wi, whA);
+                const float dwh_dwi = fabsf((eta * eta * dot(wi, whA)) / (sqrtDenom * sqrtDenom));
+                const float dist_pdf = D_A * G1 * fabsf(dot(wo, whA)) / abs_cos_theta(wo);
+                p = dist_pdf * dwh_dwi;
+            }
+            pdf_out = p;
+            if (f_live) {
+                const float cosThetaO = cos_theta(wo), cosThetaI = cos_theta(wi);
+                const float sqrtDenom = dot(wo, whB) + eta * dot(wi, whB);
+                const float factor = 1;
+                out = (f3(1.0f) - f3(fres)) * f3(0.98f) *
+                      fabsf(D_B * G * eta * eta * fabsf(dot(wi, whB)) * fabsf(dot(wo, whB)) * factor * factor /
+                            (cosThetaI * cosThetaO * sqrtDenom * sqrtDenom));
+            }
+        }
+    }
+    return out;
+}
+
 // composites (MicrofacetBXDF.h:436-586)
 typedef MicroRefl<TrowbridgeReitzD<Alpha_01_02>, FrCond> MetalLobe;       // alpha (0.01, 0.02), R = 1
-typedef MicroRefl<BeckmannD<Alpha_01_10>, FrDiel15> PlasticLobe;         // alpha (0.01, 0.1),  R = 1
-typedef MicroRefl<BeckmannD<Alpha_01_01>, FrDiel15> GlassReflLobe;        // alpha (0.01, 0.01), R = kr = 0.98
-typedef MicroTransGlass<BeckmannD<Alpha_01_01>> GlassTransLobe;
+// Plastic specular: Beckmann (0.01, 0.1), R = 1; Glass: Beckmann (0.01, 0.01), reflection R = kr = 0.98
 
 // material types (Material.hh:18-20) and texture types (Texture.hh:6) by ordinal
 constexpr int kMatDiffuse = 0, kMatLambert = 1, kMatPlastic = 3, kMatMetal = 4, kMatGlass = 5;
@@ -396,62 +519,72 @@ TRC_DEV F3 texture_value(int tex_type, F3 albedo, F2 uv) {           // Texture.
 }
 
 // Material::S_F, Material.hh:124-146.  bxPDF must be pre-set to 0 by the caller (B-3).
-TRC_DEV F3 material_S_F(int type, F3 color, F3 wo, F3& wi, F2 uu, float& pdf) {
-    switch (type) {
-        case kMatLambert:
-            return color * f3(Lambert::S_F(wo, wi, uu, pdf));
-        case kMatMetal:
-            return color * MetalLobe::S_F(1.0f, wo, wi, uu, pdf);
-        case kMatPlastic: {                                          // PlasticMaterial::S_F, :497-511
-            F2 u2 = uu;
-            if (u2.x < 0.5f) {
-                u2.x *= 2;
-                return color * (f3(0.35f, 0.12f, 0.48f) * Lambert::S_F(wo, wi, u2, pdf));
-            }
-            u2.x -= 0.5f; u2.x *= 2.0f;
-            return color * (f3(0.2f) * PlasticLobe::S_F(1.0f, wo, wi, u2, pdf));
+// Organised by LOBE rather than by material so that lanes of different materials share instructions: the
+// cosine lobe serves Lambert and Plastic's diffuse half, the Beckmann sampling serves Plastic's specular half
+// and both Glass lobes.  Every lane evaluates exactly the reference's expressions for its own material.
+template <bool STATS>
+TRC_DEV F3 material_S_F(int type, F3 color, F3 wo, F3& wi, F2 uu, float& pdf, TravCounters& cnt) {
+    const bool plastic = type == kMatPlastic, glass = type == kMatGlass;
+    F3 out = f3(0);
+    if (type == kMatMetal) {
+        ProfScope<STATS> scope(cnt, kProfMetal);
+        out = color * MetalLobe::S_F(1.0f, wo, wi, uu, pdf);
+    } else if (type == kMatLambert || (plastic && uu.x < 0.5f)) {
+        ProfScope<STATS> scope(cnt, kProfLambert);
+        F2 u2 = uu;
+        if (plastic) u2.x *= 2;                                      // PlasticMaterial::S_F, :497-511
+        const float v = Lambert::S_F(wo, wi, u2, pdf);
+        out = plastic ? color * (f3(0.35f, 0.12f, 0.48f) * v) : color * f3(v);
+    } else if (plastic || glass) {
+        const float ratio = 0.25f;                                   // GlassMaterial::S_F, :564-573
+        const bool refl = plastic || uu.x < ratio;
+        F2 u2 = uu;
+        if (plastic) { u2.x -= 0.5f; u2.x *= 2.0f; }
+        else if (refl) u2.x = uu.x / ratio;
+        else u2.x = (uu.x - ratio) / (1.0f - ratio);
+        const Beckmann d = Beckmann::make(0.01f, plastic ? 0.1f : 0.01f);
+        F3 lobe = f3(0);
+        if (wo.z != 0) {
+            F3 wh;
+            { ProfScope<STATS> scope(cnt, kProfBeckSample); wh = d.sample_wh(wo, u2); }
+            ProfScope<STATS> scope(cnt, kProfBeckEval);
+            lobe = beckmann_finish(d, refl, plastic ? 1.0f : 0.98f, wo, wh, wi, pdf);
         }
-        case kMatGlass: {                                            // GlassMaterial::S_F, :564-573
-            const float ratio = 0.25f;
-            F2 u2 = uu;
-            if (uu.x < ratio) { u2.x = uu.x / ratio; return color * GlassReflLobe::S_F(0.98f, wo, wi, u2, pdf); }
-            u2.x = (uu.x - ratio) / (1.0f - ratio);
-            return color * GlassTransLobe::S_F(wo, wi, u2, pdf);
-        }
-        default:
-            return f3(0);
+        out = plastic ? color * (f3(0.2f) * lobe) : color * lobe;
     }
+    return out;
+}
+TRC_DEV F3 material_S_F(int type, F3 color, F3 wo, F3& wi, F2 uu, float& pdf) {
+    TravCounters* none = nullptr;
+    return material_S_F<false>(type, color, wo, wi, uu, pdf, *none);     // never dereferenced when STATS = false
 }
 
 // Material::F, Material.hh:77-99 (pdf = bx.PDF, value = color * bx.F)
 TRC_DEV F3 material_F(int type, F3 color, F3 wo, F3 wi, F2 uu, float& pdf) {
-    switch (type) {
-        case kMatLambert:
-            pdf = Lambert::pdf(wo, wi);
-            return color * f3(Lambert::F(wo, wi));
-        case kMatMetal:
-            pdf = MetalLobe::pdf(wo, wi);
-            return color * MetalLobe::F(1.0f, wo, wi);
-        case kMatPlastic:                                            // PlasticMaterial::F/PDF, :469-495
-            if (uu.x < 0.5f) {
-                pdf = Lambert::pdf(wo, wi);
-                return color * (f3(0.35f, 0.12f, 0.48f) * Lambert::F(wo, wi));
-            }
-            pdf = PlasticLobe::pdf(wo, wi);
-            return color * (f3(0.2f) * PlasticLobe::F(1.0f, wo, wi));
-        case kMatGlass: {                                            // GlassMaterial::F/PDF, :543-562
-            const float ratio = 0.25f;
-            if (uu.x < ratio) {
-                pdf = ratio * GlassReflLobe::pdf(wo, wi);
-                return color * GlassReflLobe::F(0.98f, wo, wi);
-            }
-            pdf = (1 - ratio) * GlassTransLobe::pdf(wo, wi);
-            return color * GlassTransLobe::F(wo, wi);
-        }
-        default:
-            pdf = 0;
-            return f3(0);
+    const bool plastic = type == kMatPlastic, glass = type == kMatGlass;
+    if (type == kMatMetal) {
+        pdf = MetalLobe::pdf(wo, wi);
+        return color * MetalLobe::F(1.0f, wo, wi);
     }
+    if (type == kMatLambert || (plastic && uu.x < 0.5f)) {           // PlasticMaterial::F/PDF, :469-495
+        pdf = Lambert::pdf(wo, wi);
+        const float v = Lambert::F(wo, wi);
+        return plastic ? color * (f3(0.35f, 0.12f, 0.48f) * v) : color * f3(v);
+    }
+    if (plastic || glass) {                                          // GlassMaterial::F/PDF, :543-562
+        const float ratio = 0.25f;
+        const Beckmann d = Beckmann::make(0.01f, plastic ? 0.1f : 0.01f);
+        if (plastic || uu.x < ratio) {
+            const float p = BeckRefl::pdf(d, wo, wi);
+            pdf = plastic ? p : ratio * p;
+            const F3 f = BeckRefl::F(d, plastic ? 1.0f : 0.98f, wo, wi);
+            return plastic ? color * (f3(0.2f) * f) : color * f;
+        }
+        pdf = (1 - ratio) * BeckTransGlass::pdf(d, wo, wi);
+        return color * BeckTransGlass::F(d, wo, wi);
+    }
+    pdf = 0;
+    return f3(0);
 }
 
 }  // namespace trcdev

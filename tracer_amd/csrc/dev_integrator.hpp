@@ -127,13 +127,7 @@ TRC_DEV bool path_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, 
     float bxPDF = 0;                                                 // uninitialised in the reference (B-3)
     n_shaded++;
     prof<STATS>(cnt, kProfShade);
-    if (STATS) {
-        if (mtype == kMatLambert) prof<STATS>(cnt, kProfLambert);
-        else if (mtype == kMatMetal) prof<STATS>(cnt, kProfMetal);
-        else if (mtype == kMatPlastic) prof<STATS>(cnt, kProfPlastic);
-        else if (mtype == kMatGlass) prof<STATS>(cnt, kProfGlass);
-    }
-    F3 attenuation = material_S_F(mtype, hit_color(cx.sh, rec), wo, wi, uu, bxPDF);
+    F3 attenuation = material_S_F<STATS>(mtype, hit_color(cx.sh, rec), wo, wi, uu, bxPDF, cnt);
     if (bxPDF <= 0) { result = ps.color; return true; }
     F3 wiw = (nx * wi.x + ny * wi.y) + rec.sn * wi.z;                // stw * wi
     if (wi.z < 0) ps.ray = make_ray(offset_ray(hit_origin, -rec.sn), wiw);   // transmission

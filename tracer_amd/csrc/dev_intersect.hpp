@@ -20,6 +20,7 @@
 // instrumented build, because the roofline's algorithmic bytes are defined on them.
 #pragma once
 
+#include "dev_prof.hpp"
 #include "dev_scene.hpp"
 #include "dev_vec.hpp"
 
@@ -49,28 +50,6 @@ TRC_DEV void hit_init(HitRec& h) {
 TRC_DEV void check_face(HitRec& h, const Ray& ray) {   // HitRecord.hh:26-29
     bool f = dot(ray.d, h.gn) <= 0;
     h.sn = f ? h.gn : -h.gn;
-}
-
-// divergence profile sites (instrumented kernels only): how many LANES vs how many WAVEFRONTS executed a site
-enum ProfSite { kProfLoop = 0, kProfDescend, kProfSquare, kProfSphere, kProfCube, kProfTriangle, kProfShade,
-                kProfLambert, kProfMetal, kProfPlastic, kProfGlass, kProfFinish, kProfCount };
-
-struct TravCounters {   // only live in instrumented kernels
-    uint32_t rays, shaded, n_descend, n_return, leaf[4], hit_triangle, hit_cube;
-    uint32_t prof_lane[kProfCount], prof_wave[kProfCount];
-};
-TRC_DEV void counters_zero(TravCounters& c) {
-    c.rays = c.shaded = c.n_descend = c.n_return = 0; c.leaf[0] = c.leaf[1] = c.leaf[2] = c.leaf[3] = 0;
-    c.hit_triangle = c.hit_cube = 0;
-    for (int i = 0; i < kProfCount; ++i) { c.prof_lane[i] = 0; c.prof_wave[i] = 0; }
-}
-template <bool STATS>
-TRC_DEV void prof(TravCounters& c, int site) {
-    if (STATS) {
-        c.prof_lane[site]++;
-        const unsigned long long m = __ballot(1);
-        if (__lane_id() == (unsigned)(__ffsll((long long)m) - 1)) c.prof_wave[site]++;
-    }
 }
 
 // scene accessor: `small_base` is the LDS copy of the blob prefix (analytic prims, materials, top fat nodes)
@@ -376,7 +355,7 @@ TRC_DEV bool scene_hit(const SceneRef& S, const F3 root_min, const F3 root_max, 
             float4 q0, q1, q2, q3;
             load_node<ALL_LDS>(S, tag & kTagIndexMask, q0, q1, q2, q3);
             if (STATS) cnt.n_descend++;
-            prof<STATS>(cnt, kProfDescend);
+            ProfScope<STATS> scope(cnt, kProfDescend);
             float t_left = ry, t_right = ry;
             const bool left_test = box_hit_t(f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), ray, rx, ry, t_left);
             const bool right_test = box_hit_t(f3(q1.z, q1.w, q2.x), f3(q2.y, q2.z, q2.w), ray, rx, ry, t_right);
@@ -401,19 +380,19 @@ TRC_DEV bool scene_hit(const SceneRef& S, const F3 root_min, const F3 root_max, 
             bool ok;
             if (type == 1u) {
                 if (STATS) cnt.leaf[1]++;
-                prof<STATS>(cnt, kProfSquare);
+                ProfScope<STATS> scope(cnt, kProfSquare);
                 ok = square_hit_test(S, index, ray, rx, ry, rec);
             } else if (type == 0u) {
                 if (STATS) cnt.leaf[0]++;
-                prof<STATS>(cnt, kProfSphere);
+                ProfScope<STATS> scope(cnt, kProfSphere);
                 ok = sphere_hit_test<EAGER_UV>(S, index, ray, rx, ry, rec);
             } else if (type == 2u) {
                 if (STATS) cnt.leaf[2]++;
-                prof<STATS>(cnt, kProfCube);
+                ProfScope<STATS> scope(cnt, kProfCube);
                 ok = cube_hit_test<STATS>(S, index, ray, ry, rec, cnt);
             } else {
                 if (STATS) cnt.leaf[3]++;
-                prof<STATS>(cnt, kProfTriangle);
+                ProfScope<STATS> scope(cnt, kProfTriangle);
                 ok = triangle_hit_test<STATS>(S, index, ray, rx, ry, rec, cnt);
             }
             if (ok) rec.tag = tag;

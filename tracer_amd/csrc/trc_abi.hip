@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(256) k_seed(uint32_t* rng, uint32_t n_pixels, 
 // (4 wavefronts of 8x8 pixels), all `spp` samples fused: RNG texel and accumulator are read and
 // written ONCE per pixel instead of once per sample (64 B/pixel/sample in the reference).
 template <bool LDS, bool STATS, int INTEGRATOR>
-__global__ void __launch_bounds__(kBlock) k_render(const KRender kp) {
+__global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRATOR_MIS ? 3 : 4)) k_render(const KRender kp) {
     const DScene& sc = kp.ks.sc;
     const uint32_t* small_base = stage_scene(sc);
     uint32_t* stack_base = trc_smem + sc.lds_dwords;
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(kBlock) k_render(const KRender kp) {
             path_begin(ps, cast_ray(kp.cam, u, v, rng), kp.max_depth);
         }
         while (alive) {
-            prof<STATS>(cnt, kProfLoop);
+            ProfScope<STATS> loop_scope(cnt, kProfLoop);
             n_rays++;
             const bool hitted = scene_hit<LDS, STATS, false, false>(cx.S, cx.root_min, cx.root_max, ps.ray, ps.rec, FLT_MAX,
                                                                cx.stack, cx.lvstack, cnt);
@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(kBlock) k_render(const KRender kp) {
                                       ? mis_step<LDS, STATS>(cx, ps, hitted, rng, cnt, n_rays, n_shaded, color)
                                       : path_step<STATS>(cx, ps, hitted, rng, cnt, n_shaded, color);
             if (finished) {
-                prof<STATS>(cnt, kProfFinish);
+                ProfScope<STATS> scope(cnt, kProfFinish);
                 const bool bad = is_inf(color.x) || is_nan(color.x) || is_inf(color.y) || is_nan(color.y) ||
                                  is_inf(color.z) || is_nan(color.z);
                 if (bad) color = f3(0);                                         // :537-538
@@ -138,9 +138,13 @@ __global__ void __launch_bounds__(kBlock) k_render(const KRender kp) {
         }
         for (int i = 0; i < kProfCount; ++i) {       // divergence profile: lanes and wavefronts per site
             uint32_t rl = wave_sum(cnt.prof_lane[i]), rw = wave_sum(cnt.prof_wave[i]);
+            unsigned long long rc = cnt.prof_cycles[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) rc += __shfl_xor(rc, off);
             if (lane == 0) {
-                atomicAdd(&kp.stats[kStatCount + 2 * i], (unsigned long long)rl);
-                atomicAdd(&kp.stats[kStatCount + 2 * i + 1], (unsigned long long)rw);
+                atomicAdd(&kp.stats[kStatCount + 3 * i], (unsigned long long)rl);
+                atomicAdd(&kp.stats[kStatCount + 3 * i + 1], (unsigned long long)rw);
+                atomicAdd(&kp.stats[kStatCount + 3 * i + 2], rc);
             }
         }
     }
@@ -486,8 +490,8 @@ trc_status trc_create(int device, trc_ctx** out) {
     if (!ctx) return TRC_ERR_OOM;
     ctx->device = device;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void**)&ctx->d_stats, sizeof(unsigned long long) * (kStatCount + 2 * kProfCount)) != hipSuccess ||
-        hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * (kStatCount + 2 * kProfCount), ctx->stream) != hipSuccess) {
+        hipMalloc((void**)&ctx->d_stats, sizeof(unsigned long long) * (kStatCount + 3 * kProfCount)) != hipSuccess ||
+        hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * (kStatCount + 3 * kProfCount), ctx->stream) != hipSuccess) {
         trc_destroy(ctx);
         return TRC_ERR_HIP;
     }
@@ -699,13 +703,14 @@ trc_status trc_get_stats(trc_ctx* ctx, trc_stats* out) {
 }
 
 // developer diagnostic: (lanes, wavefronts) that executed each ProfSite of the instrumented kernels
-trc_status trc_debug_profile(trc_ctx* ctx, uint64_t* out, uint32_t n_pairs) {
+trc_status trc_debug_profile(trc_ctx* ctx, uint64_t* out, uint32_t n_sites) {
     if (!ctx || !out) return TRC_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    unsigned long long h[kStatCount + 2 * kProfCount];
+    unsigned long long h[kStatCount + 3 * kProfCount];
     HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (uint32_t i = 0; i < n_pairs && i < (uint32_t)kProfCount; ++i) { out[2 * i] = h[kStatCount + 2 * i]; out[2 * i + 1] = h[kStatCount + 2 * i + 1]; }
+    for (uint32_t i = 0; i < n_sites && i < (uint32_t)kProfCount; ++i)
+        for (int k = 0; k < 3; ++k) out[3 * i + k] = h[kStatCount + 3 * i + k];
     return TRC_OK;
 }
 
@@ -714,7 +719,7 @@ trc_status trc_reset_stats(trc_ctx* ctx) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     collect_events(ctx);
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * (kStatCount + 2 * kProfCount), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * (kStatCount + 3 * kProfCount), ctx->stream));
     ctx->launches = 0;
     ctx->kernel_ms = 0.0;
     return TRC_OK;

@@ -174,15 +174,15 @@ class Tracer:
         return s
 
     PROFILE_SITES = ["loop", "box_step", "square", "sphere", "cube", "triangle", "shade", "lambert", "metal",
-                     "plastic", "glass", "path_end"]
+                     "beckmann_sample", "beckmann_eval", "path_end"]
 
     def debug_profile(self):
-        """{site: (lanes, wavefronts, lanes/(64*wavefronts))} of the instrumented kernels."""
+        """{site: (lanes, wavefronts, lanes/(64*wavefronts), cycles)} of the instrumented kernels."""
         n = len(self.PROFILE_SITES)
-        buf = (C.c_uint64 * (2 * n))()
+        buf = (C.c_uint64 * (3 * n))()
         self._check(self._L.trc_debug_profile(self._h, buf, n), "trc_debug_profile")
-        return {s: (buf[2 * i], buf[2 * i + 1], buf[2 * i] / (64.0 * buf[2 * i + 1]) if buf[2 * i + 1] else 0.0)
-                for i, s in enumerate(self.PROFILE_SITES)}
+        return {s: (buf[3 * i], buf[3 * i + 1], buf[3 * i] / (64.0 * buf[3 * i + 1]) if buf[3 * i + 1] else 0.0,
+                    buf[3 * i + 2]) for i, s in enumerate(self.PROFILE_SITES)}
 
     def reset_stats(self):
         self._check(self._L.trc_reset_stats(self._h), "trc_reset_stats")
