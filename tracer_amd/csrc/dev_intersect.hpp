@@ -312,95 +312,117 @@ TRC_DEV bool triangle_hit_test(const SceneRef& S, uint32_t index, const Ray& ray
 }
 
 // ---------------------------------------------------------------- Scene::hit
+// Resumable traversal: the walk of one ray is a small state (Trav) advanced by trav_iter(), one "descend until a
+// leaf, test the leaf" round per call, so a kernel may interleave the rounds of its lanes with other work
+// (k_render_sched).  scene_hit() below runs it to completion.
 // `stack` is this lane's column of the workgroup stack (entry e at stack[e * kBlock]); `lvstack`
 // (STATS only) holds the level of the node that deferred each entry.
-template <bool ALL_LDS, bool STATS, bool ANY, bool EAGER_UV>
-TRC_DEV bool scene_hit(const SceneRef& S, const F3 root_min, const F3 root_max, const Ray& ray, HitRec& rec, const float test_t,
-                       uint32_t* stack, uint32_t* lvstack, TravCounters& cnt) {
+struct Trav {
+    uint32_t tag, sp;
+    float ry;                 // closest accepted t so far (test_t while nothing was hit)
+    int32_t level;            // STATS only: level of the interior node being expanded / parent level of a leaf
+    bool done;
+};
+
+// pops the next deferred sibling, or ends the traversal; `ret_start` = level at which the reference's first
+// upward ("came from child") iteration would run -- only counted, never executed
+template <bool STATS>
+TRC_DEV void trav_pop_or_finish(Trav& tv, int32_t ret_start, const uint32_t* stack, const uint32_t* lvstack, TravCounters& cnt) {
+    if (tv.sp == 0) {
+        if (STATS) cnt.n_return += (uint32_t)(ret_start + 1);
+        tv.done = true;
+        return;
+    }
+    tv.sp--;
+    tv.tag = stack[tv.sp * kBlock];
+    if (STATS) {
+        const int32_t ls = (int32_t)lvstack[tv.sp * kBlock];
+        cnt.n_return += (uint32_t)(ret_start - ls + 1);
+        tv.level = ls;
+        if ((tv.tag >> kTagIndexBits) == kTagInterior) tv.level += 1;
+    }
+}
+
+// Render.hh:135-153: counts the ray, rejects non-finite rays and rays that miss the root box.  Returns false
+// (tv.done = true) when the traversal is over before it starts.
+template <bool STATS>
+TRC_DEV bool trav_begin(const F3 root_min, const F3 root_max, const Ray& ray, const float test_t, Trav& tv, TravCounters& cnt) {
     if (STATS) cnt.rays++;
-    const float rx = FLT_MIN;
-    float ry = test_t;
+    tv.tag = kTagInterior << kTagIndexBits;   // root
+    tv.sp = 0;
+    tv.level = 0;
+    tv.ry = test_t;
+    tv.done = true;
     // a ray with a NaN / infinite component misses the scene (same rule as oracle/oracle.cpp Scene::hit: B-4/B-10);
     // without it NaN-ignoring min/max make such a ray "hit" every box of the tree
     const float finite_probe = fabsf(ray.o.x) + fabsf(ray.o.y) + fabsf(ray.o.z) + fabsf(ray.d.x) + fabsf(ray.d.y) + fabsf(ray.d.z);
     if (!(finite_probe < __builtin_inff())) return false;
-    if (!box_hit(root_min, root_max, ray, rx, ry))
-        return false;
+    if (!box_hit(root_min, root_max, ray, FLT_MIN, test_t)) return false;
+    tv.done = false;
+    return true;
+}
 
-    uint32_t tag = kTagInterior << kTagIndexBits;   // root
-    uint32_t sp = 0;
-    int32_t level = 0;        // level of the interior node being expanded / parent level of a leaf
-    bool done = false;
-    // pops the next deferred sibling, or ends the traversal; `ret_start` = level at which the
-    // reference's first upward ("came from child") iteration would run -- only counted, never executed
-    auto pop_or_finish = [&](int32_t ret_start) {
-        if (sp == 0) {
-            if (STATS) cnt.n_return += (uint32_t)(ret_start + 1);
-            done = true;
-            return;
-        }
-        sp--;
-        tag = stack[sp * kBlock];
-        if (STATS) {
-            const int32_t ls = (int32_t)lvstack[sp * kBlock];
-            cnt.n_return += (uint32_t)(ret_start - ls + 1);
-            level = ls;
-            if ((tag >> kTagIndexBits) == kTagInterior) level += 1;
-        }
-    };
-    while (!done) {
-        // (1) descend: expand interior nodes until this lane holds a leaf (or runs out of work); the whole
-        //     wavefront does box tests here, leaf tests are batched in (2)
-        while (!done && (tag >> kTagIndexBits) == kTagInterior) {
-            float4 q0, q1, q2, q3;
-            load_node<ALL_LDS>(S, tag & kTagIndexMask, q0, q1, q2, q3);
-            if (STATS) cnt.n_descend++;
-            ProfScope<STATS> scope(cnt, kProfDescend);
-            float t_left = ry, t_right = ry;
-            const bool left_test = box_hit_t(f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), ray, rx, ry, t_left);
-            const bool right_test = box_hit_t(f3(q1.z, q1.w, q2.x), f3(q2.y, q2.z, q2.w), ray, rx, ry, t_right);
-            if (left_test || right_test) {
-                const uint32_t tagL = __float_as_uint(q3.z), tagR = __float_as_uint(q3.w);
-                const bool left_first = t_left < t_right;            // Render.hh:174 (literal, also when only one hit)
-                if (left_test && right_test) {
-                    stack[sp * kBlock] = left_first ? tagR : tagL;    // Render.hh:171-172: visit the other one later
-                    if (STATS) lvstack[sp * kBlock] = (uint32_t)level;
-                    sp++;
-                }
-                tag = left_first ? tagL : tagR;
-                if (STATS && (tag >> kTagIndexBits) == kTagInterior) level += 1;
-            } else {
-                pop_or_finish(level - 1);
+// one round: (1) expand interior nodes until this lane holds a leaf (or runs out of work) -- the whole wavefront
+// does box tests here; (2) test the leaf.  Lanes with tv.done set idle through the call.
+template <bool ALL_LDS, bool STATS, bool ANY, bool EAGER_UV>
+TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const float test_t, Trav& tv,
+                       uint32_t* stack, uint32_t* lvstack, TravCounters& cnt) {
+    const float rx = FLT_MIN;
+    while (!tv.done && (tv.tag >> kTagIndexBits) == kTagInterior) {
+        float4 q0, q1, q2, q3;
+        load_node<ALL_LDS>(S, tv.tag & kTagIndexMask, q0, q1, q2, q3);
+        if (STATS) cnt.n_descend++;
+        ProfScope<STATS> scope(cnt, kProfDescend);
+        float t_left = tv.ry, t_right = tv.ry;
+        const bool left_test = box_hit_t(f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), ray, rx, tv.ry, t_left);
+        const bool right_test = box_hit_t(f3(q1.z, q1.w, q2.x), f3(q2.y, q2.z, q2.w), ray, rx, tv.ry, t_right);
+        if (left_test || right_test) {
+            const uint32_t tagL = __float_as_uint(q3.z), tagR = __float_as_uint(q3.w);
+            const bool left_first = t_left < t_right;            // Render.hh:174 (literal, also when only one hit)
+            if (left_test && right_test) {
+                stack[tv.sp * kBlock] = left_first ? tagR : tagL;    // Render.hh:171-172: visit the other one later
+                if (STATS) lvstack[tv.sp * kBlock] = (uint32_t)tv.level;
+                tv.sp++;
             }
-        }
-        if (done) break;
-        // (2) leaf
-        {
-            const uint32_t type = tag >> kTagIndexBits, index = tag & kTagIndexMask;
-            bool ok;
-            if (type == 1u) {
-                if (STATS) cnt.leaf[1]++;
-                ProfScope<STATS> scope(cnt, kProfSquare);
-                ok = square_hit_test(S, index, ray, rx, ry, rec);
-            } else if (type == 0u) {
-                if (STATS) cnt.leaf[0]++;
-                ProfScope<STATS> scope(cnt, kProfSphere);
-                ok = sphere_hit_test<EAGER_UV>(S, index, ray, rx, ry, rec);
-            } else if (type == 2u) {
-                if (STATS) cnt.leaf[2]++;
-                ProfScope<STATS> scope(cnt, kProfCube);
-                ok = cube_hit_test<STATS>(S, index, ray, ry, rec, cnt);
-            } else {
-                if (STATS) cnt.leaf[3]++;
-                ProfScope<STATS> scope(cnt, kProfTriangle);
-                ok = triangle_hit_test<STATS>(S, index, ray, rx, ry, rec, cnt);
-            }
-            if (ok) rec.tag = tag;
-            if (ANY && ry < test_t) return true;                      // Render.hh:244
-            pop_or_finish(level);
+            tv.tag = left_first ? tagL : tagR;
+            if (STATS && (tv.tag >> kTagIndexBits) == kTagInterior) tv.level += 1;
+        } else {
+            trav_pop_or_finish<STATS>(tv, tv.level - 1, stack, lvstack, cnt);
         }
     }
-    return ry < test_t;
+    if (!tv.done) {
+        const uint32_t type = tv.tag >> kTagIndexBits, index = tv.tag & kTagIndexMask;
+        bool ok;
+        if (type == 1u) {
+            if (STATS) cnt.leaf[1]++;
+            ProfScope<STATS> scope(cnt, kProfSquare);
+            ok = square_hit_test(S, index, ray, rx, tv.ry, rec);
+        } else if (type == 0u) {
+            if (STATS) cnt.leaf[0]++;
+            ProfScope<STATS> scope(cnt, kProfSphere);
+            ok = sphere_hit_test<EAGER_UV>(S, index, ray, rx, tv.ry, rec);
+        } else if (type == 2u) {
+            if (STATS) cnt.leaf[2]++;
+            ProfScope<STATS> scope(cnt, kProfCube);
+            ok = cube_hit_test<STATS>(S, index, ray, tv.ry, rec, cnt);
+        } else {
+            if (STATS) cnt.leaf[3]++;
+            ProfScope<STATS> scope(cnt, kProfTriangle);
+            ok = triangle_hit_test<STATS>(S, index, ray, rx, tv.ry, rec, cnt);
+        }
+        if (ok) rec.tag = tv.tag;
+        if (ANY && tv.ry < test_t) tv.done = true;                    // Render.hh:244
+        else trav_pop_or_finish<STATS>(tv, tv.level, stack, lvstack, cnt);
+    }
+}
+
+template <bool ALL_LDS, bool STATS, bool ANY, bool EAGER_UV>
+TRC_DEV bool scene_hit(const SceneRef& S, const F3 root_min, const F3 root_max, const Ray& ray, HitRec& rec, const float test_t,
+                       uint32_t* stack, uint32_t* lvstack, TravCounters& cnt) {
+    Trav tv;
+    if (!trav_begin<STATS>(root_min, root_max, ray, test_t, tv, cnt)) return false;
+    while (!tv.done) trav_iter<ALL_LDS, STATS, ANY, EAGER_UV>(S, ray, rec, test_t, tv, stack, lvstack, cnt);
+    return tv.ry < test_t;
 }
 
 }  // namespace trcdev

@@ -74,7 +74,6 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
         const float u = (float)px / (float)W;                               // no sub-pixel jitter (B-2)
         const float v = (float)py / (float)H;
 
-        // flat loop: one Scene::hit per iteration; a finished path immediately regenerates the next sample
         PathState ps;
         Pcg rng;
         uint32_t s = 0;
@@ -86,6 +85,26 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
             rng.inc = ((uint64_t)texel.x << 32) | texel.y;
             path_begin(ps, cast_ray(kp.cam, u, v, rng), kp.max_depth);
         }
+        // end of a sample: accumulate, hand the RNG words back to the texel, start the next sample (or stop)
+        auto finish_sample = [&](F3 color) {
+            ProfScope<STATS> scope(cnt, kProfFinish);
+            const bool bad = is_inf(color.x) || is_nan(color.x) || is_inf(color.y) || is_nan(color.y) ||
+                             is_inf(color.z) || is_nan(color.z);
+            if (bad) color = f3(0);                                         // :537-538
+            const uint32_t frame = kp.frame0 + s;
+            cached = (cached * (float)frame + color) / (float)(frame + 1);  // running mean, :540-541
+            texel.y = (uint32_t)rng.state; texel.x = (uint32_t)(rng.state >> 32);
+            texel.w = (uint32_t)rng.inc;   texel.z = (uint32_t)(rng.inc >> 32);
+            n_paths++;
+            if (++s == kp.spp) {
+                alive = false;
+            } else {
+                rng.state = ((uint64_t)texel.z << 32) | texel.w;
+                rng.inc = ((uint64_t)texel.x << 32) | texel.y;
+                path_begin(ps, cast_ray(kp.cam, u, v, rng), kp.max_depth);
+            }
+        };
+        // flat loop: one Scene::hit per iteration; a finished path immediately regenerates the next sample
         while (alive) {
             ProfScope<STATS> loop_scope(cnt, kProfLoop);
             n_rays++;
@@ -95,24 +114,7 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
             const bool finished = (INTEGRATOR == TRC_INTEGRATOR_MIS)
                                       ? mis_step<LDS, STATS>(cx, ps, hitted, rng, cnt, n_rays, n_shaded, color)
                                       : path_step<STATS>(cx, ps, hitted, rng, cnt, n_shaded, color);
-            if (finished) {
-                ProfScope<STATS> scope(cnt, kProfFinish);
-                const bool bad = is_inf(color.x) || is_nan(color.x) || is_inf(color.y) || is_nan(color.y) ||
-                                 is_inf(color.z) || is_nan(color.z);
-                if (bad) color = f3(0);                                         // :537-538
-                const uint32_t frame = kp.frame0 + s;
-                cached = (cached * (float)frame + color) / (float)(frame + 1);  // running mean, :540-541
-                texel.y = (uint32_t)rng.state; texel.x = (uint32_t)(rng.state >> 32);
-                texel.w = (uint32_t)rng.inc;   texel.z = (uint32_t)(rng.inc >> 32);
-                n_paths++;
-                if (++s == kp.spp) {
-                    alive = false;
-                } else {
-                    rng.state = ((uint64_t)texel.z << 32) | texel.w;
-                    rng.inc = ((uint64_t)texel.x << 32) | texel.y;
-                    path_begin(ps, cast_ray(kp.cam, u, v, rng), kp.max_depth);
-                }
-            }
+            if (finished) finish_sample(color);
         }
         float4 out; out.x = cached.x; out.y = cached.y; out.z = cached.z; out.w = 1.0f;
         reinterpret_cast<float4*>(kp.fr.accum)[pix] = out;
