@@ -307,6 +307,20 @@ void       trc_destroy(trc_ctx* ctx);
 
 /* replaces buffer creation + heap copy, AAPLRenderer.mm:213-246,610-720,1233-1355 */
 trc_status trc_upload_scene(trc_ctx* ctx, const trc_scene* scene);
+
+/* On-device LBVH build + node repack.  The reference builds its BVH on the host
+ * (BVH::buildTree, RT_Metal/Metal/BVH.hh:35-269) and lists "LBVHs, Morton Encoding" as a to-do
+ * (RT_Metal/README.md:42); this entry point replaces BVH::buildTree for scenes where the host SAH build is the
+ * bottleneck.  `scene->bvhList` holds ONLY the n_bvh LEAF records as BVH::buildNode writes them
+ * (BVH.hh:273-314: bBOX, pType, pIndex); the hierarchy is built on the GPU (30-bit Morton codes of the box
+ * centroids, stable radix sort, Karras' binary radix tree, bottom-up boxes) and used by every later
+ * trc_render / trc_trace_rays exactly like an uploaded tree. */
+trc_status trc_upload_scene_lbvh(trc_ctx* ctx, const trc_scene* scene);
+/* the device-built tree in the reference's array layout (BVH.hh:246-269): [root, leaf 0..n-1, interior
+ * 1..n-2], 2n-1 records.  out == NULL: only *n_nodes is written. */
+trc_status trc_download_bvh(trc_ctx* ctx, trc_BVH* out, uint32_t capacity, uint32_t* n_nodes);
+/* node count, depth of the deepest leaf and GPU time of the last trc_upload_scene_lbvh (bounds -> emit) */
+trc_status trc_lbvh_info(trc_ctx* ctx, uint32_t* n_nodes, uint32_t* height, float* device_build_ms);
 /* replaces memcpy(_camera_buffer.contents, ...), AAPLRenderer.mm:1183 */
 trc_status trc_set_camera(trc_ctx* ctx, const trc_Camera* camera);
 /* constant environment radiance used on a miss; stands in for

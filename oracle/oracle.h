@@ -73,6 +73,14 @@ void      orc_sppm_download(const orc_sppm* s, trc_CameraRecord* cam, trc_Photon
                             float* count, trc_Complex* complex);
 float     orc_photon_hash(const float idx[3], float hash_scale);                         /* Photon.hh:71-89 */
 
+/* LBVH (the reference lists "LBVHs, Morton Encoding" as its own to-do, RT_Metal/README.md:42, so
+ * there is no reference algorithm to restate).  This is the CPU statement of the build that
+ * trc_upload_scene_lbvh runs on the GPU: 30-bit Morton codes of the leaf-box centroids, keys (code << 32 | leaf
+ * index) sorted ascending, T. Karras' binary radix tree (HPG 2012) over the keys, boxes fitted bottom-up.
+ * leaves[0..n): leaf records as trc_host_build_node writes them; out: 2n-1 records in the layout of
+ * BVH::buildTree (BVH.hh:246-269): [root, leaf 0..n-1, interior 1..n-2].  *out_height = depth of the deepest leaf. */
+void orc_lbvh_build(const trc_BVH* leaves, uint32_t n, trc_BVH* out, uint32_t* out_height);
+
 /* deterministic math under test (identity wrappers over trc_detmath.h / libm) */
 float orc_math(int fn, float a, float b);   /* 0 sin 1 cos 2 exp 3 log 4 pow 5 asin 6 acos 7 atan2 */
 

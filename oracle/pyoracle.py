@@ -75,6 +75,8 @@ def lib(libm=False):
         L.orc_sppm_download.restype = None
         L.orc_photon_hash.argtypes = [f3, C.c_float]
         L.orc_photon_hash.restype = C.c_float
+        L.orc_lbvh_build.argtypes = [C.POINTER(abi.BVH), C.c_uint32, C.POINTER(abi.BVH), C.POINTER(C.c_uint32)]
+        L.orc_lbvh_build.restype = None
         L.orc_math.argtypes = [C.c_int, C.c_float, C.c_float]
         L.orc_math.restype = C.c_float
         _LIBS[key] = L
@@ -123,6 +125,14 @@ def render(scene_view, camera, width, height, rng, accum=None, spp=1, max_depth=
     lib(libm).orc_render(C.byref(scene_view), C.byref(camera), env_c, width, height, rng.ctypes.data,
                          accum.ctypes.data, C.byref(prm), C.byref(stats), n_threads)
     return accum, stats
+
+
+def lbvh_build(leaves, n):
+    """LBVH over `n` leaf records (ctypes array / pointer of abi.BVH) -> (abi.BVH * (2n-1), height)."""
+    out = (abi.BVH * (2 * n - 1))()
+    h = C.c_uint32(0)
+    lib().orc_lbvh_build(leaves, n, out, C.byref(h))
+    return out, h.value
 
 
 CAMREC_DTYPE = np.dtype([("ratio", np.float32, 4), ("position", np.float32, 4), ("direction", np.float32, 4),

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "trc_ctx.hpp"
+#include "trc_scene_prep.hpp"
 
 // deterministic stand-in for fillRNG (AAPLRenderer.mm:296-344): texel p = 4 outputs of
 // pcg32_srandom_r(seed, p)
@@ -219,17 +220,14 @@ void collect_events(trc_ctx* ctx) {
     ctx->pending.clear();
 }
 
-inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 
 // Repack the reference arrays into the device layout (dev_scene.hpp) and validate the tree.
 trc_status build_blob(trc_ctx* ctx, const trc_scene* s, std::vector<uint32_t>& blob, KScene& ks) {
     if (!s || !s->bvhList || s->n_bvh < 3 || (s->n_bvh & 1u) == 0) return fail(ctx, TRC_ERR_INVALID_ARG, "scene: need >= 2 leaves (n_bvh odd, >= 3)");
-    if (!s->materials || s->n_material == 0) return fail(ctx, TRC_ERR_INVALID_ARG, "scene: no materials");
-    if (s->n_index % 3) return fail(ctx, TRC_ERR_INVALID_ARG, "scene: n_index not a multiple of 3");
+    { trc_status st = validate_primitives(ctx, s); if (st != TRC_OK) return st; }
     const trc_BVH* nodes = s->bvhList;
     const uint32_t n = s->n_bvh;
     if (nodes[0].pType != TRC_PRIM_BVH) return fail(ctx, TRC_ERR_BVH_INVALID, "bvh: root is not an interior node");
-    const uint32_t n_tri = s->n_index / 3;
 
     // BFS over interior nodes: compact ids, depth, validation
     std::vector<uint32_t> interior_id(n, 0xFFFFFFFFu), order, depth_of(n, 0);
@@ -245,63 +243,25 @@ trc_status build_blob(trc_ctx* ctx, const trc_scene* s, std::vector<uint32_t>& b
             if (c == 0 || c >= n) return fail(ctx, TRC_ERR_BVH_INVALID, "bvh: child index out of range");
             if (++visited > n) return fail(ctx, TRC_ERR_BVH_INVALID, "bvh: cycle");
             depth_of[c] = depth_of[i] + 1;
-            const int32_t t = nodes[c].pType;
-            if (t == TRC_PRIM_BVH) {
+            if (nodes[c].pType == TRC_PRIM_BVH) {
                 if (interior_id[c] != 0xFFFFFFFFu) return fail(ctx, TRC_ERR_BVH_INVALID, "bvh: node reached twice");
                 interior_id[c] = (uint32_t)order.size();
                 order.push_back(c);
             } else {
                 max_leaf_depth = std::max(max_leaf_depth, depth_of[c]);
-                const uint32_t pi = nodes[c].pIndex;
-                const uint32_t limit = t == TRC_PRIM_SPHERE ? s->n_sphere : t == TRC_PRIM_SQUARE ? s->n_square
-                                     : t == TRC_PRIM_CUBE ? s->n_cube : t == TRC_PRIM_TRIANGLE ? n_tri : 0;
-                if (t < 0 || t > TRC_PRIM_TRIANGLE || pi >= limit)
-                    return fail(ctx, TRC_ERR_BVH_INVALID, "bvh: leaf with bad primitive type/index");
-                if (pi > kTagIndexMask) return fail(ctx, TRC_ERR_UNSUPPORTED, "bvh: primitive index exceeds 29 bits");
+                trc_status st = validate_leaf(ctx, s, nodes[c]);
+                if (st != TRC_OK) return st;
             }
         }
     }
     if (visited != n) return fail(ctx, TRC_ERR_BVH_INVALID, "bvh: unreachable nodes");
     if (max_leaf_depth > TRC_MAX_BVH_DEPTH) return fail(ctx, TRC_ERR_BVH_INVALID, "bvh: deeper than TRC_MAX_BVH_DEPTH");
-    for (uint32_t t = 0; t < s->n_index; ++t)
-        if (s->idxList[t] >= s->n_vertex) return fail(ctx, TRC_ERR_INVALID_ARG, "scene: triangle index out of range");
-    // materials referenced by primitives
-    auto bad_mat = [&](uint32_t m) { return m >= s->n_material; };
-    for (uint32_t i = 0; i < s->n_sphere; ++i) if (bad_mat(s->sphereList[i].material)) return fail(ctx, TRC_ERR_INVALID_ARG, "sphere material out of range");
-    for (uint32_t i = 0; i < s->n_square; ++i) if (bad_mat(s->squareList[i].material)) return fail(ctx, TRC_ERR_INVALID_ARG, "square material out of range");
-    for (uint32_t i = 0; i < s->n_cube; ++i) if (bad_mat(s->cubeList[i].material)) return fail(ctx, TRC_ERR_INVALID_ARG, "cube material out of range");
-    if (n_tri && s->n_material <= 19) return fail(ctx, TRC_ERR_INVALID_ARG, "triangles use material 19 (Triangle.hh:82): need >= 20 materials");
 
     const uint32_t n_interior = (uint32_t)order.size();
     DScene sc{};
-    auto align4 = [](uint32_t v) { return (v + 3u) & ~3u; };
-    sc.off_spheres = 0;
-    sc.off_squares = align4(sc.off_spheres + s->n_sphere * kSphereDwords);
-    sc.off_cubes = align4(sc.off_squares + s->n_square * kSquareDwords);
-    sc.off_materials = align4(sc.off_cubes + s->n_cube * kCubeDwords);
-    sc.off_nodes = align4(sc.off_materials + s->n_material * kMaterialDwords);
-    if ((uint64_t)sc.off_nodes * 4 + kNodeDwords * 4 > kLdsSceneBytes)
-        return fail(ctx, TRC_ERR_UNSUPPORTED, "analytic primitives + materials exceed the LDS staging budget");
-    // LDS per workgroup = staged prefix + traversal stack; keep 4 workgroups per CU resident (measured on
-    // MI355X: occupancy beats top-of-tree staging -- 8/16/24/40/64 KB staged on the 1 M-triangle scene gave
-    // 1826/1553/1155/1165/666 Mrays/s), so nodes are staged only into what the stack leaves of ~38 KB.
-    const uint32_t stack_dwords = std::max(1u, max_leaf_depth) * kBlock;
-    uint32_t budget_dwords = (38u * 1024u / 4u > stack_dwords) ? 38u * 1024u / 4u - stack_dwords : 0u;
-    budget_dwords = std::min(budget_dwords, kLdsSceneBytes / 4);
-    if (const char* e = std::getenv("TRC_LDS_BUDGET_KB")) {          // tuning knob: staged bytes vs occupancy
-        const long kb = std::atol(e);
-        if (kb > 0 && kb <= 128) budget_dwords = (uint32_t)kb * 256u;
-    }
-    budget_dwords = std::max(budget_dwords, sc.off_nodes + kNodeDwords);
-    sc.n_lds_nodes = std::min<uint32_t>(n_interior, (budget_dwords - sc.off_nodes) / kNodeDwords);
-    sc.lds_dwords = sc.off_nodes + sc.n_lds_nodes * kNodeDwords;
-    sc.off_tripos = align4(sc.off_nodes + n_interior * kNodeDwords);
-    const uint64_t total = (uint64_t)sc.off_tripos + (uint64_t)n_tri * kTriPosDwords + (uint64_t)n_tri * kTriAttrDwords;
-    if (total > 0xFFFFFFF0ull) return fail(ctx, TRC_ERR_UNSUPPORTED, "scene too large for 32-bit dword offsets");
-    sc.off_triattr = sc.off_tripos + n_tri * kTriPosDwords;
-    sc.n_nodes = n_interior; sc.n_spheres = s->n_sphere; sc.n_squares = s->n_square; sc.n_cubes = s->n_cube;
-    sc.n_materials = s->n_material; sc.n_triangles = n_tri;
-    sc.stack_depth = std::max(1u, max_leaf_depth);
+    uint64_t total = 0;
+    { trc_status st = layout_scene(ctx, s, n_interior, sc, total); if (st != TRC_OK) return st; }
+    plan_lds(sc, max_leaf_depth, true);
     blob.assign((size_t)total, 0u);
 
     auto tag_of = [&](uint32_t c) -> uint32_t {
@@ -318,56 +278,7 @@ trc_status build_blob(trc_ctx* ctx, const trc_scene* s, std::vector<uint32_t>& b
         q[8] = f2u(R.mini.z); q[9] = f2u(R.maxi.x); q[10] = f2u(R.maxi.y); q[11] = f2u(R.maxi.z);
         q[12] = 0; q[13] = 0; q[14] = tag_of(nd.left); q[15] = tag_of(nd.right);
     }
-    for (uint32_t i = 0; i < s->n_sphere; ++i) {
-        const trc_Sphere& sp = s->sphereList[i];
-        uint32_t* q = &blob[sc.off_spheres + (size_t)i * kSphereDwords];
-        q[0] = f2u(sp.center.x); q[1] = f2u(sp.center.y); q[2] = f2u(sp.center.z); q[3] = f2u(sp.radius);
-        q[4] = sp.material;
-    }
-    for (uint32_t i = 0; i < s->n_square; ++i) {
-        const trc_Square& sq = s->squareList[i];
-        if (sq.axis_i > 2 || sq.axis_j > 2 || sq.axis_k > 2) return fail(ctx, TRC_ERR_INVALID_ARG, "square axis out of range");
-        uint32_t* q = &blob[sc.off_squares + (size_t)i * kSquareDwords];
-        q[0] = f2u(sq.range_i.x); q[1] = f2u(sq.range_i.y); q[2] = f2u(sq.range_j.x); q[3] = f2u(sq.range_j.y);
-        // Square::area() = 2*i*j and aeraPDF() = 1/area (Square.hh:31-38), evaluated once here in binary32
-        const float di = sq.range_i.y - sq.range_i.x, dj = sq.range_j.y - sq.range_j.x;
-        const float area = 2 * di * dj;
-        const float pdf = 1 / area;
-        q[4] = f2u(sq.value_k); q[5] = f2u(pdf);
-        q[6] = (uint32_t)sq.axis_i | ((uint32_t)sq.axis_j << 2) | ((uint32_t)sq.axis_k << 4);
-        q[7] = sq.material;
-    }
-    for (uint32_t i = 0; i < s->n_cube; ++i) {
-        const trc_Cube& cb = s->cubeList[i];
-        uint32_t* q = &blob[sc.off_cubes + (size_t)i * kCubeDwords];
-        auto put_cols = [&](uint32_t* dst, const trc_float4x4& m, int ncols) {
-            for (int c = 0; c < ncols; ++c) { dst[3 * c] = f2u(m.columns[c].x); dst[3 * c + 1] = f2u(m.columns[c].y); dst[3 * c + 2] = f2u(m.columns[c].z); }
-        };
-        put_cols(q, cb.inverse_matrix, 4);
-        put_cols(q + 12, cb.model_matrix, 4);
-        put_cols(q + 24, cb.normal_matrix, 3);
-        q[33] = f2u(cb.box.mini.x); q[34] = f2u(cb.box.mini.y); q[35] = f2u(cb.box.mini.z);
-        q[36] = f2u(cb.box.maxi.x); q[37] = f2u(cb.box.maxi.y); q[38] = f2u(cb.box.maxi.z);
-        q[39] = cb.material;
-    }
-    for (uint32_t i = 0; i < s->n_material; ++i) {
-        const trc_Material& m = s->materials[i];
-        uint32_t* q = &blob[sc.off_materials + (size_t)i * kMaterialDwords];
-        q[0] = (uint32_t)m.type; q[1] = (uint32_t)m.textureInfo.type;
-        q[2] = f2u(m.textureInfo.albedo.x); q[3] = f2u(m.textureInfo.albedo.y); q[4] = f2u(m.textureInfo.albedo.z);
-        q[5] = m.specular ? 1u : 0u;
-    }
-    for (uint32_t t = 0; t < n_tri; ++t) {
-        const trc_TriangleVertex* v[3] = {&s->triList[s->idxList[3 * t]], &s->triList[s->idxList[3 * t + 1]],
-                                          &s->triList[s->idxList[3 * t + 2]]};
-        uint32_t* p = &blob[sc.off_tripos + (size_t)t * kTriPosDwords];
-        uint32_t* a = &blob[sc.off_triattr + (size_t)t * kTriAttrDwords];
-        for (int k = 0; k < 3; ++k) {
-            p[4 * k] = f2u(v[k]->v[0]); p[4 * k + 1] = f2u(v[k]->v[1]); p[4 * k + 2] = f2u(v[k]->v[2]);
-            a[3 * k] = f2u(v[k]->n[0]); a[3 * k + 1] = f2u(v[k]->n[1]); a[3 * k + 2] = f2u(v[k]->n[2]);
-            a[9 + 2 * k] = f2u(v[k]->uv[0]); a[10 + 2 * k] = f2u(v[k]->uv[1]);
-        }
-    }
+    fill_primitives(s, sc, blob);
     ks.sc = sc;
     const trc_AABB& rb = nodes[0].bBOX;
     ks.root_box[0] = rb.mini.x; ks.root_box[1] = rb.mini.y; ks.root_box[2] = rb.mini.z;
@@ -509,7 +420,7 @@ void trc_destroy(trc_ctx* ctx) {
     trc_sppm_release(ctx);
     collect_events(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
-    (void)hipFree(ctx->d_blob); (void)hipFree(ctx->d_rng); (void)hipFree(ctx->d_accum);
+    (void)hipFree(ctx->d_blob); (void)hipFree(ctx->d_bvh_ref); (void)hipFree(ctx->d_rng); (void)hipFree(ctx->d_accum);
     (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_stats); (void)hipFree(ctx->d_reduce_recv);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -524,6 +435,8 @@ trc_status trc_upload_scene(trc_ctx* ctx, const trc_scene* scene) {
     if (st != TRC_OK) return st;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_blob) { (void)hipFree(ctx->d_blob); ctx->d_blob = nullptr; }
+    if (ctx->d_bvh_ref) { (void)hipFree(ctx->d_bvh_ref); ctx->d_bvh_ref = nullptr; }
+    ctx->n_bvh_ref = 0;
     ctx->has_scene = false;
     ctx->blob_bytes = blob.size() * 4;
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_blob, ctx->blob_bytes));

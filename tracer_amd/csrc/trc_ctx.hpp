@@ -81,6 +81,9 @@ struct trc_ctx {
     uint32_t* d_blob = nullptr;
     size_t blob_bytes = 0;
     bool lds_scene = false;
+    trc_BVH* d_bvh_ref = nullptr;    // tree built by trc_upload_scene_lbvh, reference array layout (trc_download_bvh)
+    uint32_t n_bvh_ref = 0, lbvh_height = 0;
+    float lbvh_build_ms = 0.0f;
 
     bool has_camera = false;
     DCamera cam{};

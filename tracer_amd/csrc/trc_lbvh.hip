@@ -1,0 +1,450 @@
+// trc_lbvh.hip -- on-device LBVH build + fat-node repack.
+//
+// The reference builds its BVH on the host (RT_Metal/Metal/BVH.hh:35-269) and lists "LBVHs, Morton Encoding"
+// as its own to-do (RT_Metal/README.md:42).  trc_upload_scene_lbvh takes the LEAF records (what BVH::buildNode
+// writes, BVH.hh:273-314) and builds the hierarchy on the GPU:
+//
+//   k_lbvh_bounds     centroid bounds of the leaf boxes            wave min/max -> ordered-uint atomics
+//   k_lbvh_keys       30-bit Morton code of every centroid          key = code, value = leaf index
+//   k_radix_*         stable LSD radix sort, 4 passes x 8 bits      (ties keep leaf-index order)
+//   k_lbvh_hierarchy  T. Karras' binary radix tree (HPG 2012) over the 64-bit keys (code << 32 | index)
+//   k_lbvh_refit      boxes + subtree heights bottom-up             one atomic counter per interior node
+//   k_lbvh_emit       fat nodes into the scene blob (dev_scene.hpp) + the tree in the reference's own array
+//                     layout [root, leaf 0..n-1, interior 1..n-2] (BVH.hh:246-269) for trc_download_bvh
+//
+// All of it is integer / min-max work on a few bytes per leaf: HBM-bound streaming passes, no MFMA.  The CPU
+// statement of the same build is oracle/oracle_lbvh.cpp; tests compare all 2n-1 records bit for bit.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "trc_ctx.hpp"
+#include "trc_scene_prep.hpp"
+
+namespace {
+
+constexpr int kSortBlock = 256;
+constexpr int kSortItems = 16;                         // keys per thread per tile
+constexpr int kSortTile = kSortBlock * kSortItems;     // 4096 keys per workgroup
+
+struct DLeaf {            // 32 B: what the build needs of a 64-B leaf record
+    float mn[3]; uint32_t tag;      // tag = pType << 29 | pIndex
+    float mx[3]; uint32_t _pad;
+};
+
+__device__ __forceinline__ uint32_t ordered_of(float f) {      // monotone float -> uint map
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float float_of(uint32_t o) {
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+}
+__device__ __forceinline__ void leaf_centroid(const DLeaf& l, float c[3]) {
+    c[0] = (l.mn[0] + l.mx[0]) * 0.5f; c[1] = (l.mn[1] + l.mx[1]) * 0.5f; c[2] = (l.mn[2] + l.mx[2]) * 0.5f;
+}
+
+// bounds[0..2] = min, bounds[3..5] = max of the centroids, as ordered uints (init: 0xFFFFFFFF / 0)
+__global__ void __launch_bounds__(256) k_lbvh_bounds(const DLeaf* leaves, uint32_t n, uint32_t* bounds) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+    if (i < n) {
+        float c[3];
+        leaf_centroid(leaves[i], c);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            if (c[a] == c[a]) { lo[a] = hi[a] = ordered_of(c[a]); }        // NaN centroids do not take part
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[a] = min(lo[a], (uint32_t)__shfl_xor((int)lo[a], off, 64));
+            hi[a] = max(hi[a], (uint32_t)__shfl_xor((int)hi[a], off, 64));
+        }
+    }
+    if ((threadIdx.x & 63u) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { atomicMin(&bounds[a], lo[a]); atomicMax(&bounds[3 + a], hi[a]); }
+    }
+}
+
+__device__ __forceinline__ uint32_t expand_bits10(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t quantise(float c, float lo, float ext) {
+    if (!(ext > 0.0f)) return 0;
+    float v = ((c - lo) / ext) * 1024.0f;
+    if (!(v >= 0.0f)) v = 0.0f;
+    if (v > 1023.0f) v = 1023.0f;
+    return (uint32_t)v;
+}
+
+__global__ void __launch_bounds__(256) k_lbvh_keys(const DLeaf* leaves, uint32_t n, const uint32_t* bounds,
+                                                  uint32_t* keys, uint32_t* vals) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    float lo[3], ext[3], c[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { lo[a] = float_of(bounds[a]); ext[a] = float_of(bounds[3 + a]) - lo[a]; }
+    leaf_centroid(leaves[i], c);
+    keys[i] = (expand_bits10(quantise(c[0], lo[0], ext[0])) << 2) | (expand_bits10(quantise(c[1], lo[1], ext[1])) << 1) |
+              expand_bits10(quantise(c[2], lo[2], ext[2]));
+    vals[i] = i;
+}
+
+// ---- stable LSD radix sort, one 8-bit digit per pass.  hist is digit-major: hist[digit * n_blocks + block].
+__global__ void __launch_bounds__(kSortBlock) k_radix_hist(const uint32_t* keys, uint32_t n, uint32_t shift, uint32_t* hist, uint32_t n_blocks) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kSortTile;
+    for (int r = 0; r < kSortItems; ++r) {
+        const uint32_t i = base + r * kSortBlock + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// exclusive scan of `count` entries in place, one workgroup of 1024 threads
+__global__ void __launch_bounds__(1024) k_radix_scan(uint32_t* data, uint32_t count) {
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (count + 1023u) / 1024u;
+    const uint32_t b = threadIdx.x * per, e = min(b + per, count);
+    uint32_t s = 0;
+    for (uint32_t i = b; i < e; ++i) s += data[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {            // Hillis-Steele inclusive scan
+        const uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;
+    for (uint32_t i = b; i < e; ++i) { const uint32_t v = data[i]; data[i] = run; run += v; }
+}
+
+__global__ void __launch_bounds__(kSortBlock) k_radix_scatter(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
+                                                             uint32_t* vals_out, uint32_t n, uint32_t shift, const uint32_t* hist,
+                                                             uint32_t n_blocks) {
+    __shared__ uint32_t run[256];            // next output slot of each digit for this tile
+    __shared__ uint32_t wave_cnt[4][256];    // keys of each digit per wavefront in the current round
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    run[threadIdx.x] = hist[threadIdx.x * n_blocks + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) wave_cnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kSortTile;
+    for (int r = 0; r < kSortItems; ++r) {
+        const uint32_t i = base + r * kSortBlock + threadIdx.x;
+        const bool valid = i < n;
+        const uint32_t key = valid ? keys_in[i] : 0u, val = valid ? vals_in[i] : 0u;
+        const uint32_t digit = (key >> shift) & 255u;
+        // lanes of this wavefront that hold the same digit (and are valid)
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (digit >> b) & 1u;
+            const unsigned long long m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const uint32_t rank = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+        if (valid && rank == 0) wave_cnt[wave][digit] = (uint32_t)__popcll(peers);
+        __syncthreads();
+        if (valid) {
+            uint32_t off = run[digit] + rank;
+            for (uint32_t w = 0; w < wave; ++w) off += wave_cnt[w][digit];
+            keys_out[off] = key;
+            vals_out[off] = val;
+        }
+        __syncthreads();
+        {
+            uint32_t s = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s += wave_cnt[w][threadIdx.x]; wave_cnt[w][threadIdx.x] = 0; }
+            run[threadIdx.x] += s;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- Karras 2012.  Child encoding: bit 31 = leaf, low bits = sorted position (leaf) or interior index.
+constexpr uint32_t kChildLeaf = 0x80000000u;
+
+struct DTopo {
+    uint32_t* child_l; uint32_t* child_r;    // [n-1]
+    uint32_t* parent_interior;               // [n-1] parent interior index of interior i (root: 0)
+    uint32_t* parent_leaf;                   // [n]   parent interior index of sorted leaf position p
+    uint32_t* axis;                          // [n-1]
+};
+
+__device__ __forceinline__ int lbvh_delta(const uint32_t* keys, const uint32_t* vals, uint64_t ki, int64_t j, uint32_t n) {
+    if (j < 0 || j >= (int64_t)n) return -1;
+    const uint64_t kj = ((uint64_t)keys[j] << 32) | vals[j];
+    const uint64_t x = ki ^ kj;
+    return x ? __clzll((long long)x) : 64;
+}
+
+__global__ void __launch_bounds__(256) k_lbvh_hierarchy(const uint32_t* keys, const uint32_t* vals, uint32_t n, DTopo tp) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i + 1 >= (int64_t)n) return;
+    const uint64_t ki = ((uint64_t)keys[i] << 32) | vals[i];
+    auto delta = [&](int64_t j) { return lbvh_delta(keys, vals, ki, j, n); };
+    const int d = (delta(i + 1) - delta(i - 1)) < 0 ? -1 : 1;
+    const int dmin = delta(i - d);
+    int64_t lmax = 2;
+    while (delta(i + lmax * d) > dmin) lmax *= 2;
+    int64_t l = 0;
+    for (int64_t t = lmax / 2; t >= 1; t /= 2)
+        if (delta(i + (l + t) * d) > dmin) l += t;
+    const int64_t j = i + l * d;
+    const int dnode = delta(j);
+    int64_t s = 0;
+    for (int64_t t = (l + 1) / 2;; t = (t + 1) / 2) {
+        if (delta(i + (s + t) * d) > dnode) s += t;
+        if (t <= 1) break;
+    }
+    const int64_t gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int64_t first = i < j ? i : j, last = i < j ? j : i;
+    const bool leaf_l = first == gamma, leaf_r = last == gamma + 1;
+    tp.child_l[i] = (uint32_t)gamma | (leaf_l ? kChildLeaf : 0u);
+    tp.child_r[i] = (uint32_t)(gamma + 1) | (leaf_r ? kChildLeaf : 0u);
+    if (leaf_l) tp.parent_leaf[gamma] = (uint32_t)i; else tp.parent_interior[gamma] = (uint32_t)i;
+    if (leaf_r) tp.parent_leaf[gamma + 1] = (uint32_t)i; else tp.parent_interior[gamma + 1] = (uint32_t)i;
+    const int mbit = dnode - 2;
+    tp.axis[i] = (mbit >= 0 && mbit < 30) ? (uint32_t)(mbit % 3) : 0u;
+    if (i == 0) tp.parent_interior[0] = 0;
+}
+
+// boxes[i] = 6 floats (min xyz, max xyz) of interior i; height[i] = depth of the deepest leaf below i
+__global__ void __launch_bounds__(256) k_lbvh_refit(const DLeaf* leaves, const uint32_t* vals, uint32_t n, DTopo tp,
+                                                   float* boxes, uint32_t* height, uint32_t* arrived) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n) return;
+    uint32_t cur = tp.parent_leaf[p];
+    for (;;) {
+        __threadfence();
+        if (atomicAdd(&arrived[cur], 1u) == 0u) return;           // the sibling subtree is not finished yet
+        __threadfence();
+        float mn[3], mx[3];
+        uint32_t h = 0;
+        const uint32_t ch[2] = {tp.child_l[cur], tp.child_r[cur]};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float cmn[3], cmx[3];
+            uint32_t hc;
+            if (ch[k] & kChildLeaf) {
+                const DLeaf& lf = leaves[vals[ch[k] & ~kChildLeaf]];
+                cmn[0] = lf.mn[0]; cmn[1] = lf.mn[1]; cmn[2] = lf.mn[2]; cmx[0] = lf.mx[0]; cmx[1] = lf.mx[1]; cmx[2] = lf.mx[2];
+                hc = 1;
+            } else {
+                const volatile float* b = boxes + (size_t)ch[k] * 6;
+                cmn[0] = b[0]; cmn[1] = b[1]; cmn[2] = b[2]; cmx[0] = b[3]; cmx[1] = b[4]; cmx[2] = b[5];
+                hc = ((const volatile uint32_t*)height)[ch[k]] + 1;
+            }
+            if (k == 0) { for (int a = 0; a < 3; ++a) { mn[a] = cmn[a]; mx[a] = cmx[a]; } h = hc; }
+            else { for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], cmn[a]); mx[a] = fmaxf(mx[a], cmx[a]); } h = max(h, hc); }
+        }
+        float* b = boxes + (size_t)cur * 6;
+        b[0] = mn[0]; b[1] = mn[1]; b[2] = mn[2]; b[3] = mx[0]; b[4] = mx[1]; b[5] = mx[2];
+        height[cur] = h;
+        if (cur == 0) return;
+        cur = tp.parent_interior[cur];
+    }
+}
+
+// fat node i (dev_scene.hpp) + record of interior i in the reference layout; one thread per interior node
+__global__ void __launch_bounds__(256) k_lbvh_emit(const DLeaf* leaves, const uint32_t* vals, uint32_t n, DTopo tp, const float* boxes,
+                                                  uint32_t* blob_nodes, trc_BVH* ref) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i + 1 >= n) return;
+    const uint32_t ch[2] = {tp.child_l[i], tp.child_r[i]};
+    float cb[2][6];
+    uint32_t tag[2], slot[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t c = ch[k] & ~kChildLeaf;
+        if (ch[k] & kChildLeaf) {
+            const uint32_t leaf = vals[c];
+            const DLeaf& lf = leaves[leaf];
+            cb[k][0] = lf.mn[0]; cb[k][1] = lf.mn[1]; cb[k][2] = lf.mn[2]; cb[k][3] = lf.mx[0]; cb[k][4] = lf.mx[1]; cb[k][5] = lf.mx[2];
+            tag[k] = lf.tag;
+            slot[k] = leaf + 1u;
+        } else {
+            const float* b = boxes + (size_t)c * 6;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) cb[k][a] = b[a];
+            tag[k] = (kTagInterior << kTagIndexBits) | c;
+            slot[k] = n + c;                                   // interior c >= 1 here (0 is the root)
+        }
+    }
+    uint32_t* q = blob_nodes + (size_t)i * kNodeDwords;
+    q[0] = __float_as_uint(cb[0][0]); q[1] = __float_as_uint(cb[0][1]); q[2] = __float_as_uint(cb[0][2]); q[3] = __float_as_uint(cb[0][3]);
+    q[4] = __float_as_uint(cb[0][4]); q[5] = __float_as_uint(cb[0][5]); q[6] = __float_as_uint(cb[1][0]); q[7] = __float_as_uint(cb[1][1]);
+    q[8] = __float_as_uint(cb[1][2]); q[9] = __float_as_uint(cb[1][3]); q[10] = __float_as_uint(cb[1][4]); q[11] = __float_as_uint(cb[1][5]);
+    q[12] = 0; q[13] = 0; q[14] = tag[0]; q[15] = tag[1];
+
+    const uint32_t self = i == 0 ? 0u : n + i;
+    trc_BVH nd;
+    const uint32_t pi = tp.parent_interior[i];
+    nd.parent = i == 0 ? 0u : (pi == 0 ? 0u : n + pi);
+    nd.left = slot[0]; nd.right = slot[1];
+    nd.axis = tp.axis[i];
+    nd.pType = TRC_PRIM_BVH; nd.pIndex = 0; nd._pad[0] = 0; nd._pad[1] = 0;
+    const float* b = boxes + (size_t)i * 6;
+    nd.bBOX.mini.x = b[0]; nd.bBOX.mini.y = b[1]; nd.bBOX.mini.z = b[2];
+    nd.bBOX.maxi.x = b[3]; nd.bBOX.maxi.y = b[4]; nd.bBOX.maxi.z = b[5];
+    ref[self] = nd;
+    if (ch[0] & kChildLeaf) ref[slot[0]].parent = self;      // leaf records were uploaded with parent 0;
+    if (ch[1] & kChildLeaf) ref[slot[1]].parent = self;      // interior children write their own record
+}
+
+struct Buffers {
+    std::vector<void*> ptrs;
+    ~Buffers() { for (void* p : ptrs) (void)hipFree(p); }
+    template <class T> hipError_t alloc(T** out, size_t count) {
+        hipError_t e = hipMalloc((void**)out, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) ptrs.push_back(*out);
+        return e;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+trc_status trc_upload_scene_lbvh(trc_ctx* ctx, const trc_scene* s) {
+    if (!ctx) return TRC_ERR_INVALID_ARG;
+    if (!s || !s->bvhList || s->n_bvh < 2) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "lbvh: need >= 2 leaf records");
+    if (s->n_bvh > (1u << 28)) return trc_fail(ctx, TRC_ERR_UNSUPPORTED, "lbvh: more than 2^28 leaves");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { trc_status st = validate_primitives(ctx, s); if (st != TRC_OK) return st; }
+    const uint32_t n = s->n_bvh, n_interior = n - 1, n_nodes = 2 * n - 1;
+
+    // compact leaves + the reference-layout array with the leaves in place
+    std::vector<DLeaf> leaves(n);
+    std::vector<trc_BVH> ref(n_nodes);
+    std::memset(ref.data(), 0, sizeof(trc_BVH) * n_nodes);
+    for (uint32_t k = 0; k < n; ++k) {
+        const trc_BVH& l = s->bvhList[k];
+        if (l.pType == TRC_PRIM_BVH) return trc_fail(ctx, TRC_ERR_BVH_INVALID, "lbvh: input must be leaf records only");
+        { trc_status st = validate_leaf(ctx, s, l); if (st != TRC_OK) return st; }
+        DLeaf& d = leaves[k];
+        d.mn[0] = l.bBOX.mini.x; d.mn[1] = l.bBOX.mini.y; d.mn[2] = l.bBOX.mini.z;
+        d.mx[0] = l.bBOX.maxi.x; d.mx[1] = l.bBOX.maxi.y; d.mx[2] = l.bBOX.maxi.z;
+        d.tag = ((uint32_t)l.pType << kTagIndexBits) | l.pIndex; d._pad = 0;
+        ref[k + 1] = l;
+        ref[k + 1].parent = 0; ref[k + 1].left = 0; ref[k + 1].right = 0;
+    }
+
+    DScene sc{};
+    uint64_t total = 0;
+    { trc_status st = layout_scene(ctx, s, n_interior, sc, total); if (st != TRC_OK) return st; }
+    std::vector<uint32_t> blob((size_t)total, 0u);
+    fill_primitives(s, sc, blob);
+
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_blob) { (void)hipFree(ctx->d_blob); ctx->d_blob = nullptr; }
+    if (ctx->d_bvh_ref) { (void)hipFree(ctx->d_bvh_ref); ctx->d_bvh_ref = nullptr; }
+    ctx->has_scene = false; ctx->n_bvh_ref = 0;
+    ctx->blob_bytes = blob.size() * 4;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_blob, ctx->blob_bytes));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_bvh_ref, sizeof(trc_BVH) * n_nodes));
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_blob, blob.data(), ctx->blob_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bvh_ref, ref.data(), sizeof(trc_BVH) * n_nodes, hipMemcpyHostToDevice, st));
+
+    Buffers buf;
+    DLeaf* d_leaves; uint32_t *d_keys[2], *d_vals[2], *d_hist, *d_bounds, *d_height, *d_arrived;
+    float* d_boxes;
+    DTopo tp{};
+    const uint32_t n_sort_blocks = (n + kSortTile - 1) / kSortTile;
+    HIP_TRY(ctx, buf.alloc(&d_leaves, n));
+    for (int k = 0; k < 2; ++k) { HIP_TRY(ctx, buf.alloc(&d_keys[k], n)); HIP_TRY(ctx, buf.alloc(&d_vals[k], n)); }
+    HIP_TRY(ctx, buf.alloc(&d_hist, (size_t)256 * n_sort_blocks));
+    HIP_TRY(ctx, buf.alloc(&d_bounds, 6));
+    HIP_TRY(ctx, buf.alloc(&d_height, n_interior));
+    HIP_TRY(ctx, buf.alloc(&d_arrived, n_interior));
+    HIP_TRY(ctx, buf.alloc(&d_boxes, (size_t)n_interior * 6));
+    HIP_TRY(ctx, buf.alloc(&tp.child_l, n_interior)); HIP_TRY(ctx, buf.alloc(&tp.child_r, n_interior));
+    HIP_TRY(ctx, buf.alloc(&tp.parent_interior, n_interior)); HIP_TRY(ctx, buf.alloc(&tp.parent_leaf, n));
+    HIP_TRY(ctx, buf.alloc(&tp.axis, n_interior));
+    HIP_TRY(ctx, hipMemcpyAsync(d_leaves, leaves.data(), sizeof(DLeaf) * n, hipMemcpyHostToDevice, st));
+    const uint32_t bounds_init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    HIP_TRY(ctx, hipMemcpyAsync(d_bounds, bounds_init, sizeof bounds_init, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemsetAsync(d_arrived, 0, sizeof(uint32_t) * n_interior, st));
+
+    hipEvent_t e0, e1;
+    HIP_TRY(ctx, hipEventCreate(&e0)); HIP_TRY(ctx, hipEventCreate(&e1));
+    HIP_TRY(ctx, hipEventRecord(e0, st));
+    const dim3 g_leaf((n + 255) / 256), g_int((n_interior + 255) / 256), b256(256);
+    hipLaunchKernelGGL(k_lbvh_bounds, g_leaf, b256, 0, st, d_leaves, n, d_bounds);
+    hipLaunchKernelGGL(k_lbvh_keys, g_leaf, b256, 0, st, d_leaves, n, d_bounds, d_keys[0], d_vals[0]);
+    int cur = 0;
+    for (uint32_t shift = 0; shift < 32; shift += 8) {
+        hipLaunchKernelGGL(k_radix_hist, dim3(n_sort_blocks), dim3(kSortBlock), 0, st, d_keys[cur], n, shift, d_hist, n_sort_blocks);
+        hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, st, d_hist, 256u * n_sort_blocks);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(n_sort_blocks), dim3(kSortBlock), 0, st, d_keys[cur], d_vals[cur], d_keys[cur ^ 1],
+                           d_vals[cur ^ 1], n, shift, d_hist, n_sort_blocks);
+        cur ^= 1;
+    }
+    hipLaunchKernelGGL(k_lbvh_hierarchy, g_int, b256, 0, st, d_keys[cur], d_vals[cur], n, tp);
+    hipLaunchKernelGGL(k_lbvh_refit, g_leaf, b256, 0, st, d_leaves, d_vals[cur], n, tp, d_boxes, d_height, d_arrived);
+    hipLaunchKernelGGL(k_lbvh_emit, g_int, b256, 0, st, d_leaves, d_vals[cur], n, tp, d_boxes, ctx->d_blob + sc.off_nodes, ctx->d_bvh_ref);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(e1, st));
+
+    uint32_t height = 0;
+    float root_box[6];
+    HIP_TRY(ctx, hipMemcpyAsync(&height, d_height, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(root_box, d_boxes, sizeof root_box, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (height > TRC_MAX_BVH_DEPTH) return trc_fail(ctx, TRC_ERR_BVH_INVALID, "lbvh: tree deeper than TRC_MAX_BVH_DEPTH");
+
+    plan_lds(sc, height, false);      // Karras numbering is not top-of-tree first: stage the whole tree or nothing
+    sc.blob = ctx->d_blob;
+    KScene ks{};
+    ks.sc = sc;
+    for (int a = 0; a < 6; ++a) ks.root_box[a] = root_box[a];
+    ctx->ks = ks;
+    ctx->lds_scene = sc.n_lds_nodes == sc.n_nodes;
+    ctx->n_bvh_ref = n_nodes;
+    ctx->lbvh_height = height;
+    ctx->lbvh_build_ms = ms;
+    ctx->has_scene = true;
+    return TRC_OK;
+}
+
+trc_status trc_download_bvh(trc_ctx* ctx, trc_BVH* out, uint32_t capacity, uint32_t* n_nodes) {
+    if (!ctx) return TRC_ERR_INVALID_ARG;
+    if (!ctx->d_bvh_ref || ctx->n_bvh_ref == 0) return trc_fail(ctx, TRC_ERR_NO_SCENE, "trc_download_bvh: no device-built tree (trc_upload_scene_lbvh)");
+    if (n_nodes) *n_nodes = ctx->n_bvh_ref;
+    if (!out) return TRC_OK;
+    if (capacity < ctx->n_bvh_ref) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "trc_download_bvh: capacity too small");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_bvh_ref, sizeof(trc_BVH) * ctx->n_bvh_ref, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TRC_OK;
+}
+
+trc_status trc_lbvh_info(trc_ctx* ctx, uint32_t* n_nodes, uint32_t* height, float* device_build_ms) {
+    if (!ctx) return TRC_ERR_INVALID_ARG;
+    if (ctx->n_bvh_ref == 0) return trc_fail(ctx, TRC_ERR_NO_SCENE, "trc_lbvh_info: no device-built tree");
+    if (n_nodes) *n_nodes = ctx->n_bvh_ref;
+    if (height) *height = ctx->lbvh_height;
+    if (device_build_ms) *device_build_ms = ctx->lbvh_build_ms;
+    return TRC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,134 @@
+// trc_scene_prep.hpp -- host-side preparation of the device scene blob (layout in dev_scene.hpp), shared by the
+// host-tree upload (trc_upload_scene, trc_abi.hip) and the on-device LBVH upload (trc_lbvh.hip).
+#pragma once
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "trc_ctx.hpp"
+
+inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+
+// checks shared by the host-tree and the device-LBVH upload paths: primitive arrays, indices, materials
+inline trc_status validate_primitives(trc_ctx* ctx, const trc_scene* s) {
+    if (!s->materials || s->n_material == 0) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "scene: no materials");
+    if (s->n_index % 3) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "scene: n_index not a multiple of 3");
+    const uint32_t n_tri = s->n_index / 3;
+    for (uint32_t t = 0; t < s->n_index; ++t)
+        if (s->idxList[t] >= s->n_vertex) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "scene: triangle index out of range");
+    auto bad_mat = [&](uint32_t m) { return m >= s->n_material; };
+    for (uint32_t i = 0; i < s->n_sphere; ++i) if (bad_mat(s->sphereList[i].material)) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "sphere material out of range");
+    for (uint32_t i = 0; i < s->n_square; ++i) if (bad_mat(s->squareList[i].material)) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "square material out of range");
+    for (uint32_t i = 0; i < s->n_cube; ++i) if (bad_mat(s->cubeList[i].material)) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "cube material out of range");
+    if (n_tri && s->n_material <= 19) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "triangles use material 19 (Triangle.hh:82): need >= 20 materials");
+    for (uint32_t i = 0; i < s->n_square; ++i)
+        if (s->squareList[i].axis_i > 2 || s->squareList[i].axis_j > 2 || s->squareList[i].axis_k > 2)
+            return trc_fail(ctx, TRC_ERR_INVALID_ARG, "square axis out of range");
+    return TRC_OK;
+}
+inline trc_status validate_leaf(trc_ctx* ctx, const trc_scene* s, const trc_BVH& leaf) {
+    const int32_t t = leaf.pType;
+    const uint32_t pi = leaf.pIndex, n_tri = s->n_index / 3;
+    const uint32_t limit = t == TRC_PRIM_SPHERE ? s->n_sphere : t == TRC_PRIM_SQUARE ? s->n_square
+                         : t == TRC_PRIM_CUBE ? s->n_cube : t == TRC_PRIM_TRIANGLE ? n_tri : 0;
+    if (t < 0 || t > TRC_PRIM_TRIANGLE || pi >= limit) return trc_fail(ctx, TRC_ERR_BVH_INVALID, "bvh: leaf with bad primitive type/index");
+    if (pi > kTagIndexMask) return trc_fail(ctx, TRC_ERR_UNSUPPORTED, "bvh: primitive index exceeds 29 bits");
+    return TRC_OK;
+}
+
+// blob offsets for `n_interior` fat nodes (see dev_scene.hpp)
+inline trc_status layout_scene(trc_ctx* ctx, const trc_scene* s, uint32_t n_interior, DScene& sc, uint64_t& total_dwords) {
+    const uint32_t n_tri = s->n_index / 3;
+    auto align4 = [](uint32_t v) { return (v + 3u) & ~3u; };
+    sc = DScene{};
+    sc.off_spheres = 0;
+    sc.off_squares = align4(sc.off_spheres + s->n_sphere * kSphereDwords);
+    sc.off_cubes = align4(sc.off_squares + s->n_square * kSquareDwords);
+    sc.off_materials = align4(sc.off_cubes + s->n_cube * kCubeDwords);
+    sc.off_nodes = align4(sc.off_materials + s->n_material * kMaterialDwords);
+    if ((uint64_t)sc.off_nodes * 4 + kNodeDwords * 4 > kLdsSceneBytes)
+        return trc_fail(ctx, TRC_ERR_UNSUPPORTED, "analytic primitives + materials exceed the LDS staging budget");
+    sc.off_tripos = align4(sc.off_nodes + n_interior * kNodeDwords);
+    total_dwords = (uint64_t)sc.off_tripos + (uint64_t)n_tri * kTriPosDwords + (uint64_t)n_tri * kTriAttrDwords;
+    if (total_dwords > 0xFFFFFFF0ull) return trc_fail(ctx, TRC_ERR_UNSUPPORTED, "scene too large for 32-bit dword offsets");
+    sc.off_triattr = sc.off_tripos + n_tri * kTriPosDwords;
+    sc.n_nodes = n_interior; sc.n_spheres = s->n_sphere; sc.n_squares = s->n_square; sc.n_cubes = s->n_cube;
+    sc.n_materials = s->n_material; sc.n_triangles = n_tri;
+    return TRC_OK;
+}
+
+// LDS per workgroup = staged prefix + traversal stack; keep 4 workgroups per CU resident (measured on
+// MI355X: occupancy beats top-of-tree staging -- 8/16/24/40/64 KB staged on the 1 M-triangle scene gave
+// 1826/1553/1155/1165/666 Mrays/s), so nodes are staged only into what the stack leaves of ~38 KB.
+// `prefix_ok`: the first fat nodes are the top of the tree (BFS order); otherwise all or nothing.
+inline void plan_lds(DScene& sc, uint32_t max_leaf_depth, bool prefix_ok) {
+    const uint32_t stack_dwords = std::max(1u, max_leaf_depth) * kBlock;
+    uint32_t budget_dwords = (38u * 1024u / 4u > stack_dwords) ? 38u * 1024u / 4u - stack_dwords : 0u;
+    budget_dwords = std::min(budget_dwords, kLdsSceneBytes / 4);
+    if (const char* e = std::getenv("TRC_LDS_BUDGET_KB")) {          // tuning knob: staged bytes vs occupancy
+        const long kb = std::atol(e);
+        if (kb > 0 && kb <= 128) budget_dwords = (uint32_t)kb * 256u;
+    }
+    budget_dwords = std::max(budget_dwords, sc.off_nodes + kNodeDwords);
+    sc.n_lds_nodes = std::min<uint32_t>(sc.n_nodes, (budget_dwords - sc.off_nodes) / kNodeDwords);
+    if (!prefix_ok && sc.n_lds_nodes < sc.n_nodes) sc.n_lds_nodes = 0;
+    sc.lds_dwords = sc.off_nodes + sc.n_lds_nodes * kNodeDwords;
+    sc.stack_depth = std::max(1u, max_leaf_depth);
+}
+
+// analytic primitives, materials and triangles into the blob (everything but the fat nodes)
+inline void fill_primitives(const trc_scene* s, const DScene& sc, std::vector<uint32_t>& blob) {
+    const uint32_t n_tri = s->n_index / 3;
+    for (uint32_t i = 0; i < s->n_sphere; ++i) {
+        const trc_Sphere& sp = s->sphereList[i];
+        uint32_t* q = &blob[sc.off_spheres + (size_t)i * kSphereDwords];
+        q[0] = f2u(sp.center.x); q[1] = f2u(sp.center.y); q[2] = f2u(sp.center.z); q[3] = f2u(sp.radius);
+        q[4] = sp.material;
+    }
+    for (uint32_t i = 0; i < s->n_square; ++i) {
+        const trc_Square& sq = s->squareList[i];
+        uint32_t* q = &blob[sc.off_squares + (size_t)i * kSquareDwords];
+        q[0] = f2u(sq.range_i.x); q[1] = f2u(sq.range_i.y); q[2] = f2u(sq.range_j.x); q[3] = f2u(sq.range_j.y);
+        // Square::area() = 2*i*j and aeraPDF() = 1/area (Square.hh:31-38), evaluated once here in binary32
+        const float di = sq.range_i.y - sq.range_i.x, dj = sq.range_j.y - sq.range_j.x;
+        const float area = 2 * di * dj;
+        const float pdf = 1 / area;
+        q[4] = f2u(sq.value_k); q[5] = f2u(pdf);
+        q[6] = (uint32_t)sq.axis_i | ((uint32_t)sq.axis_j << 2) | ((uint32_t)sq.axis_k << 4);
+        q[7] = sq.material;
+    }
+    for (uint32_t i = 0; i < s->n_cube; ++i) {
+        const trc_Cube& cb = s->cubeList[i];
+        uint32_t* q = &blob[sc.off_cubes + (size_t)i * kCubeDwords];
+        auto put_cols = [&](uint32_t* dst, const trc_float4x4& m, int ncols) {
+            for (int c = 0; c < ncols; ++c) { dst[3 * c] = f2u(m.columns[c].x); dst[3 * c + 1] = f2u(m.columns[c].y); dst[3 * c + 2] = f2u(m.columns[c].z); }
+        };
+        put_cols(q, cb.inverse_matrix, 4);
+        put_cols(q + 12, cb.model_matrix, 4);
+        put_cols(q + 24, cb.normal_matrix, 3);
+        q[33] = f2u(cb.box.mini.x); q[34] = f2u(cb.box.mini.y); q[35] = f2u(cb.box.mini.z);
+        q[36] = f2u(cb.box.maxi.x); q[37] = f2u(cb.box.maxi.y); q[38] = f2u(cb.box.maxi.z);
+        q[39] = cb.material;
+    }
+    for (uint32_t i = 0; i < s->n_material; ++i) {
+        const trc_Material& m = s->materials[i];
+        uint32_t* q = &blob[sc.off_materials + (size_t)i * kMaterialDwords];
+        q[0] = (uint32_t)m.type; q[1] = (uint32_t)m.textureInfo.type;
+        q[2] = f2u(m.textureInfo.albedo.x); q[3] = f2u(m.textureInfo.albedo.y); q[4] = f2u(m.textureInfo.albedo.z);
+        q[5] = m.specular ? 1u : 0u;
+    }
+    for (uint32_t t = 0; t < n_tri; ++t) {
+        const trc_TriangleVertex* v[3] = {&s->triList[s->idxList[3 * t]], &s->triList[s->idxList[3 * t + 1]],
+                                          &s->triList[s->idxList[3 * t + 2]]};
+        uint32_t* p = &blob[sc.off_tripos + (size_t)t * kTriPosDwords];
+        uint32_t* a = &blob[sc.off_triattr + (size_t)t * kTriAttrDwords];
+        for (int k = 0; k < 3; ++k) {
+            p[4 * k] = f2u(v[k]->v[0]); p[4 * k + 1] = f2u(v[k]->v[1]); p[4 * k + 2] = f2u(v[k]->v[2]);
+            a[3 * k] = f2u(v[k]->n[0]); a[3 * k + 1] = f2u(v[k]->n[1]); a[3 * k + 2] = f2u(v[k]->n[2]);
+            a[9 + 2 * k] = f2u(v[k]->uv[0]); a[10 + 2 * k] = f2u(v[k]->uv[1]);
+        }
+    }
+}
+

@@ -43,6 +43,9 @@ def lib():
         L.trc_destroy.argtypes = [vp]
         L.trc_destroy.restype = None
         L.trc_upload_scene.argtypes = [vp, C.POINTER(abi.Scene)]
+        L.trc_upload_scene_lbvh.argtypes = [vp, C.POINTER(abi.Scene)]
+        L.trc_download_bvh.argtypes = [vp, C.POINTER(abi.BVH), u32, C.POINTER(u32)]
+        L.trc_lbvh_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_float)]
         L.trc_set_camera.argtypes = [vp, C.POINTER(abi.Camera)]
         L.trc_set_environment.argtypes = [vp, C.POINTER(C.c_float)]
         L.trc_resize.argtypes = [vp, u32, u32]
@@ -114,6 +117,24 @@ class Tracer:
     # --- scene / camera / frame -------------------------------------------------
     def upload_scene(self, scene_view):
         self._check(self._L.trc_upload_scene(self._h, C.byref(scene_view)), "trc_upload_scene")
+
+    def upload_scene_lbvh(self, leaves_view):
+        """Scene whose bvhList holds only leaf records (HostScene.leaves_view()); the tree is built on the GPU."""
+        self._check(self._L.trc_upload_scene_lbvh(self._h, C.byref(leaves_view)), "trc_upload_scene_lbvh")
+
+    def download_bvh(self):
+        """The device-built tree in the reference's array layout: ctypes array of abi.BVH (2n-1 records)."""
+        n = C.c_uint32(0)
+        self._check(self._L.trc_download_bvh(self._h, None, 0, C.byref(n)), "trc_download_bvh")
+        out = (abi.BVH * n.value)()
+        self._check(self._L.trc_download_bvh(self._h, out, n.value, C.byref(n)), "trc_download_bvh")
+        return out
+
+    def lbvh_info(self):
+        """(n_nodes, depth of the deepest leaf, GPU build time in ms) of the last upload_scene_lbvh."""
+        n, h, ms = C.c_uint32(0), C.c_uint32(0), C.c_float(0)
+        self._check(self._L.trc_lbvh_info(self._h, C.byref(n), C.byref(h), C.byref(ms)), "trc_lbvh_info")
+        return n.value, h.value, ms.value
 
     def set_camera(self, camera):
         self._check(self._L.trc_set_camera(self._h, C.byref(camera)), "trc_set_camera")

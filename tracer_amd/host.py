@@ -139,6 +139,24 @@ class HostScene:
         a = (C.c_uint32 * (16 * self.view.n_bvh)).from_address(C.addressof(self.view.bvhList.contents))
         return np.frombuffer(a, dtype=np.uint32).reshape(-1, 16)
 
+    def leaves(self):
+        """Pointer to the n_leaves leaf records (BVH::buildTree keeps them at [1, n], BVH.hh:246-269)."""
+        return C.cast(C.addressof(self.view.bvhList.contents) + C.sizeof(abi.BVH), C.POINTER(abi.BVH))
+
+    def leaves_view(self):
+        """Copy of `view` whose bvhList holds only the leaf records: the input of Tracer.upload_scene_lbvh."""
+        v = abi.Scene.from_buffer_copy(self.view)
+        v.bvhList = self.leaves()
+        v.n_bvh = self.n_leaves
+        return v
+
+    def view_with_bvh(self, nodes):
+        """Copy of `view` over another node array (ctypes array of abi.BVH); the caller keeps `nodes` alive."""
+        v = abi.Scene.from_buffer_copy(self.view)
+        v.bvhList = C.cast(nodes, C.POINTER(abi.BVH))
+        v.n_bvh = len(nodes)
+        return v
+
     def tree_depth(self):
         d = C.c_uint32()
         _check(lib().trc_host_tree_depth(self.view.bvhList, self.view.n_bvh, C.byref(d)), "trc_host_tree_depth")
