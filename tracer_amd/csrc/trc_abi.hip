@@ -278,7 +278,7 @@ trc_status build_blob(trc_ctx* ctx, const trc_scene* s, std::vector<uint32_t>& b
         q[8] = f2u(R.mini.z); q[9] = f2u(R.maxi.x); q[10] = f2u(R.maxi.y); q[11] = f2u(R.maxi.z);
         q[12] = 0; q[13] = 0; q[14] = tag_of(nd.left); q[15] = tag_of(nd.right);
     }
-    fill_primitives(s, sc, blob);
+    fill_primitives(s, sc, blob.data());
     ks.sc = sc;
     const trc_AABB& rb = nodes[0].bBOX;
     ks.root_box[0] = rb.mini.x; ks.root_box[1] = rb.mini.y; ks.root_box[2] = rb.mini.z;

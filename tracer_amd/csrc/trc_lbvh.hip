@@ -8,7 +8,7 @@
 //   k_lbvh_keys       30-bit Morton code of every centroid          key = code, value = leaf index
 //   k_radix_*         stable LSD radix sort, 4 passes x 8 bits      (ties keep leaf-index order)
 //   k_lbvh_hierarchy  T. Karras' binary radix tree (HPG 2012) over the 64-bit keys (code << 32 | index)
-//   k_lbvh_refit      boxes + subtree heights bottom-up             one atomic counter per interior node
+//   k_lbvh_refit_pass boxes + subtree heights bottom-up             one launch per level, no atomics / fences
 //   k_lbvh_emit       fat nodes into the scene blob (dev_scene.hpp) + the tree in the reference's own array
 //                     layout [root, leaf 0..n-1, interior 1..n-2] (BVH.hh:246-269) for trc_download_bvh
 //
@@ -18,6 +18,8 @@
 
 #include <algorithm>
 #include <cstring>
+#include <memory>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -46,16 +48,40 @@ __device__ __forceinline__ void leaf_centroid(const DLeaf& l, float c[3]) {
     c[0] = (l.mn[0] + l.mx[0]) * 0.5f; c[1] = (l.mn[1] + l.mx[1]) * 0.5f; c[2] = (l.mn[2] + l.mx[2]) * 0.5f;
 }
 
-// bounds[0..2] = min, bounds[3..5] = max of the centroids, as ordered uints (init: 0xFFFFFFFF / 0)
-__global__ void __launch_bounds__(256) k_lbvh_bounds(const DLeaf* leaves, uint32_t n, uint32_t* bounds) {
+// leaf records as uploaded (reference layout, ref_leaves = slot 1 of the output array) -> compact DLeaf; checks
+// what trc_upload_scene checks on the host (primitive type / index range) and clears the link fields
+struct LeafLimits { uint32_t n[4]; };      // spheres, squares, cubes, triangles
+__global__ void __launch_bounds__(256) k_lbvh_prepare(trc_BVH* ref_leaves, uint32_t n, LeafLimits lim, DLeaf* out, uint32_t* bad) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    trc_BVH& r = ref_leaves[i];
+    const int32_t t = r.pType;
+    const uint32_t pi = r.pIndex;
+    if (t == TRC_PRIM_BVH) atomicOr(bad, 1u);
+    else if (t < 0 || t > TRC_PRIM_TRIANGLE || pi >= lim.n[t]) atomicOr(bad, 2u);
+    else if (pi > kTagIndexMask) atomicOr(bad, 4u);
+    DLeaf d;
+    d.mn[0] = r.bBOX.mini.x; d.mn[1] = r.bBOX.mini.y; d.mn[2] = r.bBOX.mini.z;
+    d.mx[0] = r.bBOX.maxi.x; d.mx[1] = r.bBOX.maxi.y; d.mx[2] = r.bBOX.maxi.z;
+    d.tag = ((uint32_t)t << kTagIndexBits) | (pi & kTagIndexMask); d._pad = 0;
+    out[i] = d;
+    r.parent = 0; r.left = 0; r.right = 0;
+}
+
+// bounds[0..2] = min, bounds[3..5] = max of the centroids, as ordered uints (init: 0xFFFFFFFF / 0).
+// Grid-stride loop, wavefront shuffle reduction, LDS across the 4 wavefronts, 6 atomics per workgroup.
+__global__ void __launch_bounds__(256) k_lbvh_bounds(const DLeaf* leaves, uint32_t n, uint32_t* bounds) {
+    __shared__ uint32_t part[4][6];
     uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
-    if (i < n) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
         float c[3];
         leaf_centroid(leaves[i], c);
 #pragma unroll
         for (int a = 0; a < 3; ++a)
-            if (c[a] == c[a]) { lo[a] = hi[a] = ordered_of(c[a]); }        // NaN centroids do not take part
+            if (c[a] == c[a]) {                                            // NaN centroids do not take part
+                const uint32_t o = ordered_of(c[a]);
+                lo[a] = min(lo[a], o); hi[a] = max(hi[a], o);
+            }
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -65,9 +91,16 @@ __global__ void __launch_bounds__(256) k_lbvh_bounds(const DLeaf* leaves, uint32
             hi[a] = max(hi[a], (uint32_t)__shfl_xor((int)hi[a], off, 64));
         }
     }
-    if ((threadIdx.x & 63u) == 0) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { atomicMin(&bounds[a], lo[a]); atomicMax(&bounds[3 + a], hi[a]); }
+        for (int a = 0; a < 3; ++a) { part[wave][a] = lo[a]; part[wave][3 + a] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const uint32_t a = threadIdx.x;
+        atomicMin(&bounds[a], min(min(part[0][a], part[1][a]), min(part[2][a], part[3][a])));
+        atomicMax(&bounds[3 + a], max(max(part[0][3 + a], part[1][3 + a]), max(part[2][3 + a], part[3][3 + a])));
     }
 }
 
@@ -113,32 +146,54 @@ __global__ void __launch_bounds__(kSortBlock) k_radix_hist(const uint32_t* keys,
     hist[threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x];
 }
 
-// exclusive scan of `count` entries in place, one workgroup of 1024 threads
-__global__ void __launch_bounds__(1024) k_radix_scan(uint32_t* data, uint32_t count) {
-    __shared__ uint32_t part[1024];
-    const uint32_t per = (count + 1023u) / 1024u;
-    const uint32_t b = threadIdx.x * per, e = min(b + per, count);
-    uint32_t s = 0;
-    for (uint32_t i = b; i < e; ++i) s += data[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {            // Hillis-Steele inclusive scan
-        const uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
+// hist[digit][block] -> exclusive scan along the row of each digit (one workgroup per digit) + row totals;
+// k_radix_digit_base then scans the 256 totals.  Output slot of a key = digit_base[d] + hist[d][block] + rank.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)v, off, 64);
+        if (lane >= (uint32_t)off) v += t;
     }
-    uint32_t run = part[threadIdx.x] - s;
-    for (uint32_t i = b; i < e; ++i) { const uint32_t v = data[i]; data[i] = run; run += v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t block_exclusive_scan256(uint32_t v, uint32_t* wave_tot /* [4] LDS */, uint32_t& total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t inc = wave_inclusive_scan(v, lane);
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < wave; ++w) before += wave_tot[w];
+    total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    __syncthreads();
+    return before + inc - v;
+}
+__global__ void __launch_bounds__(256) k_radix_row_scan(uint32_t* hist, uint32_t n_blocks, uint32_t* row_total) {
+    __shared__ uint32_t wave_tot[4];
+    uint32_t* row = hist + (size_t)blockIdx.x * n_blocks;
+    uint32_t carry = 0;
+    for (uint32_t b = 0; b < n_blocks; b += 256) {
+        const uint32_t i = b + threadIdx.x;
+        const uint32_t v = i < n_blocks ? row[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan256(v, wave_tot, total);
+        if (i < n_blocks) row[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) row_total[blockIdx.x] = carry;
+}
+__global__ void __launch_bounds__(256) k_radix_digit_base(uint32_t* row_total) {
+    __shared__ uint32_t wave_tot[4];
+    uint32_t total;
+    row_total[threadIdx.x] = block_exclusive_scan256(row_total[threadIdx.x], wave_tot, total);
 }
 
 __global__ void __launch_bounds__(kSortBlock) k_radix_scatter(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
                                                              uint32_t* vals_out, uint32_t n, uint32_t shift, const uint32_t* hist,
-                                                             uint32_t n_blocks) {
+                                                             const uint32_t* digit_base, uint32_t n_blocks) {
     __shared__ uint32_t run[256];            // next output slot of each digit for this tile
     __shared__ uint32_t wave_cnt[4][256];    // keys of each digit per wavefront in the current round
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    run[threadIdx.x] = hist[threadIdx.x * n_blocks + blockIdx.x];
+    run[threadIdx.x] = digit_base[threadIdx.x] + hist[threadIdx.x * n_blocks + blockIdx.x];
 #pragma unroll
     for (int w = 0; w < 4; ++w) wave_cnt[w][threadIdx.x] = 0;
     __syncthreads();
@@ -182,7 +237,7 @@ constexpr uint32_t kChildLeaf = 0x80000000u;
 struct DTopo {
     uint32_t* child_l; uint32_t* child_r;    // [n-1]
     uint32_t* parent_interior;               // [n-1] parent interior index of interior i (root: 0)
-    uint32_t* parent_leaf;                   // [n]   parent interior index of sorted leaf position p
+    uint32_t* parent_leaf;                   // [n]   parent interior index of sorted leaf position p (kept for tools)
     uint32_t* axis;                          // [n-1]
 };
 
@@ -224,41 +279,41 @@ __global__ void __launch_bounds__(256) k_lbvh_hierarchy(const uint32_t* keys, co
     if (i == 0) tp.parent_interior[0] = 0;
 }
 
-// boxes[i] = 6 floats (min xyz, max xyz) of interior i; height[i] = depth of the deepest leaf below i
-__global__ void __launch_bounds__(256) k_lbvh_refit(const DLeaf* leaves, const uint32_t* vals, uint32_t n, DTopo tp,
-                                                   float* boxes, uint32_t* height, uint32_t* arrived) {
-    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= n) return;
-    uint32_t cur = tp.parent_leaf[p];
-    for (;;) {
-        __threadfence();
-        if (atomicAdd(&arrived[cur], 1u) == 0u) return;           // the sibling subtree is not finished yet
-        __threadfence();
-        float mn[3], mx[3];
-        uint32_t h = 0;
-        const uint32_t ch[2] = {tp.child_l[cur], tp.child_r[cur]};
+// boxes[i] = 6 floats (min xyz, max xyz) of interior i; height[i] = depth of the deepest leaf below i.
+// Bottom-up in PASSES, one kernel launch each: a node is fitted in pass p when both children are leaves or were
+// fitted in a pass < p (done[i] = pass of fitting, 0 = not yet).  Launch boundaries are the only synchronisation:
+// the usual single-kernel climb with one atomic counter per node needs two device-scope fences per level, and on
+// the 8-XCD part each fence writes back / invalidates an L2 (measured 6.6 ms for 1 M leaves vs 0.4 ms like this).
+__global__ void __launch_bounds__(256) k_lbvh_refit_pass(const DLeaf* leaves, const uint32_t* vals, uint32_t n, DTopo tp,
+                                                        float* boxes, uint32_t* height, uint32_t* done, uint32_t pass) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i + 1 >= n || done[i] != 0u) return;
+    const uint32_t ch[2] = {tp.child_l[i], tp.child_r[i]};
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            float cmn[3], cmx[3];
-            uint32_t hc;
-            if (ch[k] & kChildLeaf) {
-                const DLeaf& lf = leaves[vals[ch[k] & ~kChildLeaf]];
-                cmn[0] = lf.mn[0]; cmn[1] = lf.mn[1]; cmn[2] = lf.mn[2]; cmx[0] = lf.mx[0]; cmx[1] = lf.mx[1]; cmx[2] = lf.mx[2];
-                hc = 1;
-            } else {
-                const volatile float* b = boxes + (size_t)ch[k] * 6;
-                cmn[0] = b[0]; cmn[1] = b[1]; cmn[2] = b[2]; cmx[0] = b[3]; cmx[1] = b[4]; cmx[2] = b[5];
-                hc = ((const volatile uint32_t*)height)[ch[k]] + 1;
-            }
-            if (k == 0) { for (int a = 0; a < 3; ++a) { mn[a] = cmn[a]; mx[a] = cmx[a]; } h = hc; }
-            else { for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], cmn[a]); mx[a] = fmaxf(mx[a], cmx[a]); } h = max(h, hc); }
+    for (int k = 0; k < 2; ++k)
+        if (!(ch[k] & kChildLeaf)) { const uint32_t d = done[ch[k]]; if (d == 0u || d >= pass) return; }
+    float mn[3], mx[3];
+    uint32_t h = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float cmn[3], cmx[3];
+        uint32_t hc;
+        if (ch[k] & kChildLeaf) {
+            const DLeaf& lf = leaves[vals[ch[k] & ~kChildLeaf]];
+            cmn[0] = lf.mn[0]; cmn[1] = lf.mn[1]; cmn[2] = lf.mn[2]; cmx[0] = lf.mx[0]; cmx[1] = lf.mx[1]; cmx[2] = lf.mx[2];
+            hc = 1;
+        } else {
+            const float* b = boxes + (size_t)ch[k] * 6;
+            cmn[0] = b[0]; cmn[1] = b[1]; cmn[2] = b[2]; cmx[0] = b[3]; cmx[1] = b[4]; cmx[2] = b[5];
+            hc = height[ch[k]] + 1;
         }
-        float* b = boxes + (size_t)cur * 6;
-        b[0] = mn[0]; b[1] = mn[1]; b[2] = mn[2]; b[3] = mx[0]; b[4] = mx[1]; b[5] = mx[2];
-        height[cur] = h;
-        if (cur == 0) return;
-        cur = tp.parent_interior[cur];
+        if (k == 0) { for (int a = 0; a < 3; ++a) { mn[a] = cmn[a]; mx[a] = cmx[a]; } h = hc; }
+        else { for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], cmn[a]); mx[a] = fmaxf(mx[a], cmx[a]); } h = max(h, hc); }
     }
+    float* b = boxes + (size_t)i * 6;
+    b[0] = mn[0]; b[1] = mn[1]; b[2] = mn[2]; b[3] = mx[0]; b[4] = mx[1]; b[5] = mx[2];
+    height[i] = h;
+    done[i] = pass;
 }
 
 // fat node i (dev_scene.hpp) + record of interior i in the reference layout; one thread per interior node
@@ -294,6 +349,7 @@ __global__ void __launch_bounds__(256) k_lbvh_emit(const DLeaf* leaves, const ui
 
     const uint32_t self = i == 0 ? 0u : n + i;
     trc_BVH nd;
+    memset(&nd, 0, sizeof nd);                                 // padding bytes of the POD are part of the compared record
     const uint32_t pi = tp.parent_interior[i];
     nd.parent = i == 0 ? 0u : (pi == 0 ? 0u : n + pi);
     nd.left = slot[0]; nd.right = slot[1];
@@ -329,38 +385,30 @@ trc_status trc_upload_scene_lbvh(trc_ctx* ctx, const trc_scene* s) {
     { trc_status st = validate_primitives(ctx, s); if (st != TRC_OK) return st; }
     const uint32_t n = s->n_bvh, n_interior = n - 1, n_nodes = 2 * n - 1;
 
-    // compact leaves + the reference-layout array with the leaves in place
-    std::vector<DLeaf> leaves(n);
-    std::vector<trc_BVH> ref(n_nodes);
-    std::memset(ref.data(), 0, sizeof(trc_BVH) * n_nodes);
-    for (uint32_t k = 0; k < n; ++k) {
-        const trc_BVH& l = s->bvhList[k];
-        if (l.pType == TRC_PRIM_BVH) return trc_fail(ctx, TRC_ERR_BVH_INVALID, "lbvh: input must be leaf records only");
-        { trc_status st = validate_leaf(ctx, s, l); if (st != TRC_OK) return st; }
-        DLeaf& d = leaves[k];
-        d.mn[0] = l.bBOX.mini.x; d.mn[1] = l.bBOX.mini.y; d.mn[2] = l.bBOX.mini.z;
-        d.mx[0] = l.bBOX.maxi.x; d.mx[1] = l.bBOX.maxi.y; d.mx[2] = l.bBOX.maxi.z;
-        d.tag = ((uint32_t)l.pType << kTagIndexBits) | l.pIndex; d._pad = 0;
-        ref[k + 1] = l;
-        ref[k + 1].parent = 0; ref[k + 1].left = 0; ref[k + 1].right = 0;
-    }
-
     DScene sc{};
     uint64_t total = 0;
     { trc_status st = layout_scene(ctx, s, n_interior, sc, total); if (st != TRC_OK) return st; }
-    std::vector<uint32_t> blob((size_t)total, 0u);
-    fill_primitives(s, sc, blob);
+    // host side of the blob: analytic primitives + materials (prefix) and the triangle records; the fat nodes in
+    // between are written by k_lbvh_emit, so that region is neither initialised nor uploaded
+    std::unique_ptr<uint32_t[]> blob(new (std::nothrow) uint32_t[(size_t)total]);
+    if (!blob) return trc_fail(ctx, TRC_ERR_OOM, "lbvh: host staging buffer");
+    std::memset(blob.get(), 0, (size_t)sc.off_nodes * 4);
+    fill_primitives(s, sc, blob.get());
 
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_blob) { (void)hipFree(ctx->d_blob); ctx->d_blob = nullptr; }
     if (ctx->d_bvh_ref) { (void)hipFree(ctx->d_bvh_ref); ctx->d_bvh_ref = nullptr; }
     ctx->has_scene = false; ctx->n_bvh_ref = 0;
-    ctx->blob_bytes = blob.size() * 4;
+    ctx->blob_bytes = (size_t)total * 4;
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_blob, ctx->blob_bytes));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_bvh_ref, sizeof(trc_BVH) * n_nodes));
     hipStream_t st = ctx->stream;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_blob, blob.data(), ctx->blob_bytes, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bvh_ref, ref.data(), sizeof(trc_BVH) * n_nodes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_blob, blob.get(), (size_t)sc.off_nodes * 4, hipMemcpyHostToDevice, st));
+    if (total > sc.off_tripos)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_blob + sc.off_tripos, blob.get() + sc.off_tripos, ((size_t)total - sc.off_tripos) * 4, hipMemcpyHostToDevice, st));
+    // the caller's leaf records go straight to slots 1..n of the reference-layout array (BVH.hh:246-269)
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_bvh_ref, 0, sizeof(trc_BVH), st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bvh_ref + 1, s->bvhList, sizeof(trc_BVH) * n, hipMemcpyHostToDevice, st));
 
     Buffers buf;
     DLeaf* d_leaves; uint32_t *d_keys[2], *d_vals[2], *d_hist, *d_bounds, *d_height, *d_arrived;
@@ -370,15 +418,16 @@ trc_status trc_upload_scene_lbvh(trc_ctx* ctx, const trc_scene* s) {
     HIP_TRY(ctx, buf.alloc(&d_leaves, n));
     for (int k = 0; k < 2; ++k) { HIP_TRY(ctx, buf.alloc(&d_keys[k], n)); HIP_TRY(ctx, buf.alloc(&d_vals[k], n)); }
     HIP_TRY(ctx, buf.alloc(&d_hist, (size_t)256 * n_sort_blocks));
-    HIP_TRY(ctx, buf.alloc(&d_bounds, 6));
+    uint32_t* d_digit_base;
+    HIP_TRY(ctx, buf.alloc(&d_digit_base, 256));
+    HIP_TRY(ctx, buf.alloc(&d_bounds, 8));       // 6 ordered bounds + [6] = bad-leaf flags
     HIP_TRY(ctx, buf.alloc(&d_height, n_interior));
     HIP_TRY(ctx, buf.alloc(&d_arrived, n_interior));
     HIP_TRY(ctx, buf.alloc(&d_boxes, (size_t)n_interior * 6));
     HIP_TRY(ctx, buf.alloc(&tp.child_l, n_interior)); HIP_TRY(ctx, buf.alloc(&tp.child_r, n_interior));
     HIP_TRY(ctx, buf.alloc(&tp.parent_interior, n_interior)); HIP_TRY(ctx, buf.alloc(&tp.parent_leaf, n));
     HIP_TRY(ctx, buf.alloc(&tp.axis, n_interior));
-    HIP_TRY(ctx, hipMemcpyAsync(d_leaves, leaves.data(), sizeof(DLeaf) * n, hipMemcpyHostToDevice, st));
-    const uint32_t bounds_init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    const uint32_t bounds_init[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};
     HIP_TRY(ctx, hipMemcpyAsync(d_bounds, bounds_init, sizeof bounds_init, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemsetAsync(d_arrived, 0, sizeof(uint32_t) * n_interior, st));
 
@@ -386,18 +435,35 @@ trc_status trc_upload_scene_lbvh(trc_ctx* ctx, const trc_scene* s) {
     HIP_TRY(ctx, hipEventCreate(&e0)); HIP_TRY(ctx, hipEventCreate(&e1));
     HIP_TRY(ctx, hipEventRecord(e0, st));
     const dim3 g_leaf((n + 255) / 256), g_int((n_interior + 255) / 256), b256(256);
-    hipLaunchKernelGGL(k_lbvh_bounds, g_leaf, b256, 0, st, d_leaves, n, d_bounds);
+    LeafLimits lim;
+    lim.n[0] = s->n_sphere; lim.n[1] = s->n_square; lim.n[2] = s->n_cube; lim.n[3] = s->n_index / 3;
+    hipLaunchKernelGGL(k_lbvh_prepare, g_leaf, b256, 0, st, ctx->d_bvh_ref + 1, n, lim, d_leaves, d_bounds + 6);
+    hipLaunchKernelGGL(k_lbvh_bounds, dim3(std::min<uint32_t>((n + 255) / 256, 1024u)), b256, 0, st, d_leaves, n, d_bounds);
     hipLaunchKernelGGL(k_lbvh_keys, g_leaf, b256, 0, st, d_leaves, n, d_bounds, d_keys[0], d_vals[0]);
     int cur = 0;
     for (uint32_t shift = 0; shift < 32; shift += 8) {
         hipLaunchKernelGGL(k_radix_hist, dim3(n_sort_blocks), dim3(kSortBlock), 0, st, d_keys[cur], n, shift, d_hist, n_sort_blocks);
-        hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, st, d_hist, 256u * n_sort_blocks);
+        hipLaunchKernelGGL(k_radix_row_scan, dim3(256), b256, 0, st, d_hist, n_sort_blocks, d_digit_base);
+        hipLaunchKernelGGL(k_radix_digit_base, dim3(1), b256, 0, st, d_digit_base);
         hipLaunchKernelGGL(k_radix_scatter, dim3(n_sort_blocks), dim3(kSortBlock), 0, st, d_keys[cur], d_vals[cur], d_keys[cur ^ 1],
-                           d_vals[cur ^ 1], n, shift, d_hist, n_sort_blocks);
+                           d_vals[cur ^ 1], n, shift, d_hist, d_digit_base, n_sort_blocks);
         cur ^= 1;
     }
     hipLaunchKernelGGL(k_lbvh_hierarchy, g_int, b256, 0, st, d_keys[cur], d_vals[cur], n, tp);
-    hipLaunchKernelGGL(k_lbvh_refit, g_leaf, b256, 0, st, d_leaves, d_vals[cur], n, tp, d_boxes, d_height, d_arrived);
+    // refit passes: a tree of height h needs h passes; check the root every few passes beyond the usual depth
+    uint32_t pass = 0, root_done = 0, bad_leaves = 0;
+    const uint32_t pass_limit = TRC_MAX_BVH_DEPTH + 1;
+    for (uint32_t chunk = 40; pass < pass_limit && !root_done; chunk = 8) {
+        for (uint32_t k = 0; k < chunk && pass < pass_limit; ++k)
+            hipLaunchKernelGGL(k_lbvh_refit_pass, g_int, b256, 0, st, d_leaves, d_vals[cur], n, tp, d_boxes, d_height, d_arrived, ++pass);
+        HIP_TRY(ctx, hipMemcpyAsync(&root_done, d_arrived, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(&bad_leaves, d_bounds + 6, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (bad_leaves & 1u) return trc_fail(ctx, TRC_ERR_BVH_INVALID, "lbvh: input must be leaf records only");
+        if (bad_leaves & 2u) return trc_fail(ctx, TRC_ERR_BVH_INVALID, "bvh: leaf with bad primitive type/index");
+        if (bad_leaves & 4u) return trc_fail(ctx, TRC_ERR_UNSUPPORTED, "bvh: primitive index exceeds 29 bits");
+    }
+    if (!root_done) return trc_fail(ctx, TRC_ERR_BVH_INVALID, "lbvh: tree deeper than TRC_MAX_BVH_DEPTH");
     hipLaunchKernelGGL(k_lbvh_emit, g_int, b256, 0, st, d_leaves, d_vals[cur], n, tp, d_boxes, ctx->d_blob + sc.off_nodes, ctx->d_bvh_ref);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(e1, st));

@@ -79,7 +79,8 @@ inline void plan_lds(DScene& sc, uint32_t max_leaf_depth, bool prefix_ok) {
 }
 
 // analytic primitives, materials and triangles into the blob (everything but the fat nodes)
-inline void fill_primitives(const trc_scene* s, const DScene& sc, std::vector<uint32_t>& blob) {
+// (`blob` need only be zeroed up to sc.off_nodes: every dword of a triangle record is written here)
+inline void fill_primitives(const trc_scene* s, const DScene& sc, uint32_t* blob) {
     const uint32_t n_tri = s->n_index / 3;
     for (uint32_t i = 0; i < s->n_sphere; ++i) {
         const trc_Sphere& sp = s->sphereList[i];
@@ -125,10 +126,11 @@ inline void fill_primitives(const trc_scene* s, const DScene& sc, std::vector<ui
         uint32_t* p = &blob[sc.off_tripos + (size_t)t * kTriPosDwords];
         uint32_t* a = &blob[sc.off_triattr + (size_t)t * kTriAttrDwords];
         for (int k = 0; k < 3; ++k) {
-            p[4 * k] = f2u(v[k]->v[0]); p[4 * k + 1] = f2u(v[k]->v[1]); p[4 * k + 2] = f2u(v[k]->v[2]);
+            p[4 * k] = f2u(v[k]->v[0]); p[4 * k + 1] = f2u(v[k]->v[1]); p[4 * k + 2] = f2u(v[k]->v[2]); p[4 * k + 3] = 0;
             a[3 * k] = f2u(v[k]->n[0]); a[3 * k + 1] = f2u(v[k]->n[1]); a[3 * k + 2] = f2u(v[k]->n[2]);
             a[9 + 2 * k] = f2u(v[k]->uv[0]); a[10 + 2 * k] = f2u(v[k]->uv[1]);
         }
+        a[15] = 0;
     }
 }
 
