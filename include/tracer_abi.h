@@ -192,6 +192,15 @@ typedef struct trc_CameraRecord {
     uint32_t   _pad1[2];
 } trc_CameraRecord;
 
+/* RT_Metal/Metal/Medium.hh:83-109 -- 32 bytes; describes the density grid of the GridDensity medium
+ * (bound at PackageEnv ids 3/4, Render.hh:30-31) */
+typedef struct trc_GridDensityInfo {
+    float    sigma_a, sigma_s;
+    float    sigma_t, g;
+    float    invMaxDensity;
+    uint32_t nx, ny, nz;
+} trc_GridDensityInfo;
+
 #define TRC_PHOTON_HASHN 512      /* PHOTON_HASHN, RT_Metal/Metal/Common.hh:4: 512x512 photons and hash cells */
 
 /* Primitive argument table of the kernel (Render.hh:122-130) + materials of
@@ -229,7 +238,9 @@ typedef int32_t trc_status;
 /* ------------------------------------------------------------------ */
 enum trc_integrator {
     TRC_INTEGRATOR_PATH = 0,     /* tracePath, Render.metal:411-492 (the active one, :532) */
-    TRC_INTEGRATOR_MIS  = 1      /* traceMIS,  Render.metal:277-409 */
+    TRC_INTEGRATOR_MIS  = 1,     /* traceMIS,  Render.metal:277-409 */
+    TRC_INTEGRATOR_VOLUME = 2    /* traceVolume, Render.metal:78-275: traceMIS + participating media
+                                    (Medium.hh:25-199, HitRecord.hh:37-79); SURVEY 8f-3 */
 };
 
 /* flags */
@@ -422,7 +433,10 @@ typedef struct trc_host_scene trc_host_scene;
 enum trc_host_scene_kind {
     TRC_SCENE_CORNELL          = 0,  /* as shipped: 2 cubes + 7 squares (spheres not in the BVH) */
     TRC_SCENE_CORNELL_SPHERES  = 1,  /* BASELINE config 2: + the 12 spheres, materials remapped */
-    TRC_SCENE_CORNELL_MESH     = 2   /* + a triangle mesh placed by the reference transform */
+    TRC_SCENE_CORNELL_MESH     = 2,  /* + a triangle mesh placed by the reference transform */
+    TRC_SCENE_CORNELL_VOLUME   = 3   /* kind 0 + the third cube of prepareCubeList (Tracer.mm:221-243: material _NIL_,
+                                        medium GridDensity -- the cloud container the reference keeps out of
+                                        its BVH, AAPLRenderer.mm:459) as a leaf; optional mesh as in kind 2 */
 };
 
 /* mesh: optional (NULL for kinds 0/1); positions/normals/uvs as
@@ -435,6 +449,17 @@ trc_status trc_host_scene_create(int32_t kind,
 void       trc_host_scene_destroy(trc_host_scene* s);
 /* view of the assembled arrays (valid until destroy) */
 void       trc_host_scene_view(const trc_host_scene* s, trc_scene* out);
+
+/* GridDensityInfo::GridDensityInfo (Medium.hh:92-105): sigma_t = sigma_a + sigma_s, invMaxDensity = 1 / max */
+void trc_host_make_density_info(float sigma_a, float sigma_s, float g, uint32_t nx, uint32_t ny, uint32_t nz,
+                                const float* density, trc_GridDensityInfo* out);
+/* procedural stand-in for cloud/geometry/density_render.70.pbrt (100x100x40, does not travel to the GPU box):
+ * a few smooth blobs, values in [0, ~2], deterministic in `seed` */
+void trc_host_make_cloud(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t seed, float* out /* nx*ny*nz */);
+/* reads the `MakeNamedMedium ... "integer nx" .. "float density" [ ... ]` block of a pbrt-v3 file (the subset
+ * of minipbrt the reference uses, AAPLRenderer.mm:629-636); *out is malloc'ed, free with trc_host_free */
+trc_status trc_host_load_density_pbrt(const char* path, uint32_t* nx, uint32_t* ny, uint32_t* nz, float** out);
+void trc_host_free(void* p);
 
 /* minimal Wavefront OBJ reader (v / vn / vt / f; polygons fan-triangulated;
  * smooth normals generated when the file has none), standing in for ModelIO
@@ -487,6 +512,7 @@ TRC_SA(sizeof(trc_Complex) == 96 && offsetof(trc_Complex, frame_count) == 20 && 
        offsetof(trc_Complex, photonBoxSize) == 64 && offsetof(trc_Complex, photonInitialRadius) == 80 &&
        offsetof(trc_Complex, framePhotonSum) == 92, "Complex");
 TRC_SA(sizeof(trc_ray) == 32, "trc_ray");
+TRC_SA(sizeof(trc_GridDensityInfo) == 32 && offsetof(trc_GridDensityInfo, invMaxDensity) == 16 && offsetof(trc_GridDensityInfo, nx) == 20, "GridDensityInfo");
 TRC_SA(sizeof(trc_PhotonRecord) == 80 && offsetof(trc_PhotonRecord, normal) == 16 && offsetof(trc_PhotonRecord, position) == 32 &&
        offsetof(trc_PhotonRecord, direction) == 48 && offsetof(trc_PhotonRecord, step) == 64 &&
        offsetof(trc_PhotonRecord, active) == 65, "PhotonRecord");

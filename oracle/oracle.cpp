@@ -195,6 +195,8 @@ inline float Erf(float x) {
 // Ray.hh:10-33
 struct Ray {
     V3 origin, direction;
+    float eta = 1.0f;                       // Ray.hh:16
+    int medium = TRC_MEDIUM_NIL;            // Ray.hh:18 (traceVolume only)
     Ray() : origin(v3(0)), direction(v3(0)) {}
     Ray(V3 o, V3 d) : origin(o) { direction = normalize(d); }
     void update(V3 o, V3 d) { origin = o; direction = normalize(d); }
@@ -212,6 +214,9 @@ struct HitRecord {
     float PDF = 0;
     int32_t pType = -1;
     uint32_t pIndex = 0;
+    // HitRecord.hh:22-23, written by Cube::hit_test only (Cube.hh:30-31,39) and consumed by GridDensityMedium::Sample;
+    // uninitialised in the reference, zero / null here
+    Ray _r; float _t = 0; const trc_float4x4* modelMatrix = nullptr;
     void checkFace(const Ray& ray) { f = dot(ray.direction, gn) <= 0; sn = f ? gn : -gn; }
 };
 
@@ -402,10 +407,13 @@ inline bool cube_hit_test(const trc_Cube& cube, const Ray& ray, V2& range_t, Hit
     if (!aabb_hit_record(cube.box, _ray, range_t, _record)) return false;
     if (cnt) cnt->n_hit_cube++;
     _record.p = mul_point(cube.model_matrix, _record.p);
+    _record._r = _ray;                               // Cube.hh:30-31
+    _record._t = _record.t;
     _record.t = length(ray.origin - _record.p);     // distance(ray.origin, p)
     if (_record.t >= range_t.y) return false;
     range_t.y = _record.t;
     _record.material = cube.material;
+    _record.modelMatrix = &cube.model_matrix;        // Cube.hh:39
     _record.gn = normalize(mul_dir(cube.normal_matrix, _record.gn));
     _record.checkFace(ray);
     rec = _record;
@@ -1003,7 +1011,7 @@ inline Ray castRay(const trc_Camera* camera, float s, float t, RandomSampler* xs
 }
 
 // ---------------------------------------------------------------- integrators
-struct Env { const trc_Material* materials; V3 ambient; };
+struct Env { const trc_Material* materials; V3 ambient; const trc_GridDensityInfo* densityInfo = nullptr; const float* densityArray = nullptr; };
 
 // Render.metal:411-492
 V3 tracePath(int depth, Ray& ray, RandomSampler& xsampler, const Env& env, Scene& scene, Counters* cnt) {
@@ -1133,6 +1141,221 @@ V3 traceMIS(int depth, Ray& ray, RandomSampler& xsampler, const Env& env, Scene&
     return color;
 }
 
+// ---------------------------------------------------------------- participating media (traceVolume only)
+// HitRecord.hh:45-79
+inline float PhaseHG(float cosTheta, float g) {
+    float gg = g * g;
+    float denom = 1 + gg + 2 * g * cosTheta;
+    return (0.25f / PI_F) * (1 - gg) / (denom * sqrtf(denom));
+}
+// Sampling.hh:40-43
+inline V3 SphericalDirection(float sinTheta, float cosTheta, float phi, const V3& x, const V3& y, const V3& z) {
+    return (sinTheta * m_cos(phi) * x + sinTheta * m_sin(phi) * y) + cosTheta * z;
+}
+inline float HG_Sample_p(float g, const V3& wo, V3& wi, const V2& uu) {     // HitRecord.hh:58-77
+    float cosTheta;
+    if (fabsf(g) < 1e-3f) cosTheta = 1 - 2 * uu[0];
+    else {
+        float gg = g * g;
+        float sqrTerm = (1 - gg) / (1 + g - 2 * g * uu[0]);
+        cosTheta = -(1 + gg - sqrTerm * sqrTerm) / (2 * g);
+    }
+    float sinTheta = sqrtf(fmaxf(0.0f, 1 - cosTheta * cosTheta));
+    float phi = 2 * PI_F * uu[1];
+    V3 v1, v2;
+    CoordinateSystem(wo, v1, v2);
+    wi = SphericalDirection(sinTheta, cosTheta, phi, v1, v2, wo);
+    return PhaseHG(cosTheta, g);
+}
+struct MediumInteraction { V3 p = v3(0); float phaseG = 0; bool sampled = false; };   // Medium.hh:14-22
+// HomogeneousMedium::Sample, Medium.hh:38-74, as constructed at Render.metal:118: (0.02, 0.08, 0.5)
+inline V3 homogeneous_sample(const Ray& ray, const HitRecord& hitRecord, MediumInteraction& mi, RandomSampler& xsampler) {
+    const V3 sigma_a = v3(0.02f), sigma_s = v3(0.08f), sigma_t = sigma_s + sigma_a;
+    const float g = 0.5f;
+    const int nSamples = 3;
+    int channel = (int)(xsampler.sample1D() * nSamples);
+    if (channel > nSamples - 1) channel = nSamples - 1;
+    float dist = -m_log(1 - xsampler.sample1D()) / sigma_t[channel];
+    float t = fminf(dist, hitRecord.t);
+    bool sampledMedium = t < hitRecord.t;
+    const float tt = fminf(t, FLT_MAX);
+    V3 Tr = v3(m_exp(-sigma_t.x * tt), m_exp(-sigma_t.y * tt), m_exp(-sigma_t.z * tt));
+    V3 density = Tr, result = Tr;
+    if (sampledMedium) {
+        mi.p = ray.pointAt(t);
+        mi.phaseG = g;
+        mi.sampled = true;
+        density = density * sigma_t;
+        result = result * sigma_s;
+    }
+    float pdf = dot(v3(1.0f), density);
+    if (0.0f >= pdf) pdf = 1.0f; else pdf = pdf / nSamples;
+    return result / pdf;
+}
+// GridDensityMedium, Medium.hh:111-199
+inline float grid_D(const trc_GridDensityInfo& info, const float* density, int x, int y, int z) {
+    const int nx = (int)info.nx, ny = (int)info.ny, nz = (int)info.nz;
+    if (x < 0 || y < 0 || z < 0 || x >= nx || y >= ny || z >= nz) return 0;
+    return density[((size_t)z * ny + y) * nx + x];
+}
+inline float Lerp(float t, float s1, float s2) { return (1 - t) * s1 + t * s2; }       // Sampling.hh:13-16
+inline float grid_Density(const trc_GridDensityInfo& info, const float* density, const V3& p) {
+    const float nx = (float)info.nx, ny = (float)info.ny, nz = (float)info.nz;
+    V3 pSamples = v3(p.x * nx - 0.5f, p.y * ny - 0.5f, p.z * nz - 0.5f);
+    const float fx = floorf(pSamples.x), fy = floorf(pSamples.y), fz = floorf(pSamples.z);
+    // (int3) floor(...): out-of-int-range / NaN coordinates are clamped far outside the grid (Metal's conversion
+    // saturates; a plain C cast would be undefined)
+    auto to_int = [](float f) { return !(f > -2.0e9f) ? (int)-2000000000 : (f > 2.0e9f ? (int)2000000000 : (int)f); };
+    const int ix = to_int(fx), iy = to_int(fy), iz = to_int(fz);
+    V3 d = v3(pSamples.x - (float)ix, pSamples.y - (float)iy, pSamples.z - (float)iz);
+    float d00 = Lerp(d.x, grid_D(info, density, ix, iy, iz), grid_D(info, density, ix + 1, iy, iz));
+    float d10 = Lerp(d.x, grid_D(info, density, ix, iy + 1, iz), grid_D(info, density, ix + 1, iy + 1, iz));
+    float d01 = Lerp(d.x, grid_D(info, density, ix, iy, iz + 1), grid_D(info, density, ix + 1, iy, iz + 1));
+    float d11 = Lerp(d.x, grid_D(info, density, ix, iy + 1, iz + 1), grid_D(info, density, ix + 1, iy + 1, iz + 1));
+    float d0 = Lerp(d.y, d00, d10);
+    float d1 = Lerp(d.y, d01, d11);
+    return Lerp(d.z, d0, d1);
+}
+constexpr int kGridSampleMaxSteps = 1 << 16;   // the reference's `while (true)` (Medium.hh:179) is unbounded; a stale
+                                               // hitRecord._t or a zero majorant would spin forever on a GPU
+inline float grid_sample(const Env& env, const HitRecord& hitRecord, MediumInteraction& mi, RandomSampler& sampler) {
+    if (!env.densityInfo || !env.densityArray) return 1.0f;
+    const trc_GridDensityInfo& info = *env.densityInfo;
+    const Ray& ray = hitRecord._r;
+    float tMax = hitRecord._t;
+    float t = 0;
+    for (int step = 0; step < kGridSampleMaxSteps; ++step) {
+        t -= m_log(1 - sampler.sample1D()) * info.invMaxDensity / info.sigma_t;
+        if (t >= tMax) break;
+        V3 p = ray.pointAt(t);
+        if (grid_Density(info, env.densityArray, p) * info.invMaxDensity > sampler.sample1D()) {
+            mi.p = hitRecord.modelMatrix ? mul_point(*hitRecord.modelMatrix, p) : p;
+            mi.phaseG = info.g;
+            mi.sampled = true;
+            return info.sigma_s / info.sigma_t;
+        }
+    }
+    return 1.0f;
+}
+
+// Render.metal:78-275
+V3 traceVolume(int depth, Ray& ray, RandomSampler& xsampler, const Env& env, Scene& scene, Counters* cnt) {
+    HitRecord hitRecord;
+    V3 scat_attenuation = v3(0); float scat_bxPDF = 1.0f;
+    V3 ratio = v3(1.0f);
+    V3 color = v3(0.0f);
+    const trc_scene& prims = scene.prims;
+    bool hitted = scene.hit(ray, hitRecord, FLT_MAX);
+    do {
+        if (!hitted) { color = color + ratio * env.ambient; break; }          // texHDR lookup -> constant (HDR missing)
+        if (env.materials[hitRecord.material].type == TRC_MAT_DIFFUSE) {
+            V3 le = v3(env.materials[hitRecord.material].textureInfo.albedo);
+            float w = dot(-ray.direction, -hitRecord.gn);
+            return ratio * le * fabsf(w);
+        }
+        MediumInteraction mi;
+        if (ray.medium == TRC_MEDIUM_HOMOGENEOUS) ratio = ratio * homogeneous_sample(ray, hitRecord, mi, xsampler);
+        else if (ray.medium == TRC_MEDIUM_GRIDDENSITY) ratio = ratio * v3(grid_sample(env, hitRecord, mi, xsampler));
+        bool need_test = false, need_bsdf = false;
+        if (mi.sampled) {
+            V3 wi, wo = -ray.direction;
+            HG_Sample_p(mi.phaseG, wo, wi, xsampler.sample2D());
+            ray.update(mi.p, wi);
+            ray.medium = env.materials[hitRecord.material].medium;
+            need_test = true;
+        } else {
+            if (env.materials[hitRecord.material].type == TRC_MAT_NIL) {
+                if (dot(ray.direction, hitRecord.gn) < 0) {                     // enter
+                    ray = Ray(offset_ray(hitRecord.p, -hitRecord.gn), ray.direction);
+                    ray.medium = env.materials[hitRecord.material].medium;
+                } else {                                                        // depart
+                    ray = Ray(offset_ray(hitRecord.p, hitRecord.gn), ray.direction);
+                    ray.medium = TRC_MEDIUM_NIL;
+                }
+                need_test = true;
+            } else {
+                need_test = false;
+                need_bsdf = true;
+            }
+        }
+        if (need_test) hitted = scene.hit(ray, hitRecord, FLT_MAX);
+        if (!need_bsdf) continue;
+
+        const trc_Material& mat = env.materials[hitRecord.material];
+        LightSampleRecord lsr;
+        V2 uu = xsampler.sample2D();
+        const V3 hit_origin = hitRecord.p;
+        V3 _origin = offset_ray(hitRecord.p, hitRecord.sn);
+        if (xsampler.random() < 0.5f) square_sample(prims.squareList[5], uu, _origin, lsr);
+        else square_sample(prims.squareList[6], uu, _origin, lsr);
+        V3 _dir = lsr.p - _origin;
+        V3 _nor = normalize(_dir);
+        V3 nx, ny;
+        CoordinateSystem(hitRecord.sn, nx, ny);
+        const float _tr = 1.0f;
+        const float _dis = length(_dir);
+        const Ray _ray(_origin, _nor);
+        HitRecord shr;
+        const bool blocked = scene.hit(_ray, shr, _dis, true);
+        V3 minus_d = -ray.direction;
+        if (!blocked) {   // light sampling
+            V3 wo = v3(dot(nx, minus_d), dot(ny, minus_d), dot(hitRecord.sn, minus_d));
+            V3 wi = v3(dot(nx, _ray.direction), dot(ny, _ray.direction), dot(hitRecord.sn, _ray.direction));
+            float bxPDF = 0;
+            if (cnt) cnt->shaded++;
+            V3 weight = Material_F(mat, wo, wi, hitRecord.uv, bxPDF, uu);
+            float cosOnLight = fabsf(dot(lsr.n, -_nor));
+            V3 Li = v3(env.materials[lsr.material].textureInfo.albedo);
+            weight = weight * (Li * cosOnLight);
+            float dist2 = _dis * _dis;
+            float liPDF = dist2 * lsr.areaPDF / cosOnLight;
+            weight = weight * PowerHeuristic(1, liPDF, 1, bxPDF);
+            color = color + _tr * ratio * weight / liPDF;
+        }
+        // BXDF sampling
+        V3 wi = v3(0);
+        float bxPDF = 0;
+        V3 wo = v3(dot(nx, minus_d), dot(ny, minus_d), dot(hitRecord.sn, minus_d));
+        if (cnt) cnt->shaded++;
+        scat_attenuation = Material_S_F(mat, wo, wi, hitRecord.uv, uu, bxPDF);
+        scat_bxPDF = bxPDF;
+        if (bxPDF <= 0) break;
+        if (wi.z < 0) {   // transmission
+            V3 wiw = (nx * wi.x + ny * wi.y) + hitRecord.sn * wi.z;
+            ray.update(offset_ray(hit_origin, -hitRecord.sn), wiw);
+            if (dot(wiw, hitRecord.gn) < 0) ray.medium = mat.medium;            // enter
+            else ray.medium = TRC_MEDIUM_NIL;                                   // depart
+        } else {
+            V3 wiw = (nx * wi.x + ny * wi.y) + hitRecord.sn * wi.z;
+            ray.update(_origin, wiw);
+        }
+        ratio = ratio * (scat_attenuation / scat_bxPDF);
+        {
+            float p = RGBToY(ratio);
+            if (xsampler.random() > p) break;
+            ratio = ratio * (1.0f / p);
+        }
+        hitted = scene.hit(ray, hitRecord, FLT_MAX);
+        if (hitted && env.materials[hitRecord.material].type == TRC_MAT_DIFFUSE) {
+            V3 Li = v3(env.materials[hitRecord.material].textureInfo.albedo);
+            float cosOnLight = dot(-ray.direction, hitRecord.sn);
+            V3 weight = scat_attenuation * Li * cosOnLight;
+            V3 d = hitRecord.p - ray.origin;
+            float dist2 = dot(d, d);
+            float lightPDF = hitRecord.PDF * dist2 / cosOnLight;
+            weight = weight * PowerHeuristic(1, scat_bxPDF, 1, lightPDF);
+            color = color + ratio * weight / scat_bxPDF;
+            break;
+        }
+    } while ((--depth) > 0);
+    return color;
+}
+
+// density grid of the GridDensity medium for orc_render (the oracle keeps one, like PackageEnv ids 3/4)
+static const trc_GridDensityInfo* g_density_info = nullptr;
+static const float* g_density_array = nullptr;
+static trc_GridDensityInfo g_density_info_copy;
+
 // one pixel of kernelPathTracing, Render.metal:495-558, for `spp` successive frames
 void render_pixel(const trc_scene& prims, const trc_Camera* camera, const Env& env, uint32_t W, uint32_t H,
                   uint32_t x, uint32_t y, uint32_t* rng_rgba, float* accum_rgba, const trc_params& prm, Counters* cnt) {
@@ -1150,9 +1373,9 @@ void render_pixel(const trc_scene& prims, const trc_Camera* camera, const Env& e
         float v = (float)y / (float)H;
         RandomSampler rs{&rng};
         Ray ray = castRay(camera, u, v, &rs);
-        V3 color = (prm.integrator == TRC_INTEGRATOR_MIS)
-                       ? traceMIS((int)prm.max_depth, ray, rs, env, scene, cnt)
-                       : tracePath((int)prm.max_depth, ray, rs, env, scene, cnt);
+        V3 color = (prm.integrator == TRC_INTEGRATOR_VOLUME) ? traceVolume((int)prm.max_depth, ray, rs, env, scene, cnt)
+                   : (prm.integrator == TRC_INTEGRATOR_MIS)  ? traceMIS((int)prm.max_depth, ray, rs, env, scene, cnt)
+                                                             : tracePath((int)prm.max_depth, ray, rs, env, scene, cnt);
         bool bad = std::isinf(color.x) || std::isnan(color.x) || std::isinf(color.y) || std::isnan(color.y) ||
                    std::isinf(color.z) || std::isnan(color.z);
         if (bad) color = v3(0);
@@ -1532,9 +1755,15 @@ void orc_trace_rays_brute(const trc_scene* scene, const trc_ray* rays, size_t n,
     }
 }
 
+void orc_set_density(const trc_GridDensityInfo* info, const float* density) {
+    if (info && density) { g_density_info_copy = *info; g_density_info = &g_density_info_copy; g_density_array = density; }
+    else { g_density_info = nullptr; g_density_array = nullptr; }
+}
+
 void orc_render(const trc_scene* scene, const trc_Camera* camera, const float env_rgb[3], uint32_t W, uint32_t H,
                 uint32_t* rng_rgba, float* accum_rgba, const trc_params* params, trc_stats* stats, int n_threads) {
     Env env{scene->materials, v3(env_rgb[0], env_rgb[1], env_rgb[2])};
+    env.densityInfo = g_density_info; env.densityArray = g_density_array;
     const uint32_t nranks = params->tile_nranks ? params->tile_nranks : 1;
     unsigned T = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
     T = std::min<unsigned>(T, H ? H : 1);

@@ -45,6 +45,10 @@ void orc_render(const trc_scene* scene, const trc_Camera* camera, const float en
                 uint32_t width, uint32_t height, uint32_t* rng_rgba, float* accum_rgba,
                 const trc_params* params, trc_stats* stats, int n_threads);
 
+/* density grid consulted by TRC_INTEGRATOR_VOLUME (traceVolume, Render.metal:78-275; GridDensityMedium, Medium.hh:111-199);
+ * `density` is borrowed and must outlive the renders; NULL clears it */
+void orc_set_density(const trc_GridDensityInfo* info, const float* density);
+
 /* material entry points (Material.hh:77-146) in the local shading frame */
 void  orc_material_S_F(const trc_Material* m, const float wo[3], const float uv[2], const float uu[2],
                        float wi_out[3], float f_out[3], float* pdf_out);

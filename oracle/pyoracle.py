@@ -75,6 +75,8 @@ def lib(libm=False):
         L.orc_sppm_download.restype = None
         L.orc_photon_hash.argtypes = [f3, C.c_float]
         L.orc_photon_hash.restype = C.c_float
+        L.orc_set_density.argtypes = [C.POINTER(abi.GridDensityInfo), C.c_void_p]
+        L.orc_set_density.restype = None
         L.orc_lbvh_build.argtypes = [C.POINTER(abi.BVH), C.c_uint32, C.POINTER(abi.BVH), C.POINTER(C.c_uint32)]
         L.orc_lbvh_build.restype = None
         L.orc_math.argtypes = [C.c_int, C.c_float, C.c_float]
@@ -125,6 +127,22 @@ def render(scene_view, camera, width, height, rng, accum=None, spp=1, max_depth=
     lib(libm).orc_render(C.byref(scene_view), C.byref(camera), env_c, width, height, rng.ctypes.data,
                          accum.ctypes.data, C.byref(prm), C.byref(stats), n_threads)
     return accum, stats
+
+
+_DENSITY_KEEPALIVE = []
+
+
+def set_density(info, density):
+    """Density grid for integrator 2 (traceVolume); `density`: float32 array (nz, ny, nx) or None to clear."""
+    _DENSITY_KEEPALIVE.clear()
+    for libm in (False, True):
+        if density is None:
+            lib(libm).orc_set_density(None, None)
+        else:
+            assert density.dtype == np.float32 and density.flags.c_contiguous
+            lib(libm).orc_set_density(C.byref(info), density.ctypes.data)
+    if density is not None:
+        _DENSITY_KEEPALIVE.append(density)
 
 
 def lbvh_build(leaves, n):

@@ -1,0 +1,82 @@
+"""traceVolume (Render.metal:78-275) + Medium.hh in the oracle, and the host pieces around it."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from tracer_amd import abi, host
+
+W, H = 48, 36
+REF_CLOUD = "/root/reference/RT_Metal/cloud/geometry/density_render.70.pbrt"
+
+
+def render(view, integ, spp=4, seed=5, frame0=0, rng=None, accum=None):
+    cam = host.prepare_camera(W, H)
+    rng = host.fill_rng(seed, W, H) if rng is None else rng
+    acc, st = pyoracle.render(view, cam, W, H, rng, accum=accum, spp=spp, integrator=integ, frame0=frame0)
+    return acc, rng, st
+
+
+def test_density_pbrt_reader(tmp_path):
+    grid = (np.arange(2 * 3 * 4, dtype=np.float32) * 0.25).reshape(4, 3, 2)
+    text = ('MakeNamedMedium "smoke" "string type" "heterogeneous" "integer nx" 2 "integer ny" [3] "integer nz" 4\n'
+            '\t"point p0" [ 0 0 0 ] "point p1" [ 1 1 1 ]\n\t"float density" [\n' +
+            " ".join(repr(float(v)) for v in grid.ravel()) + "\n]\n")
+    f = tmp_path / "m.pbrt"
+    f.write_text(text)
+    got = host.load_density_pbrt(str(f))
+    assert got.shape == (4, 3, 2) and (got == grid).all()
+    info = host.density_info(got)
+    assert info.sigma_t == 100.0 and info.nx == 2 and info.ny == 3 and info.nz == 4
+    assert info.invMaxDensity == np.float32(1) / grid.max()
+    (tmp_path / "bad.pbrt").write_text('MakeNamedMedium "x" "integer nx" 2 "float density" [ 1 2 ]')
+    with pytest.raises(RuntimeError):
+        host.load_density_pbrt(str(tmp_path / "bad.pbrt"))
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CLOUD), reason="reference cloud grid not present (GPU box)")
+def test_reference_cloud_grid_loads():
+    g = host.load_density_pbrt(REF_CLOUD)          # AAPLRenderer.mm:629-636 reads the same block through minipbrt
+    assert g.shape == (40, 100, 100) and g.max() == 1.0 and g.min() == 0.0 and 0.2 < (g > 0).mean() < 0.4
+
+
+def test_volume_equals_mis_without_media():
+    """With every Material::medium = _NIL_ and no _NIL_-typed surface traceVolume executes exactly traceMIS."""
+    sc = host.HostScene(abi.SCENE_CORNELL_SPHERES)
+    mats = (abi.Material * sc.view.n_material)()
+    C.memmove(mats, sc.view.materials, C.sizeof(mats))
+    for m in mats:
+        m.medium = abi.MEDIUM_NIL
+    v = abi.Scene.from_buffer_copy(sc.view)
+    v.materials = C.cast(mats, C.POINTER(abi.Material))
+    a, ra, sa = render(v, abi.INTEGRATOR_MIS)
+    b, rb, sb = render(v, abi.INTEGRATOR_VOLUME)
+    assert (a.view(np.uint32) == b.view(np.uint32)).all() and (ra == rb).all() and sa.rays == sb.rays
+    # the shipped materials differ: the small cube is glass filled with the homogeneous medium (material 19)
+    c, _, _ = render(sc.view, abi.INTEGRATOR_VOLUME)
+    assert not (a.view(np.uint32) == c.view(np.uint32)).all()
+
+
+def test_grid_density_volume_scene():
+    sc = host.HostScene(abi.SCENE_CORNELL_VOLUME)
+    assert sc.n_leaves == 10 and sc.view.n_cube == 3
+    cloud = host.make_cloud()
+    assert cloud.shape == (40, 100, 100) and (cloud == host.make_cloud()).all() and (cloud == 0).mean() > 0.3
+    info = host.density_info(cloud)
+    pyoracle.set_density(info, cloud)
+    try:
+        a, ra, sa = render(sc.view, abi.INTEGRATOR_VOLUME, spp=8)
+        assert np.isfinite(a).all() and (a[..., :3] >= 0).all() and (a[..., 3] == 1).all()
+        # fused samples == one sample per call
+        b = np.zeros_like(a); rb = host.fill_rng(5, W, H)
+        for s in range(8):
+            render(sc.view, abi.INTEGRATOR_VOLUME, spp=1, frame0=s, rng=rb, accum=b)
+        assert (a.view(np.uint32) == b.view(np.uint32)).all() and (ra == rb).all()
+        # the cloud matters: without the grid the container is empty space
+        pyoracle.set_density(None, None)
+        c, _, _ = render(sc.view, abi.INTEGRATOR_VOLUME, spp=8)
+        assert not (a.view(np.uint32) == c.view(np.uint32)).all()
+    finally:
+        pyoracle.set_density(None, None)

@@ -20,9 +20,10 @@ PRIM_SPHERE, PRIM_SQUARE, PRIM_CUBE, PRIM_TRIANGLE, PRIM_BVH, PRIM_UNKNOW = rang
 # enum trc_TextureType (Texture.hh:6)
 TEX_CONSTANT, TEX_CHECKER, TEX_NOISE, TEX_IMAGE = range(4)
 # enum trc_integrator
-INTEGRATOR_PATH, INTEGRATOR_MIS = 0, 1
+INTEGRATOR_PATH, INTEGRATOR_MIS, INTEGRATOR_VOLUME = 0, 1, 2
+MEDIUM_NIL, MEDIUM_HOMOGENEOUS, MEDIUM_GRIDDENSITY = 0, 1, 2
 # enum trc_host_scene_kind
-SCENE_CORNELL, SCENE_CORNELL_SPHERES, SCENE_CORNELL_MESH = 0, 1, 2
+SCENE_CORNELL, SCENE_CORNELL_SPHERES, SCENE_CORNELL_MESH, SCENE_CORNELL_VOLUME = 0, 1, 2, 3
 FLAG_COLLECT_STATS = 1
 
 # status codes
@@ -128,6 +129,11 @@ class Scene(C.Structure):
                 ("materials", C.POINTER(Material)), ("n_material", C.c_uint32)]
 
 
+class GridDensityInfo(C.Structure):
+    _fields_ = [("sigma_a", C.c_float), ("sigma_s", C.c_float), ("sigma_t", C.c_float), ("g", C.c_float),
+                ("invMaxDensity", C.c_float), ("nx", C.c_uint32), ("ny", C.c_uint32), ("nz", C.c_uint32)]
+
+
 class Params(C.Structure):
     _fields_ = [("spp", C.c_uint32), ("max_depth", C.c_uint32), ("integrator", C.c_uint32),
                 ("frame0", C.c_uint32), ("tile_rank", C.c_uint32), ("tile_nranks", C.c_uint32),
@@ -166,7 +172,7 @@ for _t, _n in _EXPECTED_SIZES.items():
 # every symbol include/tracer_abi.h declares, by library (checked by tests/test_abi_symbols.py)
 DEVICE_SYMBOLS = [
     "trc_abi_version", "trc_status_string", "trc_last_error", "trc_create", "trc_destroy",
-    "trc_upload_scene", "trc_upload_scene_lbvh", "trc_download_bvh", "trc_lbvh_info", "trc_set_camera", "trc_set_environment", "trc_resize", "trc_seed",
+    "trc_upload_scene", "trc_upload_density", "trc_upload_scene_lbvh", "trc_download_bvh", "trc_lbvh_info", "trc_set_camera", "trc_set_environment", "trc_resize", "trc_seed",
     "trc_upload_rng", "trc_download_rng", "trc_upload_accum", "trc_download_accum", "trc_clear_accum",
     "trc_render", "trc_synchronize", "trc_trace_rays", "trc_get_stats", "trc_reset_stats", "trc_debug_profile",
     "trc_sppm_init", "trc_sppm_frames", "trc_sppm_download",
@@ -176,5 +182,6 @@ HOST_SYMBOLS = [
     "trc_host_build_node", "trc_host_build_tree", "trc_host_tree_depth", "trc_host_make_camera",
     "trc_host_prepare_camera", "trc_host_fill_rng", "trc_host_scene_create", "trc_host_scene_destroy",
     "trc_host_scene_view", "trc_host_mesh_load_obj", "trc_host_mesh_make_ball", "trc_host_mesh_replicate",
-    "trc_host_mesh_view", "trc_host_mesh_destroy",
+    "trc_host_mesh_view", "trc_host_mesh_destroy", "trc_host_make_density_info", "trc_host_make_cloud",
+    "trc_host_load_density_pbrt", "trc_host_free",
 ]

@@ -503,7 +503,7 @@ typedef MicroRefl<TrowbridgeReitzD<Alpha_01_02>, FrCond> MetalLobe;       // alp
 // Plastic specular: Beckmann (0.01, 0.1), R = 1; Glass: Beckmann (0.01, 0.01), reflection R = kr = 0.98
 
 // material types (Material.hh:18-20) and texture types (Texture.hh:6) by ordinal
-constexpr int kMatDiffuse = 0, kMatLambert = 1, kMatPlastic = 3, kMatMetal = 4, kMatGlass = 5;
+constexpr int kMatDiffuse = 0, kMatLambert = 1, kMatPlastic = 3, kMatMetal = 4, kMatGlass = 5, kMatNil = 10;
 constexpr int kTexConstant = 0, kTexChecker = 1;
 
 TRC_DEV F3 texture_value(int tex_type, F3 albedo, F2 uv) {           // Texture.hh:17-43

@@ -27,6 +27,7 @@ struct Shade {            // what the integrators need from the material table
 TRC_DEV int mat_type(const Shade& sh, uint32_t m) { return (int)sh.mats[m * kMaterialDwords]; }
 TRC_DEV int mat_tex(const Shade& sh, uint32_t m) { return (int)sh.mats[m * kMaterialDwords + 1]; }
 TRC_DEV bool mat_specular(const Shade& sh, uint32_t m) { return sh.mats[m * kMaterialDwords + 5] != 0u; }
+TRC_DEV int mat_medium(const Shade& sh, uint32_t m) { return (int)sh.mats[m * kMaterialDwords + 6]; }
 TRC_DEV F3 mat_albedo(const Shade& sh, uint32_t m) {
     const uint32_t* p = sh.mats + m * kMaterialDwords;
     return f3(__uint_as_float(p[2]), __uint_as_float(p[3]), __uint_as_float(p[4]));
@@ -69,6 +70,9 @@ struct PathCtx {
     uint32_t* stack;
     uint32_t* lvstack;
     uint32_t max_depth;
+    // traceVolume: density grid of the GridDensity medium (PackageEnv ids 3/4, Render.hh:30-31); null when absent
+    const float* density;
+    trc_GridDensityInfo dinfo;
 };
 
 // ---------------------------------------------------------------- path state machine
@@ -86,6 +90,8 @@ struct PathState {
     float scat_bxPDF;
     int depth_left;          // bounce rays the do-while may still trace (Render.metal:406,489)
     bool primary;            // the ray in flight is the camera ray
+    int medium;              // traceVolume: Ray::medium (Ray.hh:18) of the ray in flight
+    bool from_bsdf;          // traceVolume: the ray in flight left the BSDF-sampling branch (Render.metal:255-271 applies)
 };
 
 TRC_DEV void path_begin(PathState& ps, const Ray& camera_ray, uint32_t max_depth) {
@@ -97,6 +103,8 @@ TRC_DEV void path_begin(PathState& ps, const Ray& camera_ray, uint32_t max_depth
     ps.scat_bxPDF = 1.0f;
     ps.depth_left = (int)max_depth;
     ps.primary = true;
+    ps.medium = TRC_MEDIUM_NIL;
+    ps.from_bsdf = false;
 }
 
 // What happens between two Scene::hit calls of tracePath (Render.metal:432-489).  Returns true when the
@@ -141,14 +149,109 @@ TRC_DEV bool path_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, 
     return false;
 }
 
-// Same for traceMIS (Render.metal:298-406).  Lights are literally squareList[5] and [6] (:320-324, B-12).
+// ---------------------------------------------------------------- participating media (traceVolume)
+TRC_DEV float phase_hg(float cosTheta, float g) {                    // HitRecord.hh:45-49
+    float gg = g * g;
+    float denom = 1 + gg + 2 * g * cosTheta;
+    return (0.25f / kPi) * (1 - gg) / (denom * sqrtf(denom));
+}
+TRC_DEV void hg_sample_p(float g, F3 wo, F3& wi, F2 uu) {            // HitRecord.hh:58-77 (the returned pdf is unused)
+    float cosTheta;
+    if (fabsf(g) < 1e-3f) cosTheta = 1 - 2 * uu.x;
+    else {
+        float gg = g * g;
+        float sqrTerm = (1 - gg) / (1 + g - 2 * g * uu.x);
+        cosTheta = -(1 + gg - sqrTerm * sqrTerm) / (2 * g);
+    }
+    float sinTheta = sqrtf(fmaxf(0.0f, 1 - cosTheta * cosTheta));
+    float phi = 2 * kPi * uu.y;
+    F3 v1, v2;
+    coordinate_system(wo, v1, v2);
+    float sp, cp;
+    dm_sincosf(phi, &sp, &cp);
+    wi = (sinTheta * cp * v1 + sinTheta * sp * v2) + cosTheta * wo;  // SphericalDirection, Sampling.hh:40-43
+}
+struct MediumHit { F3 p; float phaseG; bool sampled; };
+// HomogeneousMedium(0.02, 0.08, 0.5).Sample, Medium.hh:38-74 / Render.metal:118-119
+TRC_DEV F3 homogeneous_sample(const Ray& ray, const HitRec& rec, MediumHit& mi, Pcg& rng) {
+    const F3 sigma_a = f3(0.02f), sigma_s = f3(0.08f), sigma_t = sigma_s + sigma_a;
+    const int nSamples = 3;
+    int channel = (int)(pcg_float(rng) * nSamples);
+    if (channel > nSamples - 1) channel = nSamples - 1;
+    float dist = -dm_logf(1 - pcg_float(rng)) / comp(sigma_t, (uint32_t)channel);
+    float t = fminf(dist, rec.t);
+    const bool sampledMedium = t < rec.t;
+    const float tt = fminf(t, FLT_MAX);
+    F3 Tr = f3(dm_expf(-sigma_t.x * tt), dm_expf(-sigma_t.y * tt), dm_expf(-sigma_t.z * tt));
+    F3 density = Tr, result = Tr;
+    if (sampledMedium) {
+        mi.p = point_at(ray, t);
+        mi.phaseG = 0.5f;
+        mi.sampled = true;
+        density = density * sigma_t;
+        result = result * sigma_s;
+    }
+    float pdf = dot(f3(1.0f), density);
+    if (0.0f >= pdf) pdf = 1.0f; else pdf = pdf / nSamples;
+    return result / pdf;
+}
+// GridDensityMedium::D / Density / Sample, Medium.hh:111-199
+TRC_DEV float grid_D(const trc_GridDensityInfo& info, const float* density, int x, int y, int z) {
+    const int nx = (int)info.nx, ny = (int)info.ny, nz = (int)info.nz;
+    if (x < 0 || y < 0 || z < 0 || x >= nx || y >= ny || z >= nz) return 0;
+    return density[((size_t)z * ny + y) * nx + x];
+}
+TRC_DEV float lerp_f(float t, float s1, float s2) { return (1 - t) * s1 + t * s2; }          // Sampling.hh:13-16
+TRC_DEV int grid_to_int(float f) { return !(f > -2.0e9f) ? -2000000000 : (f > 2.0e9f ? 2000000000 : (int)f); }
+TRC_DEV float grid_density(const trc_GridDensityInfo& info, const float* density, F3 p) {
+    const float nx = (float)info.nx, ny = (float)info.ny, nz = (float)info.nz;
+    const F3 ps = f3(p.x * nx - 0.5f, p.y * ny - 0.5f, p.z * nz - 0.5f);
+    const int ix = grid_to_int(floorf(ps.x)), iy = grid_to_int(floorf(ps.y)), iz = grid_to_int(floorf(ps.z));
+    const F3 d = f3(ps.x - (float)ix, ps.y - (float)iy, ps.z - (float)iz);
+    float d00 = lerp_f(d.x, grid_D(info, density, ix, iy, iz), grid_D(info, density, ix + 1, iy, iz));
+    float d10 = lerp_f(d.x, grid_D(info, density, ix, iy + 1, iz), grid_D(info, density, ix + 1, iy + 1, iz));
+    float d01 = lerp_f(d.x, grid_D(info, density, ix, iy, iz + 1), grid_D(info, density, ix + 1, iy, iz + 1));
+    float d11 = lerp_f(d.x, grid_D(info, density, ix, iy + 1, iz + 1), grid_D(info, density, ix + 1, iy + 1, iz + 1));
+    float d0 = lerp_f(d.y, d00, d10);
+    float d1 = lerp_f(d.y, d01, d11);
+    return lerp_f(d.z, d0, d1);
+}
+constexpr int kGridSampleMaxSteps = 1 << 16;      // same bound as oracle/oracle.cpp (the reference loop is unbounded)
+TRC_DEV float grid_sample(const PathCtx& cx, const HitRec& rec, MediumHit& mi, Pcg& rng) {
+    if (!cx.density) return 1.0f;
+    const trc_GridDensityInfo& info = cx.dinfo;
+    const float tMax = rec.vol_t;
+    float t = 0;
+    for (int step = 0; step < kGridSampleMaxSteps; ++step) {
+        t -= dm_logf(1 - pcg_float(rng)) * info.invMaxDensity / info.sigma_t;
+        if (t >= tMax) break;
+        const F3 p = rec.vol_o + rec.vol_d * t;
+        if (grid_density(info, cx.density, p) * info.invMaxDensity > pcg_float(rng)) {
+            F3 world = p;
+            if (rec.vol_cube != kTagNone) {                        // hitRecord.modelMatrix * float4(p, 1)
+                const uint32_t* cb = cx.S.small_base + cx.S.off_cubes + rec.vol_cube * kCubeDwords;
+                const float4 m0 = ld4(cb + 12), m1 = ld4(cb + 16), m2 = ld4(cb + 20);
+                const F3 mc0 = f3(m0.x, m0.y, m0.z), mc1 = f3(m0.w, m1.x, m1.y), mc2 = f3(m1.z, m1.w, m2.x), mc3 = f3(m2.y, m2.z, m2.w);
+                world = ((mc0 * p.x + mc1 * p.y) + mc2 * p.z) + mc3;
+            }
+            mi.p = world;
+            mi.phaseG = info.g;
+            mi.sampled = true;
+            return info.sigma_s / info.sigma_t;
+        }
+    }
+    return 1.0f;
+}
+
+// Same for traceMIS (Render.metal:298-406) and, with VOLUME, traceVolume (Render.metal:78-275 = traceMIS + the
+// medium block :114-158).  Lights are literally squareList[5] and [6] (:320-324, B-12).
 // The shadow ray (any-hit Scene::hit) is traced here, inside the step.
-template <bool ALL_LDS, bool STATS>
+template <bool ALL_LDS, bool STATS, bool VOLUME = false>
 TRC_DEV bool mis_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, TravCounters& cnt, uint32_t& n_rays,
                       uint32_t& n_shaded, F3& result) {
     HitRec& rec = ps.rec;
     if (!ps.primary) {
-        if (hitted && mat_type(cx.sh, rec.material) == kMatDiffuse) {   // MIS-weighted emitter hit, :390-404
+        if ((!VOLUME || ps.from_bsdf) && hitted && mat_type(cx.sh, rec.material) == kMatDiffuse) {   // MIS-weighted emitter hit, :390-404
             F3 Li = mat_albedo(cx.sh, rec.material);
             float cosOnLight = dot(-ps.ray.d, rec.sn);
             F3 weight = ps.scat_attenuation * Li * cosOnLight;
@@ -170,6 +273,33 @@ TRC_DEV bool mis_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, T
         result = ps.ratio * le * fabsf(w);
         return true;
     }
+    if (VOLUME) {                                                    // Render.metal:114-158
+        MediumHit mi;
+        mi.p = f3(0); mi.phaseG = 0; mi.sampled = false;
+        if (ps.medium == TRC_MEDIUM_HOMOGENEOUS) ps.ratio = ps.ratio * homogeneous_sample(ps.ray, rec, mi, rng);
+        else if (ps.medium == TRC_MEDIUM_GRIDDENSITY) ps.ratio = ps.ratio * f3(grid_sample(cx, rec, mi, rng));
+        if (mi.sampled) {                                            // scatter inside the medium
+            F2 u2; u2.x = pcg_float(rng); u2.y = pcg_float(rng);
+            F3 wi;
+            hg_sample_p(mi.phaseG, -ps.ray.d, wi, u2);
+            ps.ray = make_ray(mi.p, wi);
+            ps.medium = mat_medium(cx.sh, rec.material);
+            ps.from_bsdf = false;
+            return false;                                            // need_test, then `continue`
+        }
+        if (mtype == kMatNil) {                                      // medium boundary without a surface
+            if (dot(ps.ray.d, rec.gn) < 0) {
+                ps.ray = make_ray(offset_ray(rec.p, -rec.gn), ps.ray.d);
+                ps.medium = mat_medium(cx.sh, rec.material);
+            } else {
+                ps.ray = make_ray(offset_ray(rec.p, rec.gn), ps.ray.d);
+                ps.medium = TRC_MEDIUM_NIL;
+            }
+            ps.from_bsdf = false;
+            return false;
+        }
+        ps.from_bsdf = true;
+    }
     LightSample lsr;
     F2 uu; uu.x = pcg_float(rng); uu.y = pcg_float(rng);
     const F3 hit_origin = rec.p;
@@ -186,7 +316,7 @@ TRC_DEV bool mis_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, T
     HitRec shr;
     hit_init(shr);
     n_rays++;
-    const bool blocked = scene_hit<ALL_LDS, STATS, true, false>(cx.S, cx.root_min, cx.root_max, _ray, shr, _dis, cx.stack, cx.lvstack, cnt);
+    const bool blocked = scene_hit<ALL_LDS, STATS, true, false, false>(cx.S, cx.root_min, cx.root_max, _ray, shr, _dis, cx.stack, cx.lvstack, cnt);
     const F3 minus_d = -ps.ray.d;
     const F3 base_color = hit_color(cx.sh, rec);
     if (!blocked) {                                                  // light sampling, :339-356
@@ -212,8 +342,12 @@ TRC_DEV bool mis_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, T
     ps.scat_bxPDF = bxPDF;
     if (bxPDF <= 0) { result = ps.color; return true; }
     F3 wiw = (nx * wi.x + ny * wi.y) + rec.sn * wi.z;
-    if (wi.z < 0) ps.ray = make_ray(offset_ray(hit_origin, -rec.sn), wiw);
-    else ps.ray = make_ray(_origin, wiw);
+    if (wi.z < 0) {
+        ps.ray = make_ray(offset_ray(hit_origin, -rec.sn), wiw);
+        if (VOLUME) ps.medium = (dot(wiw, rec.gn) < 0) ? mat_medium(cx.sh, rec.material) : (int)TRC_MEDIUM_NIL;   // :236-243
+    } else {
+        ps.ray = make_ray(_origin, wiw);
+    }
     ps.ratio = ps.ratio * (ps.scat_attenuation / ps.scat_bxPDF);
     {
         float p = rgb_to_y(ps.ratio);

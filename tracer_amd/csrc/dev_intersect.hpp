@@ -43,9 +43,15 @@ struct HitRec {       // HitRecord.hh:9-30 (live fields) + the primitive tag
     uint32_t material;
     float PDF;
     uint32_t tag;
+    // traceVolume only (HitRecord.hh:22-23, written by Cube::hit_test, Cube.hh:30-31,39): the object-space ray and
+    // t of the last cube hit and that cube (for its model matrix); dead code in the other integrators
+    F3 vol_o, vol_d;
+    float vol_t;
+    uint32_t vol_cube;
 };
 TRC_DEV void hit_init(HitRec& h) {
     h.t = 0; h.p = f3(0); h.gn = f3(0); h.sn = f3(0); h.uv.x = 0; h.uv.y = 0; h.material = 0; h.PDF = 0; h.tag = kTagNone;
+    h.vol_o = f3(0); h.vol_d = f3(0); h.vol_t = 0; h.vol_cube = kTagNone;
 }
 TRC_DEV void check_face(HitRec& h, const Ray& ray) {   // HitRecord.hh:26-29
     bool f = dot(ray.d, h.gn) <= 0;
@@ -243,7 +249,7 @@ TRC_DEV void square_sample(const SceneRef& S, uint32_t index, F2 u, F3 pos, Ligh
     lsr.material = __float_as_uint(kx.w);
 }
 
-template <bool STATS>
+template <bool STATS, bool VOL>
 TRC_DEV bool cube_hit_test(const SceneRef& S, uint32_t index, const Ray& ray, float& ry, HitRec& rec, TravCounters& cnt) {
     const uint32_t* cb = S.small_base + S.off_cubes + index * kCubeDwords;
     // inverse matrix columns c0..c3 (xyz each)
@@ -264,6 +270,7 @@ TRC_DEV bool cube_hit_test(const SceneRef& S, uint32_t index, const Ray& ray, fl
     float t = length(ray.o - p);                            // distance(ray.origin, p), Cube.hh:32
     if (t >= ry) return false;
     ry = t;
+    if (VOL) { rec.vol_o = origin; rec.vol_d = direction; rec.vol_t = t_obj; rec.vol_cube = index; }
     const float4 n0 = ld4(cb + 24), n1 = ld4(cb + 28);
     const F3 nc0 = f3(n0.x, n0.y, n0.z), nc1 = f3(n0.w, n1.x, n1.y), nc2 = f3(n1.z, n1.w, __uint_as_float(cb[32]));
     rec.t = t;
@@ -364,7 +371,7 @@ TRC_DEV bool trav_begin(const F3 root_min, const F3 root_max, const Ray& ray, co
 
 // one round: (1) expand interior nodes until this lane holds a leaf (or runs out of work) -- the whole wavefront
 // does box tests here; (2) test the leaf.  Lanes with tv.done set idle through the call.
-template <bool ALL_LDS, bool STATS, bool ANY, bool EAGER_UV>
+template <bool ALL_LDS, bool STATS, bool ANY, bool EAGER_UV, bool VOL = false>
 TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const float test_t, Trav& tv,
                        uint32_t* stack, uint32_t* lvstack, TravCounters& cnt) {
     const float rx = FLT_MIN;
@@ -404,7 +411,7 @@ TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const flo
         } else if (type == 2u) {
             if (STATS) cnt.leaf[2]++;
             ProfScope<STATS> scope(cnt, kProfCube);
-            ok = cube_hit_test<STATS>(S, index, ray, tv.ry, rec, cnt);
+            ok = cube_hit_test<STATS, VOL>(S, index, ray, tv.ry, rec, cnt);
         } else {
             if (STATS) cnt.leaf[3]++;
             ProfScope<STATS> scope(cnt, kProfTriangle);
@@ -416,12 +423,12 @@ TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const flo
     }
 }
 
-template <bool ALL_LDS, bool STATS, bool ANY, bool EAGER_UV>
+template <bool ALL_LDS, bool STATS, bool ANY, bool EAGER_UV, bool VOL = false>
 TRC_DEV bool scene_hit(const SceneRef& S, const F3 root_min, const F3 root_max, const Ray& ray, HitRec& rec, const float test_t,
                        uint32_t* stack, uint32_t* lvstack, TravCounters& cnt) {
     Trav tv;
     if (!trav_begin<STATS>(root_min, root_max, ray, test_t, tv, cnt)) return false;
-    while (!tv.done) trav_iter<ALL_LDS, STATS, ANY, EAGER_UV>(S, ray, rec, test_t, tv, stack, lvstack, cnt);
+    while (!tv.done) trav_iter<ALL_LDS, STATS, ANY, EAGER_UV, VOL>(S, ray, rec, test_t, tv, stack, lvstack, cnt);
     return tv.ry < test_t;
 }
 

@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256) k_seed(uint32_t* rng, uint32_t n_pixels, 
 // (4 wavefronts of 8x8 pixels), all `spp` samples fused: RNG texel and accumulator are read and
 // written ONCE per pixel instead of once per sample (64 B/pixel/sample in the reference).
 template <bool LDS, bool STATS, int INTEGRATOR>
-__global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRATOR_MIS ? 3 : 4)) k_render(const KRender kp) {
+__global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRATOR_PATH ? 4 : 3)) k_render(const KRender kp) {
     const DScene& sc = kp.ks.sc;
     const uint32_t* small_base = stage_scene(sc);
     uint32_t* stack_base = trc_smem + sc.lds_dwords;
@@ -67,6 +67,8 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
         cx.stack = stack;
         cx.lvstack = lvstack;
         cx.max_depth = kp.max_depth;
+        cx.density = kp.density;
+        cx.dinfo = kp.dinfo;
 
         const size_t pix = (size_t)py * W + px;
         uint4 texel = reinterpret_cast<const uint4*>(kp.fr.rng)[pix];       // r, g, b, a
@@ -109,12 +111,13 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
         while (alive) {
             ProfScope<STATS> loop_scope(cnt, kProfLoop);
             n_rays++;
-            const bool hitted = scene_hit<LDS, STATS, false, false>(cx.S, cx.root_min, cx.root_max, ps.ray, ps.rec, FLT_MAX,
-                                                               cx.stack, cx.lvstack, cnt);
+            constexpr bool kVolume = INTEGRATOR == TRC_INTEGRATOR_VOLUME;
+            const bool hitted = scene_hit<LDS, STATS, false, false, kVolume>(cx.S, cx.root_min, cx.root_max, ps.ray, ps.rec, FLT_MAX,
+                                                                        cx.stack, cx.lvstack, cnt);
             F3 color;
-            const bool finished = (INTEGRATOR == TRC_INTEGRATOR_MIS)
-                                      ? mis_step<LDS, STATS>(cx, ps, hitted, rng, cnt, n_rays, n_shaded, color)
-                                      : path_step<STATS>(cx, ps, hitted, rng, cnt, n_shaded, color);
+            const bool finished = (INTEGRATOR == TRC_INTEGRATOR_PATH)
+                                      ? path_step<STATS>(cx, ps, hitted, rng, cnt, n_shaded, color)
+                                      : mis_step<LDS, STATS, kVolume>(cx, ps, hitted, rng, cnt, n_rays, n_shaded, color);
             if (finished) finish_sample(color);
         }
         float4 out; out.x = cached.x; out.y = cached.y; out.z = cached.z; out.w = 1.0f;
@@ -358,7 +361,10 @@ namespace {
 template <bool LDS>
 void launch_render(trc_ctx* ctx, const KRender& kp, bool stats, uint32_t integrator, size_t lds) {
     dim3 grid(ctx->n_tiles), block(kBlock);
-    if (integrator == TRC_INTEGRATOR_MIS) {
+    if (integrator == TRC_INTEGRATOR_VOLUME) {
+        if (stats) hipLaunchKernelGGL((k_render<LDS, true, TRC_INTEGRATOR_VOLUME>), grid, block, lds, ctx->stream, kp);
+        else hipLaunchKernelGGL((k_render<LDS, false, TRC_INTEGRATOR_VOLUME>), grid, block, lds, ctx->stream, kp);
+    } else if (integrator == TRC_INTEGRATOR_MIS) {
         if (stats) hipLaunchKernelGGL((k_render<LDS, true, TRC_INTEGRATOR_MIS>), grid, block, lds, ctx->stream, kp);
         else hipLaunchKernelGGL((k_render<LDS, false, TRC_INTEGRATOR_MIS>), grid, block, lds, ctx->stream, kp);
     } else {
@@ -420,7 +426,7 @@ void trc_destroy(trc_ctx* ctx) {
     trc_sppm_release(ctx);
     collect_events(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
-    (void)hipFree(ctx->d_blob); (void)hipFree(ctx->d_bvh_ref); (void)hipFree(ctx->d_rng); (void)hipFree(ctx->d_accum);
+    (void)hipFree(ctx->d_blob); (void)hipFree(ctx->d_bvh_ref); (void)hipFree(ctx->d_density); (void)hipFree(ctx->d_rng); (void)hipFree(ctx->d_accum);
     (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_stats); (void)hipFree(ctx->d_reduce_recv);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -446,6 +452,23 @@ trc_status trc_upload_scene(trc_ctx* ctx, const trc_scene* scene) {
     ctx->ks = ks;
     ctx->lds_scene = ks.sc.n_lds_nodes == ks.sc.n_nodes;      // whole tree staged in LDS
     ctx->has_scene = true;
+    return TRC_OK;
+}
+
+trc_status trc_upload_density(trc_ctx* ctx, const trc_GridDensityInfo* info, const float* density) {
+    if (!ctx) return TRC_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(ctx->d_density); ctx->d_density = nullptr;
+    ctx->dinfo = trc_GridDensityInfo{};
+    if (!info && !density) return TRC_OK;                                  // cleared
+    if (!info || !density || info->nx == 0 || info->ny == 0 || info->nz == 0) return fail(ctx, TRC_ERR_INVALID_ARG, "trc_upload_density: empty grid");
+    const uint64_t count = (uint64_t)info->nx * info->ny * info->nz;
+    if (count > (1ull << 31)) return fail(ctx, TRC_ERR_UNSUPPORTED, "trc_upload_density: more than 2^31 cells");
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_density, count * sizeof(float)));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_density, density, count * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->dinfo = *info;
     return TRC_OK;
 }
 
@@ -524,9 +547,9 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
     if (!ctx->has_camera) return fail(ctx, TRC_ERR_INVALID_ARG, "trc_render before trc_set_camera");
     const uint32_t nranks = p->tile_nranks ? p->tile_nranks : 1;
     if (p->tile_rank >= nranks) return fail(ctx, TRC_ERR_INVALID_ARG, "tile_rank >= tile_nranks");
-    if (p->integrator > TRC_INTEGRATOR_MIS) return fail(ctx, TRC_ERR_INVALID_ARG, "unknown integrator");
-    if (p->integrator == TRC_INTEGRATOR_MIS && ctx->ks.sc.n_squares < 7)
-        return fail(ctx, TRC_ERR_INVALID_ARG, "traceMIS samples squareList[5] and [6] (Render.metal:320-324)");
+    if (p->integrator > TRC_INTEGRATOR_VOLUME) return fail(ctx, TRC_ERR_INVALID_ARG, "unknown integrator");
+    if (p->integrator != TRC_INTEGRATOR_PATH && ctx->ks.sc.n_squares < 7)
+        return fail(ctx, TRC_ERR_INVALID_ARG, "traceMIS / traceVolume sample squareList[5] and [6] (Render.metal:320-324,172-176)");
     if (p->spp == 0) return TRC_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
@@ -545,6 +568,8 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
     kp.spp = p->spp; kp.max_depth = p->max_depth; kp.frame0 = p->frame0;
     kp.tiles = ctx->d_tiles;
     kp.stats = ctx->d_stats;
+    kp.density = ctx->d_density;
+    kp.dinfo = ctx->dinfo;
 
     hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);
     if (!e0 || !e1) return fail(ctx, TRC_ERR_HIP, "hipEventCreate failed");

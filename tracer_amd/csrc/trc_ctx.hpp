@@ -28,6 +28,8 @@ struct KRender {
     DFrame fr;
     uint32_t spp, max_depth, frame0, _pad;
     const uint32_t* tiles;              // tx | ty << 16, one per workgroup
+    const float* density;               // traceVolume: GridDensity medium grid (null when absent)
+    trc_GridDensityInfo dinfo;
     unsigned long long* stats;          // kStatCount counters
 };
 
@@ -84,6 +86,8 @@ struct trc_ctx {
     trc_BVH* d_bvh_ref = nullptr;    // tree built by trc_upload_scene_lbvh, reference array layout (trc_download_bvh)
     uint32_t n_bvh_ref = 0, lbvh_height = 0;
     float lbvh_build_ms = 0.0f;
+    float* d_density = nullptr;      // GridDensity medium (trc_upload_density)
+    trc_GridDensityInfo dinfo{};
 
     bool has_camera = false;
     DCamera cam{};

@@ -119,6 +119,7 @@ inline void fill_primitives(const trc_scene* s, const DScene& sc, uint32_t* blob
         q[0] = (uint32_t)m.type; q[1] = (uint32_t)m.textureInfo.type;
         q[2] = f2u(m.textureInfo.albedo.x); q[3] = f2u(m.textureInfo.albedo.y); q[4] = f2u(m.textureInfo.albedo.z);
         q[5] = m.specular ? 1u : 0u;
+        q[6] = (uint32_t)m.medium;
     }
     for (uint32_t t = 0; t < n_tri; ++t) {
         const trc_TriangleVertex* v[3] = {&s->triList[s->idxList[3 * t]], &s->triList[s->idxList[3 * t + 1]],

@@ -43,6 +43,7 @@ def lib():
         L.trc_destroy.argtypes = [vp]
         L.trc_destroy.restype = None
         L.trc_upload_scene.argtypes = [vp, C.POINTER(abi.Scene)]
+        L.trc_upload_density.argtypes = [vp, C.POINTER(abi.GridDensityInfo), vp]
         L.trc_upload_scene_lbvh.argtypes = [vp, C.POINTER(abi.Scene)]
         L.trc_download_bvh.argtypes = [vp, C.POINTER(abi.BVH), u32, C.POINTER(u32)]
         L.trc_lbvh_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_float)]
@@ -117,6 +118,14 @@ class Tracer:
     # --- scene / camera / frame -------------------------------------------------
     def upload_scene(self, scene_view):
         self._check(self._L.trc_upload_scene(self._h, C.byref(scene_view)), "trc_upload_scene")
+
+    def upload_density(self, info, density):
+        """Density grid (nz, ny, nx) float32 of the GridDensity medium for integrator 2; None clears it."""
+        if density is None:
+            self._check(self._L.trc_upload_density(self._h, None, None), "trc_upload_density")
+            return
+        assert density.dtype == np.float32 and density.flags.c_contiguous
+        self._check(self._L.trc_upload_density(self._h, C.byref(info), density.ctypes.data), "trc_upload_density")
 
     def upload_scene_lbvh(self, leaves_view):
         """Scene whose bvhList holds only leaf records (HostScene.leaves_view()); the tree is built on the GPU."""

@@ -56,6 +56,15 @@ def lib():
                                          C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
         L.trc_host_mesh_view.restype = None
         L.trc_host_mesh_destroy.argtypes = [C.c_void_p]
+        L.trc_host_make_density_info.argtypes = [C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                 C.c_void_p, C.POINTER(abi.GridDensityInfo)]
+        L.trc_host_make_density_info.restype = None
+        L.trc_host_make_cloud.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.trc_host_make_cloud.restype = None
+        L.trc_host_load_density_pbrt.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                                 C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_float))]
+        L.trc_host_free.argtypes = [C.c_void_p]
+        L.trc_host_free.restype = None
         L.trc_host_mesh_destroy.restype = None
         _LIB = L
     return _LIB
@@ -166,6 +175,35 @@ class HostScene:
         if getattr(self, "_h", None):
             lib().trc_host_scene_destroy(self._h)
             self._h = None
+
+
+def make_cloud(nx=100, ny=100, nz=40, seed=1):
+    """Procedural density grid (nz, ny, nx) float32 standing in for the reference's cloud/density_render.70.pbrt."""
+    out = np.empty((nz, ny, nx), dtype=np.float32)
+    lib().trc_host_make_cloud(nx, ny, nz, seed, out.ctypes.data)
+    return out
+
+
+def load_density_pbrt(path):
+    """The `float density` grid of a pbrt-v3 MakeNamedMedium block -> (nz, ny, nx) float32."""
+    nx, ny, nz = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    p = C.POINTER(C.c_float)()
+    _check(lib().trc_host_load_density_pbrt(path.encode(), C.byref(nx), C.byref(ny), C.byref(nz), C.byref(p)),
+           "trc_host_load_density_pbrt")
+    try:
+        n = nx.value * ny.value * nz.value
+        return np.ctypeslib.as_array(p, shape=(n,)).astype(np.float32).reshape(nz.value, ny.value, nx.value).copy()
+    finally:
+        lib().trc_host_free(p)
+
+
+def density_info(density, sigma_a=10.0, sigma_s=90.0, g=0.5):
+    """GridDensityInfo(10, 90, 0.5, nx, ny, nz, density) as at AAPLRenderer.mm:636."""
+    assert density.dtype == np.float32 and density.ndim == 3 and density.flags.c_contiguous
+    info = abi.GridDensityInfo()
+    nz, ny, nx = density.shape
+    lib().trc_host_make_density_info(sigma_a, sigma_s, g, nx, ny, nz, density.ctypes.data, C.byref(info))
+    return info
 
 
 def prepare_camera(width, height):

@@ -9,6 +9,11 @@
 //   camera                     Tracer.mm:87-125,371-411
 //   RNG texture                AAPLRenderer.mm:296-344 (arc4random -> deterministic per-pixel PCG32)
 #include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
 #include <new>
 #include <vector>
 
@@ -235,8 +240,9 @@ void trc_host_fill_rng(uint64_t seed, uint32_t width, uint32_t height, uint32_t*
 trc_status trc_host_scene_create(int32_t kind, const trc_TriangleVertex* mesh_vertices, uint32_t n_vertices,
                                  const uint32_t* mesh_indices, uint32_t n_indices, trc_host_scene** out) {
     if (!out) return TRC_ERR_INVALID_ARG;
-    if (kind < TRC_SCENE_CORNELL || kind > TRC_SCENE_CORNELL_MESH) return TRC_ERR_INVALID_ARG;
-    if (kind == TRC_SCENE_CORNELL_MESH && (!mesh_vertices || !mesh_indices || n_indices < 3 || n_indices % 3))
+    if (kind < TRC_SCENE_CORNELL || kind > TRC_SCENE_CORNELL_VOLUME) return TRC_ERR_INVALID_ARG;
+    const bool with_mesh = kind == TRC_SCENE_CORNELL_MESH || (kind == TRC_SCENE_CORNELL_VOLUME && mesh_vertices != nullptr);
+    if (with_mesh && (!mesh_vertices || !mesh_indices || n_indices < 3 || n_indices % 3))
         return TRC_ERR_INVALID_ARG;
     trc_host_scene* s = new (std::nothrow) trc_host_scene();
     if (!s) return TRC_ERR_OOM;
@@ -254,8 +260,9 @@ trc_status trc_host_scene_create(int32_t kind, const trc_TriangleVertex* mesh_ve
 
     std::vector<trc_BVH> leaves;
     trc_BVH leaf;
-    // all cubes but the last (density container), AAPLRenderer.mm:459-462
-    for (uint32_t i = 0; i + 1 < s->cubes.size(); ++i) {
+    // all cubes but the last (density container), AAPLRenderer.mm:459-462; kind VOLUME puts the container in too
+    const uint32_t n_cube_leaves = (uint32_t)s->cubes.size() - (kind == TRC_SCENE_CORNELL_VOLUME ? 0u : 1u);
+    for (uint32_t i = 0; i < n_cube_leaves; ++i) {
         trc_host_build_node(&s->cubes[i].box, &s->cubes[i].model_matrix, TRC_PRIM_CUBE, i, &leaf);
         leaves.push_back(leaf);
     }
@@ -270,7 +277,7 @@ trc_status trc_host_scene_create(int32_t kind, const trc_TriangleVertex* mesh_ve
             leaves.push_back(leaf);
         }
     }
-    if (kind == TRC_SCENE_CORNELL_MESH) {
+    if (with_mesh) {
         s->vertices.assign(mesh_vertices, mesh_vertices + n_vertices);
         s->indices.assign(mesh_indices, mesh_indices + n_indices);
         for (uint32_t i = 0; i < n_indices; ++i)
@@ -332,5 +339,84 @@ void trc_host_scene_view(const trc_host_scene* s, trc_scene* out) {
     out->idxList = s->indices.data();       out->n_index = (uint32_t)s->indices.size();
     out->materials = s->materials.data();   out->n_material = (uint32_t)s->materials.size();
 }
+
+
+// GridDensityInfo::GridDensityInfo, Medium.hh:92-105
+void trc_host_make_density_info(float sigma_a, float sigma_s, float g, uint32_t nx, uint32_t ny, uint32_t nz,
+                                const float* density, trc_GridDensityInfo* out) {
+    out->sigma_a = sigma_a; out->sigma_s = sigma_s; out->g = g;
+    out->nx = nx; out->ny = ny; out->nz = nz;
+    out->sigma_t = sigma_a + sigma_s;
+    float maxDensity = 0;
+    for (size_t i = 0; i < (size_t)nx * ny * nz; ++i) maxDensity = std::fmax(maxDensity, density[i]);
+    out->invMaxDensity = 1 / maxDensity;
+}
+
+// procedural stand-in for the reference's cloud grid: a handful of Gaussian blobs, deterministic in `seed`
+void trc_host_make_cloud(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t seed, float* out) {
+    uint64_t state = 0, inc = ((uint64_t)seed << 1u) | 1u;
+    pcg32_next(state, inc); state += 0x853c49e6748fea9bULL; pcg32_next(state, inc);
+    auto rnd = [&]() { return (float)(pcg32_next(state, inc) >> 8) * (1.0f / 16777216.0f); };
+    const int n_blobs = 9;
+    float cx[n_blobs], cy[n_blobs], cz[n_blobs], rad[n_blobs], amp[n_blobs];
+    for (int b = 0; b < n_blobs; ++b) {
+        cx[b] = 0.2f + 0.6f * rnd(); cy[b] = 0.2f + 0.6f * rnd(); cz[b] = 0.25f + 0.5f * rnd();
+        rad[b] = 0.08f + 0.14f * rnd(); amp[b] = 0.4f + 0.6f * rnd();
+    }
+    for (uint32_t z = 0; z < nz; ++z)
+        for (uint32_t y = 0; y < ny; ++y)
+            for (uint32_t x = 0; x < nx; ++x) {
+                const float px = (x + 0.5f) / nx, py = (y + 0.5f) / ny, pz = (z + 0.5f) / nz;
+                float d = 0;
+                for (int b = 0; b < n_blobs; ++b) {
+                    const float dx = px - cx[b], dy = py - cy[b], dz = pz - cz[b];
+                    d += amp[b] * std::exp(-(dx * dx + dy * dy + dz * dz) / (rad[b] * rad[b]));
+                }
+                out[((size_t)z * ny + y) * nx + x] = d < 0.05f ? 0.0f : d;      // empty space stays exactly empty
+            }
+}
+
+// `MakeNamedMedium "..." ... "integer nx" N "integer ny" N "integer nz" N ... "float density" [ v v v ... ]`
+trc_status trc_host_load_density_pbrt(const char* path, uint32_t* nx, uint32_t* ny, uint32_t* nz, float** out) {
+    if (!path || !nx || !ny || !nz || !out) return TRC_ERR_INVALID_ARG;
+    *out = nullptr;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return TRC_ERR_INVALID_ARG;
+    std::string text;
+    char chunk[1 << 16];
+    size_t got;
+    while ((got = std::fread(chunk, 1, sizeof chunk, f)) > 0) text.append(chunk, got);
+    std::fclose(f);
+    auto int_param = [&](const char* name, uint32_t* v) {
+        const std::string key = std::string("\"integer ") + name + "\"";
+        size_t p = text.find(key);
+        if (p == std::string::npos) return false;
+        p += key.size();
+        while (p < text.size() && (std::isspace((unsigned char)text[p]) || text[p] == '[')) ++p;
+        char* end = nullptr;
+        const long val = std::strtol(text.c_str() + p, &end, 10);
+        if (end == text.c_str() + p || val <= 0) return false;
+        *v = (uint32_t)val;
+        return true;
+    };
+    if (!int_param("nx", nx) || !int_param("ny", ny) || !int_param("nz", nz)) return TRC_ERR_INVALID_ARG;
+    size_t p = text.find("\"float density\"");
+    if (p == std::string::npos) return TRC_ERR_INVALID_ARG;
+    p = text.find('[', p);
+    if (p == std::string::npos) return TRC_ERR_INVALID_ARG;
+    const size_t count = (size_t)*nx * *ny * *nz;
+    float* data = (float*)std::malloc(count * sizeof(float));
+    if (!data) return TRC_ERR_OOM;
+    const char* cur = text.c_str() + p + 1;
+    for (size_t i = 0; i < count; ++i) {
+        char* end = nullptr;
+        data[i] = std::strtof(cur, &end);
+        if (end == cur) { std::free(data); return TRC_ERR_INVALID_ARG; }
+        cur = end;
+    }
+    *out = data;
+    return TRC_OK;
+}
+void trc_host_free(void* p) { std::free(p); }
 
 }  // extern "C"
