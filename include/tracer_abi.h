@@ -333,6 +333,11 @@ trc_status trc_download_bvh(trc_ctx* ctx, trc_BVH* out, uint32_t capacity, uint3
 /* node count, depth of the deepest leaf and GPU time of the last trc_upload_scene_lbvh (bounds -> emit) */
 trc_status trc_lbvh_info(trc_ctx* ctx, uint32_t* n_nodes, uint32_t* height, float* device_build_ms);
 /* replaces memcpy(_camera_buffer.contents, ...), AAPLRenderer.mm:1183 */
+/* replaces _densityInfoBuffer / _densityDataBuffer (AAPLRenderer.mm:629-643, bound at :716-720): the
+ * nx*ny*nz density grid of the GridDensity medium, x fastest (Medium.hh:121).  Consulted by
+ * TRC_INTEGRATOR_VOLUME when a ray travels in a medium of type TRC_MEDIUM_GRIDDENSITY; both pointers
+ * NULL clear it. */
+trc_status trc_upload_density(trc_ctx* ctx, const trc_GridDensityInfo* info, const float* density);
 trc_status trc_set_camera(trc_ctx* ctx, const trc_Camera* camera);
 /* constant environment radiance used on a miss; stands in for
  * packageEnv.texHDR.sample (Render.metal:434-439; the HDR blob is missing) */
