@@ -114,3 +114,28 @@ def test_edge_sizes_and_empty_inputs(gpu, cornell):
     ty, tx = np.mgrid[0:BH, 0:BW] // abi.TRC_TILE
     mine = ((tx + ty) % 97) == 0
     assert np.array_equal(big[mine].view(np.uint32), ref[mine].view(np.uint32))
+
+
+def test_volume_full_frame_through_lbvh(gpu):
+    """the two widened rows together at full size: traceVolume (cloud container + glass mesh with the homogeneous
+    medium) through a tree built on the GPU; 1 tile in 128 re-rendered by the oracle through the same tree"""
+    scene = host.HostScene(abi.SCENE_CORNELL_VOLUME, host.Mesh.ball(153, 153, 0.08))
+    cloud = host.make_cloud()
+    info = host.density_info(cloud)
+    cam = host.prepare_camera(W, H)
+    gpu.upload_scene_lbvh(scene.leaves_view())
+    tree = gpu.download_bvh()
+    gpu.upload_density(info, cloud)
+    po.set_density(info, cloud)
+    try:
+        gpu.set_camera(cam); gpu.set_environment((0.0, 0.0, 0.0)); gpu.resize(W, H); gpu.seed(77); gpu.reset_stats()
+        gpu.render(spp=4, integrator=abi.INTEGRATOR_VOLUME)
+        dev = gpu.download_accum()
+        assert np.isfinite(dev).all() and (dev[..., :3] >= 0).all()
+        ref, rst = po.render(scene.view_with_bvh(tree), cam, W, H, host.fill_rng(77, W, H), spp=4,
+                             integrator=abi.INTEGRATOR_VOLUME, tile_rank=0, tile_nranks=128)
+        mine = _tile_mask(128)
+        assert rst.rays > 0 and np.array_equal(dev[mine].view(np.uint32), ref[mine].view(np.uint32))
+    finally:
+        po.set_density(None, None)
+        gpu.upload_density(None, None)
