@@ -25,6 +25,18 @@ for name, mesh, integ, spp in [
     out.append({"config": name, "triangles": mesh.n_triangles, "bvh_nodes": sc.view.n_bvh, "depth": sc.tree_depth(),
                 "host_bvh_build_s": round(build_s, 3), "kernel_ms": round(s.kernel_ms, 2), "rays": s.rays,
                 "mrays_per_s": round(s.rays / s.kernel_ms / 1e3, 1), "mpaths_per_s": round(s.paths / s.kernel_ms / 1e3, 1)})
+# traceVolume: cloud container (procedural 100x100x40 grid) + the config-3 mesh as glass filled with the
+# homogeneous medium, 64 spp
+sc = host.HostScene(abi.SCENE_CORNELL_VOLUME, host.Mesh.ball(153, 153, 0.08))
+cloud = host.make_cloud()
+t.upload_scene(sc.view); t.upload_density(host.density_info(cloud), cloud); t.set_camera(cam); t.resize(W, H)
+for name, integ in (("traceVolume", abi.INTEGRATOR_VOLUME), ("traceMIS on the same scene", abi.INTEGRATOR_MIS)):
+    t.seed(1); t.render(spp=1, integrator=integ); t.synchronize(); t.seed(1); t.reset_stats()
+    t.render(spp=64, integrator=integ); t.synchronize()
+    s = t.stats()
+    out.append({"config": f"volume scene, {name}, 64spp", "kernel_ms": round(s.kernel_ms, 2), "rays": s.rays,
+                "mrays_per_s": round(s.rays / s.kernel_ms / 1e3, 1), "mpaths_per_s": round(s.paths / s.kernel_ms / 1e3, 1)})
+t.upload_density(None, None)
 sc = host.HostScene(abi.SCENE_CORNELL_SPHERES)
 t.upload_scene(sc.view); t.set_camera(cam); t.resize(W, H); t.seed(1); t.sppm_init(2)
 t.sppm_frames(1); t.synchronize(); t.reset_stats()
