@@ -357,6 +357,15 @@ trc_status trc_upload_accum(trc_ctx* ctx, const float* rgba /* 4*W*H */);
 trc_status trc_download_accum(trc_ctx* ctx, float* rgba /* 4*W*H */);
 trc_status trc_clear_accum(trc_ctx* ctx);
 
+/* Output stage = what fragmentShader does to the accumulator before display (Render.metal:29-75):
+ * auto-exposure from the frame's mean colour (the top mip level there; an exact mean here: per-channel sums in
+ * 2^-16 fixed point, so the result does not depend on summation order), luma = dot(mean, (0.2126, 0.7152, 0.0722)),
+ * expose = 1 - clamp(CETone(luma, 1), 0, 0.9999) (Render.hh:91-95), ACESTone(rgb, expose) (Render.hh:78-89),
+ * no sRGB curve (commented out at :73), 8-bit = (uint8)(clamp(x, 0, 1) * 255 + 0.5), alpha 255.  Rows are
+ * written top-down (the shader flips v, :51-56): out row 0 = frame row H-1.  The reference feeds its SVGF-denoised
+ * texture here; this takes the raw accumulator.  rgba8: host buffer of 4*W*H bytes; exposure_out may be NULL. */
+trc_status trc_tonemap(trc_ctx* ctx, uint8_t* rgba8, float* exposure_out);
+
 /* replaces -[AAPLRenderer render:] + kernelPathTracing dispatch
  * (AAPLRenderer.mm:1134-1196, Render.metal:495-558); asynchronous on the
  * context stream; spp samples are fused into one launch with bit-identical
@@ -465,6 +474,10 @@ void trc_host_make_cloud(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t seed, f
  * of minipbrt the reference uses, AAPLRenderer.mm:629-636); *out is malloc'ed, free with trc_host_free */
 trc_status trc_host_load_density_pbrt(const char* path, uint32_t* nx, uint32_t* ny, uint32_t* nz, float** out);
 void trc_host_free(void* p);
+
+/* "Export as PNG file" (the reference's unchecked to-do, RT_Metal/README.md:61): 8-bit RGBA, rows top-down,
+ * stored (uncompressed) deflate blocks -- no zlib dependency */
+trc_status trc_host_write_png(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height);
 
 /* minimal Wavefront OBJ reader (v / vn / vt / f; polygons fan-triangulated;
  * smooth normals generated when the file has none), standing in for ModelIO

@@ -1755,6 +1755,40 @@ void orc_trace_rays_brute(const trc_scene* scene, const trc_ray* rays, size_t n,
     }
 }
 
+// fragmentShader, Render.metal:29-75
+void orc_tonemap(const float* accum, uint32_t W, uint32_t H, uint8_t* rgba8, float* exposure_out) {
+    const size_t n = (size_t)W * H;
+    uint64_t sum[3] = {0, 0, 0};
+    for (size_t i = 0; i < n; ++i)
+        for (int c = 0; c < 3; ++c) {
+            float v = accum[4 * i + c];
+            if (!(v > 0.0f)) v = 0.0f;                       // negative / NaN radiance does not expose
+            if (v > 1048576.0f) v = 1048576.0f;
+            sum[c] += (uint64_t)(v * 65536.0f + 0.5f);
+        }
+    float mean[3];
+    for (int c = 0; c < 3; ++c) mean[c] = (float)((double)sum[c] / 65536.0 / (double)n);
+    const float luma = (mean[0] * 0.2126f + mean[1] * 0.7152f) + mean[2] * 0.0722f;
+    float mapped = 1 - m_exp(-1.0f * luma);                  // CETone(luma, 1.)
+    mapped = fminf(fmaxf(mapped, 0.0f), 0.9999f);
+    const float expose = 1.0f - mapped;
+    if (exposure_out) *exposure_out = expose;
+    const float A = 2.51f, B = 0.03f, Cc = 2.43f, D = 0.59f, E = 0.14f;
+    for (uint32_t y = 0; y < H; ++y)
+        for (uint32_t x = 0; x < W; ++x) {
+            const float* px = accum + 4 * ((size_t)(H - 1 - y) * W + x);
+            uint8_t* o = rgba8 + 4 * ((size_t)y * W + x);
+            for (int c = 0; c < 3; ++c) {
+                float col = px[c] * expose;
+                float t = (col * (A * col + B)) / (col * (Cc * col + D) + E);      // ACESTone
+                if (!(t > 0.0f)) t = 0.0f;
+                if (t > 1.0f) t = 1.0f;
+                o[c] = (uint8_t)(t * 255.0f + 0.5f);
+            }
+            o[3] = 255;
+        }
+}
+
 void orc_set_density(const trc_GridDensityInfo* info, const float* density) {
     if (info && density) { g_density_info_copy = *info; g_density_info = &g_density_info_copy; g_density_array = density; }
     else { g_density_info = nullptr; g_density_array = nullptr; }

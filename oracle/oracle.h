@@ -85,6 +85,9 @@ float     orc_photon_hash(const float idx[3], float hash_scale);                
  * BVH::buildTree (BVH.hh:246-269): [root, leaf 0..n-1, interior 1..n-2].  *out_height = depth of the deepest leaf. */
 void orc_lbvh_build(const trc_BVH* leaves, uint32_t n, trc_BVH* out, uint32_t* out_height);
 
+/* output stage, Render.metal:29-75 + Render.hh:78-95 (see trc_tonemap in tracer_abi.h for the exact definition) */
+void orc_tonemap(const float* accum_rgba, uint32_t W, uint32_t H, uint8_t* rgba8, float* exposure_out);
+
 /* deterministic math under test (identity wrappers over trc_detmath.h / libm) */
 float orc_math(int fn, float a, float b);   /* 0 sin 1 cos 2 exp 3 log 4 pow 5 asin 6 acos 7 atan2 */
 

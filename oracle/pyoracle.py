@@ -75,6 +75,8 @@ def lib(libm=False):
         L.orc_sppm_download.restype = None
         L.orc_photon_hash.argtypes = [f3, C.c_float]
         L.orc_photon_hash.restype = C.c_float
+        L.orc_tonemap.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_float)]
+        L.orc_tonemap.restype = None
         L.orc_set_density.argtypes = [C.POINTER(abi.GridDensityInfo), C.c_void_p]
         L.orc_set_density.restype = None
         L.orc_lbvh_build.argtypes = [C.POINTER(abi.BVH), C.c_uint32, C.POINTER(abi.BVH), C.POINTER(C.c_uint32)]
@@ -127,6 +129,16 @@ def render(scene_view, camera, width, height, rng, accum=None, spp=1, max_depth=
     lib(libm).orc_render(C.byref(scene_view), C.byref(camera), env_c, width, height, rng.ctypes.data,
                          accum.ctypes.data, C.byref(prm), C.byref(stats), n_threads)
     return accum, stats
+
+
+def tonemap(accum):
+    """fragmentShader's exposure + ACES on an (H, W, 4) float32 accumulator -> ((H, W, 4) uint8 top-down, exposure)."""
+    assert accum.dtype == np.float32 and accum.ndim == 3 and accum.shape[2] == 4 and accum.flags.c_contiguous
+    H, W = accum.shape[:2]
+    out = np.empty((H, W, 4), dtype=np.uint8)
+    e = C.c_float(0)
+    lib().orc_tonemap(accum.ctypes.data, W, H, out.ctypes.data, C.byref(e))
+    return out, e.value
 
 
 _DENSITY_KEEPALIVE = []

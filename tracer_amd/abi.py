@@ -173,7 +173,7 @@ for _t, _n in _EXPECTED_SIZES.items():
 DEVICE_SYMBOLS = [
     "trc_abi_version", "trc_status_string", "trc_last_error", "trc_create", "trc_destroy",
     "trc_upload_scene", "trc_upload_density", "trc_upload_scene_lbvh", "trc_download_bvh", "trc_lbvh_info", "trc_set_camera", "trc_set_environment", "trc_resize", "trc_seed",
-    "trc_upload_rng", "trc_download_rng", "trc_upload_accum", "trc_download_accum", "trc_clear_accum",
+    "trc_upload_rng", "trc_download_rng", "trc_upload_accum", "trc_download_accum", "trc_clear_accum", "trc_tonemap",
     "trc_render", "trc_synchronize", "trc_trace_rays", "trc_get_stats", "trc_reset_stats", "trc_debug_profile",
     "trc_sppm_init", "trc_sppm_frames", "trc_sppm_download",
     "trc_device_info", "trc_group_unique_id", "trc_group_init", "trc_group_reduce_accum", "trc_group_finalize",
@@ -183,5 +183,5 @@ HOST_SYMBOLS = [
     "trc_host_prepare_camera", "trc_host_fill_rng", "trc_host_scene_create", "trc_host_scene_destroy",
     "trc_host_scene_view", "trc_host_mesh_load_obj", "trc_host_mesh_make_ball", "trc_host_mesh_replicate",
     "trc_host_mesh_view", "trc_host_mesh_destroy", "trc_host_make_density_info", "trc_host_make_cloud",
-    "trc_host_load_density_pbrt", "trc_host_free",
+    "trc_host_load_density_pbrt", "trc_host_free", "trc_host_write_png",
 ]

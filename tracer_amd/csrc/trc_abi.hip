@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -154,6 +155,46 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
             }
         }
     }
+}
+
+// ---- output stage (fragmentShader, Render.metal:29-75): exposure sums, then ACES to 8 bit
+__global__ void __launch_bounds__(256) k_tonemap_sum(const float4* accum, uint32_t n, unsigned long long* sums /* [3] */) {
+    unsigned long long s[3] = {0, 0, 0};
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const float4 px = accum[i];
+        const float c[3] = {px.x, px.y, px.z};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float v = c[k];
+            if (!(v > 0.0f)) v = 0.0f;
+            if (v > 1048576.0f) v = 1048576.0f;
+            s[k] += (unsigned long long)(v * 65536.0f + 0.5f);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_xor(s[k], off, 64);
+        if ((threadIdx.x & 63u) == 0) atomicAdd(&sums[k], s[k]);
+    }
+}
+__global__ void __launch_bounds__(256) k_tonemap(const float4* accum, uint32_t W, uint32_t H, float expose, uchar4* out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= W * H) return;
+    const uint32_t y = i / W, x = i - y * W;
+    const float4 px = accum[(size_t)(H - 1u - y) * W + x];
+    const float A = 2.51f, B = 0.03f, Cc = 2.43f, D = 0.59f, E = 0.14f;
+    const float c[3] = {px.x, px.y, px.z};
+    uint32_t o[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float col = c[k] * expose;
+        float t = (col * (A * col + B)) / (col * (Cc * col + D) + E);        // ACESTone, Render.hh:78-89
+        if (!(t > 0.0f)) t = 0.0f;
+        if (t > 1.0f) t = 1.0f;
+        o[k] = (uint32_t)(t * 255.0f + 0.5f);
+    }
+    out[i] = make_uchar4((unsigned char)o[0], (unsigned char)o[1], (unsigned char)o[2], 255);
 }
 
 // Scene::hit test hook: one lane per ray, full HitRecord + per-ray traversal counters
@@ -538,6 +579,40 @@ trc_status trc_clear_accum(trc_ctx* ctx) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_accum, 0, (size_t)ctx->width * ctx->height * 16, ctx->stream));
     return TRC_OK;
+}
+
+trc_status trc_tonemap(trc_ctx* ctx, uint8_t* rgba8, float* exposure_out) {
+    if (!ctx || !rgba8) return TRC_ERR_INVALID_ARG;
+    if (!ctx->d_accum) return fail(ctx, TRC_ERR_NO_FRAME, "trc_tonemap before trc_resize");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = ctx->width * ctx->height;
+    unsigned long long* d_sums = nullptr;
+    uchar4* d_out = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d_sums, 3 * sizeof(unsigned long long)));
+    if (hipMalloc((void**)&d_out, (size_t)n * 4) != hipSuccess) { (void)hipFree(d_sums); return fail(ctx, TRC_ERR_OOM, "hipMalloc tonemap"); }
+    trc_status st = TRC_OK;
+    do {
+        unsigned long long sums[3];
+        if (hipMemsetAsync(d_sums, 0, sizeof sums, ctx->stream) != hipSuccess) { st = fail(ctx, TRC_ERR_HIP, "tonemap memset"); break; }
+        hipLaunchKernelGGL(k_tonemap_sum, dim3(std::min<uint32_t>((n + 255) / 256, 2048u)), dim3(256), 0, ctx->stream,
+                           reinterpret_cast<const float4*>(ctx->d_accum), n, d_sums);
+        if (hipMemcpyAsync(sums, d_sums, sizeof sums, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) { st = fail(ctx, TRC_ERR_HIP, "tonemap sums"); break; }
+        // same binary32 / binary64 steps as oracle/oracle.cpp orc_tonemap (exp through trc_detmath.h)
+        float mean[3];
+        for (int c = 0; c < 3; ++c) mean[c] = (float)((double)sums[c] / 65536.0 / (double)n);
+        const float luma = (mean[0] * 0.2126f + mean[1] * 0.7152f) + mean[2] * 0.0722f;
+        float mapped = 1 - dm_expf(-1.0f * luma);
+        mapped = std::fmin(std::fmax(mapped, 0.0f), 0.9999f);
+        const float expose = 1.0f - mapped;
+        if (exposure_out) *exposure_out = expose;
+        hipLaunchKernelGGL(k_tonemap, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<const float4*>(ctx->d_accum),
+                           ctx->width, ctx->height, expose, d_out);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(rgba8, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) { st = fail(ctx, TRC_ERR_HIP, "tonemap kernel"); break; }
+    } while (0);
+    (void)hipFree(d_sums); (void)hipFree(d_out);
+    return st;
 }
 
 trc_status trc_render(trc_ctx* ctx, const trc_params* p) {

@@ -43,6 +43,7 @@ def lib():
         L.trc_destroy.argtypes = [vp]
         L.trc_destroy.restype = None
         L.trc_upload_scene.argtypes = [vp, C.POINTER(abi.Scene)]
+        L.trc_tonemap.argtypes = [vp, vp, C.POINTER(C.c_float)]
         L.trc_upload_density.argtypes = [vp, C.POINTER(abi.GridDensityInfo), vp]
         L.trc_upload_scene_lbvh.argtypes = [vp, C.POINTER(abi.Scene)]
         L.trc_download_bvh.argtypes = [vp, C.POINTER(abi.BVH), u32, C.POINTER(u32)]
@@ -118,6 +119,13 @@ class Tracer:
     # --- scene / camera / frame -------------------------------------------------
     def upload_scene(self, scene_view):
         self._check(self._L.trc_upload_scene(self._h, C.byref(scene_view)), "trc_upload_scene")
+
+    def tonemap(self):
+        """fragmentShader's auto-exposure + ACES on the accumulator -> ((H, W, 4) uint8, rows top-down; exposure)."""
+        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        e = C.c_float(0)
+        self._check(self._L.trc_tonemap(self._h, out.ctypes.data, C.byref(e)), "trc_tonemap")
+        return out, e.value
 
     def upload_density(self, info, density):
         """Density grid (nz, ny, nx) float32 of the GridDensity medium for integrator 2; None clears it."""

@@ -64,6 +64,8 @@ def lib():
         L.trc_host_load_density_pbrt.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                                  C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_float))]
         L.trc_host_free.argtypes = [C.c_void_p]
+        L.trc_host_write_png.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        L.trc_host_write_png.restype = C.c_int32
         L.trc_host_free.restype = None
         L.trc_host_mesh_destroy.restype = None
         _LIB = L
@@ -195,6 +197,12 @@ def load_density_pbrt(path):
         return np.ctypeslib.as_array(p, shape=(n,)).astype(np.float32).reshape(nz.value, ny.value, nx.value).copy()
     finally:
         lib().trc_host_free(p)
+
+
+def write_png(path, rgba8):
+    """(H, W, 4) uint8, rows top-down -> PNG file."""
+    assert rgba8.dtype == np.uint8 and rgba8.ndim == 3 and rgba8.shape[2] == 4 and rgba8.flags.c_contiguous
+    _check(lib().trc_host_write_png(os.fsencode(path), rgba8.ctypes.data, rgba8.shape[1], rgba8.shape[0]), "trc_host_write_png")
 
 
 def density_info(density, sigma_a=10.0, sigma_s=90.0, g=0.5):

@@ -419,4 +419,62 @@ trc_status trc_host_load_density_pbrt(const char* path, uint32_t* nx, uint32_t* 
 }
 void trc_host_free(void* p) { std::free(p); }
 
+// PNG with stored deflate blocks: signature, IHDR, one IDAT (zlib stream of filter-0 scanlines), IEND
+trc_status trc_host_write_png(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height) {
+    if (!path || !rgba8 || width == 0 || height == 0) return TRC_ERR_INVALID_ARG;
+    static uint32_t crc_table[256];
+    static bool crc_ready = false;
+    if (!crc_ready) {
+        for (uint32_t n = 0; n < 256; ++n) {
+            uint32_t c = n;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            crc_table[n] = c;
+        }
+        crc_ready = true;
+    }
+    auto be32 = [](std::vector<uint8_t>& v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); };
+    auto chunk = [&](std::vector<uint8_t>& file, const char type[4], const std::vector<uint8_t>& data) {
+        be32(file, (uint32_t)data.size());
+        const size_t start = file.size();
+        file.insert(file.end(), type, type + 4);
+        file.insert(file.end(), data.begin(), data.end());
+        uint32_t c = 0xFFFFFFFFu;
+        for (size_t i = start; i < file.size(); ++i) c = crc_table[(c ^ file[i]) & 0xFFu] ^ (c >> 8);
+        be32(file, c ^ 0xFFFFFFFFu);
+    };
+    // raw scanlines with filter byte 0
+    const size_t stride = (size_t)width * 4;
+    std::vector<uint8_t> raw;
+    raw.reserve((stride + 1) * height);
+    for (uint32_t y = 0; y < height; ++y) {
+        raw.push_back(0);
+        raw.insert(raw.end(), rgba8 + y * stride, rgba8 + (y + 1) * stride);
+    }
+    std::vector<uint8_t> z;
+    z.reserve(raw.size() + raw.size() / 65535 * 5 + 16);
+    z.push_back(0x78); z.push_back(0x01);
+    uint32_t a = 1, b = 0;                                   // adler32
+    for (size_t pos = 0; pos < raw.size();) {
+        const size_t len = std::min<size_t>(65535, raw.size() - pos);
+        z.push_back(pos + len == raw.size() ? 1 : 0);
+        z.push_back(len & 0xFF); z.push_back(len >> 8); z.push_back(~len & 0xFF); z.push_back((~len >> 8) & 0xFF);
+        z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + len);
+        for (size_t i = pos; i < pos + len; ++i) { a = (a + raw[i]) % 65521u; b = (b + a) % 65521u; }
+        pos += len;
+    }
+    be32(z, (b << 16) | a);
+    std::vector<uint8_t> file = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    std::vector<uint8_t> ihdr;
+    be32(ihdr, width); be32(ihdr, height);
+    ihdr.push_back(8); ihdr.push_back(6); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);   // 8-bit RGBA
+    chunk(file, "IHDR", ihdr);
+    chunk(file, "IDAT", z);
+    chunk(file, "IEND", {});
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return TRC_ERR_INVALID_ARG;
+    const bool ok = std::fwrite(file.data(), 1, file.size(), f) == file.size();
+    std::fclose(f);
+    return ok ? TRC_OK : TRC_ERR_INVALID_ARG;
+}
+
 }  // extern "C"
