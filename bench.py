@@ -4,10 +4,17 @@
 Workload (BASELINE.json configs[1]): RT_Metal Cornell box + the 12 spheres, 1920x1080, 64 spp,
 tracePath, depth 8, synthetic (scene from the reference's constants, per-pixel PCG32 seeds).
 
-A "step" = one full frame of that workload: re-seed the RNG texture (so every step is the SAME
-work), render all 64 samples of this rank's pixel tiles, and -- for N > 1 -- compose the frame
-with one RCCL reduce of the accumulation buffer to rank 0.  Inputs are resident in HBM before the
-timed region.  `rays` = Scene::hit invocations, counted exactly by the kernel.
+A "step" = one pass of the hot path over one batch: re-seed the RNG texture (so every step is the SAME
+work), render all 64 samples of this rank's pixel tiles, and -- for N > 1 -- compose the frame with one
+RCCL reduce of the accumulation buffer to rank 0.  Inputs are resident in HBM before the timed region.
+`rays` = Scene::hit invocations, counted exactly by the kernel.
+
+N = 1: one 1920x1080 view.  N > 1 (weak scaling, the unit that shards is the 16x16 pixel tile): the batch
+is N such views stacked into one 1920 x (1080 N) frame (trc_params.view_height = 1080: every view has the
+same camera and its own RNG texels), tiles owned round-robin (tx + ty) % N, so every rank renders one
+view's worth of tiles drawn evenly from all views -- the per-GPU work of the N = 1 run -- and the composed
+N-view frame ends up on rank 0.  (Strong scaling of a single 1080p x 64 spp frame is latency-bound: a pixel's
+64 samples are a sequential RNG chain)
 
   python bench.py [--gpus N --steps K --warmup W]           (N = 1)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
@@ -142,7 +149,8 @@ def main():
     trc.upload_scene(scene.view)
     trc.set_camera(cam)
     trc.set_environment((0.0, 0.0, 0.0))
-    trc.resize(W, H)
+    FH = H * world                      # N stacked views
+    trc.resize(W, FH)
     if grouped:
         ids = [group_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
@@ -167,7 +175,7 @@ def main():
             trc.clear_accum()            # non-owned tiles must be zero for the sum-compose
         trc.seed(SEED)
         trc.render(spp=SPP, max_depth=DEPTH, integrator=abi.INTEGRATOR_PATH, frame0=0, tile_rank=rank,
-                   tile_nranks=world, collect_stats=collect_stats)
+                   tile_nranks=world, collect_stats=collect_stats, view_height=H)
         if grouped:
             trc.group_reduce_accum(0)
 
@@ -210,13 +218,15 @@ def main():
             "metric": "Mrays/s at 1920x1080x64spp", "value": round(rays_total / dt_max / 1e6, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "RT_Metal Cornell box + 12 spheres (BASELINE config 2), 1920x1080x64spp, "
-                                   "tracePath depth 8, 21 leaves / 41 BVH nodes",
+                                   "tracePath depth 8, 21 leaves / 41 BVH nodes" +
+                                   (f"; {world} such views stacked into one 1920x{FH} frame, one view's worth of "
+                                    f"tiles per GPU" if world > 1 else ""),
                        "integrator": "tracePath", "rays_per_step": int(rays_total / args.steps),
-                       "paths_per_step": W * H * SPP, "mpaths_per_s": round(W * H * SPP * args.steps / dt_max / 1e6, 2),
+                       "paths_per_step": W * FH * SPP, "mpaths_per_s": round(W * FH * SPP * args.steps / dt_max / 1e6, 2),
                        "tiles": f"16x16 px, owner (tx+ty)%{world}", "device": info["name"],
-                       "compose": "ncclReduce(sum) of the RGBA32F frame to rank 0" if grouped else "none"},
+                       "compose": f"ncclReduce(sum) of the {W}x{FH} RGBA32F frame to rank 0" if grouped else "none"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(world),
                          "kernel": "k_render", "kernel_ms": round(kernel_ms, 3),

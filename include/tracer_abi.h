@@ -255,7 +255,10 @@ typedef struct trc_params {
     uint32_t tile_rank;          /* this call renders tiles t with trc_tile_owner(t) == tile_rank ... */
     uint32_t tile_nranks;        /* ... of tile_nranks (1 => whole frame) */
     uint32_t flags;
-    uint32_t _reserved;
+    uint32_t view_height;        /* 0: the frame is one view.  Otherwise the frame is a vertical stack of views of
+                                    this many rows: pixel (x, y) sees the camera ray of (x, y % view_height) of a
+                                    W x view_height image -- a batch of views rendered as one frame (each pixel of
+                                    the stack has its own RNG texel); bench.py's multi-GPU workload */
 } trc_params;
 
 /* Pixel tiles: TRC_TILE x TRC_TILE pixels, row-major tile grid, owner of

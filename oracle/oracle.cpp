@@ -1370,7 +1370,8 @@ void render_pixel(const trc_scene& prims, const trc_Camera* camera, const Env& e
         pcg32_t rng = {rng_inc, rng_state};     // aggregate order {state, inc}: the words trade roles (B-1)
         uint32_t frame = prm.frame0 + s;
         float u = (float)x / (float)W;          // no sub-pixel jitter (B-2)
-        float v = (float)y / (float)H;
+        const uint32_t vh = (prm.view_height != 0 && prm.view_height < H) ? prm.view_height : H;   // stacked views
+        float v = (float)(y % vh) / (float)vh;
         RandomSampler rs{&rng};
         Ray ray = castRay(camera, u, v, &rs);
         V3 color = (prm.integrator == TRC_INTEGRATOR_VOLUME) ? traceVolume((int)prm.max_depth, ray, rs, env, scene, cnt)

@@ -116,14 +116,14 @@ def trace_rays(scene_view, rays, any_hit=False, brute=False, libm=False):
 
 
 def render(scene_view, camera, width, height, rng, accum=None, spp=1, max_depth=8, integrator=0, frame0=0,
-           env=(0.0, 0.0, 0.0), tile_rank=0, tile_nranks=1, n_threads=0, libm=False):
+           env=(0.0, 0.0, 0.0), tile_rank=0, tile_nranks=1, n_threads=0, libm=False, view_height=0):
     """kernelPathTracing on the CPU.  rng: (H,W,4) uint32, updated in place.  Returns (accum, stats)."""
     assert rng.dtype == np.uint32 and rng.shape == (height, width, 4) and rng.flags.c_contiguous
     if accum is None:
         accum = np.zeros((height, width, 4), dtype=np.float32)
     assert accum.dtype == np.float32 and accum.shape == (height, width, 4) and accum.flags.c_contiguous
     prm = abi.Params(spp=spp, max_depth=max_depth, integrator=integrator, frame0=frame0,
-                     tile_rank=tile_rank, tile_nranks=tile_nranks, flags=abi.FLAG_COLLECT_STATS)
+                     tile_rank=tile_rank, tile_nranks=tile_nranks, flags=abi.FLAG_COLLECT_STATS, view_height=view_height)
     stats = abi.Stats()
     env_c = (C.c_float * 3)(*env)
     lib(libm).orc_render(C.byref(scene_view), C.byref(camera), env_c, width, height, rng.ctypes.data,

@@ -264,3 +264,27 @@ def test_rccl_group_single_rank_roundtrip(gpu, cornell_spheres):
     after = gpu.download_accum()
     gpu.group_finalize()
     assert np.array_equal(before.view(np.uint32), after.view(np.uint32))
+
+
+def test_stacked_views_sharded_over_ranks(gpu, cornell_spheres):
+    """bench.py's N-GPU workload in miniature: 3 views stacked into one frame (trc_params.view_height), tiles of ranks
+    0..2 rendered one after the other and sum-composed == the oracle's render of the whole stack"""
+    W, h, k = 80, 56, 3
+    cam = host.prepare_camera(W, h)
+    gpu.upload_scene(cornell_spheres.view); gpu.set_camera(cam); gpu.set_environment((0.0, 0.0, 0.0)); gpu.resize(W, h * k)
+    rng = host.fill_rng(31, W, h * k)
+    composed = np.zeros((h * k, W, 4), np.float32)
+    rays = 0
+    for r in range(k):
+        gpu.upload_rng(rng); gpu.clear_accum(); gpu.reset_stats()
+        gpu.render(spp=4, tile_rank=r, tile_nranks=k, view_height=h)
+        composed += gpu.download_accum()                    # non-owned tiles are zero: sum == gather
+        rays += gpu.stats().rays
+    ref_rng = rng.copy()
+    ref, st = po.render(cornell_spheres.view, cam, W, h * k, ref_rng, spp=4, view_height=h)
+    assert np.array_equal(composed.view(np.uint32), ref.view(np.uint32)) and rays == st.rays
+    # every view is the single-view render of its RNG slice
+    gpu.resize(W, h)
+    for i in range(k):
+        gpu.upload_rng(np.ascontiguousarray(rng[i * h:(i + 1) * h])); gpu.clear_accum(); gpu.render(spp=4)
+        assert np.array_equal(gpu.download_accum().view(np.uint32), ref[i * h:(i + 1) * h].view(np.uint32))

@@ -110,3 +110,26 @@ def test_path_and_mis_integrators_see_the_same_scene():
     assert m[..., :3].mean() > 0 and p[..., :3].mean() > 0
     # NEE removes the fireflies of pure BSDF sampling: far fewer black pixels
     assert (m[..., :3].sum(axis=2) == 0).mean() < (p[..., :3].sum(axis=2) == 0).mean()
+
+
+def test_stacked_views_are_independent_frames(cornell_spheres):
+    """trc_params.view_height: a frame that stacks k views of h rows equals k separate renders of a W x h frame, each
+    with its slice of the RNG texture (the multi-GPU workload of bench.py)."""
+    W, h, k = 40, 24, 3
+    cam = host.prepare_camera(W, h)
+    rng = host.fill_rng(1234, W, h * k)
+    want_rng = rng.copy()
+    stacked, st = po.render(cornell_spheres.view, cam, W, h * k, rng, spp=3, view_height=h)
+    parts, rays = [], 0
+    for i in range(k):
+        r = np.ascontiguousarray(want_rng[i * h:(i + 1) * h])
+        a, s = po.render(cornell_spheres.view, cam, W, h, r, spp=3)
+        want_rng[i * h:(i + 1) * h] = r
+        parts.append(a); rays += s.rays
+    assert np.array_equal(stacked.view(np.uint32), np.concatenate(parts).view(np.uint32))
+    assert np.array_equal(rng, want_rng) and st.rays == rays
+    # the views differ from each other (different RNG texels), and view_height >= H means one view
+    assert not np.array_equal(parts[0], parts[1])
+    one, _ = po.render(cornell_spheres.view, cam, W, h, host.fill_rng(5, W, h), spp=2, view_height=h)
+    two, _ = po.render(cornell_spheres.view, cam, W, h, host.fill_rng(5, W, h), spp=2)
+    assert np.array_equal(one.view(np.uint32), two.view(np.uint32))

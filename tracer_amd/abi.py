@@ -137,7 +137,7 @@ class GridDensityInfo(C.Structure):
 class Params(C.Structure):
     _fields_ = [("spp", C.c_uint32), ("max_depth", C.c_uint32), ("integrator", C.c_uint32),
                 ("frame0", C.c_uint32), ("tile_rank", C.c_uint32), ("tile_nranks", C.c_uint32),
-                ("flags", C.c_uint32), ("_reserved", C.c_uint32)]
+                ("flags", C.c_uint32), ("view_height", C.c_uint32)]
 
 
 class Ray(C.Structure):

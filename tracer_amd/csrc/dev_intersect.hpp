@@ -26,7 +26,7 @@
 
 namespace trcdev {
 
-constexpr int kBlock = 256;   // threads per workgroup = one 16x16 pixel tile = 4 wavefronts of 8x8
+constexpr int kBlock = 64;    // threads per workgroup = ONE wavefront = one 8x8 pixel block (a quarter of a 16x16 tile)
 
 struct Ray {
     F3 o, d, inv;     // inv = 1.0 / direction, computed once per ray (AABB.hh:75,94 recompute it per box)

@@ -26,7 +26,8 @@ struct KRender {
     DCamera cam;
     float ambient[3];
     DFrame fr;
-    uint32_t spp, max_depth, frame0, _pad;
+    uint32_t spp, max_depth, frame0;
+    uint32_t view_height;               // rows per view of a stacked frame (= frame height for a single view)
     const uint32_t* tiles;              // tx | ty << 16, one per workgroup
     const float* density;               // traceVolume: GridDensity medium grid (null when absent)
     trc_GridDensityInfo dinfo;

@@ -65,7 +65,8 @@ inline trc_status layout_scene(trc_ctx* ctx, const trc_scene* s, uint32_t n_inte
 // `prefix_ok`: the first fat nodes are the top of the tree (BFS order); otherwise all or nothing.
 inline void plan_lds(DScene& sc, uint32_t max_leaf_depth, bool prefix_ok) {
     const uint32_t stack_dwords = std::max(1u, max_leaf_depth) * kBlock;
-    uint32_t budget_dwords = (38u * 1024u / 4u > stack_dwords) ? 38u * 1024u / 4u - stack_dwords : 0u;
+    const uint32_t per_block = 38u * 1024u / 4u * kBlock / 256u;      // 16 one-wavefront workgroups per CU
+    uint32_t budget_dwords = (per_block > stack_dwords) ? per_block - stack_dwords : 0u;
     budget_dwords = std::min(budget_dwords, kLdsSceneBytes / 4);
     if (const char* e = std::getenv("TRC_LDS_BUDGET_KB")) {          // tuning knob: staged bytes vs occupancy
         const long kb = std::atol(e);

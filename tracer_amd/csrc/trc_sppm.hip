@@ -125,9 +125,9 @@ __global__ void __launch_bounds__(kBlock) k_sppm_camera(const KSppm kp) {
     const uint32_t* small_base = stage_scene(kp.ks.sc);
     const SppmCtx cx = make_sppm_ctx(kp, small_base);
     const uint32_t tile = kp.tiles[blockIdx.x];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t px = (tile & 0xFFFFu) * TRC_TILE + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t py = (tile >> 16) * TRC_TILE + (wave >> 1) * 8u + (lane >> 3);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t px = (tile & 0xFFFFu) * 8u + (lane & 7u);
+    const uint32_t py = (tile >> 16) * 8u + (lane >> 3);
     uint32_t n_rays = 0;
     if (px < kp.W && py < kp.H) {
     const size_t pix = (size_t)py * kp.W + px;
@@ -324,9 +324,9 @@ __global__ void __launch_bounds__(256) k_sppm_sum(const uint32_t* count, DComple
 __global__ void __launch_bounds__(256) k_sppm_refine(const KSppm kp) {
     // one workgroup per 16x16 tile of this rank (same tile list as the camera pass)
     const uint32_t tile = kp.tiles[blockIdx.x];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t qx = (tile & 0xFFFFu) * TRC_TILE + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t qy = (tile >> 16) * TRC_TILE + (wave >> 1) * 8u + (lane >> 3);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t qx = (tile & 0xFFFFu) * 8u + (lane & 7u);
+    const uint32_t qy = (tile >> 16) * 8u + (lane >> 3);
     if (qx >= kp.W || qy >= kp.H) return;
     const uint32_t i = qy * kp.W + qx;
     trc_CameraRecord& c = kp.cam_rec[i];
