@@ -177,7 +177,7 @@ def main():
         trc.render(spp=SPP, max_depth=DEPTH, integrator=abi.INTEGRATOR_PATH, frame0=0, tile_rank=rank,
                    tile_nranks=world, collect_stats=collect_stats, view_height=H)
         if grouped:
-            trc.group_reduce_accum(0)
+            trc.group_reduce_accum_async(0)   # overlaps with the next step's render (second accumulator + stream)
 
     # exact algorithmic work of ONE step on this rank (instrumented kernel, untimed)
     trc.reset_stats()
@@ -226,7 +226,7 @@ def main():
                        "integrator": "tracePath", "rays_per_step": int(rays_total / args.steps),
                        "paths_per_step": W * FH * SPP, "mpaths_per_s": round(W * FH * SPP * args.steps / dt_max / 1e6, 2),
                        "tiles": f"16x16 px, owner (tx+ty)%{world}", "device": info["name"],
-                       "compose": f"ncclReduce(sum) of the {W}x{FH} RGBA32F frame to rank 0" if grouped else "none"},
+                       "compose": f"ncclReduce(sum) of the {W}x{FH} RGBA32F frame to rank 0 on a second stream, overlapped with the next step" if grouped else "none"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(world),
                          "kernel": "k_render", "kernel_ms": round(kernel_ms, 3),

@@ -414,6 +414,12 @@ trc_status trc_group_init(trc_ctx* ctx, const uint8_t id[TRC_UNIQUE_ID_BYTES], i
 /* ncclReduce(sum) of the full-frame accum buffer to `root` on the ctx stream:
  * every rank holds zeros outside its own tiles, so sum == gather */
 trc_status trc_group_reduce_accum(trc_ctx* ctx, int root);
+/* same compose, pipelined: the reduce runs on a second stream as soon as the work queued so far has finished,
+ * and the context switches to its OTHER accumulator (allocated on first use, zero-filled), so the next
+ * trc_clear_accum / trc_render overlap with the collective.  The composed frame of the call is read with
+ * trc_download_composed (root only); trc_synchronize waits for the collectives too. */
+trc_status trc_group_reduce_accum_async(trc_ctx* ctx, int root);
+trc_status trc_download_composed(trc_ctx* ctx, float* rgba /* 4*W*H */);
 trc_status trc_group_finalize(trc_ctx* ctx);
 
 /* ------------------------------------------------------------------ */

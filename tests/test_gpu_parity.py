@@ -262,8 +262,27 @@ def test_rccl_group_single_rank_roundtrip(gpu, cornell_spheres):
     gpu.group_reduce_accum(0)
     gpu.synchronize()
     after = gpu.download_accum()
-    gpu.group_finalize()
     assert np.array_equal(before.view(np.uint32), after.view(np.uint32))
+    # pipelined compose: three different frames in flight over the two accumulators; every composed frame must be
+    # the frame rendered in its step, and the context keeps rendering into the other buffer meanwhile
+    frames = []
+    for seed in (11, 12, 13):
+        gpu.clear_accum(); gpu.seed(seed); gpu.render(spp=2)
+        gpu.group_reduce_accum_async(0)
+        frames.append(gpu.download_composed())
+    gpu.synchronize()
+    for seed, got in zip((11, 12, 13), frames):
+        gpu.clear_accum(); gpu.seed(seed); gpu.render(spp=2)
+        assert np.array_equal(gpu.download_accum().view(np.uint32), got.view(np.uint32)), seed
+    # back-to-back without reading in between: the last composed frame is the last rendered one
+    for seed in (21, 22, 23, 24):
+        gpu.clear_accum(); gpu.seed(seed); gpu.render(spp=1)
+        gpu.group_reduce_accum_async(0)
+    gpu.synchronize()
+    last = gpu.download_composed()
+    gpu.clear_accum(); gpu.seed(24); gpu.render(spp=1)
+    assert np.array_equal(gpu.download_accum().view(np.uint32), last.view(np.uint32))
+    gpu.group_finalize()
 
 
 def test_stacked_views_sharded_over_ranks(gpu, cornell_spheres):

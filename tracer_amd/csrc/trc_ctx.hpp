@@ -114,6 +114,13 @@ struct trc_ctx {
     void* comm = nullptr;
     int nranks = 1, rank = 0;
     float* d_reduce_recv = nullptr;
+    // pipelined compose (trc_group_reduce_accum_async): second accumulator, communication stream, and per-buffer
+    // "reduce finished" events (ev_busy belongs to d_accum, ev_busy_alt to d_accum_alt; they swap with the buffers)
+    float* d_accum_alt = nullptr;
+    float* d_composed = nullptr;        // buffer holding the most recently composed frame (one of the two)
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_rendered = nullptr, ev_busy = nullptr, ev_busy_alt = nullptr;
+    bool busy = false, busy_alt = false;
 
     SppmState* sppm = nullptr;       // trc_sppm.hip
 };

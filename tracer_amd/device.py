@@ -68,6 +68,8 @@ def lib():
         L.trc_group_unique_id.argtypes = [C.POINTER(C.c_uint8)]
         L.trc_group_init.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int, C.c_int]
         L.trc_group_reduce_accum.argtypes = [vp, C.c_int]
+        L.trc_group_reduce_accum_async.argtypes = [vp, C.c_int]
+        L.trc_download_composed.argtypes = [vp, vp]
         L.trc_group_finalize.argtypes = [vp]
         for name in abi.DEVICE_SYMBOLS:
             f = getattr(L, name)
@@ -259,6 +261,15 @@ class Tracer:
 
     def group_reduce_accum(self, root=0):
         self._check(self._L.trc_group_reduce_accum(self._h, root), "trc_group_reduce_accum")
+
+    def group_reduce_accum_async(self, root=0):
+        """Compose on a second stream and switch to the other accumulator (see trc_group_reduce_accum_async)."""
+        self._check(self._L.trc_group_reduce_accum_async(self._h, root), "trc_group_reduce_accum_async")
+
+    def download_composed(self):
+        out = np.empty((self.height, self.width, 4), dtype=np.float32)
+        self._check(self._L.trc_download_composed(self._h, out.ctypes.data), "trc_download_composed")
+        return out
 
     def group_finalize(self):
         self._check(self._L.trc_group_finalize(self._h), "trc_group_finalize")
