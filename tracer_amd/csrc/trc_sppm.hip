@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(256) k_sppm_sum(const uint32_t* count, DComple
 }
 
 // kernelPhotonRefine, Photon.metal:498-623
-__global__ void __launch_bounds__(256) k_sppm_refine(const KSppm kp) {
+__global__ void __launch_bounds__(kBlock) k_sppm_refine(const KSppm kp) {
     // one workgroup per 16x16 tile of this rank (same tile list as the camera pass)
     const uint32_t tile = kp.tiles[blockIdx.x];
     const uint32_t lane = threadIdx.x & 63u;
@@ -535,7 +535,7 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
         HIP_TRY(ctx, hipMemsetAsync(s->d_count, 0, (size_t)nph * 4, ctx->stream));
         hipLaunchKernelGGL(k_sppm_hash, dim3(nph / 256), dim3(256), 0, ctx->stream, s->d_pho, s->d_mark, s->d_count, s->d_cx);
         hipLaunchKernelGGL(k_sppm_sum, dim3(nph / 256), dim3(256), 0, ctx->stream, s->d_count, s->d_cx);
-        hipLaunchKernelGGL(k_sppm_refine, dim3(ctx->n_tiles), dim3(256), 0, ctx->stream, kp);
+        hipLaunchKernelGGL(k_sppm_refine, dim3(ctx->n_tiles), dim3(kBlock), 0, ctx->stream, kp);
         hipLaunchKernelGGL(k_sppm_end_frame, dim3(1), dim3(64), 0, ctx->stream, s->d_cx);
         HIP_TRY(ctx, hipGetLastError());
         s->frame_count += 1;
