@@ -348,6 +348,10 @@ trc_status trc_set_environment(trc_ctx* ctx, const float rgb[3]);
 
 /* (re)allocates accum A (RGBA32F) + RNG (RGBA32Uint) for a W x H frame and
  * zeroes them; replaces texture creation, AAPLRenderer.mm:260-288 */
+/* texHDR (Render.hh:25; the reference's HDR blob is missing from its repository): equirectangular RGB float image,
+ * 3*w*h floats, row 0 at v = 0.  A ray that leaves the scene returns SampleSphericalMap (Render.hh:42-48) + a bilinear,
+ * clamp-to-edge lookup (Common.hh:11) instead of the constant of trc_set_environment; rgb == NULL clears the map. */
+trc_status trc_set_environment_map(trc_ctx* ctx, uint32_t w, uint32_t h, const float* rgb);
 trc_status trc_resize(trc_ctx* ctx, uint32_t width, uint32_t height);
 /* deterministic stand-in for fillRNG (AAPLRenderer.mm:296-344, arc4random):
  * texel(x,y) = 4 successive pcg32 outputs of pcg32_srandom_r(seed, y*W+x),

@@ -1011,7 +1011,30 @@ inline Ray castRay(const trc_Camera* camera, float s, float t, RandomSampler* xs
 }
 
 // ---------------------------------------------------------------- integrators
-struct Env { const trc_Material* materials; V3 ambient; const trc_GridDensityInfo* densityInfo = nullptr; const float* densityArray = nullptr; };
+struct Env {
+    const trc_Material* materials; V3 ambient;
+    const trc_GridDensityInfo* densityInfo = nullptr; const float* densityArray = nullptr;
+    const float* envmap = nullptr; uint32_t env_w = 0, env_h = 0;      // equirectangular RGB float image (texHDR)
+};
+// Render.hh:42-48 + `texHDR.sample(textureSampler, uv)` (Render.metal:100-105,301-304,435-438, Photon.metal:29-33):
+// linear filter, clamp-to-edge (Common.hh:11).  Metal's filtering weights are implementation-defined; this is the
+// textbook bilinear lookup at texel centres, evaluated with Lerp's operation order.  Without a map: env.ambient.
+inline V3 env_radiance(const Env& env, const V3& direction) {
+    if (!env.envmap) return env.ambient;
+    const V3 v = normalize(direction);
+    float u = m_atan2(v.z, v.x) * 0.1591f + 0.5f;
+    float w = m_asin(v.y) * 0.3183f + 0.5f;
+    const float x = u * (float)env.env_w - 0.5f, y = w * (float)env.env_h - 0.5f;
+    const float fx0 = floorf(x), fy0 = floorf(y);
+    const float fx = x - fx0, fy = y - fy0;
+    auto clampi = [](float f, uint32_t n) { return f < 0.0f ? 0u : (f > (float)(n - 1) ? n - 1 : (uint32_t)f); };
+    const uint32_t x0 = clampi(fx0, env.env_w), x1 = clampi(fx0 + 1.0f, env.env_w);
+    const uint32_t y0 = clampi(fy0, env.env_h), y1 = clampi(fy0 + 1.0f, env.env_h);
+    auto texel = [&](uint32_t xx, uint32_t yy) { const float* t = env.envmap + 3 * ((size_t)yy * env.env_w + xx); return v3(t[0], t[1], t[2]); };
+    const V3 top = (1 - fx) * texel(x0, y0) + fx * texel(x1, y0);
+    const V3 bot = (1 - fx) * texel(x0, y1) + fx * texel(x1, y1);
+    return (1 - fy) * top + fy * bot;
+}
 
 // Render.metal:411-492
 V3 tracePath(int depth, Ray& ray, RandomSampler& xsampler, const Env& env, Scene& scene, Counters* cnt) {
@@ -1020,7 +1043,7 @@ V3 tracePath(int depth, Ray& ray, RandomSampler& xsampler, const Env& env, Scene
     V3 color = v3(0.0f);
     bool hitted = scene.hit(ray, hitRecord, FLT_MAX);
     do {
-        if (!hitted) { color = color + ratio * env.ambient; break; }
+        if (!hitted) { color = color + ratio * env_radiance(env, ray.direction); break; }
         const trc_Material& mat = env.materials[hitRecord.material];
         if (mat.type == TRC_MAT_DIFFUSE) {
             V3 le = v3(mat.textureInfo.albedo);
@@ -1067,7 +1090,7 @@ V3 traceMIS(int depth, Ray& ray, RandomSampler& xsampler, const Env& env, Scene&
     const trc_scene& prims = scene.prims;
     bool hitted = scene.hit(ray, hitRecord, FLT_MAX);
     do {
-        if (!hitted) { color = color + ratio * env.ambient; break; }
+        if (!hitted) { color = color + ratio * env_radiance(env, ray.direction); break; }
         const trc_Material& mat = env.materials[hitRecord.material];
         if (mat.type == TRC_MAT_DIFFUSE) {
             V3 le = v3(mat.textureInfo.albedo);
@@ -1247,7 +1270,7 @@ V3 traceVolume(int depth, Ray& ray, RandomSampler& xsampler, const Env& env, Sce
     const trc_scene& prims = scene.prims;
     bool hitted = scene.hit(ray, hitRecord, FLT_MAX);
     do {
-        if (!hitted) { color = color + ratio * env.ambient; break; }          // texHDR lookup -> constant (HDR missing)
+        if (!hitted) { color = color + ratio * env_radiance(env, ray.direction); break; }
         if (env.materials[hitRecord.material].type == TRC_MAT_DIFFUSE) {
             V3 le = v3(env.materials[hitRecord.material].textureInfo.albedo);
             float w = dot(-ray.direction, -hitRecord.gn);
@@ -1352,6 +1375,8 @@ V3 traceVolume(int depth, Ray& ray, RandomSampler& xsampler, const Env& env, Sce
 }
 
 // density grid of the GridDensity medium for orc_render (the oracle keeps one, like PackageEnv ids 3/4)
+static const float* g_envmap = nullptr;
+static uint32_t g_env_w = 0, g_env_h = 0;
 static const trc_GridDensityInfo* g_density_info = nullptr;
 static const float* g_density_array = nullptr;
 static trc_GridDensityInfo g_density_info_copy;
@@ -1444,7 +1469,7 @@ bool traceCameraRecord(int depth, Ray& ray, RandomSampler& xsampler, CamRec& cr,
     V3 ratio = v3(1.0f);
     bool hitted = scene.hit(ray, hitRecord, FLT_MAX);
     do {
-        if (!hitted) { cr.alternative = ratio * env.ambient; return false; }
+        if (!hitted) { cr.alternative = ratio * env_radiance(env, ray.direction); return false; }
         const trc_Material& material = env.materials[hitRecord.material];
         if (material.type == TRC_MAT_DIFFUSE) {
             V3 le = v3(material.textureInfo.albedo);
@@ -1790,6 +1815,10 @@ void orc_tonemap(const float* accum, uint32_t W, uint32_t H, uint8_t* rgba8, flo
         }
 }
 
+void orc_set_environment_map(uint32_t w, uint32_t h, const float* rgb) {
+    if (rgb && w && h) { g_envmap = rgb; g_env_w = w; g_env_h = h; } else { g_envmap = nullptr; g_env_w = g_env_h = 0; }
+}
+
 void orc_set_density(const trc_GridDensityInfo* info, const float* density) {
     if (info && density) { g_density_info_copy = *info; g_density_info = &g_density_info_copy; g_density_array = density; }
     else { g_density_info = nullptr; g_density_array = nullptr; }
@@ -1799,6 +1828,7 @@ void orc_render(const trc_scene* scene, const trc_Camera* camera, const float en
                 uint32_t* rng_rgba, float* accum_rgba, const trc_params* params, trc_stats* stats, int n_threads) {
     Env env{scene->materials, v3(env_rgb[0], env_rgb[1], env_rgb[2])};
     env.densityInfo = g_density_info; env.densityArray = g_density_array;
+    env.envmap = g_envmap; env.env_w = g_env_w; env.env_h = g_env_h;
     const uint32_t nranks = params->tile_nranks ? params->tile_nranks : 1;
     unsigned T = n_threads > 0 ? (unsigned)n_threads : std::max(1u, std::thread::hardware_concurrency());
     T = std::min<unsigned>(T, H ? H : 1);
@@ -1914,6 +1944,7 @@ void orc_sppm_frames(orc_sppm* s, const trc_scene* scene, const trc_Camera* came
                      uint32_t* canvas_rng, float* accum, uint32_t n_frames) {
     SppmState& st = s->st;
     Env env{scene->materials, v3(env_rgb[0], env_rgb[1], env_rgb[2])};
+    env.envmap = g_envmap; env.env_w = g_env_w; env.env_h = g_env_h;
     for (uint32_t f = 0; f < n_frames; ++f) {
         if (st.frame_count == 0) {              // photonPrepare (view != nil)
             sppm_camera_pass(st, *scene, camera, env, canvas_rng);

@@ -48,6 +48,9 @@ void orc_render(const trc_scene* scene, const trc_Camera* camera, const float en
 /* density grid consulted by TRC_INTEGRATOR_VOLUME (traceVolume, Render.metal:78-275; GridDensityMedium, Medium.hh:111-199);
  * `density` is borrowed and must outlive the renders; NULL clears it */
 void orc_set_density(const trc_GridDensityInfo* info, const float* density);
+/* equirectangular RGB float environment (texHDR, Render.hh:25,42-48) for orc_render / orc_sppm_frames: a miss returns
+ * its bilinear lookup instead of the constant env_rgb; `rgb` (3*w*h floats, row 0 at v = 0) is borrowed; NULL clears */
+void orc_set_environment_map(uint32_t w, uint32_t h, const float* rgb);
 
 /* material entry points (Material.hh:77-146) in the local shading frame */
 void  orc_material_S_F(const trc_Material* m, const float wo[3], const float uv[2], const float uu[2],

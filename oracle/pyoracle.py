@@ -77,6 +77,8 @@ def lib(libm=False):
         L.orc_photon_hash.restype = C.c_float
         L.orc_tonemap.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_float)]
         L.orc_tonemap.restype = None
+        L.orc_set_environment_map.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_set_environment_map.restype = None
         L.orc_set_density.argtypes = [C.POINTER(abi.GridDensityInfo), C.c_void_p]
         L.orc_set_density.restype = None
         L.orc_lbvh_build.argtypes = [C.POINTER(abi.BVH), C.c_uint32, C.POINTER(abi.BVH), C.POINTER(C.c_uint32)]
@@ -139,6 +141,22 @@ def tonemap(accum):
     e = C.c_float(0)
     lib().orc_tonemap(accum.ctypes.data, W, H, out.ctypes.data, C.byref(e))
     return out, e.value
+
+
+_ENVMAP_KEEPALIVE = []
+
+
+def set_environment_map(rgb):
+    """(h, w, 3) float32 equirectangular environment, or None for the constant one."""
+    _ENVMAP_KEEPALIVE.clear()
+    for libm in (False, True):
+        if rgb is None:
+            lib(libm).orc_set_environment_map(0, 0, None)
+        else:
+            assert rgb.dtype == np.float32 and rgb.ndim == 3 and rgb.shape[2] == 3 and rgb.flags.c_contiguous
+            lib(libm).orc_set_environment_map(rgb.shape[1], rgb.shape[0], rgb.ctypes.data)
+    if rgb is not None:
+        _ENVMAP_KEEPALIVE.append(rgb)
 
 
 _DENSITY_KEEPALIVE = []

@@ -62,11 +62,31 @@ TRC_DEV Ray cast_ray(const DCamera& cam, float s, float t, Pcg& rng) {
     return make_ray(origin, sample - origin);
 }
 
+// texHDR (Render.hh:25,42-48) as an equirectangular RGB float image; null -> constant radiance `ambient`
+struct EnvMap { const float* rgb; uint32_t w, h; };
+TRC_DEV F3 env_radiance(const EnvMap& em, F3 ambient, F3 direction) {
+    if (!em.rgb) return ambient;
+    const F3 v = normalize(direction);
+    const float u = dm_atan2f(v.z, v.x) * 0.1591f + 0.5f;        // SampleSphericalMap
+    const float w = dm_asinf(v.y) * 0.3183f + 0.5f;
+    const float x = u * (float)em.w - 0.5f, y = w * (float)em.h - 0.5f;
+    const float fx0 = floorf(x), fy0 = floorf(y);
+    const float fx = x - fx0, fy = y - fy0;
+    auto clampi = [](float f, uint32_t n) { return f < 0.0f ? 0u : (f > (float)(n - 1) ? n - 1 : (uint32_t)f); };
+    const uint32_t x0 = clampi(fx0, em.w), x1 = clampi(fx0 + 1.0f, em.w);
+    const uint32_t y0 = clampi(fy0, em.h), y1 = clampi(fy0 + 1.0f, em.h);
+    auto texel = [&](uint32_t xx, uint32_t yy) { const float* t = em.rgb + 3 * ((size_t)yy * em.w + xx); return f3(t[0], t[1], t[2]); };
+    const F3 top = (1 - fx) * texel(x0, y0) + fx * texel(x1, y0);
+    const F3 bot = (1 - fx) * texel(x0, y1) + fx * texel(x1, y1);
+    return (1 - fy) * top + fy * bot;
+}
+
 struct PathCtx {
     SceneRef S;
     F3 root_min, root_max;
     Shade sh;
     F3 ambient;
+    EnvMap env;
     uint32_t* stack;
     uint32_t* lvstack;
     uint32_t max_depth;
@@ -115,7 +135,7 @@ TRC_DEV bool path_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, 
         if (--ps.depth_left <= 0) { result = ps.color; return true; }
     }
     ps.primary = false;
-    if (!hitted) { result = ps.color + ps.ratio * cx.ambient; return true; }        // :434-439
+    if (!hitted) { result = ps.color + ps.ratio * env_radiance(cx.env, cx.ambient, ps.ray.d); return true; }        // :434-439
     HitRec& rec = ps.rec;
     const int mtype = mat_type(cx.sh, rec.material);
     if (mtype == kMatDiffuse) {                                      // emitter, :441-445
@@ -265,7 +285,7 @@ TRC_DEV bool mis_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, T
         if (--ps.depth_left <= 0) { result = ps.color; return true; }   // } while ((--depth) > 0), :406
     }
     ps.primary = false;
-    if (!hitted) { result = ps.color + ps.ratio * cx.ambient; return true; }
+    if (!hitted) { result = ps.color + ps.ratio * env_radiance(cx.env, cx.ambient, ps.ray.d); return true; }
     const int mtype = mat_type(cx.sh, rec.material);
     if (mtype == kMatDiffuse) {
         F3 le = mat_albedo(cx.sh, rec.material);

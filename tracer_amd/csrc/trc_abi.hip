@@ -65,6 +65,7 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
         cx.root_max = f3(kp.ks.root_box[3], kp.ks.root_box[4], kp.ks.root_box[5]);
         cx.sh.mats = small_base + sc.off_materials;
         cx.ambient = f3(kp.ambient[0], kp.ambient[1], kp.ambient[2]);
+        cx.env.rgb = kp.env_rgb; cx.env.w = kp.env_w; cx.env.h = kp.env_h;
         cx.stack = stack;
         cx.lvstack = lvstack;
         cx.max_depth = kp.max_depth;
@@ -464,7 +465,7 @@ void trc_destroy(trc_ctx* ctx) {
     trc_sppm_release(ctx);
     collect_events(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
-    (void)hipFree(ctx->d_blob); (void)hipFree(ctx->d_bvh_ref); (void)hipFree(ctx->d_density); (void)hipFree(ctx->d_rng); (void)hipFree(ctx->d_accum);
+    (void)hipFree(ctx->d_blob); (void)hipFree(ctx->d_bvh_ref); (void)hipFree(ctx->d_density); (void)hipFree(ctx->d_envmap); (void)hipFree(ctx->d_rng); (void)hipFree(ctx->d_accum);
     (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_stats); (void)hipFree(ctx->d_reduce_recv);
     (void)hipFree(ctx->d_accum_alt);
     for (hipEvent_t e : {ctx->ev_rendered, ctx->ev_busy, ctx->ev_busy_alt}) if (e) (void)hipEventDestroy(e);
@@ -527,6 +528,21 @@ trc_status trc_set_camera(trc_ctx* ctx, const trc_Camera* c) {
 trc_status trc_set_environment(trc_ctx* ctx, const float rgb[3]) {
     if (!ctx || !rgb) return TRC_ERR_INVALID_ARG;
     ctx->ambient[0] = rgb[0]; ctx->ambient[1] = rgb[1]; ctx->ambient[2] = rgb[2];
+    return TRC_OK;
+}
+
+trc_status trc_set_environment_map(trc_ctx* ctx, uint32_t w, uint32_t h, const float* rgb) {
+    if (!ctx) return TRC_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(ctx->d_envmap); ctx->d_envmap = nullptr; ctx->env_w = ctx->env_h = 0;
+    if (!rgb) return TRC_OK;                                             // back to the constant environment
+    if (w == 0 || h == 0 || (uint64_t)w * h > (1ull << 28)) return fail(ctx, TRC_ERR_INVALID_ARG, "trc_set_environment_map: bad size");
+    const size_t bytes = (size_t)w * h * 3 * sizeof(float);
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_envmap, bytes));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_envmap, rgb, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->env_w = w; ctx->env_h = h;
     return TRC_OK;
 }
 
@@ -641,6 +657,7 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
     kp.ks = ctx->ks;
     kp.cam = ctx->cam;
     kp.ambient[0] = ctx->ambient[0]; kp.ambient[1] = ctx->ambient[1]; kp.ambient[2] = ctx->ambient[2];
+    kp.env_rgb = ctx->d_envmap; kp.env_w = ctx->env_w; kp.env_h = ctx->env_h;
     kp.fr.rng = ctx->d_rng; kp.fr.accum = ctx->d_accum; kp.fr.width = ctx->width; kp.fr.height = ctx->height;
     kp.spp = p->spp; kp.max_depth = p->max_depth; kp.frame0 = p->frame0;
     kp.view_height = (p->view_height != 0 && p->view_height < ctx->height) ? p->view_height : ctx->height;

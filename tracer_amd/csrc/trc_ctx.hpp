@@ -25,6 +25,7 @@ struct KRender {
     KScene ks;
     DCamera cam;
     float ambient[3];
+    const float* env_rgb; uint32_t env_w, env_h;      // environment map (null: constant `ambient`)
     DFrame fr;
     uint32_t spp, max_depth, frame0;
     uint32_t view_height;               // rows per view of a stacked frame (= frame height for a single view)
@@ -93,6 +94,7 @@ struct trc_ctx {
     bool has_camera = false;
     DCamera cam{};
     float ambient[3] = {0, 0, 0};
+    float* d_envmap = nullptr; uint32_t env_w = 0, env_h = 0;
 
     // frame
     uint32_t width = 0, height = 0;

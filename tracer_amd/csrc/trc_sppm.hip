@@ -33,6 +33,7 @@ struct KSppm {
     KScene ks;
     DCamera cam;
     float ambient[3];
+    const float* env_rgb; uint32_t env_w, env_h;
     uint32_t W, H, frame_count, photon_first;   // photon_first: first photon index of this rank's range
     const uint32_t* tiles;
     uint32_t* canvas_rng;
@@ -97,6 +98,7 @@ struct SppmCtx {
     F3 root_min, root_max;
     Shade sh;
     F3 ambient;
+    EnvMap env;
     uint32_t* stack;
     uint32_t* lvstack;
 };
@@ -108,6 +110,7 @@ __device__ __forceinline__ SppmCtx make_sppm_ctx(const KSppm& kp, const uint32_t
     cx.root_max = f3(kp.ks.root_box[3], kp.ks.root_box[4], kp.ks.root_box[5]);
     cx.sh.mats = small_base + sc.off_materials;
     cx.ambient = f3(kp.ambient[0], kp.ambient[1], kp.ambient[2]);
+    cx.env.rgb = kp.env_rgb; cx.env.w = kp.env_w; cx.env.h = kp.env_h;
     cx.stack = trc_smem + sc.lds_dwords + threadIdx.x;
     cx.lvstack = cx.stack + sc.stack_depth * kBlock;
     return cx;
@@ -154,7 +157,7 @@ __global__ void __launch_bounds__(kBlock) k_sppm_camera(const KSppm kp) {
         bool hitted = sppm_hit<ALL_LDS>(cx, ray, rec, n_rays);
         bool finished = false;
         do {
-            if (!hitted) { cr_alternative = ratio * cx.ambient; finished = true; break; }
+            if (!hitted) { cr_alternative = ratio * env_radiance(cx.env, cx.ambient, ray.d); finished = true; break; }
             const int mtype = mat_type(cx.sh, rec.material);
             if (mtype == kMatDiffuse) {
                 F3 le = mat_albedo(cx.sh, rec.material);
@@ -494,6 +497,7 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
     KSppm kp{};
     kp.ks = ctx->ks; kp.cam = ctx->cam;
     kp.ambient[0] = ctx->ambient[0]; kp.ambient[1] = ctx->ambient[1]; kp.ambient[2] = ctx->ambient[2];
+    kp.env_rgb = ctx->d_envmap; kp.env_w = ctx->env_w; kp.env_h = ctx->env_h;
     kp.W = s->W; kp.H = s->H;
     kp.photon_first = rank * chunk;
     kp.tiles = ctx->d_tiles;

@@ -43,6 +43,7 @@ def lib():
         L.trc_destroy.argtypes = [vp]
         L.trc_destroy.restype = None
         L.trc_upload_scene.argtypes = [vp, C.POINTER(abi.Scene)]
+        L.trc_set_environment_map.argtypes = [vp, u32, u32, vp]
         L.trc_tonemap.argtypes = [vp, vp, C.POINTER(C.c_float)]
         L.trc_upload_density.argtypes = [vp, C.POINTER(abi.GridDensityInfo), vp]
         L.trc_upload_scene_lbvh.argtypes = [vp, C.POINTER(abi.Scene)]
@@ -121,6 +122,15 @@ class Tracer:
     # --- scene / camera / frame -------------------------------------------------
     def upload_scene(self, scene_view):
         self._check(self._L.trc_upload_scene(self._h, C.byref(scene_view)), "trc_upload_scene")
+
+    def set_environment_map(self, rgb):
+        """(h, w, 3) float32 equirectangular environment; None returns to the constant one."""
+        if rgb is None:
+            self._check(self._L.trc_set_environment_map(self._h, 0, 0, None), "trc_set_environment_map")
+            return
+        assert rgb.dtype == np.float32 and rgb.ndim == 3 and rgb.shape[2] == 3 and rgb.flags.c_contiguous
+        self._check(self._L.trc_set_environment_map(self._h, rgb.shape[1], rgb.shape[0], rgb.ctypes.data),
+                    "trc_set_environment_map")
 
     def tonemap(self):
         """fragmentShader's auto-exposure + ACES on the accumulator -> ((H, W, 4) uint8, rows top-down; exposure)."""
