@@ -431,8 +431,12 @@ trc_status trc_upload_scene_lbvh(trc_ctx* ctx, const trc_scene* s) {
     HIP_TRY(ctx, hipMemcpyAsync(d_bounds, bounds_init, sizeof bounds_init, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemsetAsync(d_arrived, 0, sizeof(uint32_t) * n_interior, st));
 
-    hipEvent_t e0, e1;
-    HIP_TRY(ctx, hipEventCreate(&e0)); HIP_TRY(ctx, hipEventCreate(&e1));
+    struct Events {                 // destroyed on every exit path
+        hipEvent_t a = nullptr, b = nullptr;
+        ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } ev;
+    HIP_TRY(ctx, hipEventCreate(&ev.a)); HIP_TRY(ctx, hipEventCreate(&ev.b));
+    const hipEvent_t e0 = ev.a, e1 = ev.b;
     HIP_TRY(ctx, hipEventRecord(e0, st));
     const dim3 g_leaf((n + 255) / 256), g_int((n_interior + 255) / 256), b256(256);
     LeafLimits lim;
@@ -475,7 +479,6 @@ trc_status trc_upload_scene_lbvh(trc_ctx* ctx, const trc_scene* s) {
     HIP_TRY(ctx, hipStreamSynchronize(st));
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (height > TRC_MAX_BVH_DEPTH) return trc_fail(ctx, TRC_ERR_BVH_INVALID, "lbvh: tree deeper than TRC_MAX_BVH_DEPTH");
 
     plan_lds(sc, height, false);      // Karras numbering is not top-of-tree first: stage the whole tree or nothing
