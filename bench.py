@@ -132,6 +132,8 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)        # barrier()'s torch.cuda.synchronize() must not touch GPU 0 from every rank
     dist = None
     grouped = world > 1 or args.force_group
     if grouped:

@@ -87,3 +87,27 @@ def test_lbvh_degenerate_inputs():
         leaves[k].bBOX.maxi.x, leaves[k].bBOX.maxi.y, leaves[k].bBOX.maxi.z = x + 1, y + 1, 1
     nodes, height = pyoracle.lbvh_build(leaves, n)
     assert check_tree(nodes, n) == height and height < 16
+
+
+def test_lbvh_random_leaf_sets():
+    """property check over random leaf clouds (clustered, duplicated, huge / tiny extents): the tree is well formed,
+    boxes nest, and every leaf is reachable exactly once"""
+    rs = np.random.RandomState(11)
+    for trial in range(25):
+        n = int(rs.choice([2, 3, 5, 64, 257, 1000]))
+        scale = float(rs.choice([1e-3, 1.0, 1e4]))
+        centers = rs.normal(size=(n, 3)) * scale
+        if trial % 3 == 0:
+            centers[: n // 2] = centers[0]                      # many identical centroids
+        if trial % 5 == 0:
+            centers[:, 1] = 7.0                                 # flat axis
+        half = np.abs(rs.normal(size=(n, 3))) * scale * 0.05
+        leaves = (abi.BVH * n)()
+        for k in range(n):
+            leaves[k].pType = abi.PRIM_SPHERE; leaves[k].pIndex = k
+            lo, hi = centers[k] - half[k], centers[k] + half[k]
+            leaves[k].bBOX.mini.x, leaves[k].bBOX.mini.y, leaves[k].bBOX.mini.z = lo
+            leaves[k].bBOX.maxi.x, leaves[k].bBOX.maxi.y, leaves[k].bBOX.maxi.z = hi
+        nodes, height = pyoracle.lbvh_build(leaves, n)
+        assert check_tree(nodes, n) == height
+        assert height <= 64, (n, height)
