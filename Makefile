@@ -18,8 +18,8 @@ HOST_HDR  := tracer_amd/host/host_math.hpp include/tracer_abi.h
 HIP_SRC   := tracer_amd/csrc/trc_abi.hip tracer_amd/csrc/trc_sppm.hip tracer_amd/csrc/trc_lbvh.hip
 HIP_HDR   := $(wildcard tracer_amd/csrc/*.hpp) include/tracer_abi.h include/trc_detmath.h
 
-.PHONY: all host hip oracle clean
-all: host hip oracle
+.PHONY: all host hip oracle example clean
+all: host hip oracle example
 
 host: $(LIBDIR)/libtrc_host.so
 hip: $(LIBDIR)/libtracer_amd.so
@@ -35,6 +35,11 @@ $(LIBDIR)/libtracer_amd.so: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC) -ldl -Wl,-rpath,$(ROCM)/lib
 
+# C++ host driving the path through the C ABI only (no Python): examples/trc_render
+example: examples/trc_render
+examples/trc_render: examples/trc_render.cpp include/tracer_abi.h $(LIBDIR)/libtrc_host.so $(LIBDIR)/libtracer_amd.so
+	$(CXX) -std=c++17 -O2 -Wall -Iinclude -o $@ examples/trc_render.cpp -L$(LIBDIR) -ltracer_amd -ltrc_host -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,$(ROCM)/lib
+
 clean:
-	rm -f $(LIBDIR)/*.so
+	rm -f $(LIBDIR)/*.so examples/trc_render
 	$(MAKE) -C oracle clean

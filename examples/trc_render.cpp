@@ -1,0 +1,92 @@
+// trc_render.cpp -- a C++ host driving the path through the C ABI only (include/tracer_abi.h), the way
+// -[AAPLRenderer render:] drives the Metal path: scene prep on the host (libtrc_host.so), upload, N samples,
+// output stage, PNG.  Nothing but the two shared libraries is involved.
+//
+//   trc_render [--scene cornell|spheres|volume] [--integrator path|mis|volume] [--size W H] [--spp N]
+//              [--lbvh] [--out frame.png]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "tracer_abi.h"
+
+#define CHECK(call)                                                                                  \
+    do {                                                                                             \
+        trc_status st_ = (call);                                                                     \
+        if (st_ != TRC_OK) {                                                                         \
+            std::fprintf(stderr, "%s failed: %s (%s)\n", #call, trc_status_string(st_), ctx ? trc_last_error(ctx) : ""); \
+            return 1;                                                                                \
+        }                                                                                            \
+    } while (0)
+
+int main(int argc, char** argv) {
+    std::string scene_name = "spheres", integ_name = "path", out = "frame.png";
+    uint32_t W = 640, H = 360, spp = 64;
+    bool lbvh = false;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "--scene" && i + 1 < argc) scene_name = argv[++i];
+        else if (a == "--integrator" && i + 1 < argc) integ_name = argv[++i];
+        else if (a == "--size" && i + 2 < argc) { W = (uint32_t)std::atoi(argv[++i]); H = (uint32_t)std::atoi(argv[++i]); }
+        else if (a == "--spp" && i + 1 < argc) spp = (uint32_t)std::atoi(argv[++i]);
+        else if (a == "--lbvh") lbvh = true;
+        else if (a == "--out" && i + 1 < argc) out = argv[++i];
+        else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
+    }
+    const int kind = scene_name == "cornell" ? TRC_SCENE_CORNELL : scene_name == "volume" ? TRC_SCENE_CORNELL_VOLUME : TRC_SCENE_CORNELL_SPHERES;
+    const uint32_t integrator = integ_name == "mis" ? TRC_INTEGRATOR_MIS : integ_name == "volume" ? TRC_INTEGRATOR_VOLUME : TRC_INTEGRATOR_PATH;
+
+    trc_ctx* ctx = nullptr;
+    trc_host_scene* hs = nullptr;
+    if (trc_host_scene_create(kind, nullptr, 0, nullptr, 0, &hs) != TRC_OK) { std::fprintf(stderr, "scene prep failed\n"); return 1; }
+    trc_scene scene;
+    trc_host_scene_view(hs, &scene);
+    trc_Camera cam;
+    trc_host_prepare_camera(&cam, (float)W, (float)H);
+
+    CHECK(trc_create(0, &ctx));
+    if (lbvh) {                                   // hand over the leaf records only; the tree is built on the GPU
+        trc_scene leaves = scene;
+        leaves.bvhList = scene.bvhList + 1;       // BVH::buildTree keeps the leaves at [1, n]
+        leaves.n_bvh = (scene.n_bvh + 1) / 2;
+        CHECK(trc_upload_scene_lbvh(ctx, &leaves));
+    } else {
+        CHECK(trc_upload_scene(ctx, &scene));
+    }
+    std::vector<float> cloud;
+    if (kind == TRC_SCENE_CORNELL_VOLUME) {
+        const uint32_t nx = 100, ny = 100, nz = 40;
+        cloud.resize((size_t)nx * ny * nz);
+        trc_host_make_cloud(nx, ny, nz, 1, cloud.data());
+        trc_GridDensityInfo info;
+        trc_host_make_density_info(10.0f, 90.0f, 0.5f, nx, ny, nz, cloud.data(), &info);
+        CHECK(trc_upload_density(ctx, &info, cloud.data()));
+    }
+    CHECK(trc_set_camera(ctx, &cam));
+    CHECK(trc_resize(ctx, W, H));
+    CHECK(trc_seed(ctx, 0x5EED0000ull));
+
+    trc_params prm;
+    std::memset(&prm, 0, sizeof prm);
+    prm.spp = spp; prm.max_depth = 8; prm.integrator = integrator; prm.tile_nranks = 1;
+    const auto t0 = std::chrono::steady_clock::now();
+    CHECK(trc_render(ctx, &prm));
+    CHECK(trc_synchronize(ctx));
+    const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    trc_stats st;
+    CHECK(trc_get_stats(ctx, &st));
+
+    std::vector<uint8_t> rgba8((size_t)W * H * 4);
+    float exposure = 0;
+    CHECK(trc_tonemap(ctx, rgba8.data(), &exposure));
+    if (trc_host_write_png(out.c_str(), rgba8.data(), W, H) != TRC_OK) { std::fprintf(stderr, "cannot write %s\n", out.c_str()); return 1; }
+    std::printf("%s %ux%u %u spp %s: %llu rays, kernel %.2f ms (wall %.2f ms), %.1f Mrays/s, exposure %.4f -> %s\n",
+                scene_name.c_str(), W, H, spp, integ_name.c_str(), (unsigned long long)st.rays, st.kernel_ms, wall_ms,
+                st.rays / st.kernel_ms / 1e3, exposure, out.c_str());
+    trc_destroy(ctx);
+    trc_host_scene_destroy(hs);
+    return 0;
+}
