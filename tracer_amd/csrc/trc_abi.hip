@@ -36,8 +36,8 @@ __global__ void __launch_bounds__(256) k_seed(uint32_t* rng, uint32_t n_pixels, 
     reinterpret_cast<uint4*>(rng)[p] = out;
 }
 
-// kernelPathTracing, Render.metal:495-558.  One lane per pixel, one workgroup per 16x16 tile
-// (4 wavefronts of 8x8 pixels), all `spp` samples fused: RNG texel and accumulator are read and
+// kernelPathTracing, Render.metal:495-558.  One lane per pixel, one one-wavefront workgroup per 8x8 pixel block
+// (DESIGN.md 4.1), all `spp` samples fused: RNG texel and accumulator are read and
 // written ONCE per pixel instead of once per sample (64 B/pixel/sample in the reference).
 template <bool LDS, bool STATS, int INTEGRATOR>
 __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRATOR_PATH ? 4 : 3)) k_render(const KRender kp) {

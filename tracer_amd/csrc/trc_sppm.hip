@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(256) k_sppm_sum(const uint32_t* count, DComple
 
 // kernelPhotonRefine, Photon.metal:498-623
 __global__ void __launch_bounds__(kBlock) k_sppm_refine(const KSppm kp) {
-    // one workgroup per 16x16 tile of this rank (same tile list as the camera pass)
+    // one wavefront per 8x8 pixel block of this rank (same block list as the camera pass)
     const uint32_t tile = kp.tiles[blockIdx.x];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t qx = (tile & 0xFFFFu) * 8u + (lane & 7u);
