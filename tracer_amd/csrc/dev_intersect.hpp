@@ -369,12 +369,92 @@ TRC_DEV bool trav_begin(const F3 root_min, const F3 root_max, const Ray& ray, co
     return true;
 }
 
+// leaf test of one primitive tag; returns true when the hit was accepted (tv.ry lowered)
+template <bool STATS, bool EAGER_UV, bool VOL>
+TRC_DEV bool trav_test_leaf(const SceneRef& S, const Ray& ray, HitRec& rec, Trav& tv, uint32_t tag, TravCounters& cnt) {
+    const float rx = FLT_MIN;
+    const uint32_t type = tag >> kTagIndexBits, index = tag & kTagIndexMask;
+    bool ok;
+    if (type == 1u) {
+        if (STATS) cnt.leaf[1]++;
+        ProfScope<STATS> scope(cnt, kProfSquare);
+        ok = square_hit_test(S, index, ray, rx, tv.ry, rec);
+    } else if (type == 0u) {
+        if (STATS) cnt.leaf[0]++;
+        ProfScope<STATS> scope(cnt, kProfSphere);
+        ok = sphere_hit_test<EAGER_UV>(S, index, ray, rx, tv.ry, rec);
+    } else if (type == 2u) {
+        if (STATS) cnt.leaf[2]++;
+        ProfScope<STATS> scope(cnt, kProfCube);
+        ok = cube_hit_test<STATS, VOL>(S, index, ray, tv.ry, rec, cnt);
+    } else {
+        if (STATS) cnt.leaf[3]++;
+        ProfScope<STATS> scope(cnt, kProfTriangle);
+        ok = triangle_hit_test<STATS>(S, index, ray, rx, tv.ry, rec, cnt);
+    }
+    if (ok) rec.tag = tag;
+    return ok;
+}
+
 // one round: (1) expand interior nodes until this lane holds a leaf (or runs out of work) -- the whole wavefront
 // does box tests here; (2) test the leaf.  Lanes with tv.done set idle through the call.
+//
+// Production kernels (STATS = false) run the SPECULATIVE form of the round (Aila & Laine, HPG 2009): a lane that
+// reaches a leaf while its neighbours are still descending postpones that leaf, pops its next node and keeps
+// descending until it reaches a second leaf; then both are tested in the order they were found.  Primitives are
+// therefore tested in exactly the reference's order and against the same running closest hit; only boxes are
+// tested against a possibly staler (larger) ry, i.e. a superset of the reference's nodes is visited, and every
+// primitive met only because of that lies beyond the closest hit by then (t >= box entry > ry), so it is
+// rejected: the results are identical.  The exact traversal counters are taken by the instrumented kernels,
+// which run the plain round.
 template <bool ALL_LDS, bool STATS, bool ANY, bool EAGER_UV, bool VOL = false>
 TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const float test_t, Trav& tv,
                        uint32_t* stack, uint32_t* lvstack, TravCounters& cnt) {
     const float rx = FLT_MIN;
+    constexpr bool SPEC = !STATS;
+    if (SPEC) {
+        uint32_t pend = kTagNone;                      // postponed leaf
+        auto pop_next = [&]() {                        // next deferred sibling, or "exhausted" (kTagNone)
+            if (tv.sp == 0) { tv.tag = kTagNone; return; }
+            tv.sp--;
+            tv.tag = stack[tv.sp * kBlock];
+        };
+        for (;;) {
+            const bool interior = !tv.done && (tv.tag >> kTagIndexBits) == kTagInterior;
+            if (__ballot(interior) == 0ull) break;
+            if (interior) {
+                float4 q0, q1, q2, q3;
+                load_node<ALL_LDS>(S, tv.tag & kTagIndexMask, q0, q1, q2, q3);
+                float t_left = tv.ry, t_right = tv.ry;
+                const bool left_test = box_hit_t(f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), ray, rx, tv.ry, t_left);
+                const bool right_test = box_hit_t(f3(q1.z, q1.w, q2.x), f3(q2.y, q2.z, q2.w), ray, rx, tv.ry, t_right);
+                if (left_test || right_test) {
+                    const uint32_t tagL = __float_as_uint(q3.z), tagR = __float_as_uint(q3.w);
+                    const bool left_first = t_left < t_right;
+                    if (left_test && right_test) { stack[tv.sp * kBlock] = left_first ? tagR : tagL; tv.sp++; }
+                    tv.tag = left_first ? tagL : tagR;
+                } else {
+                    pop_next();
+                }
+                if (pend == kTagNone && (tv.tag >> kTagIndexBits) < kTagInterior) { pend = tv.tag; pop_next(); }
+            }
+        }
+        if (!tv.done) {
+            // first leaf of the round: the postponed one, or (a lane that entered the round on a leaf) the current one
+            if (pend == kTagNone && (tv.tag >> kTagIndexBits) < kTagInterior) { pend = tv.tag; pop_next(); }
+            if (pend != kTagNone) {
+                trav_test_leaf<STATS, EAGER_UV, VOL>(S, ray, rec, tv, pend, cnt);
+                if (ANY && tv.ry < test_t) tv.done = true;                       // Render.hh:244
+            }
+            if (!tv.done && (tv.tag >> kTagIndexBits) < kTagInterior) {          // second leaf, found after the first
+                trav_test_leaf<STATS, EAGER_UV, VOL>(S, ray, rec, tv, tv.tag, cnt);
+                if (ANY && tv.ry < test_t) tv.done = true;
+                else pop_next();
+            }
+            if (tv.tag == kTagNone) tv.done = true;                              // stack exhausted
+        }
+        return;
+    }
     while (!tv.done && (tv.tag >> kTagIndexBits) == kTagInterior) {
         float4 q0, q1, q2, q3;
         load_node<ALL_LDS>(S, tv.tag & kTagIndexMask, q0, q1, q2, q3);
@@ -398,26 +478,7 @@ TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const flo
         }
     }
     if (!tv.done) {
-        const uint32_t type = tv.tag >> kTagIndexBits, index = tv.tag & kTagIndexMask;
-        bool ok;
-        if (type == 1u) {
-            if (STATS) cnt.leaf[1]++;
-            ProfScope<STATS> scope(cnt, kProfSquare);
-            ok = square_hit_test(S, index, ray, rx, tv.ry, rec);
-        } else if (type == 0u) {
-            if (STATS) cnt.leaf[0]++;
-            ProfScope<STATS> scope(cnt, kProfSphere);
-            ok = sphere_hit_test<EAGER_UV>(S, index, ray, rx, tv.ry, rec);
-        } else if (type == 2u) {
-            if (STATS) cnt.leaf[2]++;
-            ProfScope<STATS> scope(cnt, kProfCube);
-            ok = cube_hit_test<STATS, VOL>(S, index, ray, tv.ry, rec, cnt);
-        } else {
-            if (STATS) cnt.leaf[3]++;
-            ProfScope<STATS> scope(cnt, kProfTriangle);
-            ok = triangle_hit_test<STATS>(S, index, ray, rx, tv.ry, rec, cnt);
-        }
-        if (ok) rec.tag = tv.tag;
+        trav_test_leaf<STATS, EAGER_UV, VOL>(S, ray, rec, tv, tv.tag, cnt);
         if (ANY && tv.ry < test_t) tv.done = true;                    // Render.hh:244
         else trav_pop_or_finish<STATS>(tv, tv.level, stack, lvstack, cnt);
     }
