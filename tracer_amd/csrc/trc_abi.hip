@@ -336,13 +336,22 @@ trc_status build_blob(trc_ctx* ctx, const trc_scene* s, std::vector<uint32_t>& b
 // every XCD receives the same mix.  Measured: handing each XCD a contiguous band of the image instead (the
 // "L2-friendly" order) costs 22 % on the Cornell scene and 44 % on the 1 M-triangle scene, because the XCD whose
 // band holds the glass / mesh pixels finishes long after the others; 8x8-tile blocks per XCD sit in between.
-std::vector<uint32_t> make_tiles(uint32_t W, uint32_t H, uint32_t nranks, uint32_t rank) {
+std::vector<uint32_t> make_tiles(uint32_t W, uint32_t H, uint32_t nranks, uint32_t rank, uint32_t view_height) {
     // ownership is decided per TRC_TILE x TRC_TILE tile; the launch unit is the 8x8 block (one wavefront)
     const uint32_t bw = (W + 7) / 8, bh = (H + 7) / 8;
     std::vector<uint32_t> mine;
     for (uint32_t by = 0; by < bh; ++by)
         for (uint32_t bx = 0; bx < bw; ++bx)
             if ((bx * 8 / TRC_TILE + by * 8 / TRC_TILE) % nranks == rank) mine.push_back(bx | (by << 16));
+    if (view_height != 0 && view_height < H) {
+        // stacked views: walk the rows of ALL views together (row within the view first), so the launch ends on the
+        // last rows of every view like a single-view launch does.  View after view, the expensive blocks of the final
+        // view would start a few ms before the end of the list and run on alone (measured 28-31 ms instead of 25).
+        std::stable_sort(mine.begin(), mine.end(), [&](uint32_t a, uint32_t b) {
+            const uint32_t ra = ((a >> 16) * 8u) % view_height / 8u, rb = ((b >> 16) * 8u) % view_height / 8u;
+            return ra < rb;
+        });
+    }
     return mine;
 }
 
@@ -379,9 +388,9 @@ size_t trc_dyn_lds_bytes(const trc_ctx* ctx, bool stats) {
     return dwords * 4;
 }
 
-trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank) {
-    if (ctx->d_tiles && ctx->tiles_nranks == nranks && ctx->tiles_rank == rank) return TRC_OK;
-    std::vector<uint32_t> tiles = make_tiles(ctx->width, ctx->height, nranks, rank);
+trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32_t view_height) {
+    if (ctx->d_tiles && ctx->tiles_nranks == nranks && ctx->tiles_rank == rank && ctx->tiles_view_height == view_height) return TRC_OK;
+    std::vector<uint32_t> tiles = make_tiles(ctx->width, ctx->height, nranks, rank, view_height);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     (void)hipFree(ctx->d_tiles); ctx->d_tiles = nullptr;
     ctx->n_tiles = (uint32_t)tiles.size();
@@ -390,7 +399,7 @@ trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank) {
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_tiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
-    ctx->tiles_nranks = nranks; ctx->tiles_rank = rank;
+    ctx->tiles_nranks = nranks; ctx->tiles_rank = rank; ctx->tiles_view_height = view_height;
     return TRC_OK;
 }
 
@@ -646,7 +655,7 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
     if (p->spp == 0) return TRC_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
-    { trc_status ts = trc_ensure_tiles(ctx, nranks, p->tile_rank); if (ts != TRC_OK) return ts; }
+    { trc_status ts = trc_ensure_tiles(ctx, nranks, p->tile_rank, p->view_height); if (ts != TRC_OK) return ts; }
     if (ctx->n_tiles == 0) return TRC_OK;
 
     const bool stats = (p->flags & TRC_FLAG_COLLECT_STATS) != 0;

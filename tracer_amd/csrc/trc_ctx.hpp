@@ -103,7 +103,7 @@ struct trc_ctx {
 
     // tiles for (nranks, rank)
     uint32_t* d_tiles = nullptr;
-    uint32_t n_tiles = 0, tiles_nranks = 0, tiles_rank = 0;
+    uint32_t n_tiles = 0, tiles_nranks = 0, tiles_rank = 0, tiles_view_height = 0;
 
     // stats
     unsigned long long* d_stats = nullptr;
@@ -158,6 +158,6 @@ bool trc_load_rccl(std::string& err);
 constexpr int kNcclUint8 = 1, kNcclUint32 = 3, kNcclFloat = 7, kNcclSum = 0, kNcclMax = 2, kNcclMin = 3;
 
 // tiles owned by `rank` of `nranks` (XCD-aware order) uploaded into ctx->d_tiles; shared by render and SPPM
-trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank);
+trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32_t view_height = 0);
 size_t trc_dyn_lds_bytes(const trc_ctx* ctx, bool stats);
 void trc_sppm_release(trc_ctx* ctx);   // frees ctx->sppm (no-op when absent)
