@@ -33,7 +33,7 @@ $(LIBDIR)/libtrc_host.so: $(HOST_SRC) $(HOST_HDR)
 # RCCL is resolved at run time (dlopen in trc_group_*), so the library loads on boxes without it.
 $(LIBDIR)/libtracer_amd.so: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC) -ldl -Wl,-rpath,$(ROCM)/lib
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC) -ldl -lpthread -Wl,-rpath,$(ROCM)/lib
 
 # C++ host driving the path through the C ABI only (no Python): examples/trc_render
 example: examples/trc_render

@@ -313,16 +313,18 @@ trc_status build_blob(trc_ctx* ctx, const trc_scene* s, std::vector<uint32_t>& b
         if (nodes[c].pType == TRC_PRIM_BVH) return (kTagInterior << kTagIndexBits) | interior_id[c];
         return ((uint32_t)nodes[c].pType << kTagIndexBits) | nodes[c].pIndex;
     };
-    for (uint32_t k = 0; k < n_interior; ++k) {
-        const trc_BVH& nd = nodes[order[k]];
-        const trc_AABB& L = nodes[nd.left].bBOX;
-        const trc_AABB& R = nodes[nd.right].bBOX;
-        uint32_t* q = &blob[sc.off_nodes + (size_t)k * kNodeDwords];
-        q[0] = f2u(L.mini.x); q[1] = f2u(L.mini.y); q[2] = f2u(L.mini.z); q[3] = f2u(L.maxi.x);
-        q[4] = f2u(L.maxi.y); q[5] = f2u(L.maxi.z); q[6] = f2u(R.mini.x); q[7] = f2u(R.mini.y);
-        q[8] = f2u(R.mini.z); q[9] = f2u(R.maxi.x); q[10] = f2u(R.maxi.y); q[11] = f2u(R.maxi.z);
-        q[12] = 0; q[13] = 0; q[14] = tag_of(nd.left); q[15] = tag_of(nd.right);
-    }
+    prep_parallel_for(n_interior, [&](size_t kb, size_t ke) {
+        for (size_t k = kb; k < ke; ++k) {
+            const trc_BVH& nd = nodes[order[k]];
+            const trc_AABB& L = nodes[nd.left].bBOX;
+            const trc_AABB& R = nodes[nd.right].bBOX;
+            uint32_t* q = &blob[sc.off_nodes + k * kNodeDwords];
+            q[0] = f2u(L.mini.x); q[1] = f2u(L.mini.y); q[2] = f2u(L.mini.z); q[3] = f2u(L.maxi.x);
+            q[4] = f2u(L.maxi.y); q[5] = f2u(L.maxi.z); q[6] = f2u(R.mini.x); q[7] = f2u(R.mini.y);
+            q[8] = f2u(R.mini.z); q[9] = f2u(R.maxi.x); q[10] = f2u(R.maxi.y); q[11] = f2u(R.maxi.z);
+            q[12] = 0; q[13] = 0; q[14] = tag_of(nd.left); q[15] = tag_of(nd.right);
+        }
+    });
     fill_primitives(s, sc, blob.data());
     ks.sc = sc;
     const trc_AABB& rb = nodes[0].bBOX;

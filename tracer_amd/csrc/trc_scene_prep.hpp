@@ -3,21 +3,41 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "trc_ctx.hpp"
 
 inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 
+// fn(begin, end) over [0, n) on up to 16 host threads (the per-triangle loops of a 1 M-triangle upload)
+template <class Fn>
+inline void prep_parallel_for(size_t n, Fn fn) {
+    const size_t hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t nt = n < (1u << 16) ? 1 : std::min<size_t>(std::min<size_t>(hw, 16), n >> 15);
+    if (nt <= 1) { fn((size_t)0, n); return; }
+    std::vector<std::thread> th;
+    const size_t chunk = (n + nt - 1) / nt;
+    for (size_t k = 0; k < nt; ++k) {
+        const size_t b = k * chunk, e = std::min(n, b + chunk);
+        if (b < e) th.emplace_back([=] { fn(b, e); });
+    }
+    for (auto& t : th) t.join();
+}
+
 // checks shared by the host-tree and the device-LBVH upload paths: primitive arrays, indices, materials
 inline trc_status validate_primitives(trc_ctx* ctx, const trc_scene* s) {
     if (!s->materials || s->n_material == 0) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "scene: no materials");
     if (s->n_index % 3) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "scene: n_index not a multiple of 3");
     const uint32_t n_tri = s->n_index / 3;
-    for (uint32_t t = 0; t < s->n_index; ++t)
-        if (s->idxList[t] >= s->n_vertex) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "scene: triangle index out of range");
+    std::atomic<bool> bad_index{false};
+    prep_parallel_for(s->n_index, [&](size_t b, size_t e) {
+        for (size_t t = b; t < e; ++t) if (s->idxList[t] >= s->n_vertex) { bad_index = true; return; }
+    });
+    if (bad_index) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "scene: triangle index out of range");
     auto bad_mat = [&](uint32_t m) { return m >= s->n_material; };
     for (uint32_t i = 0; i < s->n_sphere; ++i) if (bad_mat(s->sphereList[i].material)) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "sphere material out of range");
     for (uint32_t i = 0; i < s->n_square; ++i) if (bad_mat(s->squareList[i].material)) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "square material out of range");
@@ -122,17 +142,19 @@ inline void fill_primitives(const trc_scene* s, const DScene& sc, uint32_t* blob
         q[5] = m.specular ? 1u : 0u;
         q[6] = (uint32_t)m.medium;
     }
-    for (uint32_t t = 0; t < n_tri; ++t) {
-        const trc_TriangleVertex* v[3] = {&s->triList[s->idxList[3 * t]], &s->triList[s->idxList[3 * t + 1]],
-                                          &s->triList[s->idxList[3 * t + 2]]};
-        uint32_t* p = &blob[sc.off_tripos + (size_t)t * kTriPosDwords];
-        uint32_t* a = &blob[sc.off_triattr + (size_t)t * kTriAttrDwords];
-        for (int k = 0; k < 3; ++k) {
-            p[4 * k] = f2u(v[k]->v[0]); p[4 * k + 1] = f2u(v[k]->v[1]); p[4 * k + 2] = f2u(v[k]->v[2]); p[4 * k + 3] = 0;
-            a[3 * k] = f2u(v[k]->n[0]); a[3 * k + 1] = f2u(v[k]->n[1]); a[3 * k + 2] = f2u(v[k]->n[2]);
-            a[9 + 2 * k] = f2u(v[k]->uv[0]); a[10 + 2 * k] = f2u(v[k]->uv[1]);
+    prep_parallel_for(n_tri, [&](size_t tb, size_t te) {
+        for (size_t t = tb; t < te; ++t) {
+            const trc_TriangleVertex* v[3] = {&s->triList[s->idxList[3 * t]], &s->triList[s->idxList[3 * t + 1]],
+                                              &s->triList[s->idxList[3 * t + 2]]};
+            uint32_t* p = &blob[sc.off_tripos + t * kTriPosDwords];
+            uint32_t* a = &blob[sc.off_triattr + t * kTriAttrDwords];
+            for (int k = 0; k < 3; ++k) {
+                p[4 * k] = f2u(v[k]->v[0]); p[4 * k + 1] = f2u(v[k]->v[1]); p[4 * k + 2] = f2u(v[k]->v[2]); p[4 * k + 3] = 0;
+                a[3 * k] = f2u(v[k]->n[0]); a[3 * k + 1] = f2u(v[k]->n[1]); a[3 * k + 2] = f2u(v[k]->n[2]);
+                a[9 + 2 * k] = f2u(v[k]->uv[0]); a[10 + 2 * k] = f2u(v[k]->uv[1]);
+            }
+            a[15] = 0;
         }
-        a[15] = 0;
-    }
+    });
 }
 
