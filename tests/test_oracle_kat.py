@@ -319,3 +319,92 @@ def test_cast_ray_consumes_two_randoms_and_ignores_them_at_zero_aperture():
     assert n >= 2 and n % 2 == 0
     assert tuple(o) == (278.0, 278.0, -800.0)
     assert np.allclose(np.array(d), [0, 0, 1], atol=1e-6)            # centre of the image looks down +z
+
+
+# ------------------------------------------------------------------ published formulas, re-derived independently
+# pbrt-v3 (the source the reference's MicrofacetBXDF.h follows): Beckmann / Trowbridge-Reitz D and Lambda,
+# Torrance-Sparrow reflection and its pdf.  float64 numpy, written from the book's equations, not from the oracle.
+def _tan2_cos2phi(w):
+    c2 = w[2] * w[2]
+    s2 = max(0.0, 1 - c2)
+    tan2 = s2 / c2
+    cphi2 = 1.0 if s2 == 0 else min(1.0, max(-1.0, w[0] / math.sqrt(s2))) ** 2
+    sphi2 = 0.0 if s2 == 0 else min(1.0, max(-1.0, w[1] / math.sqrt(s2))) ** 2
+    return tan2, c2, cphi2, sphi2
+
+
+def _beckmann(ax, ay):
+    def D(wh):
+        tan2, c2, cp, sp = _tan2_cos2phi(wh)
+        return math.exp(-tan2 * (cp / ax**2 + sp / ay**2)) / (math.pi * ax * ay * c2 * c2)
+
+    def lam(w):
+        tan2, c2, cp, sp = _tan2_cos2phi(w)
+        a = 1 / (math.sqrt(cp * ax * ax + sp * ay * ay) * math.sqrt(tan2))
+        return 0.0 if a >= 1.6 else (1 - 1.259 * a + 0.396 * a * a) / (3.535 * a + 2.181 * a * a)
+    return D, lam
+
+
+def _trowbridge(ax, ay):
+    def D(wh):
+        tan2, c2, cp, sp = _tan2_cos2phi(wh)
+        e = (cp / ax**2 + sp / ay**2) * tan2
+        return 1 / (math.pi * ax * ay * c2 * c2 * (1 + e) ** 2)
+
+    def lam(w):
+        tan2, c2, cp, sp = _tan2_cos2phi(w)
+        return (-1 + math.sqrt(1 + (cp * ax * ax + sp * ay * ay) * tan2)) / 2
+    return D, lam
+
+
+def _fr_dielectric(cosi, eta):
+    sin2t = (1 - cosi * cosi) / (eta * eta)
+    if sin2t >= 1:
+        return 1.0
+    cost = math.sqrt(1 - sin2t)
+    rpar = (eta * cosi - cost) / (eta * cosi + cost)
+    rper = (cosi - eta * cost) / (cosi + eta * cost)
+    return (rpar * rpar + rper * rper) / 2
+
+
+@pytest.mark.parametrize("mtype,dist,scale,prob", [
+    (abi.MAT_GLASS, _beckmann(0.01, 0.01), 0.98, 0.25),        # reflection lobe: uu.x < 0.25, kr = 0.98
+    (abi.MAT_PLASTIC, _beckmann(0.01, 0.1), 0.2, 1.0),         # specular half: uu.x >= 0.5, ks = 0.2
+    (abi.MAT_METAL, _trowbridge(0.01, 0.02), 1.0, 1.0)])
+def test_microfacet_reflection_against_the_published_equations(mtype, dist, scale, prob):
+    D, lam = dist
+    m = lambert(albedo=(1, 1, 1), mtype=mtype)
+    f2, f3 = C.c_float * 2, C.c_float * 3
+    rs = np.random.RandomState(8)
+    checked = 0
+    for _ in range(400):
+        # directions around a mirror configuration: the lobes are alpha = 0.01 wide
+        wo = np.array([rs.uniform(-0.6, 0.6), rs.uniform(-0.6, 0.6), 0.0]); wo[2] = math.sqrt(1 - wo[0]**2 - wo[1]**2)
+        wh = np.array([rs.normal(0, 0.01), rs.normal(0, 0.02), 1.0]); wh /= np.linalg.norm(wh)
+        wi = -wo + 2 * wo.dot(wh) * wh
+        if wi[2] <= 0.05:
+            continue
+        uu = (0.1, 0.5) if mtype == abi.MAT_GLASS else (0.9, 0.5)
+        fv, pdf = f3(), C.c_float()
+        po.lib().orc_material_F(C.byref(m), f3(*wo.astype(F32)), f3(*wi.astype(F32)), f2(0.3, 0.3), f2(*uu), fv, C.byref(pdf))
+        wo32, wi32 = wo.astype(F32).astype(np.float64), wi.astype(F32).astype(np.float64)
+        h = wo32 + wi32; h /= np.linalg.norm(h)
+        G1 = 1 / (1 + lam(wo32))
+        want_pdf = prob * D(h) * G1 * abs(wo32.dot(h)) / abs(wo32[2]) / (4 * wo32.dot(h))
+        G = 1 / (1 + lam(wo32) + lam(wi32))
+        want_f = scale * D(h) * G / (4 * wi32[2] * wo32[2])
+        if mtype == abi.MAT_METAL:
+            # FrConductor(eta = (0.18, 0.15, 0.81), k = 1), approximate form of BXDF.metal:24-34, red channel
+            c, eta, k = abs(wi32.dot(h)), 0.18, 1.0
+            t = (eta * eta + k * k) * c * c
+            rpar = (t - 2 * eta * c + 1) / (t + 2 * eta * c + 1)
+            tf = eta * eta + k * k
+            rper = (tf - 2 * eta * c + c * c) / (tf + 2 * eta * c + c * c)
+            want_f *= 0.5 * (rpar + rper)
+        else:
+            want_f *= _fr_dielectric(abs(wi32.dot(h)), 1.5)
+        # the half vector of a 0.01-wide lobe is re-derived from float32 directions: allow for its conditioning
+        assert pdf.value == pytest.approx(want_pdf, rel=2e-2)
+        assert fv[0] == pytest.approx(want_f, rel=2e-2)
+        checked += 1
+    assert checked > 200
