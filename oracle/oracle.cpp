@@ -1815,6 +1815,17 @@ void orc_tonemap(const float* accum, uint32_t W, uint32_t H, uint8_t* rgba8, flo
         }
 }
 
+float orc_hg_sample(float g, const float wo[3], const float uu[2], float wi_out[3]) {      // HitRecord.hh:58-77
+    V3 wi;
+    const float pdf = HG_Sample_p(g, v3a(wo), wi, V2{uu[0], uu[1]});
+    wi_out[0] = wi.x; wi_out[1] = wi.y; wi_out[2] = wi.z;
+    return pdf;
+}
+float orc_phase_hg(float cosTheta, float g) { return PhaseHG(cosTheta, g); }                  // HitRecord.hh:45-49
+float orc_grid_density(const trc_GridDensityInfo* info, const float* density, const float p[3]) {   // Medium.hh:129-145
+    return grid_Density(*info, density, v3a(p));
+}
+
 void orc_set_environment_map(uint32_t w, uint32_t h, const float* rgb) {
     if (rgb && w && h) { g_envmap = rgb; g_env_w = w; g_env_h = h; } else { g_envmap = nullptr; g_env_w = g_env_h = 0; }
 }

@@ -91,6 +91,11 @@ void orc_lbvh_build(const trc_BVH* leaves, uint32_t n, trc_BVH* out, uint32_t* o
 /* output stage, Render.metal:29-75 + Render.hh:78-95 (see trc_tonemap in tracer_abi.h for the exact definition) */
 void orc_tonemap(const float* accum_rgba, uint32_t W, uint32_t H, uint8_t* rgba8, float* exposure_out);
 
+/* media pieces for known-answer tests (HitRecord.hh:45-77, Medium.hh:129-145) */
+float orc_hg_sample(float g, const float wo[3], const float uu[2], float wi_out[3]);
+float orc_phase_hg(float cosTheta, float g);
+float orc_grid_density(const trc_GridDensityInfo* info, const float* density, const float p[3]);
+
 /* deterministic math under test (identity wrappers over trc_detmath.h / libm) */
 float orc_math(int fn, float a, float b);   /* 0 sin 1 cos 2 exp 3 log 4 pow 5 asin 6 acos 7 atan2 */
 

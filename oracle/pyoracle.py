@@ -75,6 +75,12 @@ def lib(libm=False):
         L.orc_sppm_download.restype = None
         L.orc_photon_hash.argtypes = [f3, C.c_float]
         L.orc_photon_hash.restype = C.c_float
+        L.orc_hg_sample.argtypes = [C.c_float, f3, f3, f3]
+        L.orc_hg_sample.restype = C.c_float
+        L.orc_phase_hg.argtypes = [C.c_float, C.c_float]
+        L.orc_phase_hg.restype = C.c_float
+        L.orc_grid_density.argtypes = [C.POINTER(abi.GridDensityInfo), C.c_void_p, f3]
+        L.orc_grid_density.restype = C.c_float
         L.orc_tonemap.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_float)]
         L.orc_tonemap.restype = None
         L.orc_set_environment_map.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]

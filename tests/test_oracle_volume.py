@@ -80,3 +80,53 @@ def test_grid_density_volume_scene():
         assert not (a.view(np.uint32) == c.view(np.uint32)).all()
     finally:
         pyoracle.set_density(None, None)
+
+
+def test_henyey_greenstein_against_the_published_phase_function():
+    """HG (HitRecord.hh:45-77 = pbrt-v3 11.2): the phase function integrates to 1, its mean cosine is g (measured against
+    -wo, pbrt's convention), the sampler's returned value is the phase function of the sampled direction, and sampled
+    directions follow it."""
+    L = pyoracle.lib()
+    f2, f3 = C.c_float * 2, C.c_float * 3
+    for g in (0.5, -0.3, 0.0, 0.85):
+        mu = np.linspace(-1, 1, 20001)
+        p = np.array([L.orc_phase_hg(float(m), g) for m in mu[::50]])
+        assert np.trapezoid(p, mu[::50]) * 2 * np.pi == pytest.approx(1.0, rel=2e-3)
+        want = (1 - g * g) / (4 * np.pi * (1 + g * g + 2 * g * mu[::50]) ** 1.5)
+        assert np.allclose(p, want, rtol=1e-5)
+        rs = np.random.RandomState(5)
+        wo = np.array([0.3, -0.5, 0.81], np.float32); wo /= np.linalg.norm(wo)
+        cosines = []
+        for uu in rs.rand(4000, 2).astype(np.float32):
+            wi = f3()
+            pdf = L.orc_hg_sample(g, f3(*wo), f2(*uu), wi)
+            w = np.array(wi)
+            assert abs(np.linalg.norm(w) - 1) < 1e-5
+            c = float(np.dot(wo, w))
+            cosines.append(c)
+            # both directions point away from the scattering point: p(wo, wi) = PhaseHG(dot(wo, wi)) and forward
+            # scattering (g > 0) means wi ~ -wo, so E[dot(wo, wi)] = -g
+            assert pdf == pytest.approx((1 - g * g) / (4 * np.pi * (1 + g * g + 2 * g * c) ** 1.5), rel=2e-3)
+        assert np.mean(cosines) == pytest.approx(-g, abs=0.03)
+
+
+def test_grid_density_is_trilinear_with_zero_outside():
+    rs = np.random.RandomState(2)
+    grid = rs.rand(5, 6, 7).astype(np.float32)                  # (nz, ny, nx)
+    info = host.density_info(grid)
+    f3 = C.c_float * 3
+    L = pyoracle.lib()
+
+    def D(x, y, z):
+        return float(grid[z, y, x]) if 0 <= x < 7 and 0 <= y < 6 and 0 <= z < 5 else 0.0
+    for p in rs.uniform(-0.2, 1.2, size=(300, 3)):
+        s = p * np.array([7, 6, 5]) - 0.5
+        i = np.floor(s).astype(int); d = s - i
+        want = 0.0
+        for dz in (0, 1):
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    w = (d[0] if dx else 1 - d[0]) * (d[1] if dy else 1 - d[1]) * (d[2] if dz else 1 - d[2])
+                    want += w * D(i[0] + dx, i[1] + dy, i[2] + dz)
+        got = L.orc_grid_density(C.byref(info), grid.ctypes.data, f3(*p.astype(np.float32)))
+        assert got == pytest.approx(want, abs=2e-5)
