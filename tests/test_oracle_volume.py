@@ -90,9 +90,9 @@ def test_henyey_greenstein_against_the_published_phase_function():
     f2, f3 = C.c_float * 2, C.c_float * 3
     for g in (0.5, -0.3, 0.0, 0.85):
         mu = np.linspace(-1, 1, 20001)
-        p = np.array([L.orc_phase_hg(float(m), g) for m in mu[::50]])
-        assert np.trapezoid(p, mu[::50]) * 2 * np.pi == pytest.approx(1.0, rel=2e-3)
-        want = (1 - g * g) / (4 * np.pi * (1 + g * g + 2 * g * mu[::50]) ** 1.5)
+        p = np.array([L.orc_phase_hg(float(m), g) for m in mu[::4]])
+        assert np.trapezoid(p, mu[::4]) * 2 * np.pi == pytest.approx(1.0, rel=2e-3)
+        want = (1 - g * g) / (4 * np.pi * (1 + g * g + 2 * g * mu[::4]) ** 1.5)
         assert np.allclose(p, want, rtol=1e-5)
         rs = np.random.RandomState(5)
         wo = np.array([0.3, -0.5, 0.81], np.float32); wo /= np.linalg.norm(wo)
