@@ -244,6 +244,8 @@ enum trc_integrator {
 };
 
 /* flags */
+#define TRC_FLAG_FIXED_ORDER    2u  /* launch the pixel blocks in list order instead of "most expensive block of the
+                                       previous launch first" (a scheduling choice only: pixels are independent) */
 #define TRC_FLAG_COLLECT_STATS  1u  /* run the instrumented kernel variant: exact
                                        N_descend / N_return / leaf-test counters */
 

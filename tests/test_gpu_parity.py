@@ -307,3 +307,22 @@ def test_stacked_views_sharded_over_ranks(gpu, cornell_spheres):
     for i in range(k):
         gpu.upload_rng(np.ascontiguousarray(rng[i * h:(i + 1) * h])); gpu.clear_accum(); gpu.render(spp=4)
         assert np.array_equal(gpu.download_accum().view(np.uint32), ref[i * h:(i + 1) * h].view(np.uint32))
+
+
+def test_adaptive_launch_order_does_not_change_pixels(gpu, cornell_spheres):
+    """from the second launch on the blocks are launched most-expensive-first (rays of the previous launch); the frame,
+    the RNG texture and the counters must not notice"""
+    W, H = 200, 136                      # not a multiple of the block size: ragged blocks take part in the sort
+    cam = host.prepare_camera(W, H)
+    gpu.upload_scene(cornell_spheres.view); gpu.set_camera(cam); gpu.set_environment((0.0, 0.0, 0.0)); gpu.resize(W, H)
+    frames = []
+    for fixed in (True, False, False, True, False):
+        gpu.seed(77); gpu.clear_accum(); gpu.reset_stats()
+        gpu.render(spp=6, fixed_order=fixed)
+        frames.append((gpu.download_accum(), gpu.download_rng(), gpu.stats().rays))
+    for acc, rng, rays in frames[1:]:
+        assert np.array_equal(acc.view(np.uint32), frames[0][0].view(np.uint32))
+        assert np.array_equal(rng, frames[0][1]) and rays == frames[0][2]
+    ref_rng = host.fill_rng(77, W, H)
+    ref, st = po.render(cornell_spheres.view, cam, W, H, ref_rng, spp=6)
+    assert np.array_equal(frames[-1][0].view(np.uint32), ref.view(np.uint32)) and st.rays == frames[-1][2]

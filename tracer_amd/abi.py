@@ -25,6 +25,7 @@ MEDIUM_NIL, MEDIUM_HOMOGENEOUS, MEDIUM_GRIDDENSITY = 0, 1, 2
 # enum trc_host_scene_kind
 SCENE_CORNELL, SCENE_CORNELL_SPHERES, SCENE_CORNELL_MESH, SCENE_CORNELL_VOLUME = 0, 1, 2, 3
 FLAG_COLLECT_STATS = 1
+FLAG_FIXED_ORDER = 2
 
 # status codes
 OK = 0

@@ -47,7 +47,8 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
     uint32_t* stack = stack_base + threadIdx.x;
     uint32_t* lvstack = stack + sc.stack_depth * kBlock;
 
-    const uint32_t tile = kp.tiles[blockIdx.x];                 // 8x8 block: x | y << 16 in units of 8 pixels
+    const uint32_t canon = kp.order ? kp.order[blockIdx.x] : blockIdx.x;     // adaptive launch order (trc_render)
+    const uint32_t tile = kp.tiles[canon];                      // 8x8 block: x | y << 16 in units of 8 pixels
     const uint32_t lane = threadIdx.x;
     const uint32_t px = (tile & 0xFFFFu) * 8u + (lane & 7u);
     const uint32_t py = (tile >> 16) * 8u + (lane >> 3);
@@ -130,6 +131,7 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
     // exact work counters: wave reduction, one 64-bit atomic per wave and counter
     uint32_t r_paths = wave_sum(n_paths), r_rays = wave_sum(n_rays), r_shaded = wave_sum(n_shaded);
     if (lane == 0) {
+        kp.block_cost[canon] = r_rays;
         atomicAdd(&kp.stats[kStatPaths], (unsigned long long)r_paths);
         atomicAdd(&kp.stats[kStatRays], (unsigned long long)r_rays);
         atomicAdd(&kp.stats[kStatShaded], (unsigned long long)r_shaded);
@@ -156,6 +158,14 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
             }
         }
     }
+}
+
+// sort keys of the adaptive launch order: descending cost (clamped to 24 bits), ties in list order
+__global__ void __launch_bounds__(256) k_order_keys(const uint32_t* cost, uint32_t n, uint32_t* keys, uint32_t* vals) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = 0xFFFFFFu - min(cost[i], 0xFFFFFFu);
+    vals[i] = i;
 }
 
 // ---- output stage (fragmentShader, Render.metal:29-75): exposure sums, then ACES to 8 bit
@@ -402,6 +412,19 @@ trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     ctx->tiles_nranks = nranks; ctx->tiles_rank = rank; ctx->tiles_view_height = view_height;
+    // buffers of the adaptive launch order for this block list
+    (void)hipFree(ctx->d_block_cost); ctx->d_block_cost = nullptr;
+    for (int k = 0; k < 2; ++k) { (void)hipFree(ctx->d_order_keys[k]); (void)hipFree(ctx->d_order_vals[k]); ctx->d_order_keys[k] = ctx->d_order_vals[k] = nullptr; }
+    (void)hipFree(ctx->d_order_hist); ctx->d_order_hist = nullptr;
+    ctx->cost_valid = false;
+    if (ctx->n_tiles) {
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_block_cost, ctx->n_tiles * 4));
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_order_keys[k], ctx->n_tiles * 4));
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_order_vals[k], ctx->n_tiles * 4));
+        }
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_order_hist, (trc_sort_hist_words(ctx->n_tiles) + 256) * 4));
+    }
     return TRC_OK;
 }
 
@@ -478,6 +501,8 @@ void trc_destroy(trc_ctx* ctx) {
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     (void)hipFree(ctx->d_blob); (void)hipFree(ctx->d_bvh_ref); (void)hipFree(ctx->d_density); (void)hipFree(ctx->d_envmap); (void)hipFree(ctx->d_rng); (void)hipFree(ctx->d_accum);
     (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_stats); (void)hipFree(ctx->d_reduce_recv);
+    (void)hipFree(ctx->d_block_cost); (void)hipFree(ctx->d_order_hist);
+    for (int k = 0; k < 2; ++k) { (void)hipFree(ctx->d_order_keys[k]); (void)hipFree(ctx->d_order_vals[k]); }
     (void)hipFree(ctx->d_accum_alt);
     for (hipEvent_t e : {ctx->ev_rendered, ctx->ev_busy, ctx->ev_busy_alt}) if (e) (void)hipEventDestroy(e);
     if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
@@ -674,6 +699,19 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
     kp.view_height = (p->view_height != 0 && p->view_height < ctx->height) ? p->view_height : ctx->height;
     kp.tiles = ctx->d_tiles;
     kp.stats = ctx->d_stats;
+    kp.block_cost = ctx->d_block_cost;
+    kp.order = nullptr;
+    if (ctx->cost_valid && !(p->flags & TRC_FLAG_FIXED_ORDER)) {
+        // most expensive blocks of the previous launch first (longest-processing-time order): a block's samples are a
+        // sequential chain, so whatever starts last decides how long the GPU drains; measured 25.2 -> 23.7 ms on
+        // config 2 and 18.7 -> 16.8 ms on the 1 M-triangle scene.  Pixels do not depend on the order.
+        const uint32_t n = ctx->n_tiles;
+        hipLaunchKernelGGL(k_order_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_block_cost, n, ctx->d_order_keys[0], ctx->d_order_vals[0]);
+        int res = 0;
+        trc_sort_pairs24(ctx->stream, ctx->d_order_keys, ctx->d_order_vals, ctx->d_order_hist, ctx->d_order_hist + trc_sort_hist_words(n), n, &res);
+        kp.order = ctx->d_order_vals[res];
+    }
+    ctx->cost_valid = true;
     kp.density = ctx->d_density;
     kp.dinfo = ctx->dinfo;
 

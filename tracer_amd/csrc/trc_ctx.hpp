@@ -33,6 +33,8 @@ struct KRender {
     const float* density;               // traceVolume: GridDensity medium grid (null when absent)
     trc_GridDensityInfo dinfo;
     unsigned long long* stats;          // kStatCount counters
+    const uint32_t* order;              // launch order: order[blockIdx.x] = index into `tiles` (null: identity)
+    uint32_t* block_cost;               // rays of each block of `tiles` in this launch (the next launch's sort key)
 };
 
 struct KTrace {
@@ -103,6 +105,12 @@ struct trc_ctx {
 
     // tiles for (nranks, rank)
     uint32_t* d_tiles = nullptr;
+    // adaptive launch order: rays per block of the previous launch -> most expensive blocks first in the next one
+    uint32_t* d_block_cost = nullptr;
+    uint32_t* d_order_keys[2] = {nullptr, nullptr};
+    uint32_t* d_order_vals[2] = {nullptr, nullptr};
+    uint32_t* d_order_hist = nullptr;
+    bool cost_valid = false;
     uint32_t n_tiles = 0, tiles_nranks = 0, tiles_rank = 0, tiles_view_height = 0;
 
     // stats
@@ -160,4 +168,7 @@ constexpr int kNcclUint8 = 1, kNcclUint32 = 3, kNcclFloat = 7, kNcclSum = 0, kNc
 // tiles owned by `rank` of `nranks` (XCD-aware order) uploaded into ctx->d_tiles; shared by render and SPPM
 trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32_t view_height = 0);
 size_t trc_dyn_lds_bytes(const trc_ctx* ctx, bool stats);
+// trc_lbvh.hip: stable 24-bit radix sort of (key, value) pairs
+void trc_sort_pairs24(hipStream_t st, uint32_t* keys[2], uint32_t* vals[2], uint32_t* hist, uint32_t* digit_base, uint32_t n, int* result);
+uint32_t trc_sort_hist_words(uint32_t n);
 void trc_sppm_release(trc_ctx* ctx);   // frees ctx->sppm (no-op when absent)

@@ -375,6 +375,23 @@ struct Buffers {
 
 }  // namespace
 
+// stable LSD sort of (key, value) pairs on the 24 low key bits, 3 passes of the radix kernels above; the result is in
+// buffer *result (0 or 1) of the two ping-pong arrays.  hist: 256 * ceil(n / 4096) words, digit_base: 256 words.
+void trc_sort_pairs24(hipStream_t st, uint32_t* keys[2], uint32_t* vals[2], uint32_t* hist, uint32_t* digit_base, uint32_t n, int* result) {
+    const uint32_t n_sort_blocks = (n + kSortTile - 1) / kSortTile;
+    int cur = 0;
+    for (uint32_t shift = 0; shift < 24; shift += 8) {
+        hipLaunchKernelGGL(k_radix_hist, dim3(n_sort_blocks), dim3(kSortBlock), 0, st, keys[cur], n, shift, hist, n_sort_blocks);
+        hipLaunchKernelGGL(k_radix_row_scan, dim3(256), dim3(256), 0, st, hist, n_sort_blocks, digit_base);
+        hipLaunchKernelGGL(k_radix_digit_base, dim3(1), dim3(256), 0, st, digit_base);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(n_sort_blocks), dim3(kSortBlock), 0, st, keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n,
+                           shift, hist, digit_base, n_sort_blocks);
+        cur ^= 1;
+    }
+    *result = cur;
+}
+uint32_t trc_sort_hist_words(uint32_t n) { return 256u * ((n + kSortTile - 1) / kSortTile); }
+
 extern "C" {
 
 trc_status trc_upload_scene_lbvh(trc_ctx* ctx, const trc_scene* s) {
