@@ -47,6 +47,7 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
     uint32_t* stack = stack_base + threadIdx.x;
     uint32_t* lvstack = stack + sc.stack_depth * kBlock;
 
+    const uint64_t t_start = clock64();          // this wavefront's own duration = the next launch's sort key
     const uint32_t canon = kp.order ? kp.order[blockIdx.x] : blockIdx.x;     // adaptive launch order (trc_render)
     const uint32_t tile = kp.tiles[canon];                      // 8x8 block: x | y << 16 in units of 8 pixels
     const uint32_t lane = threadIdx.x;
@@ -131,7 +132,7 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
     // exact work counters: wave reduction, one 64-bit atomic per wave and counter
     uint32_t r_paths = wave_sum(n_paths), r_rays = wave_sum(n_rays), r_shaded = wave_sum(n_shaded);
     if (lane == 0) {
-        kp.block_cost[canon] = r_rays;
+        kp.block_cost[canon] = (uint32_t)min((unsigned long long)((clock64() - t_start) >> 6), 0xFFFFFFull);
         atomicAdd(&kp.stats[kStatPaths], (unsigned long long)r_paths);
         atomicAdd(&kp.stats[kStatRays], (unsigned long long)r_rays);
         atomicAdd(&kp.stats[kStatShaded], (unsigned long long)r_shaded);
@@ -160,7 +161,7 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
     }
 }
 
-// sort keys of the adaptive launch order: descending cost (clamped to 24 bits), ties in list order
+// sort keys of the adaptive launch order: descending cost (shader clocks / 64, clamped to 24 bits), ties in list order
 __global__ void __launch_bounds__(256) k_order_keys(const uint32_t* cost, uint32_t n, uint32_t* keys, uint32_t* vals) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
@@ -702,9 +703,10 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
     kp.block_cost = ctx->d_block_cost;
     kp.order = nullptr;
     if (ctx->cost_valid && !(p->flags & TRC_FLAG_FIXED_ORDER)) {
-        // most expensive blocks of the previous launch first (longest-processing-time order): a block's samples are a
-        // sequential chain, so whatever starts last decides how long the GPU drains; measured 25.2 -> 23.7 ms on
-        // config 2 and 18.7 -> 16.8 ms on the 1 M-triangle scene.  Pixels do not depend on the order.
+        // most expensive blocks of the previous launch first (longest-processing-time order; cost = the wavefront's
+        // measured duration): a block's samples are a sequential chain, so whatever starts last decides how long the GPU
+        // drains.  Measured: config 2 25.2 -> 22.3 ms (ray counts as the key: 23.7), the 1 M-triangle scene 18.7 -> 16.8
+        // ms.  Pixels do not depend on the order.
         const uint32_t n = ctx->n_tiles;
         hipLaunchKernelGGL(k_order_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_block_cost, n, ctx->d_order_keys[0], ctx->d_order_vals[0]);
         int res = 0;

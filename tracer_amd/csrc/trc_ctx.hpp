@@ -34,7 +34,7 @@ struct KRender {
     trc_GridDensityInfo dinfo;
     unsigned long long* stats;          // kStatCount counters
     const uint32_t* order;              // launch order: order[blockIdx.x] = index into `tiles` (null: identity)
-    uint32_t* block_cost;               // rays of each block of `tiles` in this launch (the next launch's sort key)
+    uint32_t* block_cost;               // duration of each block of `tiles` in this launch (the next launch's sort key)
 };
 
 struct KTrace {
@@ -105,7 +105,7 @@ struct trc_ctx {
 
     // tiles for (nranks, rank)
     uint32_t* d_tiles = nullptr;
-    // adaptive launch order: rays per block of the previous launch -> most expensive blocks first in the next one
+    // adaptive launch order: duration of every block in the previous launch -> most expensive blocks first in the next
     uint32_t* d_block_cost = nullptr;
     uint32_t* d_order_keys[2] = {nullptr, nullptr};
     uint32_t* d_order_vals[2] = {nullptr, nullptr};
