@@ -315,10 +315,13 @@ __global__ void __launch_bounds__(256) k_sppm_hash(const trc_PhotonRecord* pho, 
 }
 
 // kernelPhotonSumming, Photon.metal:458-496
+// (grid-stride: 128 workgroups, so the single counter sees 512 atomics per frame instead of 4096 -- they serialise)
 __global__ void __launch_bounds__(256) k_sppm_sum(const uint32_t* count, DComplex* cx) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t c = (i < kHashN * kHashN) ? count[i] : 0u;
-    uint32_t v = c > 0 ? (c > 1u ? c : 1u) : 0u;
+    uint32_t v = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < kHashN * kHashN; i += gridDim.x * blockDim.x) {
+        const uint32_t c = count[i];
+        v += c > 0 ? (c > 1u ? c : 1u) : 0u;
+    }
     v = wave_sum(v);
     if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&cx->frame_photon_sum, v);
 }
@@ -538,7 +541,7 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
         HIP_TRY(ctx, hipMemsetAsync(s->d_mark, 0, (size_t)nph * 4, ctx->stream));     // loadAction clear, :785-790
         HIP_TRY(ctx, hipMemsetAsync(s->d_count, 0, (size_t)nph * 4, ctx->stream));
         hipLaunchKernelGGL(k_sppm_hash, dim3(nph / 256), dim3(256), 0, ctx->stream, s->d_pho, s->d_mark, s->d_count, s->d_cx);
-        hipLaunchKernelGGL(k_sppm_sum, dim3(nph / 256), dim3(256), 0, ctx->stream, s->d_count, s->d_cx);
+        hipLaunchKernelGGL(k_sppm_sum, dim3(128), dim3(256), 0, ctx->stream, s->d_count, s->d_cx);
         hipLaunchKernelGGL(k_sppm_refine, dim3(ctx->n_tiles), dim3(kBlock), 0, ctx->stream, kp);
         hipLaunchKernelGGL(k_sppm_end_frame, dim3(1), dim3(64), 0, ctx->stream, s->d_cx);
         HIP_TRY(ctx, hipGetLastError());
