@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
     const uint32_t W = kp.fr.width, H = kp.fr.height;
     const bool active = px < W && py < H;
 
-    uint32_t n_rays = 0, n_shaded = 0, n_paths = 0, first_mat = 0xFFu;
+    uint32_t n_rays = 0, n_shaded = 0, n_paths = 0;
     TravCounters cnt;
     counters_zero(cnt);
 
@@ -121,7 +121,6 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
             constexpr bool kVolume = INTEGRATOR == TRC_INTEGRATOR_VOLUME;
             const bool hitted = scene_hit<LDS, STATS, false, false, kVolume>(cx.S, cx.root_min, cx.root_max, ps.ray, ps.rec, FLT_MAX,
                                                                         cx.stack, cx.lvstack, cnt);
-            if (ps.primary) first_mat = hitted ? (((ps.rec.tag >> kTagIndexBits) << 6) | (ps.rec.tag & 63u)) & 0xFFu : 0xFFu;   // primitive of the primary hit (no jitter: the same for every sample)
             F3 color;
             const bool finished = (INTEGRATOR == TRC_INTEGRATOR_PATH)
                                       ? path_step<STATS>(cx, ps, hitted, rng, cnt, n_shaded, color)
@@ -135,7 +134,7 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
 
     // exact work counters: wave reduction, one 64-bit atomic per wave and counter
     uint32_t r_paths = wave_sum(n_paths), r_rays = wave_sum(n_rays), r_shaded = wave_sum(n_shaded);
-    if (kp.pixel_cost) kp.pixel_cost[ci] = min(n_rays, 0xFFFFFFu) | (first_mat << 24);   // loop iterations + primary-hit material
+    if (kp.pixel_cost) kp.pixel_cost[ci] = n_rays;             // = loop iterations of this pixel: the next launch's sort key
     if (lane == 0) {
         kp.block_cost[canon] = (uint32_t)min((unsigned long long)((clock64() - t_start) >> 6), 0xFFFFFFull);
         atomicAdd(&kp.stats[kStatPaths], (unsigned long long)r_paths);
@@ -171,19 +170,6 @@ __global__ void __launch_bounds__(256) k_order_keys(const uint32_t* cost, uint32
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     keys[i] = 0xFFFFFFu - min(cost[i], 0xFFFFFFu);
-    vals[i] = i;
-}
-
-// pixel-order keys: longest chains first (rays in steps of 4), then grouped by the primitive of the primary hit, then in
-// list order (stable sort).  Measured per step on config 2: rays alone 20.9 ms; + primitive 20.3; rays in steps of 4 +
-// primitive 19.9; steps of 16: 20.4; primitive first, rays second: 25.4 (the tail returns).
-constexpr uint32_t kPixelKeyShift = 2;
-__global__ void __launch_bounds__(256) k_pixel_keys(const uint32_t* cost, uint32_t n, uint32_t* keys, uint32_t* vals) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t c = cost[i];
-    const uint32_t rays = min((c & 0xFFFFFFu) >> kPixelKeyShift, 0xFFFFu);
-    keys[i] = ((0xFFFFu - rays) << 8) | (c >> 24);
     vals[i] = i;
 }
 
@@ -734,8 +720,7 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
         // Scenes whose tree lives in LDS: sort PIXELS by the rays (= loop iterations) they needed in the previous launch
         // and hand each wavefront 64 consecutive ones.  Lanes of a wavefront then run out of samples at about the same
         // time (16 % of the lane-iterations were dead lanes of finished pixels) and the longest chains start first.
-        // Ties go to pixels whose primary ray hits the same primitive, so the first bounce of such a wavefront is coherent.
-        // Measured on config 2: 21.9 -> 19.9 ms per step including the 2 M-key sort.  Mesh scenes lose more through
+        // Measured on config 2: 21.9 -> 20.9 ms per step including the 2 M-key sort.  Mesh scenes lose more through
         // incoherent memory accesses than they gain (config 3: 485 -> 616 ms), so they keep the block order.
         const uint32_t n = ctx->n_tiles * 64u;
         if (!ctx->d_pixel_cost) {
@@ -746,7 +731,7 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
         }
         kp.pixel_cost = ctx->d_pixel_cost;
         if (ctx->pixel_cost_valid && !(p->flags & TRC_FLAG_FIXED_ORDER)) {
-            hipLaunchKernelGGL(k_pixel_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_pixel_cost, n, ctx->d_pix_keys[0], ctx->d_pix_vals[0]);
+            hipLaunchKernelGGL(k_order_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_pixel_cost, n, ctx->d_pix_keys[0], ctx->d_pix_vals[0]);
             int res = 0;
             trc_sort_pairs24(ctx->stream, ctx->d_pix_keys, ctx->d_pix_vals, ctx->d_pix_hist, ctx->d_pix_hist + trc_sort_hist_words(n), n, &res);
             kp.pixel_order = ctx->d_pix_vals[res];
