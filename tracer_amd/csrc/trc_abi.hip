@@ -48,14 +48,11 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
     uint32_t* lvstack = stack + sc.stack_depth * kBlock;
 
     const uint64_t t_start = clock64();          // this wavefront's own duration = the next launch's sort key
-    const uint32_t lane = threadIdx.x;
     const uint32_t canon = kp.order ? kp.order[blockIdx.x] : blockIdx.x;     // adaptive launch order (trc_render)
-    // LDS-resident scenes: pixel-granular order (trc_render) -- pixel_order[] lists canonical pixel slots (block * 64 + lane)
-    const uint32_t ci = kp.pixel_order ? kp.pixel_order[blockIdx.x * 64u + lane] : canon * 64u + lane;
-    const uint32_t tile = kp.tiles[ci >> 6];                    // 8x8 block: x | y << 16 in units of 8 pixels
-    const uint32_t pl = ci & 63u;
-    const uint32_t px = (tile & 0xFFFFu) * 8u + (pl & 7u);
-    const uint32_t py = (tile >> 16) * 8u + (pl >> 3);
+    const uint32_t tile = kp.tiles[canon];                      // 8x8 block: x | y << 16 in units of 8 pixels
+    const uint32_t lane = threadIdx.x;
+    const uint32_t px = (tile & 0xFFFFu) * 8u + (lane & 7u);
+    const uint32_t py = (tile >> 16) * 8u + (lane >> 3);
     const uint32_t W = kp.fr.width, H = kp.fr.height;
     const bool active = px < W && py < H;
 
@@ -134,7 +131,6 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
 
     // exact work counters: wave reduction, one 64-bit atomic per wave and counter
     uint32_t r_paths = wave_sum(n_paths), r_rays = wave_sum(n_rays), r_shaded = wave_sum(n_shaded);
-    if (kp.pixel_cost) kp.pixel_cost[ci] = n_rays;             // = loop iterations of this pixel: the next launch's sort key
     if (lane == 0) {
         kp.block_cost[canon] = (uint32_t)min((unsigned long long)((clock64() - t_start) >> 6), 0xFFFFFFull);
         atomicAdd(&kp.stats[kStatPaths], (unsigned long long)r_paths);
@@ -405,13 +401,6 @@ size_t trc_dyn_lds_bytes(const trc_ctx* ctx, bool stats) {
     return dwords * 4;
 }
 
-static void trc_free_pixel_order(trc_ctx* ctx) {
-    (void)hipFree(ctx->d_pixel_cost); ctx->d_pixel_cost = nullptr;
-    for (int k = 0; k < 2; ++k) { (void)hipFree(ctx->d_pix_keys[k]); (void)hipFree(ctx->d_pix_vals[k]); ctx->d_pix_keys[k] = ctx->d_pix_vals[k] = nullptr; }
-    (void)hipFree(ctx->d_pix_hist); ctx->d_pix_hist = nullptr;
-    ctx->pixel_cost_valid = false;
-}
-
 trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32_t view_height) {
     if (ctx->d_tiles && ctx->tiles_nranks == nranks && ctx->tiles_rank == rank && ctx->tiles_view_height == view_height) return TRC_OK;
     std::vector<uint32_t> tiles = make_tiles(ctx->width, ctx->height, nranks, rank, view_height);
@@ -429,7 +418,6 @@ trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32
     for (int k = 0; k < 2; ++k) { (void)hipFree(ctx->d_order_keys[k]); (void)hipFree(ctx->d_order_vals[k]); ctx->d_order_keys[k] = ctx->d_order_vals[k] = nullptr; }
     (void)hipFree(ctx->d_order_hist); ctx->d_order_hist = nullptr;
     ctx->cost_valid = false;
-    trc_free_pixel_order(ctx);
     if (ctx->n_tiles) {
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_block_cost, ctx->n_tiles * 4));
         for (int k = 0; k < 2; ++k) {
@@ -516,7 +504,6 @@ void trc_destroy(trc_ctx* ctx) {
     (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_stats); (void)hipFree(ctx->d_reduce_recv);
     (void)hipFree(ctx->d_block_cost); (void)hipFree(ctx->d_order_hist);
     for (int k = 0; k < 2; ++k) { (void)hipFree(ctx->d_order_keys[k]); (void)hipFree(ctx->d_order_vals[k]); }
-    trc_free_pixel_order(ctx);
     (void)hipFree(ctx->d_accum_alt);
     for (hipEvent_t e : {ctx->ev_rendered, ctx->ev_busy, ctx->ev_busy_alt}) if (e) (void)hipEventDestroy(e);
     if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
@@ -715,30 +702,7 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
     kp.stats = ctx->d_stats;
     kp.block_cost = ctx->d_block_cost;
     kp.order = nullptr;
-    kp.pixel_order = nullptr; kp.pixel_cost = nullptr;
-    if (ctx->lds_scene) {
-        // Scenes whose tree lives in LDS: sort PIXELS by the rays (= loop iterations) they needed in the previous launch
-        // and hand each wavefront 64 consecutive ones.  Lanes of a wavefront then run out of samples at about the same
-        // time (16 % of the lane-iterations were dead lanes of finished pixels) and the longest chains start first.
-        // Measured on config 2: 21.9 -> 20.9 ms per step including the 2 M-key sort.  Mesh scenes lose more through
-        // incoherent memory accesses than they gain (config 3: 485 -> 616 ms), so they keep the block order.
-        const uint32_t n = ctx->n_tiles * 64u;
-        if (!ctx->d_pixel_cost) {
-            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_pixel_cost, (size_t)n * 4));
-            for (int k = 0; k < 2; ++k) { HIP_TRY(ctx, hipMalloc((void**)&ctx->d_pix_keys[k], (size_t)n * 4)); HIP_TRY(ctx, hipMalloc((void**)&ctx->d_pix_vals[k], (size_t)n * 4)); }
-            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_pix_hist, (size_t)(trc_sort_hist_words(n) + 256) * 4));
-            ctx->pixel_cost_valid = false;
-        }
-        kp.pixel_cost = ctx->d_pixel_cost;
-        if (ctx->pixel_cost_valid && !(p->flags & TRC_FLAG_FIXED_ORDER)) {
-            hipLaunchKernelGGL(k_order_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_pixel_cost, n, ctx->d_pix_keys[0], ctx->d_pix_vals[0]);
-            int res = 0;
-            trc_sort_pairs24(ctx->stream, ctx->d_pix_keys, ctx->d_pix_vals, ctx->d_pix_hist, ctx->d_pix_hist + trc_sort_hist_words(n), n, &res);
-            kp.pixel_order = ctx->d_pix_vals[res];
-        }
-        ctx->pixel_cost_valid = true;
-    }
-    if (!kp.pixel_order && ctx->cost_valid && !(p->flags & TRC_FLAG_FIXED_ORDER)) {
+    if (ctx->cost_valid && !(p->flags & TRC_FLAG_FIXED_ORDER)) {
         // most expensive blocks of the previous launch first (longest-processing-time order; cost = the wavefront's
         // measured duration): a block's samples are a sequential chain, so whatever starts last decides how long the GPU
         // drains.  Measured: config 2 25.2 -> 22.3 ms (ray counts as the key: 23.7), the 1 M-triangle scene 18.7 -> 16.8

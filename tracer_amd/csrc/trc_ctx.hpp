@@ -34,8 +34,6 @@ struct KRender {
     trc_GridDensityInfo dinfo;
     unsigned long long* stats;          // kStatCount counters
     const uint32_t* order;              // launch order: order[blockIdx.x] = index into `tiles` (null: identity)
-    const uint32_t* pixel_order;        // LDS-resident scenes: launch slot (block * 64 + lane) -> canonical pixel slot
-    uint32_t* pixel_cost;               // rays of every canonical pixel slot in this launch
     uint32_t* block_cost;               // duration of each block of `tiles` in this launch (the next launch's sort key)
 };
 
@@ -113,9 +111,6 @@ struct trc_ctx {
     uint32_t* d_order_vals[2] = {nullptr, nullptr};
     uint32_t* d_order_hist = nullptr;
     bool cost_valid = false;
-    // pixel-granular order of LDS-resident scenes (allocated on first use for the current block list)
-    uint32_t* d_pixel_cost = nullptr; uint32_t* d_pix_keys[2] = {nullptr, nullptr}; uint32_t* d_pix_vals[2] = {nullptr, nullptr};
-    uint32_t* d_pix_hist = nullptr; bool pixel_cost_valid = false;
     uint32_t n_tiles = 0, tiles_nranks = 0, tiles_rank = 0, tiles_view_height = 0;
 
     // stats
