@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256) k_seed(uint32_t* rng, uint32_t n_pixels, 
 // (DESIGN.md 4.1), all `spp` samples fused: RNG texel and accumulator are read and
 // written ONCE per pixel instead of once per sample (64 B/pixel/sample in the reference).
 template <bool LDS, bool STATS, int INTEGRATOR>
-__global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRATOR_VOLUME ? 3 : (INTEGRATOR == TRC_INTEGRATOR_PATH && LDS) ? 5 : 4)) k_render(const KRender kp) {
+__global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRATOR_VOLUME ? 3 : 4)) k_render(const KRender kp) {
     const DScene& sc = kp.ks.sc;
     const uint32_t* small_base = stage_scene(sc);
     uint32_t* stack_base = trc_smem + sc.lds_dwords;
