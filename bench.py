@@ -133,7 +133,7 @@ def main():
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if torch.cuda.is_available():
-        torch.cuda.set_device(local_rank)        # barrier()'s torch.cuda.synchronize() must not touch GPU 0 from every rank
+        torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))        # barrier()'s torch.cuda.synchronize() must not touch GPU 0 from every rank
     dist = None
     grouped = world > 1 or args.force_group
     if grouped:
@@ -145,15 +145,18 @@ def main():
     from tracer_amd import abi, host
     from tracer_amd.device import Tracer, group_unique_id
 
+    # plumbing check on boxes with fewer GPUs than ranks (no RCCL between ranks sharing a GPU): every other part of the
+    # N-rank path -- rendezvous, stacked workload, tile ownership, reductions of the timings -- runs as usual
+    no_rccl = os.environ.get("TRC_BENCH_NO_RCCL") == "1"
     scene = host.HostScene(abi.SCENE_CORNELL_SPHERES)
     cam = host.prepare_camera(W, H)
-    trc = Tracer(local_rank)
+    trc = Tracer(0 if no_rccl else local_rank)
     trc.upload_scene(scene.view)
     trc.set_camera(cam)
     trc.set_environment((0.0, 0.0, 0.0))
     FH = H * world                      # N stacked views
     trc.resize(W, FH)
-    if grouped:
+    if grouped and not no_rccl:
         ids = [group_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
 
@@ -178,7 +181,7 @@ def main():
         trc.seed(SEED)
         trc.render(spp=SPP, max_depth=DEPTH, integrator=abi.INTEGRATOR_PATH, frame0=0, tile_rank=rank,
                    tile_nranks=world, collect_stats=collect_stats, view_height=H)
-        if grouped:
+        if grouped and not no_rccl:
             trc.group_reduce_accum_async(0)   # overlaps with the next step's render (second accumulator + stream)
 
     # exact algorithmic work of ONE step on this rank (instrumented kernel, untimed)
@@ -243,7 +246,8 @@ def main():
 
     def teardown():
         if grouped:
-            trc.group_finalize()
+            if not no_rccl:
+                trc.group_finalize()
             dist.barrier()
             dist.destroy_process_group()
         trc.close()
