@@ -4,6 +4,7 @@ import importlib.util
 import os
 
 import numpy as np
+import pytest
 
 from conftest import ROOT
 from oracle import pyoracle as po
@@ -40,3 +41,24 @@ def test_pmc_traffic_is_read_from_profiles():
     t = bench.pmc_traffic(1)
     assert t is None or (isinstance(t, int) and 50e6 < t < 500e6)     # ~32 B/pixel read + 32 B written at 1080p
     assert bench.pmc_traffic(8) is None
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_path_without_rccl():
+    """bench.py launched the way the driver launches N > 1 (torch.distributed.run), two ranks sharing cuda:0 with the
+    collective switched off (TRC_BENCH_NO_RCCL=1): rendezvous, stacked two-view workload, tile ownership, max-over-ranks
+    timing and the single JSON line on rank 0."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, TRC_BENCH_NO_RCCL="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env, cwd=ROOT, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    line = json.loads(lines[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 2
+    assert "cpu_baseline" not in line                                   # rank 0 at N = 1 only
+    assert line["config"]["rays_per_step"] > 4.3e8                      # two views' worth of rays
+    assert "2 such views" in line["config"]["workload"]
