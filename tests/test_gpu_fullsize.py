@@ -139,3 +139,19 @@ def test_volume_full_frame_through_lbvh(gpu):
     finally:
         po.set_density(None, None)
         gpu.upload_density(None, None)
+
+
+def test_config2_whole_headline_frame_bit_exact(gpu, cornell_spheres):
+    """the exact workload bench.py times -- Cornell + spheres, 1920x1080, 64 spp, tracePath, seed 0x5EED0000 -- every
+    pixel, the RNG texture and the ray count against the oracle (about 10 s of CPU on the GPU box's host cores)"""
+    cam = host.prepare_camera(W, H)
+    gpu.upload_scene(cornell_spheres.view); gpu.set_camera(cam); gpu.set_environment((0.0, 0.0, 0.0)); gpu.resize(W, H)
+    for launch in range(2):                      # the second launch runs in adaptive (expensive-first) order
+        gpu.seed(0x5EED0000); gpu.clear_accum(); gpu.reset_stats()
+        gpu.render(spp=64)
+    dev, dev_rng, st = gpu.download_accum(), gpu.download_rng(), gpu.stats()
+    rng = host.fill_rng(0x5EED0000, W, H)
+    ref, rst = po.render(cornell_spheres.view, cam, W, H, rng, spp=64)
+    assert st.rays == rst.rays == 219978393 and st.paths == W * H * 64
+    assert np.array_equal(dev.view(np.uint32), ref.view(np.uint32))
+    assert np.array_equal(dev_rng, rng)
