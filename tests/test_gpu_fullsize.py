@@ -155,3 +155,39 @@ def test_config2_whole_headline_frame_bit_exact(gpu, cornell_spheres):
     assert st.rays == rst.rays == 219978393 and st.paths == W * H * 64
     assert np.array_equal(dev.view(np.uint32), ref.view(np.uint32))
     assert np.array_equal(dev_rng, rng)
+
+
+@pytest.mark.parametrize("which", ["config3_mis", "config4_path_1m", "volume_lbvh"])
+def test_whole_frames_of_the_other_configurations(gpu, which):
+    """every pixel of a 1920x1080 frame (few samples, so the oracle finishes in seconds) for the mesh, the million-triangle
+    and the participating-media configurations"""
+    density = None
+    if which == "config3_mis":
+        scene, integ, spp = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.ball(153, 153, 0.08)), abi.INTEGRATOR_MIS, 4
+    elif which == "config4_path_1m":
+        scene, integ, spp = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.ball(60, 60, 0.08).replicate(12, 2.4)), abi.INTEGRATOR_PATH, 2
+    else:
+        scene, integ, spp = host.HostScene(abi.SCENE_CORNELL_VOLUME, host.Mesh.ball(60, 60, 0.08)), abi.INTEGRATOR_VOLUME, 2
+        density = host.make_cloud()
+    cam = host.prepare_camera(W, H)
+    view = scene.view
+    if which == "volume_lbvh":
+        gpu.upload_scene_lbvh(scene.leaves_view())
+        tree = gpu.download_bvh()
+        view = scene.view_with_bvh(tree)
+        info = host.density_info(density)
+        gpu.upload_density(info, density); po.set_density(info, density)
+    else:
+        gpu.upload_scene(scene.view)
+    try:
+        gpu.set_camera(cam); gpu.set_environment((0.0, 0.0, 0.0)); gpu.resize(W, H)
+        for launch in range(2):
+            gpu.seed(4242); gpu.clear_accum(); gpu.reset_stats(); gpu.render(spp=spp, integrator=integ)
+        dev, dev_rng, st = gpu.download_accum(), gpu.download_rng(), gpu.stats()
+        rng = host.fill_rng(4242, W, H)
+        ref, rst = po.render(view, cam, W, H, rng, spp=spp, integrator=integ)
+        assert st.rays == rst.rays and st.paths == W * H * spp
+        assert np.array_equal(dev.view(np.uint32), ref.view(np.uint32)) and np.array_equal(dev_rng, rng)
+    finally:
+        po.set_density(None, None)
+        gpu.upload_density(None, None)
