@@ -138,5 +138,18 @@ def test_generated_scene(gpu, seed):
             assert st.rays == rst.rays, (seed, integ)
             assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (seed, integ)
             assert np.array_equal(got_rng, rng)
+        # the same scene through a tree built on the GPU from the leaf records
+        n_leaves = (sv.n_bvh + 1) // 2
+        lv = abi.Scene.from_buffer_copy(sv)
+        lv.bvhList = C.cast(C.addressof(sv.bvhList.contents) + C.sizeof(abi.BVH), C.POINTER(abi.BVH)); lv.n_bvh = n_leaves
+        want, height = po.lbvh_build(lv.bvhList, n_leaves)
+        gpu.upload_scene_lbvh(lv)
+        tree = gpu.download_bvh()
+        assert bytes(memoryview(tree)) == bytes(memoryview(want)) and gpu.lbvh_info()[1] == height
+        tv = abi.Scene.from_buffer_copy(sv); tv.bvhList = C.cast(tree, C.POINTER(abi.BVH)); tv.n_bvh = len(tree)
+        rng = host.fill_rng(90 + seed, W, H)
+        gpu.upload_rng(rng); gpu.clear_accum(); gpu.render(spp=3, integrator=abi.INTEGRATOR_MIS, max_depth=6)
+        ref, _ = po.render(tv, cam, W, H, rng, spp=3, integrator=abi.INTEGRATOR_MIS, max_depth=6, env=(0.3, 0.4, 0.6))
+        assert np.array_equal(gpu.download_accum().view(np.uint32), ref.view(np.uint32)), (seed, "lbvh")
     finally:
         po.set_density(None, None); gpu.upload_density(None, None); gpu.set_environment((0.0, 0.0, 0.0))
