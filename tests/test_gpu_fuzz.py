@@ -153,3 +153,26 @@ def test_generated_scene(gpu, seed):
         assert np.array_equal(gpu.download_accum().view(np.uint32), ref.view(np.uint32)), (seed, "lbvh")
     finally:
         po.set_density(None, None); gpu.upload_density(None, None); gpu.set_environment((0.0, 0.0, 0.0))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_generated_scene_sppm(gpu, seed):
+    """the SPPM pass (Photon.metal) on generated scenes: accumulator, canvas RNG, photon and camera records, hash grids"""
+    rs = np.random.RandomState(3000 + seed)
+    sv, keep = random_scene(rs, n_spheres=int(rs.randint(3, 12)), n_cubes=int(rs.randint(1, 4)), n_tris=int(rs.randint(5, 80)))
+    W, H = 64, 48
+    cam = host.make_camera((rs.uniform(-100, 100), rs.uniform(-60, 60), -160.0), (0, 0, 0), (0, 1, 0), 0.0, W / H, math.radians(50), 160.0)
+    gpu.upload_scene(sv); gpu.set_camera(cam); gpu.set_environment((0.0, 0.0, 0.0)); gpu.resize(W, H)
+    gpu.seed(8); gpu.clear_accum(); gpu.sppm_init(40 + seed); gpu.sppm_frames(3)
+    dcam, dpho, dmark, dcount, dcx = gpu.sppm_download()
+    dacc, drng = gpu.download_accum(), gpu.download_rng()
+    rng = host.fill_rng(8, W, H); acc = np.zeros((H, W, 4), np.float32)
+    o = po.Sppm(W, H, 40 + seed); o.frames(sv, cam, rng, acc, 3)
+    ocam, opho, omark, ocount, ocx = o.download()
+    assert np.array_equal(drng, rng) and np.array_equal(dacc.view(np.uint32), acc.view(np.uint32))
+    assert np.array_equal(dcount, ocount) and np.array_equal(dmark, omark)
+    for f in ("flux", "normal", "position", "direction", "step", "active"):
+        assert bytes(memoryview(np.ascontiguousarray(dpho[f]))) == bytes(memoryview(np.ascontiguousarray(opho[f]))), f
+    for f in ("ratio", "position", "direction", "valid", "alternative", "flux", "radius", "photonCount"):
+        assert bytes(memoryview(np.ascontiguousarray(dcam[f]))) == bytes(memoryview(np.ascontiguousarray(ocam[f]))), f
+    assert dcx.frame_count == ocx.frame_count and dcx.totalPhotonSum == ocx.totalPhotonSum
