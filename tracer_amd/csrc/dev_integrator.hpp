@@ -93,6 +93,7 @@ struct PathCtx {
     // traceVolume: density grid of the GridDensity medium (PackageEnv ids 3/4, Render.hh:30-31); null when absent
     const float* density;
     trc_GridDensityInfo dinfo;
+    const uint8_t* occupancy;     // 1 byte per 4x4x4 brick of the grid: 0 = every cell a lookup inside could touch is zero
 };
 
 // ---------------------------------------------------------------- path state machine
@@ -246,7 +247,21 @@ TRC_DEV float grid_sample(const PathCtx& cx, const HitRec& rec, MediumHit& mi, P
         t -= dm_logf(1 - pcg_float(rng)) * info.invMaxDensity / info.sigma_t;
         if (t >= tMax) break;
         const F3 p = rec.vol_o + rec.vol_d * t;
-        if (grid_density(info, cx.density, p) * info.invMaxDensity > pcg_float(rng)) {
+        // empty-space shortcut: a lookup whose 2x2x2 footprint lies in an all-zero brick interpolates zeros to +0 (a
+        // majorant-only "null collision"), so the 8 gathers and 7 lerps are skipped; the random number is still drawn
+        float dens = 0.0f;
+        {
+            const int ix = grid_to_int(floorf(p.x * (float)info.nx - 0.5f)), iy = grid_to_int(floorf(p.y * (float)info.ny - 0.5f)),
+                      iz = grid_to_int(floorf(p.z * (float)info.nz - 0.5f));
+            bool occupied = true;
+            if (cx.occupancy) {
+                const int bx = (ix + 1) >> 2, by = (iy + 1) >> 2, bz = (iz + 1) >> 2;
+                const int nbx = ((int)info.nx + 4) >> 2, nby = ((int)info.ny + 4) >> 2, nbz = ((int)info.nz + 4) >> 2;
+                occupied = (ix >= -1 && iy >= -1 && iz >= -1 && bx < nbx && by < nby && bz < nbz) ? cx.occupancy[((size_t)bz * nby + by) * nbx + bx] != 0 : false;
+            }
+            if (occupied) dens = grid_density(info, cx.density, p);
+        }
+        if (dens * info.invMaxDensity > pcg_float(rng)) {
             F3 world = p;
             if (rec.vol_cube != kTagNone) {                        // hitRecord.modelMatrix * float4(p, 1)
                 const uint32_t* cb = cx.S.small_base + cx.S.off_cubes + rec.vol_cube * kCubeDwords;

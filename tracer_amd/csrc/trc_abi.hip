@@ -73,6 +73,7 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
         cx.max_depth = kp.max_depth;
         cx.density = kp.density;
         cx.dinfo = kp.dinfo;
+        cx.occupancy = kp.occupancy;
 
         const size_t pix = (size_t)py * W + px;
         uint4 texel = reinterpret_cast<const uint4*>(kp.fr.rng)[pix];       // r, g, b, a
@@ -500,7 +501,7 @@ void trc_destroy(trc_ctx* ctx) {
     trc_sppm_release(ctx);
     collect_events(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
-    (void)hipFree(ctx->d_blob); (void)hipFree(ctx->d_bvh_ref); (void)hipFree(ctx->d_density); (void)hipFree(ctx->d_envmap); (void)hipFree(ctx->d_rng); (void)hipFree(ctx->d_accum);
+    (void)hipFree(ctx->d_blob); (void)hipFree(ctx->d_bvh_ref); (void)hipFree(ctx->d_density); (void)hipFree(ctx->d_occupancy); (void)hipFree(ctx->d_envmap); (void)hipFree(ctx->d_rng); (void)hipFree(ctx->d_accum);
     (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_stats); (void)hipFree(ctx->d_reduce_recv);
     (void)hipFree(ctx->d_block_cost); (void)hipFree(ctx->d_order_hist);
     for (int k = 0; k < 2; ++k) { (void)hipFree(ctx->d_order_keys[k]); (void)hipFree(ctx->d_order_vals[k]); }
@@ -539,6 +540,7 @@ trc_status trc_upload_density(trc_ctx* ctx, const trc_GridDensityInfo* info, con
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     (void)hipFree(ctx->d_density); ctx->d_density = nullptr;
+    (void)hipFree(ctx->d_occupancy); ctx->d_occupancy = nullptr;
     ctx->dinfo = trc_GridDensityInfo{};
     if (!info && !density) return TRC_OK;                                  // cleared
     if (!info || !density || info->nx == 0 || info->ny == 0 || info->nz == 0) return fail(ctx, TRC_ERR_INVALID_ARG, "trc_upload_density: empty grid");
@@ -546,6 +548,24 @@ trc_status trc_upload_density(trc_ctx* ctx, const trc_GridDensityInfo* info, con
     if (count > (1ull << 31)) return fail(ctx, TRC_ERR_UNSUPPORTED, "trc_upload_density: more than 2^31 cells");
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_density, count * sizeof(float)));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_density, density, count * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    // occupancy of 4x4x4 bricks: brick b covers lookups whose base cell i = floor(p*n - 0.5) has (i + 1) >> 2 == b, i.e.
+    // the cells 4b-1 .. 4b+3 and their +1 neighbours; nonzero = any of them holds a value other than +0
+    const int nx = (int)info->nx, ny = (int)info->ny, nz = (int)info->nz;
+    const int nbx = (nx + 4) >> 2, nby = (ny + 4) >> 2, nbz = (nz + 4) >> 2;
+    std::vector<uint8_t> occ((size_t)nbx * nby * nbz, 0);
+    for (int z = 0; z < nz; ++z)
+        for (int y = 0; y < ny; ++y)
+            for (int x = 0; x < nx; ++x) {
+                const float v = density[((size_t)z * ny + y) * nx + x];
+                uint32_t bits; std::memcpy(&bits, &v, 4);
+                if (bits == 0u) continue;                                   // exactly +0: interpolates to +0
+                // cell c is touched by base cells c-1 and c: bricks (c >> 2) and ((c + 1) >> 2)
+                for (int bz = z >> 2; bz <= (z + 1) >> 2; ++bz)
+                    for (int by = y >> 2; by <= (y + 1) >> 2; ++by)
+                        for (int bx = x >> 2; bx <= (x + 1) >> 2; ++bx) occ[((size_t)bz * nby + by) * nbx + bx] = 1;
+            }
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_occupancy, occ.size()));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_occupancy, occ.data(), occ.size(), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->dinfo = *info;
     return TRC_OK;
@@ -716,6 +736,7 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
     ctx->cost_valid = true;
     kp.density = ctx->d_density;
     kp.dinfo = ctx->dinfo;
+    kp.occupancy = ctx->d_occupancy;
 
     hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);
     if (!e0 || !e1) return fail(ctx, TRC_ERR_HIP, "hipEventCreate failed");

@@ -32,6 +32,7 @@ struct KRender {
     const uint32_t* tiles;              // tx | ty << 16, one per workgroup
     const float* density;               // traceVolume: GridDensity medium grid (null when absent)
     trc_GridDensityInfo dinfo;
+    const uint8_t* occupancy;           // ... and its 4x4x4-brick occupancy (dev_integrator.hpp::grid_sample)
     unsigned long long* stats;          // kStatCount counters
     const uint32_t* order;              // launch order: order[blockIdx.x] = index into `tiles` (null: identity)
     uint32_t* block_cost;               // duration of each block of `tiles` in this launch (the next launch's sort key)
@@ -91,6 +92,7 @@ struct trc_ctx {
     uint32_t n_bvh_ref = 0, lbvh_height = 0;
     float lbvh_build_ms = 0.0f;
     float* d_density = nullptr;      // GridDensity medium (trc_upload_density)
+    uint8_t* d_occupancy = nullptr;
     trc_GridDensityInfo dinfo{};
 
     bool has_camera = false;
