@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""A/B of two (or more) builds of libtracer_amd.so on the same box: box-to-box variance between gpurun calls is
++-2.5 %, more than most kernel changes, so the variants are timed alternately (A B A B ...) in child processes.
+
+    python tools/ab_bench.py [--config 2|3|4|volume] [--rounds 3] libA.so libB.so ...
+
+Each child loads exactly one library (device.lib_path is pointed at it before the first call), warms the adaptive
+launch order up, then reports the mean kernel time of `--steps` launches."""
+import argparse, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def child(path, config, steps):
+    from tracer_amd import abi, host, device
+    device.lib_path = lambda: os.path.abspath(path)
+    W, H = 1920, 1080
+    integrator, spp = abi.INTEGRATOR_PATH, 64
+    if config == "2":
+        sc = host.HostScene(abi.SCENE_CORNELL_SPHERES)
+    elif config == "3":
+        sc = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.ball(153, 153, 0.08))
+        integrator, spp = abi.INTEGRATOR_MIS, 32
+    elif config == "4":
+        sc = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.ball(60, 60, 0.08).replicate(12, 2.4))
+        spp = 32
+    else:
+        sc = host.HostScene(abi.SCENE_CORNELL_VOLUME, host.Mesh.ball(153, 153, 0.08))
+        integrator, spp = abi.INTEGRATOR_VOLUME, 16
+    t = device.Tracer(0)
+    t.upload_scene(sc.view)
+    if config == "volume":
+        cloud = host.make_cloud()
+        t.upload_density(host.density_info(cloud), cloud)
+    t.set_camera(host.prepare_camera(W, H)); t.resize(W, H)
+    for i in range(3):
+        t.seed(0x5EED0000 + i); t.clear_accum(); t.render(spp=spp, integrator=integrator)
+    t.synchronize(); t.reset_stats()
+    for i in range(steps):
+        t.seed(0x5EED0100 + i); t.clear_accum(); t.render(spp=spp, integrator=integrator)
+    t.synchronize()
+    s = t.stats()
+    print(f"{s.kernel_ms / steps:.3f} {s.rays / steps:.0f}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="2")
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--child", default=None)
+    ap.add_argument("libs", nargs="*")
+    a = ap.parse_args()
+    if a.child:
+        child(a.child, a.config, a.steps)
+        return
+    res = {p: [] for p in a.libs}
+    for r in range(a.rounds):
+        for p in a.libs:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", p, "--config", a.config,
+                                  "--steps", str(a.steps)], capture_output=True, text=True, timeout=600)
+            if out.returncode != 0:
+                print(p, "FAILED", out.stderr[-400:]); continue
+            res[p].append(float(out.stdout.split()[0]))
+    for p, v in res.items():
+        if v:
+            print(f"{p}: " + " ".join(f"{x:.3f}" for x in v) + f"  | min {min(v):.3f} mean {sum(v) / len(v):.3f} ms")
+
+
+if __name__ == "__main__":
+    main()
