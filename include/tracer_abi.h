@@ -246,6 +246,14 @@ enum trc_integrator {
 /* flags */
 #define TRC_FLAG_FIXED_ORDER    2u  /* launch the pixel blocks in list order instead of "most expensive block of the
                                        previous launch first" (a scheduling choice only: pixels are independent) */
+#define TRC_FLAG_SOBOL          4u  /* XSampler = pbrt::SobolSampler, wired as the reference's commented-out lines do
+                                       (Render.metal:529-530): castRay still draws from the pixel's PCG stream; the
+                                       sampler is built afterwards from a COPY of that stream, the frame number and
+                                       the pixel; sample2D() (the BSDF sample of every bounce) takes successive Sobol
+                                       dimensions of the pixel's sample, random() (light pick, Russian roulette)
+                                       draws from the copy, and the texel keeps the stream as castRay left it.
+                                       TRC_INTEGRATOR_PATH / _MIS only, 2 * max_depth <= 40 dimensions; with
+                                       view_height the sampler sees the pixel and size of its own view. */
 #define TRC_FLAG_COLLECT_STATS  1u  /* run the instrumented kernel variant: exact
                                        N_descend / N_return / leaf-test counters */
 
@@ -493,6 +501,13 @@ void trc_host_free(void* p);
 /* "Export as PNG file" (the reference's unchecked to-do, RT_Metal/README.md:61): 8-bit RGBA, rows top-down,
  * stored (uncompressed) deflate blocks -- no zlib dependency */
 trc_status trc_host_write_png(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height);
+
+/* Tables of pbrt::SobolSampler (SobolSampler.hh:126-160), generated by include/trc_sobol.h from the published
+ * direction numbers instead of being stored: SobolMatrices32 for the first TRC_SOBOL_DIMS (40) dimensions
+ * (out[dim * 52 + column]) and VdCSobolMatrices[log2res - 1] / VdCSobolMatricesInv[log2res - 1] (52 words each,
+ * unused entries 0; 1 <= log2res <= 26).  libtracer_amd.so builds the same tables itself for TRC_FLAG_SOBOL. */
+void       trc_host_sobol_matrices32(uint32_t* out /* [40 * 52] */);
+trc_status trc_host_sobol_interval_tables(uint32_t log2res, uint64_t* vdc /* [52] */, uint64_t* inv /* [52] */);
 
 /* minimal Wavefront OBJ reader (v / vn / vt / f; polygons fan-triangulated;
  * smooth normals generated when the file has none), standing in for ModelIO

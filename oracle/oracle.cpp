@@ -1,7 +1,7 @@
 // oracle.cpp -- CPU oracle: scalar restatement of RT_Metal's path-tracing hot path.
 //
-// TEST INFRASTRUCTURE ONLY (see oracle.h).  PARITY PIN STATUS: unpinned beyond PCG32 --
-// the reference has no tests/goldens for this path and cannot be built here.
+// TEST INFRASTRUCTURE ONLY (see oracle.h).  PARITY PIN STATUS: unpinned beyond PCG32 and the
+// Sobol' tables (tests/test_sobol.py) -- the reference has no tests/goldens for this path and cannot be built here.
 //
 // Conventions that resolve what Metal leaves unspecified (the HIP path uses the same ones):
 //   * all arithmetic is IEEE-754 binary32, no FMA contraction (-ffp-contract=off);
@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "trc_detmath.h"
+#include "trc_sobol.h"
 
 namespace {
 
@@ -127,6 +128,76 @@ struct RandomSampler {
         float inv = 1.0f / sqrtf(p.x * p.x + p.y * p.y);     // normalize(p): on the unit circle (B-2)
         return V2{p.x * inv, p.y * inv};
     }
+};
+
+// ---------------------------------------------------------------- SobolSampler.hh
+// pbrt::SobolSampler as the reference declares it (SobolSampler.hh:26-167); its tables come from
+// include/trc_sobol.h (generated, pinned to the reference's by tests/test_sobol.py).
+struct SobolTables {
+    uint32_t m32[TRC_SOBOL_DIMS * TRC_SOBOL_MATRIX_SIZE];
+    uint64_t vdc[TRC_SOBOL_MAX_LOG2RES][TRC_SOBOL_MATRIX_SIZE], inv[TRC_SOBOL_MAX_LOG2RES][TRC_SOBOL_MATRIX_SIZE];
+    SobolTables() {
+        trc_sobol_matrices32(m32);
+        for (uint32_t m = 1; m <= TRC_SOBOL_MAX_LOG2RES; ++m) trc_sobol_interval_tables(m, vdc[m - 1], inv[m - 1]);
+    }
+};
+inline const SobolTables& sobol_tables() { static const SobolTables t; return t; }
+
+inline uint32_t RoundUpPow2(uint32_t v) {                            // Math.hh:102-112
+    v--;
+    v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16;
+    return v + 1;
+}
+inline int PBRT_Log2Int(uint32_t v) { return 31 - __builtin_clz(v); }   // Math.hh:81-83 (v != 0)
+
+// SobolSampler.hh:126-148
+inline uint64_t SobolIntervalToIndex(const uint32_t m, uint64_t sampleIndex, uint32_t px, uint32_t py) {
+    if (m == 0) return 0;
+    const SobolTables& T = sobol_tables();
+    const uint32_t m2 = m << 1;
+    uint64_t index = sampleIndex << m2;
+    uint64_t delta = 0;
+    for (int c = 0; sampleIndex; sampleIndex >>= 1, ++c)
+        if (sampleIndex & 1) delta ^= T.vdc[m - 1][c];
+    uint64_t b = (((uint64_t)px << m) | (uint32_t)py) ^ delta;
+    for (int c = 0; b; b >>= 1, ++c)
+        if (b & 1) index ^= T.inv[m - 1][c];
+    return index;
+}
+// SobolSampler.hh:154-164 (scramble 0).  The reference walks on into the next dimension's columns when the index
+// has more than 52 bits; indices here stay below 2^52 (frame < 2^(52 - 2m)).
+inline float SobolSampleFloat(uint64_t index, uint32_t dimension) {
+    const SobolTables& T = sobol_tables();
+    uint32_t v = 0;
+    for (uint32_t i = dimension * TRC_SOBOL_MATRIX_SIZE; index != 0; index >>= 1, i++)
+        if (index & 1) v ^= T.m32[i];
+    return fminf((float)v * 2.3283064365386963e-10f, 1.0f - FLT_EPSILON);
+}
+
+struct SobolSampler {
+    pcg32_t rng;                                   // a COPY of the pixel's stream (SobolSampler.hh:30,50)
+    uint32_t xy[2];
+    uint32_t resolution, log2Resolution;
+    uint64_t mSampleIndex, mSobolIndex;
+    uint32_t mDimension;
+    SobolSampler(const pcg32_t& r, uint32_t frame, uint32_t x, uint32_t y, uint32_t w, uint32_t h)   // :50-61
+        : rng(r), xy{x, y}, mSampleIndex(frame), mDimension(0) {
+        resolution = RoundUpPow2(w > h ? w : h);
+        log2Resolution = (uint32_t)PBRT_Log2Int(resolution);
+        mSobolIndex = SobolIntervalToIndex(log2Resolution, mSampleIndex, xy[0], xy[1]);
+    }
+    float random() { return randomF(&rng); }                                     // :46-48
+    float SampleDimension(uint64_t index, uint32_t dimension) const {            // :152-163
+        if (dimension >= TRC_SOBOL_DIMS) return 0;     // NumSobolDimensions: 1024 there, 40 generated here
+        float s = SobolSampleFloat(index, dimension);
+        if (dimension <= 1) {
+            s = s * (float)resolution + 0.0f;
+            s = fminf(fmaxf(s - (float)xy[dimension], 0.0f), 1.0f - FLT_EPSILON);   // clamp
+        }
+        return s;
+    }
+    float sample1D() { return SampleDimension(mSobolIndex, mDimension++); }      // :63-65
+    V2 sample2D() { float a = sample1D(); float b = sample1D(); return V2{a, b}; }
 };
 
 // ---------------------------------------------------------------- Math.hh
@@ -1037,7 +1108,8 @@ inline V3 env_radiance(const Env& env, const V3& direction) {
 }
 
 // Render.metal:411-492
-V3 tracePath(int depth, Ray& ray, RandomSampler& xsampler, const Env& env, Scene& scene, Counters* cnt) {
+template <class XSampler>
+V3 tracePath(int depth, Ray& ray, XSampler& xsampler, const Env& env, Scene& scene, Counters* cnt) {
     HitRecord hitRecord;
     V3 ratio = v3(1.0f);
     V3 color = v3(0.0f);
@@ -1082,7 +1154,8 @@ V3 tracePath(int depth, Ray& ray, RandomSampler& xsampler, const Env& env, Scene
 }
 
 // Render.metal:277-409
-V3 traceMIS(int depth, Ray& ray, RandomSampler& xsampler, const Env& env, Scene& scene, Counters* cnt) {
+template <class XSampler>
+V3 traceMIS(int depth, Ray& ray, XSampler& xsampler, const Env& env, Scene& scene, Counters* cnt) {
     HitRecord hitRecord;
     V3 scat_attenuation = v3(0); float scat_bxPDF = 1.0f;
     V3 ratio = v3(1.0f);
@@ -1399,7 +1472,14 @@ void render_pixel(const trc_scene& prims, const trc_Camera* camera, const Env& e
         float v = (float)(y % vh) / (float)vh;
         RandomSampler rs{&rng};
         Ray ray = castRay(camera, u, v, &rs);
-        V3 color = (prm.integrator == TRC_INTEGRATOR_VOLUME) ? traceVolume((int)prm.max_depth, ray, rs, env, scene, cnt)
+        V3 color;
+        if ((prm.flags & TRC_FLAG_SOBOL) && prm.integrator != TRC_INTEGRATOR_VOLUME) {
+            // Render.metal:529-530 (commented out there): built AFTER castRay, from a copy of rng; tracePath(8, ray, ss, ...)
+            SobolSampler ss(rng, frame, x, y % vh, W, vh);
+            color = (prm.integrator == TRC_INTEGRATOR_MIS) ? traceMIS((int)prm.max_depth, ray, ss, env, scene, cnt)
+                                                           : tracePath((int)prm.max_depth, ray, ss, env, scene, cnt);
+        } else
+        color = (prm.integrator == TRC_INTEGRATOR_VOLUME) ? traceVolume((int)prm.max_depth, ray, rs, env, scene, cnt)
                    : (prm.integrator == TRC_INTEGRATOR_MIS)  ? traceMIS((int)prm.max_depth, ray, rs, env, scene, cnt)
                                                              : tracePath((int)prm.max_depth, ray, rs, env, scene, cnt);
         bool bad = std::isinf(color.x) || std::isnan(color.x) || std::isinf(color.y) || std::isnan(color.y) ||
@@ -1901,6 +1981,15 @@ void orc_offset_ray(const float p[3], const float n[3], float out[3]) {
 float orc_fr_dielectric(float cosi, float eta) { return FrDielectric(cosi, eta); }
 void orc_fr_conductor(float cosi, const float eta[3], const float k[3], float out[3]) {
     V3 r = FrConductor(cosi, v3a(eta), v3a(k)); out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+uint64_t orc_sobol_interval_to_index(uint32_t m, uint64_t sample_index, uint32_t px, uint32_t py) {
+    return SobolIntervalToIndex(m, sample_index, px, py);
+}
+float orc_sobol_sample_float(uint64_t index, uint32_t dimension) { return SobolSampleFloat(index, dimension); }
+float orc_sobol_sample_dimension(uint32_t frame, uint32_t x, uint32_t y, uint32_t w, uint32_t h, uint32_t dimension) {
+    pcg32_t none{0, 1};
+    SobolSampler ss(none, frame, x, y, w, h);
+    return ss.SampleDimension(ss.mSobolIndex, dimension);
 }
 float orc_power_heuristic(int nf, float fPdf, int ng, float gPdf) { return PowerHeuristic(nf, fPdf, ng, gPdf); }
 void orc_cosine_sample_hemisphere(const float u[2], float out[3]) {

@@ -59,6 +59,11 @@ void  orc_material_F(const trc_Material* m, const float wo[3], const float wi[3]
                      const float uu[2], float f_out[3], float* pdf_out);
 float orc_material_PDF(const trc_Material* m, const float wo[3], const float wi[3], const float uu[2]);
 
+/* pbrt::SobolSampler (SobolSampler.hh:126-163) over the generated tables of include/trc_sobol.h */
+uint64_t orc_sobol_interval_to_index(uint32_t log2res, uint64_t sample_index, uint32_t px, uint32_t py);
+float    orc_sobol_sample_float(uint64_t index, uint32_t dimension);
+float    orc_sobol_sample_dimension(uint32_t frame, uint32_t x, uint32_t y, uint32_t w, uint32_t h, uint32_t dimension);
+
 /* small pieces for known-answer tests */
 void  orc_offset_ray(const float p[3], const float n[3], float out[3]);                 /* Math.hh:57-74 */
 float orc_fr_dielectric(float cosi, float eta);                                          /* BXDF.metal:3-22 */

@@ -51,6 +51,12 @@ def lib(libm=False):
         L.orc_fr_conductor.restype = None
         L.orc_power_heuristic.argtypes = [C.c_int, C.c_float, C.c_int, C.c_float]
         L.orc_power_heuristic.restype = C.c_float
+        L.orc_sobol_interval_to_index.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32]
+        L.orc_sobol_interval_to_index.restype = C.c_uint64
+        L.orc_sobol_sample_float.argtypes = [C.c_uint64, C.c_uint32]
+        L.orc_sobol_sample_float.restype = C.c_float
+        L.orc_sobol_sample_dimension.argtypes = [C.c_uint32] * 6
+        L.orc_sobol_sample_dimension.restype = C.c_float
         L.orc_cosine_sample_hemisphere.argtypes = [f3, f3]
         L.orc_cosine_sample_hemisphere.restype = None
         L.orc_erf.argtypes = [C.c_float]
@@ -124,14 +130,15 @@ def trace_rays(scene_view, rays, any_hit=False, brute=False, libm=False):
 
 
 def render(scene_view, camera, width, height, rng, accum=None, spp=1, max_depth=8, integrator=0, frame0=0,
-           env=(0.0, 0.0, 0.0), tile_rank=0, tile_nranks=1, n_threads=0, libm=False, view_height=0):
+           env=(0.0, 0.0, 0.0), tile_rank=0, tile_nranks=1, n_threads=0, libm=False, view_height=0, sobol=False):
     """kernelPathTracing on the CPU.  rng: (H,W,4) uint32, updated in place.  Returns (accum, stats)."""
     assert rng.dtype == np.uint32 and rng.shape == (height, width, 4) and rng.flags.c_contiguous
     if accum is None:
         accum = np.zeros((height, width, 4), dtype=np.float32)
     assert accum.dtype == np.float32 and accum.shape == (height, width, 4) and accum.flags.c_contiguous
     prm = abi.Params(spp=spp, max_depth=max_depth, integrator=integrator, frame0=frame0,
-                     tile_rank=tile_rank, tile_nranks=tile_nranks, flags=abi.FLAG_COLLECT_STATS, view_height=view_height)
+                     tile_rank=tile_rank, tile_nranks=tile_nranks,
+                     flags=abi.FLAG_COLLECT_STATS | (abi.FLAG_SOBOL if sobol else 0), view_height=view_height)
     stats = abi.Stats()
     env_c = (C.c_float * 3)(*env)
     lib(libm).orc_render(C.byref(scene_view), C.byref(camera), env_c, width, height, rng.ctypes.data,

@@ -6,6 +6,7 @@
 
 #include "dev_bsdf.hpp"
 #include "dev_intersect.hpp"
+#include "trc_sobol.h"
 
 namespace trcdev {
 
@@ -94,6 +95,11 @@ struct PathCtx {
     const float* density;
     trc_GridDensityInfo dinfo;
     const uint8_t* occupancy;     // 1 byte per 4x4x4 brick of the grid: 0 = every cell a lookup inside could touch is zero
+    // TRC_FLAG_SOBOL: tables of include/trc_sobol.h (null otherwise)
+    const uint32_t* sobol32;      // [40][52] generator matrices
+    const uint64_t* sobol_vdc;    // [52] VdCSobolMatrices[m - 1], then [52] VdCSobolMatricesInv[m - 1]
+    uint32_t sobol_m, sobol_res;  // log2Resolution, resolution (SobolSampler.hh:56-58)
+    uint32_t sobol_xy[2];         // thread_pos within its view
 };
 
 // ---------------------------------------------------------------- path state machine
@@ -113,7 +119,52 @@ struct PathState {
     bool primary;            // the ray in flight is the camera ray
     int medium;              // traceVolume: Ray::medium (Ray.hh:18) of the ray in flight
     bool from_bsdf;          // traceVolume: the ray in flight left the BSDF-sampling branch (Render.metal:255-271 applies)
+    uint64_t sobol_index;    // TRC_FLAG_SOBOL: mSobolIndex of this sample and the next dimension (SobolSampler.hh:37-41)
+    uint32_t sobol_dim;
 };
+
+// ---------------------------------------------------------------- pbrt::SobolSampler (SobolSampler.hh:26-167)
+// SobolIntervalToIndex, :126-148
+TRC_DEV uint64_t sobol_interval_to_index(const PathCtx& cx, uint64_t sampleIndex) {
+    const uint32_t m = cx.sobol_m;
+    if (m == 0) return 0;
+    uint64_t index = sampleIndex << (m << 1);
+    uint64_t delta = 0;
+    for (int c = 0; sampleIndex; sampleIndex >>= 1, ++c)
+        if (sampleIndex & 1) delta ^= cx.sobol_vdc[c];
+    uint64_t b = (((uint64_t)cx.sobol_xy[0] << m) | cx.sobol_xy[1]) ^ delta;
+    for (int c = 0; b; b >>= 1, ++c)
+        if (b & 1) index ^= cx.sobol_vdc[TRC_SOBOL_MATRIX_SIZE + c];
+    return index;
+}
+// SampleDimension, :152-163 over SobolSampleFloat, :150-160 (the column walk stops at 52 columns: indices stay
+// below 2^52, see oracle/oracle.cpp SobolSampleFloat)
+TRC_DEV float sobol_dimension(const PathCtx& cx, uint64_t index, uint32_t dimension) {
+    if (dimension >= TRC_SOBOL_DIMS) return 0;
+    uint32_t v = 0;
+    const uint32_t* col = cx.sobol32 + dimension * TRC_SOBOL_MATRIX_SIZE;
+    for (; index != 0; index >>= 1, ++col)
+        if (index & 1) v ^= *col;
+    float s = fminf((float)v * 2.3283064365386963e-10f, 1.0f - FLT_EPSILON);
+    if (dimension <= 1) {
+        s = s * (float)cx.sobol_res + 0.0f;
+        s = fminf(fmaxf(s - (float)(dimension == 0 ? cx.sobol_xy[0] : cx.sobol_xy[1]), 0.0f), 1.0f - FLT_EPSILON);
+    }
+    return s;
+}
+// XSampler::sample2D(): RandomSampler.hh:19-24 or SobolSampler.hh:67-72
+template <bool SOBOL>
+TRC_DEV F2 sample_2d(const PathCtx& cx, PathState& ps, Pcg& rng) {
+    F2 uu;
+    if (SOBOL) {
+        uu.x = sobol_dimension(cx, ps.sobol_index, ps.sobol_dim++);
+        uu.y = sobol_dimension(cx, ps.sobol_index, ps.sobol_dim++);
+    } else {
+        uu.x = pcg_float(rng);
+        uu.y = pcg_float(rng);
+    }
+    return uu;
+}
 
 TRC_DEV void path_begin(PathState& ps, const Ray& camera_ray, uint32_t max_depth) {
     ps.ray = camera_ray;
@@ -130,7 +181,7 @@ TRC_DEV void path_begin(PathState& ps, const Ray& camera_ray, uint32_t max_depth
 
 // What happens between two Scene::hit calls of tracePath (Render.metal:432-489).  Returns true when the
 // path is finished; `result` is then the sample's radiance.
-template <bool STATS>
+template <bool STATS, bool SOBOL = false>
 TRC_DEV bool path_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, TravCounters& cnt, uint32_t& n_shaded, F3& result) {
     if (!ps.primary) {                                               // } while ((--depth) > 0), :489
         if (--ps.depth_left <= 0) { result = ps.color; return true; }
@@ -145,7 +196,7 @@ TRC_DEV bool path_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, 
         result = ps.ratio * le * fabsf(w);
         return true;
     }
-    F2 uu; uu.x = pcg_float(rng); uu.y = pcg_float(rng);             // sample2D, :447
+    const F2 uu = sample_2d<SOBOL>(cx, ps, rng);                     // sample2D, :447
     const F3 hit_origin = rec.p;
     F3 _origin = offset_ray(rec.p, rec.sn);
     F3 nx, ny;
@@ -281,7 +332,7 @@ TRC_DEV float grid_sample(const PathCtx& cx, const HitRec& rec, MediumHit& mi, P
 // Same for traceMIS (Render.metal:298-406) and, with VOLUME, traceVolume (Render.metal:78-275 = traceMIS + the
 // medium block :114-158).  Lights are literally squareList[5] and [6] (:320-324, B-12).
 // The shadow ray (any-hit Scene::hit) is traced here, inside the step.
-template <bool ALL_LDS, bool STATS, bool VOLUME = false>
+template <bool ALL_LDS, bool STATS, bool VOLUME = false, bool SOBOL = false>
 TRC_DEV bool mis_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, TravCounters& cnt, uint32_t& n_rays,
                       uint32_t& n_shaded, F3& result) {
     HitRec& rec = ps.rec;
@@ -336,7 +387,7 @@ TRC_DEV bool mis_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, T
         ps.from_bsdf = true;
     }
     LightSample lsr;
-    F2 uu; uu.x = pcg_float(rng); uu.y = pcg_float(rng);
+    const F2 uu = sample_2d<SOBOL>(cx, ps, rng);                     // :314
     const F3 hit_origin = rec.p;
     F3 _origin = offset_ray(rec.p, rec.sn);
     if (pcg_float(rng) < 0.5f) square_sample(cx.S, 5, uu, _origin, lsr);

@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256) k_seed(uint32_t* rng, uint32_t n_pixels, 
 // kernelPathTracing, Render.metal:495-558.  One lane per pixel, one one-wavefront workgroup per 8x8 pixel block
 // (DESIGN.md 4.1), all `spp` samples fused: RNG texel and accumulator are read and
 // written ONCE per pixel instead of once per sample (64 B/pixel/sample in the reference).
-template <bool LDS, bool STATS, int INTEGRATOR>
+template <bool LDS, bool STATS, int INTEGRATOR, bool SOBOL = false>
 __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRATOR_VOLUME ? 3 : 4)) k_render(const KRender kp) {
     const DScene& sc = kp.ks.sc;
     const uint32_t* small_base = stage_scene(sc);
@@ -74,6 +74,11 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
         cx.density = kp.density;
         cx.dinfo = kp.dinfo;
         cx.occupancy = kp.occupancy;
+        if (SOBOL) {                                   // SobolSampler(rng, frame, thread_pos, vsize), SobolSampler.hh:50-61
+            cx.sobol32 = kp.sobol32; cx.sobol_vdc = kp.sobol_vdc;
+            cx.sobol_m = kp.sobol_m; cx.sobol_res = 1u << kp.sobol_m;
+            cx.sobol_xy[0] = px; cx.sobol_xy[1] = py % kp.view_height;
+        }
 
         const size_t pix = (size_t)py * W + px;
         uint4 texel = reinterpret_cast<const uint4*>(kp.fr.rng)[pix];       // r, g, b, a
@@ -85,13 +90,23 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
         PathState ps;
         Pcg rng;
         uint32_t s = 0;
+        uint64_t state_after_cast = 0;       // SOBOL: the sampler draws from a copy, the texel keeps this (SobolSampler.hh:50)
+        // castRay, then (SOBOL) the sampler of this frame: Render.metal:527-530
+        auto begin_sample = [&]() {
+            path_begin(ps, cast_ray(kp.cam, u, v, rng), kp.max_depth);
+            if (SOBOL) {
+                state_after_cast = rng.state;
+                ps.sobol_index = sobol_interval_to_index(cx, (uint64_t)(kp.frame0 + s));
+                ps.sobol_dim = 0;
+            }
+        };
         bool alive = kp.spp > 0;
         if (alive) {
             // pcg32_t rng = { rng_inc, rng_state } aggregate-initialises {state, inc}: the two 64-bit
             // words trade roles every frame (Render.metal:516-519,545-557, B-1)
             rng.state = ((uint64_t)texel.z << 32) | texel.w;
             rng.inc = ((uint64_t)texel.x << 32) | texel.y;
-            path_begin(ps, cast_ray(kp.cam, u, v, rng), kp.max_depth);
+            begin_sample();
         }
         // end of a sample: accumulate, hand the RNG words back to the texel, start the next sample (or stop)
         auto finish_sample = [&](F3 color) {
@@ -101,6 +116,7 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
             if (bad) color = f3(0);                                         // :537-538
             const uint32_t frame = kp.frame0 + s;
             cached = (cached * (float)frame + color) / (float)(frame + 1);  // running mean, :540-541
+            if (SOBOL) rng.state = state_after_cast;
             texel.y = (uint32_t)rng.state; texel.x = (uint32_t)(rng.state >> 32);
             texel.w = (uint32_t)rng.inc;   texel.z = (uint32_t)(rng.inc >> 32);
             n_paths++;
@@ -109,7 +125,7 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
             } else {
                 rng.state = ((uint64_t)texel.z << 32) | texel.w;
                 rng.inc = ((uint64_t)texel.x << 32) | texel.y;
-                path_begin(ps, cast_ray(kp.cam, u, v, rng), kp.max_depth);
+                begin_sample();
             }
         };
         // flat loop: one Scene::hit per iteration; a finished path immediately regenerates the next sample
@@ -121,8 +137,8 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
                                                                         cx.stack, cx.lvstack, cnt);
             F3 color;
             const bool finished = (INTEGRATOR == TRC_INTEGRATOR_PATH)
-                                      ? path_step<STATS>(cx, ps, hitted, rng, cnt, n_shaded, color)
-                                      : mis_step<LDS, STATS, kVolume>(cx, ps, hitted, rng, cnt, n_rays, n_shaded, color);
+                                      ? path_step<STATS, SOBOL>(cx, ps, hitted, rng, cnt, n_shaded, color)
+                                      : mis_step<LDS, STATS, kVolume, SOBOL>(cx, ps, hitted, rng, cnt, n_rays, n_shaded, color);
             if (finished) finish_sample(color);
         }
         float4 out; out.x = cached.x; out.y = cached.y; out.z = cached.z; out.w = 1.0f;
@@ -432,10 +448,34 @@ trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32
 
 namespace {
 
+// tables of pbrt::SobolSampler for a 2^m x 2^m pixel grid (include/trc_sobol.h), uploaded once per m
+trc_status ensure_sobol_tables(trc_ctx* ctx, uint32_t m) {
+    if (!ctx->d_sobol32) {
+        std::vector<uint32_t> m32(TRC_SOBOL_DIMS * TRC_SOBOL_MATRIX_SIZE);
+        trc_sobol_matrices32(m32.data());
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_sobol32, m32.size() * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_sobol32, m32.data(), m32.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_sobol_vdc, 2 * TRC_SOBOL_MATRIX_SIZE * sizeof(uint64_t)));
+        ctx->sobol_m = ~0u;
+    }
+    if (ctx->sobol_m != m) {
+        uint64_t tb[2 * TRC_SOBOL_MATRIX_SIZE] = {};
+        if (m != 0 && trc_sobol_interval_tables(m, tb, tb + TRC_SOBOL_MATRIX_SIZE) != 0)
+            return fail(ctx, TRC_ERR_UNSUPPORTED, "Sobol interval tables");
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));            // a launch in flight may still read the old tables
+        HIP_TRY(ctx, hipMemcpy(ctx->d_sobol_vdc, tb, sizeof(tb), hipMemcpyHostToDevice));
+        ctx->sobol_m = m;
+    }
+    return TRC_OK;
+}
+
 template <bool LDS>
 void launch_render(trc_ctx* ctx, const KRender& kp, bool stats, uint32_t integrator, size_t lds) {
     dim3 grid(ctx->n_tiles), block(kBlock);
-    if (integrator == TRC_INTEGRATOR_VOLUME) {
+    if (kp.sobol32) {                        // TRC_FLAG_SOBOL (production kernels of tracePath / traceMIS only)
+        if (integrator == TRC_INTEGRATOR_MIS) hipLaunchKernelGGL((k_render<LDS, false, TRC_INTEGRATOR_MIS, true>), grid, block, lds, ctx->stream, kp);
+        else hipLaunchKernelGGL((k_render<LDS, false, TRC_INTEGRATOR_PATH, true>), grid, block, lds, ctx->stream, kp);
+    } else if (integrator == TRC_INTEGRATOR_VOLUME) {
         if (stats) hipLaunchKernelGGL((k_render<LDS, true, TRC_INTEGRATOR_VOLUME>), grid, block, lds, ctx->stream, kp);
         else hipLaunchKernelGGL((k_render<LDS, false, TRC_INTEGRATOR_VOLUME>), grid, block, lds, ctx->stream, kp);
     } else if (integrator == TRC_INTEGRATOR_MIS) {
@@ -501,7 +541,7 @@ void trc_destroy(trc_ctx* ctx) {
     trc_sppm_release(ctx);
     collect_events(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
-    (void)hipFree(ctx->d_blob); (void)hipFree(ctx->d_bvh_ref); (void)hipFree(ctx->d_density); (void)hipFree(ctx->d_occupancy); (void)hipFree(ctx->d_envmap); (void)hipFree(ctx->d_rng); (void)hipFree(ctx->d_accum);
+    (void)hipFree(ctx->d_blob); (void)hipFree(ctx->d_bvh_ref); (void)hipFree(ctx->d_density); (void)hipFree(ctx->d_occupancy); (void)hipFree(ctx->d_envmap); (void)hipFree(ctx->d_sobol32); (void)hipFree(ctx->d_sobol_vdc); (void)hipFree(ctx->d_rng); (void)hipFree(ctx->d_accum);
     (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_stats); (void)hipFree(ctx->d_reduce_recv);
     (void)hipFree(ctx->d_block_cost); (void)hipFree(ctx->d_order_hist);
     for (int k = 0; k < 2; ++k) { (void)hipFree(ctx->d_order_keys[k]); (void)hipFree(ctx->d_order_vals[k]); }
@@ -707,6 +747,13 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
     if (ctx->n_tiles == 0) return TRC_OK;
 
     const bool stats = (p->flags & TRC_FLAG_COLLECT_STATS) != 0;
+    const bool sobol = (p->flags & TRC_FLAG_SOBOL) != 0;
+    if (sobol) {
+        if (p->integrator == TRC_INTEGRATOR_VOLUME || stats)
+            return fail(ctx, TRC_ERR_UNSUPPORTED, "TRC_FLAG_SOBOL: tracePath / traceMIS, production kernels only");
+        if (2ull * p->max_depth > TRC_SOBOL_DIMS)
+            return fail(ctx, TRC_ERR_UNSUPPORTED, "TRC_FLAG_SOBOL: 2 * max_depth exceeds the 40 generated dimensions");
+    }
     const size_t lds = trc_dyn_lds_bytes(ctx, stats);
     if (lds > 160 * 1024) return fail(ctx, TRC_ERR_UNSUPPORTED, "traversal stack exceeds the 160 KB LDS of a CU");
 
@@ -737,6 +784,18 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
     kp.density = ctx->d_density;
     kp.dinfo = ctx->dinfo;
     kp.occupancy = ctx->d_occupancy;
+    if (sobol) {
+        // resolution = RoundUpPow2(max(wh.x, wh.y)) of the view, log2Resolution = Log2Int(resolution) (SobolSampler.hh:56-58)
+        const uint32_t longest = ctx->width > kp.view_height ? ctx->width : kp.view_height;
+        uint32_t m = 0;
+        while ((1u << m) < longest) ++m;
+        if (m > TRC_SOBOL_MAX_LOG2RES) return fail(ctx, TRC_ERR_UNSUPPORTED, "TRC_FLAG_SOBOL: frame too large");
+        trc_status ts = ensure_sobol_tables(ctx, m);
+        if (ts != TRC_OK) return ts;
+        kp.sobol32 = ctx->d_sobol32;
+        kp.sobol_vdc = ctx->d_sobol_vdc;
+        kp.sobol_m = m;
+    }
 
     hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);
     if (!e0 || !e1) return fail(ctx, TRC_ERR_HIP, "hipEventCreate failed");

@@ -36,6 +36,9 @@ struct KRender {
     unsigned long long* stats;          // kStatCount counters
     const uint32_t* order;              // launch order: order[blockIdx.x] = index into `tiles` (null: identity)
     uint32_t* block_cost;               // duration of each block of `tiles` in this launch (the next launch's sort key)
+    const uint32_t* sobol32;            // TRC_FLAG_SOBOL: [40][52] generator matrices (null otherwise)
+    const uint64_t* sobol_vdc;          // ... [52] VdCSobolMatrices[m - 1] + [52] VdCSobolMatricesInv[m - 1]
+    uint32_t sobol_m;                   // ... log2Resolution
 };
 
 struct KTrace {
@@ -99,6 +102,7 @@ struct trc_ctx {
     DCamera cam{};
     float ambient[3] = {0, 0, 0};
     float* d_envmap = nullptr; uint32_t env_w = 0, env_h = 0;
+    uint32_t* d_sobol32 = nullptr; uint64_t* d_sobol_vdc = nullptr; uint32_t sobol_m = ~0u;   // TRC_FLAG_SOBOL tables
 
     // frame
     uint32_t width = 0, height = 0;

@@ -66,6 +66,10 @@ def lib():
         L.trc_host_free.argtypes = [C.c_void_p]
         L.trc_host_write_png.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
         L.trc_host_write_png.restype = C.c_int32
+        L.trc_host_sobol_matrices32.argtypes = [C.c_void_p]
+        L.trc_host_sobol_matrices32.restype = None
+        L.trc_host_sobol_interval_tables.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p]
+        L.trc_host_sobol_interval_tables.restype = C.c_int32
         L.trc_host_free.restype = None
         L.trc_host_mesh_destroy.restype = None
         _LIB = L
@@ -203,6 +207,21 @@ def write_png(path, rgba8):
     """(H, W, 4) uint8, rows top-down -> PNG file."""
     assert rgba8.dtype == np.uint8 and rgba8.ndim == 3 and rgba8.shape[2] == 4 and rgba8.flags.c_contiguous
     _check(lib().trc_host_write_png(os.fsencode(path), rgba8.ctypes.data, rgba8.shape[1], rgba8.shape[0]), "trc_host_write_png")
+
+
+def sobol_matrices32():
+    """SobolMatrices32 of the first 40 dimensions, (40, 52) uint32 (include/trc_sobol.h)."""
+    out = np.empty((abi.SOBOL_DIMS, abi.SOBOL_MATRIX_SIZE), dtype=np.uint32)
+    lib().trc_host_sobol_matrices32(out.ctypes.data)
+    return out
+
+
+def sobol_interval_tables(log2res):
+    """(VdCSobolMatrices[log2res - 1], VdCSobolMatricesInv[log2res - 1]) as two (52,) uint64 arrays."""
+    vdc = np.empty(abi.SOBOL_MATRIX_SIZE, dtype=np.uint64)
+    inv = np.empty(abi.SOBOL_MATRIX_SIZE, dtype=np.uint64)
+    _check(lib().trc_host_sobol_interval_tables(log2res, vdc.ctypes.data, inv.ctypes.data), "trc_host_sobol_interval_tables")
+    return vdc, inv
 
 
 def density_info(density, sigma_a=10.0, sigma_s=90.0, g=0.5):
