@@ -3,7 +3,7 @@
 // output stage, PNG.  Nothing but the two shared libraries is involved.
 //
 //   trc_render [--scene cornell|spheres|volume] [--integrator path|mis|volume] [--size W H] [--spp N]
-//              [--lbvh] [--out frame.png]
+//              [--lbvh] [--sobol] [--out frame.png]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -25,7 +25,7 @@
 int main(int argc, char** argv) {
     std::string scene_name = "spheres", integ_name = "path", out = "frame.png";
     uint32_t W = 640, H = 360, spp = 64;
-    bool lbvh = false;
+    bool lbvh = false, sobol = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--scene" && i + 1 < argc) scene_name = argv[++i];
@@ -33,6 +33,7 @@ int main(int argc, char** argv) {
         else if (a == "--size" && i + 2 < argc) { W = (uint32_t)std::atoi(argv[++i]); H = (uint32_t)std::atoi(argv[++i]); }
         else if (a == "--spp" && i + 1 < argc) spp = (uint32_t)std::atoi(argv[++i]);
         else if (a == "--lbvh") lbvh = true;
+        else if (a == "--sobol") sobol = true;
         else if (a == "--out" && i + 1 < argc) out = argv[++i];
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
@@ -72,6 +73,7 @@ int main(int argc, char** argv) {
     trc_params prm;
     std::memset(&prm, 0, sizeof prm);
     prm.spp = spp; prm.max_depth = 8; prm.integrator = integrator; prm.tile_nranks = 1;
+    if (sobol) prm.flags |= TRC_FLAG_SOBOL;      // pbrt::SobolSampler instead of the random sampler (Render.metal:529-530)
     const auto t0 = std::chrono::steady_clock::now();
     CHECK(trc_render(ctx, &prm));
     CHECK(trc_synchronize(ctx));
