@@ -61,3 +61,22 @@ def test_sobol_limits(gpu):
         assert e.value.status == abi.ERR_UNSUPPORTED
     gpu.render(spp=1, sobol=True)                                                   # still usable afterwards
     gpu.synchronize()
+
+
+def test_committed_sobol_frames(gpu):
+    """tests/golden/sobol_frames.npz (tests/golden/make_sobol_frames.py): accumulator, RNG texture and ray counts."""
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_sobol_frames as fx
+    frames = np.load(os.path.join(here, "golden", "sobol_frames.npz"))
+    for name, (kind, integ, W, H, spp, seed, frame0) in fx.CASES.items():
+        sc = host.HostScene(kind)
+        gpu.upload_scene(sc.view); gpu.set_camera(host.prepare_camera(W, H)); gpu.set_environment((0.0, 0.0, 0.0)); gpu.resize(W, H)
+        gpu.seed(seed); gpu.reset_stats()
+        gpu.render(spp=spp, integrator=integ, frame0=frame0, sobol=True)
+        assert np.array_equal(gpu.download_accum().view(np.uint32), frames[name + "_accum"].view(np.uint32)), name
+        assert np.array_equal(gpu.download_rng(), frames[name + "_rng"]), name
+        st = gpu.stats()
+        assert [st.paths, st.rays, st.shaded] == list(frames[name + "_counts"]), name

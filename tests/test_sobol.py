@@ -107,3 +107,15 @@ def test_oracle_render_with_the_sobol_sampler():
     big0, _, _ = _render(False, spp=256)
     big1, _, _ = _render(True, spp=256)
     assert abs(big0[..., :3].mean() - big1[..., :3].mean()) < 0.03 * big0[..., :3].mean()   # seed-to-seed sigma: 1 %
+
+
+def test_oracle_reproduces_committed_sobol_frames():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_sobol_frames as fx
+    frames = np.load(os.path.join(os.path.dirname(__file__), "golden", "sobol_frames.npz"))
+    for name in fx.CASES:
+        acc, rng, st = fx.render_case(name)
+        assert np.array_equal(rng, frames[name + "_rng"]), name
+        assert np.array_equal(acc.view(np.uint32), frames[name + "_accum"].view(np.uint32)), name
+        assert [st.paths, st.rays, st.shaded] == list(frames[name + "_counts"]), name
