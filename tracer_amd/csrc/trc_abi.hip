@@ -450,10 +450,10 @@ namespace {
 
 // tables of pbrt::SobolSampler for a 2^m x 2^m pixel grid (include/trc_sobol.h), uploaded once per m
 trc_status ensure_sobol_tables(trc_ctx* ctx, uint32_t m) {
-    if (!ctx->d_sobol32) {
+    if (!ctx->d_sobol_vdc) {
         std::vector<uint32_t> m32(TRC_SOBOL_DIMS * TRC_SOBOL_MATRIX_SIZE);
         trc_sobol_matrices32(m32.data());
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_sobol32, m32.size() * sizeof(uint32_t)));
+        if (!ctx->d_sobol32) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_sobol32, m32.size() * sizeof(uint32_t)));
         HIP_TRY(ctx, hipMemcpy(ctx->d_sobol32, m32.data(), m32.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_sobol_vdc, 2 * TRC_SOBOL_MATRIX_SIZE * sizeof(uint64_t)));
         ctx->sobol_m = ~0u;
