@@ -16,7 +16,7 @@ def _tile_mask(nranks):
     return ((tx + ty) % nranks) == 0
 
 
-def _check_subsample(gpu, scene, integrator, spp, nranks, seed=0xC0FFEE):
+def _check_subsample(gpu, scene, integrator, spp, nranks, seed=0xC0FFEE, sobol=False, frame0=0):
     cam = host.prepare_camera(W, H)
     gpu.upload_scene(scene.view)
     gpu.set_camera(cam)
@@ -24,13 +24,13 @@ def _check_subsample(gpu, scene, integrator, spp, nranks, seed=0xC0FFEE):
     gpu.resize(W, H)
     gpu.seed(seed)
     gpu.reset_stats()
-    gpu.render(spp=spp, integrator=integrator)
+    gpu.render(spp=spp, integrator=integrator, sobol=sobol, frame0=frame0)
     dev = gpu.download_accum()
     st = gpu.stats()
     assert st.paths == W * H * spp and st.rays >= st.paths
     assert np.isfinite(dev).all() and (dev[..., 3] == 1.0).all() and (dev[..., :3] >= 0).all()
     ref, rst = po.render(scene.view, cam, W, H, host.fill_rng(seed, W, H), spp=spp, integrator=integrator,
-                         tile_rank=0, tile_nranks=nranks)
+                         tile_rank=0, tile_nranks=nranks, sobol=sobol, frame0=frame0)
     mine = _tile_mask(nranks)
     assert mine.sum() > 5000 and rst.rays > 0
     assert np.array_equal(dev[mine].view(np.uint32), ref[mine].view(np.uint32))
@@ -42,6 +42,12 @@ def test_config3_mesh_mis_full_frame(gpu):
     scene = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.ball(153, 153, 0.08))
     assert scene.view.n_index // 3 == 46818
     _check_subsample(gpu, scene, abi.INTEGRATOR_MIS, 8, 128)
+
+
+def test_headline_frame_with_the_sobol_sampler(gpu):
+    """config 2's frame through TRC_FLAG_SOBOL: resolution 2048 (log2 11), pixel coordinates up to 1919 x 1079, frames 100..103;
+    1 tile in 32 re-rendered by the oracle"""
+    _check_subsample(gpu, host.HostScene(abi.SCENE_CORNELL_SPHERES), abi.INTEGRATOR_PATH, 4, 32, sobol=True, frame0=100)
 
 
 def test_config4_million_triangles_full_frame(gpu):
