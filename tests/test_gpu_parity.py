@@ -114,6 +114,15 @@ def test_render_with_sky_environment(gpu, cornell_spheres):
     assert_frames_equal(*_render_both(gpu, cornell_spheres, 96, 54, 8, abi.INTEGRATOR_PATH, env=(0.5, 0.7, 1.0)))
 
 
+@pytest.mark.parametrize("integrator", [abi.INTEGRATOR_PATH, abi.INTEGRATOR_MIS, abi.INTEGRATOR_VOLUME])
+def test_shallow_and_deep_paths(gpu, cornell_spheres, integrator):
+    """depth is the reference's `do { ... } while ((--depth) > 0)` (Render.metal:406,489): 0 and 1 both trace one bounce
+    ray at most, large depths are cut by Russian roulette; frames that do not start at 0 weigh the running mean"""
+    for depth, frame0 in ((0, 0), (1, 3), (2, 0), (3, 1000), (50, 7)):
+        assert_frames_equal(*_render_both(gpu, cornell_spheres, 72, 40, 4, integrator, seed=77 + depth, frame0=frame0,
+                                          max_depth=depth, env=(0.2, 0.3, 0.4)))
+
+
 def test_seed_matches_host_fill(gpu):
     gpu.resize(131, 77)
     gpu.seed(1234567)
