@@ -42,6 +42,25 @@ def test_reference_cloud_grid_loads():
     assert g.shape == (40, 100, 100) and g.max() == 1.0 and g.min() == 0.0 and 0.2 < (g > 0).mean() < 0.4
 
 
+@pytest.mark.skipif(not os.path.exists(REF_CLOUD), reason="reference cloud grid not present (GPU box)")
+def test_trace_volume_through_the_reference_cloud():
+    """the grid the reference itself renders (cloud/cloud.pbrt, read through its Include like AAPLRenderer.mm:629-636),
+    GridDensityInfo(10, 90, 0.5, ...) as at :636, in the cloud container of the volume scene"""
+    g = host.load_density_pbrt(os.path.join(os.path.dirname(os.path.dirname(REF_CLOUD)), "cloud.pbrt"))
+    info = host.density_info(g)
+    assert (info.sigma_a, info.sigma_s, info.g, info.invMaxDensity) == (10.0, 90.0, 0.5, 1.0)
+    sc = host.HostScene(abi.SCENE_CORNELL_VOLUME)
+    pyoracle.set_density(info, g)
+    try:
+        a, _, sa = render(sc.view, abi.INTEGRATOR_VOLUME, spp=8)
+    finally:
+        pyoracle.set_density(None, None)
+    b, _, sb = render(sc.view, abi.INTEGRATOR_VOLUME, spp=8)
+    assert np.isfinite(a).all() and (a[..., :3] >= 0).all()
+    changed = (a.view(np.uint32) != b.view(np.uint32)).any(axis=2).mean()
+    assert 0.05 < changed < 0.9 and sa.rays != sb.rays          # the cloud scatters light in part of the frame
+
+
 def test_volume_equals_mis_without_media():
     """With every Material::medium = _NIL_ and no _NIL_-typed surface traceVolume executes exactly traceMIS."""
     sc = host.HostScene(abi.SCENE_CORNELL_SPHERES)
