@@ -514,6 +514,11 @@ trc_status trc_host_sobol_interval_tables(uint32_t log2res, uint64_t* vdc /* [52
  * (AAPLRenderer.mm:474-511).  Returns arrays owned by the mesh handle. */
 typedef struct trc_host_mesh trc_host_mesh;
 trc_status trc_host_mesh_load_obj(const char* path, trc_host_mesh** out);
+/* every `Shape "trianglemesh"` of a pbrt-v3 file (the reference's unchecked to-do "Support pbrt-v3 file format",
+ * RT_Metal/README.md:57; it vendors minipbrt for it, Tracer/minipbrt.h:1528-1546): points through the current
+ * transformation matrix, normals through its inverse transpose (smooth normals when absent), uv / st, Include
+ * followed; shapes inside ObjectBegin/ObjectEnd and other shape types are skipped */
+trc_status trc_host_mesh_load_pbrt(const char* path, trc_host_mesh** out);
 /* procedural stand-in for the missing/untravelling assets: a displaced
  * UV-sphere "ball" with n_lat x n_lon quads (2 triangles each) */
 trc_status trc_host_mesh_make_ball(uint32_t n_lat, uint32_t n_lon, float bump, trc_host_mesh** out);

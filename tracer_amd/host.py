@@ -93,6 +93,13 @@ class Mesh:
         self.indices_ptr, self.n_indices = ip.value, ni.value
 
     @classmethod
+    def load_pbrt(cls, path):
+        """every `Shape "trianglemesh"` of a pbrt-v3 file, transformed to world space (trc_host_mesh_load_pbrt)"""
+        h = C.c_void_p()
+        _check(lib().trc_host_mesh_load_pbrt(os.fsencode(path), C.byref(h)), f"trc_host_mesh_load_pbrt({path})")
+        return cls(h)
+
+    @classmethod
     def load_obj(cls, path):
         h = C.c_void_p()
         _check(lib().trc_host_mesh_load_obj(os.fsencode(path), C.byref(h)), f"trc_host_mesh_load_obj({path})")
