@@ -52,6 +52,14 @@ def test_sobol_with_stacked_views(gpu):
     both(gpu, sc, 96, 3 * 64, 4, abi.INTEGRATOR_PATH, view_height=64)               # the sampler sees its own view
 
 
+def test_sobol_degenerate_resolutions(gpu):
+    """log2Resolution 0 (a 1 x 1 frame: SobolIntervalToIndex returns 0 for every frame, SobolSampler.hh:130) and 1"""
+    sc = host.HostScene(abi.SCENE_CORNELL_SPHERES)
+    both(gpu, sc, 1, 1, 16, abi.INTEGRATOR_PATH)
+    both(gpu, sc, 2, 1, 16, abi.INTEGRATOR_MIS, frame0=3)
+    both(gpu, sc, 1, 9, 8, abi.INTEGRATOR_PATH)
+
+
 def test_sobol_limits(gpu):
     sc = host.HostScene(abi.SCENE_CORNELL_SPHERES)
     gpu.upload_scene(sc.view); gpu.set_camera(host.prepare_camera(64, 64)); gpu.resize(64, 64); gpu.seed(1)
