@@ -3,7 +3,7 @@
 // output stage, PNG.  Nothing but the two shared libraries is involved.
 //
 //   trc_render [--scene cornell|spheres|volume] [--integrator path|mis|volume] [--size W H] [--spp N]
-//              [--lbvh] [--sobol] [--out frame.png]
+//              [--mesh file.obj|file.pbrt] [--density cloud.pbrt] [--lbvh] [--sobol] [--out frame.png]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -23,7 +23,7 @@
     } while (0)
 
 int main(int argc, char** argv) {
-    std::string scene_name = "spheres", integ_name = "path", out = "frame.png";
+    std::string scene_name = "spheres", integ_name = "path", out = "frame.png", mesh_path, density_path;
     uint32_t W = 640, H = 360, spp = 64;
     bool lbvh = false, sobol = false;
     for (int i = 1; i < argc; ++i) {
@@ -32,17 +32,31 @@ int main(int argc, char** argv) {
         else if (a == "--integrator" && i + 1 < argc) integ_name = argv[++i];
         else if (a == "--size" && i + 2 < argc) { W = (uint32_t)std::atoi(argv[++i]); H = (uint32_t)std::atoi(argv[++i]); }
         else if (a == "--spp" && i + 1 < argc) spp = (uint32_t)std::atoi(argv[++i]);
+        else if (a == "--mesh" && i + 1 < argc) mesh_path = argv[++i];          // Wavefront OBJ or pbrt-v3 trianglemeshes
+        else if (a == "--density" && i + 1 < argc) density_path = argv[++i];    // pbrt-v3 heterogeneous medium
         else if (a == "--lbvh") lbvh = true;
         else if (a == "--sobol") sobol = true;
         else if (a == "--out" && i + 1 < argc) out = argv[++i];
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
-    const int kind = scene_name == "cornell" ? TRC_SCENE_CORNELL : scene_name == "volume" ? TRC_SCENE_CORNELL_VOLUME : TRC_SCENE_CORNELL_SPHERES;
+    int kind = scene_name == "cornell" ? TRC_SCENE_CORNELL : scene_name == "volume" ? TRC_SCENE_CORNELL_VOLUME : TRC_SCENE_CORNELL_SPHERES;
+    if (!mesh_path.empty() && kind != TRC_SCENE_CORNELL_VOLUME) kind = TRC_SCENE_CORNELL_MESH;   // the mesh slot of AAPLRenderer.mm:474-603
     const uint32_t integrator = integ_name == "mis" ? TRC_INTEGRATOR_MIS : integ_name == "volume" ? TRC_INTEGRATOR_VOLUME : TRC_INTEGRATOR_PATH;
 
     trc_ctx* ctx = nullptr;
     trc_host_scene* hs = nullptr;
-    if (trc_host_scene_create(kind, nullptr, 0, nullptr, 0, &hs) != TRC_OK) { std::fprintf(stderr, "scene prep failed\n"); return 1; }
+    trc_host_mesh* mesh = nullptr;
+    const trc_TriangleVertex* mv = nullptr; const uint32_t* mi = nullptr;
+    uint32_t n_mv = 0, n_mi = 0;
+    if (!mesh_path.empty()) {
+        const bool pbrt = mesh_path.size() > 5 && mesh_path.compare(mesh_path.size() - 5, 5, ".pbrt") == 0;
+        if ((pbrt ? trc_host_mesh_load_pbrt(mesh_path.c_str(), &mesh) : trc_host_mesh_load_obj(mesh_path.c_str(), &mesh)) != TRC_OK) {
+            std::fprintf(stderr, "cannot read a triangle mesh from %s\n", mesh_path.c_str());
+            return 1;
+        }
+        trc_host_mesh_view(mesh, &mv, &n_mv, &mi, &n_mi);
+    }
+    if (trc_host_scene_create(kind, mv, n_mv, mi, n_mi, &hs) != TRC_OK) { std::fprintf(stderr, "scene prep failed\n"); return 1; }
     trc_scene scene;
     trc_host_scene_view(hs, &scene);
     trc_Camera cam;
@@ -59,9 +73,19 @@ int main(int argc, char** argv) {
     }
     std::vector<float> cloud;
     if (kind == TRC_SCENE_CORNELL_VOLUME) {
-        const uint32_t nx = 100, ny = 100, nz = 40;
-        cloud.resize((size_t)nx * ny * nz);
-        trc_host_make_cloud(nx, ny, nz, 1, cloud.data());
+        uint32_t nx = 100, ny = 100, nz = 40;
+        if (!density_path.empty()) {              // what AAPLRenderer.mm:629-636 reads through minipbrt
+            float* grid = nullptr;
+            if (trc_host_load_density_pbrt(density_path.c_str(), &nx, &ny, &nz, &grid) != TRC_OK) {
+                std::fprintf(stderr, "cannot read a density grid from %s\n", density_path.c_str());
+                return 1;
+            }
+            cloud.assign(grid, grid + (size_t)nx * ny * nz);
+            trc_host_free(grid);
+        } else {
+            cloud.resize((size_t)nx * ny * nz);
+            trc_host_make_cloud(nx, ny, nz, 1, cloud.data());
+        }
         trc_GridDensityInfo info;
         trc_host_make_density_info(10.0f, 90.0f, 0.5f, nx, ny, nz, cloud.data(), &info);
         CHECK(trc_upload_density(ctx, &info, cloud.data()));
@@ -90,5 +114,6 @@ int main(int argc, char** argv) {
                 st.rays / st.kernel_ms / 1e3, exposure, out.c_str());
     trc_destroy(ctx);
     trc_host_scene_destroy(hs);
+    trc_host_mesh_destroy(mesh);
     return 0;
 }

@@ -45,3 +45,38 @@ def test_example_renders_the_same_png_as_the_python_mirror(gpu, tmp_path, args):
     finally:
         gpu.upload_density(None, None)
     assert got.shape == want.shape and (got == want).all()
+
+
+@pytest.mark.gpu
+def test_example_ingests_pbrt_files(gpu, tmp_path):
+    """--mesh scene.pbrt (trianglemeshes through the transformation stack) and --density medium.pbrt (the block the reference
+    reads through minipbrt), against the Python mirror fed with the same files"""
+    from PIL import Image
+    W, H, spp = 128, 80, 4
+    (tmp_path / "mesh.pbrt").write_text(
+        'WorldBegin\nAttributeBegin\n  Translate 278 200 278\n  Rotate 30 0 1 0\n  Scale 120 120 120\n'
+        '  Shape "trianglemesh" "integer indices" [0 1 2  0 2 3  0 3 1  1 3 2]\n'
+        '        "point P" [ 0 1 0   -1 -1 1   1 -1 1   0 -1 -1 ]\nAttributeEnd\nWorldEnd\n')
+    grid = (np.arange(6 * 5 * 4, dtype=np.float32) % 7 / 7.0).reshape(4, 5, 6)
+    (tmp_path / "medium.pbrt").write_text('MakeNamedMedium "smoke" "string type" "heterogeneous" "integer nx" 6 "integer ny" 5 '
+                                          '"integer nz" 4 "float density" [ ' + " ".join(repr(float(x)) for x in grid.ravel()) + " ]\n")
+    out = tmp_path / "frame.png"
+    subprocess.check_output([EXE, "--scene", "volume", "--integrator", "volume", "--mesh", str(tmp_path / "mesh.pbrt"),
+                             "--density", str(tmp_path / "medium.pbrt"), "--size", str(W), str(H), "--spp", str(spp),
+                             "--out", str(out)], text=True)
+    got = np.asarray(Image.open(out).convert("RGBA"))
+    mesh = host.Mesh.load_pbrt(str(tmp_path / "mesh.pbrt"))
+    assert mesh.n_triangles == 4
+    sc = host.HostScene(abi.SCENE_CORNELL_VOLUME, mesh)
+    dens = host.load_density_pbrt(str(tmp_path / "medium.pbrt"))
+    assert np.array_equal(dens, grid)
+    gpu.upload_scene(sc.view)
+    gpu.upload_density(host.density_info(dens), dens)
+    try:
+        gpu.set_camera(host.prepare_camera(W, H)); gpu.set_environment((0.0, 0.0, 0.0)); gpu.resize(W, H)
+        gpu.seed(0x5EED0000); gpu.clear_accum()
+        gpu.render(spp=spp, integrator=abi.INTEGRATOR_VOLUME)
+        want, _ = gpu.tonemap()
+    finally:
+        gpu.upload_density(None, None)
+    assert got.shape == want.shape and (got == want).all()
