@@ -348,7 +348,7 @@ extern "C" trc_status trc_host_mesh_load_pbrt(const char* path, trc_host_mesh** 
                 if (UV) { tv.uv[0] = (float)UV->numbers[2 * v]; tv.uv[1] = (float)UV->numbers[2 * v + 1]; }
             }
             for (double k : idx) {
-                if (k < 0 || k >= (double)nv) return fail();
+                if (!(k >= 0 && k < (double)nv)) return fail();   // also rejects NaN
                 part.indices.push_back((uint32_t)k);
             }
             if (!N || !has_inv) generate_normals(part);

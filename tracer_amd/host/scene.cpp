@@ -400,6 +400,7 @@ trc_status trc_host_load_density_pbrt(const char* path, uint32_t* nx, uint32_t* 
     if (p == std::string::npos) return TRC_ERR_INVALID_ARG;
     p = text.find('[', p);
     if (p == std::string::npos) return TRC_ERR_INVALID_ARG;
+    if (*nx > 65536u || *ny > 65536u || *nz > 65536u || (uint64_t)*nx * *ny > (1ull << 31) / *nz) return TRC_ERR_INVALID_ARG;
     const size_t count = (size_t)*nx * *ny * *nz;
     float* data = (float*)std::malloc(count * sizeof(float));
     if (!data) return TRC_ERR_OOM;
