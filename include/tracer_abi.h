@@ -428,6 +428,11 @@ trc_status trc_group_init(trc_ctx* ctx, const uint8_t id[TRC_UNIQUE_ID_BYTES], i
 /* ncclReduce(sum) of the full-frame accum buffer to `root` on the ctx stream:
  * every rank holds zeros outside its own tiles, so sum == gather */
 trc_status trc_group_reduce_accum(trc_ctx* ctx, int root);
+/* sample sharding instead of tile sharding (every rank rendered the WHOLE frame from frame0 = 0 with its own seed and
+ * the same spp): ncclAllReduce(sum) of the accumulators, then / nranks -- every rank ends up with the mean of the
+ * ranks' running means, i.e. nranks * spp samples per pixel.  Unlike tile sharding the result is not the 1-GPU
+ * frame (other sample set) and, floating-point sums being order-dependent in a ring, not bit-reproducible. */
+trc_status trc_group_allreduce_mean_accum(trc_ctx* ctx);
 /* same compose, pipelined: the reduce runs on a second stream as soon as the work queued so far has finished,
  * and the context switches to its OTHER accumulator (allocated on first use, zero-filled), so the next
  * trc_clear_accum / trc_render overlap with the collective.  The composed frame of the call is read with

@@ -291,7 +291,30 @@ def test_rccl_group_single_rank_roundtrip(gpu, cornell_spheres):
     last = gpu.download_composed()
     gpu.clear_accum(); gpu.seed(24); gpu.render(spp=1)
     assert np.array_equal(gpu.download_accum().view(np.uint32), last.view(np.uint32))
+    # sample sharding: ncclAllReduce(sum) / nranks; with one rank the frame must come back unchanged
+    gpu.clear_accum(); gpu.seed(31); gpu.render(spp=3)
+    before = gpu.download_accum()
+    gpu.group_allreduce_mean_accum()
+    assert np.array_equal(gpu.download_accum().view(np.uint32), before.view(np.uint32))
     gpu.group_finalize()
+
+
+def test_sample_sharding_is_the_mean_of_the_shards(gpu, cornell_spheres):
+    """what trc_group_allreduce_mean_accum composes: N whole-frame renders with different seeds, averaged -- an N * spp
+    sample estimate of the same image (emulated on one GPU; the collective itself is covered with a 1-rank group)"""
+    W, H, spp, N = 96, 64, 16, 4
+    gpu.upload_scene(cornell_spheres.view); gpu.set_camera(host.prepare_camera(W, H)); gpu.set_environment((0.0, 0.0, 0.0))
+    gpu.resize(W, H)
+    shards = []
+    for r in range(N):
+        gpu.clear_accum(); gpu.seed(100 + r); gpu.render(spp=spp)
+        shards.append(gpu.download_accum().astype(np.float64))
+    mean = sum(shards) / N
+    gpu.clear_accum(); gpu.seed(999); gpu.render(spp=spp * N)
+    full = gpu.download_accum().astype(np.float64)
+    assert (mean[..., 3] == 1).all()
+    # both are N * spp sample estimates: their frame means agree far better than single shards do
+    assert abs(mean[..., :3].mean() - full[..., :3].mean()) < 0.1 * full[..., :3].mean()
 
 
 def test_stacked_views_sharded_over_ranks(gpu, cornell_spheres):

@@ -944,6 +944,29 @@ trc_status trc_group_reduce_accum(trc_ctx* ctx, int root) {
     return TRC_OK;
 }
 
+// Sample sharding (the alternative to tile sharding): every rank has rendered ALL pixels with its own share
+// of the samples (its own seed) from frame0 = 0; the composed frame is the mean of the ranks' running means.
+__global__ void __launch_bounds__(256) k_scale_rgb(float4* accum, size_t n, float inv) {
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    float4 a = accum[i];
+    a.x *= inv; a.y *= inv; a.z *= inv; a.w = 1.0f;
+    accum[i] = a;
+}
+trc_status trc_group_allreduce_mean_accum(trc_ctx* ctx) {
+    if (!ctx) return TRC_ERR_INVALID_ARG;
+    if (!ctx->comm) return fail(ctx, TRC_ERR_RCCL, "trc_group_allreduce_mean_accum before trc_group_init");
+    if (!ctx->d_accum) return fail(ctx, TRC_ERR_NO_FRAME, "no frame");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t pixels = (size_t)ctx->width * ctx->height;
+    int rc = g_rccl.AllReduce(ctx->d_accum, ctx->d_accum, pixels * 4, kNcclFloat, kNcclSum, ctx->comm, ctx->stream);
+    if (rc != 0) return fail(ctx, TRC_ERR_RCCL, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
+    hipLaunchKernelGGL(k_scale_rgb, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<float4*>(ctx->d_accum), pixels, 1.0f / (float)ctx->nranks);
+    HIP_TRY(ctx, hipGetLastError());
+    return TRC_OK;
+}
+
 // Pipelined variant: the reduce of the frame just rendered runs on a second stream while the context goes on
 // rendering into its OTHER accumulator, so an xGMI ring reduce of a multi-view frame (265 MB at N = 8, ~6 ms)
 // hides under the next step's render instead of adding to it.

@@ -70,6 +70,7 @@ def lib():
         L.trc_group_init.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int, C.c_int]
         L.trc_group_reduce_accum.argtypes = [vp, C.c_int]
         L.trc_group_reduce_accum_async.argtypes = [vp, C.c_int]
+        L.trc_group_allreduce_mean_accum.argtypes = [vp]
         L.trc_download_composed.argtypes = [vp, vp]
         L.trc_group_finalize.argtypes = [vp]
         for name in abi.DEVICE_SYMBOLS:
@@ -272,6 +273,10 @@ class Tracer:
 
     def group_reduce_accum(self, root=0):
         self._check(self._L.trc_group_reduce_accum(self._h, root), "trc_group_reduce_accum")
+
+    def group_allreduce_mean_accum(self):
+        """Sample sharding: mean over the ranks of their whole-frame accumulators (trc_group_allreduce_mean_accum)."""
+        self._check(self._L.trc_group_allreduce_mean_accum(self._h), "trc_group_allreduce_mean_accum")
 
     def group_reduce_accum_async(self, root=0):
         """Compose on a second stream and switch to the other accumulator (see trc_group_reduce_accum_async)."""
