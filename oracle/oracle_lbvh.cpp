@@ -110,5 +110,60 @@ extern "C" void orc_lbvh_build(const trc_BVH* leaves, uint32_t n, trc_BVH* out, 
         nd.bBOX.mini.x = std::min(L.mini.x, R.mini.x); nd.bBOX.mini.y = std::min(L.mini.y, R.mini.y); nd.bBOX.mini.z = std::min(L.mini.z, R.mini.z);
         nd.bBOX.maxi.x = std::max(L.maxi.x, R.maxi.x); nd.bBOX.maxi.y = std::max(L.maxi.y, R.maxi.y); nd.bBOX.maxi.z = std::max(L.maxi.z, R.maxi.z);
     }
+    // 10. two sweeps of tree rotations (trc_lbvh.hip k_lbvh_rotate_pass): bottom-up, every interior node may swap a child
+    // with a grandchild on the other side when the rebuilt child's surface area shrinks (best of <= 4, fixed candidate
+    // order, strict improvement).  Reverse BFS order visits every node after all nodes below it.
+    auto area = [](const trc_AABB& b) {
+        const float dx = b.maxi.x - b.mini.x, dy = b.maxi.y - b.mini.y, dz = b.maxi.z - b.mini.z;
+        return 2.0f * ((dx * dy + dy * dz) + dz * dx);
+    };
+    auto merged = [](const trc_AABB& a, const trc_AABB& b) {
+        trc_AABB m = a;
+        m.mini.x = std::min(a.mini.x, b.mini.x); m.mini.y = std::min(a.mini.y, b.mini.y); m.mini.z = std::min(a.mini.z, b.mini.z);
+        m.maxi.x = std::max(a.maxi.x, b.maxi.x); m.maxi.y = std::max(a.maxi.y, b.maxi.y); m.maxi.z = std::max(a.maxi.z, b.maxi.z);
+        return m;
+    };
+    for (int sweep = 0; sweep < 2; ++sweep) {
+        for (size_t h = order.size(); h-- > 0;) {
+            const uint32_t i = order[h];
+            const uint32_t L = out[i].left, R = out[i].right;
+            float best = 0.0f;
+            int which = -1;
+            if (out[R].pType == TRC_PRIM_BVH) {
+                const float old = area(out[R].bBOX);
+                const float a0 = area(merged(out[L].bBOX, out[out[R].right].bBOX));     // L <-> RL
+                const float a1 = area(merged(out[out[R].left].bBOX, out[L].bBOX));      // L <-> RR
+                if (old - a0 > best) { best = old - a0; which = 0; }
+                if (old - a1 > best) { best = old - a1; which = 1; }
+            }
+            if (out[L].pType == TRC_PRIM_BVH) {
+                const float old = area(out[L].bBOX);
+                const float a2 = area(merged(out[R].bBOX, out[out[L].right].bBOX));     // R <-> LL
+                const float a3 = area(merged(out[out[L].left].bBOX, out[R].bBOX));      // R <-> LR
+                if (old - a2 > best) { best = old - a2; which = 2; }
+                if (old - a3 > best) { best = old - a3; which = 3; }
+            }
+            if (which < 0) continue;
+            const bool right_side = which < 2, first = (which == 0 || which == 2);
+            const uint32_t X = right_side ? R : L, down = right_side ? L : R;
+            const uint32_t up = first ? out[X].left : out[X].right, keep = first ? out[X].right : out[X].left;
+            if (right_side) out[i].left = up; else out[i].right = up;
+            out[up].parent = i;
+            if (first) out[X].left = down; else out[X].right = down;
+            out[down].parent = X;
+            out[X].bBOX = merged(out[down].bBOX, out[keep].bBOX);
+        }
+        // the tree changed: BFS order and height again
+        order.clear(); order.push_back(0);
+        height = 0;
+        std::fill(depth.begin(), depth.end(), 0u);
+        for (size_t h = 0; h < order.size(); ++h) {
+            const uint32_t i = order[h];
+            for (uint32_t c : {out[i].left, out[i].right}) {
+                depth[c] = depth[i] + 1;
+                if (out[c].pType == TRC_PRIM_BVH) order.push_back(c); else height = std::max(height, depth[c]);
+            }
+        }
+    }
     if (out_height) *out_height = height;
 }
