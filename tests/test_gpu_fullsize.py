@@ -50,6 +50,26 @@ def test_headline_frame_with_the_sobol_sampler(gpu):
     _check_subsample(gpu, host.HostScene(abi.SCENE_CORNELL_SPHERES), abi.INTEGRATOR_PATH, 4, 32, sobol=True, frame0=100)
 
 
+def test_one_sample_per_launch_like_the_reference(gpu):
+    """the reference's own pattern: one sample per dispatch.  At this frame size such launches run k_render_strip (a strip
+    of 4 blocks per wavefront) and reuse the launch order for a few launches; six of them == six fused samples"""
+    scene = host.HostScene(abi.SCENE_CORNELL_SPHERES)
+    cam = host.prepare_camera(W, H)
+    gpu.upload_scene(scene.view); gpu.set_camera(cam); gpu.set_environment((0.0, 0.0, 0.0)); gpu.resize(W, H)
+    gpu.seed(0xABCD); gpu.clear_accum(); gpu.reset_stats()
+    for f in range(6):
+        gpu.render(spp=1, frame0=f)
+    one_by_one, rng_a, st = gpu.download_accum(), gpu.download_rng(), gpu.stats()
+    assert st.paths == W * H * 6 and st.launches == 6
+    gpu.seed(0xABCD); gpu.clear_accum()
+    gpu.render(spp=6)
+    assert np.array_equal(one_by_one.view(np.uint32), gpu.download_accum().view(np.uint32))
+    assert np.array_equal(rng_a, gpu.download_rng())
+    ref, _ = po.render(scene.view, cam, W, H, host.fill_rng(0xABCD, W, H), spp=6, tile_rank=0, tile_nranks=64)
+    mine = _tile_mask(64)
+    assert np.array_equal(one_by_one[mine].view(np.uint32), ref[mine].view(np.uint32))
+
+
 def test_config4_million_triangles_full_frame(gpu):
     """config 4: >= 1 M triangles (BVH far beyond L2), tracePath; hits on the mesh must exist in the checked tiles"""
     mesh = host.Mesh.ball(60, 60, 0.08).replicate(12, 2.4)

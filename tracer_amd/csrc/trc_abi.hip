@@ -178,6 +178,124 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
     }
 }
 
+// kernelPathTracing for launches of FEW samples per pixel (the reference's own pattern is one per dispatch): with one 8x8
+// block per wavefront a lane that has finished its few samples waits for the longest path of the wavefront -- at 1 spp
+// the wavefront runs ~9 iterations for 1.7 rays per lane.  Here a wavefront owns a strip of `kp.strip` consecutive
+// blocks of the list and every lane walks its own pixel of block after block, so a lane whose pixel is done starts
+// the same pixel of the next block at once (path regeneration across pixels instead of across samples).  The strip
+// is the unit of the adaptive launch order.  Pixels are independent: the frame is k_render's, bit for bit.
+template <bool LDS, int INTEGRATOR, bool SOBOL>
+__global__ void __launch_bounds__(kBlock, INTEGRATOR == TRC_INTEGRATOR_VOLUME ? 3 : 4) k_render_strip(const KRender kp) {
+    const DScene& sc = kp.ks.sc;
+    const uint32_t* small_base = stage_scene(sc);
+    uint32_t* stack = trc_smem + sc.lds_dwords + threadIdx.x;
+    const uint64_t t_start = clock64();
+    const uint32_t canon = kp.order ? kp.order[blockIdx.x] : blockIdx.x;     // strip index
+    const uint32_t lane = threadIdx.x;
+    const uint32_t W = kp.fr.width, H = kp.fr.height;
+    uint32_t blk = canon * kp.strip;
+    const uint32_t blk_end = min(blk + kp.strip, kp.n_tiles);
+
+    uint32_t n_rays = 0, n_shaded = 0, n_paths = 0;
+    TravCounters cnt;
+    counters_zero(cnt);
+
+    PathCtx cx;
+    cx.S = make_scene_ref(sc, small_base);
+    cx.root_min = f3(kp.ks.root_box[0], kp.ks.root_box[1], kp.ks.root_box[2]);
+    cx.root_max = f3(kp.ks.root_box[3], kp.ks.root_box[4], kp.ks.root_box[5]);
+    cx.sh.mats = small_base + sc.off_materials;
+    cx.ambient = f3(kp.ambient[0], kp.ambient[1], kp.ambient[2]);
+    cx.env.rgb = kp.env_rgb; cx.env.w = kp.env_w; cx.env.h = kp.env_h;
+    cx.stack = stack;
+    cx.lvstack = stack;
+    cx.max_depth = kp.max_depth;
+    cx.density = kp.density;
+    cx.dinfo = kp.dinfo;
+    cx.occupancy = kp.occupancy;
+    if (SOBOL) { cx.sobol32 = kp.sobol32; cx.sobol_vdc = kp.sobol_vdc; cx.sobol_m = kp.sobol_m; cx.sobol_res = 1u << kp.sobol_m; }
+
+    PathState ps;
+    Pcg rng;
+    uint4 texel;
+    F3 cached = f3(0);
+    float u = 0, v = 0;
+    uint32_t s = 0, pix = 0;
+    uint64_t state_after_cast = 0;
+    bool alive = false;
+
+    auto begin_sample = [&]() {                       // castRay, then (SOBOL) the sampler of this frame: Render.metal:527-530
+        rng.state = ((uint64_t)texel.z << 32) | texel.w;      // the two words trade roles every frame (B-1)
+        rng.inc = ((uint64_t)texel.x << 32) | texel.y;
+        path_begin(ps, cast_ray(kp.cam, u, v, rng), kp.max_depth);
+        if (SOBOL) {
+            state_after_cast = rng.state;
+            ps.sobol_index = sobol_interval_to_index(cx, (uint64_t)(kp.frame0 + s));
+            ps.sobol_dim = 0;
+        }
+    };
+    auto begin_pixel = [&]() {                        // this lane's pixel of the next block of the strip, if any
+        alive = false;
+        while (blk < blk_end) {
+            const uint32_t tile = kp.tiles[blk++];
+            const uint32_t px = (tile & 0xFFFFu) * 8u + (lane & 7u);
+            const uint32_t py = (tile >> 16) * 8u + (lane >> 3);
+            if (px < W && py < H) {
+                pix = py * W + px;
+                texel = reinterpret_cast<const uint4*>(kp.fr.rng)[pix];
+                const float4 acc = reinterpret_cast<const float4*>(kp.fr.accum)[pix];
+                cached = f3(acc.x, acc.y, acc.z);
+                u = (float)px / (float)W;                                              // no sub-pixel jitter (B-2)
+                v = (float)(py % kp.view_height) / (float)kp.view_height;
+                if (SOBOL) { cx.sobol_xy[0] = px; cx.sobol_xy[1] = py % kp.view_height; }
+                s = 0;
+                alive = true;
+                begin_sample();
+                return;
+            }
+        }
+    };
+    auto finish_sample = [&](F3 color) {
+        const bool bad = is_inf(color.x) || is_nan(color.x) || is_inf(color.y) || is_nan(color.y) ||
+                         is_inf(color.z) || is_nan(color.z);
+        if (bad) color = f3(0);                                         // :537-538
+        const uint32_t frame = kp.frame0 + s;
+        cached = (cached * (float)frame + color) / (float)(frame + 1);  // running mean, :540-541
+        if (SOBOL) rng.state = state_after_cast;
+        texel.y = (uint32_t)rng.state; texel.x = (uint32_t)(rng.state >> 32);
+        texel.w = (uint32_t)rng.inc;   texel.z = (uint32_t)(rng.inc >> 32);
+        n_paths++;
+        if (++s == kp.spp) {                                            // pixel done: write it back, take the next block's
+            float4 out; out.x = cached.x; out.y = cached.y; out.z = cached.z; out.w = 1.0f;
+            reinterpret_cast<float4*>(kp.fr.accum)[pix] = out;
+            reinterpret_cast<uint4*>(kp.fr.rng)[pix] = texel;
+            begin_pixel();
+        } else {
+            begin_sample();
+        }
+    };
+
+    begin_pixel();
+    while (alive) {
+        n_rays++;
+        constexpr bool kVolume = INTEGRATOR == TRC_INTEGRATOR_VOLUME;
+        const bool hitted = scene_hit<LDS, false, false, false, kVolume>(cx.S, cx.root_min, cx.root_max, ps.ray, ps.rec, FLT_MAX,
+                                                                  cx.stack, cx.lvstack, cnt);
+        F3 color;
+        const bool finished = (INTEGRATOR == TRC_INTEGRATOR_PATH)
+                                  ? path_step<false, SOBOL>(cx, ps, hitted, rng, cnt, n_shaded, color)
+                                  : mis_step<LDS, false, kVolume, SOBOL>(cx, ps, hitted, rng, cnt, n_rays, n_shaded, color);
+        if (finished) finish_sample(color);
+    }
+    uint32_t r_paths = wave_sum(n_paths), r_rays = wave_sum(n_rays), r_shaded = wave_sum(n_shaded);
+    if (lane == 0) {
+        kp.block_cost[canon] = (uint32_t)min((unsigned long long)((clock64() - t_start) >> 6), 0xFFFFFFull);
+        atomicAdd(&kp.stats[kStatPaths], (unsigned long long)r_paths);
+        atomicAdd(&kp.stats[kStatRays], (unsigned long long)r_rays);
+        atomicAdd(&kp.stats[kStatShaded], (unsigned long long)r_shaded);
+    }
+}
+
 // sort keys of the adaptive launch order: descending cost (shader clocks / 64, clamped to 24 bits), ties in list order
 __global__ void __launch_bounds__(256) k_order_keys(const uint32_t* cost, uint32_t n, uint32_t* keys, uint32_t* vals) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -434,7 +552,7 @@ trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32
     (void)hipFree(ctx->d_block_cost); ctx->d_block_cost = nullptr;
     for (int k = 0; k < 2; ++k) { (void)hipFree(ctx->d_order_keys[k]); (void)hipFree(ctx->d_order_vals[k]); ctx->d_order_keys[k] = ctx->d_order_vals[k] = nullptr; }
     (void)hipFree(ctx->d_order_hist); ctx->d_order_hist = nullptr;
-    ctx->cost_valid = false;
+    ctx->cost_valid = false; ctx->d_last_order = nullptr;
     if (ctx->n_tiles) {
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_block_cost, ctx->n_tiles * 4));
         for (int k = 0; k < 2; ++k) {
@@ -472,6 +590,16 @@ trc_status ensure_sobol_tables(trc_ctx* ctx, uint32_t m) {
 template <bool LDS>
 void launch_render(trc_ctx* ctx, const KRender& kp, bool stats, uint32_t integrator, size_t lds) {
     dim3 grid(ctx->n_tiles), block(kBlock);
+    if (kp.strip > 1) {                      // few samples per pixel: a strip of blocks per wavefront (production kernels)
+        dim3 sgrid((ctx->n_tiles + kp.strip - 1) / kp.strip);
+        if (kp.sobol32) {
+            if (integrator == TRC_INTEGRATOR_MIS) hipLaunchKernelGGL((k_render_strip<LDS, TRC_INTEGRATOR_MIS, true>), sgrid, block, lds, ctx->stream, kp);
+            else hipLaunchKernelGGL((k_render_strip<LDS, TRC_INTEGRATOR_PATH, true>), sgrid, block, lds, ctx->stream, kp);
+        } else if (integrator == TRC_INTEGRATOR_VOLUME) hipLaunchKernelGGL((k_render_strip<LDS, TRC_INTEGRATOR_VOLUME, false>), sgrid, block, lds, ctx->stream, kp);
+        else if (integrator == TRC_INTEGRATOR_MIS) hipLaunchKernelGGL((k_render_strip<LDS, TRC_INTEGRATOR_MIS, false>), sgrid, block, lds, ctx->stream, kp);
+        else hipLaunchKernelGGL((k_render_strip<LDS, TRC_INTEGRATOR_PATH, false>), sgrid, block, lds, ctx->stream, kp);
+        return;
+    }
     if (kp.sobol32) {                        // TRC_FLAG_SOBOL (production kernels of tracePath / traceMIS only)
         if (integrator == TRC_INTEGRATOR_MIS) hipLaunchKernelGGL((k_render<LDS, false, TRC_INTEGRATOR_MIS, true>), grid, block, lds, ctx->stream, kp);
         else hipLaunchKernelGGL((k_render<LDS, false, TRC_INTEGRATOR_PATH, true>), grid, block, lds, ctx->stream, kp);
@@ -522,6 +650,8 @@ trc_status trc_create(int device, trc_ctx** out) {
     trc_ctx* ctx = new (std::nothrow) trc_ctx();
     if (!ctx) return TRC_ERR_OOM;
     ctx->device = device;
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) ctx->cu_count = cus; }
+    if (ctx->cu_count <= 0) ctx->cu_count = 256;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void**)&ctx->d_stats, sizeof(unsigned long long) * (kStatCount + 3 * kProfCount)) != hipSuccess ||
         hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * (kStatCount + 3 * kProfCount), ctx->stream) != hipSuccess) {
@@ -769,16 +899,35 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
     kp.stats = ctx->d_stats;
     kp.block_cost = ctx->d_block_cost;
     kp.order = nullptr;
-    if (ctx->cost_valid && !(p->flags & TRC_FLAG_FIXED_ORDER)) {
+    // launches of few samples per pixel give every wavefront a strip of consecutive blocks (k_render_strip); the unit of the
+    // adaptive order is then the strip, and durations recorded for another strip length say nothing
+    kp.n_tiles = ctx->n_tiles;
+    kp.strip = 1;
+    if (!stats) {
+        // measured at 1920x1080 (kernel ms for 64 samples in launches of 1 / 4 / 16 spp): strip 1: 80.8 / 33.0 / 24.4,
+        // 2: 52.2 / 31.7 / 25.8, 3: 46.8 / 32.2 / 28.0, 4: 46.0 / 34.4 / 31.6, 6: 52.7 / 44.6 / 42.0 -- longer strips
+        // leave too few workgroups (the frame has 32 400 blocks for 4 096 wavefront slots)
+        const uint32_t want = p->spp == 1 ? 4u : p->spp == 2 ? 3u : p->spp < 8 ? 2u : 1u;
+        const uint32_t slots = (uint32_t)ctx->cu_count * 16u;
+        const uint32_t room = ctx->n_tiles / (slots + slots / 2u);          // keep >= 1.5 workgroups per slot
+        kp.strip = std::max(1u, std::min(want, room));
+    }
+    if (ctx->cost_strip != kp.strip) { ctx->cost_valid = false; ctx->cost_strip = kp.strip; ctx->d_last_order = nullptr; }
+    if (ctx->cost_valid && !(p->flags & TRC_FLAG_FIXED_ORDER) && kp.strip > 1 && ctx->d_last_order && ctx->order_age < 4) {
+        kp.order = ctx->d_last_order;              // short launches: the order of a few launches ago is as good, and 13 tiny
+        ctx->order_age++;                          // sort launches per 0.7 ms render are not
+    } else if (ctx->cost_valid && !(p->flags & TRC_FLAG_FIXED_ORDER)) {
         // most expensive blocks of the previous launch first (longest-processing-time order; cost = the wavefront's
         // measured duration): a block's samples are a sequential chain, so whatever starts last decides how long the GPU
         // drains.  Measured: config 2 25.2 -> 22.3 ms (ray counts as the key: 23.7), the 1 M-triangle scene 18.7 -> 16.8
         // ms.  Pixels do not depend on the order.
-        const uint32_t n = ctx->n_tiles;
+        const uint32_t n = (ctx->n_tiles + kp.strip - 1) / kp.strip;
         hipLaunchKernelGGL(k_order_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_block_cost, n, ctx->d_order_keys[0], ctx->d_order_vals[0]);
         int res = 0;
         trc_sort_pairs24(ctx->stream, ctx->d_order_keys, ctx->d_order_vals, ctx->d_order_hist, ctx->d_order_hist + trc_sort_hist_words(n), n, &res);
         kp.order = ctx->d_order_vals[res];
+        ctx->d_last_order = kp.order;
+        ctx->order_age = 0;
     }
     ctx->cost_valid = true;
     kp.density = ctx->d_density;

@@ -34,6 +34,7 @@ struct KRender {
     trc_GridDensityInfo dinfo;
     const uint8_t* occupancy;           // ... and its 4x4x4-brick occupancy (dev_integrator.hpp::grid_sample)
     unsigned long long* stats;          // kStatCount counters
+    uint32_t n_tiles, strip;            // k_render_strip: blocks in `tiles`, consecutive blocks per wavefront (1: k_render)
     const uint32_t* order;              // launch order: order[blockIdx.x] = index into `tiles` (null: identity)
     uint32_t* block_cost;               // duration of each block of `tiles` in this launch (the next launch's sort key)
     const uint32_t* sobol32;            // TRC_FLAG_SOBOL: [40][52] generator matrices (null otherwise)
@@ -116,7 +117,9 @@ struct trc_ctx {
     uint32_t* d_order_keys[2] = {nullptr, nullptr};
     uint32_t* d_order_vals[2] = {nullptr, nullptr};
     uint32_t* d_order_hist = nullptr;
-    bool cost_valid = false;
+    bool cost_valid = false; uint32_t cost_strip = 1;
+    const uint32_t* d_last_order = nullptr; uint32_t order_age = 0;     // most recent sorted order (short launches reuse it)
+    int cu_count = 0;
     uint32_t n_tiles = 0, tiles_nranks = 0, tiles_rank = 0, tiles_view_height = 0;
 
     // stats
