@@ -18,7 +18,7 @@ HOST_HDR  := tracer_amd/host/host_math.hpp tracer_amd/host/pbrt_text.hpp include
 HIP_SRC   := tracer_amd/csrc/trc_abi.hip tracer_amd/csrc/trc_sppm.hip tracer_amd/csrc/trc_lbvh.hip
 HIP_HDR   := $(wildcard tracer_amd/csrc/*.hpp) include/tracer_abi.h include/trc_detmath.h include/trc_sobol.h
 
-.PHONY: all host hip oracle example clean
+.PHONY: all host hip oracle example clean variant
 all: host hip oracle example
 
 host: $(LIBDIR)/libtrc_host.so
@@ -34,6 +34,11 @@ $(LIBDIR)/libtrc_host.so: $(HOST_SRC) $(HOST_HDR)
 $(LIBDIR)/libtracer_amd.so: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC) -ldl -lpthread -Wl,-rpath,$(ROCM)/lib
+
+# A/B variants of the device library for tools/ab_bench.py:  make variant NAME=unchecked DEFS=-DTRC_SPEC_UNCHECKED
+variant:
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) $(DEFS) -shared -o build/lib$(NAME).so $(HIP_SRC) -ldl -lpthread -Wl,-rpath,$(ROCM)/lib
 
 # C++ host driving the path through the C ABI only (no Python): examples/trc_render
 example: examples/trc_render

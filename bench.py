@@ -9,21 +9,29 @@ work), render all 64 samples of this rank's pixel tiles, and -- for N > 1 -- com
 RCCL reduce of the accumulation buffer to rank 0.  Inputs are resident in HBM before the timed region.
 `rays` = Scene::hit invocations, counted exactly by the kernel.
 
-N = 1: one 1920x1080 view.  N > 1 (weak scaling, the unit that shards is the 16x16 pixel tile): the batch
-is N such views stacked into one 1920 x (1080 N) frame (trc_params.view_height = 1080: every view has the
-same camera and its own RNG texels), tiles owned round-robin (tx + ty) % N, so every rank renders one
-view's worth of tiles drawn evenly from all views -- the per-GPU work of the N = 1 run -- and the composed
-N-view frame ends up on rank 0.  (Strong scaling of a single 1080p x 64 spp frame is latency-bound: a pixel's
-64 samples are a sequential RNG chain)
+  python bench.py [--gpus N --steps K --warmup W] [--scaling strong|weak]
 
-  python bench.py [--gpus N --steps K --warmup W]           (N = 1)
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+N > 1 is launched either by the driver (python -m torch.distributed.run ... bench.py --gpus N: RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* in the environment) or by bench.py itself: with WORLD_SIZE unset, `--gpus N` spawns N fresh
+child processes of this script (before anything touches the GPU) and relays rank 0's JSON line.
 
-Prints ONE JSON line on rank 0 (see README / DESIGN.md for the roofline definition).
+Two multi-GPU workloads, BOTH measured in every N > 1 run (the primary one fills the top-level fields, the other
+one is reported under "other_scaling"):
+  strong (default; the metric as BASELINE.json names it): the ONE 1920x1080x64spp frame, its 16x16 pixel tiles owned
+      round-robin (tx + ty) % N, every rank renders all 64 samples of its tiles, one ncclReduce(sum) composes the
+      frame on rank 0.  A pixel's 64 samples are a sequential RNG chain (Render.metal:545-557), so the GPU drains on
+      its slowest 8x8 blocks however few blocks it owns: expect well below linear.
+  weak: N such views stacked into one 1920 x (1080 N) frame (trc_params.view_height), same ownership rule, i.e. one
+      view's worth of tiles per GPU -- the N = 1 work per GPU; metric string says so.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the roofline definitions).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,6 +41,8 @@ sys.path.insert(0, ROOT)
 W, H, SPP, DEPTH = 1920, 1080, 64, 8
 SEED = 0x5EED0000
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+N_SIMD = 1024                # 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles (ibid., line 54)
+KERNEL = "k_render<true, false, 0"      # rocprof name prefix of the production tracePath kernel on an LDS-resident scene
 
 
 def algorithmic_bytes(st, n_pixels):
@@ -45,9 +55,8 @@ def algorithmic_bytes(st, n_pixels):
 
 def cpu_baseline(scene, cam, budget_s=20.0):
     """The CPU oracle (a port of the same algorithm) on a bounded tile subsample of the SAME workload."""
-    import numpy as np
     from oracle import pyoracle as po
-    from tracer_amd import abi, host
+    from tracer_amd import host
     cores = os.cpu_count() or 1
     rng = host.fill_rng(SEED, W, H)
     # calibrate on 1 tile in 256, then pick the subsample that fits the budget
@@ -74,7 +83,6 @@ def cpu_baseline(scene, cam, budget_s=20.0):
 def cpu_rt_weekend():
     """BASELINE config 1: the reference's RT_Weekend CPU path (C++ restatement, oracle/cpu_baseline.cpp)
     on the Cornell box at 400x400x16 spp, all host cores, row bands like main.swift:77-87."""
-    import subprocess
     exe = os.path.join(ROOT, "oracle", "cpu_baseline")
     if not os.path.exists(exe):
         return None
@@ -86,15 +94,53 @@ def cpu_rt_weekend():
                       f"box 400x400x16spp: {r['rays']} rays in {r['seconds']:.2f} s, {r['mpaths_per_s']} Mpaths/s"}
 
 
-def pmc_traffic(world):
-    """HBM bytes per launch from rocprofv3 PMC passes (profiles/*/traffic.json, produced by
-    tools/tools_pmc.sh + tools/tools_traffic.py with the gfx950 FETCH_SIZE x2 correction); None if absent."""
+def lib_source_hash():
+    """Identity of the device library: sha256 over the sources it is built from (the .so itself is not
+    byte-reproducible across builds).  tools/pmc_summary.py stores the same value next to the counters it collects."""
+    h = hashlib.sha256()
+    files = []
+    for d in ("tracer_amd/csrc", "include"):
+        files += [os.path.join(d, f) for f in sorted(os.listdir(os.path.join(ROOT, d)))]
+    for f in files:
+        h.update(f.encode())
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_summary():
+    """Newest committed PMC summary of the bench kernel (profiles/r*/pmc_config2.json, written by
+    tools/pmc_summary.py from rocprofv3 --pmc passes of THIS script); None if absent."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
-    if not files or world != 1:
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_config2.json")))
+    if not files:
         return None
-    t = json.load(open(files[-1]))
-    return t.get("hbm_bytes_per_launch")
+    p = json.load(open(files[-1]))
+    p["_file"] = os.path.relpath(files[-1], ROOT)
+    return p
+
+
+def roofline_extras(kernel_ms):
+    """(traffic, hbm_physical_frac, roofline_valu) from the committed PMC summary -- only when it was collected on
+    the library that is running (same source hash, same kernel name); otherwise (None, None, {"stale": ...})."""
+    p = pmc_summary()
+    if p is None:
+        return None, None, None
+    mine = lib_source_hash()
+    if p.get("lib_source_hash") != mine or not str(p.get("kernel", "")).startswith(KERNEL):
+        return None, None, {"stale": f"{p['_file']} was collected on library {p.get('lib_source_hash')} / kernel "
+                                     f"{p.get('kernel')!r}; running {mine} / {KERNEL!r}"}
+    traffic = int(p["hbm_bytes_per_launch"])
+    cyc = p["GRBM_GUI_ACTIVE"] / 8.0                       # summed over the 8 XCDs
+    valu = {
+        "bound": "valu-issue", "kernel": p["kernel"], "unit": "wave-instructions/launch",
+        "insts_valu": int(p["SQ_INSTS_VALU"]), "peak": int(N_SIMD * cyc / 2.0),
+        "frac": round(p["SQ_INSTS_VALU"] * 2.0 / (N_SIMD * cyc), 4),
+        "lane_utilisation": round(p["SQ_THREAD_CYCLES_VALU"] / (64.0 * p["SQ_INSTS_VALU"]), 4),
+        "useful_lane_frac": round(p["SQ_THREAD_CYCLES_VALU"] / 64.0 * 2.0 / (N_SIMD * cyc), 4),
+        "shader_cycles_per_launch": int(cyc), "pmc_kernel_ms": p.get("kernel_ms"),
+        "source": p["_file"], "lib_source_hash": mine,
+    }
+    return traffic, round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), valu
 
 
 def _with_c_stdout_on_stderr(fn):
@@ -113,52 +159,135 @@ def _with_c_stdout_on_stderr(fn):
         os.close(saved)
 
 
-def main():
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def visible_gpus():
+    """GPUs of this node WITHOUT initialising HIP in this process (a process that touched the GPU must not start
+    the ranks): KFD topology nodes with SIMDs; ROCR/HIP_VISIBLE_DEVICES narrow it."""
+    n = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for d in os.listdir(base):
+            try:
+                props = open(os.path.join(base, d, "properties")).read()
+            except OSError:
+                continue
+            for line in props.splitlines():
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+    except OSError:
+        pass
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v:
+            n = min(n, len([x for x in v.split(",") if x.strip()])) if n else len([x for x in v.split(",") if x.strip()])
+    return n
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: N fresh children of this script, one per rank, started before
+    this process has touched the GPU (never an exec from a process that has).  Rank 0's stdout is relayed."""
+    port = _free_port()
+    env0 = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="which N > 1 workload fills the top-level fields (the other one goes to other_scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-scaling", action="store_true", help="N > 1: measure only the primary workload")
     ap.add_argument("--force-group", action="store_true",
                     help="exercise the gloo rendezvous + RCCL compose path even with one rank (plumbing check)")
-    args = ap.parse_args()
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="ranks only rendezvous (gloo), exchange their ranks and print the line skeleton: the launcher "
+                         "/ relay / reduction plumbing without a GPU (tests/test_bench_helpers.py)")
+    args = ap.parse_args(argv)
 
-    import torch  # plumbing only: rendezvous / barrier / max-over-ranks; loaded first so ONE HIP runtime is used
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, argv))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
-    if torch.cuda.is_available():
-        torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))        # barrier()'s torch.cuda.synchronize() must not touch GPU 0 from every rank
-    dist = None
     grouped = world > 1 or args.force_group
+    dist = torch = None
     if grouped:
+        import torch  # plumbing only: rendezvous / barrier / max-over-ranks (N = 1 runs without it)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         _with_c_stdout_on_stderr(lambda: dist.init_process_group("gloo", rank=rank, world_size=world))
 
+    def reduce_scalar(x, op):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=getattr(dist.ReduceOp, op))
+        return float(t.item())
+
+    def gather_list(x):
+        if dist is None:
+            return [x]
+        out = [None] * world
+        dist.all_gather_object(out, x)
+        return out
+
+    if args.rendezvous_only:
+        ranks = gather_list(rank)
+        total = reduce_scalar(float(rank + 1), "SUM")
+        if rank == 0:
+            print(json.dumps({"rendezvous_only": True, "n_gpus": world, "ranks": ranks, "sum": total,
+                              "scaling": args.scaling}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     from tracer_amd import abi, host
     from tracer_amd.device import Tracer, group_unique_id
 
-    # plumbing check on boxes with fewer GPUs than ranks (no RCCL between ranks sharing a GPU): every other part of the
-    # N-rank path -- rendezvous, stacked workload, tile ownership, reductions of the timings -- runs as usual
-    no_rccl = os.environ.get("TRC_BENCH_NO_RCCL") == "1"
+    # ranks > GPUs (plumbing check on a 1-GPU box): share the GPUs, no RCCL between ranks on one device -- every other
+    # part of the N-rank path (rendezvous, workloads, tile ownership, reductions of the timings) runs as usual
+    n_dev = visible_gpus() or 1
+    no_rccl = os.environ.get("TRC_BENCH_NO_RCCL") == "1" or (world > n_dev)
+    device = local_rank % n_dev
+    if torch is not None and torch.cuda.is_available():
+        torch.cuda.set_device(device)          # barrier()'s torch.cuda.synchronize() must not touch GPU 0 from every rank
     scene = host.HostScene(abi.SCENE_CORNELL_SPHERES)
     cam = host.prepare_camera(W, H)
-    trc = Tracer(0 if no_rccl else local_rank)
+    trc = Tracer(device)
     trc.upload_scene(scene.view)
     trc.set_camera(cam)
     trc.set_environment((0.0, 0.0, 0.0))
-    FH = H * world                      # N stacked views
-    trc.resize(W, FH)
-    if grouped and not no_rccl:
+    use_rccl = grouped and not no_rccl
+    if use_rccl:
         ids = [group_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
+        trc.resize(W, H)
 
         def init_comm():
             trc.group_init(ids[0], world, rank)
@@ -170,74 +299,138 @@ def main():
 
     def barrier():
         trc.synchronize()
-        if torch.cuda.is_available():
+        if torch is not None and torch.cuda.is_available():
             torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
-    def step(collect_stats=False):
-        if grouped:
-            trc.clear_accum()            # non-owned tiles must be zero for the sum-compose
-        trc.seed(SEED)
-        trc.render(spp=SPP, max_depth=DEPTH, integrator=abi.INTEGRATOR_PATH, frame0=0, tile_rank=rank,
-                   tile_nranks=world, collect_stats=collect_stats, view_height=H)
-        if grouped and not no_rccl:
-            trc.group_reduce_accum_async(0)   # overlaps with the next step's render (second accumulator + stream)
+    def measure(mode, steps, warmup):
+        """K timed steps of one workload; returns the rank-0 view of it (dict) -- every rank must call it."""
+        stacked = mode == "weak" and world > 1
+        FH = H * world if stacked else H
+        trc.resize(W, FH)
 
-    # exact algorithmic work of ONE step on this rank (instrumented kernel, untimed)
-    trc.reset_stats()
-    step(collect_stats=True)
-    trc.synchronize()
-    st1 = trc.stats()
-    own_pixels = st1.paths // SPP
-    bytes_per_launch = algorithmic_bytes(st1, own_pixels)
-    rays_per_launch = st1.rays
+        def step(seed=SEED, collect_stats=False):
+            if grouped:
+                trc.clear_accum()            # non-owned tiles must be zero for the sum-compose
+            trc.seed(seed)
+            trc.render(spp=SPP, max_depth=DEPTH, integrator=abi.INTEGRATOR_PATH, frame0=0, tile_rank=rank,
+                       tile_nranks=world, collect_stats=collect_stats, view_height=H)
+            if use_rccl:
+                trc.group_reduce_accum_async(0)   # overlaps with the next step's render (second accumulator + stream)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    trc.reset_stats()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    st = trc.stats()
-    assert st.rays == rays_per_launch * args.steps, "steps are not identical work"
+        # exact algorithmic work of ONE step on this rank (instrumented kernel, untimed)
+        trc.reset_stats()
+        step(collect_stats=True)
+        trc.synchronize()
+        st1 = trc.stats()
+        own_pixels = st1.paths // SPP
+        bytes_per_launch = algorithmic_bytes(st1, own_pixels)
+        rays_per_launch = st1.rays
 
-    rays_total, dt_max = float(st.rays), dt
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt_max = float(t.item())
-        r = torch.tensor([rays_total], dtype=torch.float64)
-        dist.all_reduce(r, op=dist.ReduceOp.SUM)
-        rays_total = float(r.item())
+        for _ in range(warmup):
+            step()
+        barrier()
+        trc.reset_stats()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        st = trc.stats()
+        assert st.rays == rays_per_launch * steps, "steps are not identical work"
+        kernel_ms = st.kernel_ms / max(1, st.launches)          # HIP events on the render stream
+
+        # the same K steps with a DIFFERENT seed each (a progressive renderer never replays a frame: the adaptive
+        # launch order then works from the previous frame's costs, not from this frame's own)
+        barrier()
+        trc.reset_stats()
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(steps):
+            step(seed=SEED + 0x1000 + i)
+        barrier()
+        dt_vary = time.perf_counter() - t1
+        st_vary = trc.stats()
+        kernel_ms_vary = st_vary.kernel_ms / max(1, st_vary.launches)
+
+        # the compose alone (not overlapped): one synchronous reduce per iteration
+        compose_ms = None
+        if use_rccl:
+            barrier()
+            t2 = time.perf_counter()
+            for _ in range(steps):
+                trc.group_reduce_accum(0)
+            barrier()
+            compose_ms = (time.perf_counter() - t2) / steps * 1e3
+
+        dt_max = reduce_scalar(dt, "MAX")
+        dt_vary_max = reduce_scalar(dt_vary, "MAX")
+        rays_total = reduce_scalar(float(st.rays), "SUM")
+        rays_vary_total = reduce_scalar(float(st_vary.rays), "SUM")
+        per_rank = gather_list({"rank": rank, "kernel_ms": round(kernel_ms, 3), "kernel_ms_vary_seed": round(kernel_ms_vary, 3),
+                                "compose_ms": None if compose_ms is None else round(compose_ms, 3),
+                                "rays_per_step": int(st.rays // steps), "device": device})
+        name = "Mrays/s at 1920x1080x64spp"
+        if stacked:
+            name = f"Mrays/s over {world} stacked 1920x1080x64spp views, one view's worth of tiles per GPU (weak scaling)"
+        return {
+            "mode": mode if world > 1 else "single", "metric": name, "value": round(rays_total / dt_max / 1e6, 2),
+            "ms_per_step": round(dt_max / steps * 1e3, 3), "rays_per_step": int(rays_total / steps),
+            "frame": [W, FH], "paths_per_step": W * FH * SPP,
+            "mpaths_per_s": round(W * FH * SPP * steps / dt_max / 1e6, 2),
+            "vary_seed": {"value": round(rays_vary_total / dt_vary_max / 1e6, 2),
+                          "ms_per_step": round(dt_vary_max / steps * 1e3, 3), "kernel_ms": round(kernel_ms_vary, 3),
+                          "what": "the same K steps with a different RNG seed per step (frame k's block costs order frame k+1)"},
+            "per_rank": per_rank, "kernel_ms": kernel_ms, "bytes_per_launch": bytes_per_launch,
+            "rays_per_launch": rays_per_launch,
+        }
+
+    primary = measure(args.scaling, args.steps, args.warmup)
+    other = None
+    if world > 1 and not args.no_other_scaling:
+        other = measure("weak" if args.scaling == "strong" else "strong", args.steps, args.warmup)
 
     if rank == 0:
-        kernel_ms = st.kernel_ms / max(1, st.launches)          # HIP events on the render stream
-        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        kernel_ms = primary["kernel_ms"]
+        achieved = primary["bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
+        traffic, hbm_frac, valu = roofline_extras(kernel_ms) if world == 1 else (None, None, None)
         info = trc.device_info()
+        FH = primary["frame"][1]
+        compose = "none"
+        if grouped:
+            compose = (f"ncclReduce(sum) of the {W}x{FH} RGBA32F frame to rank 0 on a second stream, overlapped with the "
+                       f"next step" if use_rccl else "SWITCHED OFF (ranks share a GPU: plumbing run, not a measurement)")
         line = {
-            "metric": "Mrays/s at 1920x1080x64spp", "value": round(rays_total / dt_max / 1e6, 2), "unit": "Mrays/s",
+            "metric": primary["metric"], "value": primary["value"], "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt_max / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ms_per_step": primary["ms_per_step"], "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "RT_Metal Cornell box + 12 spheres (BASELINE config 2), 1920x1080x64spp, "
                                    "tracePath depth 8, 21 leaves / 41 BVH nodes" +
-                                   (f"; {world} such views stacked into one 1920x{FH} frame, one view's worth of "
-                                    f"tiles per GPU" if world > 1 else ""),
-                       "integrator": "tracePath", "rays_per_step": int(rays_total / args.steps),
-                       "paths_per_step": W * FH * SPP, "mpaths_per_s": round(W * FH * SPP * args.steps / dt_max / 1e6, 2),
-                       "tiles": f"16x16 px, owner (tx+ty)%{world}", "device": info["name"],
-                       "compose": f"ncclReduce(sum) of the {W}x{FH} RGBA32F frame to rank 0 on a second stream, overlapped with the next step" if grouped else "none"},
+                                   ("" if world == 1 else
+                                    (f"; ONE frame, its 16x16 tiles sharded over {world} GPUs" if primary["mode"] == "strong" else
+                                     f"; {world} such views stacked into one 1920x{FH} frame, one view's worth of tiles per GPU")),
+                       "integrator": "tracePath", "rays_per_step": primary["rays_per_step"],
+                       "paths_per_step": primary["paths_per_step"], "mpaths_per_s": primary["mpaths_per_s"],
+                       "tiles": f"16x16 px, owner (tx+ty)%{world}", "device": info["name"], "compose": compose},
+            "vary_seed": primary["vary_seed"],
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(world),
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "hbm_physical_frac": hbm_frac,
                          "kernel": "k_render", "kernel_ms": round(kernel_ms, 3),
-                         "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                         "bytes_per_ray": round(bytes_per_launch / max(1, rays_per_launch), 1)},
+                         "algorithmic_bytes_per_launch": int(primary["bytes_per_launch"]),
+                         "bytes_per_ray": round(primary["bytes_per_launch"] / max(1, primary["rays_per_launch"]), 1),
+                         "note": "algorithmic bytes of the REFERENCE's access pattern (SURVEY 8d); the scene is LDS-resident, "
+                                 "so frac > 1 is possible and the binding resource is VALU issue: see roofline_valu"},
+            "roofline_valu": valu,
         }
+        if world > 1:
+            line["per_rank"] = primary["per_rank"]
+            if other is not None:
+                line["other_scaling"] = {k: other[k] for k in ("mode", "metric", "value", "ms_per_step", "rays_per_step",
+                                                              "frame", "vary_seed", "per_rank")}
         if not args.no_cpu_baseline and world == 1:      # CPU baselines: rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(scene, cam)
             line["cpu_rt_weekend"] = cpu_rt_weekend()
@@ -246,7 +439,7 @@ def main():
 
     def teardown():
         if grouped:
-            if not no_rccl:
+            if use_rccl:
                 trc.group_finalize()
             dist.barrier()
             dist.destroy_process_group()

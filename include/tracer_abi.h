@@ -390,7 +390,10 @@ trc_status trc_tonemap(trc_ctx* ctx, uint8_t* rgba8, float* exposure_out);
 trc_status trc_render(trc_ctx* ctx, const trc_params* params);
 trc_status trc_synchronize(trc_ctx* ctx);
 
-/* test hook = Scene::hit (Render.hh:135-252) on a batch of rays (host buffers) */
+/* test hook = Scene::hit (Render.hh:135-252) on a batch of rays (host buffers).  `any_hit` is a bit set: */
+#define TRC_TRACE_ANY_HIT     1   /* stop at the first accepted hit closer than tmax (shadow rays, Render.hh:244) */
+#define TRC_TRACE_PRODUCTION  2   /* walk the tree exactly as the render kernels do (speculative two-leaf rounds,
+                                     no instrumentation): same hit record, n_descend / n_return / n_leaf left 0 */
 trc_status trc_trace_rays(trc_ctx* ctx, const trc_ray* rays, size_t n, trc_hit* out, int any_hit);
 
 trc_status trc_get_stats(trc_ctx* ctx, trc_stats* out);   /* synchronises the stream */
@@ -527,6 +530,10 @@ trc_status trc_host_mesh_load_pbrt(const char* path, trc_host_mesh** out);
 /* procedural stand-in for the missing/untravelling assets: a displaced
  * UV-sphere "ball" with n_lat x n_lon quads (2 triangles each) */
 trc_status trc_host_mesh_make_ball(uint32_t n_lat, uint32_t n_lon, float bump, trc_host_mesh** out);
+/* a mesh handle over caller arrays (copied): the vertex / index buffers a host already holds -- what the reference
+ * gets from MDLMesh.vertexBuffers / submesh.indexBuffer (AAPLRenderer.mm:527-529) */
+trc_status trc_host_mesh_from_arrays(const trc_TriangleVertex* vertices, uint32_t n_vertices,
+                                     const uint32_t* indices, uint32_t n_indices, trc_host_mesh** out);
 /* k x k grid replication (config 4: >= 1 M triangles) */
 trc_status trc_host_mesh_replicate(const trc_host_mesh* src, uint32_t k, float spacing, trc_host_mesh** out);
 void       trc_host_mesh_view(const trc_host_mesh* m, const trc_TriangleVertex** vertices,
@@ -570,6 +577,8 @@ TRC_SA(sizeof(trc_Complex) == 96 && offsetof(trc_Complex, frame_count) == 20 && 
        offsetof(trc_Complex, photonBoxSize) == 64 && offsetof(trc_Complex, photonInitialRadius) == 80 &&
        offsetof(trc_Complex, framePhotonSum) == 92, "Complex");
 TRC_SA(sizeof(trc_ray) == 32, "trc_ray");
+TRC_SA(sizeof(trc_hit) == 80 && offsetof(trc_hit, p) == 16 && offsetof(trc_hit, uv) == 52 && offsetof(trc_hit, n_descend) == 68, "trc_hit");
+TRC_SA(sizeof(trc_params) == 32 && sizeof(trc_stats) == 104, "trc_params / trc_stats");
 TRC_SA(sizeof(trc_GridDensityInfo) == 32 && offsetof(trc_GridDensityInfo, invMaxDensity) == 16 && offsetof(trc_GridDensityInfo, nx) == 20, "GridDensityInfo");
 TRC_SA(sizeof(trc_PhotonRecord) == 80 && offsetof(trc_PhotonRecord, normal) == 16 && offsetof(trc_PhotonRecord, position) == 32 &&
        offsetof(trc_PhotonRecord, direction) == 48 && offsetof(trc_PhotonRecord, step) == 64 &&

@@ -20,6 +20,7 @@
 #include <cfloat>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -1636,10 +1637,29 @@ inline void exRNG(const pcg32_t& rng, uint32_t* t) {   // Render.hh:109-120
     t[2] = (uint32_t)(rng.inc >> 32);   t[3] = (uint32_t)rng.inc;
 }
 
+// The per-pixel and per-photon passes touch only their own record / texel / pixel, so they run over contiguous index
+// bands on all host cores; every item computes what the serial loop computed (results do not depend on the thread
+// count).  ORC_THREADS caps the pool.
+template <typename F>
+void sppm_parallel(size_t n, F&& body) {
+    unsigned T = std::max(1u, std::thread::hardware_concurrency());
+    if (const char* e = std::getenv("ORC_THREADS")) T = std::max(1, std::atoi(e));
+    T = (unsigned)std::min<size_t>(T, std::max<size_t>(1, n / 256));
+    if (T <= 1) { body((size_t)0, n); return; }
+    std::vector<std::thread> pool;
+    const size_t unit = (n + T - 1) / T;
+    for (unsigned t = 0; t < T; ++t) {
+        const size_t b = std::min(n, t * unit), e = std::min(n, b + unit);
+        if (b < e) pool.emplace_back([&body, b, e]() { body(b, e); });
+    }
+    for (auto& th : pool) th.join();
+}
+
 // kernelCameraRecording, Photon.metal:96-167
 void sppm_camera_pass(SppmState& st, const trc_scene& prims, const trc_Camera* camera, const Env& env, uint32_t* canvas_rng) {
     Scene scene{prims, nullptr};
-    for (uint32_t y = 0; y < st.H; ++y)
+    sppm_parallel(st.H, [&](size_t y0, size_t y1) {
+    for (uint32_t y = (uint32_t)y0; y < (uint32_t)y1; ++y)
         for (uint32_t x = 0; x < st.W; ++x) {
             uint32_t* texel = canvas_rng + 4 * ((size_t)y * st.W + x);
             pcg32_t rng = toRNG(texel);
@@ -1654,6 +1674,7 @@ void sppm_camera_pass(SppmState& st, const trc_scene& prims, const trc_Camera* c
             slot = cr;
             exRNG(rng, texel);
         }
+    });
 }
 
 // kernelCameraReducing + kernelPhotonParams + kernelPhotonRadius, Photon.metal:169-218,357-384
@@ -1677,7 +1698,8 @@ void sppm_prepare_params(SppmState& st) {
 // kernelPhotonRecording, Photon.metal:286-355
 void sppm_photon_pass(SppmState& st, const trc_scene& prims, const Env& env) {
     Scene scene{prims, nullptr};
-    for (uint32_t idx = 0; idx < kHashN * kHashN; ++idx) {
+    sppm_parallel((size_t)kHashN * kHashN, [&](size_t i0, size_t i1) {
+    for (uint32_t idx = (uint32_t)i0; idx < (uint32_t)i1; ++idx) {
         PhoRec pc = st.pho[idx];
         uint32_t* texel = &st.photon_rng[4 * (size_t)idx];
         pcg32_t rng = toRNG(texel);
@@ -1704,6 +1726,7 @@ void sppm_photon_pass(SppmState& st, const trc_scene& prims, const Env& env) {
         st.pho[idx] = pc;
         exRNG(rng, texel);
     }
+    });
 }
 
 // kernelPhotonHashing + the point raster PhotonMarkVS/FS + kernelPhotonSumming, Photon.metal:386-496.
@@ -1734,7 +1757,8 @@ void sppm_hash_pass(SppmState& st) {
 // kernelPhotonRefine, Photon.metal:498-623
 void sppm_refine_pass(SppmState& st, float* accum) {
     const float fN = (float)kHashN;
-    for (size_t i = 0; i < (size_t)st.W * st.H; ++i) {
+    sppm_parallel((size_t)st.W * st.H, [&](size_t p0, size_t p1) {
+    for (size_t i = p0; i < p1; ++i) {
         CamRec& c = st.cam[i];
         float* px = accum + 4 * i;
         const float frame = (float)st.frame_count, frame1 = (float)(st.frame_count + 1);
@@ -1793,6 +1817,7 @@ void sppm_refine_pass(SppmState& st, float* accum) {
         if (std::isnan(result.x) || std::isnan(result.y) || std::isnan(result.z)) result = v3(0);
         px[0] = result.x; px[1] = result.y; px[2] = result.z; px[3] = 1.0f;
     }
+    });
 }
 
 inline void fill_hit(trc_hit& o, bool hit, const HitRecord& rec, float tmax_after, uint32_t nd, uint32_t nr, uint32_t nl) {

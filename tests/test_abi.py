@@ -67,7 +67,9 @@ def test_ctypes_layout_matches_header_offsets():
     assert off(abi.TextureInfo, "albedo") == 16
     assert off(abi.Camera, "vfov") == 48 and off(abi.Camera, "focus_dist") == 64 and off(abi.Camera, "u") == 80
     assert off(abi.Camera, "cornerLowLeft") == 160
-    assert C.sizeof(abi.Hit) == 84 or C.sizeof(abi.Hit) % 4 == 0
+    # trc_hit / trc_params / trc_stats: the header static-asserts the same numbers
+    assert C.sizeof(abi.Hit) == 80 and off(abi.Hit, "p") == 16 and off(abi.Hit, "uv") == 52 and off(abi.Hit, "n_descend") == 68
+    assert C.sizeof(abi.Params) == 32 and C.sizeof(abi.Stats) == 104
 
 
 def test_trc_create_fails_loudly_without_gpu_when_no_device():

@@ -37,28 +37,70 @@ def test_cpu_rt_weekend_leg_schema():
     assert leg["value"] > 0 and leg["cores"] >= 1 and "400x400x16" in leg["sample"]
 
 
-def test_pmc_traffic_is_read_from_profiles():
-    t = bench.pmc_traffic(1)
-    assert t is None or (isinstance(t, int) and 50e6 < t < 500e6)     # ~32 B/pixel read + 32 B written at 1080p
-    assert bench.pmc_traffic(8) is None
+def test_roofline_extras_only_from_a_summary_of_the_running_library(tmp_path, monkeypatch):
+    """roofline.traffic / roofline_valu come from a committed PMC summary and ONLY if it was collected on the library
+    that is running (source hash + kernel name); a stale summary yields nulls and says why"""
+    mine = bench.lib_source_hash()
+    good = {"kernel": "k_render<true, false, 0, false>", "lib_source_hash": mine, "hbm_bytes_per_launch": 140000000,
+            "GRBM_GUI_ACTIVE": 8 * 52.7e6, "SQ_INSTS_VALU": 17.1e9, "SQ_THREAD_CYCLES_VALU": 17.1e9 * 16, "kernel_ms": 22.0}
+    monkeypatch.setattr(bench, "pmc_summary", lambda: dict(good, _file="profiles/rXX/pmc_config2.json"))
+    traffic, frac, valu = bench.roofline_extras(22.0)
+    assert traffic == 140000000 and abs(frac - 140e6 / 22e-3 / 8e12) < 1e-6
+    assert abs(valu["frac"] - 17.1e9 * 2 / (1024 * 52.7e6)) < 1e-3 and abs(valu["lane_utilisation"] - 0.25) < 1e-9
+    assert abs(valu["useful_lane_frac"] - valu["frac"] * 0.25) < 1e-3
+    monkeypatch.setattr(bench, "pmc_summary", lambda: dict(good, lib_source_hash="0123", _file="x.json"))
+    traffic, frac, valu = bench.roofline_extras(22.0)
+    assert traffic is None and frac is None and "stale" in valu
+    monkeypatch.setattr(bench, "pmc_summary", lambda: None)
+    assert bench.roofline_extras(22.0) == (None, None, None)
+
+
+def test_self_launch_spawns_the_ranks_and_relays_rank0(tmp_path):
+    """`python bench.py --gpus 2` with WORLD_SIZE unset: bench.py starts the two ranks itself (fresh children with RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_*), they rendezvous over gloo and rank 0's single JSON line comes back on stdout.
+    --rendezvous-only stops before the first GPU call, so this runs here; the rendering part of the same path runs in
+    test_two_rank_bench_path_without_rccl on the GPU box."""
+    import json, subprocess, sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only",
+                          "--scaling", "weak"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line == {"rendezvous_only": True, "n_gpus": 2, "ranks": [0, 1], "sum": 3.0, "scaling": "weak"}
+
+
+def test_gpu_count_probe_does_not_touch_hip():
+    assert isinstance(bench.visible_gpus(), int) and bench.visible_gpus() >= 0
 
 
 @pytest.mark.gpu
-def test_two_rank_bench_path_without_rccl():
-    """bench.py launched the way the driver launches N > 1 (torch.distributed.run), two ranks sharing cuda:0 with the
-    collective switched off (TRC_BENCH_NO_RCCL=1): rendezvous, stacked two-view workload, tile ownership, max-over-ranks
-    timing and the single JSON line on rank 0."""
-    import json, os, subprocess, sys
-    from conftest import ROOT
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_two_rank_bench_path_without_rccl(launcher):
+    """bench.py with two ranks sharing cuda:0 (collective switched off automatically: more ranks than GPUs), started by
+    bench.py itself and the way the driver starts N > 1 (torch.distributed.run): rendezvous, BOTH workloads (the named
+    frame tile-sharded = strong, stacked views = weak), tile ownership, max-over-ranks timing, one JSON line."""
+    import json, subprocess, sys
     env = dict(os.environ, TRC_BENCH_NO_RCCL="1")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"),
-                          "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env, cwd=ROOT, capture_output=True,
-                         text=True, timeout=600)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    if launcher == "self":
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", "29517"] + tail
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
     line = json.loads(lines[-1])
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 2
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["steps"] == 2
+    assert line["metric"] == "Mrays/s at 1920x1080x64spp"
     assert "cpu_baseline" not in line                                   # rank 0 at N = 1 only
-    assert line["config"]["rays_per_step"] > 4.3e8                      # two views' worth of rays
-    assert "2 such views" in line["config"]["workload"]
+    assert line["config"]["rays_per_step"] == 219978393                 # the ONE named frame, whatever N
+    assert len(line["per_rank"]) == 2 and sum(r["rays_per_step"] for r in line["per_rank"]) == 219978393
+    weak = line["other_scaling"]
+    assert weak["mode"] == "weak" and "2 stacked" in weak["metric"] and weak["frame"] == [1920, 2160]
+    assert weak["rays_per_step"] > 4.3e8                                # two views' worth of rays

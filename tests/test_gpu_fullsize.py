@@ -1,6 +1,7 @@
-"""BASELINE configs 3, 4, 5 at full frame size (1920x1080) on the GPU, checked against the oracle on a
-subsample and through size-independent properties.  The reference's OBJ assets do not travel to the GPU box:
-procedural stand-ins of the same triangle counts are used."""
+"""BASELINE configs 2, 3, 4, 5 AS NAMED -- full frame size (1920x1080), full sample counts, the reference's own mesh
+assets -- on the GPU, checked against the oracle: whole frames at low sample counts, a tile subsample at the full
+count, and the whole 64-frame SPPM pass.  /root/reference does not exist on the GPU box; coatball.obj and teapot.obj
+travel as vertex / index arrays (tests/golden/meshes.npz, tests/golden/make_mesh_fixtures.py)."""
 import numpy as np
 import pytest
 
@@ -37,11 +38,24 @@ def _check_subsample(gpu, scene, integrator, spp, nranks, seed=0xC0FFEE, sobol=F
     return dev
 
 
-def test_config3_mesh_mis_full_frame(gpu):
-    """config 3: Cornell + a 46.8k-triangle mesh (coatball.obj's size), traceMIS; 1 tile in 128 re-rendered by the oracle"""
-    scene = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.ball(153, 153, 0.08))
-    assert scene.view.n_index // 3 == 46818
-    _check_subsample(gpu, scene, abi.INTEGRATOR_MIS, 8, 128)
+def coatball_scene():
+    """config 3: Cornell + RT_Metal/coatball/coatball.obj placed by AAPLRenderer.mm:513-525,562-572, material 19"""
+    scene = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.golden("coatball"))
+    assert scene.view.n_index // 3 == 46816
+    return scene
+
+
+def teapot_grid_scene():
+    """config 4: RT_Metal/meshes/teapot.obj (15 704 triangles) on an 8 x 8 grid (spacing 80 object units: the pots interlock) = 1 005 056 triangles, 2.0 M BVH nodes
+    (129 MB of reference nodes: far beyond the 32 MB of L2), placed by the same transform"""
+    mesh = host.Mesh.golden("teapot").replicate(8, 80.0)
+    assert mesh.n_triangles == 64 * 15704 >= 1_000_000
+    return host.HostScene(abi.SCENE_CORNELL_MESH, mesh)
+
+
+def test_config3_as_named_coatball_mis_256spp(gpu):
+    """BASELINE config 3 as named: coatball.obj, traceMIS, 1920x1080 x 256 spp; 1 tile in 256 re-rendered by the oracle"""
+    _check_subsample(gpu, coatball_scene(), abi.INTEGRATOR_MIS, 256, 256)
 
 
 def test_headline_frame_with_the_sobol_sampler(gpu):
@@ -70,13 +84,12 @@ def test_one_sample_per_launch_like_the_reference(gpu):
     assert np.array_equal(one_by_one[mine].view(np.uint32), ref[mine].view(np.uint32))
 
 
-def test_config4_million_triangles_full_frame(gpu):
-    """config 4: >= 1 M triangles (BVH far beyond L2), tracePath; hits on the mesh must exist in the checked tiles"""
-    mesh = host.Mesh.ball(60, 60, 0.08).replicate(12, 2.4)
-    assert mesh.n_triangles >= 1_000_000
-    scene = host.HostScene(abi.SCENE_CORNELL_MESH, mesh)
+def test_config4_as_named_million_triangles_256spp(gpu):
+    """BASELINE config 4 as named on one GPU: teapot.obj replicated to >= 1 M triangles, tracePath, 1920x1080 x 256 spp;
+    1 tile in 256 re-rendered by the oracle; hits on the mesh must exist among the primary rays"""
+    scene = teapot_grid_scene()
     assert scene.tree_depth() <= abi.TRC_MAX_BVH_DEPTH
-    _check_subsample(gpu, scene, abi.INTEGRATOR_PATH, 4, 128)
+    _check_subsample(gpu, scene, abi.INTEGRATOR_PATH, 256, 256)
     # Scene::hit on the big tree: primary rays, bit-exact incl. traversal counters
     from conftest import camera_rays
     rays = camera_rays(host.prepare_camera(W, H), W, H, step=12)
@@ -88,8 +101,10 @@ def test_config4_million_triangles_full_frame(gpu):
     assert np.array_equal(dev["t"].view(np.uint32), ref["t"].view(np.uint32))
 
 
-def test_config5_sppm_full_frame(gpu, cornell_spheres):
-    """config 5: SPPM at 1080p, 2 frames, the whole pass against the (single-threaded) oracle"""
+@pytest.mark.parametrize("n_frames", [2, 64])
+def test_config5_sppm_full_frame(gpu, cornell_spheres, n_frames):
+    """BASELINE config 5 as named on one GPU: SPPM at 1080p, 512^2 photons per frame, 64 frames (and 2), the whole pass --
+    camera records, photon records, both hash grids, Complex, canvas RNG, refined frame -- against the oracle"""
     cam = host.prepare_camera(W, H)
     gpu.upload_scene(cornell_spheres.view)
     gpu.set_camera(cam)
@@ -97,14 +112,15 @@ def test_config5_sppm_full_frame(gpu, cornell_spheres):
     gpu.resize(W, H)
     gpu.seed(8)
     gpu.sppm_init(9)
-    gpu.sppm_frames(2)
+    gpu.sppm_frames(n_frames)
     dcam, dpho, dmark, dcount, dcx = gpu.sppm_download()
     dacc = gpu.download_accum()
     rng = host.fill_rng(8, W, H)
     acc = np.zeros((H, W, 4), np.float32)
     s = po.Sppm(W, H, 9)
-    s.frames(cornell_spheres.view, cam, rng, acc, 2)
+    s.frames(cornell_spheres.view, cam, rng, acc, n_frames)
     ocam, opho, omark, ocount, ocx = s.download()
+    assert dcx.frame_count == ocx.frame_count == n_frames
     assert dcx.totalPhotonSum == ocx.totalPhotonSum and dcx.photonInitialRadius == ocx.photonInitialRadius
     assert np.array_equal(dcount, ocount) and np.array_equal(dmark, omark)
     assert dpho.tobytes() == opho.tobytes()
@@ -185,13 +201,13 @@ def test_config2_whole_headline_frame_bit_exact(gpu, cornell_spheres):
 
 @pytest.mark.parametrize("which", ["config3_mis", "config4_path_1m", "volume_lbvh"])
 def test_whole_frames_of_the_other_configurations(gpu, which):
-    """every pixel of a 1920x1080 frame (few samples, so the oracle finishes in seconds) for the mesh, the million-triangle
-    and the participating-media configurations"""
+    """every pixel of a 1920x1080 frame (few samples, so the oracle finishes in seconds) for config 3 (coatball.obj,
+    traceMIS), config 4 (teapot.obj x 64, tracePath) and the participating-media scene"""
     density = None
     if which == "config3_mis":
-        scene, integ, spp = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.ball(153, 153, 0.08)), abi.INTEGRATOR_MIS, 4
+        scene, integ, spp = coatball_scene(), abi.INTEGRATOR_MIS, 4
     elif which == "config4_path_1m":
-        scene, integ, spp = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.ball(60, 60, 0.08).replicate(12, 2.4)), abi.INTEGRATOR_PATH, 2
+        scene, integ, spp = teapot_grid_scene(), abi.INTEGRATOR_PATH, 2
     else:
         scene, integ, spp = host.HostScene(abi.SCENE_CORNELL_VOLUME, host.Mesh.ball(60, 60, 0.08)), abi.INTEGRATOR_VOLUME, 2
         density = host.make_cloud()

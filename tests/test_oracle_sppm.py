@@ -66,3 +66,21 @@ def test_new_photons_start_on_the_ceiling_light():
     alive = p["step"] == 1
     assert 0.3 < alive.mean() < 1.0
     assert (p["position"][alive][:, 1] < 554.95).all()        # below the light plane (y = 554.9 + offset)
+
+
+def test_threaded_passes_equal_the_serial_loops(monkeypatch):
+    """the oracle runs the per-pixel / per-photon passes on all host cores (so that 64 frames at 1080p can be checked on
+    the GPU box); every item is independent, so any thread count gives the serial result, byte for byte"""
+    scene = host.HostScene(abi.SCENE_CORNELL_SPHERES)
+    W, H = 96, 54
+    cam = host.prepare_camera(W, H)
+    out = []
+    for threads in ("1", "5"):
+        monkeypatch.setenv("ORC_THREADS", threads)
+        rng = host.fill_rng(3, W, H)
+        acc = np.zeros((H, W, 4), np.float32)
+        s = po.Sppm(W, H, 9)
+        s.frames(scene.view, cam, rng, acc, 3)
+        c, p, mark, count, cx = s.download()
+        out.append((rng.tobytes(), acc.tobytes(), c.tobytes(), p.tobytes(), mark.tobytes(), count.tobytes(), cx.totalPhotonSum))
+    assert out[0] == out[1]

@@ -12,32 +12,19 @@ sys.path.insert(0, ROOT)
 
 
 def child(path, config, steps):
-    from tracer_amd import abi, host, device
-    device.lib_path = lambda: os.path.abspath(path)
-    W, H = 1920, 1080
-    integrator, spp = abi.INTEGRATOR_PATH, 64
-    if config == "2":
-        sc = host.HostScene(abi.SCENE_CORNELL_SPHERES)
-    elif config == "3":
-        sc = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.ball(153, 153, 0.08))
-        integrator, spp = abi.INTEGRATOR_MIS, 32
-    elif config == "4":
-        sc = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.ball(60, 60, 0.08).replicate(12, 2.4))
-        spp = 32
-    else:
-        sc = host.HostScene(abi.SCENE_CORNELL_VOLUME, host.Mesh.ball(153, 153, 0.08))
-        integrator, spp = abi.INTEGRATOR_VOLUME, 16
+    os.environ["TRC_AMD_LIB"] = os.path.abspath(path)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import workloads as wlmod
+    from tracer_amd import device
+    wl = wlmod.make(config)
+    spp = {"2": 64, "3": 32, "4": 32, "volume": 16}[config]
     t = device.Tracer(0)
-    t.upload_scene(sc.view)
-    if config == "volume":
-        cloud = host.make_cloud()
-        t.upload_density(host.density_info(cloud), cloud)
-    t.set_camera(host.prepare_camera(W, H)); t.resize(W, H)
+    wlmod.setup(t, wl)
     for i in range(3):
-        t.seed(0x5EED0000 + i); t.clear_accum(); t.render(spp=spp, integrator=integrator)
+        t.seed(0x5EED0000 + i); t.clear_accum(); t.render(spp=spp, integrator=wl["integrator"])
     t.synchronize(); t.reset_stats()
     for i in range(steps):
-        t.seed(0x5EED0100 + i); t.clear_accum(); t.render(spp=spp, integrator=integrator)
+        t.seed(0x5EED0100 + i); t.clear_accum(); t.render(spp=spp, integrator=wl["integrator"])
     t.synchronize()
     s = t.stats()
     print(f"{s.kernel_ms / steps:.3f} {s.rays / steps:.0f}")

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""gpurun_out/<tag>/ (tools/pmc_collect.sh) -> one JSON summary: per-launch averages of every counter for the kernel
+whose name contains <kernel-substring> (the LONGEST-running match if several), the rocprofv3 --stats row of that
+kernel, the derived figures, the workload's own JSON line and the source hash of the library that ran.
+
+    python3 tools/pmc_summary.py <tag> <kernel-substring> <out.json>
+
+Derived (MI355X_MICROARCH.md): FETCH_SIZE / WRITE_SIZE are KB; FETCH_SIZE counts 128-B requests at 64 B on gfx950 ->
+doubled; GRBM_GUI_ACTIVE is summed over the 8 XCDs; a wave64 VALU instruction issues over 2 cycles of a SIMD-32.
+"""
+import collections, csv, glob, hashlib, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, sub, out_path = sys.argv[1], sys.argv[2], sys.argv[3]
+
+
+def lib_source_hash():
+    h = hashlib.sha256()
+    for d in ("tracer_amd/csrc", "include"):
+        for f in sorted(os.listdir(os.path.join(ROOT, d))):
+            h.update(os.path.join(d, f).encode())
+            h.update(open(os.path.join(ROOT, d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+stats_row, kernel = None, None
+for f in glob.glob(f"gpurun_out/{tag}/trace/*/*_kernel_stats.csv"):
+    rows = [r for r in csv.DictReader(open(f)) if sub in r["Name"]]
+    if rows:
+        stats_row = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+        kernel = stats_row["Name"]
+if kernel is None:
+    raise SystemExit(f"no kernel matching {sub!r} in gpurun_out/{tag}/trace")
+vals = collections.defaultdict(list)
+meta = {}
+for f in glob.glob(f"gpurun_out/{tag}/pmc_*/*/*_counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if r["Kernel_Name"] == kernel:
+            vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            meta = {"VGPR_Count": int(r["VGPR_Count"]), "LDS_Block_Size": int(r["LDS_Block_Size"]),
+                    "Scratch_Size": int(r.get("Scratch_Size", 0) or 0), "Workgroup_Size": int(r["Workgroup_Size"]),
+                    "Grid_Size": int(r["Grid_Size"])}
+res = {"kernel": kernel.replace("void ", "").replace("(KRender)", ""), "tag": tag, "lib_source_hash": lib_source_hash()}
+res.update(meta)
+for c, v in sorted(vals.items()):
+    res[c] = sum(v) / len(v)
+res["launches_sampled"] = {c: len(v) for c, v in vals.items()}
+res["kernel_ms"] = float(stats_row["AverageNs"]) / 1e6
+res["kernel_stats_row"] = stats_row
+if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
+    res["hbm_bytes_per_launch"] = int((2 * res["FETCH_SIZE"] + res["WRITE_SIZE"]) * 1024)
+    res["hbm_gbs"] = res["hbm_bytes_per_launch"] / res["kernel_ms"] / 1e6
+    res["hbm_physical_frac"] = res["hbm_gbs"] / 8000.0
+if "GRBM_GUI_ACTIVE" in res and "SQ_INSTS_VALU" in res:
+    cyc = res["GRBM_GUI_ACTIVE"] / 8.0
+    res["shader_cycles_per_launch"] = cyc
+    res["valu_issue_frac"] = res["SQ_INSTS_VALU"] * 2.0 / (1024 * cyc)
+    if "SQ_THREAD_CYCLES_VALU" in res:
+        res["valu_lane_utilisation"] = res["SQ_THREAD_CYCLES_VALU"] / (64.0 * res["SQ_INSTS_VALU"])
+        res["valu_useful_lane_frac"] = res["valu_issue_frac"] * res["valu_lane_utilisation"]
+if "TCC_HIT_sum" in res and "TCC_MISS_sum" in res and res["TCC_HIT_sum"] + res["TCC_MISS_sum"] > 0:
+    res["l2_hit_rate"] = res["TCC_HIT_sum"] / (res["TCC_HIT_sum"] + res["TCC_MISS_sum"])
+if "SQ_WAVE_CYCLES" in res:
+    for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+        if k in res:
+            res[k.lower() + "_frac_of_wave_cycles"] = res[k] / res["SQ_WAVE_CYCLES"]
+try:
+    last = [l for l in open(f"gpurun_out/{tag}/trace.log").read().splitlines() if l.startswith("{")][-1]
+    res["workload_line"] = json.loads(last)
+except Exception:
+    res["workload_line"] = None
+json.dump(res, open(out_path, "w"), indent=1, sort_keys=True)
+print(json.dumps({k: res[k] for k in res if k not in ("kernel_stats_row", "launches_sampled", "workload_line")}, indent=1, sort_keys=True))

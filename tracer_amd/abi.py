@@ -27,6 +27,7 @@ SCENE_CORNELL, SCENE_CORNELL_SPHERES, SCENE_CORNELL_MESH, SCENE_CORNELL_VOLUME =
 FLAG_COLLECT_STATS = 1
 FLAG_FIXED_ORDER = 2
 FLAG_SOBOL = 4
+TRACE_ANY_HIT, TRACE_PRODUCTION = 1, 2
 SOBOL_DIMS, SOBOL_MATRIX_SIZE = 40, 52
 
 # status codes
@@ -184,7 +185,7 @@ DEVICE_SYMBOLS = [
 HOST_SYMBOLS = [
     "trc_host_build_node", "trc_host_build_tree", "trc_host_tree_depth", "trc_host_make_camera",
     "trc_host_prepare_camera", "trc_host_fill_rng", "trc_host_scene_create", "trc_host_scene_destroy",
-    "trc_host_scene_view", "trc_host_mesh_load_obj", "trc_host_mesh_load_pbrt", "trc_host_mesh_make_ball", "trc_host_mesh_replicate",
+    "trc_host_scene_view", "trc_host_mesh_load_obj", "trc_host_mesh_load_pbrt", "trc_host_mesh_make_ball", "trc_host_mesh_replicate", "trc_host_mesh_from_arrays",
     "trc_host_mesh_view", "trc_host_mesh_destroy", "trc_host_make_density_info", "trc_host_make_cloud",
     "trc_host_load_density_pbrt", "trc_host_free", "trc_host_write_png", "trc_host_sobol_matrices32",
     "trc_host_sobol_interval_tables",

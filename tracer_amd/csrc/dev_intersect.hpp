@@ -401,24 +401,37 @@ TRC_DEV bool trav_test_leaf(const SceneRef& S, const Ray& ray, HitRec& rec, Trav
 //
 // Production kernels (STATS = false) run the SPECULATIVE form of the round (Aila & Laine, HPG 2009): a lane that
 // reaches a leaf while its neighbours are still descending postpones that leaf, pops its next node and keeps
-// descending until it reaches a second leaf; then both are tested in the order they were found.  Primitives are
-// therefore tested in exactly the reference's order and against the same running closest hit; only boxes are
-// tested against a possibly staler (larger) ry, i.e. a superset of the reference's nodes is visited, and every
-// primitive met only because of that lies beyond the closest hit by then (t >= box entry > ry), so it is
-// rejected: the results are identical.  The exact traversal counters are taken by the instrumented kernels,
-// which run the plain round.
+// descending until it reaches a second leaf.  The postponed leaf is tested first.  What the lane did after the
+// postponement ran against an ry the reference would already have lowered IF that test accepts a hit, so:
+//   * test rejected (ry unchanged): every box test of the speculative stretch saw exactly the reference's ry -- its
+//     pushes, pops and the second leaf ARE the reference's next steps, and the second leaf is tested at once;
+//   * test accepted: the lane returns to the snapshot taken at the postponement (tag + stack height) and walks that
+//     stretch again in the next round with the new ry.  Speculative pushes lie above the snapshot height and the
+//     stretch never pops below it (a dead end there parks the lane, kTagStall), so the snapshot is still intact.
+// Hence the sequence of box tests that count, primitive tests and ry values is the reference's own, step for step
+// -- no argument about floating-point containment of a primitive in its box is needed (a sphere is even larger
+// than its box: MakeSphere inflates the radius, not the AABB, Tracer.mm:165-172).  The exact traversal counters are
+// taken by the instrumented kernels, which run the plain round.
 template <bool ALL_LDS, bool STATS, bool ANY, bool EAGER_UV, bool VOL = false>
 TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const float test_t, Trav& tv,
                        uint32_t* stack, uint32_t* lvstack, TravCounters& cnt) {
     const float rx = FLT_MIN;
     constexpr bool SPEC = !STATS;
     if (SPEC) {
+        constexpr uint32_t kTagStall = 5u << kTagIndexBits;   // speculative dead end at the snapshot height: wait for the test
+#ifdef TRC_SPEC_UNCHECKED   // A/B builds only (Makefile `variant`): round 1's unchecked round -- what the snapshot costs, and
+        constexpr bool kChecked = false;                      // the build tests/test_gpu_traversal.py must FAIL on
+#else
+        constexpr bool kChecked = true;
+#endif
         uint32_t pend = kTagNone;                      // postponed leaf
+        uint32_t snap_tag = kTagNone, snap_sp = 0;     // state right after the postponement
         auto pop_next = [&]() {                        // next deferred sibling, or "exhausted" (kTagNone)
             if (tv.sp == 0) { tv.tag = kTagNone; return; }
             tv.sp--;
             tv.tag = stack[tv.sp * kBlock];
         };
+        auto postpone = [&]() { pend = tv.tag; pop_next(); snap_tag = tv.tag; snap_sp = tv.sp; };
         for (;;) {
             const bool interior = !tv.done && (tv.tag >> kTagIndexBits) == kTagInterior;
             if (__ballot(interior) == 0ull) break;
@@ -433,20 +446,24 @@ TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const flo
                     const bool left_first = t_left < t_right;
                     if (left_test && right_test) { stack[tv.sp * kBlock] = left_first ? tagR : tagL; tv.sp++; }
                     tv.tag = left_first ? tagL : tagR;
+                } else if (kChecked && pend != kTagNone && tv.sp == snap_sp) {
+                    tv.tag = kTagStall;                // would consume an entry from below the snapshot
                 } else {
                     pop_next();
                 }
-                if (pend == kTagNone && (tv.tag >> kTagIndexBits) < kTagInterior) { pend = tv.tag; pop_next(); }
+                if (pend == kTagNone && (tv.tag >> kTagIndexBits) < kTagInterior) postpone();
             }
         }
         if (!tv.done) {
             // first leaf of the round: the postponed one, or (a lane that entered the round on a leaf) the current one
-            if (pend == kTagNone && (tv.tag >> kTagIndexBits) < kTagInterior) { pend = tv.tag; pop_next(); }
+            if (pend == kTagNone && (tv.tag >> kTagIndexBits) < kTagInterior) postpone();
             if (pend != kTagNone) {
-                trav_test_leaf<STATS, EAGER_UV, VOL>(S, ray, rec, tv, pend, cnt);
+                const bool accepted = trav_test_leaf<STATS, EAGER_UV, VOL>(S, ray, rec, tv, pend, cnt);
                 if (ANY && tv.ry < test_t) tv.done = true;                       // Render.hh:244
+                else if (kChecked && accepted) { tv.tag = snap_tag; tv.sp = snap_sp; }   // ry moved: redo the speculative stretch
+                else if (tv.tag == kTagStall) pop_next();                        // the dead end was real
             }
-            if (!tv.done && (tv.tag >> kTagIndexBits) < kTagInterior) {          // second leaf, found after the first
+            if (!tv.done && (tv.tag >> kTagIndexBits) < kTagInterior) {          // next leaf of the reference's order
                 trav_test_leaf<STATS, EAGER_UV, VOL>(S, ray, rec, tv, tv.tag, cnt);
                 if (ANY && tv.ry < test_t) tv.done = true;
                 else pop_next();

@@ -344,8 +344,10 @@ __global__ void __launch_bounds__(256) k_tonemap(const float4* accum, uint32_t W
     out[i] = make_uchar4((unsigned char)o[0], (unsigned char)o[1], (unsigned char)o[2], 255);
 }
 
-// Scene::hit test hook: one lane per ray, full HitRecord + per-ray traversal counters
-template <bool LDS, bool ANY>
+// Scene::hit test hook: one lane per ray, full HitRecord + per-ray traversal counters.  STATS = true is the plain
+// round with the exact counters; STATS = false is the traversal the render kernels run (speculative round,
+// dev_intersect.hpp::trav_iter), counters left at zero.
+template <bool LDS, bool ANY, bool STATS>
 __global__ void __launch_bounds__(kBlock) k_trace(const KTrace kp) {
     const DScene& sc = kp.ks.sc;
     const uint32_t* small_base = stage_scene(sc);
@@ -360,7 +362,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(const KTrace kp) {
     hit_init(rec);
     TravCounters cnt;
     counters_zero(cnt);
-    const bool h = scene_hit<LDS, true, ANY, true>(S, f3(kp.ks.root_box[0], kp.ks.root_box[1], kp.ks.root_box[2]),
+    const bool h = scene_hit<LDS, STATS, ANY, true>(S, f3(kp.ks.root_box[0], kp.ks.root_box[1], kp.ks.root_box[2]),
                                                  f3(kp.ks.root_box[3], kp.ks.root_box[4], kp.ks.root_box[5]), ray, rec, in.tmax, stack, lvstack, cnt);
     trc_hit o;
     memset(&o, 0, sizeof o);
@@ -398,6 +400,23 @@ hipEvent_t get_event(trc_ctx* ctx) {
     hipEvent_t e = nullptr;
     if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
+}
+
+// folds the per-launch event pairs that have already completed into kernel_ms without waiting (oldest first; the
+// stream is in order, so the first unfinished pair ends the scan).  Called from trc_render, so a host that never
+// synchronises through trc_synchronize / trc_get_stats (one launch + one download per frame, the reference's own
+// pattern) keeps a bounded list.
+void collect_finished_events(trc_ctx* ctx) {
+    size_t done = 0;
+    for (; done < ctx->pending.size(); ++done) {
+        if (hipEventQuery(ctx->pending[done].second) != hipSuccess) break;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ctx->pending[done].first, ctx->pending[done].second) == hipSuccess) ctx->kernel_ms += ms;
+        ctx->event_pool.push_back(ctx->pending[done].first);
+        ctx->event_pool.push_back(ctx->pending[done].second);
+    }
+    (void)hipGetLastError();          // hipEventQuery reports hipErrorNotReady through the sticky error too
+    ctx->pending.erase(ctx->pending.begin(), ctx->pending.begin() + (ptrdiff_t)done);
 }
 
 // drains finished per-launch event pairs into kernel_ms (call after a stream sync)
@@ -509,7 +528,8 @@ Rccl g_rccl;
 
 bool trc_load_rccl(std::string& err) {
     Rccl& r = g_rccl;
-    if (r.handle) return true;
+    if (r.ready) return true;
+    if (r.handle) { dlclose(r.handle); r = Rccl{}; }        // an earlier attempt found the library but not every symbol
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
         r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
@@ -525,8 +545,11 @@ bool trc_load_rccl(std::string& err) {
     r.GetErrorString = (const char* (*)(int))dlsym(r.handle, "ncclGetErrorString");
     if (!r.GetUniqueId || !r.CommInitRank || !r.Reduce || !r.AllReduce || !r.AllGather || !r.CommDestroy) {
         err = "librccl: missing symbols";
+        dlclose(r.handle);
+        r = Rccl{};
         return false;
     }
+    r.ready = true;
     return true;
 }
 
@@ -537,30 +560,30 @@ size_t trc_dyn_lds_bytes(const trc_ctx* ctx, bool stats) {
 }
 
 trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32_t view_height) {
-    if (ctx->d_tiles && ctx->tiles_nranks == nranks && ctx->tiles_rank == rank && ctx->tiles_view_height == view_height) return TRC_OK;
+    if (ctx->d_tiles && ctx->d_block_cost && ctx->tiles_nranks == nranks && ctx->tiles_rank == rank && ctx->tiles_view_height == view_height) return TRC_OK;
     std::vector<uint32_t> tiles = make_tiles(ctx->width, ctx->height, nranks, rank, view_height);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // the cache key (tiles_nranks ...) is written LAST: a failed allocation below leaves the list invalid, so the next
+    // call rebuilds it instead of launching with a null block_cost / order buffer
+    ctx->tiles_nranks = 0;
     (void)hipFree(ctx->d_tiles); ctx->d_tiles = nullptr;
-    ctx->n_tiles = (uint32_t)tiles.size();
-    if (ctx->n_tiles) {
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tiles, tiles.size() * 4));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_tiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    ctx->tiles_nranks = nranks; ctx->tiles_rank = rank; ctx->tiles_view_height = view_height;
-    // buffers of the adaptive launch order for this block list
     (void)hipFree(ctx->d_block_cost); ctx->d_block_cost = nullptr;
     for (int k = 0; k < 2; ++k) { (void)hipFree(ctx->d_order_keys[k]); (void)hipFree(ctx->d_order_vals[k]); ctx->d_order_keys[k] = ctx->d_order_vals[k] = nullptr; }
     (void)hipFree(ctx->d_order_hist); ctx->d_order_hist = nullptr;
     ctx->cost_valid = false; ctx->d_last_order = nullptr;
+    ctx->n_tiles = (uint32_t)tiles.size();
     if (ctx->n_tiles) {
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_block_cost, ctx->n_tiles * 4));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tiles, tiles.size() * 4));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_block_cost, tiles.size() * 4));
         for (int k = 0; k < 2; ++k) {
-            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_order_keys[k], ctx->n_tiles * 4));
-            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_order_vals[k], ctx->n_tiles * 4));
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_order_keys[k], tiles.size() * 4));
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_order_vals[k], tiles.size() * 4));
         }
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_order_hist, (trc_sort_hist_words(ctx->n_tiles) + 256) * 4));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_tiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
+    ctx->tiles_nranks = nranks; ctx->tiles_rank = rank; ctx->tiles_view_height = view_height;
     return TRC_OK;
 }
 
@@ -775,6 +798,8 @@ trc_status trc_set_environment_map(trc_ctx* ctx, uint32_t w, uint32_t h, const f
 
 trc_status trc_resize(trc_ctx* ctx, uint32_t width, uint32_t height) {
     if (!ctx || width == 0 || height == 0 || width > 65535u * 8u || height > 65535u * 8u) return TRC_ERR_INVALID_ARG;
+    // pixel indices are 32-bit in the seed / tonemap / strip / SPPM kernels
+    if ((uint64_t)width * height >= (1ull << 32)) return fail(ctx, TRC_ERR_UNSUPPORTED, "trc_resize: 2^32 pixels or more");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->comm_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->comm_stream));
@@ -811,6 +836,7 @@ static trc_status copy_frame(trc_ctx* ctx, void* dev, void* host, bool to_device
     if (to_device) HIP_TRY(ctx, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     else HIP_TRY(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    collect_events(ctx);
     return TRC_OK;
 }
 trc_status trc_upload_rng(trc_ctx* ctx, const uint32_t* rgba) { return copy_frame(ctx, ctx ? ctx->d_rng : nullptr, (void*)rgba, true); }
@@ -946,13 +972,18 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
         kp.sobol_m = m;
     }
 
+    collect_finished_events(ctx);
     hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);
-    if (!e0 || !e1) return fail(ctx, TRC_ERR_HIP, "hipEventCreate failed");
-    HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
-    if (ctx->lds_scene) launch_render<true>(ctx, kp, stats, p->integrator, lds);
-    else launch_render<false>(ctx, kp, stats, p->integrator, lds);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+    auto give_back = [&]() { if (e0) ctx->event_pool.push_back(e0); if (e1) ctx->event_pool.push_back(e1); };
+    if (!e0 || !e1) { give_back(); return fail(ctx, TRC_ERR_HIP, "hipEventCreate failed"); }
+    hipError_t le = hipEventRecord(e0, ctx->stream);
+    if (le == hipSuccess) {
+        if (ctx->lds_scene) launch_render<true>(ctx, kp, stats, p->integrator, lds);
+        else launch_render<false>(ctx, kp, stats, p->integrator, lds);
+        le = hipGetLastError();
+    }
+    if (le == hipSuccess) le = hipEventRecord(e1, ctx->stream);
+    if (le != hipSuccess) { give_back(); return fail(ctx, TRC_ERR_HIP, std::string("k_render launch: ") + hipGetErrorString(le)); }
     ctx->pending.emplace_back(e0, e1);
     ctx->launches++;
     return TRC_OK;
@@ -972,6 +1003,7 @@ trc_status trc_trace_rays(trc_ctx* ctx, const trc_ray* rays, size_t n, trc_hit* 
     if (!ctx->has_scene) return fail(ctx, TRC_ERR_NO_SCENE, "trc_trace_rays before trc_upload_scene");
     if (n == 0) return TRC_OK;
     if (n > 0x7FFFFFFFu) return fail(ctx, TRC_ERR_INVALID_ARG, "too many rays in one call");
+    if (any_hit & ~(TRC_TRACE_ANY_HIT | TRC_TRACE_PRODUCTION)) return fail(ctx, TRC_ERR_INVALID_ARG, "trc_trace_rays: unknown mode bits");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     trc_ray* d_rays = nullptr; trc_hit* d_hits = nullptr;
     HIP_TRY(ctx, hipMalloc((void**)&d_rays, n * sizeof(trc_ray)));
@@ -983,13 +1015,16 @@ trc_status trc_trace_rays(trc_ctx* ctx, const trc_ray* rays, size_t n, trc_hit* 
         kp.ks = ctx->ks; kp.rays = d_rays; kp.hits = d_hits; kp.n = (uint32_t)n;
         const size_t lds = trc_dyn_lds_bytes(ctx, true);
         dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+        const bool any = (any_hit & TRC_TRACE_ANY_HIT) != 0, prod = (any_hit & TRC_TRACE_PRODUCTION) != 0;
+#define TRC_LAUNCH_TRACE(L, A, S) hipLaunchKernelGGL((k_trace<L, A, S>), grid, block, lds, ctx->stream, kp)
         if (ctx->lds_scene) {
-            if (any_hit) hipLaunchKernelGGL((k_trace<true, true>), grid, block, lds, ctx->stream, kp);
-            else hipLaunchKernelGGL((k_trace<true, false>), grid, block, lds, ctx->stream, kp);
+            if (prod) { if (any) TRC_LAUNCH_TRACE(true, true, false); else TRC_LAUNCH_TRACE(true, false, false); }
+            else      { if (any) TRC_LAUNCH_TRACE(true, true, true);  else TRC_LAUNCH_TRACE(true, false, true); }
         } else {
-            if (any_hit) hipLaunchKernelGGL((k_trace<false, true>), grid, block, lds, ctx->stream, kp);
-            else hipLaunchKernelGGL((k_trace<false, false>), grid, block, lds, ctx->stream, kp);
+            if (prod) { if (any) TRC_LAUNCH_TRACE(false, true, false); else TRC_LAUNCH_TRACE(false, false, false); }
+            else      { if (any) TRC_LAUNCH_TRACE(false, true, true);  else TRC_LAUNCH_TRACE(false, false, true); }
         }
+#undef TRC_LAUNCH_TRACE
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { st = fail(ctx, TRC_ERR_HIP, std::string("k_trace launch: ") + hipGetErrorString(e)); break; }
         if (hipMemcpyAsync(out, d_hits, n * sizeof(trc_hit), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { st = fail(ctx, TRC_ERR_HIP, "D2H hits"); break; }

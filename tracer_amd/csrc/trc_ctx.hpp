@@ -161,6 +161,7 @@ inline trc_status trc_fail(trc_ctx* ctx, trc_status s, const std::string& msg) {
 struct IdBlob { char internal[TRC_UNIQUE_ID_BYTES]; };   // ncclUniqueId, passed by value
 struct Rccl {
     void* handle = nullptr;
+    bool ready = false;              // every entry point below resolved
     int (*GetUniqueId)(void*) = nullptr;
     int (*CommInitRank)(void**, int, IdBlob, int) = nullptr;
     int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;

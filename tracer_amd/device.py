@@ -21,7 +21,8 @@ class TracerError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtracer_amd.so")
+    """The in-tree build; TRC_AMD_LIB points the A/B tools (tools/ab_bench.py) at another build of the same library."""
+    return os.environ.get("TRC_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtracer_amd.so")
 
 
 def lib():
@@ -212,13 +213,15 @@ class Tracer:
     def synchronize(self):
         self._check(self._L.trc_synchronize(self._h), "trc_synchronize")
 
-    def trace_rays(self, rays, any_hit=False):
-        """rays: structured array with the layout of trc_ray -> structured array of trc_hit."""
+    def trace_rays(self, rays, any_hit=False, production=False):
+        """rays: structured array with the layout of trc_ray -> structured array of trc_hit.
+        production=True walks the tree as the render kernels do (no counters)."""
         from .dtypes import HIT_DTYPE, RAY_DTYPE
         assert rays.dtype == RAY_DTYPE and rays.flags.c_contiguous
         hits = np.zeros(len(rays), dtype=HIT_DTYPE)
         self._check(self._L.trc_trace_rays(self._h, rays.ctypes.data, len(rays), hits.ctypes.data,
-                                           1 if any_hit else 0), "trc_trace_rays")
+                                           (abi.TRACE_ANY_HIT if any_hit else 0) | (abi.TRACE_PRODUCTION if production else 0)),
+                    "trc_trace_rays")
         return hits
 
     def stats(self):

@@ -50,6 +50,8 @@ def lib():
         L.trc_host_mesh_load_obj.restype = C.c_int32
         L.trc_host_mesh_make_ball.argtypes = [C.c_uint32, C.c_uint32, C.c_float, C.POINTER(C.c_void_p)]
         L.trc_host_mesh_make_ball.restype = C.c_int32
+        L.trc_host_mesh_from_arrays.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.trc_host_mesh_from_arrays.restype = C.c_int32
         L.trc_host_mesh_replicate.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.POINTER(C.c_void_p)]
         L.trc_host_mesh_replicate.restype = C.c_int32
         L.trc_host_mesh_view.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32),
@@ -104,6 +106,25 @@ class Mesh:
         h = C.c_void_p()
         _check(lib().trc_host_mesh_load_obj(os.fsencode(path), C.byref(h)), f"trc_host_mesh_load_obj({path})")
         return cls(h)
+
+    @classmethod
+    def from_arrays(cls, vertices, indices):
+        """vertices: (n, 8) float32 rows of {position, normal, uv} (trc_TriangleVertex); indices: uint32, 3 per triangle."""
+        v = np.ascontiguousarray(vertices, dtype=np.float32)
+        i = np.ascontiguousarray(indices, dtype=np.uint32).ravel()
+        assert v.ndim == 2 and v.shape[1] == 8
+        h = C.c_void_p()
+        _check(lib().trc_host_mesh_from_arrays(v.ctypes.data, v.shape[0], i.ctypes.data, i.size, C.byref(h)),
+               "trc_host_mesh_from_arrays")
+        return cls(h)
+
+    @classmethod
+    def golden(cls, name):
+        """The reference's own OBJ assets as committed vertex / index arrays (tests/golden/meshes.npz, written by
+        tests/golden/make_mesh_fixtures.py from RT_Metal/coatball/coatball.obj and RT_Metal/meshes/teapot.obj)."""
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "meshes.npz")
+        z = np.load(path)
+        return cls.from_arrays(z[name + "_vertices"], z[name + "_indices"])
 
     @classmethod
     def ball(cls, n_lat, n_lon, bump=0.05):

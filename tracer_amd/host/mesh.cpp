@@ -403,6 +403,19 @@ trc_status trc_host_mesh_make_ball(uint32_t n_lat, uint32_t n_lon, float bump, t
     return TRC_OK;
 }
 
+trc_status trc_host_mesh_from_arrays(const trc_TriangleVertex* vertices, uint32_t n_vertices, const uint32_t* indices,
+                                     uint32_t n_indices, trc_host_mesh** out) {
+    if (!vertices || !indices || !out || n_vertices == 0 || n_indices < 3 || n_indices % 3) return TRC_ERR_INVALID_ARG;
+    for (uint32_t i = 0; i < n_indices; ++i)
+        if (indices[i] >= n_vertices) return TRC_ERR_INVALID_ARG;
+    trc_host_mesh* m = new (std::nothrow) trc_host_mesh();
+    if (!m) return TRC_ERR_OOM;
+    m->vertices.assign(vertices, vertices + n_vertices);
+    m->indices.assign(indices, indices + n_indices);
+    *out = m;
+    return TRC_OK;
+}
+
 trc_status trc_host_mesh_replicate(const trc_host_mesh* src, uint32_t k, float spacing, trc_host_mesh** out) {
     if (!src || !out || k == 0) return TRC_ERR_INVALID_ARG;
     trc_host_mesh* m = new (std::nothrow) trc_host_mesh();
