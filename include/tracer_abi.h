@@ -254,6 +254,11 @@ enum trc_integrator {
                                        draws from the copy, and the texel keeps the stream as castRay left it.
                                        TRC_INTEGRATOR_PATH / _MIS only, 2 * max_depth <= 40 dimensions; with
                                        view_height the sampler sees the pixel and size of its own view. */
+#define TRC_FLAG_SMALL_BLOCKS    8u  /* one 4x4 pixel block on 16 lanes per wavefront instead of 8x8 on 64 (a scheduling
+                                       choice only: pixels are independent).  Pays when a launch has about as many
+                                       blocks as the GPU has wavefront slots, i.e. a rank's share of a strong-scaled
+                                       frame; chosen automatically there unless TRC_FLAG_LARGE_BLOCKS is set */
+#define TRC_FLAG_LARGE_BLOCKS   16u
 #define TRC_FLAG_COLLECT_STATS  1u  /* run the instrumented kernel variant: exact
                                        N_descend / N_return / leaf-test counters */
 
@@ -392,8 +397,9 @@ trc_status trc_synchronize(trc_ctx* ctx);
 
 /* test hook = Scene::hit (Render.hh:135-252) on a batch of rays (host buffers).  `any_hit` is a bit set: */
 #define TRC_TRACE_ANY_HIT     1   /* stop at the first accepted hit closer than tmax (shadow rays, Render.hh:244) */
-#define TRC_TRACE_PRODUCTION  2   /* walk the tree exactly as the render kernels do (speculative two-leaf rounds,
-                                     no instrumentation): same hit record, n_descend / n_return / n_leaf left 0 */
+#define TRC_TRACE_PRODUCTION  2   /* walk the tree with the round the render kernels run (no instrumentation; on trees
+                                     read from global memory the wavefront leaves the descent early, dev_intersect.hpp):
+                                     same hit record, n_descend / n_return / n_leaf left 0 */
 trc_status trc_trace_rays(trc_ctx* ctx, const trc_ray* rays, size_t n, trc_hit* out, int any_hit);
 
 trc_status trc_get_stats(trc_ctx* ctx, trc_stats* out);   /* synchronises the stream */

@@ -1,9 +1,11 @@
-"""The traversal the RENDER kernels run (speculative two-leaf rounds, dev_intersect.hpp::trav_iter) through the
+"""The traversal the RENDER kernels run (production instantiations of dev_intersect.hpp::trav_iter) through the
 Scene::hit test hook: trc_trace_rays(..., TRC_TRACE_PRODUCTION) against the oracle's literal Render.hh:135-252 walk.
 
 Counters are not produced by the production walk; the whole HitRecord is compared bit for bit.  The adversarial
-batches aim at the one place where a speculative walk could leave the reference's order: a primitive that is tested
-although the reference would already have culled its box with a freshly lowered closest hit.
+batches aim at the one place where a walk that reorders work across lanes could leave the reference's order: a
+primitive that is tested although the reference would already have culled its box with a freshly lowered closest hit
+(round 1's speculative round does exactly that: built as `make variant NAME=unchecked DEFS=-DTRC_SPEC_UNCHECKED` it
+fails test_adversarial_batches, 6 of 6 seeds -- profiles/r02/traversal_teeth.txt).
   * spheres LARGER than their boxes (MakeSphere inflates the radius by 1e-4, not the AABB, Tracer.mm:165-172) with an
     occluder placed between the sphere surface and the box face,
   * rays that start inside many nested / overlapping boxes,

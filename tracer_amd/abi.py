@@ -27,6 +27,7 @@ SCENE_CORNELL, SCENE_CORNELL_SPHERES, SCENE_CORNELL_MESH, SCENE_CORNELL_VOLUME =
 FLAG_COLLECT_STATS = 1
 FLAG_FIXED_ORDER = 2
 FLAG_SOBOL = 4
+FLAG_SMALL_BLOCKS, FLAG_LARGE_BLOCKS = 8, 16
 TRACE_ANY_HIT, TRACE_PRODUCTION = 1, 2
 SOBOL_DIMS, SOBOL_MATRIX_SIZE = 40, 52
 

@@ -399,39 +399,36 @@ TRC_DEV bool trav_test_leaf(const SceneRef& S, const Ray& ray, HitRec& rec, Trav
 // one round: (1) expand interior nodes until this lane holds a leaf (or runs out of work) -- the whole wavefront
 // does box tests here; (2) test the leaf.  Lanes with tv.done set idle through the call.
 //
-// Production kernels (STATS = false) run the SPECULATIVE form of the round (Aila & Laine, HPG 2009): a lane that
-// reaches a leaf while its neighbours are still descending postpones that leaf, pops its next node and keeps
-// descending until it reaches a second leaf.  The postponed leaf is tested first.  What the lane did after the
-// postponement ran against an ry the reference would already have lowered IF that test accepts a hit, so:
-//   * test rejected (ry unchanged): every box test of the speculative stretch saw exactly the reference's ry -- its
-//     pushes, pops and the second leaf ARE the reference's next steps, and the second leaf is tested at once;
-//   * test accepted: the lane returns to the snapshot taken at the postponement (tag + stack height) and walks that
-//     stretch again in the next round with the new ry.  Speculative pushes lie above the snapshot height and the
-//     stretch never pops below it (a dead end there parks the lane, kTagStall), so the snapshot is still intact.
-// Hence the sequence of box tests that count, primitive tests and ry values is the reference's own, step for step
-// -- no argument about floating-point containment of a primitive in its box is needed (a sphere is even larger
-// than its box: MakeSphere inflates the radius, not the AABB, Tracer.mm:165-172).  The exact traversal counters are
-// taken by the instrumented kernels, which run the plain round.
+// Every lane performs exactly ITS OWN sequence of the reference's steps (box tests against its own running closest
+// hit, near child first, far child deferred without a re-test, primitive tests in that order); what a production
+// kernel is free to choose is the INTERLEAVING across the lanes of a wavefront:
+//   * the instrumented kernels descend until every lane holds a leaf (and take the exact counters);
+//   * production kernels on a tree read from global memory leave the descent as soon as fewer than
+//     TRC_DESCEND_MIN_GLOBAL lanes are still descending while others wait with a leaf: a few lanes of a mesh ray
+//     batch walk 50-300 nodes while their neighbours need 10, and a dependent L2 round trip per step makes waiting
+//     for them the dominant cost (config 3: 77.8 -> 70.7 ms, config 4: 40.9 -> 35.7 ms with 8; 2 / 4 / 6 / 12 / 16 /
+//     24 / 40 measured: tools/ab_bench.py).  The stragglers resume in the next round;
+//   * on an LDS-resident tree the plain round is the fastest (22.7 ms; thresholds 2..40: 24.0-25.5 ms).
+// Round 1 shipped a SPECULATIVE round instead (Aila & Laine 2009: a lane that reaches a leaf early postpones it and keeps
+// descending against its not-yet-updated closest hit).  That visits a superset of the reference's boxes and can test a
+// primitive the reference culls -- harmless only if a primitive's computed t is never below its box's computed entry
+// t, which does not hold (MakeSphere makes spheres LARGER than their boxes, Tracer.mm:165-172;
+// tests/test_gpu_traversal.py constructs the case and the speculative round fails it).  A checked form (snapshot +
+// rollback when the postponed test accepts) is exact but slower than the plain round (measured: 23.9 / 75.5 / 39.3 ms
+// against 22.6 / 77.8 / 40.9 plain and 22.7 / 70.8 / 35.7 for the threshold round); the unchecked one survives only as
+// the A/B variant TRC_SPEC_UNCHECKED, the build that must FAIL the adversarial test.
 template <bool ALL_LDS, bool STATS, bool ANY, bool EAGER_UV, bool VOL = false>
 TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const float test_t, Trav& tv,
                        uint32_t* stack, uint32_t* lvstack, TravCounters& cnt) {
     const float rx = FLT_MIN;
-    constexpr bool SPEC = !STATS;
-    if (SPEC) {
-        constexpr uint32_t kTagStall = 5u << kTagIndexBits;   // speculative dead end at the snapshot height: wait for the test
-#ifdef TRC_SPEC_UNCHECKED   // A/B builds only (Makefile `variant`): round 1's unchecked round -- what the snapshot costs, and
-        constexpr bool kChecked = false;                      // the build tests/test_gpu_traversal.py must FAIL on
-#else
-        constexpr bool kChecked = true;
-#endif
+#ifdef TRC_SPEC_UNCHECKED
+    if (!STATS) {
         uint32_t pend = kTagNone;                      // postponed leaf
-        uint32_t snap_tag = kTagNone, snap_sp = 0;     // state right after the postponement
         auto pop_next = [&]() {                        // next deferred sibling, or "exhausted" (kTagNone)
             if (tv.sp == 0) { tv.tag = kTagNone; return; }
             tv.sp--;
             tv.tag = stack[tv.sp * kBlock];
         };
-        auto postpone = [&]() { pend = tv.tag; pop_next(); snap_tag = tv.tag; snap_sp = tv.sp; };
         for (;;) {
             const bool interior = !tv.done && (tv.tag >> kTagIndexBits) == kTagInterior;
             if (__ballot(interior) == 0ull) break;
@@ -446,24 +443,19 @@ TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const flo
                     const bool left_first = t_left < t_right;
                     if (left_test && right_test) { stack[tv.sp * kBlock] = left_first ? tagR : tagL; tv.sp++; }
                     tv.tag = left_first ? tagL : tagR;
-                } else if (kChecked && pend != kTagNone && tv.sp == snap_sp) {
-                    tv.tag = kTagStall;                // would consume an entry from below the snapshot
                 } else {
                     pop_next();
                 }
-                if (pend == kTagNone && (tv.tag >> kTagIndexBits) < kTagInterior) postpone();
+                if (pend == kTagNone && (tv.tag >> kTagIndexBits) < kTagInterior) { pend = tv.tag; pop_next(); }
             }
         }
         if (!tv.done) {
-            // first leaf of the round: the postponed one, or (a lane that entered the round on a leaf) the current one
-            if (pend == kTagNone && (tv.tag >> kTagIndexBits) < kTagInterior) postpone();
+            if (pend == kTagNone && (tv.tag >> kTagIndexBits) < kTagInterior) { pend = tv.tag; pop_next(); }
             if (pend != kTagNone) {
-                const bool accepted = trav_test_leaf<STATS, EAGER_UV, VOL>(S, ray, rec, tv, pend, cnt);
+                trav_test_leaf<STATS, EAGER_UV, VOL>(S, ray, rec, tv, pend, cnt);
                 if (ANY && tv.ry < test_t) tv.done = true;                       // Render.hh:244
-                else if (kChecked && accepted) { tv.tag = snap_tag; tv.sp = snap_sp; }   // ry moved: redo the speculative stretch
-                else if (tv.tag == kTagStall) pop_next();                        // the dead end was real
             }
-            if (!tv.done && (tv.tag >> kTagIndexBits) < kTagInterior) {          // next leaf of the reference's order
+            if (!tv.done && (tv.tag >> kTagIndexBits) < kTagInterior) {          // second leaf, found after the first
                 trav_test_leaf<STATS, EAGER_UV, VOL>(S, ray, rec, tv, tv.tag, cnt);
                 if (ANY && tv.ry < test_t) tv.done = true;
                 else pop_next();
@@ -472,7 +464,22 @@ TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const flo
         }
         return;
     }
-    while (!tv.done && (tv.tag >> kTagIndexBits) == kTagInterior) {
+#endif
+#ifndef TRC_DESCEND_MIN_LDS
+#define TRC_DESCEND_MIN_LDS 1
+#endif
+#ifndef TRC_DESCEND_MIN_GLOBAL
+#define TRC_DESCEND_MIN_GLOBAL 8
+#endif
+    constexpr int kDescendMin = ALL_LDS ? TRC_DESCEND_MIN_LDS : TRC_DESCEND_MIN_GLOBAL;
+    for (;;) {
+        const bool interior = !tv.done && (tv.tag >> kTagIndexBits) == kTagInterior;
+        if (!STATS && kDescendMin > 1) {
+            const unsigned long long m = __ballot(interior);
+            if (m == 0ull) break;
+            if (__popcll(m) < kDescendMin && __ballot(!tv.done && !interior) != 0ull) break;
+            if (!interior) continue;
+        } else if (!interior) break;
         float4 q0, q1, q2, q3;
         load_node<ALL_LDS>(S, tv.tag & kTagIndexMask, q0, q1, q2, q3);
         if (STATS) cnt.n_descend++;
@@ -494,7 +501,7 @@ TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const flo
             trav_pop_or_finish<STATS>(tv, tv.level - 1, stack, lvstack, cnt);
         }
     }
-    if (!tv.done) {
+    if (!tv.done && (tv.tag >> kTagIndexBits) != kTagInterior) {
         trav_test_leaf<STATS, EAGER_UV, VOL>(S, ray, rec, tv, tv.tag, cnt);
         if (ANY && tv.ry < test_t) tv.done = true;                    // Render.hh:244
         else trav_pop_or_finish<STATS>(tv, tv.level, stack, lvstack, cnt);

@@ -43,18 +43,18 @@ template <bool LDS, bool STATS, int INTEGRATOR, bool SOBOL = false>
 __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRATOR_VOLUME ? 3 : 4)) k_render(const KRender kp) {
     const DScene& sc = kp.ks.sc;
     const uint32_t* small_base = stage_scene(sc);
-    uint32_t* stack_base = trc_smem + sc.lds_dwords;
-    uint32_t* stack = stack_base + threadIdx.x;
-    uint32_t* lvstack = stack + sc.stack_depth * kBlock;
+    uint32_t* stack = lane_stack(sc);
+    uint32_t* lvstack = lane_lvstack(sc);
 
     const uint64_t t_start = clock64();          // this wavefront's own duration = the next launch's sort key
     const uint32_t canon = kp.order ? kp.order[blockIdx.x] : blockIdx.x;     // adaptive launch order (trc_render)
-    const uint32_t tile = kp.tiles[canon];                      // 8x8 block: x | y << 16 in units of 8 pixels
+    const uint32_t tile = kp.tiles[canon];                      // pixel block: x | y << 16 in units of the block edge
     const uint32_t lane = threadIdx.x;
-    const uint32_t px = (tile & 0xFFFFu) * 8u + (lane & 7u);
-    const uint32_t py = (tile >> 16) * 8u + (lane >> 3);
+    const uint32_t bs = kp.blk_shift;                           // 3: 8x8 pixels, all 64 lanes; 2: 4x4 pixels, lanes 0..15
+    const uint32_t px = ((tile & 0xFFFFu) << bs) + (lane & ((1u << bs) - 1u));
+    const uint32_t py = ((tile >> 16) << bs) + (lane >> bs);
     const uint32_t W = kp.fr.width, H = kp.fr.height;
-    const bool active = px < W && py < H;
+    const bool active = lane < (1u << (2u * bs)) && px < W && py < H;
 
     uint32_t n_rays = 0, n_shaded = 0, n_paths = 0;
     TravCounters cnt;
@@ -188,7 +188,7 @@ template <bool LDS, int INTEGRATOR, bool SOBOL>
 __global__ void __launch_bounds__(kBlock, INTEGRATOR == TRC_INTEGRATOR_VOLUME ? 3 : 4) k_render_strip(const KRender kp) {
     const DScene& sc = kp.ks.sc;
     const uint32_t* small_base = stage_scene(sc);
-    uint32_t* stack = trc_smem + sc.lds_dwords + threadIdx.x;
+    uint32_t* stack = lane_stack(sc);
     const uint64_t t_start = clock64();
     const uint32_t canon = kp.order ? kp.order[blockIdx.x] : blockIdx.x;     // strip index
     const uint32_t lane = threadIdx.x;
@@ -238,9 +238,10 @@ __global__ void __launch_bounds__(kBlock, INTEGRATOR == TRC_INTEGRATOR_VOLUME ? 
         alive = false;
         while (blk < blk_end) {
             const uint32_t tile = kp.tiles[blk++];
-            const uint32_t px = (tile & 0xFFFFu) * 8u + (lane & 7u);
-            const uint32_t py = (tile >> 16) * 8u + (lane >> 3);
-            if (px < W && py < H) {
+            const uint32_t bs = kp.blk_shift;
+            const uint32_t px = ((tile & 0xFFFFu) << bs) + (lane & ((1u << bs) - 1u));
+            const uint32_t py = ((tile >> 16) << bs) + (lane >> bs);
+            if (lane < (1u << (2u * bs)) && px < W && py < H) {
                 pix = py * W + px;
                 texel = reinterpret_cast<const uint4*>(kp.fr.rng)[pix];
                 const float4 acc = reinterpret_cast<const float4*>(kp.fr.accum)[pix];
@@ -351,8 +352,8 @@ template <bool LDS, bool ANY, bool STATS>
 __global__ void __launch_bounds__(kBlock) k_trace(const KTrace kp) {
     const DScene& sc = kp.ks.sc;
     const uint32_t* small_base = stage_scene(sc);
-    uint32_t* stack = trc_smem + sc.lds_dwords + threadIdx.x;
-    uint32_t* lvstack = stack + sc.stack_depth * kBlock;
+    uint32_t* stack = lane_stack(sc);
+    uint32_t* lvstack = lane_lvstack(sc);
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= kp.n) return;
     const trc_ray in = kp.rays[i];
@@ -392,6 +393,8 @@ namespace {
 }  // namespace
 
 namespace {
+
+constexpr bool kAutoSmallBlocks = false;      // decided by measurement (tools/tile_balance.py); see DESIGN.md section 5
 
 inline trc_status fail(trc_ctx* ctx, trc_status st, const std::string& msg) { return trc_fail(ctx, st, msg); }
 
@@ -503,19 +506,21 @@ trc_status build_blob(trc_ctx* ctx, const trc_scene* s, std::vector<uint32_t>& b
 // every XCD receives the same mix.  Measured: handing each XCD a contiguous band of the image instead (the
 // "L2-friendly" order) costs 22 % on the Cornell scene and 44 % on the 1 M-triangle scene, because the XCD whose
 // band holds the glass / mesh pixels finishes long after the others; 8x8-tile blocks per XCD sit in between.
-std::vector<uint32_t> make_tiles(uint32_t W, uint32_t H, uint32_t nranks, uint32_t rank, uint32_t view_height) {
-    // ownership is decided per TRC_TILE x TRC_TILE tile; the launch unit is the 8x8 block (one wavefront)
-    const uint32_t bw = (W + 7) / 8, bh = (H + 7) / 8;
+std::vector<uint32_t> make_tiles(uint32_t W, uint32_t H, uint32_t nranks, uint32_t rank, uint32_t view_height, uint32_t blk_shift) {
+    // ownership is decided per TRC_TILE x TRC_TILE tile; the launch unit is the pixel block of one wavefront:
+    // 8x8 (blk_shift 3) or, for launches with too few blocks to fill the GPU, 4x4 on 16 lanes (blk_shift 2)
+    const uint32_t e = 1u << blk_shift;
+    const uint32_t bw = (W + e - 1) / e, bh = (H + e - 1) / e;
     std::vector<uint32_t> mine;
     for (uint32_t by = 0; by < bh; ++by)
         for (uint32_t bx = 0; bx < bw; ++bx)
-            if ((bx * 8 / TRC_TILE + by * 8 / TRC_TILE) % nranks == rank) mine.push_back(bx | (by << 16));
+            if ((bx * e / TRC_TILE + by * e / TRC_TILE) % nranks == rank) mine.push_back(bx | (by << 16));
     if (view_height != 0 && view_height < H) {
         // stacked views: walk the rows of ALL views together (row within the view first), so the launch ends on the
         // last rows of every view like a single-view launch does.  View after view, the expensive blocks of the final
         // view would start a few ms before the end of the list and run on alone (measured 28-31 ms instead of 25).
         std::stable_sort(mine.begin(), mine.end(), [&](uint32_t a, uint32_t b) {
-            const uint32_t ra = ((a >> 16) * 8u) % view_height / 8u, rb = ((b >> 16) * 8u) % view_height / 8u;
+            const uint32_t ra = ((a >> 16) * e) % view_height / e, rb = ((b >> 16) * e) % view_height / e;
             return ra < rb;
         });
     }
@@ -559,9 +564,10 @@ size_t trc_dyn_lds_bytes(const trc_ctx* ctx, bool stats) {
     return dwords * 4;
 }
 
-trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32_t view_height) {
-    if (ctx->d_tiles && ctx->d_block_cost && ctx->tiles_nranks == nranks && ctx->tiles_rank == rank && ctx->tiles_view_height == view_height) return TRC_OK;
-    std::vector<uint32_t> tiles = make_tiles(ctx->width, ctx->height, nranks, rank, view_height);
+trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32_t view_height, uint32_t blk_shift) {
+    if (ctx->d_tiles && ctx->d_block_cost && ctx->tiles_nranks == nranks && ctx->tiles_rank == rank &&
+        ctx->tiles_view_height == view_height && ctx->tiles_blk_shift == blk_shift) return TRC_OK;
+    std::vector<uint32_t> tiles = make_tiles(ctx->width, ctx->height, nranks, rank, view_height, blk_shift);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     // the cache key (tiles_nranks ...) is written LAST: a failed allocation below leaves the list invalid, so the next
     // call rebuilds it instead of launching with a null block_cost / order buffer
@@ -583,7 +589,7 @@ trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_tiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
-    ctx->tiles_nranks = nranks; ctx->tiles_rank = rank; ctx->tiles_view_height = view_height;
+    ctx->tiles_nranks = nranks; ctx->tiles_rank = rank; ctx->tiles_view_height = view_height; ctx->tiles_blk_shift = blk_shift;
     return TRC_OK;
 }
 
@@ -899,7 +905,20 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
     if (p->spp == 0) return TRC_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
-    { trc_status ts = trc_ensure_tiles(ctx, nranks, p->tile_rank, p->view_height); if (ts != TRC_OK) return ts; }
+    // Launch geometry.  One 8x8 block per wavefront fills the GPU when there are many more blocks than wavefront slots
+    // (32 400 blocks for 4 096 slots at 1080p).  A rank that owns 1/N of the frame (strong scaling) has about one block
+    // per slot: the launch then lasts as long as its slowest wavefront, and a wavefront is as slow as the union of its
+    // 64 pixels' branches.  4x4 blocks on 16 lanes give 4x the wavefronts, each with a quarter of the pixels to wait
+    // for -- the same pixels, the same arithmetic per pixel (TRC_FLAG_SMALL_BLOCKS forces it, _LARGE_BLOCKS forbids it).
+    uint32_t blk_shift = 3;
+    {
+        const uint64_t slots = (uint64_t)ctx->cu_count * 16u;
+        const uint64_t blocks8 = (uint64_t)((ctx->width + 7) / 8) * ((ctx->height + 7) / 8) / nranks;
+        const bool fits = ctx->width <= 65535u * 4u && ctx->height <= 65535u * 4u;
+        if ((p->flags & TRC_FLAG_SMALL_BLOCKS) && fits) blk_shift = 2;
+        else if (!(p->flags & TRC_FLAG_LARGE_BLOCKS) && fits && kAutoSmallBlocks && blocks8 < 2 * slots && p->spp >= 8) blk_shift = 2;
+    }
+    { trc_status ts = trc_ensure_tiles(ctx, nranks, p->tile_rank, p->view_height, blk_shift); if (ts != TRC_OK) return ts; }
     if (ctx->n_tiles == 0) return TRC_OK;
 
     const bool stats = (p->flags & TRC_FLAG_COLLECT_STATS) != 0;
@@ -922,6 +941,7 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
     kp.spp = p->spp; kp.max_depth = p->max_depth; kp.frame0 = p->frame0;
     kp.view_height = (p->view_height != 0 && p->view_height < ctx->height) ? p->view_height : ctx->height;
     kp.tiles = ctx->d_tiles;
+    kp.blk_shift = blk_shift;
     kp.stats = ctx->d_stats;
     kp.block_cost = ctx->d_block_cost;
     kp.order = nullptr;

@@ -34,6 +34,7 @@ struct KRender {
     trc_GridDensityInfo dinfo;
     const uint8_t* occupancy;           // ... and its 4x4x4-brick occupancy (dev_integrator.hpp::grid_sample)
     unsigned long long* stats;          // kStatCount counters
+    uint32_t blk_shift;                 // log2 of the pixel-block edge of one wavefront: 3 (8x8, 64 lanes) or 2 (4x4, 16 lanes)
     uint32_t n_tiles, strip;            // k_render_strip: blocks in `tiles`, consecutive blocks per wavefront (1: k_render)
     const uint32_t* order;              // launch order: order[blockIdx.x] = index into `tiles` (null: identity)
     uint32_t* block_cost;               // duration of each block of `tiles` in this launch (the next launch's sort key)
@@ -58,6 +59,11 @@ __device__ __forceinline__ const uint32_t* stage_scene(const DScene& sc) {
     __syncthreads();
     return trc_smem;
 }
+
+// this lane's column of the traversal stack (one row per entry); the instrumented kernels keep a second region of the
+// same size for the levels
+__device__ __forceinline__ uint32_t* lane_stack(const DScene& sc) { return trc_smem + sc.lds_dwords + threadIdx.x; }
+__device__ __forceinline__ uint32_t* lane_lvstack(const DScene& sc) { return trc_smem + sc.lds_dwords + sc.stack_depth * kBlock + threadIdx.x; }
 
 __device__ __forceinline__ SceneRef make_scene_ref(const DScene& sc, const uint32_t* small_base) {
     SceneRef S;
@@ -120,7 +126,7 @@ struct trc_ctx {
     bool cost_valid = false; uint32_t cost_strip = 1;
     const uint32_t* d_last_order = nullptr; uint32_t order_age = 0;     // most recent sorted order (short launches reuse it)
     int cu_count = 0;
-    uint32_t n_tiles = 0, tiles_nranks = 0, tiles_rank = 0, tiles_view_height = 0;
+    uint32_t n_tiles = 0, tiles_nranks = 0, tiles_rank = 0, tiles_view_height = 0, tiles_blk_shift = 3;
 
     // stats
     unsigned long long* d_stats = nullptr;
@@ -176,7 +182,7 @@ bool trc_load_rccl(std::string& err);
 constexpr int kNcclUint8 = 1, kNcclUint32 = 3, kNcclFloat = 7, kNcclSum = 0, kNcclMax = 2, kNcclMin = 3;
 
 // tiles owned by `rank` of `nranks` (XCD-aware order) uploaded into ctx->d_tiles; shared by render and SPPM
-trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32_t view_height = 0);
+trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32_t view_height = 0, uint32_t blk_shift = 3);
 size_t trc_dyn_lds_bytes(const trc_ctx* ctx, bool stats);
 // trc_lbvh.hip: stable 24-bit radix sort of (key, value) pairs
 void trc_sort_pairs24(hipStream_t st, uint32_t* keys[2], uint32_t* vals[2], uint32_t* hist, uint32_t* digit_base, uint32_t n, int* result);

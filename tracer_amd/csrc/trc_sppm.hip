@@ -111,8 +111,8 @@ __device__ __forceinline__ SppmCtx make_sppm_ctx(const KSppm& kp, const uint32_t
     cx.sh.mats = small_base + sc.off_materials;
     cx.ambient = f3(kp.ambient[0], kp.ambient[1], kp.ambient[2]);
     cx.env.rgb = kp.env_rgb; cx.env.w = kp.env_w; cx.env.h = kp.env_h;
-    cx.stack = trc_smem + sc.lds_dwords + threadIdx.x;
-    cx.lvstack = cx.stack + sc.stack_depth * kBlock;
+    cx.stack = lane_stack(sc);
+    cx.lvstack = lane_lvstack(sc);
     return cx;
 }
 template <bool ALL_LDS>

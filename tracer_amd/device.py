@@ -203,9 +203,10 @@ class Tracer:
 
     # --- the hot path --------------------------------------------------------------
     def render(self, spp=1, max_depth=8, integrator=abi.INTEGRATOR_PATH, frame0=0, tile_rank=0, tile_nranks=1,
-               collect_stats=False, view_height=0, fixed_order=False, sobol=False):
+               collect_stats=False, view_height=0, fixed_order=False, sobol=False, small_blocks=None):
         flags = ((abi.FLAG_COLLECT_STATS if collect_stats else 0) | (abi.FLAG_FIXED_ORDER if fixed_order else 0) |
-                 (abi.FLAG_SOBOL if sobol else 0))
+                 (abi.FLAG_SOBOL if sobol else 0) |
+                 (0 if small_blocks is None else (abi.FLAG_SMALL_BLOCKS if small_blocks else abi.FLAG_LARGE_BLOCKS)))
         prm = abi.Params(spp=spp, max_depth=max_depth, integrator=integrator, frame0=frame0, tile_rank=tile_rank,
                          tile_nranks=tile_nranks, flags=flags, view_height=view_height)
         self._check(self._L.trc_render(self._h, C.byref(prm)), "trc_render")
