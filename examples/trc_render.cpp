@@ -4,6 +4,8 @@
 //
 //   trc_render [--scene cornell|spheres|volume] [--integrator path|mis|volume] [--size W H] [--spp N]
 //              [--mesh file.obj|file.pbrt] [--density cloud.pbrt] [--lbvh] [--sobol] [--out frame.png]
+//   trc_render --pbrt scene.pbrt [--integrator path|mis] [--spp N] [--size W H] [--out frame.png]
+//              a whole pbrt-v3 scene (camera, film, lights, materials, spheres, meshes: trc_host_scene_load_pbrt)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -23,14 +25,15 @@
     } while (0)
 
 int main(int argc, char** argv) {
-    std::string scene_name = "spheres", integ_name = "path", out = "frame.png", mesh_path, density_path;
+    std::string scene_name = "spheres", integ_name = "path", out = "frame.png", mesh_path, density_path, pbrt_path;
     uint32_t W = 640, H = 360, spp = 64;
-    bool lbvh = false, sobol = false;
+    bool lbvh = false, sobol = false, size_given = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--scene" && i + 1 < argc) scene_name = argv[++i];
         else if (a == "--integrator" && i + 1 < argc) integ_name = argv[++i];
-        else if (a == "--size" && i + 2 < argc) { W = (uint32_t)std::atoi(argv[++i]); H = (uint32_t)std::atoi(argv[++i]); }
+        else if (a == "--size" && i + 2 < argc) { W = (uint32_t)std::atoi(argv[++i]); H = (uint32_t)std::atoi(argv[++i]); size_given = true; }
+        else if (a == "--pbrt" && i + 1 < argc) pbrt_path = argv[++i];          // a whole pbrt-v3 scene
         else if (a == "--spp" && i + 1 < argc) spp = (uint32_t)std::atoi(argv[++i]);
         else if (a == "--mesh" && i + 1 < argc) mesh_path = argv[++i];          // Wavefront OBJ or pbrt-v3 trianglemeshes
         else if (a == "--density" && i + 1 < argc) density_path = argv[++i];    // pbrt-v3 heterogeneous medium
@@ -56,11 +59,27 @@ int main(int argc, char** argv) {
         }
         trc_host_mesh_view(mesh, &mv, &n_mv, &mi, &n_mi);
     }
-    if (trc_host_scene_create(kind, mv, n_mv, mi, n_mi, &hs) != TRC_OK) { std::fprintf(stderr, "scene prep failed\n"); return 1; }
+    trc_Camera cam;
+    if (!pbrt_path.empty()) {
+        trc_pbrt_info info;
+        if (trc_host_scene_load_pbrt(pbrt_path.c_str(), &hs, &cam, &info, nullptr, 0) != TRC_OK) {
+            std::fprintf(stderr, "cannot read a scene from %s\n", pbrt_path.c_str());
+            return 1;
+        }
+        if (!size_given) { W = info.xres; H = info.yres; }         // the camera's aspect is the film's
+        if (integrator != TRC_INTEGRATOR_PATH && !info.mis_ready) {
+            std::fprintf(stderr, "%s has no rectangular area light: traceMIS samples squareList[5] / [6]; use --integrator path\n", pbrt_path.c_str());
+            return 1;
+        }
+        scene_name = pbrt_path;
+        std::fprintf(stderr, "%s: %u shapes (%u not handled), %u materials not handled\n", pbrt_path.c_str(), info.n_shapes,
+                     info.n_unsupported_shapes, info.n_unsupported_materials);
+    } else {
+        if (trc_host_scene_create(kind, mv, n_mv, mi, n_mi, &hs) != TRC_OK) { std::fprintf(stderr, "scene prep failed\n"); return 1; }
+        trc_host_prepare_camera(&cam, (float)W, (float)H);
+    }
     trc_scene scene;
     trc_host_scene_view(hs, &scene);
-    trc_Camera cam;
-    trc_host_prepare_camera(&cam, (float)W, (float)H);
 
     CHECK(trc_create(0, &ctx));
     if (lbvh) {                                   // hand over the leaf records only; the tree is built on the GPU

@@ -533,6 +533,43 @@ trc_status trc_host_mesh_load_obj(const char* path, trc_host_mesh** out);
  * transformation matrix, normals through its inverse transpose (smooth normals when absent), uv / st, Include
  * followed; shapes inside ObjectBegin/ObjectEnd and other shape types are skipped */
 trc_status trc_host_mesh_load_pbrt(const char* path, trc_host_mesh** out);
+/* A whole scene from a pbrt-v3 file -- the reference's unchecked to-do "Support pbrt-v3 file format"
+ * (RT_Metal/README.md:57, the vendored parser RT_Metal/Tracer/minipbrt.h:1528-1546, its one call site
+ * AAPLRenderer.mm:626-651): Camera "perspective" + LookAt, Film resolution, AreaLightSource "diffuse", Material
+ * matte / plastic / metal / mirror / glass (+ MakeNamedMaterial / NamedMaterial), Shape "sphere" and "trianglemesh"
+ * through the transformation and attribute stacks, Include.  Mapping onto the reference's primitives
+ * (tracer_amd/host/pbrt_scene.cpp): sphere -> trc_Sphere; a trianglemesh that is an axis-aligned rectangle ->
+ * trc_Square, emitters placed at squareList[5] / [6] (the two lights traceMIS samples); any other mesh -> triangles with
+ * material 19.
+ * `info` / `shapes` (optional, up to `capacity` entries in file order) describe what was parsed and what it became;
+ * the scene handle is used like one from trc_host_scene_create. */
+enum trc_pbrt_material { TRC_PBRT_MATTE = 0, TRC_PBRT_PLASTIC = 1, TRC_PBRT_METAL = 2, TRC_PBRT_MIRROR = 3,
+                         TRC_PBRT_GLASS = 4, TRC_PBRT_OTHER = 5 };
+typedef struct trc_pbrt_info {
+    float    camera_to_world[16];   /* row-major, inverse of the CTM at the Camera directive (minipbrt Camera::cameraToWorld) */
+    float    fov, lensradius, focaldistance;
+    uint32_t perspective;           /* Camera "perspective" */
+    uint32_t xres, yres;            /* Film "image" */
+    uint32_t n_shapes;              /* world shapes in file order (object templates excluded) */
+    uint32_t n_unsupported_shapes, n_unsupported_materials, n_triangle_material_conflicts;
+    uint32_t mis_ready;             /* squareList[5] and [6] are emitters: TRC_INTEGRATOR_MIS / _VOLUME are usable */
+} trc_pbrt_info;
+typedef struct trc_pbrt_shape {
+    int32_t  kind;                  /* TRC_PRIM_SPHERE, TRC_PRIM_TRIANGLE (trianglemesh) or -1 (not handled) */
+    float    shape_to_world[16];    /* row-major CTM at the Shape directive */
+    float    radius;                /* spheres */
+    uint32_t n_vertices, n_indices; /* triangle meshes */
+    int32_t  material;              /* enum trc_pbrt_material of the graphics state */
+    float    color[3];              /* Kd (matte, plastic, other), Kr (mirror), Kt (glass), 1 (metal) */
+    int32_t  emitter;               /* inside an AreaLightSource "diffuse" */
+    float    L[3];
+    int32_t  mapped_type;           /* TRC_PRIM_SPHERE / _SQUARE / _TRIANGLE it became, -1 if dropped */
+    uint32_t mapped_index;          /* index in that primitive list (first triangle for a mesh) */
+    uint32_t mapped_material;       /* index into the scene's material table */
+} trc_pbrt_shape;
+trc_status trc_host_scene_load_pbrt(const char* path, trc_host_scene** out_scene, trc_Camera* out_camera,
+                                    trc_pbrt_info* info, trc_pbrt_shape* shapes, uint32_t capacity);
+
 /* procedural stand-in for the missing/untravelling assets: a displaced
  * UV-sphere "ball" with n_lat x n_lon quads (2 triangles each) */
 trc_status trc_host_mesh_make_ball(uint32_t n_lat, uint32_t n_lon, float bump, trc_host_mesh** out);

@@ -139,6 +139,24 @@ class GridDensityInfo(C.Structure):
                 ("invMaxDensity", C.c_float), ("nx", C.c_uint32), ("ny", C.c_uint32), ("nz", C.c_uint32)]
 
 
+# enum trc_pbrt_material
+PBRT_MATTE, PBRT_PLASTIC, PBRT_METAL, PBRT_MIRROR, PBRT_GLASS, PBRT_OTHER = range(6)
+
+
+class PbrtInfo(C.Structure):
+    _fields_ = [("camera_to_world", C.c_float * 16), ("fov", C.c_float), ("lensradius", C.c_float),
+                ("focaldistance", C.c_float), ("perspective", C.c_uint32), ("xres", C.c_uint32), ("yres", C.c_uint32),
+                ("n_shapes", C.c_uint32), ("n_unsupported_shapes", C.c_uint32), ("n_unsupported_materials", C.c_uint32),
+                ("n_triangle_material_conflicts", C.c_uint32), ("mis_ready", C.c_uint32)]
+
+
+class PbrtShape(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("shape_to_world", C.c_float * 16), ("radius", C.c_float),
+                ("n_vertices", C.c_uint32), ("n_indices", C.c_uint32), ("material", C.c_int32), ("color", C.c_float * 3),
+                ("emitter", C.c_int32), ("L", C.c_float * 3), ("mapped_type", C.c_int32), ("mapped_index", C.c_uint32),
+                ("mapped_material", C.c_uint32)]
+
+
 class Params(C.Structure):
     _fields_ = [("spp", C.c_uint32), ("max_depth", C.c_uint32), ("integrator", C.c_uint32),
                 ("frame0", C.c_uint32), ("tile_rank", C.c_uint32), ("tile_nranks", C.c_uint32),
@@ -186,7 +204,7 @@ DEVICE_SYMBOLS = [
 HOST_SYMBOLS = [
     "trc_host_build_node", "trc_host_build_tree", "trc_host_tree_depth", "trc_host_make_camera",
     "trc_host_prepare_camera", "trc_host_fill_rng", "trc_host_scene_create", "trc_host_scene_destroy",
-    "trc_host_scene_view", "trc_host_mesh_load_obj", "trc_host_mesh_load_pbrt", "trc_host_mesh_make_ball", "trc_host_mesh_replicate", "trc_host_mesh_from_arrays",
+    "trc_host_scene_view", "trc_host_scene_load_pbrt", "trc_host_mesh_load_obj", "trc_host_mesh_load_pbrt", "trc_host_mesh_make_ball", "trc_host_mesh_replicate", "trc_host_mesh_from_arrays",
     "trc_host_mesh_view", "trc_host_mesh_destroy", "trc_host_make_density_info", "trc_host_make_cloud",
     "trc_host_load_density_pbrt", "trc_host_free", "trc_host_write_png", "trc_host_sobol_matrices32",
     "trc_host_sobol_interval_tables",

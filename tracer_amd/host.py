@@ -42,6 +42,9 @@ def lib():
         L.trc_host_scene_create.argtypes = [C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                             C.POINTER(C.c_void_p)]
         L.trc_host_scene_create.restype = C.c_int32
+        L.trc_host_scene_load_pbrt.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(abi.Camera),
+                                               C.POINTER(abi.PbrtInfo), C.POINTER(abi.PbrtShape), C.c_uint32]
+        L.trc_host_scene_load_pbrt.restype = C.c_int32
         L.trc_host_scene_destroy.argtypes = [C.c_void_p]
         L.trc_host_scene_destroy.restype = None
         L.trc_host_scene_view.argtypes = [C.c_void_p, C.POINTER(abi.Scene)]
@@ -169,6 +172,19 @@ class HostScene:
         _check(st, "trc_host_scene_create")
         self.view = abi.Scene()
         lib().trc_host_scene_view(self._h, C.byref(self.view))
+
+    @classmethod
+    def from_pbrt(cls, path, max_shapes=4096):
+        """A whole scene from a pbrt-v3 file (trc_host_scene_load_pbrt) -> (scene, camera, info, [shape descriptions])."""
+        self = cls.__new__(cls)
+        self._h, self._mesh = C.c_void_p(), None
+        cam, info = abi.Camera(), abi.PbrtInfo()
+        shapes = (abi.PbrtShape * max_shapes)()
+        _check(lib().trc_host_scene_load_pbrt(os.fsencode(path), C.byref(self._h), C.byref(cam), C.byref(info), shapes,
+                                              max_shapes), f"trc_host_scene_load_pbrt({path})")
+        self.view = abi.Scene()
+        lib().trc_host_scene_view(self._h, C.byref(self.view))
+        return self, cam, info, [shapes[i] for i in range(min(info.n_shapes, max_shapes))]
 
     @property
     def n_leaves(self):

@@ -122,119 +122,6 @@ trc_status trc_host_mesh_load_obj(const char* path, trc_host_mesh** out) {
 // CoordinateSystem / CoordSysTransform, Attribute and Transform stacks, WorldBegin, Include), normals through the
 // inverse transpose, uv (`uv` or `st`), merged into one 32-byte-vertex mesh; shapes without normals get smooth
 // ones.  tests/test_pbrt_reader.py checks points, indices and matrices against the reference's minipbrt.
-namespace {
-
-struct M4 { float m[4][4]; };     // row-major, p' = M * p, like pbrt's Matrix4x4
-M4 m4_identity() { M4 r; std::memset(&r, 0, sizeof r); for (int i = 0; i < 4; ++i) r.m[i][i] = 1; return r; }
-M4 m4_mul(const M4& a, const M4& b) {
-    M4 r;
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j)
-            r.m[i][j] = a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j] + a.m[i][2] * b.m[2][j] + a.m[i][3] * b.m[3][j];
-    return r;
-}
-bool m4_inverse(const M4& a, M4& out) {                      // Gauss-Jordan with partial pivoting, in double
-    double w[4][8];
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) { w[i][j] = a.m[i][j]; w[i][4 + j] = i == j ? 1.0 : 0.0; }
-    for (int c = 0; c < 4; ++c) {
-        int p = c;
-        for (int r = c + 1; r < 4; ++r) if (std::fabs(w[r][c]) > std::fabs(w[p][c])) p = r;
-        if (w[p][c] == 0.0) return false;
-        for (int j = 0; j < 8; ++j) std::swap(w[c][j], w[p][j]);
-        const double inv = 1.0 / w[c][c];
-        for (int j = 0; j < 8; ++j) w[c][j] *= inv;
-        for (int r = 0; r < 4; ++r) {
-            if (r == c) continue;
-            const double f = w[r][c];
-            if (f != 0.0) for (int j = 0; j < 8; ++j) w[r][j] -= f * w[c][j];
-        }
-    }
-    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) out.m[i][j] = (float)w[i][4 + j];
-    return true;
-}
-
-struct PbrtToken { enum Kind { Word, String, Number, Open, Close, End } kind; std::string text; double value; };
-
-struct PbrtLexer {
-    const std::string& s;
-    size_t i = 0;
-    explicit PbrtLexer(const std::string& text) : s(text) {}
-    PbrtToken next() {
-        while (i < s.size() && std::isspace((unsigned char)s[i])) ++i;
-        PbrtToken t; t.value = 0;
-        if (i >= s.size()) { t.kind = PbrtToken::End; return t; }
-        const char c = s[i];
-        if (c == '[') { ++i; t.kind = PbrtToken::Open; return t; }
-        if (c == ']') { ++i; t.kind = PbrtToken::Close; return t; }
-        if (c == '"') {
-            const size_t e = s.find('"', i + 1);
-            t.kind = PbrtToken::String;
-            t.text = s.substr(i + 1, (e == std::string::npos ? s.size() : e) - i - 1);
-            i = e == std::string::npos ? s.size() : e + 1;
-            return t;
-        }
-        if (std::isdigit((unsigned char)c) || c == '-' || c == '+' || c == '.') {
-            char* end = nullptr;
-            t.value = std::strtod(s.c_str() + i, &end);
-            if (end != s.c_str() + i) { t.kind = PbrtToken::Number; i = (size_t)(end - s.c_str()); return t; }
-        }
-        size_t e = i;
-        while (e < s.size() && !std::isspace((unsigned char)s[e]) && s[e] != '[' && s[e] != ']' && s[e] != '"') ++e;
-        if (e == i) ++e;
-        t.kind = PbrtToken::Word; t.text = s.substr(i, e - i); i = e;
-        return t;
-    }
-    PbrtToken peek() { const size_t save = i; PbrtToken t = next(); i = save; return t; }
-};
-
-// numbers of a directive's fixed arguments (optionally bracketed, as in `Transform [ ... ]`)
-bool read_numbers(PbrtLexer& lx, size_t n, std::vector<float>& out) {
-    out.clear();
-    bool bracket = false;
-    if (lx.peek().kind == PbrtToken::Open) { lx.next(); bracket = true; }
-    for (size_t k = 0; k < n; ++k) {
-        PbrtToken t = lx.next();
-        if (t.kind != PbrtToken::Number) return false;
-        out.push_back((float)t.value);
-    }
-    if (bracket && lx.next().kind != PbrtToken::Close) return false;
-    return true;
-}
-
-struct PbrtParam { std::string type, name; std::vector<double> numbers; };
-
-// parameter list after a directive: ("type name" value | [ values ])*
-bool read_params(PbrtLexer& lx, std::vector<PbrtParam>& out) {
-    out.clear();
-    while (lx.peek().kind == PbrtToken::String) {
-        if (lx.peek().text.find_first_of(" \t") == std::string::npos) break;   // not a "type name" declaration
-        PbrtToken decl = lx.next();
-        PbrtParam p;
-        const size_t sp = decl.text.find_first_of(" \t");
-        p.type = decl.text.substr(0, sp);
-        size_t b = decl.text.find_first_not_of(" \t", sp);
-        p.name = b == std::string::npos ? std::string() : decl.text.substr(b);
-        PbrtToken v = lx.next();
-        if (v.kind == PbrtToken::Open) {
-            for (;;) {
-                PbrtToken e = lx.next();
-                if (e.kind == PbrtToken::Close) break;
-                if (e.kind == PbrtToken::End) return false;
-                if (e.kind == PbrtToken::Number) p.numbers.push_back(e.value);
-            }
-        } else if (v.kind == PbrtToken::Number) {
-            p.numbers.push_back(v.value);
-        } else if (v.kind != PbrtToken::String && v.kind != PbrtToken::Word) {
-            return false;
-        }
-        out.push_back(std::move(p));
-    }
-    return true;
-}
-
-}  // namespace
-
 extern "C" trc_status trc_host_mesh_load_pbrt(const char* path, trc_host_mesh** out) {
     if (!path || !out) return TRC_ERR_INVALID_ARG;
     *out = nullptr;
@@ -266,28 +153,11 @@ extern "C" trc_status trc_host_mesh_load_pbrt(const char* path, trc_host_mesh** 
             ctm = m4_mul(ctm, m);
         } else if (d == "Rotate") {                                 // pbrt-v3 Rotate(theta, axis)
             if (!read_numbers(lx, 4, a)) return fail();
-            const trc_float3 ax = normalize(f3(a[1], a[2], a[3]));
-            const float th = a[0] * 3.14159265358979323846f / 180.0f, sn = std::sin(th), cs = std::cos(th);
-            M4 m = m4_identity();
-            m.m[0][0] = ax.x * ax.x + (1 - ax.x * ax.x) * cs; m.m[0][1] = ax.x * ax.y * (1 - cs) - ax.z * sn; m.m[0][2] = ax.x * ax.z * (1 - cs) + ax.y * sn;
-            m.m[1][0] = ax.x * ax.y * (1 - cs) + ax.z * sn; m.m[1][1] = ax.y * ax.y + (1 - ax.y * ax.y) * cs; m.m[1][2] = ax.y * ax.z * (1 - cs) - ax.x * sn;
-            m.m[2][0] = ax.x * ax.z * (1 - cs) - ax.y * sn; m.m[2][1] = ax.y * ax.z * (1 - cs) + ax.x * sn; m.m[2][2] = ax.z * ax.z + (1 - ax.z * ax.z) * cs;
-            ctm = m4_mul(ctm, m);
+            ctm = m4_mul(ctm, m4_rotate(a[0], a[1], a[2], a[3]));
         } else if (d == "LookAt") {                                 // pbrt-v3 LookAt: the world-to-camera matrix
             if (!read_numbers(lx, 9, a)) return fail();
-            const trc_float3 pos = f3(a[0], a[1], a[2]), look = f3(a[3], a[4], a[5]), up = f3(a[6], a[7], a[8]);
-            const trc_float3 dir = normalize(look - pos);
-            trc_float3 right = cross(normalize(up), dir);
-            if (length(right) == 0) return fail();
-            right = normalize(right);
-            const trc_float3 new_up = cross(dir, right);
-            M4 c2w = m4_identity();
-            c2w.m[0][0] = right.x; c2w.m[1][0] = right.y; c2w.m[2][0] = right.z;
-            c2w.m[0][1] = new_up.x; c2w.m[1][1] = new_up.y; c2w.m[2][1] = new_up.z;
-            c2w.m[0][2] = dir.x; c2w.m[1][2] = dir.y; c2w.m[2][2] = dir.z;
-            c2w.m[0][3] = pos.x; c2w.m[1][3] = pos.y; c2w.m[2][3] = pos.z;
             M4 w2c;
-            if (!m4_inverse(c2w, w2c)) return fail();
+            if (!m4_look_at(a.data(), w2c)) return fail();
             ctm = m4_mul(ctm, w2c);
         } else if (d == "Transform" || d == "ConcatTransform") {    // 16 numbers, column-major
             if (!read_numbers(lx, 16, a)) return fail();
