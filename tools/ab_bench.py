@@ -12,6 +12,11 @@ sys.path.insert(0, ROOT)
 
 
 def child(path, config, steps):
+    if "@" in path:                        # lib.so@NAME=VALUE[@NAME=VALUE]: the same build under other environment knobs
+        path, *envs = path.split("@")
+        for e in envs:
+            k, v = e.split("=", 1)
+            os.environ[k] = v
     os.environ["TRC_AMD_LIB"] = os.path.abspath(path)
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import workloads as wlmod

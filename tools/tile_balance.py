@@ -11,14 +11,16 @@ t = Tracer(0); t.upload_scene(sc.view); t.set_camera(host.prepare_camera(W, H));
 t.seed(0x5EED0000); t.render(spp=64); t.synchronize()
 t.seed(0x5EED0000); t.reset_stats(); t.render(spp=64); t.synchronize(); full = t.stats().kernel_ms
 print(f"N=1: {full:.2f} ms")
-for N in (2, 4, 8):
-    ms = []
-    for r in range(N):
-        for rep in range(2):            # the second launch of a block list runs in adaptive (expensive-first) order
-            t.seed(0x5EED0000); t.reset_stats(); t.render(spp=64, tile_rank=r, tile_nranks=N); t.synchronize()
-        ms.append(t.stats().kernel_ms)
-    print(f"N={N}: per-rank kernel ms {' '.join(f'{m:.2f}' for m in ms)}; max {max(ms):.2f}, ideal {full / N:.2f}, "
-          f"render-only efficiency {full / N / max(ms):.3f}")
+for small in (False, True):
+    print("strong scaling of the named frame, " + ("4x4 pixel blocks on 16 lanes (TRC_FLAG_SMALL_BLOCKS)" if small else "8x8 pixel blocks"))
+    for N in (1, 2, 4, 8):
+        ms = []
+        for r in range(N):
+            for rep in range(2):            # the second launch of a block list runs in adaptive (expensive-first) order
+                t.seed(0x5EED0000); t.reset_stats(); t.render(spp=64, tile_rank=r, tile_nranks=N, small_blocks=small); t.synchronize()
+            ms.append(t.stats().kernel_ms)
+        print(f"N={N}: per-rank kernel ms {' '.join(f'{m:.2f}' for m in ms)}; max {max(ms):.2f}, ideal {full / N:.2f}, "
+              f"render-only efficiency {full / N / max(ms):.3f}")
 
 print("weak-scaling workload of bench.py: N views stacked, one view's worth of tiles per rank")
 for N in (2, 8):

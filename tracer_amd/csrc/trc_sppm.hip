@@ -10,8 +10,8 @@
 //   kernelPhotonHashing + PhotonMarkVS/FS point raster :386-456 -> k_sppm_hash: the raster pass becomes
 //       atomicMax(photon index) for the mark (Metal resolves same-pixel writes in primitive order: the LAST
 //       point = highest index wins) and atomicAdd for the additively blended count
-//   kernelPhotonSumming     :458-496  -> k_sppm_sum
-//   kernelPhotonRefine      :498-623  -> k_sppm_refine
+//   kernelPhotonSumming     :458-496  -> k_sppm_table   (the frame's photon sum + the per-cell gather table)
+//   kernelPhotonRefine      :498-623  -> k_sppm_refine  (one 48-byte table read per hash cell, four cells in flight)
 // All launches go to the context stream in order; nothing synchronises with the host.
 #include "trc_ctx.hpp"
 
@@ -43,6 +43,7 @@ struct KSppm {
     trc_PhotonRecord* pho_rec;
     uint32_t* mark;          // winning photon index + 1 per cell, 0 = empty
     uint32_t* count;
+    const float4* cells;     // gather table of k_sppm_table: 3 float4 per hash cell + one record for out-of-range reads
     DComplex* cx;
     unsigned long long* stats;   // ctx counters: rays += Scene::hit calls of the camera and photon passes
 };
@@ -314,95 +315,132 @@ __global__ void __launch_bounds__(256) k_sppm_hash(const trc_PhotonRecord* pho, 
     atomicAdd(&count[cell], 1u);
 }
 
-// kernelPhotonSumming, Photon.metal:458-496
-// (grid-stride: 128 workgroups, so the single counter sees 512 atomics per frame instead of 4096 -- they serialise)
-__global__ void __launch_bounds__(256) k_sppm_sum(const uint32_t* count, DComplex* cx) {
+// kernelPhotonSumming (Photon.metal:458-496) + the gather table of the refine pass.
+//
+// The reference's refine reads, per hash cell a pixel looks at, the mark texture (which photon won the cell), the count
+// texture (how many fell into it) and then three fields of that photon's 80-byte record: four dependent gathers from
+// three arrays.  Which photon a cell shows and with what weight is the same for every pixel of the frame, so it is
+// resolved ONCE per cell here (262 144 cells, a streaming pass over the two grids the sum reads anyway) into one
+// 48-byte record per cell:   q0 = photon position, Correction (= count; -1: empty cell)
+//                            q1 = photon direction          q2 = photon flux
+// Record 512*512 stands for the reference's out-of-range texture read (returns 0: photon (0,0), count 0,
+// Photon.metal:556-558).  (grid-stride: 128 workgroups, so the single counter sees 512 atomics per frame, not 4096)
+__global__ void __launch_bounds__(256) k_sppm_table(const uint32_t* mark, const uint32_t* count, const trc_PhotonRecord* pho,
+                                                    float4* cells, DComplex* cx) {
     uint32_t v = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < kHashN * kHashN; i += gridDim.x * blockDim.x) {
-        const uint32_t c = count[i];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= kHashN * kHashN; i += gridDim.x * blockDim.x) {
+        const bool oob = i == kHashN * kHashN;
+        const uint32_t c = oob ? 0u : count[i], mk = oob ? 1u : mark[i];
         v += c > 0 ? (c > 1u ? c : 1u) : 0u;
+        float4 q0 = make_float4(0, 0, 0, -1.0f), q1 = make_float4(0, 0, 0, 0), q2 = q1;
+        if (mk != 0u) {
+            const trc_PhotonRecord& ph = pho[mk - 1u];
+            q0 = make_float4(ph.position.x, ph.position.y, ph.position.z, (float)c);
+            q1 = make_float4(ph.direction.x, ph.direction.y, ph.direction.z, 0.0f);
+            q2 = make_float4(ph.flux.x, ph.flux.y, ph.flux.z, 0.0f);
+        }
+        cells[3u * i] = q0; cells[3u * i + 1u] = q1; cells[3u * i + 2u] = q2;
     }
     v = wave_sum(v);
     if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&cx->frame_photon_sum, v);
 }
 
-// kernelPhotonRefine, Photon.metal:498-623
+// kernelPhotonRefine, Photon.metal:498-623: progressive radius / flux update of every visible point from the photons
+// of the hash cells its query sphere touches, then the running mean of the frame.
+//
+// One lane per pixel, one wavefront per 8x8 block.  At 1080p neighbouring pixels are ~1.5 hash cells apart (cell edge
+// = 1.5 x the initial radius = 0.5 scene units, pixel footprint 0.77), so lanes share no cells and there is nothing to
+// stage for the wavefront; what the pass was waiting for (70 % of its wavefront cycles, rocprofv3 SQ_WAIT_ANY) is the
+// CHAIN of gathers per cell, one cell after the other.  Here a lane walks its cells -- in the reference's z, y, x
+// order, which fixes the floating-point summation order -- four at a time: four hashes, then four independent table
+// reads in flight together, then the four contributions added in order; direction and flux are fetched only for a
+// photon that passed the distance test.
+#ifndef TRC_REFINE_CHUNK
+#define TRC_REFINE_CHUNK 4
+#endif
+constexpr int kRefineChunk = TRC_REFINE_CHUNK;
 __global__ void __launch_bounds__(kBlock) k_sppm_refine(const KSppm kp) {
-    // one wavefront per 8x8 pixel block of this rank (same block list as the camera pass)
     const uint32_t tile = kp.tiles[blockIdx.x];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t qx = (tile & 0xFFFFu) * 8u + (lane & 7u);
     const uint32_t qy = (tile >> 16) * 8u + (lane >> 3);
     if (qx >= kp.W || qy >= kp.H) return;
-    const uint32_t i = qy * kp.W + qx;
-    trc_CameraRecord& c = kp.cam_rec[i];
-    float4* px = reinterpret_cast<float4*>(kp.accum) + i;
-    const float4 cached = *px;
-    const F3 cache = f3(cached.x, cached.y, cached.z);
+    const uint32_t pixel = qy * kp.W + qx;
+    trc_CameraRecord& vp = kp.cam_rec[pixel];                            // the pixel's visible point
+    float4* px = reinterpret_cast<float4*>(kp.accum) + pixel;
+    const float4 shown = *px;
+    const F3 mean = f3(shown.x, shown.y, shown.z);
     const float frame = (float)kp.frame_count, frame1 = (float)(kp.frame_count + 1);
-    if (!c.valid) {
-        F3 result = (cache * frame + ld3(c.alternative)) / frame1;
-        float4 o; o.x = result.x; o.y = result.y; o.z = result.z; o.w = 1.0f;
-        *px = o;
+    if (!vp.valid) {                                                     // nothing diffuse was seen: the stored radiance
+        const F3 result = (mean * frame + ld3(vp.alternative)) / frame1;
+        *px = make_float4(result.x, result.y, result.z, 1.0f);
         return;
     }
     const DComplex& cx = *kp.cx;
-    const F3 QueryPosition = ld3(c.position), QueryDirection = ld3(c.direction), QueryReflectance = ld3(c.ratio);
-    F3 QueryFlux = ld3(c.flux);
-    float QueryRadius = c.radius;
-    uint32_t QueryPhotonCount = c.photonCount;
-    const F3 BBoxMin = f3(cx.box_min[0], cx.box_min[1], cx.box_min[2]);
-    const float HashScale = cx.hash_scale;
-    const float fN = (float)kHashN;
-    F3 rmin = QueryPosition - f3(QueryRadius) - BBoxMin, rmax = QueryPosition + f3(QueryRadius) - BBoxMin;
-    const F3 RangeMin = f3(fabsf(rmin.x), fabsf(rmin.y), fabsf(rmin.z)) * HashScale;
-    const F3 RangeMax = f3(fabsf(rmax.x), fabsf(rmax.y), fabsf(rmax.z)) * HashScale;
-    F3 _Flux = f3(0);
-    uint32_t _PhotonCount = 0;
-    for (int iz = (int)RangeMin.z; iz <= (int)RangeMax.z; iz++)
-        for (int iy = (int)RangeMin.y; iy <= (int)RangeMax.y; iy++)
-            for (int ix = (int)RangeMin.x; ix <= (int)RangeMax.x; ix++) {
-                const F3 hashIndex = f3((float)ix, (float)iy, (float)iz);
-                const float hashed = ph_hash(hashIndex, HashScale, fN);
+    const F3 at = ld3(vp.position), facing = ld3(vp.direction), reflectance = ld3(vp.ratio);
+    F3 flux = ld3(vp.flux);
+    float radius = vp.radius;
+    uint32_t n_photons = vp.photonCount;
+    const F3 box_min = f3(cx.box_min[0], cx.box_min[1], cx.box_min[2]);
+    const float scale = cx.hash_scale, fN = (float)kHashN;
+    // cells touched by the query sphere's box, as the reference derives them (abs() included, :533-536)
+    const F3 lo = at - f3(radius) - box_min, hi = at + f3(radius) - box_min;
+    const F3 flo = f3(fabsf(lo.x), fabsf(lo.y), fabsf(lo.z)) * scale, fhi = f3(fabsf(hi.x), fabsf(hi.y), fabsf(hi.z)) * scale;
+    const int x0 = (int)flo.x, x1 = (int)fhi.x, y0 = (int)flo.y, y1 = (int)fhi.y, z0 = (int)flo.z, z1 = (int)fhi.z;
+    F3 gathered = f3(0);
+    uint32_t gathered_n = 0;
+    int ix = x0, iy = y0, iz = z0;
+    bool more = x0 <= x1 && y0 <= y1 && z0 <= z1;
+    while (more) {
+        F3 cell[kRefineChunk];
+        uint32_t rec[kRefineChunk];
+        bool use[kRefineChunk];
+#pragma unroll
+        for (int j = 0; j < kRefineChunk; ++j) {                         // the next (up to) four cells: hash -> table index
+            use[j] = more;
+            cell[j] = f3((float)ix, (float)iy, (float)iz);
+            rec[j] = kHashN * kHashN;                                    // out-of-range read
+            if (more) {
+                const float hashed = ph_hash(cell[j], scale, fN);
                 const float hx = ph_mod(hashed, fN) - 1.0f, hy = floorf(hashed / fN) - 1.0f;
-                uint32_t winner; float Correction;
-                if (hx >= 0.0f && hx < fN && hy >= 0.0f && hy < fN) {
-                    const uint32_t cell = (uint32_t)hy * kHashN + (uint32_t)hx;
-                    const uint32_t mk = kp.mark[cell];
-                    if (mk == 0u) continue;                           // PhotonIndex2D.x < 0: empty cell
-                    winner = mk - 1u;
-                    Correction = (float)kp.count[cell];
-                } else { winner = 0u; Correction = 0.0f; }           // out-of-range texture read returns 0
-                const trc_PhotonRecord& ph = kp.pho_rec[winner];
-                const F3 PhotonPosition = ld3(ph.position);
-                const F3 _RangeMin = hashIndex / HashScale + BBoxMin;
-                const F3 _RangeMax = (hashIndex + f3(1.0f)) / HashScale + BBoxMin;
-                if ((_RangeMin.x < PhotonPosition.x) && (PhotonPosition.x < _RangeMax.x) &&
-                    (_RangeMin.y < PhotonPosition.y) && (PhotonPosition.y < _RangeMax.y) &&
-                    (_RangeMin.z < PhotonPosition.z) && (PhotonPosition.z < _RangeMax.z)) {
-                    const float d = length(PhotonPosition - QueryPosition);
-                    if ((d < QueryRadius) && (-dot(QueryDirection, ld3(ph.direction)) > 0.001f)) {
-                        _Flux = _Flux + ld3(ph.flux) * Correction;
-                        _PhotonCount = (uint32_t)((float)_PhotonCount + Correction);
-                    }
-                }
+                if (hx >= 0.0f && hx < fN && hy >= 0.0f && hy < fN) rec[j] = (uint32_t)hy * kHashN + (uint32_t)hx;
+                if (++ix > x1) { ix = x0; if (++iy > y1) { iy = y0; if (++iz > z1) more = false; } }
             }
-    _Flux = _Flux * (QueryReflectance / 3.141592f);                    // BRDF (Lambertian)
-    const float alpha = 0.8f;                                          // progressive refinement
-    float g = fminf(((float)QueryPhotonCount + (float)_PhotonCount * alpha) / (float)(QueryPhotonCount + _PhotonCount), 1.0f);
-    QueryRadius = QueryRadius * sqrtf(g);
-    QueryPhotonCount = (uint32_t)((float)QueryPhotonCount + (float)_PhotonCount * alpha);
-    QueryFlux = (QueryFlux + _Flux) * g;
-    st3(c.flux, QueryFlux);
-    c.radius = QueryRadius;
-    c.photonCount = QueryPhotonCount;
-    float TotalPhotonNum = cx.total_photon_sum;
-    TotalPhotonNum += (float)cx.frame_photon_sum;
-    F3 color = QueryFlux / (QueryRadius * QueryRadius * 3.141592f * TotalPhotonNum);
-    F3 result = (cache * frame + color) / frame1;
+        }
+        float4 q0[kRefineChunk];
+#pragma unroll
+        for (int j = 0; j < kRefineChunk; ++j) q0[j] = use[j] ? kp.cells[3u * rec[j]] : make_float4(0, 0, 0, -1.0f);
+#pragma unroll
+        for (int j = 0; j < kRefineChunk; ++j) {
+            const float weight = q0[j].w;                                // Correction; -1 marks an empty cell (:560)
+            if (!use[j] || weight < 0.0f) continue;
+            const F3 p = f3(q0[j].x, q0[j].y, q0[j].z);
+            const F3 cmin = cell[j] / scale + box_min, cmax = (cell[j] + f3(1.0f)) / scale + box_min;
+            if (!((cmin.x < p.x) && (p.x < cmax.x) && (cmin.y < p.y) && (p.y < cmax.y) && (cmin.z < p.z) && (p.z < cmax.z))) continue;
+            const float d = length(p - at);
+            if (!(d < radius)) continue;
+            const float4 q1 = kp.cells[3u * rec[j] + 1u];
+            if (!(-dot(facing, f3(q1.x, q1.y, q1.z)) > 0.001f)) continue;
+            const float4 q2 = kp.cells[3u * rec[j] + 2u];
+            gathered = gathered + f3(q2.x, q2.y, q2.z) * weight;
+            gathered_n = (uint32_t)((float)gathered_n + weight);
+        }
+    }
+    gathered = gathered * (reflectance / 3.141592f);                     // Lambertian BRDF
+    const float alpha = 0.8f;                                            // progressive photon mapping (:596-603)
+    const float g = fminf(((float)n_photons + (float)gathered_n * alpha) / (float)(n_photons + gathered_n), 1.0f);
+    radius = radius * sqrtf(g);
+    n_photons = (uint32_t)((float)n_photons + (float)gathered_n * alpha);
+    flux = (flux + gathered) * g;
+    st3(vp.flux, flux);
+    vp.radius = radius;
+    vp.photonCount = n_photons;
+    float emitted = cx.total_photon_sum;
+    emitted += (float)cx.frame_photon_sum;
+    const F3 radiance = flux / (radius * radius * 3.141592f * emitted);
+    F3 result = (mean * frame + radiance) / frame1;
     if (is_nan(result.x) || is_nan(result.y) || is_nan(result.z)) result = f3(0);
-    float4 o; o.x = result.x; o.y = result.y; o.z = result.z; o.w = 1.0f;
-    *px = o;
+    *px = make_float4(result.x, result.y, result.z, 1.0f);
 }
 
 // completion handler, AAPLRenderer.mm:1031-1036
@@ -421,6 +459,7 @@ struct SppmState {
     trc_PhotonRecord* d_pho = nullptr;
     uint32_t* d_mark = nullptr;
     uint32_t* d_count = nullptr;
+    float4* d_cells = nullptr;       // gather table of k_sppm_table
     DComplex* d_cx = nullptr;
 };
 
@@ -429,7 +468,7 @@ void trc_sppm_release(trc_ctx* ctx) {
     SppmState* s = ctx->sppm;
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(s->d_photon_rng); (void)hipFree(s->d_cam); (void)hipFree(s->d_pho);
-    (void)hipFree(s->d_mark); (void)hipFree(s->d_count); (void)hipFree(s->d_cx);
+    (void)hipFree(s->d_mark); (void)hipFree(s->d_count); (void)hipFree(s->d_cells); (void)hipFree(s->d_cx);
     delete s;
     ctx->sppm = nullptr;
 }
@@ -460,6 +499,7 @@ trc_status trc_sppm_init(trc_ctx* ctx, uint64_t photon_seed) {
     HIP_TRY(ctx, hipMalloc((void**)&s->d_pho, nph * sizeof(trc_PhotonRecord)));
     HIP_TRY(ctx, hipMalloc((void**)&s->d_mark, nph * 4));
     HIP_TRY(ctx, hipMalloc((void**)&s->d_count, nph * 4));
+    HIP_TRY(ctx, hipMalloc((void**)&s->d_cells, (nph + 1) * 3 * sizeof(float4)));
     HIP_TRY(ctx, hipMalloc((void**)&s->d_cx, sizeof(DComplex)));
     HIP_TRY(ctx, hipMemsetAsync(s->d_cam, 0, np * sizeof(trc_CameraRecord), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(s->d_pho, 0, nph * sizeof(trc_PhotonRecord), ctx->stream));
@@ -505,7 +545,7 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
     kp.photon_first = rank * chunk;
     kp.tiles = ctx->d_tiles;
     kp.canvas_rng = ctx->d_rng; kp.accum = ctx->d_accum; kp.photon_rng = s->d_photon_rng;
-    kp.cam_rec = s->d_cam; kp.pho_rec = s->d_pho; kp.mark = s->d_mark; kp.count = s->d_count; kp.cx = s->d_cx;
+    kp.cam_rec = s->d_cam; kp.pho_rec = s->d_pho; kp.mark = s->d_mark; kp.count = s->d_count; kp.cells = s->d_cells; kp.cx = s->d_cx;
     kp.stats = ctx->d_stats;
     const size_t lds = trc_dyn_lds_bytes(ctx, false);
     const bool all_lds = ctx->lds_scene;
@@ -541,7 +581,7 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
         HIP_TRY(ctx, hipMemsetAsync(s->d_mark, 0, (size_t)nph * 4, ctx->stream));     // loadAction clear, :785-790
         HIP_TRY(ctx, hipMemsetAsync(s->d_count, 0, (size_t)nph * 4, ctx->stream));
         hipLaunchKernelGGL(k_sppm_hash, dim3(nph / 256), dim3(256), 0, ctx->stream, s->d_pho, s->d_mark, s->d_count, s->d_cx);
-        hipLaunchKernelGGL(k_sppm_sum, dim3(128), dim3(256), 0, ctx->stream, s->d_count, s->d_cx);
+        hipLaunchKernelGGL(k_sppm_table, dim3(128), dim3(256), 0, ctx->stream, s->d_mark, s->d_count, s->d_pho, s->d_cells, s->d_cx);
         hipLaunchKernelGGL(k_sppm_refine, dim3(ctx->n_tiles), dim3(kBlock), 0, ctx->stream, kp);
         hipLaunchKernelGGL(k_sppm_end_frame, dim3(1), dim3(64), 0, ctx->stream, s->d_cx);
         HIP_TRY(ctx, hipGetLastError());
