@@ -240,8 +240,9 @@ extern "C" trc_status trc_host_scene_load_pbrt(const char* path, trc_host_scene*
         } else if (d == "Film") {
             PbrtToken kind = lx.next();
             if (kind.kind != PbrtToken::String || !read_params_with_strings(lx, params, strs)) return fail();
-            inf.xres = (uint32_t)float_of(params, "xresolution", 640.0f);
-            inf.yres = (uint32_t)float_of(params, "yresolution", 480.0f);
+            auto res = [](float v) { return !(v >= 1.0f) ? 1u : (v > 524280.0f ? 524280u : (uint32_t)v); };   // what trc_resize accepts
+            inf.xres = res(float_of(params, "xresolution", 640.0f));
+            inf.yres = res(float_of(params, "yresolution", 480.0f));
         } else if (d == "WorldBegin") { ctm = m4_identity(); named["world"] = ctm; }
         else if (d == "AttributeBegin") { tstack.push_back(ctm); gstack.push_back(g); }
         else if (d == "AttributeEnd") {
