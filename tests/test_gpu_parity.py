@@ -358,3 +358,23 @@ def test_adaptive_launch_order_does_not_change_pixels(gpu, cornell_spheres):
     ref_rng = host.fill_rng(77, W, H)
     ref, st = po.render(cornell_spheres.view, cam, W, H, ref_rng, spp=6)
     assert np.array_equal(frames[-1][0].view(np.uint32), ref.view(np.uint32)) and st.rays == frames[-1][2]
+
+
+@pytest.mark.parametrize("W,H,spp,integrator", [(160, 90, 16, abi.INTEGRATOR_PATH), (97, 61, 3, abi.INTEGRATOR_MIS),
+                                               (131, 77, 9, abi.INTEGRATOR_VOLUME)])
+def test_small_pixel_blocks_render_the_same_frame(gpu, cornell_spheres, W, H, spp, integrator):
+    """TRC_FLAG_SMALL_BLOCKS (one 4x4 pixel block on 16 lanes per wavefront, the strong-scaling launch geometry) is a
+    scheduling choice: frame, RNG texture and ray count equal the 8x8-block launch, ragged frames and few-sample (strip)
+    launches included, also for a rank's share of the tiles"""
+    cam = host.prepare_camera(W, H)
+    gpu.upload_scene(cornell_spheres.view); gpu.set_camera(cam); gpu.set_environment((0.2, 0.3, 0.4)); gpu.resize(W, H)
+    out = []
+    for small in (False, True):
+        for rank, nranks in ((0, 1), (1, 3)):
+            gpu.seed(99); gpu.clear_accum(); gpu.reset_stats()
+            gpu.render(spp=spp, integrator=integrator, small_blocks=small, tile_rank=rank, tile_nranks=nranks)
+            out.append((gpu.download_accum(), gpu.download_rng(), gpu.stats().rays))
+    for a, b in ((out[0], out[2]), (out[1], out[3])):
+        assert a[2] == b[2] and np.array_equal(a[1], b[1]) and np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+    ref, rst = po.render(cornell_spheres.view, cam, W, H, host.fill_rng(99, W, H), spp=spp, integrator=integrator, env=(0.2, 0.3, 0.4))
+    assert rst.rays == out[2][2] and np.array_equal(out[2][0].view(np.uint32), ref.view(np.uint32))
