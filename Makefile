@@ -18,11 +18,12 @@ HOST_HDR  := tracer_amd/host/host_math.hpp tracer_amd/host/host_scene.hpp tracer
 HIP_SRC   := tracer_amd/csrc/trc_abi.hip tracer_amd/csrc/trc_sppm.hip tracer_amd/csrc/trc_lbvh.hip
 HIP_HDR   := $(wildcard tracer_amd/csrc/*.hpp) include/tracer_abi.h include/trc_detmath.h include/trc_sobol.h
 
-.PHONY: all host hip oracle example clean variant
-all: host hip oracle example
+.PHONY: all host hip hip_fast oracle example clean variant
+all: host hip hip_fast oracle example
 
 host: $(LIBDIR)/libtrc_host.so
 hip: $(LIBDIR)/libtracer_amd.so
+hip_fast: $(LIBDIR)/libtracer_amd_fast.so
 oracle:
 	$(MAKE) -C oracle
 
@@ -34,6 +35,15 @@ $(LIBDIR)/libtrc_host.so: $(HOST_SRC) $(HOST_HDR)
 $(LIBDIR)/libtracer_amd.so: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC) -ldl -lpthread -Wl,-rpath,$(ROCM)/lib
+
+# The same sources under fast-math rules (what the reference's shaders are compiled with: MTL_FAST_MATH): approximate
+# division / sqrt (v_rcp_f32, v_sqrt_f32), FMA contraction, denormals flushed.  NaN / Inf semantics and signed zeros are
+# kept (the integrators scrub NaN samples, Render.metal:537-538).  NOT comparable bit for bit with the oracle: parity of
+# this build is statistical (tests/test_gpu_fast_math.py); trc_build_flavor() tells a host which one it loaded.
+FASTFLAGS := -fno-hip-fp32-correctly-rounded-divide-sqrt -ffp-contract=fast -fgpu-flush-denormals-to-zero -DTRC_FAST_MATH=1
+$(LIBDIR)/libtracer_amd_fast.so: $(HIP_SRC) $(HIP_HDR)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) $(FASTFLAGS) -shared -o $@ $(HIP_SRC) -ldl -lpthread -Wl,-rpath,$(ROCM)/lib
 
 # A/B variants of the device library for tools/ab_bench.py:  make variant NAME=unchecked DEFS=-DTRC_SPEC_UNCHECKED
 variant:

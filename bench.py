@@ -94,6 +94,33 @@ def cpu_rt_weekend():
                       f"box 400x400x16spp: {r['rays']} rays in {r['seconds']:.2f} s, {r['mpaths_per_s']} Mpaths/s"}
 
 
+def fast_math_leg(scene, cam, steps):
+    """The same K steps on libtracer_amd_fast.so (the sources under fast-math rules, like the reference's MTL_FAST_MATH
+    shaders).  Reported beside the headline, never as it: only the exact build is comparable with the oracle."""
+    from tracer_amd import abi, device
+    if not os.path.exists(device.fast_lib_path()):
+        return None
+    t = device.Tracer(0, fast_math=True)
+    try:
+        t.upload_scene(scene.view); t.set_camera(cam); t.set_environment((0.0, 0.0, 0.0)); t.resize(W, H)
+        for _ in range(2):
+            t.seed(SEED); t.render(spp=SPP, max_depth=DEPTH, integrator=abi.INTEGRATOR_PATH)
+        t.synchronize(); t.reset_stats()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            t.seed(SEED); t.render(spp=SPP, max_depth=DEPTH, integrator=abi.INTEGRATOR_PATH)
+        t.synchronize()
+        dt = time.perf_counter() - t0
+        st = t.stats()
+        return {"library": "tracer_amd/lib/libtracer_amd_fast.so", "value": round(st.rays / dt / 1e6, 2), "unit": "Mrays/s",
+                "ms_per_step": round(dt / steps * 1e3, 3), "kernel_ms": round(st.kernel_ms / max(1, st.launches), 3),
+                "rays_per_step": int(st.rays // steps),
+                "what": "approximate division / sqrt, FMA contraction, denormals flushed; agrees with the exact build "
+                        "statistically (tests/test_gpu_fast_math.py), not bit for bit -- not the headline"}
+    finally:
+        t.close()
+
+
 def lib_source_hash():
     """Identity of the device library: sha256 over the sources it is built from (the .so itself is not
     byte-reproducible across builds).  tools/pmc_summary.py stores the same value next to the counters it collects."""
@@ -431,6 +458,8 @@ def main(argv=None):
             if other is not None:
                 line["other_scaling"] = {k: other[k] for k in ("mode", "metric", "value", "ms_per_step", "rays_per_step",
                                                               "frame", "vary_seed", "per_rank")}
+        if world == 1:
+            line["fast_math_variant"] = fast_math_leg(scene, cam, args.steps)
         if not args.no_cpu_baseline and world == 1:      # CPU baselines: rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(scene, cam)
             line["cpu_rt_weekend"] = cpu_rt_weekend()

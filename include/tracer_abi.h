@@ -326,6 +326,11 @@ typedef struct trc_ctx trc_ctx;  /* one per GPU, single-threaded, owns one HIP s
 /* ------------------------------------------------------------------ */
 
 uint32_t    trc_abi_version(void);
+/* "exact" = libtracer_amd.so: IEEE division / sqrt, no FMA contraction -- the build every parity statement is about;
+ * "fast-math" = libtracer_amd_fast.so: the same sources under fast-math rules, as the reference compiles its shaders
+ * (MTL_FAST_MATH): approximate division / sqrt, FMA contraction, denormals flushed; results agree with the exact build
+ * statistically, not bit for bit */
+const char* trc_build_flavor(void);
 const char* trc_status_string(trc_status s);
 /* last error text of this context (HIP error string etc.), never NULL */
 const char* trc_last_error(const trc_ctx* ctx);

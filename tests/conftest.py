@@ -22,6 +22,7 @@ def pytest_configure(config):
 def _ensure_built():
     need = [os.path.join(ROOT, "tracer_amd", "lib", "libtrc_host.so"),
             os.path.join(ROOT, "tracer_amd", "lib", "libtracer_amd.so"),
+            os.path.join(ROOT, "tracer_amd", "lib", "libtracer_amd_fast.so"),
             os.path.join(ROOT, "oracle", "liboracle.so"),
             os.path.join(ROOT, "oracle", "liboracle_libm.so")]
     if not all(os.path.exists(p) for p in need):

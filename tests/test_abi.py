@@ -38,7 +38,11 @@ def test_device_library_exports_every_declared_symbol():
     assert not missing, missing
     # the library LOADS without a GPU; only trc_create reports the missing device (no silent fallback)
     L = device.lib()
-    assert L.trc_abi_version() == abi.TRC_ABI_VERSION
+    assert L.trc_abi_version() == abi.TRC_ABI_VERSION and L.trc_build_flavor() == b"exact"
+    # the fast-math build of the same sources exports the same ABI and says what it is
+    fast = _exported(device.fast_lib_path())
+    assert not [s for s in declared if s not in fast]
+    assert device.lib(fast_math=True).trc_build_flavor() == b"fast-math"
 
 
 def test_host_library_exports_every_declared_symbol():

@@ -651,6 +651,14 @@ extern "C" {
 
 uint32_t trc_abi_version(void) { return TRC_ABI_VERSION; }
 
+const char* trc_build_flavor(void) {
+#ifdef TRC_FAST_MATH
+    return "fast-math";
+#else
+    return "exact";
+#endif
+}
+
 const char* trc_status_string(trc_status s) {
     switch (s) {
         case TRC_OK: return "ok";

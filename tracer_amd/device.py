@@ -12,6 +12,7 @@ import numpy as np
 from . import abi
 
 _LIB = None
+_LIB_FAST = None
 
 
 class TracerError(RuntimeError):
@@ -25,63 +26,77 @@ def lib_path():
     return os.environ.get("TRC_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtracer_amd.so")
 
 
-def lib():
-    """Load libtracer_amd.so (fails loudly when the HIP extension has not been built)."""
-    global _LIB
+def fast_lib_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtracer_amd_fast.so")
+
+
+def lib(fast_math=False):
+    """Load libtracer_amd.so (fails loudly when the HIP extension has not been built); fast_math=True loads the
+    fast-math build of the same sources (libtracer_amd_fast.so) instead."""
+    global _LIB, _LIB_FAST
+    if fast_math:
+        if _LIB_FAST is None:
+            _LIB_FAST = _load(fast_lib_path())
+            assert _LIB_FAST.trc_build_flavor() == b"fast-math"
+        return _LIB_FAST
     if _LIB is None:
-        path = lib_path()
-        if not os.path.exists(path):
-            raise RuntimeError(f"{path} is missing: the HIP extension is not built "
-                               f"(run `make hip` or __graft_entry__.build()); there is no CPU fallback")
-        L = C.CDLL(path)
-        vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
-        L.trc_abi_version.restype = u32
-        L.trc_status_string.argtypes = [i32]
-        L.trc_status_string.restype = C.c_char_p
-        L.trc_last_error.argtypes = [vp]
-        L.trc_last_error.restype = C.c_char_p
-        L.trc_create.argtypes = [C.c_int, C.POINTER(vp)]
-        L.trc_destroy.argtypes = [vp]
-        L.trc_destroy.restype = None
-        L.trc_upload_scene.argtypes = [vp, C.POINTER(abi.Scene)]
-        L.trc_set_environment_map.argtypes = [vp, u32, u32, vp]
-        L.trc_tonemap.argtypes = [vp, vp, C.POINTER(C.c_float)]
-        L.trc_upload_density.argtypes = [vp, C.POINTER(abi.GridDensityInfo), vp]
-        L.trc_upload_scene_lbvh.argtypes = [vp, C.POINTER(abi.Scene)]
-        L.trc_download_bvh.argtypes = [vp, C.POINTER(abi.BVH), u32, C.POINTER(u32)]
-        L.trc_lbvh_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_float)]
-        L.trc_set_camera.argtypes = [vp, C.POINTER(abi.Camera)]
-        L.trc_set_environment.argtypes = [vp, C.POINTER(C.c_float)]
-        L.trc_resize.argtypes = [vp, u32, u32]
-        L.trc_seed.argtypes = [vp, u64]
-        for name in ("trc_upload_rng", "trc_download_rng", "trc_upload_accum", "trc_download_accum"):
-            getattr(L, name).argtypes = [vp, vp]
-        L.trc_clear_accum.argtypes = [vp]
-        L.trc_render.argtypes = [vp, C.POINTER(abi.Params)]
-        L.trc_synchronize.argtypes = [vp]
-        L.trc_trace_rays.argtypes = [vp, vp, C.c_size_t, vp, C.c_int]
-        L.trc_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
-        L.trc_reset_stats.argtypes = [vp]
-        L.trc_debug_profile.argtypes = [vp, C.POINTER(C.c_uint64), u32]
-        L.trc_sppm_init.argtypes = [vp, u64]
-        L.trc_sppm_frames.argtypes = [vp, u32]
-        L.trc_sppm_download.argtypes = [vp, vp, vp, vp, vp, C.POINTER(abi.Complex)]
-        L.trc_device_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
-        L.trc_group_unique_id.argtypes = [C.POINTER(C.c_uint8)]
-        L.trc_group_init.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int, C.c_int]
-        L.trc_group_reduce_accum.argtypes = [vp, C.c_int]
-        L.trc_group_reduce_accum_async.argtypes = [vp, C.c_int]
-        L.trc_group_allreduce_mean_accum.argtypes = [vp]
-        L.trc_download_composed.argtypes = [vp, vp]
-        L.trc_group_finalize.argtypes = [vp]
-        for name in abi.DEVICE_SYMBOLS:
-            f = getattr(L, name)
-            if name not in ("trc_abi_version", "trc_status_string", "trc_last_error", "trc_destroy"):
-                f.restype = i32
-        if L.trc_abi_version() != abi.TRC_ABI_VERSION:
-            raise RuntimeError("libtracer_amd.so ABI version mismatch")
-        _LIB = L
+        _LIB = _load(lib_path())
     return _LIB
+
+
+def _load(path):
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: the HIP extension is not built "
+                           f"(run `make hip` or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(path)
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
+    L.trc_abi_version.restype = u32
+    L.trc_build_flavor.restype = C.c_char_p
+    L.trc_status_string.argtypes = [i32]
+    L.trc_status_string.restype = C.c_char_p
+    L.trc_last_error.argtypes = [vp]
+    L.trc_last_error.restype = C.c_char_p
+    L.trc_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.trc_destroy.argtypes = [vp]
+    L.trc_destroy.restype = None
+    L.trc_upload_scene.argtypes = [vp, C.POINTER(abi.Scene)]
+    L.trc_set_environment_map.argtypes = [vp, u32, u32, vp]
+    L.trc_tonemap.argtypes = [vp, vp, C.POINTER(C.c_float)]
+    L.trc_upload_density.argtypes = [vp, C.POINTER(abi.GridDensityInfo), vp]
+    L.trc_upload_scene_lbvh.argtypes = [vp, C.POINTER(abi.Scene)]
+    L.trc_download_bvh.argtypes = [vp, C.POINTER(abi.BVH), u32, C.POINTER(u32)]
+    L.trc_lbvh_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_float)]
+    L.trc_set_camera.argtypes = [vp, C.POINTER(abi.Camera)]
+    L.trc_set_environment.argtypes = [vp, C.POINTER(C.c_float)]
+    L.trc_resize.argtypes = [vp, u32, u32]
+    L.trc_seed.argtypes = [vp, u64]
+    for name in ("trc_upload_rng", "trc_download_rng", "trc_upload_accum", "trc_download_accum"):
+        getattr(L, name).argtypes = [vp, vp]
+    L.trc_clear_accum.argtypes = [vp]
+    L.trc_render.argtypes = [vp, C.POINTER(abi.Params)]
+    L.trc_synchronize.argtypes = [vp]
+    L.trc_trace_rays.argtypes = [vp, vp, C.c_size_t, vp, C.c_int]
+    L.trc_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
+    L.trc_reset_stats.argtypes = [vp]
+    L.trc_debug_profile.argtypes = [vp, C.POINTER(C.c_uint64), u32]
+    L.trc_sppm_init.argtypes = [vp, u64]
+    L.trc_sppm_frames.argtypes = [vp, u32]
+    L.trc_sppm_download.argtypes = [vp, vp, vp, vp, vp, C.POINTER(abi.Complex)]
+    L.trc_device_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
+    L.trc_group_unique_id.argtypes = [C.POINTER(C.c_uint8)]
+    L.trc_group_init.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int, C.c_int]
+    L.trc_group_reduce_accum.argtypes = [vp, C.c_int]
+    L.trc_group_reduce_accum_async.argtypes = [vp, C.c_int]
+    L.trc_group_allreduce_mean_accum.argtypes = [vp]
+    L.trc_download_composed.argtypes = [vp, vp]
+    L.trc_group_finalize.argtypes = [vp]
+    for name in abi.DEVICE_SYMBOLS:
+        f = getattr(L, name)
+        if name not in ("trc_abi_version", "trc_build_flavor", "trc_status_string", "trc_last_error", "trc_destroy"):
+            f.restype = i32
+    if L.trc_abi_version() != abi.TRC_ABI_VERSION:
+        raise RuntimeError("libtracer_amd.so ABI version mismatch")
+    return L
 
 
 def group_unique_id():
@@ -95,8 +110,8 @@ def group_unique_id():
 class Tracer:
     """One context per GPU (single-threaded, one HIP stream)."""
 
-    def __init__(self, device=0):
-        self._L = lib()
+    def __init__(self, device=0, fast_math=False):
+        self._L = lib(fast_math)
         self._h = C.c_void_p()
         st = self._L.trc_create(device, C.byref(self._h))
         if st != abi.OK:
