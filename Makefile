@@ -37,7 +37,8 @@ $(LIBDIR)/libtracer_amd.so: $(HIP_SRC) $(HIP_HDR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC) -ldl -lpthread -Wl,-rpath,$(ROCM)/lib
 
 # The same sources under fast-math rules (what the reference's shaders are compiled with: MTL_FAST_MATH): approximate
-# division / sqrt (v_rcp_f32, v_sqrt_f32), FMA contraction, denormals flushed.  NaN / Inf semantics and signed zeros are
+# division / sqrt (v_rcp_f32, v_sqrt_f32), FMA contraction, denormals flushed, hardware exp / log / sin / cos
+# (include/trc_detmath.h under TRC_FAST_MATH).  NaN / Inf semantics and signed zeros are
 # kept (the integrators scrub NaN samples, Render.metal:537-538).  NOT comparable bit for bit with the oracle: parity of
 # this build is statistical (tests/test_gpu_fast_math.py); trc_build_flavor() tells a host which one it loaded.
 FASTFLAGS := -fno-hip-fp32-correctly-rounded-divide-sqrt -ffp-contract=fast -fgpu-flush-denormals-to-zero -DTRC_FAST_MATH=1

@@ -39,7 +39,18 @@
 #define DM_NAN_F     __builtin_nanf("")
 
 /* sin and cos of x, |x| < 8192; shared Cody-Waite reduction to [-pi/4, pi/4] */
+/* libtracer_amd_fast.so (TRC_FAST_MATH, device code only): the hardware's own transcendentals (v_exp_f32, v_log_f32,
+ * v_sin_f32, v_cos_f32) instead of the reproducible polynomials -- that build is not compared bit for bit anyway */
+#if defined(TRC_FAST_MATH) && defined(__HIP_DEVICE_COMPILE__) && !defined(TRC_FAST_KEEP_DETMATH)
+#define DM_FAST_DEVICE 1
+#else
+#define DM_FAST_DEVICE 0
+#endif
+
 TRC_HD void dm_sincosf(float xx, float* s_out, float* c_out) {
+#if DM_FAST_DEVICE
+    *s_out = __sinf(xx); *c_out = __cosf(xx); return;
+#endif
     const float FOPI = 1.27323954473516f;          /* 4/pi */
     const float DP1 = 0.78515625f;
     const float DP2 = 2.4187564849853515625e-4f;
@@ -74,6 +85,9 @@ TRC_HD float dm_sinf(float x) { float s, c; dm_sincosf(x, &s, &c); return s; }
 TRC_HD float dm_cosf(float x) { float s, c; dm_sincosf(x, &s, &c); return c; }
 
 TRC_HD float dm_expf(float xx) {
+#if DM_FAST_DEVICE
+    return __expf(xx);
+#endif
     const float MAXLOGF = 88.72283905206835f;
     const float MINLOGF = -103.278929903431851103f;   /* log(2^-149) */
     const float LOG2EF = 1.44269504088896341f;
@@ -98,6 +112,9 @@ TRC_HD float dm_expf(float xx) {
 }
 
 TRC_HD float dm_logf(float xx) {
+#if DM_FAST_DEVICE
+    return __logf(xx);
+#endif
     const float SQRTHF = 0.707106781186547524f;
     float x = xx;
     if (x != x) return x;
@@ -121,6 +138,9 @@ TRC_HD float dm_logf(float xx) {
 
 /* x^y for x >= 0 (the path only raises [0,1] bases to positive powers) */
 TRC_HD float dm_powf(float x, float y) {
+#if DM_FAST_DEVICE
+    return __powf(x, y);
+#endif
     if (y == 0.0f) return 1.0f;
     if (x == 0.0f) return (y > 0.0f) ? 0.0f : DM_INF_F;
     return dm_expf(y * dm_logf(x));

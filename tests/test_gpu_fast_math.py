@@ -34,7 +34,9 @@ def test_first_hits_are_the_exact_builds(gpu, fast, request, scene_name):
     assert same.mean() > 0.9999, f"{(~same).sum()} of {len(rays)} primary rays hit something else"
     h = same & (a["hit"] != 0)
     rel = np.abs(a["t"][h] - b["t"][h]) / a["t"][h]
-    assert rel.max() < 1e-3 and np.median(rel) < 1e-6 and np.abs(a["p"][h] - b["p"][h]).max() < 0.05     # stated tolerance on t
+    # stated tolerance: t within 1e-3 relative (median < 1e-6), the hit point within 3e-4 of the distance travelled
+    assert rel.max() < 1e-3 and np.median(rel) < 1e-6
+    assert (np.abs(a["p"][h] - b["p"][h]).max(axis=1) <= 3e-4 * np.maximum(a["t"][h], 100.0)).all()
 
 
 def test_frames_agree_like_two_exact_renders(gpu, fast, cornell_spheres):
