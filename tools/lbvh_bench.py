@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""LBVH vs host SAH on the 1.04 M-triangle scene: build times and render throughput through either tree."""
+"""LBVH vs host SAH on config 4's scene (teapot.obj x 64 = 1.0 M triangles): build / upload times and render throughput
+through either tree."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tracer_amd import abi, host
 from tracer_amd.device import Tracer
 W, H = 1920, 1080
-mesh = host.Mesh.ball(60, 60, 0.08).replicate(12, 2.4)
+mesh = host.Mesh.golden("teapot").replicate(8, 80.0)
 t0 = time.time(); sc = host.HostScene(abi.SCENE_CORNELL_MESH, mesh); host_s = time.time() - t0
 t = Tracer(0); t.set_camera(host.prepare_camera(W, H)); t.resize(W, H)
 def run(label):

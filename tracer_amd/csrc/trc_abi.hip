@@ -297,6 +297,41 @@ __global__ void __launch_bounds__(kBlock, INTEGRATOR == TRC_INTEGRATOR_VOLUME ? 
     }
 }
 
+// blob triangle records from the caller's arrays (trc_scene_prep.hpp): one thread per triangle, 3 gathered 32-byte
+// vertices in, 7 float4 out
+__global__ void __launch_bounds__(256) k_repack_triangles(const trc_TriangleVertex* __restrict__ verts, const uint32_t* __restrict__ idx,
+                                                          uint32_t n_tri, float4* __restrict__ tripos, float4* __restrict__ triattr) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_tri) return;
+    const trc_TriangleVertex a = verts[idx[3 * t]], b = verts[idx[3 * t + 1]], c = verts[idx[3 * t + 2]];
+    tripos[3 * (size_t)t] = make_float4(a.v[0], a.v[1], a.v[2], 0.0f);
+    tripos[3 * (size_t)t + 1] = make_float4(b.v[0], b.v[1], b.v[2], 0.0f);
+    tripos[3 * (size_t)t + 2] = make_float4(c.v[0], c.v[1], c.v[2], 0.0f);
+    triattr[4 * (size_t)t] = make_float4(a.n[0], a.n[1], a.n[2], b.n[0]);
+    triattr[4 * (size_t)t + 1] = make_float4(b.n[1], b.n[2], c.n[0], c.n[1]);
+    triattr[4 * (size_t)t + 2] = make_float4(c.n[2], a.uv[0], a.uv[1], b.uv[0]);
+    triattr[4 * (size_t)t + 3] = make_float4(b.uv[1], c.uv[0], c.uv[1], 0.0f);
+}
+
+trc_status trc_repack_triangles(trc_ctx* ctx, const trc_scene* s, const DScene& sc, uint32_t* d_blob) {
+    const uint32_t n_tri = s->n_index / 3;
+    if (n_tri == 0) return TRC_OK;
+    trc_TriangleVertex* d_verts = nullptr;
+    uint32_t* d_idx = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d_verts, (size_t)s->n_vertex * sizeof(trc_TriangleVertex)));
+    if (hipMalloc((void**)&d_idx, (size_t)s->n_index * 4) != hipSuccess) { (void)hipFree(d_verts); return trc_fail(ctx, TRC_ERR_OOM, "hipMalloc triangle indices"); }
+    trc_status st = TRC_OK;
+    do {
+        if (hipMemcpyAsync(d_verts, s->triList, (size_t)s->n_vertex * sizeof(trc_TriangleVertex), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(d_idx, s->idxList, (size_t)s->n_index * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { st = trc_fail(ctx, TRC_ERR_HIP, "H2D triangles"); break; }
+        hipLaunchKernelGGL(k_repack_triangles, dim3((n_tri + 255) / 256), dim3(256), 0, ctx->stream, d_verts, d_idx, n_tri,
+                           reinterpret_cast<float4*>(d_blob + sc.off_tripos), reinterpret_cast<float4*>(d_blob + sc.off_triattr));
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { st = trc_fail(ctx, TRC_ERR_HIP, "k_repack_triangles"); break; }
+    } while (0);
+    (void)hipFree(d_verts); (void)hipFree(d_idx);
+    return st;
+}
+
 // sort keys of the adaptive launch order: descending cost (shader clocks / 64, clamped to 24 bits), ties in list order
 __global__ void __launch_bounds__(256) k_order_keys(const uint32_t* cost, uint32_t n, uint32_t* keys, uint32_t* vals) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -435,7 +470,7 @@ void collect_events(trc_ctx* ctx) {
 
 
 // Repack the reference arrays into the device layout (dev_scene.hpp) and validate the tree.
-trc_status build_blob(trc_ctx* ctx, const trc_scene* s, std::vector<uint32_t>& blob, KScene& ks) {
+trc_status build_blob(trc_ctx* ctx, const trc_scene* s, std::vector<uint32_t>& blob, uint64_t& blob_total, KScene& ks) {
     if (!s || !s->bvhList || s->n_bvh < 3 || (s->n_bvh & 1u) == 0) return fail(ctx, TRC_ERR_INVALID_ARG, "scene: need >= 2 leaves (n_bvh odd, >= 3)");
     { trc_status st = validate_primitives(ctx, s); if (st != TRC_OK) return st; }
     const trc_BVH* nodes = s->bvhList;
@@ -475,7 +510,8 @@ trc_status build_blob(trc_ctx* ctx, const trc_scene* s, std::vector<uint32_t>& b
     uint64_t total = 0;
     { trc_status st = layout_scene(ctx, s, n_interior, sc, total); if (st != TRC_OK) return st; }
     plan_lds(sc, max_leaf_depth, true);
-    blob.assign((size_t)total, 0u);
+    blob.assign((size_t)sc.off_tripos, 0u);      // analytic primitives, materials, fat nodes; triangle records are made on the device
+    blob_total = total;
 
     auto tag_of = [&](uint32_t c) -> uint32_t {
         if (nodes[c].pType == TRC_PRIM_BVH) return (kTagInterior << kTagIndexBits) | interior_id[c];
@@ -723,17 +759,19 @@ trc_status trc_upload_scene(trc_ctx* ctx, const trc_scene* scene) {
     if (!ctx) return TRC_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     std::vector<uint32_t> blob;
+    uint64_t blob_total = 0;
     KScene ks{};
-    trc_status st = build_blob(ctx, scene, blob, ks);
+    trc_status st = build_blob(ctx, scene, blob, blob_total, ks);
     if (st != TRC_OK) return st;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_blob) { (void)hipFree(ctx->d_blob); ctx->d_blob = nullptr; }
     if (ctx->d_bvh_ref) { (void)hipFree(ctx->d_bvh_ref); ctx->d_bvh_ref = nullptr; }
     ctx->n_bvh_ref = 0;
     ctx->has_scene = false;
-    ctx->blob_bytes = blob.size() * 4;
+    ctx->blob_bytes = (size_t)blob_total * 4;
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_blob, ctx->blob_bytes));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_blob, blob.data(), ctx->blob_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_blob, blob.data(), blob.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    { trc_status rs = trc_repack_triangles(ctx, scene, ks.sc, ctx->d_blob); if (rs != TRC_OK) return rs; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ks.sc.blob = ctx->d_blob;
     ctx->ks = ks;

@@ -490,9 +490,9 @@ trc_status trc_upload_scene_lbvh(trc_ctx* ctx, const trc_scene* s) {
     DScene sc{};
     uint64_t total = 0;
     { trc_status st = layout_scene(ctx, s, n_interior, sc, total); if (st != TRC_OK) return st; }
-    // host side of the blob: analytic primitives + materials (prefix) and the triangle records; the fat nodes in
-    // between are written by k_lbvh_emit, so that region is neither initialised nor uploaded
-    std::unique_ptr<uint32_t[]> blob(new (std::nothrow) uint32_t[(size_t)total]);
+    // host side of the blob: analytic primitives + materials (the prefix).  The fat nodes are written by k_lbvh_emit, the
+    // triangle records by k_repack_triangles from the caller's vertex / index arrays: neither is staged on the host
+    std::unique_ptr<uint32_t[]> blob(new (std::nothrow) uint32_t[(size_t)sc.off_nodes]);
     if (!blob) return trc_fail(ctx, TRC_ERR_OOM, "lbvh: host staging buffer");
     std::memset(blob.get(), 0, (size_t)sc.off_nodes * 4);
     fill_primitives(s, sc, blob.get());
@@ -506,8 +506,7 @@ trc_status trc_upload_scene_lbvh(trc_ctx* ctx, const trc_scene* s) {
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_bvh_ref, sizeof(trc_BVH) * n_nodes));
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_blob, blob.get(), (size_t)sc.off_nodes * 4, hipMemcpyHostToDevice, st));
-    if (total > sc.off_tripos)
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_blob + sc.off_tripos, blob.get() + sc.off_tripos, ((size_t)total - sc.off_tripos) * 4, hipMemcpyHostToDevice, st));
+    { trc_status rs = trc_repack_triangles(ctx, s, sc, ctx->d_blob); if (rs != TRC_OK) return rs; }
     // the caller's leaf records go straight to slots 1..n of the reference-layout array (BVH.hh:246-269)
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_bvh_ref, 0, sizeof(trc_BVH), st));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bvh_ref + 1, s->bvhList, sizeof(trc_BVH) * n, hipMemcpyHostToDevice, st));

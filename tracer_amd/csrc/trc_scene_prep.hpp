@@ -99,10 +99,9 @@ inline void plan_lds(DScene& sc, uint32_t max_leaf_depth, bool prefix_ok) {
     sc.stack_depth = std::max(1u, max_leaf_depth);
 }
 
-// analytic primitives, materials and triangles into the blob (everything but the fat nodes)
-// (`blob` need only be zeroed up to sc.off_nodes: every dword of a triangle record is written here)
+// analytic primitives and materials into the blob (the fat nodes are written by the caller, the triangle records on the
+// device: trc_repack_triangles)
 inline void fill_primitives(const trc_scene* s, const DScene& sc, uint32_t* blob) {
-    const uint32_t n_tri = s->n_index / 3;
     for (uint32_t i = 0; i < s->n_sphere; ++i) {
         const trc_Sphere& sp = s->sphereList[i];
         uint32_t* q = &blob[sc.off_spheres + (size_t)i * kSphereDwords];
@@ -142,19 +141,11 @@ inline void fill_primitives(const trc_scene* s, const DScene& sc, uint32_t* blob
         q[5] = m.specular ? 1u : 0u;
         q[6] = (uint32_t)m.medium;
     }
-    prep_parallel_for(n_tri, [&](size_t tb, size_t te) {
-        for (size_t t = tb; t < te; ++t) {
-            const trc_TriangleVertex* v[3] = {&s->triList[s->idxList[3 * t]], &s->triList[s->idxList[3 * t + 1]],
-                                              &s->triList[s->idxList[3 * t + 2]]};
-            uint32_t* p = &blob[sc.off_tripos + t * kTriPosDwords];
-            uint32_t* a = &blob[sc.off_triattr + t * kTriAttrDwords];
-            for (int k = 0; k < 3; ++k) {
-                p[4 * k] = f2u(v[k]->v[0]); p[4 * k + 1] = f2u(v[k]->v[1]); p[4 * k + 2] = f2u(v[k]->v[2]); p[4 * k + 3] = 0;
-                a[3 * k] = f2u(v[k]->n[0]); a[3 * k + 1] = f2u(v[k]->n[1]); a[3 * k + 2] = f2u(v[k]->n[2]);
-                a[9 + 2 * k] = f2u(v[k]->uv[0]); a[10 + 2 * k] = f2u(v[k]->uv[1]);
-            }
-            a[15] = 0;
-        }
-    });
 }
 
+
+// Triangle records of the blob (dev_scene.hpp: positions 48 B, attributes 64 B per triangle) built ON THE DEVICE from the
+// caller's vertex and index arrays: 32 B per vertex + 12 B per triangle cross PCIe instead of 112 B per triangle of
+// host-staged records, and the gather runs at HBM speed (1 M triangles: 29 MB up + 0.1 ms, against 112 MB staged by the
+// host).  Queued on the context stream; the temporary copies are freed after the stream has drained.
+trc_status trc_repack_triangles(trc_ctx* ctx, const trc_scene* s, const DScene& sc, uint32_t* d_blob);
