@@ -245,6 +245,8 @@ def main(argv=None):
                     help="which N > 1 workload fills the top-level fields (the other one goes to other_scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-scaling", action="store_true", help="N > 1: measure only the primary workload")
+    ap.add_argument("--no-fast-math", action="store_true",
+                    help="skip the fast_math_variant leg (profiling runs: both builds name their kernels alike)")
     ap.add_argument("--force-group", action="store_true",
                     help="exercise the gloo rendezvous + RCCL compose path even with one rank (plumbing check)")
     ap.add_argument("--rendezvous-only", action="store_true",
@@ -458,7 +460,7 @@ def main(argv=None):
             if other is not None:
                 line["other_scaling"] = {k: other[k] for k in ("mode", "metric", "value", "ms_per_step", "rays_per_step",
                                                               "frame", "vary_seed", "per_rank")}
-        if world == 1:
+        if world == 1 and not args.no_fast_math:
             line["fast_math_variant"] = fast_math_leg(scene, cam, args.steps)
         if not args.no_cpu_baseline and world == 1:      # CPU baselines: rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(scene, cam)
