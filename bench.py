@@ -217,22 +217,46 @@ def visible_gpus():
     return n
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, timeout_s=1800.0):
     """`python bench.py --gpus N` without a launcher: N fresh children of this script, one per rank, started before
-    this process has touched the GPU (never an exec from a process that has).  Rank 0's stdout is relayed."""
+    this process has touched the GPU (never an exec from a process that has).  Rank 0's stdout is relayed.  A rank that
+    dies takes the others with it (they would wait in a barrier for ever): the children are OUR processes, ended by
+    PID, and the launcher returns the failure instead of hanging."""
+    import tempfile
+    import threading
     port = _free_port()
     env0 = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out0 = tempfile.TemporaryFile(mode="w+")
     procs = []
     for r in range(n):
         env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, cwd=ROOT,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0)
+                                      stdout=out0 if r == 0 else sys.stderr))
+    deadline = time.monotonic() + timeout_s
+    failed = None
+    while any(p.poll() is None for p in procs):
+        bad = [p for p in procs if p.poll() not in (None, 0)]
+        if bad or time.monotonic() > deadline:
+            failed = bad[0].returncode if bad else 124
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_end = time.monotonic() + 10.0
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, t_end - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    out0.seek(0)
+    sys.stdout.write(out0.read())
     sys.stdout.flush()
-    return max(abs(c) for c in codes)
+    if failed is not None:
+        sys.stderr.write(f"bench.py: a rank failed (exit code {failed}); the other ranks were stopped\n")
+        return abs(failed) or 1
+    return max(abs(p.returncode) for p in procs)
 
 
 def main(argv=None):
@@ -249,6 +273,7 @@ def main(argv=None):
                     help="skip the fast_math_variant leg (profiling runs: both builds name their kernels alike)")
     ap.add_argument("--force-group", action="store_true",
                     help="exercise the gloo rendezvous + RCCL compose path even with one rank (plumbing check)")
+    ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)     # test hook: this rank exits with 3 at once
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="ranks only rendezvous (gloo), exchange their ranks and print the line skeleton: the launcher "
                          "/ relay / reduction plumbing without a GPU (tests/test_bench_helpers.py)")
@@ -258,6 +283,8 @@ def main(argv=None):
         sys.exit(launch_ranks(args.gpus, argv))
 
     rank = int(os.environ.get("RANK", "0"))
+    if rank == args.fail_rank:
+        raise SystemExit(3)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:

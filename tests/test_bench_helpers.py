@@ -71,6 +71,17 @@ def test_self_launch_spawns_the_ranks_and_relays_rank0(tmp_path):
     assert line == {"rendezvous_only": True, "n_gpus": 2, "ranks": [0, 1], "sum": 3.0, "scaling": "weak"}
 
 
+def test_self_launch_does_not_hang_when_a_rank_dies():
+    """rank 1 exits at once; rank 0 would wait for it in the rendezvous for ever -- the launcher stops it and reports"""
+    import subprocess, sys, time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only", "--fail-rank", "1"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 3 and time.time() - t0 < 60
+    assert "a rank failed" in out.stderr and not out.stdout.strip()
+
+
 def test_gpu_count_probe_does_not_touch_hip():
     assert isinstance(bench.visible_gpus(), int) and bench.visible_gpus() >= 0
 
