@@ -408,3 +408,108 @@ def test_microfacet_reflection_against_the_published_equations(mtype, dist, scal
         assert fv[0] == pytest.approx(want_f, rel=2e-2)
         checked += 1
     assert checked > 200
+
+
+def test_glass_transmission_against_the_published_equations():
+    """pbrt-v3 MicrofacetTransmission::f / Pdf (the source MicrofacetBXDF.h:64-135 follows) in float64: eta = etaB/etaA on
+    the outside, wh = normalize(wo + eta wi), f = (1 - F) T |D G eta^2 |wi.wh| |wo.wh| / (cos_i cos_o (wo.wh + eta wi.wh)^2)|
+    (radiance mode factor 1), pdf = D(wh) G1(wo) |wo.wh| / |cos_o| * |eta^2 wi.wh / (wo.wh + eta wi.wh)^2|.  As instantiated by
+    GlassMaterial (:541): Beckmann (0.01, 0.01), T = 0.98, etaA = 1, etaB = 1.5, its own Fresnel with eta = etaA = 1 (F = 0),
+    and Material::PDF scales by the lobe probability 0.75 (:554-562)."""
+    D, lam = _beckmann(0.01, 0.01)
+    m = lambert(albedo=(1, 1, 1), mtype=abi.MAT_GLASS)
+    f2, f3 = C.c_float * 2, C.c_float * 3
+    rs = np.random.RandomState(18)
+    checked = 0
+    for _ in range(600):
+        wo = np.array([rs.uniform(-0.5, 0.5), rs.uniform(-0.5, 0.5), 0.0]); wo[2] = math.sqrt(1 - wo[0]**2 - wo[1]**2)
+        wh = np.array([rs.normal(0, 0.01), rs.normal(0, 0.01), 1.0]); wh /= np.linalg.norm(wh)
+        # Snell through the micro-normal, entering (eta_i / eta_t = 1 / 1.5)
+        e = 1 / 1.5
+        c = wo.dot(wh)
+        s2t = e * e * (1 - c * c)
+        wi = -e * wo + (e * c - math.sqrt(1 - s2t)) * wh
+        if wi[2] >= -0.05:
+            continue
+        fv, pdf = f3(), C.c_float()
+        po.lib().orc_material_F(C.byref(m), f3(*wo.astype(F32)), f3(*wi.astype(F32)), f2(0.3, 0.3), f2(0.6, 0.5), fv, C.byref(pdf))
+        wo32, wi32 = wo.astype(F32).astype(np.float64), wi.astype(F32).astype(np.float64)
+        eta = 1.5
+        h = wo32 + eta * wi32; h /= np.linalg.norm(h)
+        if h[2] < 0:
+            h = -h
+        denom = wo32.dot(h) + eta * wi32.dot(h)
+        G = 1 / (1 + lam(wo32) + lam(wi32))
+        want_f = 0.98 * abs(D(h) * G * eta * eta * abs(wi32.dot(h)) * abs(wo32.dot(h)) / (wi32[2] * wo32[2] * denom * denom))
+        G1 = 1 / (1 + lam(wo32))
+        want_pdf = 0.75 * D(h) * G1 * abs(wo32.dot(h)) / abs(wo32[2]) * abs(eta * eta * wi32.dot(h) / (denom * denom))
+        assert fv[0] == fv[1] == fv[2]
+        assert fv[0] == pytest.approx(want_f, rel=3e-2) and pdf.value == pytest.approx(want_pdf, rel=3e-2)
+        checked += 1
+    assert checked > 300
+
+
+def _sampled_half_vectors(mtype, wo, n, seed, lobe_u):
+    """wh = normalize(wo + wi) of n reflection samples of Material::S_F (uu.x remapped into the lobe by lobe_u)"""
+    m = lambert(albedo=(1, 1, 1), mtype=mtype)
+    rs = np.random.RandomState(seed)
+    out = []
+    for u in rs.rand(n, 2):
+        wi, f, pdf = S_F(m, wo, (lobe_u(u[0]), u[1]))
+        if pdf > 0:
+            h = np.array(wo, np.float64) + np.array(wi, np.float64)
+            out.append(h / np.linalg.norm(h))
+    return np.array(out)
+
+
+def test_visible_normal_sampling_at_normal_incidence_follows_the_slope_distributions():
+    """at wo = +z every microfacet is visible, so the sampled slopes follow the distribution itself: Beckmann slopes / alpha
+    are Gaussian, r^2 ~ Exp(1) (mean 1, median ln 2); Trowbridge-Reitz: CDF(r) = r^2 / (1 + r^2) (quartiles 1/sqrt 3, 1, sqrt 3)"""
+    wo = (0.0, 0.0, 1.0)
+    wh = _sampled_half_vectors(abi.MAT_PLASTIC, wo, 12000, 5, lambda u: 0.5 + 0.5 * u)          # Beckmann (0.01, 0.1), specular half
+    sx, sy = -wh[:, 0] / wh[:, 2] / 0.01, -wh[:, 1] / wh[:, 2] / 0.1
+    r2 = sx * sx + sy * sy
+    assert len(r2) > 11000 and r2.mean() == pytest.approx(1.0, rel=0.04) and np.median(r2) == pytest.approx(math.log(2), rel=0.05)
+    assert abs(sx.mean()) < 0.03 and abs(sy.mean()) < 0.03 and sx.var() == pytest.approx(0.5, rel=0.06) and sy.var() == pytest.approx(0.5, rel=0.06)
+    wh = _sampled_half_vectors(abi.MAT_METAL, wo, 12000, 6, lambda u: u)                           # Trowbridge-Reitz (0.01, 0.02)
+    r = np.hypot(-wh[:, 0] / wh[:, 2] / 0.01, -wh[:, 1] / wh[:, 2] / 0.02)
+    q1, q2, q3 = np.percentile(r, [25, 50, 75])
+    assert q1 == pytest.approx(1 / math.sqrt(3), rel=0.05) and q2 == pytest.approx(1.0, rel=0.05) and q3 == pytest.approx(math.sqrt(3), rel=0.06)
+
+
+@pytest.mark.parametrize("mtype,dist,alpha,lobe_u", [
+    (abi.MAT_PLASTIC, _beckmann(0.01, 0.1), (0.01, 0.1), lambda u: 0.5 + 0.5 * u),
+    (abi.MAT_METAL, _trowbridge(0.01, 0.02), (0.01, 0.02), lambda u: u)])
+def test_visible_normal_sampling_at_oblique_incidence(mtype, dist, alpha, lobe_u):
+    """Heitz's visible-normal distribution D_wo(wh) = D(wh) G1(wo) max(0, wo.wh) / cos_o, integrated in float64 over slope
+    space from the published D and Lambda: the sampled half vectors must fall into the quadrants / the 1-alpha disc with
+    those probabilities (the general branch of BeckmannSample11 / TrowbridgeReitzSample11 at 60 degrees)"""
+    D, lam = dist
+    ax, ay = alpha
+    wo = np.array([math.sin(math.radians(60)) * 0.8, math.sin(math.radians(60)) * 0.6, math.cos(math.radians(60))])
+    wh = _sampled_half_vectors(mtype, tuple(wo.astype(F32)), 9000, 9, lobe_u)
+    sx, sy = -wh[:, 0] / wh[:, 2], -wh[:, 1] / wh[:, 2]
+    # reference probabilities on a grid in (slope / alpha) space, wide enough for Trowbridge-Reitz's heavy tails
+    g = np.concatenate([-np.geomspace(400, 0.02, 500), [0.0], np.geomspace(0.02, 400, 500)])
+    edges = np.concatenate([[g[0]], 0.5 * (g[1:] + g[:-1]), [g[-1]]])
+    cell = np.diff(edges)
+    gx, gy = np.meshgrid(g * ax, g * ay, indexing="ij")
+    area = np.outer(cell * ax, cell * ay)
+    nz = 1 / np.sqrt(1 + gx * gx + gy * gy)
+    hx, hy, hz = -gx * nz, -gy * nz, nz
+    # D(wh) of the published distributions, vectorised: tan^2 = slope^2, cos^2 phi = sx^2 / slope^2
+    e = (gx / ax) ** 2 + (gy / ay) ** 2
+    c4 = hz ** 4
+    dens = np.exp(-e) / (math.pi * ax * ay * c4) if mtype == abi.MAT_PLASTIC else 1 / (math.pi * ax * ay * c4 * (1 + e) ** 2)
+    spot = (len(g) // 2 + 37, len(g) // 2 - 11)
+    assert dens[spot] == pytest.approx(D(np.array([hx[spot], hy[spot], hz[spot]])), rel=1e-9)   # same D as the scalar form above
+    G1 = 1 / (1 + lam(wo))
+    w = dens * G1 * np.maximum(0.0, hx * wo[0] + hy * wo[1] + hz * wo[2]) / wo[2] * nz ** 3 * area    # d(omega) = cos^3 ds_x ds_y
+    assert w.sum() == pytest.approx(1.0, abs=0.01)                                 # D_wo is normalised (Heitz 2014)
+    w /= w.sum()
+    for name, region_g, region_s in (
+            ("slope_x < 0", gx < 0, sx < 0),
+            ("slope_y < 0", gy < 0, sy < 0),
+            ("inside the one-alpha ellipse", (gx / ax) ** 2 + (gy / ay) ** 2 < 1, (sx / ax) ** 2 + (sy / ay) ** 2 < 1)):
+        want, got = w[region_g].sum(), region_s.mean()
+        assert got == pytest.approx(want, abs=0.02), (name, want, got)
