@@ -13,7 +13,7 @@ CXXFLAGS  := -std=c++17 -O2 -fPIC -Wall -Wextra -ffp-contract=off -Iinclude
 HIPFLAGS  := -std=c++17 -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -Iinclude -Itracer_amd/csrc \
              -Wall -Wno-unused-function
 
-HOST_SRC  := tracer_amd/host/bvh_builder.cpp tracer_amd/host/scene.cpp tracer_amd/host/mesh.cpp tracer_amd/host/pbrt_scene.cpp tracer_amd/host/sobol.cpp
+HOST_SRC  := tracer_amd/host/bvh_builder.cpp tracer_amd/host/scene.cpp tracer_amd/host/mesh.cpp tracer_amd/host/pbrt_scene.cpp
 HOST_HDR  := tracer_amd/host/host_math.hpp tracer_amd/host/host_scene.hpp tracer_amd/host/pbrt_text.hpp include/tracer_abi.h include/trc_sobol.h
 HIP_SRC   := tracer_amd/csrc/trc_abi.hip tracer_amd/csrc/trc_sppm.hip tracer_amd/csrc/trc_lbvh.hip
 HIP_HDR   := $(wildcard tracer_amd/csrc/*.hpp) include/tracer_abi.h include/trc_detmath.h include/trc_sobol.h

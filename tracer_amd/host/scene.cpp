@@ -20,6 +20,7 @@
 #include "host_math.hpp"
 #include "host_scene.hpp"
 #include "pbrt_text.hpp"
+#include "trc_sobol.h"
 
 using namespace trc;
 
@@ -407,6 +408,15 @@ trc_status trc_host_write_png(const char* path, const uint8_t* rgba8, uint32_t w
     const bool ok = std::fwrite(file.data(), 1, file.size(), f) == file.size();
     std::fclose(f);
     return ok ? TRC_OK : TRC_ERR_INVALID_ARG;
+}
+
+// C-ABI view of include/trc_sobol.h (tables of pbrt::SobolSampler, SobolSampler.hh:126-160) for hosts and tests; the
+// device library builds the same tables itself
+void trc_host_sobol_matrices32(uint32_t* out) { trc_sobol_matrices32(out); }
+
+trc_status trc_host_sobol_interval_tables(uint32_t log2res, uint64_t* vdc, uint64_t* inv) {
+    if (!vdc || !inv) return TRC_ERR_INVALID_ARG;
+    return trc_sobol_interval_tables(log2res, vdc, inv) == 0 ? TRC_OK : TRC_ERR_INVALID_ARG;
 }
 
 }  // extern "C"
