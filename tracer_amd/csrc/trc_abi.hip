@@ -39,8 +39,20 @@ __global__ void __launch_bounds__(256) k_seed(uint32_t* rng, uint32_t n_pixels, 
 // kernelPathTracing, Render.metal:495-558.  One lane per pixel, one one-wavefront workgroup per 8x8 pixel block
 // (DESIGN.md 4.1), all `spp` samples fused: RNG texel and accumulator are read and
 // written ONCE per pixel instead of once per sample (64 B/pixel/sample in the reference).
+// wavefronts per SIMD the register allocation aims at (launch bounds): tracePath fits 96 VGPRs with 2 spilled dwords
+// (5 waves: 21.5 -> 20.8 ms on config 2; 6 waves / 80 VGPRs: 21.6), traceMIS needs 128 (5 waves with 39 spilled dwords:
+// 63.2 -> 67.4 ms on config 3)
+#ifndef TRC_PATH_WAVES
+#define TRC_PATH_WAVES 5
+#endif
+#ifndef TRC_MIS_WAVES
+#define TRC_MIS_WAVES 4
+#endif
 template <bool LDS, bool STATS, int INTEGRATOR, bool SOBOL = false>
-__global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRATOR_VOLUME ? 3 : 4)) k_render(const KRender kp) {
+#ifndef TRC_VOLUME_WAVES
+#define TRC_VOLUME_WAVES 4
+#endif
+__global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRATOR_VOLUME ? TRC_VOLUME_WAVES : (INTEGRATOR == TRC_INTEGRATOR_MIS ? TRC_MIS_WAVES : TRC_PATH_WAVES))) k_render(const KRender kp) {
     const DScene& sc = kp.ks.sc;
     const uint32_t* small_base = stage_scene(sc);
     uint32_t* stack = lane_stack(sc);
@@ -184,8 +196,11 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
 // blocks of the list and every lane walks its own pixel of block after block, so a lane whose pixel is done starts
 // the same pixel of the next block at once (path regeneration across pixels instead of across samples).  The strip
 // is the unit of the adaptive launch order.  Pixels are independent: the frame is k_render's, bit for bit.
+#ifndef TRC_STRIP_PATH_WAVES
+#define TRC_STRIP_PATH_WAVES 4
+#endif
 template <bool LDS, int INTEGRATOR, bool SOBOL>
-__global__ void __launch_bounds__(kBlock, INTEGRATOR == TRC_INTEGRATOR_VOLUME ? 3 : 4) k_render_strip(const KRender kp) {
+__global__ void __launch_bounds__(kBlock, INTEGRATOR == TRC_INTEGRATOR_VOLUME ? 3 : (INTEGRATOR == TRC_INTEGRATOR_PATH ? TRC_STRIP_PATH_WAVES : 4)) k_render_strip(const KRender kp) {
     const DScene& sc = kp.ks.sc;
     const uint32_t* small_base = stage_scene(sc);
     uint32_t* stack = lane_stack(sc);

@@ -124,8 +124,17 @@ __device__ __forceinline__ bool sppm_hit(const SppmCtx& cx, const Ray& ray, HitR
 }
 
 // kernelCameraRecording, Photon.metal:96-167 + traceCameraRecord :3-92
+#ifndef TRC_SPPM_CAMERA_WAVES
+#define TRC_SPPM_CAMERA_WAVES 4
+#endif
+#ifndef TRC_SPPM_PHOTON_WAVES
+#define TRC_SPPM_PHOTON_WAVES 5
+#endif
+#ifndef TRC_SPPM_REFINE_WAVES
+#define TRC_SPPM_REFINE_WAVES 5
+#endif
 template <bool ALL_LDS>
-__global__ void __launch_bounds__(kBlock) k_sppm_camera(const KSppm kp) {
+__global__ void __launch_bounds__(kBlock, TRC_SPPM_CAMERA_WAVES) k_sppm_camera(const KSppm kp) {
     const uint32_t* small_base = stage_scene(kp.ks.sc);
     const SppmCtx cx = make_sppm_ctx(kp, small_base);
     const uint32_t tile = kp.tiles[blockIdx.x];
@@ -228,7 +237,7 @@ __global__ void __launch_bounds__(256) k_sppm_radius(trc_CameraRecord* cam_rec, 
 
 // kernelPhotonRecording, Photon.metal:286-355 + tracePhotonRecord :220-285
 template <bool ALL_LDS>
-__global__ void __launch_bounds__(kBlock) k_sppm_photon(const KSppm kp) {
+__global__ void __launch_bounds__(kBlock, TRC_SPPM_PHOTON_WAVES) k_sppm_photon(const KSppm kp) {
     const uint32_t* small_base = stage_scene(kp.ks.sc);
     const SppmCtx cx = make_sppm_ctx(kp, small_base);
     const uint32_t idx = kp.photon_first + blockIdx.x * kBlock + threadIdx.x;     // grid covers exactly this rank's photon range
@@ -359,7 +368,7 @@ __global__ void __launch_bounds__(256) k_sppm_table(const uint32_t* mark, const 
 #define TRC_REFINE_CHUNK 4
 #endif
 constexpr int kRefineChunk = TRC_REFINE_CHUNK;
-__global__ void __launch_bounds__(kBlock) k_sppm_refine(const KSppm kp) {
+__global__ void __launch_bounds__(kBlock, TRC_SPPM_REFINE_WAVES) k_sppm_refine(const KSppm kp) {
     const uint32_t tile = kp.tiles[blockIdx.x];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t qx = (tile & 0xFFFFu) * 8u + (lane & 7u);
