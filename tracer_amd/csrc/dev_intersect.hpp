@@ -12,8 +12,9 @@
 // Traversal design (MI355X): the reference walks parent pointers with a 32-bit "visit the
 // sibling later" bitmask and spends one loop iteration per level on the way back up.  Here the
 // deferred sibling is pushed on a per-lane short stack in LDS (column layout: entry e of lane l
-// at stack[e * 256 + l], so a wavefront's push/pop is one conflict-free ds_write/ds_read_b32),
-// which removes every upward iteration while visiting boxes and primitives in EXACTLY the
+// at stack[e * 64 + l], so a wavefront's push/pop is one conflict-free ds_write/ds_read_b32;
+// the tracePath render kernels keep only the first 16 entries there and deeper ones in global
+// rows: stack_put below), which removes every upward iteration while visiting boxes and primitives in EXACTLY the
 // reference's order -- near child first by hit_t, far child later WITHOUT re-testing its box
 // (Render.hh:171-174,204-208) -- so closest-hit ties resolve identically.  The upward
 // iterations the reference would have executed are still COUNTED (exactly) in the
@@ -64,6 +65,8 @@ struct SceneRef {
     const uint32_t* blob;
     uint32_t off_nodes, off_spheres, off_squares, off_cubes, off_materials, off_tripos, off_triattr;
     uint32_t n_lds_nodes;
+    uint32_t stack_lds;       // traversal-stack entries per lane that live in LDS ...
+    uint32_t* ovf;            // ... deeper ones in this lane's column of the workgroup's overflow rows (global memory)
 };
 TRC_DEV float4 ld4(const uint32_t* p) { return *reinterpret_cast<const float4*>(p); }
 
@@ -333,15 +336,31 @@ struct Trav {
 
 // pops the next deferred sibling, or ends the traversal; `ret_start` = level at which the reference's first
 // upward ("came from child") iteration would run -- only counted, never executed
-template <bool STATS>
-TRC_DEV void trav_pop_or_finish(Trav& tv, int32_t ret_start, const uint32_t* stack, const uint32_t* lvstack, TravCounters& cnt) {
+// Entry e of a lane's stack.  A ray rarely has more than a dozen siblings pending, but the stack must hold the tree's
+// depth.  HYB (the tracePath render kernels on trees read from memory, whose registers allow 5 waves/SIMD if LDS does):
+// the first S.stack_lds entries live in LDS, deeper ones in the workgroup's rows in global memory.  The other kernels
+// keep the whole stack in LDS (measured: the second level costs traceMIS / traceVolume 2.7 % and buys them nothing at 4
+// waves/SIMD).
+template <bool HYB>
+TRC_DEV void stack_put(const SceneRef& S, uint32_t* stack, uint32_t e, uint32_t v) {
+    if (!HYB || e < S.stack_lds) stack[e * kBlock] = v;
+    else S.ovf[(e - S.stack_lds) * kBlock] = v;
+}
+template <bool HYB>
+TRC_DEV uint32_t stack_get(const SceneRef& S, const uint32_t* stack, uint32_t e) {
+    if (!HYB || e < S.stack_lds) return stack[e * kBlock];
+    return S.ovf[(e - S.stack_lds) * kBlock];
+}
+
+template <bool HYB, bool STATS>
+TRC_DEV void trav_pop_or_finish(const SceneRef& S, Trav& tv, int32_t ret_start, const uint32_t* stack, const uint32_t* lvstack, TravCounters& cnt) {
     if (tv.sp == 0) {
         if (STATS) cnt.n_return += (uint32_t)(ret_start + 1);
         tv.done = true;
         return;
     }
     tv.sp--;
-    tv.tag = stack[tv.sp * kBlock];
+    tv.tag = stack_get<HYB>(S, stack, tv.sp);
     if (STATS) {
         const int32_t ls = (int32_t)lvstack[tv.sp * kBlock];
         cnt.n_return += (uint32_t)(ret_start - ls + 1);
@@ -417,7 +436,7 @@ TRC_DEV bool trav_test_leaf(const SceneRef& S, const Ray& ray, HitRec& rec, Trav
 // rollback when the postponed test accepts) is exact but slower than the plain round (measured: 23.9 / 75.5 / 39.3 ms
 // against 22.6 / 77.8 / 40.9 plain and 22.7 / 70.8 / 35.7 for the threshold round); the unchecked one survives only as
 // the A/B variant TRC_SPEC_UNCHECKED, the build that must FAIL the adversarial test.
-template <bool ALL_LDS, bool STATS, bool ANY, bool EAGER_UV, bool VOL = false>
+template <bool ALL_LDS, bool STATS, bool ANY, bool EAGER_UV, bool VOL = false, bool HYB = false>
 TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const float test_t, Trav& tv,
                        uint32_t* stack, uint32_t* lvstack, TravCounters& cnt) {
     const float rx = FLT_MIN;
@@ -427,7 +446,7 @@ TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const flo
         auto pop_next = [&]() {                        // next deferred sibling, or "exhausted" (kTagNone)
             if (tv.sp == 0) { tv.tag = kTagNone; return; }
             tv.sp--;
-            tv.tag = stack[tv.sp * kBlock];
+            tv.tag = stack_get<HYB>(S, stack, tv.sp);
         };
         for (;;) {
             const bool interior = !tv.done && (tv.tag >> kTagIndexBits) == kTagInterior;
@@ -441,7 +460,7 @@ TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const flo
                 if (left_test || right_test) {
                     const uint32_t tagL = __float_as_uint(q3.z), tagR = __float_as_uint(q3.w);
                     const bool left_first = t_left < t_right;
-                    if (left_test && right_test) { stack[tv.sp * kBlock] = left_first ? tagR : tagL; tv.sp++; }
+                    if (left_test && right_test) { stack_put<HYB>(S, stack, tv.sp, left_first ? tagR : tagL); tv.sp++; }
                     tv.tag = left_first ? tagL : tagR;
                 } else {
                     pop_next();
@@ -491,29 +510,29 @@ TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const flo
             const uint32_t tagL = __float_as_uint(q3.z), tagR = __float_as_uint(q3.w);
             const bool left_first = t_left < t_right;            // Render.hh:174 (literal, also when only one hit)
             if (left_test && right_test) {
-                stack[tv.sp * kBlock] = left_first ? tagR : tagL;    // Render.hh:171-172: visit the other one later
+                stack_put<HYB>(S, stack, tv.sp, left_first ? tagR : tagL);    // Render.hh:171-172: visit the other one later
                 if (STATS) lvstack[tv.sp * kBlock] = (uint32_t)tv.level;
                 tv.sp++;
             }
             tv.tag = left_first ? tagL : tagR;
             if (STATS && (tv.tag >> kTagIndexBits) == kTagInterior) tv.level += 1;
         } else {
-            trav_pop_or_finish<STATS>(tv, tv.level - 1, stack, lvstack, cnt);
+            trav_pop_or_finish<HYB, STATS>(S, tv, tv.level - 1, stack, lvstack, cnt);
         }
     }
     if (!tv.done && (tv.tag >> kTagIndexBits) != kTagInterior) {
         trav_test_leaf<STATS, EAGER_UV, VOL>(S, ray, rec, tv, tv.tag, cnt);
         if (ANY && tv.ry < test_t) tv.done = true;                    // Render.hh:244
-        else trav_pop_or_finish<STATS>(tv, tv.level, stack, lvstack, cnt);
+        else trav_pop_or_finish<HYB, STATS>(S, tv, tv.level, stack, lvstack, cnt);
     }
 }
 
-template <bool ALL_LDS, bool STATS, bool ANY, bool EAGER_UV, bool VOL = false>
+template <bool ALL_LDS, bool STATS, bool ANY, bool EAGER_UV, bool VOL = false, bool HYB = false>
 TRC_DEV bool scene_hit(const SceneRef& S, const F3 root_min, const F3 root_max, const Ray& ray, HitRec& rec, const float test_t,
                        uint32_t* stack, uint32_t* lvstack, TravCounters& cnt) {
     Trav tv;
     if (!trav_begin<STATS>(root_min, root_max, ray, test_t, tv, cnt)) return false;
-    while (!tv.done) trav_iter<ALL_LDS, STATS, ANY, EAGER_UV, VOL>(S, ray, rec, test_t, tv, stack, lvstack, cnt);
+    while (!tv.done) trav_iter<ALL_LDS, STATS, ANY, EAGER_UV, VOL, HYB>(S, ray, rec, test_t, tv, stack, lvstack, cnt);
     return tv.ry < test_t;
 }
 

@@ -53,6 +53,7 @@ struct DScene {
     uint32_t n_lds_nodes;
     uint32_t n_nodes, n_spheres, n_squares, n_cubes, n_materials, n_triangles;
     uint32_t stack_depth;     // max pending siblings = tree depth (checked <= TRC_MAX_BVH_DEPTH)
+    uint32_t stack_lds;       // stack entries per lane kept in LDS (= stack_depth unless a launch provides overflow rows)
 };
 
 struct DCamera {

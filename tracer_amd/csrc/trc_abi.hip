@@ -39,20 +39,25 @@ __global__ void __launch_bounds__(256) k_seed(uint32_t* rng, uint32_t n_pixels, 
 // kernelPathTracing, Render.metal:495-558.  One lane per pixel, one one-wavefront workgroup per 8x8 pixel block
 // (DESIGN.md 4.1), all `spp` samples fused: RNG texel and accumulator are read and
 // written ONCE per pixel instead of once per sample (64 B/pixel/sample in the reference).
-// wavefronts per SIMD the register allocation aims at (launch bounds): tracePath fits 96 VGPRs with 2 spilled dwords
-// (5 waves: 21.5 -> 20.8 ms on config 2; 6 waves / 80 VGPRs: 21.6), traceMIS needs 128 (5 waves with 39 spilled dwords:
-// 63.2 -> 67.4 ms on config 3)
+// wavefronts per SIMD the register allocation aims at (launch bounds), each measured (profiles/r02/
+// compiler_flags_and_occupancy.txt, lds_plan_and_stack.txt): tracePath on an LDS-resident tree fits 96 VGPRs with 2
+// spilled dwords (5 waves: 21.5 -> 20.8 ms on config 2; 6 waves / 80 VGPRs: 21.3-21.6); on a tree read from memory the
+// sixth wave hides more latency than its spills cost (1 M triangles: 32.8 -> 31.8 ms; 7 waves: 33.4) -- provided LDS
+// lets it in (plan_launch_lds); traceMIS needs 128 (5 waves: 63.2 -> 63.7 ms on config 3), traceVolume 128 (5: 55 -> 84 ms)
 #ifndef TRC_PATH_WAVES
 #define TRC_PATH_WAVES 5
+#endif
+#ifndef TRC_PATH_WAVES_GLOBAL
+#define TRC_PATH_WAVES_GLOBAL 6
 #endif
 #ifndef TRC_MIS_WAVES
 #define TRC_MIS_WAVES 4
 #endif
-template <bool LDS, bool STATS, int INTEGRATOR, bool SOBOL = false>
 #ifndef TRC_VOLUME_WAVES
 #define TRC_VOLUME_WAVES 4
 #endif
-__global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRATOR_VOLUME ? TRC_VOLUME_WAVES : (INTEGRATOR == TRC_INTEGRATOR_MIS ? TRC_MIS_WAVES : TRC_PATH_WAVES))) k_render(const KRender kp) {
+template <bool LDS, bool STATS, int INTEGRATOR, bool SOBOL = false>
+__global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRATOR_VOLUME ? TRC_VOLUME_WAVES : (INTEGRATOR == TRC_INTEGRATOR_MIS ? TRC_MIS_WAVES : (LDS ? TRC_PATH_WAVES : TRC_PATH_WAVES_GLOBAL)))) k_render(const KRender kp) {
     const DScene& sc = kp.ks.sc;
     const uint32_t* small_base = stage_scene(sc);
     uint32_t* stack = lane_stack(sc);
@@ -75,6 +80,8 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
     if (active) {
         PathCtx cx;
         cx.S = make_scene_ref(sc, small_base);
+        constexpr bool kHybridStack = !LDS && !STATS && INTEGRATOR == TRC_INTEGRATOR_PATH;     // plan_launch_lds
+        if (kHybridStack) cx.S.ovf = kp.stack_ovf + (size_t)blockIdx.x * (sc.stack_depth - sc.stack_lds) * kBlock + lane;
         cx.root_min = f3(kp.ks.root_box[0], kp.ks.root_box[1], kp.ks.root_box[2]);
         cx.root_max = f3(kp.ks.root_box[3], kp.ks.root_box[4], kp.ks.root_box[5]);
         cx.sh.mats = small_base + sc.off_materials;
@@ -145,7 +152,7 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
             ProfScope<STATS> loop_scope(cnt, kProfLoop);
             n_rays++;
             constexpr bool kVolume = INTEGRATOR == TRC_INTEGRATOR_VOLUME;
-            const bool hitted = scene_hit<LDS, STATS, false, false, kVolume>(cx.S, cx.root_min, cx.root_max, ps.ray, ps.rec, FLT_MAX,
+            const bool hitted = scene_hit<LDS, STATS, false, false, kVolume, kHybridStack>(cx.S, cx.root_min, cx.root_max, ps.ray, ps.rec, FLT_MAX,
                                                                         cx.stack, cx.lvstack, cnt);
             F3 color;
             const bool finished = (INTEGRATOR == TRC_INTEGRATOR_PATH)
@@ -217,6 +224,8 @@ __global__ void __launch_bounds__(kBlock, INTEGRATOR == TRC_INTEGRATOR_VOLUME ? 
 
     PathCtx cx;
     cx.S = make_scene_ref(sc, small_base);
+    constexpr bool kHybridStack = !LDS && INTEGRATOR == TRC_INTEGRATOR_PATH;
+    if (kHybridStack) cx.S.ovf = kp.stack_ovf + (size_t)blockIdx.x * (sc.stack_depth - sc.stack_lds) * kBlock + lane;
     cx.root_min = f3(kp.ks.root_box[0], kp.ks.root_box[1], kp.ks.root_box[2]);
     cx.root_max = f3(kp.ks.root_box[3], kp.ks.root_box[4], kp.ks.root_box[5]);
     cx.sh.mats = small_base + sc.off_materials;
@@ -295,7 +304,7 @@ __global__ void __launch_bounds__(kBlock, INTEGRATOR == TRC_INTEGRATOR_VOLUME ? 
     while (alive) {
         n_rays++;
         constexpr bool kVolume = INTEGRATOR == TRC_INTEGRATOR_VOLUME;
-        const bool hitted = scene_hit<LDS, false, false, false, kVolume>(cx.S, cx.root_min, cx.root_max, ps.ray, ps.rec, FLT_MAX,
+        const bool hitted = scene_hit<LDS, false, false, false, kVolume, kHybridStack>(cx.S, cx.root_min, cx.root_max, ps.ray, ps.rec, FLT_MAX,
                                                                   cx.stack, cx.lvstack, cnt);
         F3 color;
         const bool finished = (INTEGRATOR == TRC_INTEGRATOR_PATH)
@@ -609,10 +618,34 @@ bool trc_load_rccl(std::string& err) {
     return true;
 }
 
-size_t trc_dyn_lds_bytes(const trc_ctx* ctx, bool stats) {
-    const DScene& sc = ctx->ks.sc;
-    size_t dwords = sc.lds_dwords + (size_t)sc.stack_depth * kBlock * (stats ? 2u : 1u);
+static size_t dyn_lds_bytes(const DScene& sc, bool stats) {
+    size_t dwords = sc.lds_dwords + (size_t)sc.stack_lds * kBlock * (stats ? 2u : 1u);
     return dwords * 4;
+}
+size_t trc_dyn_lds_bytes(const trc_ctx* ctx, bool stats) { return dyn_lds_bytes(ctx->ks.sc, stats); }
+
+// LDS plan of ONE production render launch on a tree that is read from memory.  A CU holds 4 x W one-wavefront
+// workgroups (W = the waves per SIMD the kernel's registers allow) only if each fits 160 KB / (4 W) of LDS: the lane
+// stacks plus the staged scene prefix.  plan_lds (upload time) assumes W = 4 and a stack as deep as the tree; here
+//  * the stack keeps kStackLdsLevels entries per lane in LDS, deeper entries go to per-workgroup rows in global memory
+//    (dev_intersect.hpp::stack_put) -- a ray rarely has more siblings pending, the tree depth is the worst case;
+//  * the node prefix takes what is left of the workgroup's share (host trees: any prefix of the BFS order may be staged).
+// Measured on the 1 M-triangle scene (depth 27: 6.9 KB of stack): the tracePath kernel (5 waves/SIMD by registers) was
+// held at 4 by LDS; 34.9 -> 32.8 ms per 32-spp launch once it fits.
+constexpr uint32_t kStackLdsLevels = 16;
+static void plan_launch_lds(const trc_ctx* ctx, DScene& sc, uint32_t waves_per_simd, bool hybrid) {
+    static const bool off = std::getenv("TRC_NO_LDS_FIT") != nullptr;                 // A/B knobs
+    static const char* lv = std::getenv("TRC_STACK_LDS_LEVELS");
+    if (off) return;
+    const uint32_t levels = lv && std::atoi(lv) > 0 ? (uint32_t)std::atoi(lv) : kStackLdsLevels;
+    if (hybrid) sc.stack_lds = std::min(sc.stack_depth, levels);
+    if (!ctx->lds_prefix_ok) return;                                                   // all or nothing was decided at upload
+    const uint32_t per_wg = ((160u * 1024u / 4u) / (4u * waves_per_simd)) & ~127u;     // dwords; LDS is granted in 512-byte units
+    const uint32_t stack = sc.stack_lds * kBlock;
+    uint32_t room = std::max(per_wg > stack ? per_wg - stack : 0u, sc.off_nodes + kNodeDwords);
+    room = std::min(room, kLdsSceneBytes / 4);
+    sc.n_lds_nodes = std::min(sc.n_nodes, (room - sc.off_nodes) / kNodeDwords);
+    sc.lds_dwords = sc.off_nodes + sc.n_lds_nodes * kNodeDwords;
 }
 
 trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32_t view_height, uint32_t blk_shift) {
@@ -763,7 +796,7 @@ void trc_destroy(trc_ctx* ctx) {
     (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_stats); (void)hipFree(ctx->d_reduce_recv);
     (void)hipFree(ctx->d_block_cost); (void)hipFree(ctx->d_order_hist);
     for (int k = 0; k < 2; ++k) { (void)hipFree(ctx->d_order_keys[k]); (void)hipFree(ctx->d_order_vals[k]); }
-    (void)hipFree(ctx->d_accum_alt);
+    (void)hipFree(ctx->d_accum_alt); (void)hipFree(ctx->d_stack_ovf);
     for (hipEvent_t e : {ctx->ev_rendered, ctx->ev_busy, ctx->ev_busy_alt}) if (e) (void)hipEventDestroy(e);
     if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -791,6 +824,7 @@ trc_status trc_upload_scene(trc_ctx* ctx, const trc_scene* scene) {
     ks.sc.blob = ctx->d_blob;
     ctx->ks = ks;
     ctx->lds_scene = ks.sc.n_lds_nodes == ks.sc.n_nodes;      // whole tree staged in LDS
+    ctx->lds_prefix_ok = true;
     ctx->has_scene = true;
     return TRC_OK;
 }
@@ -990,8 +1024,7 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
         if (2ull * p->max_depth > TRC_SOBOL_DIMS)
             return fail(ctx, TRC_ERR_UNSUPPORTED, "TRC_FLAG_SOBOL: 2 * max_depth exceeds the 40 generated dimensions");
     }
-    const size_t lds = trc_dyn_lds_bytes(ctx, stats);
-    if (lds > 160 * 1024) return fail(ctx, TRC_ERR_UNSUPPORTED, "traversal stack exceeds the 160 KB LDS of a CU");
+    if (trc_dyn_lds_bytes(ctx, stats) > 160 * 1024) return fail(ctx, TRC_ERR_UNSUPPORTED, "traversal stack exceeds the 160 KB LDS of a CU");
 
     KRender kp{};
     kp.ks = ctx->ks;
@@ -1052,6 +1085,24 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
         kp.sobol_vdc = ctx->d_sobol_vdc;
         kp.sobol_m = m;
     }
+
+    if (!stats && !ctx->lds_scene) {
+        const bool strip = kp.strip > 1;
+        const uint32_t waves = p->integrator == TRC_INTEGRATOR_PATH ? (strip ? TRC_STRIP_PATH_WAVES : TRC_PATH_WAVES_GLOBAL)
+                             : p->integrator == TRC_INTEGRATOR_MIS ? (strip ? 4 : TRC_MIS_WAVES) : (strip ? 3 : TRC_VOLUME_WAVES);
+        plan_launch_lds(ctx, kp.ks.sc, waves, p->integrator == TRC_INTEGRATOR_PATH);
+        const size_t rows = kp.ks.sc.stack_depth - kp.ks.sc.stack_lds;
+        const size_t need = rows * kBlock * sizeof(uint32_t) * ctx->n_tiles;           // one set of rows per workgroup
+        if (need > ctx->stack_ovf_bytes) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->d_stack_ovf) { (void)hipFree(ctx->d_stack_ovf); ctx->d_stack_ovf = nullptr; }
+            ctx->stack_ovf_bytes = 0;
+            if (hipMalloc((void**)&ctx->d_stack_ovf, need) != hipSuccess) return fail(ctx, TRC_ERR_OOM, "hipMalloc traversal-stack overflow rows");
+            ctx->stack_ovf_bytes = need;
+        }
+        kp.stack_ovf = ctx->d_stack_ovf;
+    }
+    const size_t lds = dyn_lds_bytes(kp.ks.sc, stats);
 
     collect_finished_events(ctx);
     hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);

@@ -34,6 +34,7 @@ struct KRender {
     trc_GridDensityInfo dinfo;
     const uint8_t* occupancy;           // ... and its 4x4x4-brick occupancy (dev_integrator.hpp::grid_sample)
     unsigned long long* stats;          // kStatCount counters
+    uint32_t* stack_ovf;                // (stack_depth - stack_lds) rows of 64 entries per workgroup (null: the stack is all LDS)
     uint32_t blk_shift;                 // log2 of the pixel-block edge of one wavefront: 3 (8x8, 64 lanes) or 2 (4x4, 16 lanes)
     uint32_t n_tiles, strip;            // k_render_strip: blocks in `tiles`, consecutive blocks per wavefront (1: k_render)
     const uint32_t* order;              // launch order: order[blockIdx.x] = index into `tiles` (null: identity)
@@ -63,7 +64,7 @@ __device__ __forceinline__ const uint32_t* stage_scene(const DScene& sc) {
 // this lane's column of the traversal stack (one row per entry); the instrumented kernels keep a second region of the
 // same size for the levels
 __device__ __forceinline__ uint32_t* lane_stack(const DScene& sc) { return trc_smem + sc.lds_dwords + threadIdx.x; }
-__device__ __forceinline__ uint32_t* lane_lvstack(const DScene& sc) { return trc_smem + sc.lds_dwords + sc.stack_depth * kBlock + threadIdx.x; }
+__device__ __forceinline__ uint32_t* lane_lvstack(const DScene& sc) { return trc_smem + sc.lds_dwords + sc.stack_lds * kBlock + threadIdx.x; }
 
 __device__ __forceinline__ SceneRef make_scene_ref(const DScene& sc, const uint32_t* small_base) {
     SceneRef S;
@@ -73,6 +74,8 @@ __device__ __forceinline__ SceneRef make_scene_ref(const DScene& sc, const uint3
     S.off_cubes = sc.off_cubes; S.off_materials = sc.off_materials;
     S.off_tripos = sc.off_tripos; S.off_triattr = sc.off_triattr;
     S.n_lds_nodes = sc.n_lds_nodes;
+    S.stack_lds = sc.stack_lds;
+    S.ovf = nullptr;
     return S;
 }
 
@@ -98,6 +101,9 @@ struct trc_ctx {
     uint32_t* d_blob = nullptr;
     size_t blob_bytes = 0;
     bool lds_scene = false;
+    bool lds_prefix_ok = false;         // the fat nodes are in top-of-tree-first order: any prefix may be staged
+    uint32_t* d_stack_ovf = nullptr;    // traversal-stack overflow rows of the render launches (deep trees only)
+    size_t stack_ovf_bytes = 0;
     trc_BVH* d_bvh_ref = nullptr;    // tree built by trc_upload_scene_lbvh, reference array layout (trc_download_bvh)
     uint32_t n_bvh_ref = 0, lbvh_height = 0;
     float lbvh_build_ms = 0.0f;

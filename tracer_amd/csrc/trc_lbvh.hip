@@ -604,6 +604,7 @@ trc_status trc_upload_scene_lbvh(trc_ctx* ctx, const trc_scene* s) {
     for (int a = 0; a < 6; ++a) ks.root_box[a] = root_box[a];
     ctx->ks = ks;
     ctx->lds_scene = sc.n_lds_nodes == sc.n_nodes;
+    ctx->lds_prefix_ok = false;
     ctx->n_bvh_ref = n_nodes;
     ctx->lbvh_height = height;
     ctx->lbvh_build_ms = ms;

@@ -79,24 +79,22 @@ inline trc_status layout_scene(trc_ctx* ctx, const trc_scene* s, uint32_t n_inte
     return TRC_OK;
 }
 
-// LDS per workgroup = staged prefix + traversal stack; keep 4 workgroups per CU resident (measured on
-// MI355X: occupancy beats top-of-tree staging -- 8/16/24/40/64 KB staged on the 1 M-triangle scene gave
-// 1826/1553/1155/1165/666 Mrays/s), so nodes are staged only into what the stack leaves of ~38 KB.
+// Upload-time LDS plan (k_trace, the SPPM passes, the instrumented kernels; production render launches refine it per
+// kernel: trc_abi.hip::plan_launch_lds).  LDS per workgroup = staged prefix + traversal stack; keep 16 one-wavefront
+// workgroups per CU resident (measured on MI355X: occupancy beats top-of-tree staging -- 8/16/24/40/64 KB staged on the
+// 1 M-triangle scene gave 1826/1553/1155/1165/666 Mrays/s), so nodes are staged only into what the stack leaves of 9.5 KB.
 // `prefix_ok`: the first fat nodes are the top of the tree (BFS order); otherwise all or nothing.
 inline void plan_lds(DScene& sc, uint32_t max_leaf_depth, bool prefix_ok) {
     const uint32_t stack_dwords = std::max(1u, max_leaf_depth) * kBlock;
     const uint32_t per_block = 38u * 1024u / 4u * kBlock / 256u;      // 16 one-wavefront workgroups per CU
     uint32_t budget_dwords = (per_block > stack_dwords) ? per_block - stack_dwords : 0u;
     budget_dwords = std::min(budget_dwords, kLdsSceneBytes / 4);
-    if (const char* e = std::getenv("TRC_LDS_BUDGET_KB")) {          // tuning knob: staged bytes vs occupancy
-        const long kb = std::atol(e);
-        if (kb > 0 && kb <= 128) budget_dwords = (uint32_t)kb * 256u;
-    }
     budget_dwords = std::max(budget_dwords, sc.off_nodes + kNodeDwords);
     sc.n_lds_nodes = std::min<uint32_t>(sc.n_nodes, (budget_dwords - sc.off_nodes) / kNodeDwords);
     if (!prefix_ok && sc.n_lds_nodes < sc.n_nodes) sc.n_lds_nodes = 0;
     sc.lds_dwords = sc.off_nodes + sc.n_lds_nodes * kNodeDwords;
     sc.stack_depth = std::max(1u, max_leaf_depth);
+    sc.stack_lds = sc.stack_depth;
 }
 
 // analytic primitives and materials into the blob (the fat nodes are written by the caller, the triangle records on the
