@@ -30,7 +30,8 @@ def make(config):
     else:
         raise SystemExit(f"unknown config {config}")
     lds = scene.view.n_bvh <= 255          # every Cornell-only scene fits LDS; mesh scenes read nodes through L2
-    kernel = f"k_render<{'true' if lds else 'false'}, false, {integ}"
+    # production kernels: one-wavefront workgroups on an LDS-resident tree, persistent workgroups on a tree read from memory
+    kernel = f"k_render<true, false, {integ}" if lds else f"k_render_pwg<{integ}, false>"
     return {"scene": scene, "integrator": integ, "spp": spp, "kernel": kernel, "density": density, "what": what}
 
 

@@ -36,52 +36,27 @@ __global__ void __launch_bounds__(256) k_seed(uint32_t* rng, uint32_t n_pixels, 
     reinterpret_cast<uint4*>(rng)[p] = out;
 }
 
-// kernelPathTracing, Render.metal:495-558.  One lane per pixel, one one-wavefront workgroup per 8x8 pixel block
-// (DESIGN.md 4.1), all `spp` samples fused: RNG texel and accumulator are read and
-// written ONCE per pixel instead of once per sample (64 B/pixel/sample in the reference).
-// wavefronts per SIMD the register allocation aims at (launch bounds), each measured (profiles/r02/
-// compiler_flags_and_occupancy.txt, lds_plan_and_stack.txt): tracePath on an LDS-resident tree fits 96 VGPRs with 2
-// spilled dwords (5 waves: 21.5 -> 20.8 ms on config 2; 6 waves / 80 VGPRs: 21.3-21.6); on a tree read from memory the
-// sixth wave hides more latency than its spills cost (1 M triangles: 32.8 -> 31.8 ms; 7 waves: 33.4) -- provided LDS
-// lets it in (plan_launch_lds); traceMIS needs 128 (5 waves: 63.2 -> 63.7 ms on config 3), traceVolume 128 (5: 55 -> 84 ms)
-#ifndef TRC_PATH_WAVES
-#define TRC_PATH_WAVES 5
-#endif
-#ifndef TRC_PATH_WAVES_GLOBAL
-#define TRC_PATH_WAVES_GLOBAL 6
-#endif
-#ifndef TRC_MIS_WAVES
-#define TRC_MIS_WAVES 4
-#endif
-#ifndef TRC_VOLUME_WAVES
-#define TRC_VOLUME_WAVES 4
-#endif
-template <bool LDS, bool STATS, int INTEGRATOR, bool SOBOL = false>
-__global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRATOR_VOLUME ? TRC_VOLUME_WAVES : (INTEGRATOR == TRC_INTEGRATOR_MIS ? TRC_MIS_WAVES : (LDS ? TRC_PATH_WAVES : TRC_PATH_WAVES_GLOBAL)))) k_render(const KRender kp) {
-    const DScene& sc = kp.ks.sc;
-    const uint32_t* small_base = stage_scene(sc);
-    uint32_t* stack = lane_stack(sc);
-    uint32_t* lvstack = lane_lvstack(sc);
-
+// One pixel block (8x8 pixels on 64 lanes, or 4x4 on 16) of kernelPathTracing: all `spp` samples of every pixel, RNG texel
+// and accumulator read and written once.  `slot` = position of the block in the launch order; `stack` / `lvstack` / `ovf` =
+// this lane's columns of the wavefront's traversal stack.  Shared by k_render (one block per one-wavefront workgroup) and
+// k_render_pwg (wavefronts of a persistent workgroup pulling blocks from a queue).
+template <bool LDS, bool STATS, int INTEGRATOR, bool SOBOL, bool HYB>
+__device__ __forceinline__ void render_block(const KRender& kp, const DScene& sc, const uint32_t* small_base, uint32_t* stack, uint32_t* lvstack,
+                                             uint32_t* ovf, const uint32_t slot, const uint32_t lane,
+                                             uint32_t& n_rays, uint32_t& n_shaded, uint32_t& n_paths, TravCounters& cnt) {
     const uint64_t t_start = clock64();          // this wavefront's own duration = the next launch's sort key
-    const uint32_t canon = kp.order ? kp.order[blockIdx.x] : blockIdx.x;     // adaptive launch order (trc_render)
+    const uint32_t canon = kp.order ? kp.order[slot] : slot;     // adaptive launch order (trc_render)
     const uint32_t tile = kp.tiles[canon];                      // pixel block: x | y << 16 in units of the block edge
-    const uint32_t lane = threadIdx.x;
     const uint32_t bs = kp.blk_shift;                           // 3: 8x8 pixels, all 64 lanes; 2: 4x4 pixels, lanes 0..15
     const uint32_t px = ((tile & 0xFFFFu) << bs) + (lane & ((1u << bs) - 1u));
     const uint32_t py = ((tile >> 16) << bs) + (lane >> bs);
     const uint32_t W = kp.fr.width, H = kp.fr.height;
     const bool active = lane < (1u << (2u * bs)) && px < W && py < H;
 
-    uint32_t n_rays = 0, n_shaded = 0, n_paths = 0;
-    TravCounters cnt;
-    counters_zero(cnt);
-
     if (active) {
         PathCtx cx;
         cx.S = make_scene_ref(sc, small_base);
-        constexpr bool kHybridStack = !LDS && !STATS && INTEGRATOR == TRC_INTEGRATOR_PATH;     // plan_launch_lds
-        if (kHybridStack) cx.S.ovf = kp.stack_ovf + (size_t)blockIdx.x * (sc.stack_depth - sc.stack_lds) * kBlock + lane;
+        cx.S.ovf = ovf;
         cx.root_min = f3(kp.ks.root_box[0], kp.ks.root_box[1], kp.ks.root_box[2]);
         cx.root_max = f3(kp.ks.root_box[3], kp.ks.root_box[4], kp.ks.root_box[5]);
         cx.sh.mats = small_base + sc.off_materials;
@@ -152,7 +127,7 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
             ProfScope<STATS> loop_scope(cnt, kProfLoop);
             n_rays++;
             constexpr bool kVolume = INTEGRATOR == TRC_INTEGRATOR_VOLUME;
-            const bool hitted = scene_hit<LDS, STATS, false, false, kVolume, kHybridStack>(cx.S, cx.root_min, cx.root_max, ps.ray, ps.rec, FLT_MAX,
+            const bool hitted = scene_hit<LDS, STATS, false, false, kVolume, HYB>(cx.S, cx.root_min, cx.root_max, ps.ray, ps.rec, FLT_MAX,
                                                                         cx.stack, cx.lvstack, cnt);
             F3 color;
             const bool finished = (INTEGRATOR == TRC_INTEGRATOR_PATH)
@@ -165,10 +140,60 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
         reinterpret_cast<uint4*>(kp.fr.rng)[pix] = texel;
     }
 
+    if (lane == 0) kp.block_cost[canon] = (uint32_t)min((unsigned long long)((clock64() - t_start) >> 6), 0xFFFFFFull);
+}
+
+// kernelPathTracing, Render.metal:495-558.  One lane per pixel, one one-wavefront workgroup per 8x8 pixel block
+// (DESIGN.md 4.1), all `spp` samples fused: RNG texel and accumulator are read and
+// written ONCE per pixel instead of once per sample (64 B/pixel/sample in the reference).
+// wavefronts per SIMD the register allocation aims at (launch bounds), each measured (profiles/r02/
+// compiler_flags_and_occupancy.txt, lds_plan_and_stack.txt): tracePath on an LDS-resident tree fits 96 VGPRs with 2
+// spilled dwords (5 waves: 21.5 -> 20.8 ms on config 2; 6 waves / 80 VGPRs: 21.3-21.6); on a tree read from memory the
+// sixth wave hides more latency than its spills cost (1 M triangles: 32.8 -> 31.8 ms; 7 waves: 33.4) -- provided LDS
+// lets it in (plan_launch_lds); traceMIS needs 128 (5 waves: 63.2 -> 63.7 ms on config 3), traceVolume 128 (5: 55 -> 84 ms)
+#ifndef TRC_PATH_WAVES
+#define TRC_PATH_WAVES 5
+#endif
+#ifndef TRC_PATH_WAVES_GLOBAL
+#define TRC_PATH_WAVES_GLOBAL 6
+#endif
+#ifndef TRC_MIS_WAVES
+#define TRC_MIS_WAVES 4
+#endif
+#ifndef TRC_VOLUME_WAVES
+#define TRC_VOLUME_WAVES 4
+#endif
+// persistent workgroups (k_render_pwg): wavefronts per workgroup x workgroups per CU = the waves per CU above
+#ifndef TRC_PWG_WAVES_PATH
+#define TRC_PWG_WAVES_PATH 12
+#endif
+#ifndef TRC_PWG_PER_CU_PATH
+#define TRC_PWG_PER_CU_PATH 2
+#endif
+#ifndef TRC_PWG_WAVES_OTHER
+#define TRC_PWG_WAVES_OTHER 16
+#endif
+#ifndef TRC_PWG_PER_CU_OTHER
+#define TRC_PWG_PER_CU_OTHER 1
+#endif
+template <bool LDS, bool STATS, int INTEGRATOR, bool SOBOL = false>
+__global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRATOR_VOLUME ? TRC_VOLUME_WAVES : (INTEGRATOR == TRC_INTEGRATOR_MIS ? TRC_MIS_WAVES : (LDS ? TRC_PATH_WAVES : TRC_PATH_WAVES_GLOBAL)))) k_render(const KRender kp) {
+    const DScene& sc = kp.ks.sc;
+    const uint32_t* small_base = stage_scene(sc);
+    uint32_t* stack = lane_stack(sc);
+    uint32_t* lvstack = lane_lvstack(sc);
+
+    const uint32_t lane = threadIdx.x;
+    uint32_t n_rays = 0, n_shaded = 0, n_paths = 0;
+    TravCounters cnt;
+    counters_zero(cnt);
+    constexpr bool kHybridStack = !LDS && !STATS && INTEGRATOR == TRC_INTEGRATOR_PATH;     // plan_launch_lds
+    uint32_t* ovf = kHybridStack ? kp.stack_ovf + (size_t)blockIdx.x * (sc.stack_depth - sc.stack_lds) * kBlock + lane : nullptr;
+    render_block<LDS, STATS, INTEGRATOR, SOBOL, kHybridStack>(kp, sc, small_base, stack, lvstack, ovf, blockIdx.x, lane, n_rays, n_shaded, n_paths, cnt);
+
     // exact work counters: wave reduction, one 64-bit atomic per wave and counter
     uint32_t r_paths = wave_sum(n_paths), r_rays = wave_sum(n_rays), r_shaded = wave_sum(n_shaded);
     if (lane == 0) {
-        kp.block_cost[canon] = (uint32_t)min((unsigned long long)((clock64() - t_start) >> 6), 0xFFFFFFull);
         atomicAdd(&kp.stats[kStatPaths], (unsigned long long)r_paths);
         atomicAdd(&kp.stats[kStatRays], (unsigned long long)r_rays);
         atomicAdd(&kp.stats[kStatShaded], (unsigned long long)r_shaded);
@@ -194,6 +219,49 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
                 atomicAdd(&kp.stats[kStatCount + 3 * i + 2], rc);
             }
         }
+    }
+}
+
+// kernelPathTracing on a tree that is READ FROM MEMORY (mesh scenes), production launches of >= 8 spp: persistent
+// workgroups.  With one wavefront per workgroup every wavefront stages its own copy of the top of the tree, and 16-24 copies
+// per CU leave room for ~45 nodes (5 levels) each.  Here a workgroup is as many wavefronts as one (tracePath: half a) CU
+// holds, they stage ONE prefix -- 30-60 KB, the top 9-10 levels -- and then every wavefront on its own pulls pixel
+// blocks from a device-wide queue in the launch order (longest first) until it is empty, so no wavefront slot waits
+// for a sibling (what cost the 4-wavefront workgroups of DESIGN section 9 their 20 %).  Same blocks, same arithmetic per
+// lane.  Measured (profiles/r02/persistent_workgroups.txt): 2.4-3 % on configs 3 / 4 and the traceVolume scene -- most
+// of a mesh ray's steps are deep in the tree, below any prefix.  Workgroup shapes: tracePath 12 wavefronts x 2 per CU (10
+// x 2 leaves the SIMDs 3+3+2+2 and only one workgroup fits: 48 ms; 8 x 3: 36.8 against 31.1), the others 16 x 1 (8 x 2: +0.5 %).
+constexpr int pwg_waves(int integrator) { return integrator == TRC_INTEGRATOR_PATH ? TRC_PWG_WAVES_PATH : TRC_PWG_WAVES_OTHER; }
+constexpr int pwg_per_cu(int integrator) { return integrator == TRC_INTEGRATOR_PATH ? TRC_PWG_PER_CU_PATH : TRC_PWG_PER_CU_OTHER; }
+template <int INTEGRATOR, bool SOBOL>
+__global__ void __launch_bounds__(64 * pwg_waves(INTEGRATOR), pwg_waves(INTEGRATOR) * pwg_per_cu(INTEGRATOR) / 4) k_render_pwg(const KRender kp) {
+    const DScene& sc = kp.ks.sc;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(sc.blob);
+        uint4* dst = reinterpret_cast<uint4*>(trc_smem);
+        const uint32_t n16 = sc.lds_dwords >> 2;
+        for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+    }
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    constexpr bool kHybridStack = INTEGRATOR == TRC_INTEGRATOR_PATH;
+    uint32_t* stack = trc_smem + sc.lds_dwords + wave * sc.stack_lds * kBlock + lane;
+    uint32_t* ovf = kHybridStack ? kp.stack_ovf + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * (sc.stack_depth - sc.stack_lds) * kBlock + lane : nullptr;
+    uint32_t n_rays = 0, n_shaded = 0, n_paths = 0;
+    TravCounters cnt;
+    counters_zero(cnt);
+    for (;;) {
+        uint32_t slot = 0;
+        if (lane == 0) slot = atomicAdd(kp.queue, 1u);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if (slot >= kp.n_tiles) break;
+        render_block<false, false, INTEGRATOR, SOBOL, kHybridStack>(kp, sc, trc_smem, stack, nullptr, ovf, slot, lane, n_rays, n_shaded, n_paths, cnt);
+    }
+    uint32_t r_paths = wave_sum(n_paths), r_rays = wave_sum(n_rays), r_shaded = wave_sum(n_shaded);
+    if (lane == 0) {
+        atomicAdd(&kp.stats[kStatPaths], (unsigned long long)r_paths);
+        atomicAdd(&kp.stats[kStatRays], (unsigned long long)r_rays);
+        atomicAdd(&kp.stats[kStatShaded], (unsigned long long)r_shaded);
     }
 }
 
@@ -648,6 +716,23 @@ static void plan_launch_lds(const trc_ctx* ctx, DScene& sc, uint32_t waves_per_s
     sc.lds_dwords = sc.off_nodes + sc.n_lds_nodes * kNodeDwords;
 }
 
+// LDS plan of a persistent-workgroup launch (k_render_pwg): `waves` wavefronts share one staged prefix; the workgroup's
+// share of the CU's 160 KB minus the wavefronts' stacks is all node prefix.  False when even one node does not fit.
+constexpr uint32_t kPwgStackLdsLevels = 16;      // 4 / 8 / 16 entries per lane in LDS: 33.5 / 31.1 / 30.8 ms on the 1 M-triangle scene
+static bool plan_pwg_lds(DScene& sc, uint32_t waves, uint32_t per_cu, bool hybrid) {
+    static const char* lv = std::getenv("TRC_STACK_LDS_LEVELS");
+    const uint32_t levels = lv && std::atoi(lv) > 0 ? (uint32_t)std::atoi(lv) : kPwgStackLdsLevels;
+    DScene t = sc;
+    if (hybrid) t.stack_lds = std::min(t.stack_depth, levels);
+    const uint32_t per_wg = ((160u * 1024u / 4u) / per_cu) & ~127u;
+    const uint32_t stacks = waves * t.stack_lds * kBlock;
+    if (per_wg < stacks + t.off_nodes + kNodeDwords) return false;
+    t.n_lds_nodes = std::min(t.n_nodes, (per_wg - stacks - t.off_nodes) / kNodeDwords);
+    t.lds_dwords = t.off_nodes + t.n_lds_nodes * kNodeDwords;
+    sc = t;
+    return true;
+}
+
 trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32_t view_height, uint32_t blk_shift) {
     if (ctx->d_tiles && ctx->d_block_cost && ctx->tiles_nranks == nranks && ctx->tiles_rank == rank &&
         ctx->tiles_view_height == view_height && ctx->tiles_blk_shift == blk_shift) return TRC_OK;
@@ -728,6 +813,26 @@ void launch_render(trc_ctx* ctx, const KRender& kp, bool stats, uint32_t integra
     }
 }
 
+// persistent workgroups (k_render_pwg): grid = workgroups the GPU holds at once, block = the workgroup's wavefronts
+template <int INTEGRATOR, bool SOBOL>
+hipError_t launch_pwg_one(trc_ctx* ctx, const KRender& kp, uint32_t grid, size_t lds) {
+    static size_t granted = 0;                 // more than 64 KB of dynamic LDS has to be asked for once per kernel
+    if (lds > granted) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_pwg<INTEGRATOR, SOBOL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        if (e != hipSuccess) return e;
+        granted = 160 * 1024;
+    }
+    hipLaunchKernelGGL((k_render_pwg<INTEGRATOR, SOBOL>), dim3(grid), dim3(64 * pwg_waves(INTEGRATOR)), lds, ctx->stream, kp);
+    return hipSuccess;
+}
+hipError_t launch_render_pwg(trc_ctx* ctx, const KRender& kp, uint32_t integrator, uint32_t grid, size_t lds) {
+    if (kp.sobol32) return integrator == TRC_INTEGRATOR_MIS ? launch_pwg_one<TRC_INTEGRATOR_MIS, true>(ctx, kp, grid, lds)
+                                                            : launch_pwg_one<TRC_INTEGRATOR_PATH, true>(ctx, kp, grid, lds);
+    if (integrator == TRC_INTEGRATOR_VOLUME) return launch_pwg_one<TRC_INTEGRATOR_VOLUME, false>(ctx, kp, grid, lds);
+    if (integrator == TRC_INTEGRATOR_MIS) return launch_pwg_one<TRC_INTEGRATOR_MIS, false>(ctx, kp, grid, lds);
+    return launch_pwg_one<TRC_INTEGRATOR_PATH, false>(ctx, kp, grid, lds);
+}
+
 }  // namespace
 
 // ======================================================================= C ABI
@@ -796,7 +901,7 @@ void trc_destroy(trc_ctx* ctx) {
     (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_stats); (void)hipFree(ctx->d_reduce_recv);
     (void)hipFree(ctx->d_block_cost); (void)hipFree(ctx->d_order_hist);
     for (int k = 0; k < 2; ++k) { (void)hipFree(ctx->d_order_keys[k]); (void)hipFree(ctx->d_order_vals[k]); }
-    (void)hipFree(ctx->d_accum_alt); (void)hipFree(ctx->d_stack_ovf);
+    (void)hipFree(ctx->d_accum_alt); (void)hipFree(ctx->d_stack_ovf); (void)hipFree(ctx->d_queue);
     for (hipEvent_t e : {ctx->ev_rendered, ctx->ev_busy, ctx->ev_busy_alt}) if (e) (void)hipEventDestroy(e);
     if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1086,13 +1191,25 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
         kp.sobol_m = m;
     }
 
+    bool pwg = false;
+    uint32_t pwg_waves_n = 0, pwg_grid = 0;
     if (!stats && !ctx->lds_scene) {
         const bool strip = kp.strip > 1;
-        const uint32_t waves = p->integrator == TRC_INTEGRATOR_PATH ? (strip ? TRC_STRIP_PATH_WAVES : TRC_PATH_WAVES_GLOBAL)
-                             : p->integrator == TRC_INTEGRATOR_MIS ? (strip ? 4 : TRC_MIS_WAVES) : (strip ? 3 : TRC_VOLUME_WAVES);
-        plan_launch_lds(ctx, kp.ks.sc, waves, p->integrator == TRC_INTEGRATOR_PATH);
+        const bool is_path = p->integrator == TRC_INTEGRATOR_PATH;
+        static const bool no_pwg = std::getenv("TRC_NO_PWG") != nullptr;                // A/B knob
+        if (!no_pwg && !strip && ctx->lds_prefix_ok) {
+            pwg_waves_n = (uint32_t)pwg_waves((int)p->integrator);
+            const uint32_t per_cu = (uint32_t)pwg_per_cu((int)p->integrator);
+            pwg = plan_pwg_lds(kp.ks.sc, pwg_waves_n, per_cu, is_path);
+            pwg_grid = (uint32_t)ctx->cu_count * per_cu;
+        }
+        if (!pwg) {
+            const uint32_t waves = is_path ? (strip ? TRC_STRIP_PATH_WAVES : TRC_PATH_WAVES_GLOBAL)
+                                 : p->integrator == TRC_INTEGRATOR_MIS ? (strip ? 4 : TRC_MIS_WAVES) : (strip ? 3 : TRC_VOLUME_WAVES);
+            plan_launch_lds(ctx, kp.ks.sc, waves, is_path);
+        }
         const size_t rows = kp.ks.sc.stack_depth - kp.ks.sc.stack_lds;
-        const size_t need = rows * kBlock * sizeof(uint32_t) * ctx->n_tiles;           // one set of rows per workgroup
+        const size_t need = rows * kBlock * sizeof(uint32_t) * (pwg ? (size_t)pwg_grid * pwg_waves_n : (size_t)ctx->n_tiles);   // rows per wavefront
         if (need > ctx->stack_ovf_bytes) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             if (ctx->d_stack_ovf) { (void)hipFree(ctx->d_stack_ovf); ctx->d_stack_ovf = nullptr; }
@@ -1102,7 +1219,12 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
         }
         kp.stack_ovf = ctx->d_stack_ovf;
     }
-    const size_t lds = dyn_lds_bytes(kp.ks.sc, stats);
+    const size_t lds = pwg ? ((size_t)kp.ks.sc.lds_dwords + (size_t)pwg_waves_n * kp.ks.sc.stack_lds * kBlock) * 4 : dyn_lds_bytes(kp.ks.sc, stats);
+    if (pwg) {
+        if (!ctx->d_queue && hipMalloc((void**)&ctx->d_queue, sizeof(uint32_t)) != hipSuccess) return fail(ctx, TRC_ERR_OOM, "hipMalloc block queue");
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(uint32_t), ctx->stream));
+        kp.queue = ctx->d_queue;
+    }
 
     collect_finished_events(ctx);
     hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);
@@ -1110,9 +1232,10 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
     if (!e0 || !e1) { give_back(); return fail(ctx, TRC_ERR_HIP, "hipEventCreate failed"); }
     hipError_t le = hipEventRecord(e0, ctx->stream);
     if (le == hipSuccess) {
-        if (ctx->lds_scene) launch_render<true>(ctx, kp, stats, p->integrator, lds);
+        if (pwg) le = launch_render_pwg(ctx, kp, p->integrator, pwg_grid, lds);
+        else if (ctx->lds_scene) launch_render<true>(ctx, kp, stats, p->integrator, lds);
         else launch_render<false>(ctx, kp, stats, p->integrator, lds);
-        le = hipGetLastError();
+        if (le == hipSuccess) le = hipGetLastError();
     }
     if (le == hipSuccess) le = hipEventRecord(e1, ctx->stream);
     if (le != hipSuccess) { give_back(); return fail(ctx, TRC_ERR_HIP, std::string("k_render launch: ") + hipGetErrorString(le)); }

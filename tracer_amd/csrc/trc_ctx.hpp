@@ -34,7 +34,8 @@ struct KRender {
     trc_GridDensityInfo dinfo;
     const uint8_t* occupancy;           // ... and its 4x4x4-brick occupancy (dev_integrator.hpp::grid_sample)
     unsigned long long* stats;          // kStatCount counters
-    uint32_t* stack_ovf;                // (stack_depth - stack_lds) rows of 64 entries per workgroup (null: the stack is all LDS)
+    uint32_t* stack_ovf;                // (stack_depth - stack_lds) rows of 64 entries per wavefront (null: the stack is all LDS)
+    uint32_t* queue;                    // k_render_pwg: next position of the launch order to hand out
     uint32_t blk_shift;                 // log2 of the pixel-block edge of one wavefront: 3 (8x8, 64 lanes) or 2 (4x4, 16 lanes)
     uint32_t n_tiles, strip;            // k_render_strip: blocks in `tiles`, consecutive blocks per wavefront (1: k_render)
     const uint32_t* order;              // launch order: order[blockIdx.x] = index into `tiles` (null: identity)
@@ -104,6 +105,7 @@ struct trc_ctx {
     bool lds_prefix_ok = false;         // the fat nodes are in top-of-tree-first order: any prefix may be staged
     uint32_t* d_stack_ovf = nullptr;    // traversal-stack overflow rows of the render launches (deep trees only)
     size_t stack_ovf_bytes = 0;
+    uint32_t* d_queue = nullptr;        // block queue head of the persistent-workgroup launches
     trc_BVH* d_bvh_ref = nullptr;    // tree built by trc_upload_scene_lbvh, reference array layout (trc_download_bvh)
     uint32_t n_bvh_ref = 0, lbvh_height = 0;
     float lbvh_build_ms = 0.0f;
