@@ -29,6 +29,20 @@ struct DComplex {           // device-side Complex (Camera.hh:27-55) + the bound
     uint32_t key_min[3], key_max[3];
 };
 
+// The visible points (CameraRecord, Photon.hh:30-53: 112-byte records in the reference) as planes, one float4 / uint per
+// pixel: a wavefront's access to one field is 8 rows x 128 contiguous bytes instead of 64 x 12 bytes scattered over 7 KB,
+// and a pass touches only the planes it changes -- the camera pass reads none (a field keeps its value by not being
+// stored), the refine reads three or one and rewrites flux | radius and the count.  trc_sppm_download packs them back
+// into the reference's records.
+struct VisiblePoints {
+    float4* ratio_valid;     // ratio.xyz | valid (bits of a uint: 0 / 1)
+    float4* position;
+    float4* direction;
+    float4* alternative;
+    float4* flux_radius;     // flux.xyz | radius
+    uint32_t* count;         // photonCount
+};
+
 struct KSppm {
     KScene ks;
     DCamera cam;
@@ -39,7 +53,7 @@ struct KSppm {
     uint32_t* canvas_rng;
     float* accum;
     uint32_t* photon_rng;
-    trc_CameraRecord* cam_rec;
+    VisiblePoints vp;
     trc_PhotonRecord* pho_rec;
     uint32_t* mark;          // winning photon index + 1 per cell, 0 = empty
     uint32_t* count;
@@ -149,17 +163,12 @@ __global__ void __launch_bounds__(kBlock, TRC_SPPM_CAMERA_WAVES) k_sppm_camera(c
     const float u = (float)px / (float)kp.W, v = (float)py / (float)kp.H;
     Ray ray = cast_ray(kp.cam, u, v, rng);
 
-    trc_CameraRecord& slot = kp.cam_rec[pix];
-    F3 cr_ratio = ld3(slot.ratio), cr_position = ld3(slot.position), cr_direction = ld3(slot.direction);
-    F3 cr_alternative = ld3(slot.alternative), cr_flux = ld3(slot.flux);
-    float cr_radius = slot.radius;
-    uint32_t cr_count = slot.photonCount;
-    int depth = 8;
-    if (kp.frame_count == 0) {      // cr.reset(), Photon.hh:42-52 (alternative is NOT reset)
-        cr_ratio = f3(1); cr_position = f3(0); cr_direction = f3(0); cr_flux = f3(0); cr_radius = 0; cr_count = 0;
-        depth = 3;
-    }
-    bool valid = false;
+    // cr.reset() on the first frame (Photon.hh:42-52; `alternative` is NOT reset); a field of the record the pass does not
+    // assign keeps its value: it is simply not stored
+    const bool first = kp.frame_count == 0;
+    int depth = first ? 3 : 8;
+    bool valid = false, alt_set = false;
+    F3 cr_ratio = f3(1), cr_position = f3(0), cr_direction = f3(0), cr_alternative = f3(0);
     {
         HitRec rec;
         hit_init(rec);
@@ -167,12 +176,12 @@ __global__ void __launch_bounds__(kBlock, TRC_SPPM_CAMERA_WAVES) k_sppm_camera(c
         bool hitted = sppm_hit<ALL_LDS>(cx, ray, rec, n_rays);
         bool finished = false;
         do {
-            if (!hitted) { cr_alternative = ratio * env_radiance(cx.env, cx.ambient, ray.d); finished = true; break; }
+            if (!hitted) { cr_alternative = ratio * env_radiance(cx.env, cx.ambient, ray.d); alt_set = true; finished = true; break; }
             const int mtype = mat_type(cx.sh, rec.material);
             if (mtype == kMatDiffuse) {
                 F3 le = mat_albedo(cx.sh, rec.material);
                 float w = dot(-ray.d, -rec.gn);
-                cr_alternative = ratio * le * fabsf(w);
+                cr_alternative = ratio * le * fabsf(w); alt_set = true;
                 finished = true; break;
             }
             if (!mat_specular(cx.sh, rec.material)) {
@@ -194,12 +203,17 @@ __global__ void __launch_bounds__(kBlock, TRC_SPPM_CAMERA_WAVES) k_sppm_camera(c
             if (is_inf(ratio.x) || is_inf(ratio.y) || is_inf(ratio.z) || is_nan(ratio.x) || is_nan(ratio.y) || is_nan(ratio.z)) ratio = f3(1.0f);
             hitted = sppm_hit<ALL_LDS>(cx, ray, rec, n_rays);
         } while ((--depth) > 0);
-        if (!finished) cr_alternative = f3(0);
+        if (!finished) { cr_alternative = f3(0); alt_set = true; }
     }
-    st3(slot.ratio, cr_ratio); st3(slot.position, cr_position); st3(slot.direction, cr_direction);
-    slot.valid = valid ? 1 : 0;
-    st3(slot.alternative, cr_alternative); st3(slot.flux, cr_flux);
-    slot.radius = cr_radius; slot.photonCount = cr_count;
+    if (valid || first) {
+        kp.vp.ratio_valid[pix] = make_float4(cr_ratio.x, cr_ratio.y, cr_ratio.z, __uint_as_float(valid ? 1u : 0u));
+        kp.vp.position[pix] = make_float4(cr_position.x, cr_position.y, cr_position.z, 0.0f);
+        kp.vp.direction[pix] = make_float4(cr_direction.x, cr_direction.y, cr_direction.z, 0.0f);
+    } else {
+        kp.vp.ratio_valid[pix].w = __uint_as_float(0u);
+    }
+    if (alt_set) kp.vp.alternative[pix] = make_float4(cr_alternative.x, cr_alternative.y, cr_alternative.z, 0.0f);
+    if (first) { kp.vp.flux_radius[pix] = make_float4(0, 0, 0, 0); kp.vp.count[pix] = 0u; }
     reinterpret_cast<uint4*>(kp.canvas_rng)[pix] = ex_rng(rng);
 
     if (kp.frame_count == 0 && valid) {         // cameraAABB + kernelCameraReducing: exact min/max of the valid positions
@@ -230,9 +244,9 @@ __global__ void k_sppm_params(DComplex* x) {
 }
 
 // kernelPhotonRadius, Photon.metal:374-384
-__global__ void __launch_bounds__(256) k_sppm_radius(trc_CameraRecord* cam_rec, uint32_t n, const DComplex* cx) {
+__global__ void __launch_bounds__(256) k_sppm_radius(float4* flux_radius, uint32_t n, const DComplex* cx) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) cam_rec[i].radius = cx->initial_radius;
+    if (i < n) flux_radius[i].w = cx->initial_radius;
 }
 
 // kernelPhotonRecording, Photon.metal:286-355 + tracePhotonRecord :220-285
@@ -375,21 +389,23 @@ __global__ void __launch_bounds__(kBlock, TRC_SPPM_REFINE_WAVES) k_sppm_refine(c
     const uint32_t qy = (tile >> 16) * 8u + (lane >> 3);
     if (qx >= kp.W || qy >= kp.H) return;
     const uint32_t pixel = qy * kp.W + qx;
-    trc_CameraRecord& vp = kp.cam_rec[pixel];                            // the pixel's visible point
+    const float4 rv = kp.vp.ratio_valid[pixel];                          // the pixel's visible point
     float4* px = reinterpret_cast<float4*>(kp.accum) + pixel;
     const float4 shown = *px;
     const F3 mean = f3(shown.x, shown.y, shown.z);
     const float frame = (float)kp.frame_count, frame1 = (float)(kp.frame_count + 1);
-    if (!vp.valid) {                                                     // nothing diffuse was seen: the stored radiance
-        const F3 result = (mean * frame + ld3(vp.alternative)) / frame1;
+    if (__float_as_uint(rv.w) == 0u) {                                   // nothing diffuse was seen: the stored radiance
+        const float4 alt = kp.vp.alternative[pixel];
+        const F3 result = (mean * frame + f3(alt.x, alt.y, alt.z)) / frame1;
         *px = make_float4(result.x, result.y, result.z, 1.0f);
         return;
     }
     const DComplex& cx = *kp.cx;
-    const F3 at = ld3(vp.position), facing = ld3(vp.direction), reflectance = ld3(vp.ratio);
-    F3 flux = ld3(vp.flux);
-    float radius = vp.radius;
-    uint32_t n_photons = vp.photonCount;
+    const float4 vpos = kp.vp.position[pixel], vdir = kp.vp.direction[pixel], fr = kp.vp.flux_radius[pixel];
+    const F3 at = f3(vpos.x, vpos.y, vpos.z), facing = f3(vdir.x, vdir.y, vdir.z), reflectance = f3(rv.x, rv.y, rv.z);
+    F3 flux = f3(fr.x, fr.y, fr.z);
+    float radius = fr.w;
+    uint32_t n_photons = kp.vp.count[pixel];
     const F3 box_min = f3(cx.box_min[0], cx.box_min[1], cx.box_min[2]);
     const float scale = cx.hash_scale, fN = (float)kHashN;
     // cells touched by the query sphere's box, as the reference derives them (abs() included, :533-536)
@@ -441,15 +457,32 @@ __global__ void __launch_bounds__(kBlock, TRC_SPPM_REFINE_WAVES) k_sppm_refine(c
     radius = radius * sqrtf(g);
     n_photons = (uint32_t)((float)n_photons + (float)gathered_n * alpha);
     flux = (flux + gathered) * g;
-    st3(vp.flux, flux);
-    vp.radius = radius;
-    vp.photonCount = n_photons;
+    kp.vp.flux_radius[pixel] = make_float4(flux.x, flux.y, flux.z, radius);
+    kp.vp.count[pixel] = n_photons;
     float emitted = cx.total_photon_sum;
     emitted += (float)cx.frame_photon_sum;
     const F3 radiance = flux / (radius * radius * 3.141592f * emitted);
     F3 result = (mean * frame + radiance) / frame1;
     if (is_nan(result.x) || is_nan(result.y) || is_nan(result.z)) result = f3(0);
     *px = make_float4(result.x, result.y, result.z, 1.0f);
+}
+
+// the planes back into the reference's 112-byte records (trc_sppm_download)
+__global__ void __launch_bounds__(256) k_sppm_pack_records(const VisiblePoints vp, trc_CameraRecord* out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 rv = vp.ratio_valid[i], po = vp.position[i], di = vp.direction[i], al = vp.alternative[i], fr = vp.flux_radius[i];
+    trc_CameraRecord r;
+    memset(&r, 0, sizeof r);
+    r.ratio.x = rv.x; r.ratio.y = rv.y; r.ratio.z = rv.z;
+    r.position.x = po.x; r.position.y = po.y; r.position.z = po.z;
+    r.direction.x = di.x; r.direction.y = di.y; r.direction.z = di.z;
+    r.valid = __float_as_uint(rv.w) ? 1 : 0;
+    r.alternative.x = al.x; r.alternative.y = al.y; r.alternative.z = al.z;
+    r.flux.x = fr.x; r.flux.y = fr.y; r.flux.z = fr.z;
+    r.radius = fr.w;
+    r.photonCount = vp.count[i];
+    out[i] = r;
 }
 
 // completion handler, AAPLRenderer.mm:1031-1036
@@ -464,7 +497,8 @@ __global__ void k_sppm_end_frame(DComplex* x) {
 struct SppmState {
     uint32_t W = 0, H = 0, frame_count = 0;
     uint32_t* d_photon_rng = nullptr;
-    trc_CameraRecord* d_cam = nullptr;
+    void* d_vp = nullptr;            // the visible-point planes, one allocation
+    VisiblePoints vp{};
     trc_PhotonRecord* d_pho = nullptr;
     uint32_t* d_mark = nullptr;
     uint32_t* d_count = nullptr;
@@ -476,7 +510,7 @@ void trc_sppm_release(trc_ctx* ctx) {
     if (!ctx || !ctx->sppm) return;
     SppmState* s = ctx->sppm;
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(s->d_photon_rng); (void)hipFree(s->d_cam); (void)hipFree(s->d_pho);
+    (void)hipFree(s->d_photon_rng); (void)hipFree(s->d_vp); (void)hipFree(s->d_pho);
     (void)hipFree(s->d_mark); (void)hipFree(s->d_count); (void)hipFree(s->d_cells); (void)hipFree(s->d_cx);
     delete s;
     ctx->sppm = nullptr;
@@ -504,13 +538,19 @@ trc_status trc_sppm_init(trc_ctx* ctx, uint64_t photon_seed) {
     s->W = ctx->width; s->H = ctx->height;
     const size_t np = (size_t)s->W * s->H, nph = (size_t)kHashN * kHashN;
     HIP_TRY(ctx, hipMalloc((void**)&s->d_photon_rng, nph * 16));
-    HIP_TRY(ctx, hipMalloc((void**)&s->d_cam, np * sizeof(trc_CameraRecord)));
+    const size_t vp_bytes = np * (5 * sizeof(float4) + sizeof(uint32_t));
+    HIP_TRY(ctx, hipMalloc(&s->d_vp, vp_bytes));
+    {
+        float4* q = static_cast<float4*>(s->d_vp);
+        s->vp.ratio_valid = q; s->vp.position = q + np; s->vp.direction = q + 2 * np; s->vp.alternative = q + 3 * np;
+        s->vp.flux_radius = q + 4 * np; s->vp.count = reinterpret_cast<uint32_t*>(q + 5 * np);
+    }
     HIP_TRY(ctx, hipMalloc((void**)&s->d_pho, nph * sizeof(trc_PhotonRecord)));
     HIP_TRY(ctx, hipMalloc((void**)&s->d_mark, nph * 4));
     HIP_TRY(ctx, hipMalloc((void**)&s->d_count, nph * 4));
     HIP_TRY(ctx, hipMalloc((void**)&s->d_cells, (nph + 1) * 3 * sizeof(float4)));
     HIP_TRY(ctx, hipMalloc((void**)&s->d_cx, sizeof(DComplex)));
-    HIP_TRY(ctx, hipMemsetAsync(s->d_cam, 0, np * sizeof(trc_CameraRecord), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(s->d_vp, 0, vp_bytes, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(s->d_pho, 0, nph * sizeof(trc_PhotonRecord), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(s->d_mark, 0, nph * 4, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(s->d_count, 0, nph * 4, ctx->stream));
@@ -554,7 +594,7 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
     kp.photon_first = rank * chunk;
     kp.tiles = ctx->d_tiles;
     kp.canvas_rng = ctx->d_rng; kp.accum = ctx->d_accum; kp.photon_rng = s->d_photon_rng;
-    kp.cam_rec = s->d_cam; kp.pho_rec = s->d_pho; kp.mark = s->d_mark; kp.count = s->d_count; kp.cells = s->d_cells; kp.cx = s->d_cx;
+    kp.vp = s->vp; kp.pho_rec = s->d_pho; kp.mark = s->d_mark; kp.count = s->d_count; kp.cells = s->d_cells; kp.cx = s->d_cx;
     kp.stats = ctx->d_stats;
     const size_t lds = trc_dyn_lds_bytes(ctx, false);
     const bool all_lds = ctx->lds_scene;
@@ -577,7 +617,7 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
                 if (rc) return rccl_fail("ncclAllReduce(max)", rc);
             }
             hipLaunchKernelGGL(k_sppm_params, dim3(1), dim3(64), 0, ctx->stream, s->d_cx);
-            hipLaunchKernelGGL(k_sppm_radius, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, s->d_cam, np, s->d_cx);
+            hipLaunchKernelGGL(k_sppm_radius, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, s->vp.flux_radius, np, s->d_cx);
         }
         if (s->frame_count % 2) camera_pass();          // photonWork re-runs the camera pass on odd frames, :953-955
         if (all_lds) hipLaunchKernelGGL((k_sppm_photon<true>), dim3(chunk / kBlock), dim3(kBlock), lds, ctx->stream, kp);
@@ -605,7 +645,15 @@ trc_status trc_sppm_download(trc_ctx* ctx, trc_CameraRecord* cam, trc_PhotonReco
     if (!s) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "trc_sppm_download before trc_sppm_init");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t np = (size_t)s->W * s->H, nph = (size_t)kHashN * kHashN;
-    if (cam) HIP_TRY(ctx, hipMemcpyAsync(cam, s->d_cam, np * sizeof(trc_CameraRecord), hipMemcpyDeviceToHost, ctx->stream));
+    trc_CameraRecord* d_packed = nullptr;
+    if (cam) {
+        HIP_TRY(ctx, hipMalloc((void**)&d_packed, np * sizeof(trc_CameraRecord)));
+        hipLaunchKernelGGL(k_sppm_pack_records, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, s->vp, d_packed, (uint32_t)np);
+        hipError_t ce = hipMemcpyAsync(cam, d_packed, np * sizeof(trc_CameraRecord), hipMemcpyDeviceToHost, ctx->stream);
+        if (ce == hipSuccess) ce = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_packed);
+        if (ce != hipSuccess) return trc_fail(ctx, TRC_ERR_HIP, std::string("trc_sppm_download: camera records: ") + hipGetErrorString(ce));
+    }
     if (pho) HIP_TRY(ctx, hipMemcpyAsync(pho, s->d_pho, nph * sizeof(trc_PhotonRecord), hipMemcpyDeviceToHost, ctx->stream));
     std::vector<uint32_t> hm, hc;
     if (mark) { hm.resize(nph); HIP_TRY(ctx, hipMemcpyAsync(hm.data(), s->d_mark, nph * 4, hipMemcpyDeviceToHost, ctx->stream)); }
