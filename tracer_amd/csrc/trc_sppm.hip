@@ -11,7 +11,7 @@
 //       atomicMax(photon index) for the mark (Metal resolves same-pixel writes in primitive order: the LAST
 //       point = highest index wins) and atomicAdd for the additively blended count
 //   kernelPhotonSumming     :458-496  -> k_sppm_table   (the frame's photon sum + the per-cell gather table)
-//   kernelPhotonRefine      :498-623  -> k_sppm_refine  (one 48-byte table read per hash cell, four cells in flight)
+//   kernelPhotonRefine      :498-623  -> k_sppm_refine  (one 16-byte table read per hash cell, four cells in flight; 32 more for a photon in range)
 // All launches go to the context stream in order; nothing synchronises with the host.
 #include "trc_ctx.hpp"
 
@@ -21,6 +21,7 @@
 namespace {
 
 constexpr uint32_t kHashN = TRC_PHOTON_HASHN;
+constexpr uint32_t kCellsB = kHashN * kHashN + 1u;      // gather table: float4 index of array B (after the kHashN^2 + 1 entries of A)
 
 struct DComplex {           // device-side Complex (Camera.hh:27-55) + the bound keys of the camera reduce
     float box_min[3], box_max[3], box_size[3];
@@ -57,7 +58,7 @@ struct KSppm {
     trc_PhotonRecord* pho_rec;
     uint32_t* mark;          // winning photon index + 1 per cell, 0 = empty
     uint32_t* count;
-    const float4* cells;     // gather table of k_sppm_table: 3 float4 per hash cell + one record for out-of-range reads
+    const float4* cells;     // gather table of k_sppm_table: array A (1 float4 per hash cell + 1 for out-of-range reads), then array B (2 each)
     DComplex* cx;
     unsigned long long* stats;   // ctx counters: rays += Scene::hit calls of the camera and photon passes
 };
@@ -343,9 +344,11 @@ __global__ void __launch_bounds__(256) k_sppm_hash(const trc_PhotonRecord* pho, 
 // The reference's refine reads, per hash cell a pixel looks at, the mark texture (which photon won the cell), the count
 // texture (how many fell into it) and then three fields of that photon's 80-byte record: four dependent gathers from
 // three arrays.  Which photon a cell shows and with what weight is the same for every pixel of the frame, so it is
-// resolved ONCE per cell here (262 144 cells, a streaming pass over the two grids the sum reads anyway) into one
-// 48-byte record per cell:   q0 = photon position, Correction (= count; -1: empty cell)
-//                            q1 = photon direction          q2 = photon flux
+// resolved ONCE per cell here (262 144 cells, a streaming pass over the two grids the sum reads anyway) into
+//    q0 = photon position, Correction (= count; -1: empty cell)     -- array A, 16 bytes per cell: what EVERY visited
+//                                                                      cell costs; 4.2 MB, i.e. about one XCD's L2
+//    q1 = photon direction, q2 = photon flux                         -- array B, 32 bytes per cell, read only for a
+//                                                                      photon that passed the distance test
 // Record 512*512 stands for the reference's out-of-range texture read (returns 0: photon (0,0), count 0,
 // Photon.metal:556-558).  (grid-stride: 128 workgroups, so the single counter sees 512 atomics per frame, not 4096)
 __global__ void __launch_bounds__(256) k_sppm_table(const uint32_t* mark, const uint32_t* count, const trc_PhotonRecord* pho,
@@ -362,7 +365,7 @@ __global__ void __launch_bounds__(256) k_sppm_table(const uint32_t* mark, const 
             q1 = make_float4(ph.direction.x, ph.direction.y, ph.direction.z, 0.0f);
             q2 = make_float4(ph.flux.x, ph.flux.y, ph.flux.z, 0.0f);
         }
-        cells[3u * i] = q0; cells[3u * i + 1u] = q1; cells[3u * i + 2u] = q2;
+        cells[i] = q0; cells[kCellsB + 2u * i] = q1; cells[kCellsB + 2u * i + 1u] = q2;
     }
     v = wave_sum(v);
     if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&cx->frame_photon_sum, v);
@@ -434,7 +437,7 @@ __global__ void __launch_bounds__(kBlock, TRC_SPPM_REFINE_WAVES) k_sppm_refine(c
         }
         float4 q0[kRefineChunk];
 #pragma unroll
-        for (int j = 0; j < kRefineChunk; ++j) q0[j] = use[j] ? kp.cells[3u * rec[j]] : make_float4(0, 0, 0, -1.0f);
+        for (int j = 0; j < kRefineChunk; ++j) q0[j] = use[j] ? kp.cells[rec[j]] : make_float4(0, 0, 0, -1.0f);
 #pragma unroll
         for (int j = 0; j < kRefineChunk; ++j) {
             const float weight = q0[j].w;                                // Correction; -1 marks an empty cell (:560)
@@ -444,9 +447,9 @@ __global__ void __launch_bounds__(kBlock, TRC_SPPM_REFINE_WAVES) k_sppm_refine(c
             if (!((cmin.x < p.x) && (p.x < cmax.x) && (cmin.y < p.y) && (p.y < cmax.y) && (cmin.z < p.z) && (p.z < cmax.z))) continue;
             const float d = length(p - at);
             if (!(d < radius)) continue;
-            const float4 q1 = kp.cells[3u * rec[j] + 1u];
+            const float4 q1 = kp.cells[kCellsB + 2u * rec[j]];
             if (!(-dot(facing, f3(q1.x, q1.y, q1.z)) > 0.001f)) continue;
-            const float4 q2 = kp.cells[3u * rec[j] + 2u];
+            const float4 q2 = kp.cells[kCellsB + 2u * rec[j] + 1u];
             gathered = gathered + f3(q2.x, q2.y, q2.z) * weight;
             gathered_n = (uint32_t)((float)gathered_n + weight);
         }
