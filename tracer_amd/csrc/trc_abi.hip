@@ -1201,7 +1201,7 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
             pwg_waves_n = (uint32_t)pwg_waves((int)p->integrator);
             const uint32_t per_cu = (uint32_t)pwg_per_cu((int)p->integrator);
             pwg = plan_pwg_lds(kp.ks.sc, pwg_waves_n, per_cu, is_path);
-            pwg_grid = (uint32_t)ctx->cu_count * per_cu;
+            pwg_grid = std::min((uint32_t)ctx->cu_count * per_cu, (ctx->n_tiles + pwg_waves_n - 1) / pwg_waves_n);   // small frames: no idle workgroups
         }
         if (!pwg) {
             const uint32_t waves = is_path ? (strip ? TRC_STRIP_PATH_WAVES : TRC_PATH_WAVES_GLOBAL)
