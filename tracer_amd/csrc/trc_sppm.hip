@@ -15,6 +15,7 @@
 // All launches go to the context stream in order; nothing synchronises with the host.
 #include "trc_ctx.hpp"
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -32,9 +33,10 @@ struct DComplex {           // device-side Complex (Camera.hh:27-55) + the bound
 
 // The visible points (CameraRecord, Photon.hh:30-53: 112-byte records in the reference) as planes, one float4 / uint per
 // pixel: a wavefront's access to one field is 8 rows x 128 contiguous bytes instead of 64 x 12 bytes scattered over 7 KB,
-// and a pass touches only the planes it changes -- the camera pass reads none (a field keeps its value by not being
-// stored), the refine reads three or one and rewrites flux | radius and the count.  trc_sppm_download packs them back
-// into the reference's records.
+// and a pass touches only the planes it needs -- the refine reads three or one and rewrites flux | radius and the count.
+// The four planes the camera pass writes exist TWICE: the pass of frame k + 1 reads copy A and writes copy B (a field it
+// does not assign is carried over) while the refine of frame k still reads A, so it can run beside frame k on its own
+// stream (trc_sppm_frames).  trc_sppm_download packs the current copy back into the reference's records.
 struct VisiblePoints {
     float4* ratio_valid;     // ratio.xyz | valid (bits of a uint: 0 / 1)
     float4* position;
@@ -54,7 +56,8 @@ struct KSppm {
     uint32_t* canvas_rng;
     float* accum;
     uint32_t* photon_rng;
-    VisiblePoints vp;
+    VisiblePoints vp;        // the visible points the pass writes (camera) / works on (refine)
+    VisiblePoints vp_prev;   // camera pass: the copy it takes unassigned fields from (== vp on the first frame)
     trc_PhotonRecord* pho_rec;
     uint32_t* mark;          // winning photon index + 1 per cell, 0 = empty
     uint32_t* count;
@@ -210,10 +213,14 @@ __global__ void __launch_bounds__(kBlock, TRC_SPPM_CAMERA_WAVES) k_sppm_camera(c
         kp.vp.ratio_valid[pix] = make_float4(cr_ratio.x, cr_ratio.y, cr_ratio.z, __uint_as_float(valid ? 1u : 0u));
         kp.vp.position[pix] = make_float4(cr_position.x, cr_position.y, cr_position.z, 0.0f);
         kp.vp.direction[pix] = make_float4(cr_direction.x, cr_direction.y, cr_direction.z, 0.0f);
-    } else {
-        kp.vp.ratio_valid[pix].w = __uint_as_float(0u);
+    } else {                                    // ratio, position, direction keep their values; valid = 0
+        float4 rv = kp.vp_prev.ratio_valid[pix];
+        rv.w = __uint_as_float(0u);
+        kp.vp.ratio_valid[pix] = rv;
+        kp.vp.position[pix] = kp.vp_prev.position[pix];
+        kp.vp.direction[pix] = kp.vp_prev.direction[pix];
     }
-    if (alt_set) kp.vp.alternative[pix] = make_float4(cr_alternative.x, cr_alternative.y, cr_alternative.z, 0.0f);
+    kp.vp.alternative[pix] = alt_set ? make_float4(cr_alternative.x, cr_alternative.y, cr_alternative.z, 0.0f) : kp.vp_prev.alternative[pix];
     if (first) { kp.vp.flux_radius[pix] = make_float4(0, 0, 0, 0); kp.vp.count[pix] = 0u; }
     reinterpret_cast<uint4*>(kp.canvas_rng)[pix] = ex_rng(rng);
 
@@ -501,7 +508,11 @@ struct SppmState {
     uint32_t W = 0, H = 0, frame_count = 0;
     uint32_t* d_photon_rng = nullptr;
     void* d_vp = nullptr;            // the visible-point planes, one allocation
-    VisiblePoints vp{};
+    VisiblePoints vp[2]{};           // [cur] = current values; the two share flux_radius and count
+    int cur = 0;
+    hipStream_t cam_stream = nullptr;    // the camera pass of the next odd frame runs here, beside the current frame
+    hipEvent_t ev_main = nullptr, ev_cam = nullptr;
+    uint32_t cam_ahead = 0;          // frame whose camera pass is already in flight on cam_stream (0 = none)
     trc_PhotonRecord* d_pho = nullptr;
     uint32_t* d_mark = nullptr;
     uint32_t* d_count = nullptr;
@@ -513,6 +524,9 @@ void trc_sppm_release(trc_ctx* ctx) {
     if (!ctx || !ctx->sppm) return;
     SppmState* s = ctx->sppm;
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (s->cam_stream) { (void)hipStreamSynchronize(s->cam_stream); (void)hipStreamDestroy(s->cam_stream); }
+    if (s->ev_main) (void)hipEventDestroy(s->ev_main);
+    if (s->ev_cam) (void)hipEventDestroy(s->ev_cam);
     (void)hipFree(s->d_photon_rng); (void)hipFree(s->d_vp); (void)hipFree(s->d_pho);
     (void)hipFree(s->d_mark); (void)hipFree(s->d_count); (void)hipFree(s->d_cells); (void)hipFree(s->d_cx);
     delete s;
@@ -541,13 +555,24 @@ trc_status trc_sppm_init(trc_ctx* ctx, uint64_t photon_seed) {
     s->W = ctx->width; s->H = ctx->height;
     const size_t np = (size_t)s->W * s->H, nph = (size_t)kHashN * kHashN;
     HIP_TRY(ctx, hipMalloc((void**)&s->d_photon_rng, nph * 16));
-    const size_t vp_bytes = np * (5 * sizeof(float4) + sizeof(uint32_t));
+    const size_t vp_bytes = np * (9 * sizeof(float4) + sizeof(uint32_t));
     HIP_TRY(ctx, hipMalloc(&s->d_vp, vp_bytes));
     {
         float4* q = static_cast<float4*>(s->d_vp);
-        s->vp.ratio_valid = q; s->vp.position = q + np; s->vp.direction = q + 2 * np; s->vp.alternative = q + 3 * np;
-        s->vp.flux_radius = q + 4 * np; s->vp.count = reinterpret_cast<uint32_t*>(q + 5 * np);
+        for (int c = 0; c < 2; ++c) {
+            VisiblePoints& v = s->vp[c];
+            v.ratio_valid = q + (4 * c) * np; v.position = q + (4 * c + 1) * np; v.direction = q + (4 * c + 2) * np;
+            v.alternative = q + (4 * c + 3) * np;
+            v.flux_radius = q + 8 * np; v.count = reinterpret_cast<uint32_t*>(q + 9 * np);
+        }
     }
+    {   // lowest priority: the pass fills what the frame beside it leaves idle
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        HIP_TRY(ctx, hipStreamCreateWithPriority(&s->cam_stream, hipStreamNonBlocking, least));
+    }
+    HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_main, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_cam, hipEventDisableTiming));
     HIP_TRY(ctx, hipMalloc((void**)&s->d_pho, nph * sizeof(trc_PhotonRecord)));
     HIP_TRY(ctx, hipMalloc((void**)&s->d_mark, nph * 4));
     HIP_TRY(ctx, hipMalloc((void**)&s->d_count, nph * 4));
@@ -597,21 +622,39 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
     kp.photon_first = rank * chunk;
     kp.tiles = ctx->d_tiles;
     kp.canvas_rng = ctx->d_rng; kp.accum = ctx->d_accum; kp.photon_rng = s->d_photon_rng;
-    kp.vp = s->vp; kp.pho_rec = s->d_pho; kp.mark = s->d_mark; kp.count = s->d_count; kp.cells = s->d_cells; kp.cx = s->d_cx;
+    kp.vp = kp.vp_prev = s->vp[s->cur]; kp.pho_rec = s->d_pho; kp.mark = s->d_mark; kp.count = s->d_count; kp.cells = s->d_cells; kp.cx = s->d_cx;
     kp.stats = ctx->d_stats;
     const size_t lds = trc_dyn_lds_bytes(ctx, false);
     const bool all_lds = ctx->lds_scene;
     auto rccl_fail = [&](const char* what, int rc) {
         return trc_fail(ctx, TRC_ERR_RCCL, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
     };
-    auto camera_pass = [&]() {
-        if (all_lds) hipLaunchKernelGGL((k_sppm_camera<true>), dim3(ctx->n_tiles), dim3(kBlock), lds, ctx->stream, kp);
-        else hipLaunchKernelGGL((k_sppm_camera<false>), dim3(ctx->n_tiles), dim3(kBlock), lds, ctx->stream, kp);
+    auto camera_launch = [&](const KSppm& k, hipStream_t st) {
+        if (all_lds) hipLaunchKernelGGL((k_sppm_camera<true>), dim3(ctx->n_tiles), dim3(kBlock), lds, st, k);
+        else hipLaunchKernelGGL((k_sppm_camera<false>), dim3(ctx->n_tiles), dim3(kBlock), lds, st, k);
     };
+    // The camera pass of an odd frame depends on nothing the photon / refine passes produce (its RNG texels, the scene,
+    // the copy of the visible points it reads), and it lasts as long as its slowest wavefront -- an 8-bounce specular
+    // chain, 0.4 ms at 1080p with the GPU 90 % idle.  So it runs on its own stream, reading copy
+    // `cur` of the visible points and writing copy `cur ^ 1`, after everything queued so far on the context stream (the
+    // refines that still read the copy it overwrites); the refine of ITS frame waits for it and switches copies.  Within
+    // one call it is started a whole frame early, at the top of the even frame before.
+    auto camera_beside = [&](uint32_t frame) -> trc_status {
+        KSppm kc = kp;
+        kc.frame_count = frame; kc.vp_prev = s->vp[s->cur]; kc.vp = s->vp[s->cur ^ 1];
+        HIP_TRY(ctx, hipEventRecord(s->ev_main, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(s->cam_stream, s->ev_main, 0));
+        camera_launch(kc, s->cam_stream);
+        HIP_TRY(ctx, hipEventRecord(s->ev_cam, s->cam_stream));
+        s->cam_ahead = frame;
+        return TRC_OK;
+    };
+    static const bool serial_camera = std::getenv("TRC_SPPM_SERIAL_CAMERA") != nullptr;     // A/B knob: no frame of lead
     for (uint32_t f = 0; f < n_frames; ++f) {
         kp.frame_count = s->frame_count;
+        kp.vp = kp.vp_prev = s->vp[s->cur];
         if (s->frame_count == 0) {                      // photonPrepare, AAPLRenderer.mm:860-947
-            camera_pass();
+            camera_launch(kp, ctx->stream);
             if (grouped) {
                 DComplex* cx = s->d_cx;
                 int rc = g_rccl.AllReduce(cx->key_min, cx->key_min, 3, kNcclUint32, kNcclMin, ctx->comm, ctx->stream);
@@ -620,9 +663,11 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
                 if (rc) return rccl_fail("ncclAllReduce(max)", rc);
             }
             hipLaunchKernelGGL(k_sppm_params, dim3(1), dim3(64), 0, ctx->stream, s->d_cx);
-            hipLaunchKernelGGL(k_sppm_radius, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, s->vp.flux_radius, np, s->d_cx);
+            hipLaunchKernelGGL(k_sppm_radius, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, s->vp[0].flux_radius, np, s->d_cx);
         }
-        if (s->frame_count % 2) camera_pass();          // photonWork re-runs the camera pass on odd frames, :953-955
+        const bool camera_frame = (s->frame_count % 2) != 0;       // photonWork re-runs the camera pass on odd frames, :953-955
+        if (camera_frame && s->cam_ahead != s->frame_count) { trc_status ts = camera_beside(s->frame_count); if (ts != TRC_OK) return ts; }
+        if (!camera_frame && f + 1 < n_frames && !serial_camera) { trc_status ts = camera_beside(s->frame_count + 1); if (ts != TRC_OK) return ts; }
         if (all_lds) hipLaunchKernelGGL((k_sppm_photon<true>), dim3(chunk / kBlock), dim3(kBlock), lds, ctx->stream, kp);
         else hipLaunchKernelGGL((k_sppm_photon<false>), dim3(chunk / kBlock), dim3(kBlock), lds, ctx->stream, kp);
         if (grouped) {                                  // every rank needs every photon for hashing + refine
@@ -634,6 +679,11 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
         HIP_TRY(ctx, hipMemsetAsync(s->d_count, 0, (size_t)nph * 4, ctx->stream));
         hipLaunchKernelGGL(k_sppm_hash, dim3(nph / 256), dim3(256), 0, ctx->stream, s->d_pho, s->d_mark, s->d_count, s->d_cx);
         hipLaunchKernelGGL(k_sppm_table, dim3(128), dim3(256), 0, ctx->stream, s->d_mark, s->d_count, s->d_pho, s->d_cells, s->d_cx);
+        if (camera_frame) {                             // this frame's visible points: wait for them, switch copies
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->ev_cam, 0));
+            s->cur ^= 1; s->cam_ahead = 0;
+            kp.vp = kp.vp_prev = s->vp[s->cur];
+        }
         hipLaunchKernelGGL(k_sppm_refine, dim3(ctx->n_tiles), dim3(kBlock), 0, ctx->stream, kp);
         hipLaunchKernelGGL(k_sppm_end_frame, dim3(1), dim3(64), 0, ctx->stream, s->d_cx);
         HIP_TRY(ctx, hipGetLastError());
@@ -651,7 +701,7 @@ trc_status trc_sppm_download(trc_ctx* ctx, trc_CameraRecord* cam, trc_PhotonReco
     trc_CameraRecord* d_packed = nullptr;
     if (cam) {
         HIP_TRY(ctx, hipMalloc((void**)&d_packed, np * sizeof(trc_CameraRecord)));
-        hipLaunchKernelGGL(k_sppm_pack_records, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, s->vp, d_packed, (uint32_t)np);
+        hipLaunchKernelGGL(k_sppm_pack_records, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, s->vp[s->cur], d_packed, (uint32_t)np);
         hipError_t ce = hipMemcpyAsync(cam, d_packed, np * sizeof(trc_CameraRecord), hipMemcpyDeviceToHost, ctx->stream);
         if (ce == hipSuccess) ce = hipStreamSynchronize(ctx->stream);
         (void)hipFree(d_packed);
