@@ -79,9 +79,38 @@ __device__ __forceinline__ uint4 ex_rng(const Pcg& r) {
     uint4 t; t.x = (uint32_t)(r.state >> 32); t.y = (uint32_t)r.state; t.z = (uint32_t)(r.inc >> 32); t.w = (uint32_t)r.inc; return t;
 }
 
+// a / b for a divisor that many quotients share (the hash constants, the frame's hash scale).  The compiler's binary32
+// division is v_div_scale x 2, v_rcp_f32, a Newton step on the reciprocal, a * y, two residual corrections,
+// v_div_fixup: 10-11 instructions.  The reciprocal and its Newton step depend on b alone, so they are taken once
+// (DivBy) and a quotient costs the multiply and the SAME two fused corrections: 5 instructions, the same bits.  What is
+// left out is only the operand scaling / special-case fix-up, which matters for denormal or near-overflow operands,
+// infinities and NaNs; the hash works on cell indices (< 2^24), moduli (< 2^23) and the hash scale (finite, > 0).
+struct DivBy { float b, y; };
+__device__ __forceinline__ DivBy div_by(float b) {
+    DivBy d; d.b = b;
+    const float y0 = __builtin_amdgcn_rcpf(b);
+    d.y = __builtin_fmaf(__builtin_fmaf(-b, y0, 1.0f), y0, y0);
+    return d;
+}
+__device__ __forceinline__ float operator/(float a, const DivBy d) {
+    float q = a * d.y;
+    q = __builtin_fmaf(__builtin_fmaf(-d.b, q, a), d.y, q);
+    return __builtin_fmaf(__builtin_fmaf(-d.b, q, a), d.y, q);
+}
+__device__ __forceinline__ F3 operator/(F3 a, const DivBy d) { return f3(a.x / d, a.y / d, a.z / d); }
+struct HashDiv { DivBy scale, q[4], m[4]; };           // the divisors of ph_hash
+__device__ __forceinline__ HashDiv hash_div(float HashScale) {
+    HashDiv h;
+    h.scale = div_by(HashScale);
+    const float q[4] = {1225.0f, 1585.0f, 2457.0f, 2098.0f}, m[4] = {4194287.0f, 4194277.0f, 4194191.0f, 4194167.0f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { h.q[k] = div_by(q[k]); h.m[k] = div_by(m[k]); }
+    return h;
+}
+
 // Photon.hh:57-89
 __device__ __forceinline__ float ph_mod(float x, float y) { return x - y * floorf(x / y); }
-__device__ __forceinline__ float ph_hash(const F3 idx, const float HashScale, const float BufInfo) {
+__device__ __forceinline__ float ph_hash(const F3 idx, const HashDiv& hd, const float BufInfo) {
     const float HashNum = BufInfo * BufInfo;
     const float n[4] = {idx.x, idx.y, idx.z, idx.x + idx.y - idx.z};
     const float q[4] = {1225.0f, 1585.0f, 2457.0f, 2098.0f};
@@ -91,13 +120,13 @@ __device__ __forceinline__ float ph_hash(const F3 idx, const float HashScale, co
     float nm[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        float nk = n[k] * 4194304.0f / HashScale;
-        float beta = floorf(nk / q[k]);
+        float nk = n[k] * 4194304.0f / hd.scale;
+        float beta = floorf(nk / hd.q[k]);
         float pk = a[k] * (nk - beta * q[k]) - beta * r[k];
         float sgn = (-pk > 0.0f) ? 1.0f : ((-pk < 0.0f) ? -1.0f : 0.0f);
         beta = (sgn + 1.0f) * 0.5f * m[k];
         nk = pk + beta;
-        nm[k] = nk / m[k];
+        nm[k] = nk / hd.m[k];
     }
     float d = ((nm[0] * 1.0f + nm[1] * -1.0f) + nm[2] * 1.0f) + nm[3] * -1.0f;
     float fr = d - floorf(d);
@@ -338,7 +367,7 @@ __global__ void __launch_bounds__(256) k_sppm_hash(const trc_PhotonRecord* pho, 
     const float scale = cx->hash_scale;
     F3 hi = (position - f3(cx->box_min[0], cx->box_min[1], cx->box_min[2])) * scale;
     hi = f3(floorf(hi.x), floorf(hi.y), floorf(hi.z));
-    const float hashed = ph_hash(hi, scale, (float)kHashN);
+    const float hashed = ph_hash(hi, hash_div(scale), (float)kHashN);
     const float tx = ph_mod(hashed, (float)kHashN) - 1.0f, ty = floorf(hashed / (float)kHashN) - 1.0f;
     if (!(tx >= 0.0f && tx < (float)kHashN && ty >= 0.0f && ty < (float)kHashN)) return;
     const uint32_t cell = (uint32_t)ty * kHashN + (uint32_t)tx;
@@ -418,6 +447,7 @@ __global__ void __launch_bounds__(kBlock, TRC_SPPM_REFINE_WAVES) k_sppm_refine(c
     uint32_t n_photons = kp.vp.count[pixel];
     const F3 box_min = f3(cx.box_min[0], cx.box_min[1], cx.box_min[2]);
     const float scale = cx.hash_scale, fN = (float)kHashN;
+    const HashDiv hd = hash_div(scale);
     // cells touched by the query sphere's box, as the reference derives them (abs() included, :533-536)
     const F3 lo = at - f3(radius) - box_min, hi = at + f3(radius) - box_min;
     const F3 flo = f3(fabsf(lo.x), fabsf(lo.y), fabsf(lo.z)) * scale, fhi = f3(fabsf(hi.x), fabsf(hi.y), fabsf(hi.z)) * scale;
@@ -436,7 +466,7 @@ __global__ void __launch_bounds__(kBlock, TRC_SPPM_REFINE_WAVES) k_sppm_refine(c
             cell[j] = f3((float)ix, (float)iy, (float)iz);
             rec[j] = kHashN * kHashN;                                    // out-of-range read
             if (more) {
-                const float hashed = ph_hash(cell[j], scale, fN);
+                const float hashed = ph_hash(cell[j], hd, fN);
                 const float hx = ph_mod(hashed, fN) - 1.0f, hy = floorf(hashed / fN) - 1.0f;
                 if (hx >= 0.0f && hx < fN && hy >= 0.0f && hy < fN) rec[j] = (uint32_t)hy * kHashN + (uint32_t)hx;
                 if (++ix > x1) { ix = x0; if (++iy > y1) { iy = y0; if (++iz > z1) more = false; } }
@@ -450,7 +480,7 @@ __global__ void __launch_bounds__(kBlock, TRC_SPPM_REFINE_WAVES) k_sppm_refine(c
             const float weight = q0[j].w;                                // Correction; -1 marks an empty cell (:560)
             if (!use[j] || weight < 0.0f) continue;
             const F3 p = f3(q0[j].x, q0[j].y, q0[j].z);
-            const F3 cmin = cell[j] / scale + box_min, cmax = (cell[j] + f3(1.0f)) / scale + box_min;
+            const F3 cmin = cell[j] / hd.scale + box_min, cmax = (cell[j] + f3(1.0f)) / hd.scale + box_min;
             if (!((cmin.x < p.x) && (p.x < cmax.x) && (cmin.y < p.y) && (p.y < cmax.y) && (cmin.z < p.z) && (p.z < cmax.z))) continue;
             const float d = length(p - at);
             if (!(d < radius)) continue;
