@@ -434,6 +434,10 @@ trc_status trc_sppm_download(trc_ctx* ctx, trc_CameraRecord* camera_records /* W
                              trc_PhotonRecord* photon_records /* 512*512 */, float* mark /* 512*512*4 */,
                              float* count /* 512*512 */, trc_Complex* complex);
 
+/* test hook like trc_trace_rays: `hash()` of Photon.hh:71-89 for n cell indices (3 floats each) at one hash scale, as
+ * the hashing and refine passes evaluate it (the index into the 512 x 512 grid, before the -1 shift) */
+trc_status trc_sppm_hash_cells(trc_ctx* ctx, const float* cells /* n*3 */, size_t n, float hash_scale, float* out /* n */);
+
 /* --- multi-GPU: pixel tiles sharded over ranks, one RCCL reduce -------- */
 #define TRC_UNIQUE_ID_BYTES 128
 /* rank 0 creates the id, every rank gets the same bytes out-of-band */

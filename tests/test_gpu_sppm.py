@@ -99,3 +99,27 @@ def test_sppm_through_a_one_rank_communicator(gpu, cornell_spheres):
     a, b = outs
     assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
     assert a[1].tobytes() == b[1].tobytes() and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and a[4] == b[4]
+
+
+@pytest.mark.parametrize("scale", [0.37, 1.0, 1.5, 2.0, 3.999, 17.3, 250.0, 1.0e-3])
+def test_hash_equals_the_oracle_cell_for_cell(gpu, scale):
+    """The device evaluates the divisions of `hash()` (Photon.hh:71-89) with one refined reciprocal per shared divisor and
+    the compiler's two fused corrections per quotient (trc_sppm.hip::DivBy).  That must be the IEEE quotient, i.e. the
+    oracle's `/`: compared here directly, cell for cell, over the grid's own index range, large indices, non-integers,
+    negative fourth components (x + y - z) and zeros, at hash scales from 1e-3 to 250."""
+    import ctypes as C
+    rs = np.random.RandomState(int(scale * 1000) % 65521)
+    n = 40000
+    cells = np.concatenate([
+        rs.randint(0, 600, size=(n, 3)).astype(np.float32),                       # what the passes feed it
+        rs.randint(0, 1 << 24, size=(n // 4, 3)).astype(np.float32),              # up to 2^24
+        (rs.uniform(0, 600, size=(n // 4, 3))).astype(np.float32),                # non-integer
+        np.zeros((4, 3), np.float32),
+        np.array([[0, 0, 599], [599, 0, 0], [1, 1, 2], [0, 0, 1]], np.float32),   # x + y - z <= 0
+    ])
+    dev = gpu.sppm_hash_cells(cells, scale)
+    L = po.lib()
+    f3 = C.c_float * 3
+    ref = np.array([L.orc_photon_hash(f3(*c), C.c_float(scale)) for c in cells], np.float32)
+    bad = np.flatnonzero(dev.view(np.uint32) != ref.view(np.uint32))
+    assert len(bad) == 0, f"{len(bad)} of {len(cells)} hashes differ; first: cell {cells[bad[0]]} dev {dev[bad[0]]} ref {ref[bad[0]]}"

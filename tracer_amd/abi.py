@@ -198,7 +198,7 @@ DEVICE_SYMBOLS = [
     "trc_upload_scene", "trc_upload_density", "trc_upload_scene_lbvh", "trc_download_bvh", "trc_lbvh_info", "trc_set_camera", "trc_set_environment", "trc_set_environment_map", "trc_resize", "trc_seed",
     "trc_upload_rng", "trc_download_rng", "trc_upload_accum", "trc_download_accum", "trc_clear_accum", "trc_tonemap",
     "trc_render", "trc_synchronize", "trc_trace_rays", "trc_get_stats", "trc_reset_stats", "trc_debug_profile",
-    "trc_sppm_init", "trc_sppm_frames", "trc_sppm_download",
+    "trc_sppm_init", "trc_sppm_frames", "trc_sppm_download", "trc_sppm_hash_cells",
     "trc_device_info", "trc_group_unique_id", "trc_group_init", "trc_group_reduce_accum", "trc_group_reduce_accum_async", "trc_group_allreduce_mean_accum", "trc_download_composed", "trc_group_finalize",
 ]
 HOST_SYMBOLS = [

@@ -525,6 +525,13 @@ __global__ void __launch_bounds__(256) k_sppm_pack_records(const VisiblePoints v
     out[i] = r;
 }
 
+// trc_sppm_hash_cells
+__global__ void __launch_bounds__(256) k_sppm_hash_cells(const float* cells, uint32_t n, float scale, float* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = ph_hash(f3(cells[3 * i], cells[3 * i + 1], cells[3 * i + 2]), hash_div(scale), (float)kHashN);
+}
+
 // completion handler, AAPLRenderer.mm:1031-1036
 __global__ void k_sppm_end_frame(DComplex* x) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -719,6 +726,26 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
         HIP_TRY(ctx, hipGetLastError());
         s->frame_count += 1;
     }
+    return TRC_OK;
+}
+
+trc_status trc_sppm_hash_cells(trc_ctx* ctx, const float* cells, size_t n, float hash_scale, float* out) {
+    if (!ctx || (n && (!cells || !out))) return TRC_ERR_INVALID_ARG;
+    if (n == 0) return TRC_OK;
+    if (n > 0x7FFFFFFFu / 3u) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "trc_sppm_hash_cells: too many cells in one call");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float *d_in = nullptr, *d_out = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d_in, n * 12));
+    if (hipMalloc((void**)&d_out, n * 4) != hipSuccess) { (void)hipFree(d_in); return trc_fail(ctx, TRC_ERR_OOM, "hipMalloc"); }
+    hipError_t e = hipMemcpyAsync(d_in, cells, n * 12, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_sppm_hash_cells, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_in, (uint32_t)n, hash_scale, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream); else (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    if (e != hipSuccess) return trc_fail(ctx, TRC_ERR_HIP, std::string("trc_sppm_hash_cells: ") + hipGetErrorString(e));
     return TRC_OK;
 }
 

@@ -82,6 +82,7 @@ def _load(path):
     L.trc_sppm_init.argtypes = [vp, u64]
     L.trc_sppm_frames.argtypes = [vp, u32]
     L.trc_sppm_download.argtypes = [vp, vp, vp, vp, vp, C.POINTER(abi.Complex)]
+    L.trc_sppm_hash_cells.argtypes = [vp, vp, C.c_size_t, C.c_float, vp]
     L.trc_device_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
     L.trc_group_unique_id.argtypes = [C.POINTER(C.c_uint8)]
     L.trc_group_init.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int, C.c_int]
@@ -271,6 +272,14 @@ class Tracer:
 
     def sppm_frames(self, n_frames=1):
         self._check(self._L.trc_sppm_frames(self._h, n_frames), "trc_sppm_frames")
+
+    def sppm_hash_cells(self, cells, hash_scale):
+        """Photon.hh hash() of n cell indices (n x 3 float32) at one scale, evaluated on the device."""
+        cells = np.ascontiguousarray(cells, dtype=np.float32).reshape(-1, 3)
+        out = np.empty(len(cells), dtype=np.float32)
+        self._check(self._L.trc_sppm_hash_cells(self._h, cells.ctypes.data, len(cells), float(hash_scale), out.ctypes.data),
+                    "trc_sppm_hash_cells")
+        return out
 
     def sppm_download(self):
         """(camera records, photon records, mark grid, count grid, Complex) in the reference's layouts"""
