@@ -193,10 +193,11 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
 
     // exact work counters: wave reduction, one 64-bit atomic per wave and counter
     uint32_t r_paths = wave_sum(n_paths), r_rays = wave_sum(n_rays), r_shaded = wave_sum(n_shaded);
+    unsigned long long* const stats = stat_row(kp.stats, blockIdx.x);
     if (lane == 0) {
-        atomicAdd(&kp.stats[kStatPaths], (unsigned long long)r_paths);
-        atomicAdd(&kp.stats[kStatRays], (unsigned long long)r_rays);
-        atomicAdd(&kp.stats[kStatShaded], (unsigned long long)r_shaded);
+        atomicAdd(&stats[kStatPaths], (unsigned long long)r_paths);
+        atomicAdd(&stats[kStatRays], (unsigned long long)r_rays);
+        atomicAdd(&stats[kStatShaded], (unsigned long long)r_shaded);
     }
     if (STATS) {
         uint32_t v[8] = {cnt.n_descend, cnt.n_return, cnt.leaf[0], cnt.leaf[1], cnt.leaf[2], cnt.leaf[3],
@@ -206,7 +207,7 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             uint32_t r = wave_sum(v[i]);
-            if (lane == 0) atomicAdd(&kp.stats[slot[i]], (unsigned long long)r);
+            if (lane == 0) atomicAdd(&stats[slot[i]], (unsigned long long)r);
         }
         for (int i = 0; i < kProfCount; ++i) {       // divergence profile: lanes and wavefronts per site
             uint32_t rl = wave_sum(cnt.prof_lane[i]), rw = wave_sum(cnt.prof_wave[i]);
@@ -214,9 +215,9 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) rc += __shfl_xor(rc, off);
             if (lane == 0) {
-                atomicAdd(&kp.stats[kStatCount + 3 * i], (unsigned long long)rl);
-                atomicAdd(&kp.stats[kStatCount + 3 * i + 1], (unsigned long long)rw);
-                atomicAdd(&kp.stats[kStatCount + 3 * i + 2], rc);
+                atomicAdd(&stats[kStatCount + 3 * i], (unsigned long long)rl);
+                atomicAdd(&stats[kStatCount + 3 * i + 1], (unsigned long long)rw);
+                atomicAdd(&stats[kStatCount + 3 * i + 2], rc);
             }
         }
     }
@@ -259,9 +260,10 @@ __global__ void __launch_bounds__(64 * pwg_waves(INTEGRATOR), pwg_waves(INTEGRAT
     }
     uint32_t r_paths = wave_sum(n_paths), r_rays = wave_sum(n_rays), r_shaded = wave_sum(n_shaded);
     if (lane == 0) {
-        atomicAdd(&kp.stats[kStatPaths], (unsigned long long)r_paths);
-        atomicAdd(&kp.stats[kStatRays], (unsigned long long)r_rays);
-        atomicAdd(&kp.stats[kStatShaded], (unsigned long long)r_shaded);
+        unsigned long long* const stats = stat_row(kp.stats, blockIdx.x * (blockDim.x >> 6) + wave);
+        atomicAdd(&stats[kStatPaths], (unsigned long long)r_paths);
+        atomicAdd(&stats[kStatRays], (unsigned long long)r_rays);
+        atomicAdd(&stats[kStatShaded], (unsigned long long)r_shaded);
     }
 }
 
@@ -383,9 +385,10 @@ __global__ void __launch_bounds__(kBlock, INTEGRATOR == TRC_INTEGRATOR_VOLUME ? 
     uint32_t r_paths = wave_sum(n_paths), r_rays = wave_sum(n_rays), r_shaded = wave_sum(n_shaded);
     if (lane == 0) {
         kp.block_cost[canon] = (uint32_t)min((unsigned long long)((clock64() - t_start) >> 6), 0xFFFFFFull);
-        atomicAdd(&kp.stats[kStatPaths], (unsigned long long)r_paths);
-        atomicAdd(&kp.stats[kStatRays], (unsigned long long)r_rays);
-        atomicAdd(&kp.stats[kStatShaded], (unsigned long long)r_shaded);
+        unsigned long long* const stats = stat_row(kp.stats, blockIdx.x);
+        atomicAdd(&stats[kStatPaths], (unsigned long long)r_paths);
+        atomicAdd(&stats[kStatRays], (unsigned long long)r_rays);
+        atomicAdd(&stats[kStatShaded], (unsigned long long)r_shaded);
     }
 }
 
@@ -422,6 +425,15 @@ trc_status trc_repack_triangles(trc_ctx* ctx, const trc_scene* s, const DScene& 
     } while (0);
     (void)hipFree(d_verts); (void)hipFree(d_idx);
     return st;
+}
+
+// the counters' rows (stat_row) summed into one row
+__global__ void __launch_bounds__(64) k_stats_sum(const unsigned long long* rows, unsigned long long* sum) {
+    const uint32_t c = threadIdx.x;
+    if (c >= kStatRowStride) return;
+    unsigned long long v = 0;
+    for (uint32_t r = 0; r < kStatRows; ++r) v += rows[(size_t)r * kStatRowStride + c];
+    sum[c] = v;
 }
 
 // sort keys of the adaptive launch order: descending cost (shader clocks / 64, clamped to 24 bits), ties in list order
@@ -879,8 +891,9 @@ trc_status trc_create(int device, trc_ctx** out) {
     { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) ctx->cu_count = cus; }
     if (ctx->cu_count <= 0) ctx->cu_count = 256;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void**)&ctx->d_stats, sizeof(unsigned long long) * (kStatCount + 3 * kProfCount)) != hipSuccess ||
-        hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * (kStatCount + 3 * kProfCount), ctx->stream) != hipSuccess) {
+        hipMalloc((void**)&ctx->d_stats, sizeof(unsigned long long) * kStatRows * kStatRowStride) != hipSuccess ||
+        hipMalloc((void**)&ctx->d_stats_sum, sizeof(unsigned long long) * kStatRowStride) != hipSuccess ||
+        hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * kStatRows * kStatRowStride, ctx->stream) != hipSuccess) {
         trc_destroy(ctx);
         return TRC_ERR_HIP;
     }
@@ -898,7 +911,7 @@ void trc_destroy(trc_ctx* ctx) {
     collect_events(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     (void)hipFree(ctx->d_blob); (void)hipFree(ctx->d_bvh_ref); (void)hipFree(ctx->d_density); (void)hipFree(ctx->d_occupancy); (void)hipFree(ctx->d_envmap); (void)hipFree(ctx->d_sobol32); (void)hipFree(ctx->d_sobol_vdc); (void)hipFree(ctx->d_rng); (void)hipFree(ctx->d_accum);
-    (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_stats); (void)hipFree(ctx->d_reduce_recv);
+    (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_stats); (void)hipFree(ctx->d_stats_sum); (void)hipFree(ctx->d_reduce_recv);
     (void)hipFree(ctx->d_block_cost); (void)hipFree(ctx->d_order_hist);
     for (int k = 0; k < 2; ++k) { (void)hipFree(ctx->d_order_keys[k]); (void)hipFree(ctx->d_order_vals[k]); }
     (void)hipFree(ctx->d_accum_alt); (void)hipFree(ctx->d_stack_ovf); (void)hipFree(ctx->d_queue);
@@ -1294,7 +1307,8 @@ trc_status trc_get_stats(trc_ctx* ctx, trc_stats* out) {
     if (!ctx || !out) return TRC_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     unsigned long long h[kStatCount];
-    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    hipLaunchKernelGGL(k_stats_sum, dim3(1), dim3(64), 0, ctx->stream, ctx->d_stats, ctx->d_stats_sum);
+    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_stats_sum, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     collect_events(ctx);
     std::memset(out, 0, sizeof *out);
@@ -1313,7 +1327,8 @@ trc_status trc_debug_profile(trc_ctx* ctx, uint64_t* out, uint32_t n_sites) {
     if (!ctx || !out) return TRC_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     unsigned long long h[kStatCount + 3 * kProfCount];
-    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    hipLaunchKernelGGL(k_stats_sum, dim3(1), dim3(64), 0, ctx->stream, ctx->d_stats, ctx->d_stats_sum);
+    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_stats_sum, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (uint32_t i = 0; i < n_sites && i < (uint32_t)kProfCount; ++i)
         for (int k = 0; k < 3; ++k) out[3 * i + k] = h[kStatCount + 3 * i + k];
@@ -1325,7 +1340,7 @@ trc_status trc_reset_stats(trc_ctx* ctx) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     collect_events(ctx);
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * (kStatCount + 3 * kProfCount), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * kStatRows * kStatRowStride, ctx->stream));
     ctx->launches = 0;
     ctx->kernel_ms = 0.0;
     return TRC_OK;

@@ -80,6 +80,17 @@ __device__ __forceinline__ SceneRef make_scene_ref(const DScene& sc, const uint3
     return S;
 }
 
+// Work counters live in kStatRows copies of one row; a wavefront adds to row (its index mod kStatRows) and the reader
+// sums the rows.  One row for everybody meant one 64-bit atomic per wavefront and counter on ONE address: device-scope
+// atomics on a line are served one after the other (~12 ns each, measured), and 32 400 wavefronts x 3 counters held a
+// 1-spp frame at 1.2 ms and the SPPM camera pass at 0.4 ms -- whatever the kernels did.
+constexpr uint32_t kStatRows = 1024;
+constexpr uint32_t kStatRowStride = ((kStatCount + 3 * kProfCount + 15) / 16) * 16;      // 64-bit words; rows start on 128-byte lines
+static_assert(kStatRowStride <= 64, "k_stats_sum sums a row with one 64-thread workgroup");
+__device__ __forceinline__ unsigned long long* stat_row(unsigned long long* stats, uint32_t wave_index) {
+    return stats + (size_t)(wave_index & (kStatRows - 1u)) * kStatRowStride;
+}
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -137,7 +148,8 @@ struct trc_ctx {
     uint32_t n_tiles = 0, tiles_nranks = 0, tiles_rank = 0, tiles_view_height = 0, tiles_blk_shift = 3;
 
     // stats
-    unsigned long long* d_stats = nullptr;
+    unsigned long long* d_stats = nullptr;       // kStatRows rows of kStatRowStride counters (stat_row)
+    unsigned long long* d_stats_sum = nullptr;   // their sum, made by trc_get_stats / trc_debug_profile
     uint64_t launches = 0;
     double kernel_ms = 0.0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // per-launch event pairs not yet read

@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(kBlock, TRC_SPPM_CAMERA_WAVES) k_sppm_camera(c
     }
     }
     const uint32_t r = wave_sum(n_rays);
-    if (lane == 0 && r) atomicAdd(&kp.stats[kStatRays], (unsigned long long)r);
+    if (lane == 0 && r) atomicAdd(&stat_row(kp.stats, blockIdx.x)[kStatRays], (unsigned long long)r);
 }
 
 // kernelPhotonParams, Photon.metal:357-372
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(kBlock, TRC_SPPM_PHOTON_WAVES) k_sppm_photon(c
     slot.step = (uint8_t)step; slot.active = active ? 1 : 0;
     reinterpret_cast<uint4*>(kp.photon_rng)[idx] = ex_rng(rng);
     const uint32_t r = wave_sum(n_rays);
-    if ((threadIdx.x & 63u) == 0 && r) atomicAdd(&kp.stats[kStatRays], (unsigned long long)r);
+    if ((threadIdx.x & 63u) == 0 && r) atomicAdd(&stat_row(kp.stats, blockIdx.x)[kStatRays], (unsigned long long)r);
 }
 
 // kernelPhotonHashing + point raster (PhotonMarkVS/FS), Photon.metal:386-456
