@@ -285,8 +285,12 @@ __global__ void __launch_bounds__(kBlock, INTEGRATOR == TRC_INTEGRATOR_VOLUME ? 
     const uint32_t canon = kp.order ? kp.order[blockIdx.x] : blockIdx.x;     // strip index
     const uint32_t lane = threadIdx.x;
     const uint32_t W = kp.fr.width, H = kp.fr.height;
-    uint32_t blk = canon * kp.strip;
-    const uint32_t blk_end = min(blk + kp.strip, kp.n_tiles);
+    // the strip's pixels form one pool: pixel p = lane (p mod block size) of block (p / block size); a lane whose pixel is
+    // done takes the next unclaimed one, so no lane waits for "its" pixel of the next block while others still trace
+    const uint32_t blk0 = canon * kp.strip;
+    const uint32_t bshift = 2u * kp.blk_shift;                               // log2(pixels per block): 6 or 4
+    const uint32_t pool_end = (min(blk0 + kp.strip, kp.n_tiles) - blk0) << bshift;
+    uint32_t pool_next = 0;                                                  // wave-uniform: next unclaimed pool index
 
     uint32_t n_rays = 0, n_shaded = 0, n_paths = 0;
     TravCounters cnt;
@@ -316,7 +320,7 @@ __global__ void __launch_bounds__(kBlock, INTEGRATOR == TRC_INTEGRATOR_VOLUME ? 
     float u = 0, v = 0;
     uint32_t s = 0, pix = 0;
     uint64_t state_after_cast = 0;
-    bool alive = false;
+    bool alive = false, want = true;                  // want: this lane needs a (new) pixel
 
     auto begin_sample = [&]() {                       // castRay, then (SOBOL) the sampler of this frame: Render.metal:527-530
         rng.state = ((uint64_t)texel.z << 32) | texel.w;      // the two words trade roles every frame (B-1)
@@ -328,27 +332,31 @@ __global__ void __launch_bounds__(kBlock, INTEGRATOR == TRC_INTEGRATOR_VOLUME ? 
             ps.sobol_dim = 0;
         }
     };
-    auto begin_pixel = [&]() {                        // this lane's pixel of the next block of the strip, if any
-        alive = false;
-        while (blk < blk_end) {
-            const uint32_t tile = kp.tiles[blk++];
-            const uint32_t bs = kp.blk_shift;
-            const uint32_t px = ((tile & 0xFFFFu) << bs) + (lane & ((1u << bs) - 1u));
-            const uint32_t py = ((tile >> 16) << bs) + (lane >> bs);
-            if (lane < (1u << (2u * bs)) && px < W && py < H) {
-                pix = py * W + px;
-                texel = reinterpret_cast<const uint4*>(kp.fr.rng)[pix];
-                const float4 acc = reinterpret_cast<const float4*>(kp.fr.accum)[pix];
-                cached = f3(acc.x, acc.y, acc.z);
-                u = (float)px / (float)W;                                              // no sub-pixel jitter (B-2)
-                v = (float)(py % kp.view_height) / (float)kp.view_height;
-                if (SOBOL) { cx.sobol_xy[0] = px; cx.sobol_xy[1] = py % kp.view_height; }
-                s = 0;
-                alive = true;
-                begin_sample();
-                return;
-            }
-        }
+    // hands pool indices to the lanes that want one (called where the whole wavefront is converged); a lane whose index
+    // falls outside the frame (ragged edge blocks) simply asks again in the next round
+    auto deal_pixels = [&]() {
+        const unsigned long long m = __ballot(want);
+        if (m == 0ull) return;
+        const uint32_t mine = pool_next + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        pool_next += (uint32_t)__popcll(m);
+        if (!want) return;
+        if (mine >= pool_end) { want = false; return; }                        // the pool is empty: this lane is done
+        const uint32_t tile = kp.tiles[blk0 + (mine >> bshift)];
+        const uint32_t l = mine & ((1u << bshift) - 1u), bs = kp.blk_shift;
+        const uint32_t px = ((tile & 0xFFFFu) << bs) + (l & ((1u << bs) - 1u));
+        const uint32_t py = ((tile >> 16) << bs) + (l >> bs);
+        if (px >= W || py >= H) return;                                        // not a pixel: ask again
+        pix = py * W + px;
+        texel = reinterpret_cast<const uint4*>(kp.fr.rng)[pix];
+        const float4 acc = reinterpret_cast<const float4*>(kp.fr.accum)[pix];
+        cached = f3(acc.x, acc.y, acc.z);
+        u = (float)px / (float)W;                                              // no sub-pixel jitter (B-2)
+        v = (float)(py % kp.view_height) / (float)kp.view_height;
+        if (SOBOL) { cx.sobol_xy[0] = px; cx.sobol_xy[1] = py % kp.view_height; }
+        s = 0;
+        want = false;
+        alive = true;
+        begin_sample();
     };
     auto finish_sample = [&](F3 color) {
         const bool bad = is_inf(color.x) || is_nan(color.x) || is_inf(color.y) || is_nan(color.y) ||
@@ -364,23 +372,27 @@ __global__ void __launch_bounds__(kBlock, INTEGRATOR == TRC_INTEGRATOR_VOLUME ? 
             float4 out; out.x = cached.x; out.y = cached.y; out.z = cached.z; out.w = 1.0f;
             reinterpret_cast<float4*>(kp.fr.accum)[pix] = out;
             reinterpret_cast<uint4*>(kp.fr.rng)[pix] = texel;
-            begin_pixel();
+            alive = false;
+            want = true;
         } else {
             begin_sample();
         }
     };
 
-    begin_pixel();
-    while (alive) {
-        n_rays++;
-        constexpr bool kVolume = INTEGRATOR == TRC_INTEGRATOR_VOLUME;
-        const bool hitted = scene_hit<LDS, false, false, false, kVolume, kHybridStack>(cx.S, cx.root_min, cx.root_max, ps.ray, ps.rec, FLT_MAX,
-                                                                  cx.stack, cx.lvstack, cnt);
-        F3 color;
-        const bool finished = (INTEGRATOR == TRC_INTEGRATOR_PATH)
-                                  ? path_step<false, SOBOL>(cx, ps, hitted, rng, cnt, n_shaded, color)
-                                  : mis_step<LDS, false, kVolume, SOBOL>(cx, ps, hitted, rng, cnt, n_rays, n_shaded, color);
-        if (finished) finish_sample(color);
+    for (;;) {                                        // wave-uniform loop: every lane stays in it until nobody has or wants work
+        deal_pixels();
+        if (__ballot(alive || want) == 0ull) break;
+        if (alive) {
+            n_rays++;
+            constexpr bool kVolume = INTEGRATOR == TRC_INTEGRATOR_VOLUME;
+            const bool hitted = scene_hit<LDS, false, false, false, kVolume, kHybridStack>(cx.S, cx.root_min, cx.root_max, ps.ray, ps.rec, FLT_MAX,
+                                                                      cx.stack, cx.lvstack, cnt);
+            F3 color;
+            const bool finished = (INTEGRATOR == TRC_INTEGRATOR_PATH)
+                                      ? path_step<false, SOBOL>(cx, ps, hitted, rng, cnt, n_shaded, color)
+                                      : mis_step<LDS, false, kVolume, SOBOL>(cx, ps, hitted, rng, cnt, n_rays, n_shaded, color);
+            if (finished) finish_sample(color);
+        }
     }
     uint32_t r_paths = wave_sum(n_paths), r_rays = wave_sum(n_rays), r_shaded = wave_sum(n_shaded);
     if (lane == 0) {
@@ -1162,10 +1174,12 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
     kp.n_tiles = ctx->n_tiles;
     kp.strip = 1;
     if (!stats) {
-        // measured at 1920x1080 (kernel ms for 64 samples in launches of 1 / 4 / 16 spp): strip 1: 80.8 / 33.0 / 24.4,
-        // 2: 52.2 / 31.7 / 25.8, 3: 46.8 / 32.2 / 28.0, 4: 46.0 / 34.4 / 31.6, 6: 52.7 / 44.6 / 42.0 -- longer strips
-        // leave too few workgroups (the frame has 32 400 blocks for 4 096 wavefront slots)
-        const uint32_t want = p->spp == 1 ? 4u : p->spp == 2 ? 3u : p->spp < 8 ? 2u : 1u;
+        // blocks per wavefront, measured at 1920x1080 (wall ms for 64 samples in launches of 1 / 4 spp) with the pooled
+        // pixels of k_render_strip: strip 2: 37.6 / 28.4, 3: 36.6 / 29.7, 4: 37.5 / 31.5, >= 5: 38.8 / 35.6 -- longer strips
+        // leave too few workgroups (the frame has 32 400 blocks for 4 096 wavefront slots); one block per wavefront: 80.8 / 33.0
+        uint32_t want = p->spp <= 2 ? 3u : p->spp < 8 ? 2u : 1u;
+        static const char* strip_env = std::getenv("TRC_STRIP_LEN");           // A/B knob: blocks per wavefront for spp < 8
+        if (strip_env && std::atoi(strip_env) > 0 && p->spp < 8) want = (uint32_t)std::atoi(strip_env);
         const uint32_t slots = (uint32_t)ctx->cu_count * 16u;
         const uint32_t room = ctx->n_tiles / (slots + slots / 2u);          // keep >= 1.5 workgroups per slot
         kp.strip = std::max(1u, std::min(want, room));
