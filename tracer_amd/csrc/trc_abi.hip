@@ -1178,8 +1178,8 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
         // pixels of k_render_strip: strip 2: 37.6 / 28.4, 3: 36.6 / 29.7, 4: 37.5 / 31.5, >= 5: 38.8 / 35.6 -- longer strips
         // leave too few workgroups (the frame has 32 400 blocks for 4 096 wavefront slots); one block per wavefront: 80.8 / 33.0
         uint32_t want = p->spp <= 2 ? 3u : p->spp < 8 ? 2u : 1u;
-        static const char* strip_env = std::getenv("TRC_STRIP_LEN");           // A/B knob: blocks per wavefront for spp < 8
-        if (strip_env && std::atoi(strip_env) > 0 && p->spp < 8) want = (uint32_t)std::atoi(strip_env);
+        static const char* strip_env = std::getenv("TRC_STRIP_LEN");           // A/B knob: blocks per wavefront, any spp
+        if (strip_env && std::atoi(strip_env) > 0) want = (uint32_t)std::atoi(strip_env);
         const uint32_t slots = (uint32_t)ctx->cu_count * 16u;
         const uint32_t room = ctx->n_tiles / (slots + slots / 2u);          // keep >= 1.5 workgroups per slot
         kp.strip = std::max(1u, std::min(want, room));
