@@ -80,3 +80,12 @@ def gpu():
     t = device.Tracer(0)
     yield t
     t.close()
+
+
+@pytest.fixture(autouse=True)
+def _gpu_default_state(request):
+    """The Tracer is shared by the whole session: a test that leaves a sky environment behind must not change what a
+    later test (in whatever order the files are named on the command line) renders."""
+    if "gpu" in request.fixturenames:
+        request.getfixturevalue("gpu").set_environment((0.0, 0.0, 0.0))
+    yield
