@@ -545,7 +545,7 @@ namespace {
 
 namespace {
 
-constexpr bool kAutoSmallBlocks = false;      // decided by measurement (tools/tile_balance.py); see DESIGN.md section 5
+constexpr bool kAutoSmallBlocks = true;       // decided by measurement (tools/small_blocks_bench.py, tile_balance.py); DESIGN.md section 5
 
 inline trc_status fail(trc_ctx* ctx, trc_status st, const std::string& msg) { return trc_fail(ctx, st, msg); }
 
@@ -1141,7 +1141,11 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
         const uint64_t blocks8 = (uint64_t)((ctx->width + 7) / 8) * ((ctx->height + 7) / 8) / nranks;
         const bool fits = ctx->width <= 65535u * 4u && ctx->height <= 65535u * 4u;
         if ((p->flags & TRC_FLAG_SMALL_BLOCKS) && fits) blk_shift = 2;
-        else if (!(p->flags & TRC_FLAG_LARGE_BLOCKS) && fits && kAutoSmallBlocks && blocks8 < 2 * slots && p->spp >= 8) blk_shift = 2;
+        // automatic only where it was measured to pay: fewer 8x8 blocks than wavefront slots (a small frame, or an eighth
+        // of a 1080p frame), tracePath on an LDS-resident scene, a fused launch -- 920 / 2 040 / 3 600 blocks: 8.5 / 8.3 / 8.9
+        // -> 7.0 / 7.2 / 7.4 ms at 64 spp; 5 700 blocks: 8.5 -> 9.7 ms
+        else if (!(p->flags & TRC_FLAG_LARGE_BLOCKS) && fits && kAutoSmallBlocks && blocks8 <= slots && p->spp >= 8 &&
+                 p->integrator == TRC_INTEGRATOR_PATH && ctx->lds_scene) blk_shift = 2;
     }
     { trc_status ts = trc_ensure_tiles(ctx, nranks, p->tile_rank, p->view_height, blk_shift); if (ts != TRC_OK) return ts; }
     if (ctx->n_tiles == 0) return TRC_OK;
