@@ -3,6 +3,7 @@ triangle soup, random materials and textures, random camera with a real aperture
 oracle -- Scene::hit batches with counters, and small frames of all three integrators, bit for bit."""
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import pytest
@@ -102,7 +103,13 @@ def random_scene(rs, n_spheres, n_cubes, n_tris):
     return sv, keep
 
 
-@pytest.mark.parametrize("seed", list(range(1, 31)))
+# TRC_FUZZ_SEEDS="a:b" / TRC_FUZZ_SPP=n: a longer or differently shaped run by hand (spp >= 8 takes the fused kernels:
+# persistent workgroups on the big trees, automatic 4x4 blocks on the small ones; the default 5 takes the strip kernels)
+_SEEDS = os.environ.get("TRC_FUZZ_SEEDS", "1:31").split(":")
+_SPP = int(os.environ.get("TRC_FUZZ_SPP", "5"))
+
+
+@pytest.mark.parametrize("seed", list(range(int(_SEEDS[0]), int(_SEEDS[1]))))
 def test_generated_scene(gpu, seed):
     rs = np.random.RandomState(1000 + seed)
     big = seed % 3 == 0                                   # every third scene: tree too large for LDS
@@ -132,9 +139,9 @@ def test_generated_scene(gpu, seed):
         for integ in (abi.INTEGRATOR_PATH, abi.INTEGRATOR_MIS, abi.INTEGRATOR_VOLUME):
             for launch in range(2):
                 rng = host.fill_rng(50 + seed, W, H)
-                gpu.upload_rng(rng); gpu.clear_accum(); gpu.reset_stats(); gpu.render(spp=5, integrator=integ, max_depth=6)
+                gpu.upload_rng(rng); gpu.clear_accum(); gpu.reset_stats(); gpu.render(spp=_SPP, integrator=integ, max_depth=6)
             got, got_rng, st = gpu.download_accum(), gpu.download_rng(), gpu.stats()
-            ref, rst = po.render(sv, cam, W, H, rng, spp=5, integrator=integ, max_depth=6, env=(0.3, 0.4, 0.6))
+            ref, rst = po.render(sv, cam, W, H, rng, spp=_SPP, integrator=integ, max_depth=6, env=(0.3, 0.4, 0.6))
             assert st.rays == rst.rays, (seed, integ)
             assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (seed, integ)
             assert np.array_equal(got_rng, rng)
