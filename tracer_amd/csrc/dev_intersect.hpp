@@ -69,16 +69,37 @@ struct SceneRef {
     uint32_t* ovf;            // ... deeper ones in this lane's column of the workgroup's overflow rows (global memory)
 };
 TRC_DEV float4 ld4(const uint32_t* p) { return *reinterpret_cast<const float4*>(p); }
+// The same 16-byte load with the address space spelled out.  Where a lane reads either the LDS copy or the blob, the
+// compiler otherwise merges both sides into ONE flat_load through a selected pointer, and a FLAT instruction is issued to
+// the LDS and the vector-memory path alike (and returns out of order: both counters must drain).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float trc_v4f __attribute__((ext_vector_type(4)));
+TRC_DEV float4 ld4_global(const uint32_t* p) {
+    const trc_v4f v = *(const __attribute__((address_space(1))) trc_v4f*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+TRC_DEV float4 ld4_lds(const uint32_t* p) {
+    const trc_v4f v = *(const __attribute__((address_space(3))) trc_v4f*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+TRC_DEV uint32_t ld1_global(const uint32_t* p) { return *(const __attribute__((address_space(1))) uint32_t*)p; }
+TRC_DEV void st1_global(uint32_t* p, uint32_t v) { *(__attribute__((address_space(1))) uint32_t*)p = v; }
+#else
+TRC_DEV float4 ld4_global(const uint32_t* p) { return ld4(p); }
+TRC_DEV float4 ld4_lds(const uint32_t* p) { return ld4(p); }
+TRC_DEV uint32_t ld1_global(const uint32_t* p) { return *p; }
+TRC_DEV void st1_global(uint32_t* p, uint32_t v) { *p = v; }
+#endif
 
 // fat-node fetch: LDS for the staged top of the tree, global memory below it.  ALL_LDS = whole tree staged.
 template <bool ALL_LDS>
 TRC_DEV void load_node(const SceneRef& S, uint32_t idx, float4& q0, float4& q1, float4& q2, float4& q3) {
     if (ALL_LDS || idx < S.n_lds_nodes) {
         const uint32_t* np = S.small_base + S.off_nodes + idx * kNodeDwords;
-        q0 = ld4(np); q1 = ld4(np + 4); q2 = ld4(np + 8); q3 = ld4(np + 12);
+        q0 = ld4_lds(np); q1 = ld4_lds(np + 4); q2 = ld4_lds(np + 8); q3 = ld4_lds(np + 12);
     } else {
         const uint32_t* np = S.blob + S.off_nodes + (size_t)idx * kNodeDwords;
-        q0 = ld4(np); q1 = ld4(np + 4); q2 = ld4(np + 8); q3 = ld4(np + 12);
+        q0 = ld4_global(np); q1 = ld4_global(np + 4); q2 = ld4_global(np + 8); q3 = ld4_global(np + 12);
     }
 }
 
@@ -344,12 +365,12 @@ struct Trav {
 template <bool HYB>
 TRC_DEV void stack_put(const SceneRef& S, uint32_t* stack, uint32_t e, uint32_t v) {
     if (!HYB || e < S.stack_lds) stack[e * kBlock] = v;
-    else S.ovf[(e - S.stack_lds) * kBlock] = v;
+    else st1_global(S.ovf + (e - S.stack_lds) * kBlock, v);
 }
 template <bool HYB>
 TRC_DEV uint32_t stack_get(const SceneRef& S, const uint32_t* stack, uint32_t e) {
     if (!HYB || e < S.stack_lds) return stack[e * kBlock];
-    return S.ovf[(e - S.stack_lds) * kBlock];
+    return ld1_global(S.ovf + (e - S.stack_lds) * kBlock);
 }
 
 template <bool HYB, bool STATS>
