@@ -138,7 +138,12 @@ def pmc_summary():
     """Newest committed PMC summary of the bench kernel (profiles/r*/pmc_config2.json, written by
     tools/pmc_summary.py from rocprofv3 --pmc passes of THIS script); None if absent."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_config2.json")))
+    import re
+
+    def round_of(path):                  # profiles/r03 < profiles/r10: by number, not by name
+        m = re.search(r"r(\d+)$", os.path.basename(os.path.dirname(path)))
+        return int(m.group(1)) if m else -1
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_config2.json")), key=round_of)
     if not files:
         return None
     p = json.load(open(files[-1]))
@@ -146,28 +151,39 @@ def pmc_summary():
     return p
 
 
-def roofline_extras(kernel_ms):
-    """(traffic, hbm_physical_frac, roofline_valu) from the committed PMC summary -- only when it was collected on
-    the library that is running (same source hash, same kernel name); otherwise (None, None, {"stale": ...})."""
-    p = pmc_summary()
-    if p is None:
-        return None, None, None
-    mine = lib_source_hash()
-    if p.get("lib_source_hash") != mine or not str(p.get("kernel", "")).startswith(KERNEL):
-        return None, None, {"stale": f"{p['_file']} was collected on library {p.get('lib_source_hash')} / kernel "
-                                     f"{p.get('kernel')!r}; running {mine} / {KERNEL!r}"}
-    traffic = int(p["hbm_bytes_per_launch"])
+def valu_roofline(p, kernel_ms=None, source=None, lib_hash=None):
+    """The binding bound of these kernels: VALU issue.  A wave64 VALU instruction occupies a SIMD-32 for 2 cycles
+    (MI355X_MICROARCH.md), so a launch of `cyc` shader cycles can issue at most N_SIMD * cyc / 2 of them.
+    achieved / peak in wave-instructions per launch, from a PMC summary `p` (tools/pmc_summary.py)."""
     cyc = p["GRBM_GUI_ACTIVE"] / 8.0                       # summed over the 8 XCDs
-    valu = {
-        "bound": "valu-issue", "kernel": p["kernel"], "unit": "wave-instructions/launch",
-        "insts_valu": int(p["SQ_INSTS_VALU"]), "peak": int(N_SIMD * cyc / 2.0),
-        "frac": round(p["SQ_INSTS_VALU"] * 2.0 / (N_SIMD * cyc), 4),
+    traffic = int(p["hbm_bytes_per_launch"]) if p.get("hbm_bytes_per_launch") is not None else None
+    ms = kernel_ms if kernel_ms is not None else p.get("kernel_ms")
+    return {
+        "bound": "valu-issue", "achieved": int(p["SQ_INSTS_VALU"]), "peak": int(N_SIMD * cyc / 2.0),
+        "unit": "VALU wave-instructions/launch", "frac": round(p["SQ_INSTS_VALU"] * 2.0 / (N_SIMD * cyc), 4),
+        "traffic": traffic,
+        "hbm_physical_frac": None if traffic is None or not ms else round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
         "lane_utilisation": round(p["SQ_THREAD_CYCLES_VALU"] / (64.0 * p["SQ_INSTS_VALU"]), 4),
         "useful_lane_frac": round(p["SQ_THREAD_CYCLES_VALU"] / 64.0 * 2.0 / (N_SIMD * cyc), 4),
-        "shader_cycles_per_launch": int(cyc), "pmc_kernel_ms": p.get("kernel_ms"),
-        "source": p["_file"], "lib_source_hash": mine,
+        "kernel": p["kernel"], "shader_cycles_per_launch": int(cyc), "pmc_kernel_ms": p.get("kernel_ms"),
+        "source": source, "lib_source_hash": lib_hash,
     }
-    return traffic, round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), valu
+
+
+def roofline_from_pmc(kernel_ms):
+    """`roofline` of the bench line from the committed PMC summary -- only when it was collected on the library that is
+    running (same source hash, same kernel name); otherwise the object says why it carries no number."""
+    p = pmc_summary()
+    mine = lib_source_hash()
+    if p is None:
+        return {"bound": "valu-issue", "achieved": None, "peak": None, "unit": "VALU wave-instructions/launch", "frac": None,
+                "traffic": None, "stale": "no profiles/r*/pmc_config2.json (tools/pmc_collect.sh)", "lib_source_hash": mine}
+    if p.get("lib_source_hash") != mine or not str(p.get("kernel", "")).startswith(KERNEL):
+        return {"bound": "valu-issue", "achieved": None, "peak": None, "unit": "VALU wave-instructions/launch", "frac": None,
+                "traffic": None, "lib_source_hash": mine,
+                "stale": f"{p['_file']} was collected on library {p.get('lib_source_hash')} / kernel {p.get('kernel')!r}; "
+                         f"running {mine} / {KERNEL!r}"}
+    return valu_roofline(p, kernel_ms, p["_file"], mine)
 
 
 def _with_c_stdout_on_stderr(fn):
@@ -326,10 +342,13 @@ def main(argv=None):
     from tracer_amd import abi, host
     from tracer_amd.device import Tracer, group_unique_id
 
-    # ranks > GPUs (plumbing check on a 1-GPU box): share the GPUs, no RCCL between ranks on one device -- every other
-    # part of the N-rank path (rendezvous, workloads, tile ownership, reductions of the timings) runs as usual
+    # ranks > GPUs (plumbing run on a 1-GPU box): the ranks share the GPUs, and since RCCL refuses two ranks on one
+    # device the compose goes through the collectives table of trc_group_set_collectives (host-staged, gloo) -- the same
+    # reduce program, the same pipelined two-accumulator compose, every other part of the N-rank path as usual.  The line
+    # says "plumbing": ranks time-slicing one GPU measure nothing.
     n_dev = visible_gpus() or 1
     no_rccl = os.environ.get("TRC_BENCH_NO_RCCL") == "1" or (world > n_dev)
+    plumbing = grouped and no_rccl
     device = local_rank % n_dev
     if torch is not None and torch.cuda.is_available():
         torch.cuda.set_device(device)          # barrier()'s torch.cuda.synchronize() must not touch GPU 0 from every rank
@@ -352,6 +371,12 @@ def main(argv=None):
             trc.synchronize()
         # RCCL prints a version banner through C stdio on fd 1; keep stdout clean for the single JSON line
         _with_c_stdout_on_stderr(init_comm)
+    elif plumbing:
+        from tracer_amd.gloo_collectives import GlooCollectives
+        trc.resize(W, H)
+        coll = GlooCollectives()
+        trc.set_collectives(coll, world, rank)
+    composing = use_rccl or plumbing
 
     def barrier():
         trc.synchronize()
@@ -372,7 +397,7 @@ def main(argv=None):
             trc.seed(seed)
             trc.render(spp=SPP, max_depth=DEPTH, integrator=abi.INTEGRATOR_PATH, frame0=0, tile_rank=rank,
                        tile_nranks=world, collect_stats=collect_stats, view_height=H)
-            if use_rccl:
+            if composing:
                 trc.group_reduce_accum_async(0)   # overlaps with the next step's render (second accumulator + stream)
 
         # exact algorithmic work of ONE step on this rank (instrumented kernel, untimed)
@@ -413,7 +438,7 @@ def main(argv=None):
 
         # the compose alone (not overlapped): one synchronous reduce per iteration
         compose_ms = None
-        if use_rccl:
+        if composing:
             barrier()
             t2 = time.perf_counter()
             for _ in range(steps):
@@ -451,13 +476,15 @@ def main(argv=None):
     if rank == 0:
         kernel_ms = primary["kernel_ms"]
         achieved = primary["bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
-        traffic, hbm_frac, valu = roofline_extras(kernel_ms) if world == 1 else (None, None, None)
+        roof = roofline_from_pmc(kernel_ms) if world == 1 else None
         info = trc.device_info()
         FH = primary["frame"][1]
         compose = "none"
         if grouped:
             compose = (f"ncclReduce(sum) of the {W}x{FH} RGBA32F frame to rank 0 on a second stream, overlapped with the "
-                       f"next step" if use_rccl else "SWITCHED OFF (ranks share a GPU: plumbing run, not a measurement)")
+                       f"next step" if use_rccl else
+                       f"PLUMBING RUN, NOT A MEASUREMENT: {world} ranks share {n_dev} GPU(s); reduce(sum) of the {W}x{FH} frame "
+                       f"through trc_group_set_collectives (host-staged, gloo) because RCCL refuses two ranks on one device")
         line = {
             "metric": primary["metric"], "value": primary["value"], "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -472,16 +499,19 @@ def main(argv=None):
                        "paths_per_step": primary["paths_per_step"], "mpaths_per_s": primary["mpaths_per_s"],
                        "tiles": f"16x16 px, owner (tx+ty)%{world}", "device": info["name"], "compose": compose},
             "vary_seed": primary["vary_seed"],
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "hbm_physical_frac": hbm_frac,
-                         "kernel": "k_render", "kernel_ms": round(kernel_ms, 3),
-                         "algorithmic_bytes_per_launch": int(primary["bytes_per_launch"]),
-                         "bytes_per_ray": round(primary["bytes_per_launch"] / max(1, primary["rays_per_launch"]), 1),
-                         "note": "algorithmic bytes of the REFERENCE's access pattern (SURVEY 8d); the scene is LDS-resident, "
-                                 "so frac > 1 is possible and the binding resource is VALU issue: see roofline_valu"},
-            "roofline_valu": valu,
+            # the BINDING bound of the dominant kernel: VALU issue (PMC counters of this library, profiles/rNN/pmc_config2.json)
+            "roofline": roof,
+            # the north_star's figure: bytes the REFERENCE's access pattern would move for this work over the
+            # kernel time.  Not a bound here -- the scene is LDS-resident, so it can exceed the HBM peak; physical traffic
+            # is roofline.traffic / roofline.hbm_physical_frac
+            "roofline_hbm_algorithmic": {
+                "bound": "hbm (algorithmic bytes, not a physical bound)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "kernel": "k_render", "kernel_ms": round(kernel_ms, 3),
+                "algorithmic_bytes_per_launch": int(primary["bytes_per_launch"]),
+                "bytes_per_ray": round(primary["bytes_per_launch"] / max(1, primary["rays_per_launch"]), 1)},
         }
+        if plumbing:
+            line["plumbing"] = True
         if world > 1:
             line["per_rank"] = primary["per_rank"]
             if other is not None:
@@ -497,7 +527,7 @@ def main(argv=None):
 
     def teardown():
         if grouped:
-            if use_rccl:
+            if composing:
                 trc.group_finalize()
             dist.barrier()
             dist.destroy_process_group()

@@ -30,7 +30,10 @@ extern "C" {
 /* gcc / clang / hipcc, C and C++ alike */
 #define TRC_ALIGN(n) __attribute__((aligned(n)))
 
-#define TRC_ABI_VERSION 1
+/* 2: trc_trace_rays' last argument became a bit set (TRC_TRACE_*: 2 now means the production closest-hit walk, it used
+ *    to mean any-hit); trc_build_flavor, trc_sppm_hash_cells, trc_host_scene_load_pbrt, trc_host_mesh_from_arrays added
+ * 3: trc_group_set_collectives, trc_debug_set */
+#define TRC_ABI_VERSION 3
 
 /* ------------------------------------------------------------------ */
 /* vector / matrix PODs (Apple simd layout)                            */
@@ -319,7 +322,17 @@ typedef struct trc_stats {
     double   kernel_ms;          /* sum of hipEvent durations of those launches, on the ctx stream */
 } trc_stats;
 
-typedef struct trc_ctx trc_ctx;  /* one per GPU, single-threaded, owns one HIP stream */
+/* Threading contract.  A context owns its device buffers, one render stream (+ a communication stream and the SPPM
+ * camera stream) and all per-launch state; nothing is shared between contexts except the process-wide RCCL symbol table,
+ * which is resolved once under a lock.  Therefore:
+ *   - calls on ONE context must not overlap: a context is used by one thread at a time (any thread -- the reference's
+ *     completion handlers arrive off the main thread, AAPLRenderer.mm:1148-1150 -- every entry point selects the
+ *     context's device itself);
+ *   - DIFFERENT contexts, on the same GPU or on different GPUs, may be driven from different threads concurrently;
+ *   - trc_* calls are asynchronous on the context's stream unless they hand host memory back (downloads, trc_get_stats,
+ *     trc_trace_rays, trc_tonemap, trc_synchronize), which wait for the stream.
+ * tests/test_gpu_multicontext.py drives two contexts interleaved and from two threads. */
+typedef struct trc_ctx trc_ctx;
 
 /* ------------------------------------------------------------------ */
 /* device path: libtracer_amd.so                                       */
@@ -458,6 +471,43 @@ trc_status trc_group_allreduce_mean_accum(trc_ctx* ctx);
 trc_status trc_group_reduce_accum_async(trc_ctx* ctx, int root);
 trc_status trc_download_composed(trc_ctx* ctx, float* rgba /* 4*W*H */);
 trc_status trc_group_finalize(trc_ctx* ctx);
+
+/* The collectives behind every trc_group_* / grouped trc_sppm_frames call, as a table.  RCCL (trc_group_init) is the
+ * default; a host that has its own transport -- MPI, a socket mesh, gloo in the Python harness -- or that runs several
+ * ranks on ONE GPU (where RCCL refuses a second rank on a device) installs its own with trc_group_set_collectives and
+ * needs no communicator.  The program of collectives is the same either way:
+ *   compose          reduce(sum, f32, 4*W*H) of the accumulator to the root           (trc_group_reduce_accum[_async])
+ *   sample sharding  allreduce(sum, f32, 4*W*H)                                        (trc_group_allreduce_mean_accum)
+ *   SPPM frame 0     allreduce(min, u32, 3) + allreduce(max, u32, 3) of the bound keys (Photon.metal:169-218's reduction)
+ *   SPPM every frame allgather of the photon records, 512*512/N * 80 bytes per rank    (so that kernelPhotonSumming,
+ *                    Photon.metal:458-496, sees every photon on every rank)
+ * Every function works IN PLACE on `buf`, is called by all ranks in the same order, returns 0 on success, and must
+ * be complete (result visible to work queued later on `stream`) in stream order:
+ *   host_staged = 0: `buf` is DEVICE memory and `stream` the hipStream_t the surrounding work is queued on (enqueue
+ *                    on it, or synchronise it);
+ *   host_staged = 1: the library waits for the stream, copies the buffer into pinned HOST memory, calls the function
+ *                    with that host pointer (stream = NULL; it may block), and copies the result back -- slow,
+ *                    meant for tests, 1-GPU plumbing runs and hosts without a GPU-aware transport.
+ * reduce: the result is defined on `root` only.  allgather: rank r's contribution sits at buf + r * bytes_per_rank on
+ * entry, all of them on return.  dtype / op use ncclDataType_t / ncclRedOp_t ordinals. */
+enum trc_coll_dtype { TRC_DT_U8 = 1, TRC_DT_U32 = 3, TRC_DT_F32 = 7 };
+enum trc_coll_op { TRC_OP_SUM = 0, TRC_OP_MAX = 2, TRC_OP_MIN = 3 };
+typedef struct trc_collectives {
+    void* user;
+    int32_t host_staged;
+    int32_t _pad;
+    int (*reduce)(void* user, void* buf, size_t count, int dtype, int op, int root, void* stream);
+    int (*allreduce)(void* user, void* buf, size_t count, int dtype, int op, void* stream);
+    int (*allgather)(void* user, void* buf, size_t bytes_per_rank, void* stream);
+} trc_collectives;
+/* installs `table` (copied) and makes the context rank `rank` of `nranks`; replaces a communicator made by
+ * trc_group_init.  trc_group_finalize removes it.  table == NULL: same as trc_group_finalize. */
+trc_status trc_group_set_collectives(trc_ctx* ctx, const trc_collectives* table, int nranks, int rank);
+
+/* A/B and test knobs of ONE context (the defaults come from the environment variables of the same upper-case names at
+ * trc_create): "no_lds_fit", "stack_lds_levels", "strip_len", "no_pwg", "sppm_serial_camera" (tools/README.md).
+ * They change scheduling only, never a pixel.  Unknown name: TRC_ERR_INVALID_ARG. */
+trc_status trc_debug_set(trc_ctx* ctx, const char* knob, int value);
 
 /* ------------------------------------------------------------------ */
 /* host path: libtrc_host.so (CPU only)                                */

@@ -1,0 +1,112 @@
+"""One rank of an N-rank run whose ranks SHARE a GPU: the whole trc_group_* / grouped SPPM path with the collectives
+supplied through trc_group_set_collectives (host-staged, gloo between the processes) instead of RCCL, which refuses two
+ranks on one device.  Started by tests/test_gpu_shared_gpu_ranks.py; not a test module itself.
+
+env: RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT, TRC_ROOT, TRC_OUT (directory), TRC_CASE = small | config4 | config5
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.environ["TRC_ROOT"])
+import torch.distributed as dist  # noqa: E402
+
+from tracer_amd import abi, host  # noqa: E402
+from tracer_amd.device import Tracer  # noqa: E402
+from tracer_amd.gloo_collectives import GlooCollectives  # noqa: E402
+
+
+def owner_mask(W, H, world, rank):
+    ty, tx = np.mgrid[0:H, 0:W] // abi.TRC_TILE
+    return ((tx + ty) % world) == rank
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).view(np.uint8).tobytes()).hexdigest()
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    case, outdir = os.environ["TRC_CASE"], os.environ["TRC_OUT"]
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    coll = GlooCollectives()
+    out = {}
+    t = Tracer(0)                                   # every rank on the same GPU
+    if case == "small":
+        W, H, spp = 320, 192, 6
+        scene = host.HostScene(abi.SCENE_CORNELL_SPHERES)
+        t.upload_scene(scene.view); t.set_camera(host.prepare_camera(W, H)); t.set_environment((0.0, 0.0, 0.0)); t.resize(W, H)
+        t.set_collectives(coll, world, rank)
+        # path-traced frame: synchronous compose, then three pipelined steps in flight
+        t.clear_accum(); t.seed(31); t.render(spp=spp, tile_rank=rank, tile_nranks=world); t.group_reduce_accum(0)
+        if rank == 0:
+            out["sync"] = t.download_accum()
+        for step in range(3):
+            t.clear_accum(); t.seed(40 + step); t.render(spp=spp, tile_rank=rank, tile_nranks=world)
+            t.group_reduce_accum_async(0)
+            if rank == 0:
+                out[f"async{step}"] = t.download_composed()
+        # sample sharding: every rank the whole frame with its own seed, allreduce + 1/N
+        t.synchronize(); t.clear_accum(); t.seed(100 + rank); t.render(spp=spp); t.group_allreduce_mean_accum()
+        out["mean"] = t.download_accum()
+        # SPPM: bound keys all-reduced, photon records all-gathered, frame composed
+        t.synchronize(); t.clear_accum(); t.seed(8); t.sppm_init(9); t.sppm_frames(3)
+        cam, pho, mark, count, cx = t.sppm_download()
+        t.group_reduce_accum(0)
+        own = owner_mask(W, H, world, rank).ravel()
+        out["cam_own"] = cam[own].view(np.uint8)
+        out["pho"] = pho.view(np.uint8); out["mark"] = mark; out["count"] = count
+        out["total"] = np.float32(cx.totalPhotonSum); out["box"] = np.array([cx.photonBox.mini.x, cx.photonBox.mini.y, cx.photonBox.mini.z,
+                                                                              cx.photonBox.maxi.x, cx.photonBox.maxi.y, cx.photonBox.maxi.z], np.float32)
+        if rank == 0:
+            out["sppm"] = t.download_accum()
+        out["calls"] = np.array([coll.calls["reduce"], coll.calls["allreduce"], coll.calls["allgather"]])
+    elif case == "config4":
+        # BASELINE config 4 as an N-rank tile split at the named size: Cornell + teapot.obj x 64 (1 005 056 triangles), tracePath
+        W, H, spp = 1920, 1080, 2
+        scene = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.golden("teapot").replicate(8, 80.0))
+        t.upload_scene(scene.view); t.set_camera(host.prepare_camera(W, H)); t.set_environment((0.0, 0.0, 0.0)); t.resize(W, H)
+        t.set_collectives(coll, world, rank)
+        t.clear_accum(); t.seed(0x5EED0004); t.render(spp=spp, tile_rank=rank, tile_nranks=world); t.group_reduce_accum(0)
+        st = t.stats()
+        out["rays"] = np.uint64(st.rays); out["paths"] = np.uint64(st.paths)
+        own = owner_mask(W, H, world, rank)
+        rng = t.download_rng()
+        out["rng_own_sha"] = np.array(sha(rng[own]))
+        if rank == 0:
+            out["frame"] = t.download_accum()
+        # 8 spp more through the persistent-workgroup kernel (>= 8 spp on a tree read from memory), pipelined compose
+        t.clear_accum(); t.seed(0x5EED0005); t.render(spp=8, tile_rank=rank, tile_nranks=world); t.group_reduce_accum_async(0)
+        if rank == 0:
+            out["frame8"] = t.download_composed()
+    elif case == "config5":
+        # BASELINE config 5 as an N-rank split at the named size: SPPM on the config-2 scene, 512^2 photons per frame
+        W, H, frames = 1920, 1080, 4
+        scene = host.HostScene(abi.SCENE_CORNELL_SPHERES)
+        t.upload_scene(scene.view); t.set_camera(host.prepare_camera(W, H)); t.set_environment((0.0, 0.0, 0.0)); t.resize(W, H)
+        t.set_collectives(coll, world, rank)
+        t.clear_accum(); t.seed(0x5EED0050); t.sppm_init(0x5EED0051); t.sppm_frames(frames)
+        cam, pho, mark, count, cx = t.sppm_download()
+        t.group_reduce_accum(0)
+        own = owner_mask(W, H, world, rank).ravel()
+        out["cam_own_sha"] = np.array(sha(cam[own]))
+        out["pho_sha"] = np.array(sha(pho)); out["mark_sha"] = np.array(sha(mark)); out["count_sha"] = np.array(sha(count))
+        out["total"] = np.float32(cx.totalPhotonSum); out["hash_scale"] = np.float32(cx.photonHashScale)
+        rng = t.download_rng().reshape(-1, 4)
+        out["rng_own_sha"] = np.array(sha(rng[own]))
+        if rank == 0:
+            out["frame"] = t.download_accum()
+        out["calls"] = np.array([coll.calls["reduce"], coll.calls["allreduce"], coll.calls["allgather"]])
+    else:
+        raise SystemExit(f"unknown case {case}")
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
+    t.group_finalize()
+    dist.barrier()
+    dist.destroy_process_group()
+    t.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -37,22 +37,34 @@ def test_cpu_rt_weekend_leg_schema():
     assert leg["value"] > 0 and leg["cores"] >= 1 and "400x400x16" in leg["sample"]
 
 
-def test_roofline_extras_only_from_a_summary_of_the_running_library(tmp_path, monkeypatch):
-    """roofline.traffic / roofline_valu come from a committed PMC summary and ONLY if it was collected on the library
-    that is running (source hash + kernel name); a stale summary yields nulls and says why"""
+def test_roofline_only_from_a_summary_of_the_running_library(tmp_path, monkeypatch):
+    """The line's `roofline` (the binding VALU-issue bound, with traffic / hbm_physical_frac) comes from a committed PMC
+    summary and ONLY if it was collected on the library that is running (source hash + kernel name); a stale or missing
+    summary yields an object without numbers that says why.  frac is a fraction of a real peak: never above 1."""
     mine = bench.lib_source_hash()
     good = {"kernel": "k_render<true, false, 0, false>", "lib_source_hash": mine, "hbm_bytes_per_launch": 140000000,
             "GRBM_GUI_ACTIVE": 8 * 52.7e6, "SQ_INSTS_VALU": 17.1e9, "SQ_THREAD_CYCLES_VALU": 17.1e9 * 16, "kernel_ms": 22.0}
     monkeypatch.setattr(bench, "pmc_summary", lambda: dict(good, _file="profiles/rXX/pmc_config2.json"))
-    traffic, frac, valu = bench.roofline_extras(22.0)
-    assert traffic == 140000000 and abs(frac - 140e6 / 22e-3 / 8e12) < 1e-6
-    assert abs(valu["frac"] - 17.1e9 * 2 / (1024 * 52.7e6)) < 1e-3 and abs(valu["lane_utilisation"] - 0.25) < 1e-9
-    assert abs(valu["useful_lane_frac"] - valu["frac"] * 0.25) < 1e-3
+    r = bench.roofline_from_pmc(22.0)
+    assert r["bound"] == "valu-issue" and r["traffic"] == 140000000 and abs(r["hbm_physical_frac"] - 140e6 / 22e-3 / 8e12) < 1e-6
+    assert abs(r["frac"] - 17.1e9 * 2 / (1024 * 52.7e6)) < 1e-3 and abs(r["lane_utilisation"] - 0.25) < 1e-9
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["frac"] <= 1.0
+    assert abs(r["useful_lane_frac"] - r["frac"] * 0.25) < 1e-3 and r["lib_source_hash"] == mine
     monkeypatch.setattr(bench, "pmc_summary", lambda: dict(good, lib_source_hash="0123", _file="x.json"))
-    traffic, frac, valu = bench.roofline_extras(22.0)
-    assert traffic is None and frac is None and "stale" in valu
+    r = bench.roofline_from_pmc(22.0)
+    assert r["frac"] is None and r["traffic"] is None and "stale" in r and r["bound"] == "valu-issue"
     monkeypatch.setattr(bench, "pmc_summary", lambda: None)
-    assert bench.roofline_extras(22.0) == (None, None, None)
+    r = bench.roofline_from_pmc(22.0)
+    assert r["frac"] is None and "stale" in r
+
+
+def test_pmc_summary_is_chosen_by_round_number(tmp_path, monkeypatch):
+    import json
+    for rnd in ("r02", "r09", "r10"):
+        os.makedirs(tmp_path / "profiles" / rnd)
+        (tmp_path / "profiles" / rnd / "pmc_config2.json").write_text(json.dumps({"round": rnd}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.pmc_summary()["round"] == "r10"
 
 
 def test_self_launch_spawns_the_ranks_and_relays_rank0(tmp_path):
@@ -88,10 +100,11 @@ def test_gpu_count_probe_does_not_touch_hip():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("launcher", ["self", "torchrun"])
-def test_two_rank_bench_path_without_rccl(launcher):
-    """bench.py with two ranks sharing cuda:0 (collective switched off automatically: more ranks than GPUs), started by
-    bench.py itself and the way the driver starts N > 1 (torch.distributed.run): rendezvous, BOTH workloads (the named
-    frame tile-sharded = strong, stacked views = weak), tile ownership, max-over-ranks timing, one JSON line."""
+def test_two_rank_bench_path_on_one_gpu(launcher):
+    """bench.py with two ranks sharing cuda:0 (more ranks than GPUs: the compose goes through trc_group_set_collectives
+    with the gloo table instead of RCCL, and the line is marked plumbing), started by bench.py itself and the way the driver
+    starts N > 1 (torch.distributed.run): rendezvous, BOTH workloads (the named frame tile-sharded = strong, stacked views =
+    weak), tile ownership, the pipelined compose, max-over-ranks timing, one JSON line."""
     import json, subprocess, sys
     env = dict(os.environ, TRC_BENCH_NO_RCCL="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
@@ -115,3 +128,5 @@ def test_two_rank_bench_path_without_rccl(launcher):
     weak = line["other_scaling"]
     assert weak["mode"] == "weak" and "2 stacked" in weak["metric"] and weak["frame"] == [1920, 2160]
     assert weak["rays_per_step"] > 4.3e8                                # two views' worth of rays
+    assert line["plumbing"] is True and "PLUMBING" in line["config"]["compose"]
+    assert all(r["compose_ms"] is not None for r in line["per_rank"])   # the reduce really ran (host-staged)

@@ -1,0 +1,138 @@
+"""Every N > 1 path executed with N > 1 on a ONE-GPU box: the ranks are processes sharing cuda:0, and the collectives of
+trc_group_reduce_accum[_async], trc_group_allreduce_mean_accum and the grouped trc_sppm_frames go through the table of
+trc_group_set_collectives (host-staged, gloo between the processes) instead of RCCL, which refuses a second rank on a
+device.  Everything else is the code an 8-GPU run executes: tile ownership, photon index ranges, the reduce / allreduce /
+allgather program, the pipelined two-accumulator compose.  Bar: N ranks == 1 rank, bit for bit -- at a small
+size for 2 and 8 ranks, and at 1920x1080 for BASELINE configs 4 (teapot x 64, 2 spp + 8 spp) and 5 (4 SPPM frames).
+The reference has no counterpart (multi-device is commented out, AAPLRenderer.mm:139-146)."""
+import hashlib
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from tracer_amd import abi, host
+
+pytestmark = pytest.mark.gpu
+WORKER = os.path.join(ROOT, "tests", "_rank_worker.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_ranks(case, world, outdir, timeout=900):
+    os.makedirs(outdir, exist_ok=True)
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), TRC_ROOT=ROOT, TRC_OUT=str(outdir), TRC_CASE=case, OMP_NUM_THREADS="4",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, WORKER], env=env))
+    try:
+        for p in procs:
+            assert p.wait(timeout=timeout) == 0, f"a rank of {case} x{world} failed"
+    finally:
+        for p in procs:                      # our own children, by PID
+            if p.poll() is None:
+                p.kill()
+    return [np.load(os.path.join(outdir, f"rank{r}.npz")) for r in range(world)]
+
+
+def owner_mask(W, H, world, rank):
+    ty, tx = np.mgrid[0:H, 0:W] // abi.TRC_TILE
+    return ((tx + ty) % world) == rank
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).view(np.uint8).tobytes()).hexdigest()
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_every_group_call_with_n_ranks_on_one_gpu(gpu, tmp_path, world):
+    res = run_ranks("small", world, tmp_path / f"small{world}")
+    W, H, spp = 320, 192, 6
+    scene = host.HostScene(abi.SCENE_CORNELL_SPHERES)
+    gpu.upload_scene(scene.view); gpu.set_camera(host.prepare_camera(W, H)); gpu.set_environment((0.0, 0.0, 0.0)); gpu.resize(W, H)
+    gpu.clear_accum(); gpu.seed(31); gpu.render(spp=spp)
+    assert np.array_equal(bits(res[0]["sync"]), bits(gpu.download_accum()))
+    for step in range(3):
+        gpu.clear_accum(); gpu.seed(40 + step); gpu.render(spp=spp)
+        assert np.array_equal(bits(res[0][f"async{step}"]), bits(gpu.download_accum())), step
+    # sample sharding: mean of the ranks' whole frames; every rank holds the same result.  The float sum over ranks is
+    # order-dependent in general -- gloo's is not specified -- so compare with the float64 mean to a few ulp
+    frames = []
+    for r in range(world):
+        gpu.clear_accum(); gpu.seed(100 + r); gpu.render(spp=spp)
+        frames.append(gpu.download_accum()[..., :3].astype(np.float64))
+    want = np.mean(frames, axis=0)
+    for r in range(world):
+        got = res[r]["mean"][..., :3].astype(np.float64)
+        assert np.allclose(got, want, rtol=2e-6, atol=1e-7)
+        assert np.array_equal(bits(res[r]["mean"]), bits(res[0]["mean"]))
+    # SPPM
+    gpu.clear_accum(); gpu.seed(8); gpu.sppm_init(9); gpu.sppm_frames(3)
+    cam, pho, mark, count, cx = gpu.sppm_download()
+    assert np.array_equal(bits(res[0]["sppm"]), bits(gpu.download_accum()))
+    for r in range(world):
+        own = owner_mask(W, H, world, r).ravel()
+        assert np.array_equal(res[r]["cam_own"], cam[own].view(np.uint8)), r
+        assert np.array_equal(res[r]["pho"], pho.view(np.uint8)) and np.array_equal(res[r]["count"], count)
+        assert np.array_equal(bits(res[r]["mark"]), bits(mark))
+        assert res[r]["total"] == np.float32(cx.totalPhotonSum)
+        box = np.array([cx.photonBox.mini.x, cx.photonBox.mini.y, cx.photonBox.mini.z,
+                        cx.photonBox.maxi.x, cx.photonBox.maxi.y, cx.photonBox.maxi.z], np.float32)
+        assert np.array_equal(bits(res[r]["box"]), bits(box))
+        # the collective program of SURVEY 8e: 1 + 3 + 1 reduces, 1 + 2 all-reduces, 3 all-gathers
+        assert list(res[r]["calls"]) == [5, 3, 3]
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_config4_as_an_n_rank_tile_split_at_1080p(gpu, tmp_path, world):
+    res = run_ranks("config4", world, tmp_path / f"c4_{world}", timeout=1500)
+    W, H = 1920, 1080
+    scene = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.golden("teapot").replicate(8, 80.0))
+    gpu.upload_scene(scene.view); gpu.set_camera(host.prepare_camera(W, H)); gpu.set_environment((0.0, 0.0, 0.0)); gpu.resize(W, H)
+    gpu.reset_stats()
+    gpu.clear_accum(); gpu.seed(0x5EED0004); gpu.render(spp=2)
+    one = gpu.download_accum()
+    st = gpu.stats()
+    rng = gpu.download_rng()
+    assert np.array_equal(bits(res[0]["frame"]), bits(one))
+    assert sum(int(r["rays"]) for r in res) == st.rays and sum(int(r["paths"]) for r in res) == st.paths == W * H * 2
+    for r in range(world):
+        assert str(res[r]["rng_own_sha"]) == sha(rng[owner_mask(W, H, world, r)]), r
+    gpu.clear_accum(); gpu.seed(0x5EED0005); gpu.render(spp=8)
+    assert np.array_equal(bits(res[0]["frame8"]), bits(gpu.download_accum()))
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_config5_sppm_as_an_n_rank_split_at_1080p(gpu, tmp_path, world):
+    res = run_ranks("config5", world, tmp_path / f"c5_{world}", timeout=1500)
+    W, H, frames = 1920, 1080, 4
+    scene = host.HostScene(abi.SCENE_CORNELL_SPHERES)
+    gpu.upload_scene(scene.view); gpu.set_camera(host.prepare_camera(W, H)); gpu.set_environment((0.0, 0.0, 0.0)); gpu.resize(W, H)
+    gpu.clear_accum(); gpu.seed(0x5EED0050); gpu.sppm_init(0x5EED0051); gpu.sppm_frames(frames)
+    cam, pho, mark, count, cx = gpu.sppm_download()
+    rng = gpu.download_rng().reshape(-1, 4)
+    assert np.array_equal(bits(res[0]["frame"]), bits(gpu.download_accum()))
+    for r in range(world):
+        own = owner_mask(W, H, world, r).ravel()
+        assert str(res[r]["cam_own_sha"]) == sha(cam[own]), r
+        assert str(res[r]["rng_own_sha"]) == sha(rng[own]), r
+        assert str(res[r]["pho_sha"]) == sha(pho) and str(res[r]["mark_sha"]) == sha(mark) and str(res[r]["count_sha"]) == sha(count), r
+        assert res[r]["total"] == np.float32(cx.totalPhotonSum) and res[r]["hash_scale"] == np.float32(cx.photonHashScale)
+        assert list(res[r]["calls"]) == [1, 2, frames]

@@ -7,10 +7,13 @@ Triangle,Texture,Material,Camera}.hh (see the header for file:line).
 """
 import ctypes as C
 
-TRC_ABI_VERSION = 1
+TRC_ABI_VERSION = 3
 TRC_TILE = 16
 TRC_MAX_BVH_DEPTH = 64
 TRC_UNIQUE_ID_BYTES = 128
+# enum trc_coll_dtype / trc_coll_op (ncclDataType_t / ncclRedOp_t ordinals)
+DT_U8, DT_U32, DT_F32 = 1, 3, 7
+OP_SUM, OP_MAX, OP_MIN = 0, 2, 3
 
 # enum trc_PrimitiveType (BVH.hh:6-8)
 PRIM_SPHERE, PRIM_SQUARE, PRIM_CUBE, PRIM_TRIANGLE, PRIM_BVH, PRIM_UNKNOW = range(6)
@@ -200,6 +203,7 @@ DEVICE_SYMBOLS = [
     "trc_render", "trc_synchronize", "trc_trace_rays", "trc_get_stats", "trc_reset_stats", "trc_debug_profile",
     "trc_sppm_init", "trc_sppm_frames", "trc_sppm_download", "trc_sppm_hash_cells",
     "trc_device_info", "trc_group_unique_id", "trc_group_init", "trc_group_reduce_accum", "trc_group_reduce_accum_async", "trc_group_allreduce_mean_accum", "trc_download_composed", "trc_group_finalize",
+    "trc_group_set_collectives", "trc_debug_set",
 ]
 HOST_SYMBOLS = [
     "trc_host_build_node", "trc_host_build_tree", "trc_host_tree_depth", "trc_host_make_camera",

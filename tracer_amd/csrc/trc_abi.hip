@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -563,13 +564,14 @@ hipEvent_t get_event(trc_ctx* ctx) {
 void collect_finished_events(trc_ctx* ctx) {
     size_t done = 0;
     for (; done < ctx->pending.size(); ++done) {
-        if (hipEventQuery(ctx->pending[done].second) != hipSuccess) break;
+        const hipError_t q = hipEventQuery(ctx->pending[done].second);
+        if (q == hipErrorNotReady) { (void)hipGetLastError(); break; }      // "not ready" is reported through the sticky error too
+        if (q != hipSuccess) break;                                        // a real error stays for the caller's next check
         float ms = 0.0f;
         if (hipEventElapsedTime(&ms, ctx->pending[done].first, ctx->pending[done].second) == hipSuccess) ctx->kernel_ms += ms;
         ctx->event_pool.push_back(ctx->pending[done].first);
         ctx->event_pool.push_back(ctx->pending[done].second);
     }
-    (void)hipGetLastError();          // hipEventQuery reports hipErrorNotReady through the sticky error too
     ctx->pending.erase(ctx->pending.begin(), ctx->pending.begin() + (ptrdiff_t)done);
 }
 
@@ -683,7 +685,10 @@ std::vector<uint32_t> make_tiles(uint32_t W, uint32_t H, uint32_t nranks, uint32
 
 Rccl g_rccl;
 
+// the one piece of process-wide state: resolved once, under a lock (contexts may be created from several threads)
+static std::mutex g_rccl_lock;
 bool trc_load_rccl(std::string& err) {
+    std::lock_guard<std::mutex> guard(g_rccl_lock);
     Rccl& r = g_rccl;
     if (r.ready) return true;
     if (r.handle) { dlclose(r.handle); r = Rccl{}; }        // an earlier attempt found the library but not every symbol
@@ -726,10 +731,8 @@ size_t trc_dyn_lds_bytes(const trc_ctx* ctx, bool stats) { return dyn_lds_bytes(
 // held at 4 by LDS; 34.9 -> 32.8 ms per 32-spp launch once it fits.
 constexpr uint32_t kStackLdsLevels = 16;
 static void plan_launch_lds(const trc_ctx* ctx, DScene& sc, uint32_t waves_per_simd, bool hybrid) {
-    static const bool off = std::getenv("TRC_NO_LDS_FIT") != nullptr;                 // A/B knobs
-    static const char* lv = std::getenv("TRC_STACK_LDS_LEVELS");
-    if (off) return;
-    const uint32_t levels = lv && std::atoi(lv) > 0 ? (uint32_t)std::atoi(lv) : kStackLdsLevels;
+    if (ctx->knobs.no_lds_fit) return;                                                 // A/B knobs (trc_debug_set)
+    const uint32_t levels = ctx->knobs.stack_lds_levels > 0 ? (uint32_t)ctx->knobs.stack_lds_levels : kStackLdsLevels;
     if (hybrid) sc.stack_lds = std::min(sc.stack_depth, levels);
     if (!ctx->lds_prefix_ok) return;                                                   // all or nothing was decided at upload
     const uint32_t per_wg = ((160u * 1024u / 4u) / (4u * waves_per_simd)) & ~127u;     // dwords; LDS is granted in 512-byte units
@@ -743,9 +746,8 @@ static void plan_launch_lds(const trc_ctx* ctx, DScene& sc, uint32_t waves_per_s
 // LDS plan of a persistent-workgroup launch (k_render_pwg): `waves` wavefronts share one staged prefix; the workgroup's
 // share of the CU's 160 KB minus the wavefronts' stacks is all node prefix.  False when even one node does not fit.
 constexpr uint32_t kPwgStackLdsLevels = 16;      // 4 / 8 / 16 entries per lane in LDS: 33.5 / 31.1 / 30.8 ms on the 1 M-triangle scene
-static bool plan_pwg_lds(DScene& sc, uint32_t waves, uint32_t per_cu, bool hybrid) {
-    static const char* lv = std::getenv("TRC_STACK_LDS_LEVELS");
-    const uint32_t levels = lv && std::atoi(lv) > 0 ? (uint32_t)std::atoi(lv) : kPwgStackLdsLevels;
+static bool plan_pwg_lds(const trc_ctx* ctx, DScene& sc, uint32_t waves, uint32_t per_cu, bool hybrid) {
+    const uint32_t levels = ctx->knobs.stack_lds_levels > 0 ? (uint32_t)ctx->knobs.stack_lds_levels : kPwgStackLdsLevels;
     DScene t = sc;
     if (hybrid) t.stack_lds = std::min(t.stack_depth, levels);
     const uint32_t per_wg = ((160u * 1024u / 4u) / per_cu) & ~127u;
@@ -840,11 +842,13 @@ void launch_render(trc_ctx* ctx, const KRender& kp, bool stats, uint32_t integra
 // persistent workgroups (k_render_pwg): grid = workgroups the GPU holds at once, block = the workgroup's wavefronts
 template <int INTEGRATOR, bool SOBOL>
 hipError_t launch_pwg_one(trc_ctx* ctx, const KRender& kp, uint32_t grid, size_t lds) {
-    static size_t granted = 0;                 // more than 64 KB of dynamic LDS has to be asked for once per kernel
-    if (lds > granted) {
+    // more than 64 KB of dynamic LDS has to be asked for once per kernel AND per device (the attribute is set on the
+    // current device's copy of the function): remembered in the context, which is bound to one device
+    const uint32_t bit = 1u << (INTEGRATOR * 2 + (SOBOL ? 1 : 0));
+    if (lds > 64 * 1024 && !(ctx->pwg_lds_granted & bit)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render_pwg<INTEGRATOR, SOBOL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         if (e != hipSuccess) return e;
-        granted = 160 * 1024;
+        ctx->pwg_lds_granted |= bit;
     }
     hipLaunchKernelGGL((k_render_pwg<INTEGRATOR, SOBOL>), dim3(grid), dim3(64 * pwg_waves(INTEGRATOR)), lds, ctx->stream, kp);
     return hipSuccess;
@@ -858,6 +862,82 @@ hipError_t launch_render_pwg(trc_ctx* ctx, const KRender& kp, uint32_t integrato
 }
 
 }  // namespace
+
+// ----------------------------------------------------------------------- collectives: RCCL or the caller's table
+namespace {
+
+size_t dtype_bytes(int dtype) { return dtype == kNcclUint8 ? 1 : 4; }
+
+std::string rccl_error(const char* what, int rc) {
+    return std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+}
+
+// host-staged table call: wait for the producers on `st`, bring `bytes` at `buf` to pinned host memory, let the caller's
+// function work on it, put the result back (only where the collective defines one)
+template <typename Call>
+trc_status staged(trc_ctx* ctx, void* buf, size_t bytes, bool copy_back, hipStream_t st, const char* what, Call&& call) {
+    if (bytes > ctx->h_stage_bytes) {
+        if (ctx->h_stage) { (void)hipHostFree(ctx->h_stage); ctx->h_stage = nullptr; ctx->h_stage_bytes = 0; }
+        HIP_TRY(ctx, hipHostMalloc(&ctx->h_stage, bytes, hipHostMallocDefault));
+        ctx->h_stage_bytes = bytes;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_stage, buf, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    const int rc = call(ctx->h_stage);
+    if (rc != 0) return trc_fail(ctx, TRC_ERR_RCCL, std::string(what) + ": the caller's collective returned " + std::to_string(rc));
+    if (copy_back) {
+        HIP_TRY(ctx, hipMemcpyAsync(buf, ctx->h_stage, bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));          // the staging buffer is reused by the next collective
+    }
+    return TRC_OK;
+}
+
+}  // namespace
+
+trc_status trc_coll_reduce(trc_ctx* ctx, void* buf, size_t count, int dtype, int op, int root, hipStream_t st, const char* what) {
+    if (ctx->coll_active) {
+        const trc_collectives& c = ctx->coll;
+        if (!c.host_staged) {
+            const int rc = c.reduce(c.user, buf, count, dtype, op, root, (void*)st);
+            return rc == 0 ? TRC_OK : trc_fail(ctx, TRC_ERR_RCCL, std::string(what) + ": the caller's collective returned " + std::to_string(rc));
+        }
+        return staged(ctx, buf, count * dtype_bytes(dtype), ctx->rank == root, st, what,
+                      [&](void* h) { return c.reduce(c.user, h, count, dtype, op, root, nullptr); });
+    }
+    if (!ctx->comm) return trc_fail(ctx, TRC_ERR_RCCL, std::string(what) + " before trc_group_init / trc_group_set_collectives");
+    const int rc = g_rccl.Reduce(buf, buf, count, dtype, op, root, ctx->comm, st);      // in place on the root (sendbuff == recvbuff is allowed)
+    return rc == 0 ? TRC_OK : trc_fail(ctx, TRC_ERR_RCCL, rccl_error(what, rc));
+}
+
+trc_status trc_coll_allreduce(trc_ctx* ctx, void* buf, size_t count, int dtype, int op, hipStream_t st, const char* what) {
+    if (ctx->coll_active) {
+        const trc_collectives& c = ctx->coll;
+        if (!c.host_staged) {
+            const int rc = c.allreduce(c.user, buf, count, dtype, op, (void*)st);
+            return rc == 0 ? TRC_OK : trc_fail(ctx, TRC_ERR_RCCL, std::string(what) + ": the caller's collective returned " + std::to_string(rc));
+        }
+        return staged(ctx, buf, count * dtype_bytes(dtype), true, st, what,
+                      [&](void* h) { return c.allreduce(c.user, h, count, dtype, op, nullptr); });
+    }
+    if (!ctx->comm) return trc_fail(ctx, TRC_ERR_RCCL, std::string(what) + " before trc_group_init / trc_group_set_collectives");
+    const int rc = g_rccl.AllReduce(buf, buf, count, dtype, op, ctx->comm, st);
+    return rc == 0 ? TRC_OK : trc_fail(ctx, TRC_ERR_RCCL, rccl_error(what, rc));
+}
+
+trc_status trc_coll_allgather(trc_ctx* ctx, void* buf, size_t bytes_per_rank, hipStream_t st, const char* what) {
+    if (ctx->coll_active) {
+        const trc_collectives& c = ctx->coll;
+        if (!c.host_staged) {
+            const int rc = c.allgather(c.user, buf, bytes_per_rank, (void*)st);
+            return rc == 0 ? TRC_OK : trc_fail(ctx, TRC_ERR_RCCL, std::string(what) + ": the caller's collective returned " + std::to_string(rc));
+        }
+        return staged(ctx, buf, bytes_per_rank * (size_t)ctx->nranks, true, st, what,
+                      [&](void* h) { return c.allgather(c.user, h, bytes_per_rank, nullptr); });
+    }
+    if (!ctx->comm) return trc_fail(ctx, TRC_ERR_RCCL, std::string(what) + " before trc_group_init / trc_group_set_collectives");
+    const int rc = g_rccl.AllGather(static_cast<char*>(buf) + (size_t)ctx->rank * bytes_per_rank, buf, bytes_per_rank, kNcclUint8, ctx->comm, st);
+    return rc == 0 ? TRC_OK : trc_fail(ctx, TRC_ERR_RCCL, rccl_error(what, rc));
+}
 
 // ======================================================================= C ABI
 extern "C" {
@@ -902,6 +982,17 @@ trc_status trc_create(int device, trc_ctx** out) {
     ctx->device = device;
     { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess) ctx->cu_count = cus; }
     if (ctx->cu_count <= 0) ctx->cu_count = 256;
+    {
+        auto env_int = [](const char* name, bool flag) {
+            const char* v = std::getenv(name);
+            return !v ? 0 : flag ? 1 : std::max(0, std::atoi(v));
+        };
+        ctx->knobs.no_lds_fit = env_int("TRC_NO_LDS_FIT", true);
+        ctx->knobs.stack_lds_levels = env_int("TRC_STACK_LDS_LEVELS", false);
+        ctx->knobs.strip_len = env_int("TRC_STRIP_LEN", false);
+        ctx->knobs.no_pwg = env_int("TRC_NO_PWG", true);
+        ctx->knobs.sppm_serial_camera = env_int("TRC_SPPM_SERIAL_CAMERA", true);
+    }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void**)&ctx->d_stats, sizeof(unsigned long long) * kStatRows * kStatRowStride) != hipSuccess ||
         hipMalloc((void**)&ctx->d_stats_sum, sizeof(unsigned long long) * kStatRowStride) != hipSuccess ||
@@ -927,6 +1018,7 @@ void trc_destroy(trc_ctx* ctx) {
     (void)hipFree(ctx->d_block_cost); (void)hipFree(ctx->d_order_hist);
     for (int k = 0; k < 2; ++k) { (void)hipFree(ctx->d_order_keys[k]); (void)hipFree(ctx->d_order_vals[k]); }
     (void)hipFree(ctx->d_accum_alt); (void)hipFree(ctx->d_stack_ovf); (void)hipFree(ctx->d_queue);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     for (hipEvent_t e : {ctx->ev_rendered, ctx->ev_busy, ctx->ev_busy_alt}) if (e) (void)hipEventDestroy(e);
     if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1054,6 +1146,7 @@ trc_status trc_seed(trc_ctx* ctx, uint64_t seed) {
     if (!ctx->d_rng) return fail(ctx, TRC_ERR_NO_FRAME, "trc_seed before trc_resize");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint32_t n = ctx->width * ctx->height;
+    trc_sppm_order_after_camera(ctx);
     hipLaunchKernelGGL(k_seed, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_rng, n, seed);
     HIP_TRY(ctx, hipGetLastError());
     return TRC_OK;
@@ -1064,6 +1157,7 @@ static trc_status copy_frame(trc_ctx* ctx, void* dev, void* host, bool to_device
     if (!dev) return fail(ctx, TRC_ERR_NO_FRAME, "frame buffers not allocated (trc_resize)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t bytes = (size_t)ctx->width * ctx->height * 16;
+    trc_sppm_order_after_camera(ctx);
     if (to_device) HIP_TRY(ctx, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     else HIP_TRY(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1129,6 +1223,7 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
         return fail(ctx, TRC_ERR_INVALID_ARG, "traceMIS / traceVolume sample squareList[5] and [6] (Render.metal:320-324,172-176)");
     if (p->spp == 0) return TRC_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    collect_finished_events(ctx);        // before any launch of this call: it may consume a "not ready" sticky error
 
     // Launch geometry.  One 8x8 block per wavefront fills the GPU when there are many more blocks than wavefront slots
     // (32 400 blocks for 4 096 slots at 1080p).  A rank that owns 1/N of the frame (strong scaling) has about one block
@@ -1182,8 +1277,7 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
         // pixels of k_render_strip: strip 2: 37.6 / 28.4, 3: 36.6 / 29.7, 4: 37.5 / 31.5, >= 5: 38.8 / 35.6 -- longer strips
         // leave too few workgroups (the frame has 32 400 blocks for 4 096 wavefront slots); one block per wavefront: 80.8 / 33.0
         uint32_t want = p->spp <= 2 ? 3u : p->spp < 8 ? 2u : 1u;
-        static const char* strip_env = std::getenv("TRC_STRIP_LEN");           // A/B knob: blocks per wavefront, any spp
-        if (strip_env && std::atoi(strip_env) > 0) want = (uint32_t)std::atoi(strip_env);
+        if (ctx->knobs.strip_len > 0) want = (uint32_t)ctx->knobs.strip_len;   // A/B knob: blocks per wavefront, any spp
         const uint32_t slots = (uint32_t)ctx->cu_count * 16u;
         const uint32_t room = ctx->n_tiles / (slots + slots / 2u);          // keep >= 1.5 workgroups per slot
         kp.strip = std::max(1u, std::min(want, room));
@@ -1227,11 +1321,10 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
     if (!stats && !ctx->lds_scene) {
         const bool strip = kp.strip > 1;
         const bool is_path = p->integrator == TRC_INTEGRATOR_PATH;
-        static const bool no_pwg = std::getenv("TRC_NO_PWG") != nullptr;                // A/B knob
-        if (!no_pwg && !strip && ctx->lds_prefix_ok) {
+        if (!ctx->knobs.no_pwg && !strip && ctx->lds_prefix_ok) {                       // no_pwg: A/B knob
             pwg_waves_n = (uint32_t)pwg_waves((int)p->integrator);
             const uint32_t per_cu = (uint32_t)pwg_per_cu((int)p->integrator);
-            pwg = plan_pwg_lds(kp.ks.sc, pwg_waves_n, per_cu, is_path);
+            pwg = plan_pwg_lds(ctx, kp.ks.sc, pwg_waves_n, per_cu, is_path);
             pwg_grid = std::min((uint32_t)ctx->cu_count * per_cu, (ctx->n_tiles + pwg_waves_n - 1) / pwg_waves_n);   // small frames: no idle workgroups
         }
         if (!pwg) {
@@ -1257,7 +1350,7 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
         kp.queue = ctx->d_queue;
     }
 
-    collect_finished_events(ctx);
+    HIP_TRY(ctx, hipGetLastError());     // the order / sort / memset launches above
     hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);
     auto give_back = [&]() { if (e0) ctx->event_pool.push_back(e0); if (e1) ctx->event_pool.push_back(e1); };
     if (!e0 || !e1) { give_back(); return fail(ctx, TRC_ERR_HIP, "hipEventCreate failed"); }
@@ -1392,6 +1485,7 @@ trc_status trc_group_init(trc_ctx* ctx, const uint8_t id[TRC_UNIQUE_ID_BYTES], i
     if (!trc_load_rccl(err)) return fail(ctx, TRC_ERR_RCCL, err);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->comm) { g_rccl.CommDestroy(ctx->comm); ctx->comm = nullptr; }
+    ctx->coll_active = false;
     IdBlob blob;
     std::memcpy(&blob, id, TRC_UNIQUE_ID_BYTES);
     int rc = g_rccl.CommInitRank(&ctx->comm, nranks, blob, rank);
@@ -1405,15 +1499,12 @@ trc_status trc_group_init(trc_ctx* ctx, const uint8_t id[TRC_UNIQUE_ID_BYTES], i
 
 trc_status trc_group_reduce_accum(trc_ctx* ctx, int root) {
     if (!ctx) return TRC_ERR_INVALID_ARG;
-    if (!ctx->comm) return fail(ctx, TRC_ERR_RCCL, "trc_group_reduce_accum before trc_group_init");
+    if (!ctx->grouped()) return fail(ctx, TRC_ERR_RCCL, "trc_group_reduce_accum before trc_group_init / trc_group_set_collectives");
     if (!ctx->d_accum) return fail(ctx, TRC_ERR_NO_FRAME, "no frame");
     if (root < 0 || root >= ctx->nranks) return TRC_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t count = (size_t)ctx->width * ctx->height * 4;
-    // ncclFloat = 7, ncclSum = 0; in place on the root (sendbuff == recvbuff is allowed)
-    int rc = g_rccl.Reduce(ctx->d_accum, ctx->d_accum, count, 7, 0, root, ctx->comm, ctx->stream);
-    if (rc != 0) return fail(ctx, TRC_ERR_RCCL, std::string("ncclReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
-    return TRC_OK;
+    return trc_coll_reduce(ctx, ctx->d_accum, count, kNcclFloat, kNcclSum, root, ctx->stream, "reduce(sum) of the accumulator");
 }
 
 // Sample sharding (the alternative to tile sharding): every rank has rendered ALL pixels with its own share
@@ -1427,12 +1518,11 @@ __global__ void __launch_bounds__(256) k_scale_rgb(float4* accum, size_t n, floa
 }
 trc_status trc_group_allreduce_mean_accum(trc_ctx* ctx) {
     if (!ctx) return TRC_ERR_INVALID_ARG;
-    if (!ctx->comm) return fail(ctx, TRC_ERR_RCCL, "trc_group_allreduce_mean_accum before trc_group_init");
+    if (!ctx->grouped()) return fail(ctx, TRC_ERR_RCCL, "trc_group_allreduce_mean_accum before trc_group_init / trc_group_set_collectives");
     if (!ctx->d_accum) return fail(ctx, TRC_ERR_NO_FRAME, "no frame");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t pixels = (size_t)ctx->width * ctx->height;
-    int rc = g_rccl.AllReduce(ctx->d_accum, ctx->d_accum, pixels * 4, kNcclFloat, kNcclSum, ctx->comm, ctx->stream);
-    if (rc != 0) return fail(ctx, TRC_ERR_RCCL, std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
+    { trc_status cs = trc_coll_allreduce(ctx, ctx->d_accum, pixels * 4, kNcclFloat, kNcclSum, ctx->stream, "allreduce(sum) of the accumulator"); if (cs != TRC_OK) return cs; }
     hipLaunchKernelGGL(k_scale_rgb, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, ctx->stream,
                        reinterpret_cast<float4*>(ctx->d_accum), pixels, 1.0f / (float)ctx->nranks);
     HIP_TRY(ctx, hipGetLastError());
@@ -1444,7 +1534,7 @@ trc_status trc_group_allreduce_mean_accum(trc_ctx* ctx) {
 // hides under the next step's render instead of adding to it.
 trc_status trc_group_reduce_accum_async(trc_ctx* ctx, int root) {
     if (!ctx) return TRC_ERR_INVALID_ARG;
-    if (!ctx->comm) return fail(ctx, TRC_ERR_RCCL, "trc_group_reduce_accum_async before trc_group_init");
+    if (!ctx->grouped()) return fail(ctx, TRC_ERR_RCCL, "trc_group_reduce_accum_async before trc_group_init / trc_group_set_collectives");
     if (!ctx->d_accum) return fail(ctx, TRC_ERR_NO_FRAME, "no frame");
     if (root < 0 || root >= ctx->nranks) return TRC_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1463,8 +1553,7 @@ trc_status trc_group_reduce_accum_async(trc_ctx* ctx, int root) {
     // reduce the current accumulator once everything queued so far on the render stream has finished
     HIP_TRY(ctx, hipEventRecord(ctx->ev_rendered, ctx->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_rendered, 0));
-    int rc = g_rccl.Reduce(ctx->d_accum, ctx->d_accum, count, kNcclFloat, kNcclSum, root, ctx->comm, ctx->comm_stream);
-    if (rc != 0) return fail(ctx, TRC_ERR_RCCL, std::string("ncclReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
+    { trc_status cs = trc_coll_reduce(ctx, ctx->d_accum, count, kNcclFloat, kNcclSum, root, ctx->comm_stream, "reduce(sum) of the accumulator"); if (cs != TRC_OK) return cs; }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_busy, ctx->comm_stream));
     ctx->busy = true;
     ctx->d_composed = ctx->d_accum;
@@ -1487,14 +1576,41 @@ trc_status trc_download_composed(trc_ctx* ctx, float* rgba) {
 
 trc_status trc_group_finalize(trc_ctx* ctx) {
     if (!ctx) return TRC_ERR_INVALID_ARG;
-    if (ctx->comm) {
+    if (ctx->grouped()) {
         (void)hipSetDevice(ctx->device);
         if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
         (void)hipStreamSynchronize(ctx->stream);
-        g_rccl.CommDestroy(ctx->comm);
+        if (ctx->comm) g_rccl.CommDestroy(ctx->comm);
         ctx->comm = nullptr;
+        ctx->coll_active = false;
     }
     ctx->nranks = 1; ctx->rank = 0;
+    return TRC_OK;
+}
+
+trc_status trc_group_set_collectives(trc_ctx* ctx, const trc_collectives* table, int nranks, int rank) {
+    if (!ctx) return TRC_ERR_INVALID_ARG;
+    if (!table) return trc_group_finalize(ctx);
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, TRC_ERR_INVALID_ARG, "trc_group_set_collectives: rank / nranks");
+    if (!table->reduce || !table->allreduce || !table->allgather) return fail(ctx, TRC_ERR_INVALID_ARG, "trc_group_set_collectives: the table needs reduce, allreduce and allgather");
+    { trc_status fs = trc_group_finalize(ctx); if (fs != TRC_OK) return fs; }
+    ctx->coll = *table;
+    ctx->coll_active = true;
+    ctx->nranks = nranks; ctx->rank = rank;
+    return TRC_OK;
+}
+
+trc_status trc_debug_set(trc_ctx* ctx, const char* knob, int value) {
+    if (!ctx || !knob) return TRC_ERR_INVALID_ARG;
+    const std::string k(knob);
+    int* slot = k == "no_lds_fit" ? &ctx->knobs.no_lds_fit : k == "stack_lds_levels" ? &ctx->knobs.stack_lds_levels
+              : k == "strip_len" ? &ctx->knobs.strip_len : k == "no_pwg" ? &ctx->knobs.no_pwg
+              : k == "sppm_serial_camera" ? &ctx->knobs.sppm_serial_camera : nullptr;
+    if (!slot) return fail(ctx, TRC_ERR_INVALID_ARG, "trc_debug_set: unknown knob " + k);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // a launch in flight keeps the plan it was made with
+    *slot = value < 0 ? 0 : value;
+    ctx->cost_valid = false;                               // block costs recorded under another launch geometry say nothing
     return TRC_OK;
 }
 

@@ -168,6 +168,21 @@ struct trc_ctx {
     bool busy = false, busy_alt = false;
 
     SppmState* sppm = nullptr;       // trc_sppm.hip
+
+    // caller-supplied collectives (trc_group_set_collectives) instead of an RCCL communicator
+    trc_collectives coll{};
+    bool coll_active = false;
+    void* h_stage = nullptr;            // pinned staging buffer of host-staged collectives
+    size_t h_stage_bytes = 0;
+
+    // A/B and test knobs, per context: defaults from the environment at trc_create (TRC_NO_LDS_FIT, TRC_STACK_LDS_LEVELS,
+    // TRC_STRIP_LEN, TRC_NO_PWG, TRC_SPPM_SERIAL_CAMERA), changed through trc_debug_set
+    struct Knobs { int no_lds_fit = 0, stack_lds_levels = 0, strip_len = 0, no_pwg = 0, sppm_serial_camera = 0; } knobs;
+    // k_render_pwg instantiations that were granted > 64 KB of dynamic LDS on THIS context's device (bit = integrator * 2 +
+    // sobol): hipFuncSetAttribute applies to the current device only, so the grant is per context, not per process
+    uint32_t pwg_lds_granted = 0;
+
+    bool grouped() const { return comm != nullptr || coll_active; }
 };
 
 
@@ -201,6 +216,12 @@ bool trc_load_rccl(std::string& err);
 // ncclDataType_t / ncclRedOp_t ordinals (rccl.h:448-466)
 constexpr int kNcclUint8 = 1, kNcclUint32 = 3, kNcclFloat = 7, kNcclSum = 0, kNcclMax = 2, kNcclMin = 3;
 
+// The three collectives the group calls need, in place on device buffers, through RCCL (ctx->comm) or the caller's table
+// (ctx->coll; host-staged tables get the data in pinned host memory).  `what` names the call in error messages.
+trc_status trc_coll_reduce(trc_ctx* ctx, void* buf, size_t count, int dtype, int op, int root, hipStream_t st, const char* what);
+trc_status trc_coll_allreduce(trc_ctx* ctx, void* buf, size_t count, int dtype, int op, hipStream_t st, const char* what);
+trc_status trc_coll_allgather(trc_ctx* ctx, void* buf, size_t bytes_per_rank, hipStream_t st, const char* what);
+
 // tiles owned by `rank` of `nranks` (XCD-aware order) uploaded into ctx->d_tiles; shared by render and SPPM
 trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32_t view_height = 0, uint32_t blk_shift = 3);
 size_t trc_dyn_lds_bytes(const trc_ctx* ctx, bool stats);
@@ -208,3 +229,4 @@ size_t trc_dyn_lds_bytes(const trc_ctx* ctx, bool stats);
 void trc_sort_pairs24(hipStream_t st, uint32_t* keys[2], uint32_t* vals[2], uint32_t* hist, uint32_t* digit_base, uint32_t n, int* result);
 uint32_t trc_sort_hist_words(uint32_t n);
 void trc_sppm_release(trc_ctx* ctx);   // frees ctx->sppm (no-op when absent)
+void trc_sppm_order_after_camera(trc_ctx* ctx);   // context stream waits for a camera pass running ahead (no-op when none)

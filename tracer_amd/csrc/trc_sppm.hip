@@ -550,12 +550,20 @@ struct SppmState {
     hipStream_t cam_stream = nullptr;    // the camera pass of the next odd frame runs here, beside the current frame
     hipEvent_t ev_main = nullptr, ev_cam = nullptr;
     uint32_t cam_ahead = 0;          // frame whose camera pass is already in flight on cam_stream (0 = none)
+    bool poisoned = false;           // a frame failed half-way (collective / HIP error): the pass state is undefined
     trc_PhotonRecord* d_pho = nullptr;
     uint32_t* d_mark = nullptr;
     uint32_t* d_count = nullptr;
     float4* d_cells = nullptr;       // gather table of k_sppm_table
     DComplex* d_cx = nullptr;
 };
+
+// a camera pass running ahead on its own stream reads and advances the canvas RNG texels: whatever the caller queues next
+// on the context stream that touches them (trc_seed, trc_upload_rng) is ordered after it
+void trc_sppm_order_after_camera(trc_ctx* ctx) {
+    if (!ctx || !ctx->sppm || ctx->sppm->cam_ahead == 0) return;
+    (void)hipStreamWaitEvent(ctx->stream, ctx->sppm->ev_cam, 0);
+}
 
 void trc_sppm_release(trc_ctx* ctx) {
     if (!ctx || !ctx->sppm) return;
@@ -643,7 +651,8 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
     // the pixels of ITS tiles, and bounces ITS photon index range; the camera-record AABB is all-reduced
     // (min/max on order-preserving keys: exact) and the photon records are all-gathered every frame so that
     // every rank hashes the full photon set.  All of it is deterministic: N ranks == 1 rank, bit for bit.
-    const bool grouped = ctx->comm != nullptr;
+    if (s->poisoned) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "an earlier trc_sppm_frames failed half-way through a frame: call trc_sppm_init again");
+    const bool grouped = ctx->grouped();
     const uint32_t nranks = grouped ? (uint32_t)ctx->nranks : 1u, rank = grouped ? (uint32_t)ctx->rank : 0u;
     const uint32_t np = s->W * s->H, nph = kHashN * kHashN;
     if (nph % (nranks * kBlock)) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "512*512 photons must split evenly over the ranks");
@@ -663,8 +672,12 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
     kp.stats = ctx->d_stats;
     const size_t lds = trc_dyn_lds_bytes(ctx, false);
     const bool all_lds = ctx->lds_scene;
-    auto rccl_fail = [&](const char* what, int rc) {
-        return trc_fail(ctx, TRC_ERR_RCCL, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
+    // a frame that fails after its first launch leaves RNG texels advanced and a camera pass possibly in flight: no
+    // retry can reproduce the frame, so the state is marked and the caller has to start over (trc_sppm_init)
+    auto frame_failed = [&](trc_status st) {
+        s->poisoned = true;
+        (void)hipStreamSynchronize(s->cam_stream);
+        return st;
     };
     auto camera_launch = [&](const KSppm& k, hipStream_t st) {
         if (all_lds) hipLaunchKernelGGL((k_sppm_camera<true>), dim3(ctx->n_tiles), dim3(kBlock), lds, st, k);
@@ -686,44 +699,45 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
         s->cam_ahead = frame;
         return TRC_OK;
     };
-    static const bool serial_camera = std::getenv("TRC_SPPM_SERIAL_CAMERA") != nullptr;     // A/B knob: no frame of lead
+    const bool serial_camera = ctx->knobs.sppm_serial_camera != 0;                          // A/B knob: no frame of lead
     for (uint32_t f = 0; f < n_frames; ++f) {
         kp.frame_count = s->frame_count;
         kp.vp = kp.vp_prev = s->vp[s->cur];
         if (s->frame_count == 0) {                      // photonPrepare, AAPLRenderer.mm:860-947
             camera_launch(kp, ctx->stream);
             if (grouped) {
-                DComplex* cx = s->d_cx;
-                int rc = g_rccl.AllReduce(cx->key_min, cx->key_min, 3, kNcclUint32, kNcclMin, ctx->comm, ctx->stream);
-                if (rc) return rccl_fail("ncclAllReduce(min)", rc);
-                rc = g_rccl.AllReduce(cx->key_max, cx->key_max, 3, kNcclUint32, kNcclMax, ctx->comm, ctx->stream);
-                if (rc) return rccl_fail("ncclAllReduce(max)", rc);
+                DComplex* cx = s->d_cx;              // the reference's ping-pong tree over the records, Photon.metal:169-218
+                trc_status cs = trc_coll_allreduce(ctx, cx->key_min, 3, kNcclUint32, kNcclMin, ctx->stream, "allreduce(min) of the bound keys");
+                if (cs == TRC_OK) cs = trc_coll_allreduce(ctx, cx->key_max, 3, kNcclUint32, kNcclMax, ctx->stream, "allreduce(max) of the bound keys");
+                if (cs != TRC_OK) return frame_failed(cs);
             }
             hipLaunchKernelGGL(k_sppm_params, dim3(1), dim3(64), 0, ctx->stream, s->d_cx);
             hipLaunchKernelGGL(k_sppm_radius, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, s->vp[0].flux_radius, np, s->d_cx);
         }
         const bool camera_frame = (s->frame_count % 2) != 0;       // photonWork re-runs the camera pass on odd frames, :953-955
-        if (camera_frame && s->cam_ahead != s->frame_count) { trc_status ts = camera_beside(s->frame_count); if (ts != TRC_OK) return ts; }
-        if (!camera_frame && f + 1 < n_frames && !serial_camera) { trc_status ts = camera_beside(s->frame_count + 1); if (ts != TRC_OK) return ts; }
+        if (camera_frame && s->cam_ahead != s->frame_count) { trc_status ts = camera_beside(s->frame_count); if (ts != TRC_OK) return frame_failed(ts); }
+        if (!camera_frame && f + 1 < n_frames && !serial_camera && s->cam_ahead != s->frame_count + 1) {
+            trc_status ts = camera_beside(s->frame_count + 1);
+            if (ts != TRC_OK) return frame_failed(ts);
+        }
         if (all_lds) hipLaunchKernelGGL((k_sppm_photon<true>), dim3(chunk / kBlock), dim3(kBlock), lds, ctx->stream, kp);
         else hipLaunchKernelGGL((k_sppm_photon<false>), dim3(chunk / kBlock), dim3(kBlock), lds, ctx->stream, kp);
         if (grouped) {                                  // every rank needs every photon for hashing + refine
-            int rc = g_rccl.AllGather(s->d_pho + (size_t)rank * chunk, s->d_pho, (size_t)chunk * sizeof(trc_PhotonRecord),
-                                      kNcclUint8, ctx->comm, ctx->stream);
-            if (rc) return rccl_fail("ncclAllGather(photons)", rc);
+            trc_status cs = trc_coll_allgather(ctx, s->d_pho, (size_t)chunk * sizeof(trc_PhotonRecord), ctx->stream, "allgather of the photon records");
+            if (cs != TRC_OK) return frame_failed(cs);
         }
-        HIP_TRY(ctx, hipMemsetAsync(s->d_mark, 0, (size_t)nph * 4, ctx->stream));     // loadAction clear, :785-790
-        HIP_TRY(ctx, hipMemsetAsync(s->d_count, 0, (size_t)nph * 4, ctx->stream));
+        if (hipMemsetAsync(s->d_mark, 0, (size_t)nph * 4, ctx->stream) != hipSuccess ||     // loadAction clear, :785-790
+            hipMemsetAsync(s->d_count, 0, (size_t)nph * 4, ctx->stream) != hipSuccess) return frame_failed(trc_fail(ctx, TRC_ERR_HIP, "SPPM grid clear"));
         hipLaunchKernelGGL(k_sppm_hash, dim3(nph / 256), dim3(256), 0, ctx->stream, s->d_pho, s->d_mark, s->d_count, s->d_cx);
         hipLaunchKernelGGL(k_sppm_table, dim3(128), dim3(256), 0, ctx->stream, s->d_mark, s->d_count, s->d_pho, s->d_cells, s->d_cx);
         if (camera_frame) {                             // this frame's visible points: wait for them, switch copies
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->ev_cam, 0));
+            if (hipStreamWaitEvent(ctx->stream, s->ev_cam, 0) != hipSuccess) return frame_failed(trc_fail(ctx, TRC_ERR_HIP, "SPPM camera event"));
             s->cur ^= 1; s->cam_ahead = 0;
             kp.vp = kp.vp_prev = s->vp[s->cur];
         }
         hipLaunchKernelGGL(k_sppm_refine, dim3(ctx->n_tiles), dim3(kBlock), 0, ctx->stream, kp);
         hipLaunchKernelGGL(k_sppm_end_frame, dim3(1), dim3(64), 0, ctx->stream, s->d_cx);
-        HIP_TRY(ctx, hipGetLastError());
+        { const hipError_t le = hipGetLastError(); if (le != hipSuccess) return frame_failed(trc_fail(ctx, TRC_ERR_HIP, std::string("SPPM frame: ") + hipGetErrorString(le))); }
         s->frame_count += 1;
     }
     return TRC_OK;

@@ -91,6 +91,8 @@ def _load(path):
     L.trc_group_allreduce_mean_accum.argtypes = [vp]
     L.trc_download_composed.argtypes = [vp, vp]
     L.trc_group_finalize.argtypes = [vp]
+    L.trc_group_set_collectives.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.trc_debug_set.argtypes = [vp, C.c_char_p, C.c_int]
     for name in abi.DEVICE_SYMBOLS:
         f = getattr(L, name)
         if name not in ("trc_abi_version", "trc_build_flavor", "trc_status_string", "trc_last_error", "trc_destroy"):
@@ -314,6 +316,17 @@ class Tracer:
         out = np.empty((self.height, self.width, 4), dtype=np.float32)
         self._check(self._L.trc_download_composed(self._h, out.ctypes.data), "trc_download_composed")
         return out
+
+    def set_collectives(self, table, nranks, rank):
+        """Caller-supplied collectives instead of an RCCL communicator (trc_group_set_collectives); `table` is an
+        object with a ctypes `table` attribute (tracer_amd.gloo_collectives.GlooCollectives) and must outlive the group."""
+        self._coll = table
+        self._check(self._L.trc_group_set_collectives(self._h, C.byref(table.table) if table is not None else None, nranks, rank),
+                    "trc_group_set_collectives")
+
+    def debug_set(self, knob, value):
+        """A/B and test knobs of this context (trc_debug_set): scheduling only, never a pixel."""
+        self._check(self._L.trc_debug_set(self._h, knob.encode(), int(value)), "trc_debug_set")
 
     def group_finalize(self):
         self._check(self._L.trc_group_finalize(self._h), "trc_group_finalize")

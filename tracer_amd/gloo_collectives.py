@@ -1,0 +1,93 @@
+"""Host-staged collectives over torch.distributed (gloo) for `trc_group_set_collectives` -- harness code for tests and
+for `bench.py --gpus N` on a box with fewer than N GPUs (RCCL refuses two ranks on one device).  The library stages the
+device buffer through pinned host memory and hands these callbacks a host pointer; they run the collective in place.
+
+Nothing here computes anything of the path: reduce(sum) with zeros outside a rank's own tiles is a gather, min / max of
+order-preserving keys are exact, the all-gather moves bytes.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class Collectives(C.Structure):
+    """trc_collectives"""
+    _fields_ = [("user", C.c_void_p), ("host_staged", C.c_int32), ("_pad", C.c_int32),
+                ("reduce", REDUCE_FN), ("allreduce", ALLREDUCE_FN), ("allgather", ALLGATHER_FN)]
+
+
+_NP = {abi.DT_U8: np.uint8, abi.DT_U32: np.uint32, abi.DT_F32: np.float32}
+
+
+class GlooCollectives:
+    """table = GlooCollectives(group=None); tracer.set_collectives(table, world, rank).  Keeps the ctypes callbacks
+    alive; `calls` counts what the library asked for (tests assert the collective program)."""
+
+    def __init__(self, group=None):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist, self._group = torch, dist, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.calls = {"reduce": 0, "allreduce": 0, "allgather": 0}
+        self._cb = (REDUCE_FN(self._reduce), ALLREDUCE_FN(self._allreduce), ALLGATHER_FN(self._allgather))
+        self.table = Collectives(None, 1, 0, *self._cb)
+
+    def _view(self, buf, count, dtype):
+        return np.ctypeslib.as_array(C.cast(buf, C.POINTER(np.ctypeslib.as_ctypes_type(_NP[dtype]))), shape=(count,))
+
+    def _op(self, op):
+        R = self._dist.ReduceOp
+        return {abi.OP_SUM: R.SUM, abi.OP_MAX: R.MAX, abi.OP_MIN: R.MIN}[op]
+
+    def _tensor(self, a):
+        # gloo has no unsigned 32-bit reductions: widen (values are exact in int64), narrow on the way back
+        if a.dtype == np.uint32:
+            return self._torch.from_numpy(a.astype(np.int64)), True
+        return self._torch.from_numpy(a), False
+
+    def _reduce(self, user, buf, count, dtype, op, root, stream):
+        try:
+            a = self._view(buf, count, dtype)
+            t, widened = self._tensor(a)
+            self._dist.reduce(t, dst=root, op=self._op(op), group=self._group)
+            if widened and self.rank == root:
+                a[:] = t.numpy().astype(a.dtype)
+            self.calls["reduce"] += 1
+            return 0
+        except Exception as e:      # never let an exception cross the C boundary
+            print(f"GlooCollectives.reduce: {e!r}", flush=True)
+            return 1
+
+    def _allreduce(self, user, buf, count, dtype, op, stream):
+        try:
+            a = self._view(buf, count, dtype)
+            t, widened = self._tensor(a)
+            self._dist.all_reduce(t, op=self._op(op), group=self._group)
+            if widened:
+                a[:] = t.numpy().astype(a.dtype)
+            self.calls["allreduce"] += 1
+            return 0
+        except Exception as e:
+            print(f"GlooCollectives.allreduce: {e!r}", flush=True)
+            return 1
+
+    def _allgather(self, user, buf, bytes_per_rank, stream):
+        try:
+            a = self._view(buf, bytes_per_rank * self.world, abi.DT_U8)
+            mine = self._torch.from_numpy(a[self.rank * bytes_per_rank:(self.rank + 1) * bytes_per_rank].copy())
+            parts = [self._torch.empty(bytes_per_rank, dtype=self._torch.uint8) for _ in range(self.world)]
+            self._dist.all_gather(parts, mine, group=self._group)
+            for r, p in enumerate(parts):
+                a[r * bytes_per_rank:(r + 1) * bytes_per_rank] = p.numpy()
+            self.calls["allgather"] += 1
+            return 0
+        except Exception as e:
+            print(f"GlooCollectives.allgather: {e!r}", flush=True)
+            return 1
