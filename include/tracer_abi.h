@@ -428,6 +428,11 @@ trc_status trc_reset_stats(trc_ctx* ctx);
  * 3 sphere, 4 cube, 5 triangle, 6 shade, 7 cosine lobe, 8 Metal, 9 Beckmann sampling,
  * 10 Beckmann lobe evaluation (Plastic specular + Glass), 11 path end */
 trc_status trc_debug_profile(trc_ctx* ctx, uint64_t* out, uint32_t n_sites);
+/* developer diagnostic: the pixel blocks of the last trc_render (x | y << 16, in units of the block edge 1 << *blk_shift)
+ * and the duration each one's wavefront measured (shader clocks / 64 -- the sort key of the adaptive launch order); with
+ * strips (spp < 8) the costs are per strip; a block that ran as four 4x4 quarters reports its slowest quarter with the top
+ * bit set.  Any pointer may be NULL; at most `capacity` entries are written. */
+trc_status trc_debug_block_costs(trc_ctx* ctx, uint32_t* tiles, uint32_t* costs, uint32_t capacity, uint32_t* n_blocks, uint32_t* blk_shift);
 
 /* device info for the bench line */
 trc_status trc_device_info(trc_ctx* ctx, char* name, size_t name_len, int* cu_count, size_t* hbm_bytes);
@@ -505,8 +510,10 @@ typedef struct trc_collectives {
 trc_status trc_group_set_collectives(trc_ctx* ctx, const trc_collectives* table, int nranks, int rank);
 
 /* A/B and test knobs of ONE context (the defaults come from the environment variables of the same upper-case names at
- * trc_create): "no_lds_fit", "stack_lds_levels", "strip_len", "no_pwg", "sppm_serial_camera" (tools/README.md).
- * They change scheduling only, never a pixel.  Unknown name: TRC_ERR_INVALID_ARG. */
+ * trc_create): "no_lds_fit", "stack_lds_levels", "strip_len", "no_pwg", "sppm_serial_camera" (tools/README.md), and
+ * "no_split" (no cost-adaptive block size), "force_blk_shift" (k + 1 forces 2^k x 2^k pixel blocks per wavefront, k = 0..3: measurement only), and
+ * "sppm_timing" (event pairs around an SPPM frame's photon pass and its hash / table / refine passes, added to
+ * trc_stats.kernel_ms; one `launch` per frame).  They change scheduling / bookkeeping only, never a pixel.  Unknown name: TRC_ERR_INVALID_ARG. */
 trc_status trc_debug_set(trc_ctx* ctx, const char* knob, int value);
 
 /* ------------------------------------------------------------------ */

@@ -1,0 +1,72 @@
+"""Cost-adaptive block size (trc_abi.hip::k_plan_split): from the second launch of a block list on, the 8x8 blocks whose
+previous launch lasted longest run as four 4x4 quarters on 16 lanes each -- and a first launch with no more blocks than
+wavefront slots runs every block as quarters.  Which blocks are split is a scheduling choice made from measured durations;
+pixels are independent, so every launch must produce the frame, the RNG texture and the ray count of the plain launch
+(TRC_FLAG_LARGE_BLOCKS | TRC_FLAG_FIXED_ORDER), which the other parity tests compare with the oracle."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tracer_amd import abi, host
+
+pytestmark = pytest.mark.gpu
+
+
+def _launch(gpu, seed, **kw):
+    gpu.seed(seed); gpu.clear_accum(); gpu.reset_stats()
+    gpu.render(**kw)
+    frame, rng, rays = gpu.download_accum(), gpu.download_rng(), gpu.stats().rays
+    _, costs, _ = gpu.block_costs()
+    return frame, rng, rays, int((costs >> 31).sum()), len(costs)
+
+
+def _same(a, b):
+    return a[2] == b[2] and np.array_equal(a[1], b[1]) and np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+
+
+def test_quarters_on_an_lds_resident_scene(gpu, cornell_spheres):
+    W, H, spp = 640, 360, 9                         # 3 600 blocks <= 4 096 wavefront slots: the first launch is all quarters
+    cam = host.prepare_camera(W, H)
+    gpu.upload_scene(cornell_spheres.view); gpu.set_camera(cam); gpu.set_environment((0.2, 0.3, 0.4)); gpu.resize(W, H)
+    gpu.debug_set("no_split", 0)                    # also resets what the context knows about the blocks' costs
+    plain = _launch(gpu, 5, spp=spp, small_blocks=False, fixed_order=True)
+    assert plain[3] == 0
+    gpu.debug_set("no_split", 0)
+    runs = [_launch(gpu, 5, spp=spp) for _ in range(4)]
+    for r in runs:
+        assert _same(r, plain)
+    assert runs[0][3] == runs[0][4] == 3600         # launch 1: every block as quarters
+    assert 0 < runs[1][3] < 3600                    # launch 2 on: only the blocks the plan picks
+    ref, st = po.render(cornell_spheres.view, cam, W, H, host.fill_rng(5, W, H), spp=spp, env=(0.2, 0.3, 0.4))
+    assert st.rays == plain[2] and np.array_equal(plain[0].view(np.uint32), ref.view(np.uint32))
+    # a different seed every launch (a progressive renderer never replays a frame): still the plain frames
+    for s in (6, 7):
+        a = _launch(gpu, s, spp=spp)
+        gpu.debug_set("no_split", 1)
+        b = _launch(gpu, s, spp=spp, small_blocks=False, fixed_order=True)
+        gpu.debug_set("no_split", 0)
+        assert _same(a, b)
+
+
+@pytest.mark.parametrize("integrator", [abi.INTEGRATOR_PATH, abi.INTEGRATOR_MIS])
+def test_quarters_on_a_tree_read_from_memory(gpu, integrator):
+    """a rank's share of a mesh scene: persistent workgroups pull whole blocks and quarters from one queue"""
+    W, H, spp = 960, 540, 8
+    scene = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.golden("teapot"))
+    gpu.upload_scene(scene.view); gpu.set_camera(host.prepare_camera(W, H)); gpu.set_environment((0.0, 0.0, 0.0)); gpu.resize(W, H)
+    gpu.debug_set("no_split", 0)
+    plain = _launch(gpu, 11, spp=spp, integrator=integrator, tile_rank=1, tile_nranks=2, small_blocks=False, fixed_order=True)
+    gpu.debug_set("no_split", 0)
+    runs = [_launch(gpu, 11, spp=spp, integrator=integrator, tile_rank=1, tile_nranks=2) for _ in range(4)]
+    for r in runs:
+        assert _same(r, plain)
+    assert runs[0][3] == 0 and max(r[3] for r in runs[1:]) > 0, [r[3] for r in runs]
+
+
+def test_the_plan_leaves_a_full_frame_alone(gpu, cornell_spheres):
+    """many more blocks than wavefront slots: the work term of the plan's model wins, nothing is split"""
+    W, H, spp = 1920, 1080, 8
+    gpu.upload_scene(cornell_spheres.view); gpu.set_camera(host.prepare_camera(W, H)); gpu.resize(W, H)
+    gpu.debug_set("no_split", 0)
+    runs = [_launch(gpu, 3, spp=spp) for _ in range(3)]
+    assert [r[3] for r in runs] == [0, 0, 0] and _same(runs[0], runs[2])

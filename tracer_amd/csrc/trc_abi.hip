@@ -46,13 +46,18 @@ __device__ __forceinline__ void render_block(const KRender& kp, const DScene& sc
                                              uint32_t* ovf, const uint32_t slot, const uint32_t lane,
                                              uint32_t& n_rays, uint32_t& n_shaded, uint32_t& n_paths, TravCounters& cnt) {
     const uint64_t t_start = clock64();          // this wavefront's own duration = the next launch's sort key
-    const uint32_t canon = kp.order ? kp.order[slot] : slot;     // adaptive launch order (trc_render)
-    const uint32_t tile = kp.tiles[canon];                      // pixel block: x | y << 16 in units of the block edge
-    const uint32_t bs = kp.blk_shift;                           // 3: 8x8 pixels, all 64 lanes; 2: 4x4 pixels, lanes 0..15
-    const uint32_t px = ((tile & 0xFFFFu) << bs) + (lane & ((1u << bs) - 1u));
-    const uint32_t py = ((tile >> 16) << bs) + (lane >> bs);
+    const uint32_t entry = kp.order ? kp.order[slot] : slot;     // adaptive launch order / cost-adaptive block size (trc_render)
+    const uint32_t index = entry & kLaunchIndexMask, code = entry >> kLaunchCodeShift;
+    const uint32_t tile = kp.tiles[index];                      // pixel block: x | y << 16 in units of the block edge
+    // 3: 8x8 pixels, all 64 lanes; 2: 4x4 pixels, lanes 0..15 -- the whole list (kp.blk_shift), or one quarter of an 8x8
+    // block whose previous launch ran long (code 1..4: quarter code - 1, x fastest)
+    const uint32_t bs = code ? 2u : kp.blk_shift;
+    const uint32_t qx = code ? ((code - 1u) & 1u) << 2 : 0u, qy = code ? ((code - 1u) >> 1) << 2 : 0u;
+    const uint32_t px = ((tile & 0xFFFFu) << kp.blk_shift) + qx + (lane & ((1u << bs) - 1u));
+    const uint32_t py = ((tile >> 16) << kp.blk_shift) + qy + (lane >> bs);
     const uint32_t W = kp.fr.width, H = kp.fr.height;
     const bool active = lane < (1u << (2u * bs)) && px < W && py < H;
+    const uint32_t canon = index * kp.cost_stride + (code ? code - 1u : 0u);
 
     if (active) {
         PathCtx cx;
@@ -179,6 +184,7 @@ __device__ __forceinline__ void render_block(const KRender& kp, const DScene& sc
 #endif
 template <bool LDS, bool STATS, int INTEGRATOR, bool SOBOL = false>
 __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRATOR_VOLUME ? TRC_VOLUME_WAVES : (INTEGRATOR == TRC_INTEGRATOR_MIS ? TRC_MIS_WAVES : (LDS ? TRC_PATH_WAVES : TRC_PATH_WAVES_GLOBAL)))) k_render(const KRender kp) {
+    if (kp.n_launch && blockIdx.x >= *kp.n_launch) return;      // the grid is sized for the most quarters a plan may splice in
     const DScene& sc = kp.ks.sc;
     const uint32_t* small_base = stage_scene(sc);
     uint32_t* stack = lane_stack(sc);
@@ -252,11 +258,12 @@ __global__ void __launch_bounds__(64 * pwg_waves(INTEGRATOR), pwg_waves(INTEGRAT
     uint32_t n_rays = 0, n_shaded = 0, n_paths = 0;
     TravCounters cnt;
     counters_zero(cnt);
+    const uint32_t n_entries = kp.n_launch ? *kp.n_launch : kp.n_tiles;
     for (;;) {
         uint32_t slot = 0;
         if (lane == 0) slot = atomicAdd(kp.queue, 1u);
         slot = __builtin_amdgcn_readfirstlane(slot);
-        if (slot >= kp.n_tiles) break;
+        if (slot >= n_entries) break;
         render_block<false, false, INTEGRATOR, SOBOL, kHybridStack>(kp, sc, trc_smem, stack, nullptr, ovf, slot, lane, n_rays, n_shaded, n_paths, cnt);
     }
     uint32_t r_paths = wave_sum(n_paths), r_rays = wave_sum(n_rays), r_shaded = wave_sum(n_shaded);
@@ -449,12 +456,122 @@ __global__ void __launch_bounds__(64) k_stats_sum(const unsigned long long* rows
     sum[c] = v;
 }
 
-// sort keys of the adaptive launch order: descending cost (shader clocks / 64, clamped to 24 bits), ties in list order
-__global__ void __launch_bounds__(256) k_order_keys(const uint32_t* cost, uint32_t n, uint32_t* keys, uint32_t* vals) {
+// sort keys of the adaptive launch order: descending cost (shader clocks / 64, clamped to 24 bits), ties in list order.
+// stride 4: the last launch may have run an 8x8 block as four quarters (split[i] != 0).  Its cost as ONE block is then
+// what it measured when it last ran whole (whole[i], kept by k_build_launch), or -- a first launch made of quarters only
+// -- an estimate from its slowest quarter on the high side.
+constexpr float kQuarterCost = 0.85f;        // a quarter's duration relative to its 8x8 block's: what the plan assumes for
+                                             // a block it has not split yet (measured: 0.8-0.9 for the blocks that matter)
+constexpr float kQuarterEstimate = 0.65f;
+__device__ __forceinline__ uint32_t max_quarter(const uint32_t* q) { return max(max(q[0], q[1]), max(q[2], q[3])); }
+__global__ void __launch_bounds__(256) k_order_keys(const uint32_t* cost, const uint32_t* split, const uint32_t* whole, uint32_t stride, uint32_t n,
+                                                    uint32_t* keys, uint32_t* vals) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    keys[i] = 0xFFFFFFu - min(cost[i], 0xFFFFFFu);
+    uint32_t c = cost[(size_t)i * stride];
+    if (stride == 4u && split[i])
+        c = whole[i] ? whole[i] : (uint32_t)((float)max_quarter(cost + (size_t)i * 4u) * (1.0f / kQuarterEstimate));
+    keys[i] = 0xFFFFFFu - min(c, 0xFFFFFFu);
     vals[i] = i;
+}
+
+// Cost-adaptive block size.  A block's samples are a sequential chain, so a launch cannot end before its slowest
+// wavefront; a rank that owns about as many 8x8 blocks as the GPU has wavefront slots (a strong-scaled share of a frame)
+// lasts exactly that long, while most slots sit idle.  An 8x8 block run as four 4x4 quarters on 16 lanes each ends earlier
+// (a quarter waits for 16 pixels' branches, not 64) but occupies four slots and issues ~3x the instructions -- so only
+// the blocks that would otherwise decide the launch are split.  Input: the blocks in descending order of their cost as
+// whole blocks (keys[r] = 0xFFFFFF - cost, vals[r] = block).  Model of a launch that splits the K most expensive blocks:
+//     makespan(K) = max( cost[K], longest quarter, (sum + (4 * kQuarterCost - 1) * prefix(K)) / slots )
+// -- the longest block left whole; the longest quarter: the slowest one MEASURED in the previous launch, and
+// kQuarterCost x the most expensive block that launch ran whole if K reaches it; the work over the wavefront slots.  One
+// workgroup picks the smallest K <= k_max that minimises it: a launch with many more blocks than slots gets K = 0 from
+// the third term, an eighth of a 1080p frame splits the few blocks above the longest quarter.
+__global__ void __launch_bounds__(1024) k_plan_split(const uint32_t* keys, const uint32_t* vals, const uint32_t* split, const uint32_t* cost,
+                                                     uint32_t n, uint32_t k_max, uint32_t slots, uint32_t* plan) {
+    __shared__ double s_sum[1024];
+    __shared__ float s_best[1024];
+    __shared__ uint32_t s_k[1024];
+    __shared__ uint32_t s_q[1024], s_first[1024];
+    const uint32_t t = threadIdx.x, per = (n + 1023u) / 1024u;
+    const uint32_t lo = min(n, t * per), hi = min(n, lo + per);
+    double local = 0.0;
+    uint32_t q_max = 0u, first_whole = 0xFFFFFFFFu;
+    for (uint32_t r = lo; r < hi; ++r) {
+        local += (double)(0xFFFFFFu - keys[r]);
+        const uint32_t i = vals[r];
+        if (split[i]) q_max = max(q_max, max_quarter(cost + (size_t)i * 4u));
+        else if (first_whole == 0xFFFFFFFFu) first_whole = r;
+    }
+    s_sum[t] = local; s_q[t] = q_max; s_first[t] = first_whole;
+    __syncthreads();
+    if (t == 0) {                                   // exclusive scan of 1024 partial sums + two reductions: serial, a few microseconds
+        double run = 0.0;
+        uint32_t q = 0u, f = 0xFFFFFFFFu;
+        for (uint32_t i = 0; i < 1024u; ++i) {
+            const double v = s_sum[i]; s_sum[i] = run; run += v;
+            q = max(q, s_q[i]); f = min(f, s_first[i]);
+        }
+        s_q[0] = q; s_first[0] = f;
+        plan[2] = (uint32_t)min(run / (double)slots, 4294967295.0);     // diagnostics: work / slots of the unsplit launch,
+        plan[3] = q;                                                    // the longest quarter of the previous launch
+    }
+    __syncthreads();
+    double total = s_sum[1023];
+    for (uint32_t r = min(n, 1023u * per); r < n; ++r) total += (double)(0xFFFFFFu - keys[r]);
+    const float quarter_seen = (float)s_q[0];
+    const uint32_t r_whole = s_first[0];            // most expensive block the previous launch ran whole
+    const float quarter_new = r_whole < n ? kQuarterCost * (float)(0xFFFFFFu - keys[r_whole]) : 0.0f;
+    const double extra = 4.0 * (double)kQuarterCost - 1.0;
+    float best = 3.0e38f;
+    uint32_t best_k = 0;
+    double prefix = s_sum[t];                       // cost of the blocks before rank `lo`
+    auto candidate = [&](uint32_t k, float whole) {       // split ranks 0 .. k-1
+        const float quarter = k == 0u ? 0.0f : (k > r_whole ? fmaxf(quarter_seen, quarter_new) : quarter_seen);
+        const float work = (float)((total + extra * prefix) / (double)slots);
+        const float m = fmaxf(fmaxf(whole, quarter), work);
+        if (m < best) { best = m; best_k = k; }
+    };
+    for (uint32_t k = lo; k < hi && k <= k_max; ++k) {
+        candidate(k, (float)(0xFFFFFFu - keys[k]));
+        prefix += (double)(0xFFFFFFu - keys[k]);
+    }
+    if (hi == n && lo < hi && n <= k_max) candidate(n, 0.0f);          // ... and "every block as quarters"
+    s_best[t] = best; s_k[t] = best_k;
+    __syncthreads();
+    for (uint32_t off = 512u; off > 0u; off >>= 1) {
+        if (t < off) {
+            const float a = s_best[t], b = s_best[t + off];
+            if (b < a || (b == a && s_k[t + off] < s_k[t])) { s_best[t] = b; s_k[t] = s_k[t + off]; }
+        }
+        __syncthreads();
+    }
+    if (t == 0) { plan[0] = s_k[0]; plan[1] = n + 3u * s_k[0]; }
+}
+// the launch list of a plan: ranks 0 .. K-1 as four quarters each (the longest blocks first), then the other blocks whole
+__global__ void __launch_bounds__(256) k_build_launch(const uint32_t* keys, const uint32_t* vals, uint32_t n, const uint32_t* plan, uint32_t* launch,
+                                                      uint32_t* split, uint32_t* whole) {
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t K = plan[0], i = vals[r];
+    if (r < K) {
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) launch[4u * r + j] = i | ((j + 1u) << kLaunchCodeShift);
+        if (!split[i]) whole[i] = max(1u, 0xFFFFFFu - keys[r]);     // what it cost as one block, for as long as it runs as quarters
+        split[i] = 1u;
+    } else {
+        launch[3u * K + r] = i;
+        split[i] = 0u;
+    }
+}
+// every block as four quarters (a first launch of few blocks: nothing is known about their costs yet)
+__global__ void __launch_bounds__(256) k_build_launch_all_quarters(uint32_t n, uint32_t* plan, uint32_t* launch, uint32_t* split, uint32_t* whole) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i == 0) { plan[0] = n; plan[1] = 4u * n; plan[2] = 0u; plan[3] = 0u; }
+    if (i >= n) return;
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; ++j) launch[4u * i + j] = i | ((j + 1u) << kLaunchCodeShift);
+    split[i] = 1u;
+    whole[i] = 0u;            // never measured as one block: k_order_keys estimates it from the slowest quarter
 }
 
 // ---- output stage (fragmentShader, Render.metal:29-75): exposure sums, then ACES to 8 bit
@@ -550,12 +667,7 @@ constexpr bool kAutoSmallBlocks = true;       // decided by measurement (tools/s
 
 inline trc_status fail(trc_ctx* ctx, trc_status st, const std::string& msg) { return trc_fail(ctx, st, msg); }
 
-hipEvent_t get_event(trc_ctx* ctx) {
-    if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
-    hipEvent_t e = nullptr;
-    if (hipEventCreate(&e) != hipSuccess) return nullptr;
-    return e;
-}
+hipEvent_t get_event(trc_ctx* ctx) { return trc_get_event(ctx); }
 
 // folds the per-launch event pairs that have already completed into kernel_ms without waiting (oldest first; the
 // stream is in order, so the first unfinished pair ends the scan).  Called from trc_render, so a host that never
@@ -685,6 +797,13 @@ std::vector<uint32_t> make_tiles(uint32_t W, uint32_t H, uint32_t nranks, uint32
 
 Rccl g_rccl;
 
+hipEvent_t trc_get_event(trc_ctx* ctx) {
+    if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
 // the one piece of process-wide state: resolved once, under a lock (contexts may be created from several threads)
 static std::mutex g_rccl_lock;
 bool trc_load_rccl(std::string& err) {
@@ -771,11 +890,20 @@ trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32
     (void)hipFree(ctx->d_block_cost); ctx->d_block_cost = nullptr;
     for (int k = 0; k < 2; ++k) { (void)hipFree(ctx->d_order_keys[k]); (void)hipFree(ctx->d_order_vals[k]); ctx->d_order_keys[k] = ctx->d_order_vals[k] = nullptr; }
     (void)hipFree(ctx->d_order_hist); ctx->d_order_hist = nullptr;
-    ctx->cost_valid = false; ctx->d_last_order = nullptr;
+    (void)hipFree(ctx->d_split); ctx->d_split = nullptr;
+    (void)hipFree(ctx->d_whole); ctx->d_whole = nullptr;
+    (void)hipFree(ctx->d_launch); ctx->d_launch = nullptr;
+    ctx->cost_valid = false; ctx->d_last_order = nullptr; ctx->cost_quarters = false; ctx->launch_cap = 0;
     ctx->n_tiles = (uint32_t)tiles.size();
     if (ctx->n_tiles) {
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tiles, tiles.size() * 4));
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_block_cost, tiles.size() * 4));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_block_cost, tiles.size() * 16));      // 4 slots per block: whole, or its quarters
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_split, tiles.size() * 4));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_whole, tiles.size() * 4));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_launch, tiles.size() * 16));
+        if (!ctx->d_plan) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_plan, 4 * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_split, 0, tiles.size() * 4, ctx->stream));
+        ctx->launch_cap = (uint32_t)tiles.size() * 4u;
         for (int k = 0; k < 2; ++k) {
             HIP_TRY(ctx, hipMalloc((void**)&ctx->d_order_keys[k], tiles.size() * 4));
             HIP_TRY(ctx, hipMalloc((void**)&ctx->d_order_vals[k], tiles.size() * 4));
@@ -812,8 +940,8 @@ trc_status ensure_sobol_tables(trc_ctx* ctx, uint32_t m) {
 }
 
 template <bool LDS>
-void launch_render(trc_ctx* ctx, const KRender& kp, bool stats, uint32_t integrator, size_t lds) {
-    dim3 grid(ctx->n_tiles), block(kBlock);
+void launch_render(trc_ctx* ctx, const KRender& kp, bool stats, uint32_t integrator, size_t lds, uint32_t n_workgroups) {
+    dim3 grid(n_workgroups), block(kBlock);
     if (kp.strip > 1) {                      // few samples per pixel: a strip of blocks per wavefront (production kernels)
         dim3 sgrid((ctx->n_tiles + kp.strip - 1) / kp.strip);
         if (kp.sobol32) {
@@ -1015,7 +1143,7 @@ void trc_destroy(trc_ctx* ctx) {
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     (void)hipFree(ctx->d_blob); (void)hipFree(ctx->d_bvh_ref); (void)hipFree(ctx->d_density); (void)hipFree(ctx->d_occupancy); (void)hipFree(ctx->d_envmap); (void)hipFree(ctx->d_sobol32); (void)hipFree(ctx->d_sobol_vdc); (void)hipFree(ctx->d_rng); (void)hipFree(ctx->d_accum);
     (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_stats); (void)hipFree(ctx->d_stats_sum); (void)hipFree(ctx->d_reduce_recv);
-    (void)hipFree(ctx->d_block_cost); (void)hipFree(ctx->d_order_hist);
+    (void)hipFree(ctx->d_block_cost); (void)hipFree(ctx->d_order_hist); (void)hipFree(ctx->d_split); (void)hipFree(ctx->d_whole); (void)hipFree(ctx->d_launch); (void)hipFree(ctx->d_plan);
     for (int k = 0; k < 2; ++k) { (void)hipFree(ctx->d_order_keys[k]); (void)hipFree(ctx->d_order_vals[k]); }
     (void)hipFree(ctx->d_accum_alt); (void)hipFree(ctx->d_stack_ovf); (void)hipFree(ctx->d_queue);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
@@ -1231,17 +1359,10 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
     // 64 pixels' branches.  4x4 blocks on 16 lanes give 4x the wavefronts, each with a quarter of the pixels to wait
     // for -- the same pixels, the same arithmetic per pixel (TRC_FLAG_SMALL_BLOCKS forces it, _LARGE_BLOCKS forbids it).
     uint32_t blk_shift = 3;
-    {
-        const uint64_t slots = (uint64_t)ctx->cu_count * 16u;
-        const uint64_t blocks8 = (uint64_t)((ctx->width + 7) / 8) * ((ctx->height + 7) / 8) / nranks;
-        const bool fits = ctx->width <= 65535u * 4u && ctx->height <= 65535u * 4u;
-        if ((p->flags & TRC_FLAG_SMALL_BLOCKS) && fits) blk_shift = 2;
-        // automatic only where it was measured to pay: fewer 8x8 blocks than wavefront slots (a small frame, or an eighth
-        // of a 1080p frame), tracePath on an LDS-resident scene, a fused launch -- 920 / 2 040 / 3 600 blocks: 8.5 / 8.3 / 8.9
-        // -> 7.0 / 7.2 / 7.4 ms at 64 spp; 5 700 blocks: 8.5 -> 9.7 ms
-        else if (!(p->flags & TRC_FLAG_LARGE_BLOCKS) && fits && kAutoSmallBlocks && blocks8 <= slots && p->spp >= 8 &&
-                 p->integrator == TRC_INTEGRATOR_PATH && ctx->lds_scene) blk_shift = 2;
-    }
+    const uint64_t blocks8 = (uint64_t)((ctx->width + 7) / 8) * ((ctx->height + 7) / 8) / nranks;
+    const bool fits = ctx->width <= 65535u * 4u && ctx->height <= 65535u * 4u;
+    if ((p->flags & TRC_FLAG_SMALL_BLOCKS) && fits) blk_shift = 2;
+    if (ctx->knobs.force_blk_shift > 0) blk_shift = std::min(3u, (uint32_t)ctx->knobs.force_blk_shift - 1u);   // measurement knob: 2^k x 2^k pixel blocks
     { trc_status ts = trc_ensure_tiles(ctx, nranks, p->tile_rank, p->view_height, blk_shift); if (ts != TRC_OK) return ts; }
     if (ctx->n_tiles == 0) return TRC_OK;
 
@@ -1282,23 +1403,60 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
         const uint32_t room = ctx->n_tiles / (slots + slots / 2u);          // keep >= 1.5 workgroups per slot
         kp.strip = std::max(1u, std::min(want, room));
     }
-    if (ctx->cost_strip != kp.strip) { ctx->cost_valid = false; ctx->cost_strip = kp.strip; ctx->d_last_order = nullptr; }
+    // Launch list.  (1) Order: most expensive blocks of the previous launch first (longest-processing-time order; cost = the
+    // wavefront's measured duration): a block's samples are a sequential chain, so whatever starts last decides how long
+    // the GPU drains.  Measured: config 2 25.2 -> 22.3 ms (ray counts as the key: 23.7), the 1 M-triangle scene 18.7 ->
+    // 16.8 ms.  (2) Cost-adaptive block size (k_plan_split): the blocks that would decide the launch run as four 4x4
+    // quarters.  Pixels depend on neither.
+    const bool quarters_ok = kp.strip == 1 && blk_shift == 3;             // the list's blocks are 8x8: costs live in 4 slots per block
+    kp.cost_stride = quarters_ok ? 4u : 1u;
+    if (ctx->cost_strip != kp.strip || ctx->cost_quarters != quarters_ok) {
+        ctx->cost_valid = false; ctx->cost_strip = kp.strip; ctx->cost_quarters = quarters_ok; ctx->d_last_order = nullptr;
+    }
+    const bool may_split = quarters_ok && !stats && p->spp >= 8 && !ctx->knobs.no_split &&
+                           !(p->flags & (TRC_FLAG_LARGE_BLOCKS | TRC_FLAG_FIXED_ORDER));
+    // wavefront slots of the kernel this launch runs (the plan's model; the launch bounds of k_render / k_render_pwg)
+    const uint32_t waves_per_simd = p->integrator == TRC_INTEGRATOR_PATH ? (ctx->lds_scene ? TRC_PATH_WAVES : TRC_PATH_WAVES_GLOBAL)
+                                  : p->integrator == TRC_INTEGRATOR_MIS ? TRC_MIS_WAVES : TRC_VOLUME_WAVES;
+    const uint32_t wave_slots = (uint32_t)ctx->cu_count * 4u * waves_per_simd;
+    uint32_t grid_cap = ctx->n_tiles;                                     // workgroups of a one-block-per-workgroup launch
+    bool planned = false;
     if (ctx->cost_valid && !(p->flags & TRC_FLAG_FIXED_ORDER) && kp.strip > 1 && ctx->d_last_order && ctx->order_age < 4) {
         kp.order = ctx->d_last_order;              // short launches: the order of a few launches ago is as good, and 13 tiny
         ctx->order_age++;                          // sort launches per 0.7 ms render are not
     } else if (ctx->cost_valid && !(p->flags & TRC_FLAG_FIXED_ORDER)) {
-        // most expensive blocks of the previous launch first (longest-processing-time order; cost = the wavefront's
-        // measured duration): a block's samples are a sequential chain, so whatever starts last decides how long the GPU
-        // drains.  Measured: config 2 25.2 -> 22.3 ms (ray counts as the key: 23.7), the 1 M-triangle scene 18.7 -> 16.8
-        // ms.  Pixels do not depend on the order.
         const uint32_t n = (ctx->n_tiles + kp.strip - 1) / kp.strip;
-        hipLaunchKernelGGL(k_order_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_block_cost, n, ctx->d_order_keys[0], ctx->d_order_vals[0]);
+        hipLaunchKernelGGL(k_order_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_block_cost, ctx->d_split, ctx->d_whole, kp.cost_stride, n,
+                           ctx->d_order_keys[0], ctx->d_order_vals[0]);
         int res = 0;
         trc_sort_pairs24(ctx->stream, ctx->d_order_keys, ctx->d_order_vals, ctx->d_order_hist, ctx->d_order_hist + trc_sort_hist_words(n), n, &res);
         kp.order = ctx->d_order_vals[res];
         ctx->d_last_order = kp.order;
         ctx->order_age = 0;
+        if (may_split) {
+            const uint32_t k_max = std::min(n, 2u * wave_slots);
+            hipLaunchKernelGGL(k_plan_split, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_order_keys[res], ctx->d_order_vals[res], ctx->d_split, ctx->d_block_cost,
+                               n, k_max, wave_slots, ctx->d_plan);
+            hipLaunchKernelGGL(k_build_launch, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_order_keys[res], ctx->d_order_vals[res], n, ctx->d_plan,
+                               ctx->d_launch, ctx->d_split, ctx->d_whole);
+            kp.order = ctx->d_launch;
+            kp.n_launch = ctx->d_plan + 1;
+            grid_cap = n + 3u * k_max;
+            planned = true;
+        }
+    } else if (may_split && !ctx->cost_valid && kAutoSmallBlocks && fits && blocks8 <= (uint64_t)ctx->cu_count * 16u &&
+               p->integrator == TRC_INTEGRATOR_PATH && ctx->lds_scene) {
+        // nothing is known about the blocks yet and there are no more of them than wavefront slots (a small frame, or an
+        // eighth of a 1080p frame): every block as quarters -- measured on whole small frames at 64 spp (920 / 2 040 / 3 600
+        // blocks: 8.5 / 8.3 / 8.9 -> 7.0 / 7.2 / 7.4 ms); from the second launch on the plan decides block by block
+        hipLaunchKernelGGL(k_build_launch_all_quarters, dim3((ctx->n_tiles + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_tiles, ctx->d_plan, ctx->d_launch, ctx->d_split, ctx->d_whole);
+        kp.order = ctx->d_launch;
+        kp.n_launch = ctx->d_plan + 1;
+        grid_cap = 4u * ctx->n_tiles;
+        planned = true;
     }
+    if (!planned && ctx->split_live) HIP_TRY(ctx, hipMemsetAsync(ctx->d_split, 0, (size_t)ctx->n_tiles * 4, ctx->stream));   // this launch runs every block whole
+    ctx->split_live = planned;
     ctx->cost_valid = true;
     kp.density = ctx->d_density;
     kp.dinfo = ctx->dinfo;
@@ -1325,7 +1483,7 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
             pwg_waves_n = (uint32_t)pwg_waves((int)p->integrator);
             const uint32_t per_cu = (uint32_t)pwg_per_cu((int)p->integrator);
             pwg = plan_pwg_lds(ctx, kp.ks.sc, pwg_waves_n, per_cu, is_path);
-            pwg_grid = std::min((uint32_t)ctx->cu_count * per_cu, (ctx->n_tiles + pwg_waves_n - 1) / pwg_waves_n);   // small frames: no idle workgroups
+            pwg_grid = std::min((uint32_t)ctx->cu_count * per_cu, (grid_cap + pwg_waves_n - 1) / pwg_waves_n);   // small frames: no idle workgroups
         }
         if (!pwg) {
             const uint32_t waves = is_path ? (strip ? TRC_STRIP_PATH_WAVES : TRC_PATH_WAVES_GLOBAL)
@@ -1333,7 +1491,7 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
             plan_launch_lds(ctx, kp.ks.sc, waves, is_path);
         }
         const size_t rows = kp.ks.sc.stack_depth - kp.ks.sc.stack_lds;
-        const size_t need = rows * kBlock * sizeof(uint32_t) * (pwg ? (size_t)pwg_grid * pwg_waves_n : (size_t)ctx->n_tiles);   // rows per wavefront
+        const size_t need = rows * kBlock * sizeof(uint32_t) * (pwg ? (size_t)pwg_grid * pwg_waves_n : (size_t)grid_cap);   // rows per wavefront
         if (need > ctx->stack_ovf_bytes) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             if (ctx->d_stack_ovf) { (void)hipFree(ctx->d_stack_ovf); ctx->d_stack_ovf = nullptr; }
@@ -1357,8 +1515,8 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
     hipError_t le = hipEventRecord(e0, ctx->stream);
     if (le == hipSuccess) {
         if (pwg) le = launch_render_pwg(ctx, kp, p->integrator, pwg_grid, lds);
-        else if (ctx->lds_scene) launch_render<true>(ctx, kp, stats, p->integrator, lds);
-        else launch_render<false>(ctx, kp, stats, p->integrator, lds);
+        else if (ctx->lds_scene) launch_render<true>(ctx, kp, stats, p->integrator, lds, grid_cap);
+        else launch_render<false>(ctx, kp, stats, p->integrator, lds, grid_cap);
         if (le == hipSuccess) le = hipGetLastError();
     }
     if (le == hipSuccess) le = hipEventRecord(e1, ctx->stream);
@@ -1443,6 +1601,30 @@ trc_status trc_debug_profile(trc_ctx* ctx, uint64_t* out, uint32_t n_sites) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (uint32_t i = 0; i < n_sites && i < (uint32_t)kProfCount; ++i)
         for (int k = 0; k < 3; ++k) out[3 * i + k] = h[kStatCount + 3 * i + k];
+    return TRC_OK;
+}
+
+// developer diagnostic: the pixel blocks of the last trc_render (x | y << 16 in units of the block edge) and the duration
+// each one's wavefront measured (shader clocks / 64, the adaptive order's sort key)
+trc_status trc_debug_block_costs(trc_ctx* ctx, uint32_t* tiles, uint32_t* costs, uint32_t capacity, uint32_t* n_blocks, uint32_t* blk_shift) {
+    if (!ctx) return TRC_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n_blocks) *n_blocks = ctx->n_tiles;
+    if (blk_shift) *blk_shift = ctx->tiles_blk_shift;
+    const uint32_t n = std::min(capacity, ctx->n_tiles);
+    if (n == 0 || !ctx->d_tiles) return TRC_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (tiles) HIP_TRY(ctx, hipMemcpy(tiles, ctx->d_tiles, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (costs) {
+        const uint32_t stride = ctx->cost_quarters ? 4u : 1u;
+        std::vector<uint32_t> c((size_t)n * stride), sp(n, 0u);
+        HIP_TRY(ctx, hipMemcpy(c.data(), ctx->d_block_cost, c.size() * 4, hipMemcpyDeviceToHost));
+        if (stride == 4u) HIP_TRY(ctx, hipMemcpy(sp.data(), ctx->d_split, (size_t)n * 4, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n; ++i) {        // a block that ran as quarters: its slowest quarter, top bit set
+            const uint32_t* q = &c[(size_t)i * stride];
+            costs[i] = sp[i] ? (std::max(std::max(q[0], q[1]), std::max(q[2], q[3])) | 0x80000000u) : q[0];
+        }
+    }
     return TRC_OK;
 }
 
@@ -1605,7 +1787,8 @@ trc_status trc_debug_set(trc_ctx* ctx, const char* knob, int value) {
     const std::string k(knob);
     int* slot = k == "no_lds_fit" ? &ctx->knobs.no_lds_fit : k == "stack_lds_levels" ? &ctx->knobs.stack_lds_levels
               : k == "strip_len" ? &ctx->knobs.strip_len : k == "no_pwg" ? &ctx->knobs.no_pwg
-              : k == "sppm_serial_camera" ? &ctx->knobs.sppm_serial_camera : nullptr;
+              : k == "sppm_serial_camera" ? &ctx->knobs.sppm_serial_camera : k == "sppm_timing" ? &ctx->knobs.sppm_timing
+              : k == "force_blk_shift" ? &ctx->knobs.force_blk_shift : k == "no_split" ? &ctx->knobs.no_split : nullptr;
     if (!slot) return fail(ctx, TRC_ERR_INVALID_ARG, "trc_debug_set: unknown knob " + k);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // a launch in flight keeps the plan it was made with

@@ -16,6 +16,10 @@ using namespace trcdev;
 // ======================================================================= kernels
 extern __shared__ __attribute__((aligned(16))) uint32_t trc_smem[];
 
+// launch-list entries (KRender::order): index into the block list | child code << 29
+constexpr uint32_t kLaunchCodeShift = 29u;
+constexpr uint32_t kLaunchIndexMask = (1u << kLaunchCodeShift) - 1u;
+
 struct KScene {
     DScene sc;
     float root_box[6];
@@ -38,8 +42,13 @@ struct KRender {
     uint32_t* queue;                    // k_render_pwg: next position of the launch order to hand out
     uint32_t blk_shift;                 // log2 of the pixel-block edge of one wavefront: 3 (8x8, 64 lanes) or 2 (4x4, 16 lanes)
     uint32_t n_tiles, strip;            // k_render_strip: blocks in `tiles`, consecutive blocks per wavefront (1: k_render)
-    const uint32_t* order;              // launch order: order[blockIdx.x] = index into `tiles` (null: identity)
-    uint32_t* block_cost;               // duration of each block of `tiles` in this launch (the next launch's sort key)
+    const uint32_t* order;              // launch list: order[slot] = index into `tiles` | child code << 29 (null: identity).
+                                        // Child code 0: the whole block; 1..4: one 4x4 quarter of an 8x8 block on 16 lanes
+                                        // (cost-adaptive block size, plan_split).  k_render_strip: strip indices, no codes.
+    const uint32_t* n_launch;           // device word: entries of `order` in this launch (null: n_tiles); workgroups past it exit
+    uint32_t* block_cost;               // duration of each block in this launch (the next launch's sort key): slot 4 * tile +
+                                        // max(code - 1, 0) when the list may hold quarters (cost_stride 4), else slot `tile`
+    uint32_t cost_stride;
     const uint32_t* sobol32;            // TRC_FLAG_SOBOL: [40][52] generator matrices (null otherwise)
     const uint64_t* sobol_vdc;          // ... [52] VdCSobolMatrices[m - 1] + [52] VdCSobolMatricesInv[m - 1]
     uint32_t sobol_m;                   // ... log2Resolution
@@ -142,6 +151,15 @@ struct trc_ctx {
     uint32_t* d_order_keys[2] = {nullptr, nullptr};
     uint32_t* d_order_vals[2] = {nullptr, nullptr};
     uint32_t* d_order_hist = nullptr;
+    // cost-adaptive block size (trc_abi.hip::plan_split): which 8x8 blocks the last launch ran as four 4x4 quarters, the
+    // launch list with the quarters spliced in, and the plan {quarters' parents K, entries}
+    uint32_t* d_split = nullptr;
+    uint32_t* d_whole = nullptr;        // cost of a block when it last ran whole (while it runs as quarters)
+    uint32_t* d_launch = nullptr;
+    uint32_t* d_plan = nullptr;
+    uint32_t launch_cap = 0;            // entries d_launch holds = the grid of a launch that may split
+    bool split_live = false;            // d_split holds flags of the last launch's plan (else all zero)
+    bool cost_quarters = false;         // d_block_cost / d_split describe a launch made with cost_stride 4
     bool cost_valid = false; uint32_t cost_strip = 1;
     const uint32_t* d_last_order = nullptr; uint32_t order_age = 0;     // most recent sorted order (short launches reuse it)
     int cu_count = 0;
@@ -177,7 +195,7 @@ struct trc_ctx {
 
     // A/B and test knobs, per context: defaults from the environment at trc_create (TRC_NO_LDS_FIT, TRC_STACK_LDS_LEVELS,
     // TRC_STRIP_LEN, TRC_NO_PWG, TRC_SPPM_SERIAL_CAMERA), changed through trc_debug_set
-    struct Knobs { int no_lds_fit = 0, stack_lds_levels = 0, strip_len = 0, no_pwg = 0, sppm_serial_camera = 0; } knobs;
+    struct Knobs { int no_lds_fit = 0, stack_lds_levels = 0, strip_len = 0, no_pwg = 0, sppm_serial_camera = 0, sppm_timing = 0, force_blk_shift = 0, no_split = 0; } knobs;
     // k_render_pwg instantiations that were granted > 64 KB of dynamic LDS on THIS context's device (bit = integrator * 2 +
     // sobol): hipFuncSetAttribute applies to the current device only, so the grant is per context, not per process
     uint32_t pwg_lds_granted = 0;
@@ -228,5 +246,6 @@ size_t trc_dyn_lds_bytes(const trc_ctx* ctx, bool stats);
 // trc_lbvh.hip: stable 24-bit radix sort of (key, value) pairs
 void trc_sort_pairs24(hipStream_t st, uint32_t* keys[2], uint32_t* vals[2], uint32_t* hist, uint32_t* digit_base, uint32_t n, int* result);
 uint32_t trc_sort_hist_words(uint32_t n);
+hipEvent_t trc_get_event(trc_ctx* ctx);   // from the context's pool (null on failure); pairs go to ctx->pending
 void trc_sppm_release(trc_ctx* ctx);   // frees ctx->sppm (no-op when absent)
 void trc_sppm_order_after_camera(trc_ctx* ctx);   // context stream waits for a camera pass running ahead (no-op when none)

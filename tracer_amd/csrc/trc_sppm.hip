@@ -720,12 +720,25 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
             trc_status ts = camera_beside(s->frame_count + 1);
             if (ts != TRC_OK) return frame_failed(ts);
         }
+        // knob "sppm_timing": the frame's two segments on the context stream -- [photon pass] and [hash, table,
+        // refine], i.e. everything but the collectives -- timed with event pairs into trc_stats.kernel_ms / launches
+        hipEvent_t seg[4] = {nullptr, nullptr, nullptr, nullptr};
+        const bool timing = ctx->knobs.sppm_timing != 0;
+        if (timing) {
+            for (hipEvent_t& e : seg) e = trc_get_event(ctx);
+            if (!seg[0] || !seg[1] || !seg[2] || !seg[3]) return frame_failed(trc_fail(ctx, TRC_ERR_HIP, "hipEventCreate failed"));
+            ctx->pending.emplace_back(seg[0], seg[1]); ctx->pending.emplace_back(seg[2], seg[3]);
+            ctx->launches++;
+            (void)hipEventRecord(seg[0], ctx->stream);
+        }
         if (all_lds) hipLaunchKernelGGL((k_sppm_photon<true>), dim3(chunk / kBlock), dim3(kBlock), lds, ctx->stream, kp);
         else hipLaunchKernelGGL((k_sppm_photon<false>), dim3(chunk / kBlock), dim3(kBlock), lds, ctx->stream, kp);
+        if (timing) (void)hipEventRecord(seg[1], ctx->stream);
         if (grouped) {                                  // every rank needs every photon for hashing + refine
             trc_status cs = trc_coll_allgather(ctx, s->d_pho, (size_t)chunk * sizeof(trc_PhotonRecord), ctx->stream, "allgather of the photon records");
             if (cs != TRC_OK) return frame_failed(cs);
         }
+        if (timing) (void)hipEventRecord(seg[2], ctx->stream);
         if (hipMemsetAsync(s->d_mark, 0, (size_t)nph * 4, ctx->stream) != hipSuccess ||     // loadAction clear, :785-790
             hipMemsetAsync(s->d_count, 0, (size_t)nph * 4, ctx->stream) != hipSuccess) return frame_failed(trc_fail(ctx, TRC_ERR_HIP, "SPPM grid clear"));
         hipLaunchKernelGGL(k_sppm_hash, dim3(nph / 256), dim3(256), 0, ctx->stream, s->d_pho, s->d_mark, s->d_count, s->d_cx);
@@ -737,6 +750,7 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
         }
         hipLaunchKernelGGL(k_sppm_refine, dim3(ctx->n_tiles), dim3(kBlock), 0, ctx->stream, kp);
         hipLaunchKernelGGL(k_sppm_end_frame, dim3(1), dim3(64), 0, ctx->stream, s->d_cx);
+        if (timing) (void)hipEventRecord(seg[3], ctx->stream);
         { const hipError_t le = hipGetLastError(); if (le != hipSuccess) return frame_failed(trc_fail(ctx, TRC_ERR_HIP, std::string("SPPM frame: ") + hipGetErrorString(le))); }
         s->frame_count += 1;
     }

@@ -93,6 +93,7 @@ def _load(path):
     L.trc_group_finalize.argtypes = [vp]
     L.trc_group_set_collectives.argtypes = [vp, vp, C.c_int, C.c_int]
     L.trc_debug_set.argtypes = [vp, C.c_char_p, C.c_int]
+    L.trc_debug_block_costs.argtypes = [vp, vp, vp, u32, C.POINTER(u32), C.POINTER(u32)]
     for name in abi.DEVICE_SYMBOLS:
         f = getattr(L, name)
         if name not in ("trc_abi_version", "trc_build_flavor", "trc_status_string", "trc_last_error", "trc_destroy"):
@@ -327,6 +328,15 @@ class Tracer:
     def debug_set(self, knob, value):
         """A/B and test knobs of this context (trc_debug_set): scheduling only, never a pixel."""
         self._check(self._L.trc_debug_set(self._h, knob.encode(), int(value)), "trc_debug_set")
+
+    def block_costs(self):
+        """(tiles, costs, blk_shift) of the last render launch (trc_debug_block_costs)."""
+        n, bs = C.c_uint32(0), C.c_uint32(0)
+        self._check(self._L.trc_debug_block_costs(self._h, None, None, 0, C.byref(n), C.byref(bs)), "trc_debug_block_costs")
+        tiles, costs = np.zeros(n.value, np.uint32), np.zeros(n.value, np.uint32)
+        self._check(self._L.trc_debug_block_costs(self._h, tiles.ctypes.data, costs.ctypes.data, n.value, C.byref(n), C.byref(bs)),
+                    "trc_debug_block_costs")
+        return tiles, costs, bs.value
 
     def group_finalize(self):
         self._check(self._L.trc_group_finalize(self._h), "trc_group_finalize")
