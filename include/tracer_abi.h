@@ -417,7 +417,11 @@ trc_status trc_synchronize(trc_ctx* ctx);
 #define TRC_TRACE_ANY_HIT     1   /* stop at the first accepted hit closer than tmax (shadow rays, Render.hh:244) */
 #define TRC_TRACE_PRODUCTION  2   /* walk the tree with the round the render kernels run (no instrumentation; on trees
                                      read from global memory the wavefront leaves the descent early, dev_intersect.hpp):
-                                     same hit record, n_descend / n_return / n_leaf left 0 */
+                                     same hit record, n_descend / n_return / n_leaf left 0.  With TRC_TRACE_ANY_HIT it
+                                     is the order-free walk the render kernels give shadow rays: an any-hit query only
+                                     asks WHETHER something lies in front of tmax, which does not depend on the order
+                                     the tree is walked in, but which primitive is met first does -- only `hit` is
+                                     defined then (pType -1, the other fields 0) */
 trc_status trc_trace_rays(trc_ctx* ctx, const trc_ray* rays, size_t n, trc_hit* out, int any_hit);
 
 trc_status trc_get_stats(trc_ctx* ctx, trc_stats* out);   /* synchronises the stream */

@@ -64,9 +64,11 @@ def test_quarters_on_a_tree_read_from_memory(gpu, integrator):
 
 
 def test_the_plan_leaves_a_full_frame_alone(gpu, cornell_spheres):
-    """many more blocks than wavefront slots: the work term of the plan's model wins, nothing is split"""
+    """many more blocks than wavefront slots: the work term of the plan's model wins -- nothing is split but the odd
+    block whose measured duration sticks out of the ideal makespan (a stalled wavefront)"""
     W, H, spp = 1920, 1080, 8
     gpu.upload_scene(cornell_spheres.view); gpu.set_camera(host.prepare_camera(W, H)); gpu.resize(W, H)
     gpu.debug_set("no_split", 0)
     runs = [_launch(gpu, 3, spp=spp) for _ in range(3)]
-    assert [r[3] for r in runs] == [0, 0, 0] and _same(runs[0], runs[2])
+    assert _same(runs[0], runs[1]) and _same(runs[0], runs[2])
+    assert runs[0][3] == 0 and max(r[3] for r in runs) <= 32400 // 100, [r[3] for r in runs]

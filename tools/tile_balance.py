@@ -5,8 +5,9 @@ rank.  No hardware scaling curve exists for this repository (one GPU per box): t
 
     python3 tools/tile_balance.py --config 2|4|5 [--spp S] [--ranks 2,4,8]
 
-config 2 / 4 (path tracing): rank r renders the tiles (tx + ty) % N == r of the one named frame, every rank twice (the
-second launch of a block list runs in the adaptive expensive-first order).
+config 2 / 4 (path tracing): rank r renders the tiles (tx + ty) % N == r of the one named frame, every rank four times (from
+the second launch of a block list on, the adaptive expensive-first order and the cost-adaptive block size apply; the
+fourth launch is reported).
 config 5 (SPPM): rank r runs its share of every pass (camera + refine on its tiles, its photon index range, hash / table
 over ALL photons) with the collectives of trc_group_set_collectives served from a 1-rank pass running in lock step in a
 second context (bit-identical photons: tests/test_gpu_shared_gpu_ranks.py), timed per frame with the "sppm_timing" knob:
@@ -52,7 +53,7 @@ def path_traced(cfg):
         for N in ranks:
             ms, rays = [], []
             for r in range(N):
-                for rep in range(2):
+                for rep in range(4):        # launch 1 measures the blocks, later ones run in adaptive order with the plan's quarters
                     t.seed(0x5EED0000); t.reset_stats()
                     t.render(spp=spp, integrator=wl["integrator"], tile_rank=r, tile_nranks=N, small_blocks=small); t.synchronize()
                 st = t.stats()

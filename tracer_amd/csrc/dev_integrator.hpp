@@ -399,10 +399,15 @@ TRC_DEV bool mis_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, T
     const float _tr = 1.0f;
     const float _dis = length(_dir);
     const Ray _ray = make_ray(_origin, _nor);
-    HitRec shr;
-    hit_init(shr);
     n_rays++;
-    const bool blocked = scene_hit<ALL_LDS, STATS, true, false, false>(cx.S, cx.root_min, cx.root_max, _ray, shr, _dis, cx.stack, cx.lvstack, cnt);
+    bool blocked;
+    if (STATS || !TRC_ANYHIT_FREE) {                                  // the reference's walk (the exact counters are defined on it)
+        HitRec shr;
+        hit_init(shr);
+        blocked = scene_hit<ALL_LDS, STATS, true, false, false>(cx.S, cx.root_min, cx.root_max, _ray, shr, _dis, cx.stack, cx.lvstack, cnt);
+    } else {                                                          // any-hit: the answer does not depend on the order (dev_intersect.hpp)
+        blocked = scene_occluded<ALL_LDS, false, false>(cx.S, cx.root_min, cx.root_max, _ray, _dis, cx.stack, cx.S.stack_lds);
+    }
     const F3 minus_d = -ps.ray.d;
     const F3 base_color = hit_color(cx.sh, rec);
     if (!blocked) {                                                  // light sampling, :339-356

@@ -557,4 +557,121 @@ TRC_DEV bool scene_hit(const SceneRef& S, const F3 root_min, const F3 root_max, 
     return tv.ry < test_t;
 }
 
+// ---------------------------------------------------------------- any-hit, order-free (production kernels)
+// A shadow ray only asks WHETHER something lies in (FLT_MIN, test_t): Scene::hit returns at the first accepted hit
+// (Render.hh:244) and nothing lowers range_t.y before that, so every box and primitive of an any-hit walk is tested
+// against the same fixed range -- the set of boxes that pass and the answer do not depend on the visiting order (which
+// primitive is found first does; no caller of the any-hit form reads the record: Render.metal:335-337) -- with one
+// exception that is kept, the pick between the children when only one box passes (below).  The
+// production kernels therefore walk shadow rays in whatever order hides latency best: a lane holds up to TWO pending
+// subtrees in hand (the deepest ones, like a depth-first walk) and expands both in one step -- two independent node
+// fetches in flight per lane, four box tests, half the dependent round trips of the one-node-at-a-time walk; no hit_t,
+// no near / far ordering, no HitRecord.  The instrumented kernels keep the reference's walk (their counters are defined
+// on it), and tests/test_gpu_traversal.py compares the two on the adversarial batches.
+// Pending subtrees beyond the two in hand go to the lane's stack; two fronts can leave up to two entries per level
+// there, twice what the stack is sized for, so a lane whose stack fills up starts over one node at a time (`wide` off:
+// at most one entry per level, the depth the stack is sized for).  Same answer: the order is free.
+// Two corners of the reference's arithmetic are kept.  A square or a triangle met at EXACTLY t == test_t is "accepted" by
+// its hit_test (Square.hh / Triangle.hh reject only t > range_t.y) but leaves range_t.y where it was, so Scene::hit does
+// not report it (range_t.y < test_t, Render.hh:244,250): not an occluder here either.  And an accepted test whose t is
+// NaN (overflowing coordinates) makes range_t.y NaN, after which every later test of the reference's walk passes and
+// the answer does depend on the order: such a ray is handed back to the reference's walk (return value 2).
+#ifndef TRC_ANYHIT_FREE
+#define TRC_ANYHIT_FREE 1        // production kernels: shadow rays through scene_occluded (0: the reference's walk everywhere)
+#endif
+#ifndef TRC_ANYHIT_WIDE
+#define TRC_ANYHIT_WIDE 0        // 1: two subtrees in hand (measured slower: the second node costs the MIS kernels 31 spilled registers)
+#endif
+enum : uint32_t { kOccludedNo = 0u, kOccludedYes = 1u, kOccludedAskReference = 2u };
+template <bool ALL_LDS, bool VOL, bool HYB>
+TRC_DEV uint32_t scene_occluded_free(const SceneRef& S, const F3 root_min, const F3 root_max, const Ray& ray, const float test_t,
+                                     uint32_t* stack, const uint32_t stack_cap) {
+    Trav tb;
+    TravCounters nocount;
+    if (!trav_begin<false>(root_min, root_max, ray, test_t, tb, nocount)) return kOccludedNo;
+    const float rx = FLT_MIN;
+    constexpr uint32_t kRoot = kTagInterior << kTagIndexBits;
+    uint32_t cur0 = kRoot, cur1 = kTagNone, sp = 0;
+    bool wide = TRC_ANYHIT_WIDE != 0, found = false, ask_reference = false;
+    HitRec rec;                                   // written by the primitive tests, read by nobody
+    hit_init(rec);
+    auto is_interior = [](uint32_t tag) { return tag != kTagNone && (tag >> kTagIndexBits) == kTagInterior; };
+    auto is_leaf = [](uint32_t tag) { return tag != kTagNone && (tag >> kTagIndexBits) != kTagInterior; };
+    bool restarted = false;                       // this step ran out of stack: what it still finds belongs to the abandoned walk
+    auto give = [&](uint32_t tag) {               // a box that passed: into the hand, else onto the stack
+        if (restarted) return;
+        if (cur0 == kTagNone) cur0 = tag;
+        else if (wide && cur1 == kTagNone) cur1 = tag;
+        else if (sp < stack_cap) { stack_put<HYB>(S, stack, sp, tag); sp++; }
+        else { wide = false; restarted = true; sp = 0; cur0 = kRoot; cur1 = kTagNone; }      // stack full: start over, one node at a time
+    };
+    constexpr int kDescendMin = ALL_LDS ? TRC_DESCEND_MIN_LDS : TRC_DESCEND_MIN_GLOBAL;
+    for (;;) {
+        // ---- box steps: every lane with an interior node in hand expands it (both of them when it holds two)
+        for (;;) {
+            const bool i0 = is_interior(cur0), i1 = is_interior(cur1);
+            const unsigned long long m = __ballot(i0 || i1);
+            if (m == 0ull) break;
+            if (__popcll(m) < kDescendMin && __ballot(is_leaf(cur0) || is_leaf(cur1)) != 0ull) break;
+            if (!(i0 || i1)) continue;
+            float4 a0, a1, a2, a3, b0, b1, b2, b3;
+            const uint32_t t0 = cur0, t1 = cur1;
+            restarted = false;
+            if (i0) load_node<ALL_LDS>(S, t0 & kTagIndexMask, a0, a1, a2, a3);
+            if (i1) load_node<ALL_LDS>(S, t1 & kTagIndexMask, b0, b1, b2, b3);
+            if (i0) cur0 = kTagNone;
+            if (i1) cur1 = kTagNone;
+            // both children pass: both are walked, in any order.  ONE passes: the reference still picks by
+            // (t_left < t_right) with the other side's t left at range_t.y (Render.hh:161-174) -- a lone child entered at
+            // exactly t == range_t.y loses to its sibling, whose box did NOT pass, and is never visited.  Kept literally.
+            auto expand = [&](const float4& q0, const float4& q1, const float4& q2, const float4& q3) {
+                float t_left = test_t, t_right = test_t;
+                const bool l = box_hit_t(f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), ray, rx, test_t, t_left);
+                const bool r = box_hit_t(f3(q1.z, q1.w, q2.x), f3(q2.y, q2.z, q2.w), ray, rx, test_t, t_right);
+                const uint32_t tagL = __float_as_uint(q3.z), tagR = __float_as_uint(q3.w);
+                if (l && r) { give(tagL); give(tagR); }
+                else if (l || r) give(t_left < t_right ? tagL : tagR);
+            };
+            if (i0) expand(a0, a1, a2, a3);
+            if (i1 && wide) expand(b0, b1, b2, b3);
+            // refill the hand from the stack (deepest pending subtrees first)
+            if (restarted) continue;
+            if (cur0 == kTagNone && sp > 0u) { sp--; cur0 = stack_get<HYB>(S, stack, sp); }
+            if (wide && cur1 == kTagNone && sp > 0u) { sp--; cur1 = stack_get<HYB>(S, stack, sp); }
+        }
+        // ---- primitive tests: the leaves in hand, one after the other
+#pragma unroll 1
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t tag = k == 0 ? cur0 : cur1;
+            const bool leaf = !found && is_leaf(tag);
+            if (__ballot(leaf) == 0ull) continue;
+            if (leaf) {
+                Trav tv;
+                tv.ry = test_t;
+                if (trav_test_leaf<false, false, VOL>(S, ray, rec, tv, tag, nocount)) {
+                    if (tv.ry < test_t) found = true;                 // Render.hh:244
+                    else if (!(tv.ry == test_t)) { found = true; ask_reference = true; }      // NaN: the order matters from here on
+                }
+                if (k == 0) cur0 = kTagNone; else cur1 = kTagNone;
+            }
+        }
+        if (found) { cur0 = cur1 = kTagNone; sp = 0; }
+        if (cur0 == kTagNone && sp > 0u) { sp--; cur0 = stack_get<HYB>(S, stack, sp); }
+        if (wide && cur1 == kTagNone && sp > 0u) { sp--; cur1 = stack_get<HYB>(S, stack, sp); }
+        if (__ballot(cur0 != kTagNone || cur1 != kTagNone) == 0ull) break;
+    }
+    return ask_reference ? kOccludedAskReference : (found ? kOccludedYes : kOccludedNo);
+}
+// the any-hit Scene::hit of the production kernels: order-free, the reference's walk for the rays that need it
+template <bool ALL_LDS, bool VOL, bool HYB>
+TRC_DEV bool scene_occluded(const SceneRef& S, const F3 root_min, const F3 root_max, const Ray& ray, const float test_t,
+                            uint32_t* stack, const uint32_t stack_cap) {
+    const uint32_t r = scene_occluded_free<ALL_LDS, VOL, HYB>(S, root_min, root_max, ray, test_t, stack, stack_cap);
+    if (r != kOccludedAskReference) return r == kOccludedYes;
+    HitRec rec;
+    hit_init(rec);
+    TravCounters nocount;
+    return scene_hit<ALL_LDS, false, true, false, VOL, HYB>(S, root_min, root_max, ray, rec, test_t, stack, nullptr, nocount);
+}
+
 }  // namespace trcdev

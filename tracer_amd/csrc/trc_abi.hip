@@ -632,13 +632,16 @@ __global__ void __launch_bounds__(kBlock) k_trace(const KTrace kp) {
     hit_init(rec);
     TravCounters cnt;
     counters_zero(cnt);
-    const bool h = scene_hit<LDS, STATS, ANY, true>(S, f3(kp.ks.root_box[0], kp.ks.root_box[1], kp.ks.root_box[2]),
-                                                 f3(kp.ks.root_box[3], kp.ks.root_box[4], kp.ks.root_box[5]), ray, rec, in.tmax, stack, lvstack, cnt);
+    constexpr bool kOrderFree = ANY && !STATS && TRC_ANYHIT_FREE;      // the production kernels' shadow-ray walk: only the answer is defined
+    const F3 root_min = f3(kp.ks.root_box[0], kp.ks.root_box[1], kp.ks.root_box[2]), root_max = f3(kp.ks.root_box[3], kp.ks.root_box[4], kp.ks.root_box[5]);
+    bool h;
+    if (kOrderFree) h = scene_occluded<LDS, false, false>(S, root_min, root_max, ray, in.tmax, stack, sc.stack_lds);
+    else h = scene_hit<LDS, STATS, ANY, true>(S, root_min, root_max, ray, rec, in.tmax, stack, lvstack, cnt);
     trc_hit o;
     memset(&o, 0, sizeof o);
     o.hit = h ? 1 : 0;
     o.pType = -1;
-    if (h) {
+    if (h && !kOrderFree) {
         o.pType = (int32_t)(rec.tag >> kTagIndexBits);
         o.pIndex = rec.tag & kTagIndexMask;
         o.t = rec.t;

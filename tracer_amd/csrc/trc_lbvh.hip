@@ -401,9 +401,26 @@ __global__ void __launch_bounds__(256) k_lbvh_rotate_pass(const DLeaf* leaves, c
     for (int k = 0; k < 3; ++k) { q[k] = fminf(bd[k], bk[k]); q[3 + k] = fmaxf(bd[3 + k], bk[3 + k]); }
 }
 
-// fat node i (dev_scene.hpp) + record of interior i in the reference layout; one thread per interior node
+// depth of interior node i (root 0): a walk up the parent links, <= TRC_MAX_BVH_DEPTH steps
+__global__ void __launch_bounds__(256) k_lbvh_depth(uint32_t n_interior, const uint32_t* parent_interior, uint32_t* keys, uint32_t* vals) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_interior) return;
+    uint32_t d = 0;
+    for (uint32_t j = i; j != 0u && d < 255u; j = parent_interior[j]) ++d;
+    keys[i] = d; vals[i] = i;
+}
+// rank[interior] = its position in the depth-sorted order
+__global__ void __launch_bounds__(256) k_lbvh_rank(uint32_t n_interior, const uint32_t* sorted_vals, uint32_t* rank) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p < n_interior) rank[sorted_vals[p]] = p;
+}
+
+// fat node of interior i (dev_scene.hpp) + its record in the reference layout; one thread per interior node.  The fat nodes
+// are numbered by DEPTH (rank[]: a stable sort of the interior nodes by their depth, root = 0), not by Karras index: any
+// prefix of the array is then a top of the tree, which is what the render kernels stage in LDS (stage_scene, k_render_pwg)
+// -- the numbering host-built trees get from their BFS walk (trc_abi.hip::build_blob).
 __global__ void __launch_bounds__(256) k_lbvh_emit(const DLeaf* leaves, const uint32_t* vals, uint32_t n, DTopo tp, const float* boxes,
-                                                  uint32_t* blob_nodes, trc_BVH* ref) {
+                                                  const uint32_t* rank, uint32_t* blob_nodes, trc_BVH* ref) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i + 1 >= n) return;
     const uint32_t ch[2] = {tp.child_l[i], tp.child_r[i]};
@@ -422,11 +439,11 @@ __global__ void __launch_bounds__(256) k_lbvh_emit(const DLeaf* leaves, const ui
             const float* b = boxes + (size_t)c * 6;
 #pragma unroll
             for (int a = 0; a < 6; ++a) cb[k][a] = b[a];
-            tag[k] = (kTagInterior << kTagIndexBits) | c;
+            tag[k] = (kTagInterior << kTagIndexBits) | rank[c];
             slot[k] = n + c;                                   // interior c >= 1 here (0 is the root)
         }
     }
-    uint32_t* q = blob_nodes + (size_t)i * kNodeDwords;
+    uint32_t* q = blob_nodes + (size_t)rank[i] * kNodeDwords;
     q[0] = __float_as_uint(cb[0][0]); q[1] = __float_as_uint(cb[0][1]); q[2] = __float_as_uint(cb[0][2]); q[3] = __float_as_uint(cb[0][3]);
     q[4] = __float_as_uint(cb[0][4]); q[5] = __float_as_uint(cb[0][5]); q[6] = __float_as_uint(cb[1][0]); q[7] = __float_as_uint(cb[1][1]);
     q[8] = __float_as_uint(cb[1][2]); q[9] = __float_as_uint(cb[1][3]); q[10] = __float_as_uint(cb[1][4]); q[11] = __float_as_uint(cb[1][5]);
@@ -584,7 +601,22 @@ trc_status trc_upload_scene_lbvh(trc_ctx* ctx, const trc_scene* s) {
         trc_status rs = refit();
         if (rs != TRC_OK) return rs;
     }
-    hipLaunchKernelGGL(k_lbvh_emit, g_int, b256, 0, st, d_leaves, d_vals[cur], n, tp, d_boxes, ctx->d_blob + sc.off_nodes, ctx->d_bvh_ref);
+    // fat-node numbering: interior nodes sorted by depth (one stable 8-bit radix pass; the root is the only node of depth 0)
+    uint32_t* d_rank = nullptr;                         // reuses the arrival array (the heights in d_height are read back below)
+    {
+        uint32_t* dk[2] = {d_keys[cur ^ 1], nullptr};
+        uint32_t* dv[2] = {d_vals[cur ^ 1], nullptr};
+        HIP_TRY(ctx, buf.alloc(&dk[1], n_interior)); HIP_TRY(ctx, buf.alloc(&dv[1], n_interior));
+        d_rank = d_arrived;
+        hipLaunchKernelGGL(k_lbvh_depth, g_int, b256, 0, st, n_interior, tp.parent_interior, dk[0], dv[0]);
+        const uint32_t nsb = (n_interior + kSortTile - 1) / kSortTile;
+        hipLaunchKernelGGL(k_radix_hist, dim3(nsb), dim3(kSortBlock), 0, st, dk[0], n_interior, 0u, d_hist, nsb);
+        hipLaunchKernelGGL(k_radix_row_scan, dim3(256), b256, 0, st, d_hist, nsb, d_digit_base);
+        hipLaunchKernelGGL(k_radix_digit_base, dim3(1), b256, 0, st, d_digit_base);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(nsb), dim3(kSortBlock), 0, st, dk[0], dv[0], dk[1], dv[1], n_interior, 0u, d_hist, d_digit_base, nsb);
+        hipLaunchKernelGGL(k_lbvh_rank, g_int, b256, 0, st, n_interior, dv[1], d_rank);
+    }
+    hipLaunchKernelGGL(k_lbvh_emit, g_int, b256, 0, st, d_leaves, d_vals[cur], n, tp, d_boxes, d_rank, ctx->d_blob + sc.off_nodes, ctx->d_bvh_ref);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(e1, st));
 
@@ -597,14 +629,14 @@ trc_status trc_upload_scene_lbvh(trc_ctx* ctx, const trc_scene* s) {
     (void)hipEventElapsedTime(&ms, e0, e1);
     if (height > TRC_MAX_BVH_DEPTH) return trc_fail(ctx, TRC_ERR_BVH_INVALID, "lbvh: tree deeper than TRC_MAX_BVH_DEPTH");
 
-    plan_lds(sc, height, false);      // Karras numbering is not top-of-tree first: stage the whole tree or nothing
+    plan_lds(sc, height, true);       // the fat nodes are numbered by depth: any prefix may be staged
     sc.blob = ctx->d_blob;
     KScene ks{};
     ks.sc = sc;
     for (int a = 0; a < 6; ++a) ks.root_box[a] = root_box[a];
     ctx->ks = ks;
     ctx->lds_scene = sc.n_lds_nodes == sc.n_nodes;
-    ctx->lds_prefix_ok = false;
+    ctx->lds_prefix_ok = true;
     ctx->n_bvh_ref = n_nodes;
     ctx->lbvh_height = height;
     ctx->lbvh_build_ms = ms;
