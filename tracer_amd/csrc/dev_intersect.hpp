@@ -307,10 +307,15 @@ TRC_DEV bool cube_hit_test(const SceneRef& S, uint32_t index, const Ray& ray, fl
     return true;
 }
 
-template <bool STATS>
-TRC_DEV bool triangle_hit_test(const SceneRef& S, uint32_t index, const Ray& ray, float rx, float& ry, HitRec& rec, TravCounters& cnt) {
+struct TriPos { float4 a, b, c; };       // the 48-byte position record of one triangle
+TRC_DEV TriPos load_tripos(const SceneRef& S, uint32_t index) {
     const uint32_t* tp = S.blob + S.off_tripos + (size_t)index * kTriPosDwords;
-    const float4 a4 = ld4(tp), b4 = ld4(tp + 4), c4 = ld4(tp + 8);
+    TriPos t; t.a = ld4_global(tp); t.b = ld4_global(tp + 4); t.c = ld4_global(tp + 8);
+    return t;
+}
+template <bool STATS>
+TRC_DEV bool triangle_hit_test(const SceneRef& S, uint32_t index, const TriPos& pos, const Ray& ray, float rx, float& ry, HitRec& rec, TravCounters& cnt) {
+    const float4 a4 = pos.a, b4 = pos.b, c4 = pos.c;
     const F3 v0 = f3(a4.x, a4.y, a4.z), v1 = f3(b4.x, b4.y, b4.z), v2 = f3(c4.x, c4.y, c4.z);
     F3 v0v1 = v1 - v0;
     F3 v0v2 = v2 - v0;
@@ -409,9 +414,10 @@ TRC_DEV bool trav_begin(const F3 root_min, const F3 root_max, const Ray& ray, co
     return true;
 }
 
-// leaf test of one primitive tag; returns true when the hit was accepted (tv.ry lowered)
+// leaf test of one primitive tag; returns true when the hit was accepted (tv.ry lowered).  `pre`: the triangle's positions
+// when the caller fetched them ahead (TRC_TRI_EARLY), else null
 template <bool STATS, bool EAGER_UV, bool VOL>
-TRC_DEV bool trav_test_leaf(const SceneRef& S, const Ray& ray, HitRec& rec, Trav& tv, uint32_t tag, TravCounters& cnt) {
+TRC_DEV bool trav_test_leaf(const SceneRef& S, const Ray& ray, HitRec& rec, Trav& tv, uint32_t tag, TravCounters& cnt, const TriPos* pre = nullptr) {
     const float rx = FLT_MIN;
     const uint32_t type = tag >> kTagIndexBits, index = tag & kTagIndexMask;
     bool ok;
@@ -430,7 +436,8 @@ TRC_DEV bool trav_test_leaf(const SceneRef& S, const Ray& ray, HitRec& rec, Trav
     } else {
         if (STATS) cnt.leaf[3]++;
         ProfScope<STATS> scope(cnt, kProfTriangle);
-        ok = triangle_hit_test<STATS>(S, index, ray, rx, tv.ry, rec, cnt);
+        ok = pre ? triangle_hit_test<STATS>(S, index, *pre, ray, rx, tv.ry, rec, cnt)
+                 : triangle_hit_test<STATS>(S, index, load_tripos(S, index), ray, rx, tv.ry, rec, cnt);
     }
     if (ok) rec.tag = tag;
     return ok;
@@ -512,6 +519,19 @@ TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const flo
 #define TRC_DESCEND_MIN_GLOBAL 8
 #endif
     constexpr int kDescendMin = ALL_LDS ? TRC_DESCEND_MIN_LDS : TRC_DESCEND_MIN_GLOBAL;
+    // TRC_TRI_EARLY (trees read from memory, production walk): the moment a lane's next stop becomes a triangle, its 48
+    // bytes of positions are requested, so the fetch runs beside the box steps the rest of the wavefront still takes
+    // instead of starting when the leaf phase does.  Same data, same test.
+#ifndef TRC_TRI_EARLY
+#define TRC_TRI_EARLY 0
+#endif
+    constexpr bool kTriEarly = TRC_TRI_EARLY && !ALL_LDS && !STATS;
+    TriPos pre;
+    bool have_pre = false;
+    auto fetch_ahead = [&]() {
+        if (kTriEarly && !tv.done && (tv.tag >> kTagIndexBits) == 3u) { pre = load_tripos(S, tv.tag & kTagIndexMask); have_pre = true; }
+    };
+    fetch_ahead();                 // a leaf popped at the end of the previous round
     for (;;) {
         const bool interior = !tv.done && (tv.tag >> kTagIndexBits) == kTagInterior;
         if (!STATS && kDescendMin > 1) {
@@ -540,9 +560,10 @@ TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const flo
         } else {
             trav_pop_or_finish<HYB, STATS>(S, tv, tv.level - 1, stack, lvstack, cnt);
         }
+        fetch_ahead();
     }
     if (!tv.done && (tv.tag >> kTagIndexBits) != kTagInterior) {
-        trav_test_leaf<STATS, EAGER_UV, VOL>(S, ray, rec, tv, tv.tag, cnt);
+        trav_test_leaf<STATS, EAGER_UV, VOL>(S, ray, rec, tv, tv.tag, cnt, (kTriEarly && have_pre) ? &pre : nullptr);
         if (ANY && tv.ry < test_t) tv.done = true;                    // Render.hh:244
         else trav_pop_or_finish<HYB, STATS>(S, tv, tv.level, stack, lvstack, cnt);
     }
@@ -605,7 +626,10 @@ TRC_DEV uint32_t scene_occluded_free(const SceneRef& S, const F3 root_min, const
         else if (sp < stack_cap) { stack_put<HYB>(S, stack, sp, tag); sp++; }
         else { wide = false; restarted = true; sp = 0; cur0 = kRoot; cur1 = kTagNone; }      // stack full: start over, one node at a time
     };
-    constexpr int kDescendMin = ALL_LDS ? TRC_DESCEND_MIN_LDS : TRC_DESCEND_MIN_GLOBAL;
+#ifndef TRC_OCCL_DESCEND_MIN
+#define TRC_OCCL_DESCEND_MIN 1      // plain round: shadow rays of a wavefront walk left-first, i.e. together (1 / 4 / 8 / 16 / 32: 50.9 / 50.9 / 51.3 / 52.1 / 53.1 ms on config 3)
+#endif
+    constexpr int kDescendMin = ALL_LDS ? TRC_DESCEND_MIN_LDS : TRC_OCCL_DESCEND_MIN;
     for (;;) {
         // ---- box steps: every lane with an interior node in hand expands it (both of them when it holds two)
         for (;;) {
@@ -629,7 +653,11 @@ TRC_DEV uint32_t scene_occluded_free(const SceneRef& S, const F3 root_min, const
                 const bool l = box_hit_t(f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), ray, rx, test_t, t_left);
                 const bool r = box_hit_t(f3(q1.z, q1.w, q2.x), f3(q2.y, q2.z, q2.w), ray, rx, test_t, t_right);
                 const uint32_t tagL = __float_as_uint(q3.z), tagR = __float_as_uint(q3.w);
+#if defined(TRC_ANYHIT_NEAR)
+                if (l && r) { if (t_left < t_right) { give(tagL); give(tagR); } else { give(tagR); give(tagL); } }
+#else
                 if (l && r) { give(tagL); give(tagR); }
+#endif
                 else if (l || r) give(t_left < t_right ? tagL : tagR);
             };
             if (i0) expand(a0, a1, a2, a3);
