@@ -25,7 +25,7 @@
     } while (0)
 
 int main(int argc, char** argv) {
-    std::string scene_name = "spheres", integ_name = "path", out = "frame.png", mesh_path, density_path, pbrt_path;
+    std::string scene_name = "spheres", integ_name = "path", out = "frame.png", mesh_path, density_path, pbrt_path, hdr_path;
     uint32_t W = 640, H = 360, spp = 64;
     bool lbvh = false, sobol = false, size_given = false;
     for (int i = 1; i < argc; ++i) {
@@ -35,7 +35,8 @@ int main(int argc, char** argv) {
         else if (a == "--size" && i + 2 < argc) { W = (uint32_t)std::atoi(argv[++i]); H = (uint32_t)std::atoi(argv[++i]); size_given = true; }
         else if (a == "--pbrt" && i + 1 < argc) pbrt_path = argv[++i];          // a whole pbrt-v3 scene
         else if (a == "--spp" && i + 1 < argc) spp = (uint32_t)std::atoi(argv[++i]);
-        else if (a == "--mesh" && i + 1 < argc) mesh_path = argv[++i];          // Wavefront OBJ or pbrt-v3 trianglemeshes
+        else if (a == "--mesh" && i + 1 < argc) mesh_path = argv[++i];          // Wavefront OBJ, PLY or pbrt-v3 trianglemeshes
+        else if (a == "--hdr" && i + 1 < argc) hdr_path = argv[++i];            // Radiance .hdr backdrop (the reference's texHDR)
         else if (a == "--density" && i + 1 < argc) density_path = argv[++i];    // pbrt-v3 heterogeneous medium
         else if (a == "--lbvh") lbvh = true;
         else if (a == "--sobol") sobol = true;
@@ -53,7 +54,9 @@ int main(int argc, char** argv) {
     uint32_t n_mv = 0, n_mi = 0;
     if (!mesh_path.empty()) {
         const bool pbrt = mesh_path.size() > 5 && mesh_path.compare(mesh_path.size() - 5, 5, ".pbrt") == 0;
-        if ((pbrt ? trc_host_mesh_load_pbrt(mesh_path.c_str(), &mesh) : trc_host_mesh_load_obj(mesh_path.c_str(), &mesh)) != TRC_OK) {
+        const bool ply = mesh_path.size() > 4 && mesh_path.compare(mesh_path.size() - 4, 4, ".ply") == 0;
+        if ((pbrt ? trc_host_mesh_load_pbrt(mesh_path.c_str(), &mesh) : ply ? trc_host_mesh_load_ply(mesh_path.c_str(), &mesh)
+                  : trc_host_mesh_load_obj(mesh_path.c_str(), &mesh)) != TRC_OK) {
             std::fprintf(stderr, "cannot read a triangle mesh from %s\n", mesh_path.c_str());
             return 1;
         }
@@ -72,8 +75,8 @@ int main(int argc, char** argv) {
             return 1;
         }
         scene_name = pbrt_path;
-        std::fprintf(stderr, "%s: %u shapes (%u not handled), %u materials not handled\n", pbrt_path.c_str(), info.n_shapes,
-                     info.n_unsupported_shapes, info.n_unsupported_materials);
+        std::fprintf(stderr, "%s: %u shapes (%u not handled), %u materials and %u textures not handled\n", pbrt_path.c_str(), info.n_shapes,
+                     info.n_unsupported_shapes, info.n_unsupported_materials, info.n_unsupported_textures);
     } else {
         if (trc_host_scene_create(kind, mv, n_mv, mi, n_mi, &hs) != TRC_OK) { std::fprintf(stderr, "scene prep failed\n"); return 1; }
         trc_host_prepare_camera(&cam, (float)W, (float)H);
@@ -108,6 +111,14 @@ int main(int argc, char** argv) {
         trc_GridDensityInfo info;
         trc_host_make_density_info(10.0f, 90.0f, 0.5f, nx, ny, nz, cloud.data(), &info);
         CHECK(trc_upload_density(ctx, &info, cloud.data()));
+    }
+    if (!hdr_path.empty()) {                     // AAPLRenderer.mm:352-383: the equirectangular backdrop, rows bottom-up
+        uint32_t ew = 0, eh = 0;
+        float* env = nullptr;
+        if (trc_host_load_hdr(hdr_path.c_str(), &ew, &eh, &env) != TRC_OK) { std::fprintf(stderr, "cannot read a Radiance .hdr image from %s\n", hdr_path.c_str()); return 1; }
+        const trc_status es = trc_set_environment_map(ctx, ew, eh, env);
+        trc_host_free(env);
+        CHECK(es);
     }
     CHECK(trc_set_camera(ctx, &cam));
     CHECK(trc_resize(ctx, W, H));

@@ -32,7 +32,8 @@ extern "C" {
 
 /* 2: trc_trace_rays' last argument became a bit set (TRC_TRACE_*: 2 now means the production closest-hit walk, it used
  *    to mean any-hit); trc_build_flavor, trc_sppm_hash_cells, trc_host_scene_load_pbrt, trc_host_mesh_from_arrays added
- * 3: trc_group_set_collectives, trc_debug_set */
+ * 3: trc_group_set_collectives, trc_debug_set, trc_debug_block_costs; trc_pbrt_info / trc_pbrt_shape grew (textures,
+ *    plymesh / disk / cylinder); trc_host_mesh_load_ply, trc_host_load_hdr */
 #define TRC_ABI_VERSION 3
 
 /* ------------------------------------------------------------------ */
@@ -582,6 +583,11 @@ void trc_host_make_cloud(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t seed, f
 trc_status trc_host_load_density_pbrt(const char* path, uint32_t* nx, uint32_t* ny, uint32_t* nz, float** out);
 void trc_host_free(void* p);
 
+/* Radiance RGBE (.hdr) image -> float RGB, rows BOTTOM-UP (what trc_set_environment_map takes, and what the reference's
+ * vertically flipped HDR texture holds: vulture_hide_4k.hdr, AAPLRenderer.mm:352-383, sampled through Render.hh:42-48);
+ * flat and run-length-encoded scanlines; *rgb is malloc'ed (3 * w * h floats), free with trc_host_free */
+trc_status trc_host_load_hdr(const char* path, uint32_t* width, uint32_t* height, float** rgb);
+
 /* "Export as PNG file" (the reference's unchecked to-do, RT_Metal/README.md:61): 8-bit RGBA, rows top-down,
  * stored (uncompressed) deflate blocks -- no zlib dependency */
 trc_status trc_host_write_png(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height);
@@ -603,11 +609,16 @@ trc_status trc_host_mesh_load_obj(const char* path, trc_host_mesh** out);
  * transformation matrix, normals through its inverse transpose (smooth normals when absent), uv / st, Include
  * followed; shapes inside ObjectBegin/ObjectEnd and other shape types are skipped */
 trc_status trc_host_mesh_load_pbrt(const char* path, trc_host_mesh** out);
+/* the triangles of a PLY file (ascii / binary_little_endian / binary_big_endian; x y z, optional nx ny nz and u v | s t;
+ * triangles as they are, quads split (0 1 3) (2 3 1), larger polygons fanned) -- what `Shape "plymesh"` of a pbrt-v3 scene
+ * refers to and what minipbrt's PLYMesh::triangle_mesh() returns (minipbrt.cpp:4380-4450) */
+trc_status trc_host_mesh_load_ply(const char* path, trc_host_mesh** out);
 /* A whole scene from a pbrt-v3 file -- the reference's unchecked to-do "Support pbrt-v3 file format"
  * (RT_Metal/README.md:57, the vendored parser RT_Metal/Tracer/minipbrt.h:1528-1546, its one call site
  * AAPLRenderer.mm:626-651): Camera "perspective" + LookAt, Film resolution, AreaLightSource "diffuse", Material
- * matte / plastic / metal / mirror / glass (+ MakeNamedMaterial / NamedMaterial), Shape "sphere" and "trianglemesh"
- * through the transformation and attribute stacks, Include.  Mapping onto the reference's primitives
+ * matte / plastic / metal / mirror / glass (+ MakeNamedMaterial / NamedMaterial), Texture "checkerboard", Shape "sphere",
+ * "trianglemesh", "plymesh" (the PLY file is read: ascii / binary, triangles and quads), "disk" and "cylinder"
+ * (tessellated) through the transformation and attribute stacks, Include.  Mapping onto the reference's primitives
  * (tracer_amd/host/pbrt_scene.cpp): sphere -> trc_Sphere; a trianglemesh that is an axis-aligned rectangle ->
  * trc_Square, emitters placed at squareList[5] / [6] (the two lights traceMIS samples); any other mesh -> triangles with
  * material 19.
@@ -615,6 +626,12 @@ trc_status trc_host_mesh_load_pbrt(const char* path, trc_host_mesh** out);
  * the scene handle is used like one from trc_host_scene_create. */
 enum trc_pbrt_material { TRC_PBRT_MATTE = 0, TRC_PBRT_PLASTIC = 1, TRC_PBRT_METAL = 2, TRC_PBRT_MIRROR = 3,
                          TRC_PBRT_GLASS = 4, TRC_PBRT_OTHER = 5 };
+/* what the file's Shape directive was (sphere / trianglemesh keep the primitive-type ordinals they map to) */
+enum trc_pbrt_shape_kind { TRC_PBRT_SHAPE_SPHERE = 0, TRC_PBRT_SHAPE_TRIANGLEMESH = 3, TRC_PBRT_SHAPE_DISK = 6,
+                           TRC_PBRT_SHAPE_CYLINDER = 7, TRC_PBRT_SHAPE_PLYMESH = 8 };
+/* what the material's colour parameter names ("texture Kd" "name"): nothing, a 2-D checkerboard (rendered through the
+ * reference's TextureInfo{Checker}, Texture.hh:17-43, with albedo = tex1), any other texture class (not rendered) */
+enum trc_pbrt_texture { TRC_PBRT_TEX_NONE = 0, TRC_PBRT_TEX_CHECKERBOARD = 1, TRC_PBRT_TEX_OTHER = 2 };
 typedef struct trc_pbrt_info {
     float    camera_to_world[16];   /* row-major, inverse of the CTM at the Camera directive (minipbrt Camera::cameraToWorld) */
     float    fov, lensradius, focaldistance;
@@ -623,12 +640,13 @@ typedef struct trc_pbrt_info {
     uint32_t n_shapes;              /* world shapes in file order (object templates excluded) */
     uint32_t n_unsupported_shapes, n_unsupported_materials, n_triangle_material_conflicts;
     uint32_t mis_ready;             /* squareList[5] and [6] are emitters: TRC_INTEGRATOR_MIS / _VOLUME are usable */
+    uint32_t n_unsupported_textures;/* shapes whose colour names a texture other than a 2-D checkerboard */
 } trc_pbrt_info;
 typedef struct trc_pbrt_shape {
-    int32_t  kind;                  /* TRC_PRIM_SPHERE, TRC_PRIM_TRIANGLE (trianglemesh) or -1 (not handled) */
+    int32_t  kind;                  /* enum trc_pbrt_shape_kind, or -1 (a shape class that is not handled) */
     float    shape_to_world[16];    /* row-major CTM at the Shape directive */
-    float    radius;                /* spheres */
-    uint32_t n_vertices, n_indices; /* triangle meshes */
+    float    radius;                /* spheres, disks, cylinders */
+    uint32_t n_vertices, n_indices; /* triangle meshes, PLY meshes; disks / cylinders: of their tessellation */
     int32_t  material;              /* enum trc_pbrt_material of the graphics state */
     float    color[3];              /* Kd (matte, plastic, other), Kr (mirror), Kt (glass), 1 (metal) */
     int32_t  emitter;               /* inside an AreaLightSource "diffuse" */
@@ -636,6 +654,10 @@ typedef struct trc_pbrt_shape {
     int32_t  mapped_type;           /* TRC_PRIM_SPHERE / _SQUARE / _TRIANGLE it became, -1 if dropped */
     uint32_t mapped_index;          /* index in that primitive list (first triangle for a mesh) */
     uint32_t mapped_material;       /* index into the scene's material table */
+    float    zmin, zmax;            /* cylinder; disk: both = height */
+    float    innerradius, phimax;   /* disk; disk and cylinder (degrees) */
+    int32_t  texture;               /* enum trc_pbrt_texture of the material's colour parameter */
+    float    tex2[3];               /* checkerboard: the second colour (color[] holds tex1) */
 } trc_pbrt_shape;
 trc_status trc_host_scene_load_pbrt(const char* path, trc_host_scene** out_scene, trc_Camera* out_camera,
                                     trc_pbrt_info* info, trc_pbrt_shape* shapes, uint32_t capacity);

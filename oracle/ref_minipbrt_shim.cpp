@@ -37,6 +37,7 @@ extern "C" int ref_minipbrt_triangle_meshes(const char* path, unsigned* n_vertic
     if (!loader.load(path)) return -1;
     minipbrt::Scene* scene = loader.take_scene();
     if (!scene) return -2;
+    scene->load_all_ply_meshes();          // `Shape "plymesh"` -> TriangleMesh in place, through minipbrt's own PLY reader
     // shapes of object definitions (ObjectBegin .. ObjectEnd) are templates, not part of the world
     std::vector<bool> in_object(scene->shapes.size(), false);
     for (minipbrt::Object* o : scene->objects)
@@ -78,10 +79,15 @@ extern "C" void ref_minipbrt_free(void* p) { std::free(p); }
 // What the REFERENCE's parser makes of a whole scene file, flattened for tests/test_pbrt_scene.py (the yardstick of
 // trc_host_scene_load_pbrt): camera (cameraToWorld, fov, lensradius, focaldistance), film resolution, and per world
 // shape in file order: type, shapeToWorld (row-major), sphere radius, mesh sizes, material type + its colour
-// (Kd / Kr / Kt), area light L.  `shapes` holds 32 floats per shape:
-//   [0] type (0 sphere, 3 trianglemesh, -1 other)  [1..16] shapeToWorld  [17] radius  [18] n_vertices  [19] n_indices
+// (Kd / Kr / Kt), area light L.  `shapes` holds 40 floats per shape:
+//   [0] type (0 sphere, 3 trianglemesh, 6 disk, 7 cylinder, 8 plymesh, -1 other)  [1..16] shapeToWorld
+//   [17] radius (sphere, disk, cylinder)  [18] n_vertices  [19] n_indices (trianglemesh; plymesh: of the PLY file as
+//   minipbrt's PLYMesh::triangle_mesh() loads it)
 //   [20] material (0 matte 1 plastic 2 metal 3 mirror 4 glass 5 other, -1 none)  [21..23] colour
 //   [24] has area light  [25..27] L * scale
+//   [28] what the colour parameter names: 0 a constant, 1 a 2-D checkerboard texture, 2 another texture
+//   [29..31] / [32..34] the checkerboard's tex1 / tex2 values
+//   [35] zmin (cylinder) / height (disk)  [36] zmax / height  [37] innerradius (disk)  [38] phimax (disk, cylinder)
 extern "C" int ref_minipbrt_describe(const char* path, float camera[20], int film[2], float** shapes, unsigned* n_shapes) {
     minipbrt::Loader loader;
     if (!loader.load(path)) return -1;
@@ -106,28 +112,50 @@ extern "C" int ref_minipbrt_describe(const char* path, float camera[20], int fil
     for (size_t k = 0; k < scene->shapes.size(); ++k) {
         if (in_object[k]) continue;
         minipbrt::Shape* s = scene->shapes[k];
-        float rec[32] = {0};
+        float rec[40] = {0};
         rec[0] = -1.0f;
         std::memcpy(rec + 1, &s->shapeToWorld.start[0][0], 16 * sizeof(float));
         if (s->type() == minipbrt::ShapeType::Sphere) { rec[0] = 0.0f; rec[17] = static_cast<minipbrt::Sphere*>(s)->radius; }
         else if (s->type() == minipbrt::ShapeType::TriangleMesh) {
             auto* m = static_cast<minipbrt::TriangleMesh*>(s);
             rec[0] = 3.0f; rec[18] = (float)m->num_vertices; rec[19] = (float)m->num_indices;
+        } else if (s->type() == minipbrt::ShapeType::Disk) {
+            auto* d = static_cast<minipbrt::Disk*>(s);
+            rec[0] = 6.0f; rec[17] = d->radius; rec[35] = rec[36] = d->height; rec[37] = d->innerradius; rec[38] = d->phimax;
+        } else if (s->type() == minipbrt::ShapeType::Cylinder) {
+            auto* c = static_cast<minipbrt::Cylinder*>(s);
+            rec[0] = 7.0f; rec[17] = c->radius; rec[35] = c->zmin; rec[36] = c->zmax; rec[38] = c->phimax;
+        } else if (s->type() == minipbrt::ShapeType::PLYMesh) {
+            rec[0] = 8.0f;
+            if (minipbrt::TriangleMesh* m = s->triangle_mesh()) {        // reads the PLY file (minipbrt.cpp:4380-4450)
+                rec[18] = (float)m->num_vertices; rec[19] = (float)m->num_indices;
+                delete m;
+            }
         }
         rec[20] = -1.0f;
         if (s->material != minipbrt::kInvalidIndex && s->material < scene->materials.size()) {
             minipbrt::Material* m = scene->materials[s->material];
             const float* c = nullptr;
             const float one[3] = {1, 1, 1};
+            uint32_t tex = minipbrt::kInvalidIndex;
             switch (m->type()) {
-                case minipbrt::MaterialType::Matte: rec[20] = 0; c = static_cast<minipbrt::MatteMaterial*>(m)->Kd.value; break;
-                case minipbrt::MaterialType::Plastic: rec[20] = 1; c = static_cast<minipbrt::PlasticMaterial*>(m)->Kd.value; break;
+                case minipbrt::MaterialType::Matte: { auto& k = static_cast<minipbrt::MatteMaterial*>(m)->Kd; rec[20] = 0; c = k.value; tex = k.texture; break; }
+                case minipbrt::MaterialType::Plastic: { auto& k = static_cast<minipbrt::PlasticMaterial*>(m)->Kd; rec[20] = 1; c = k.value; tex = k.texture; break; }
                 case minipbrt::MaterialType::Metal: rec[20] = 2; c = one; break;
-                case minipbrt::MaterialType::Mirror: rec[20] = 3; c = static_cast<minipbrt::MirrorMaterial*>(m)->Kr.value; break;
-                case minipbrt::MaterialType::Glass: rec[20] = 4; c = static_cast<minipbrt::GlassMaterial*>(m)->Kt.value; break;
+                case minipbrt::MaterialType::Mirror: { auto& k = static_cast<minipbrt::MirrorMaterial*>(m)->Kr; rec[20] = 3; c = k.value; tex = k.texture; break; }
+                case minipbrt::MaterialType::Glass: { auto& k = static_cast<minipbrt::GlassMaterial*>(m)->Kt; rec[20] = 4; c = k.value; tex = k.texture; break; }
                 default: rec[20] = 5; c = nullptr; break;
             }
             if (c) { rec[21] = c[0]; rec[22] = c[1]; rec[23] = c[2]; }
+            if (tex != minipbrt::kInvalidIndex && tex < scene->textures.size()) {
+                minipbrt::Texture* t = scene->textures[tex];
+                rec[28] = 2.0f;
+                if (t->type() == minipbrt::TextureType::Checkerboard2D) {
+                    auto* cb = static_cast<minipbrt::Checkerboard2DTexture*>(t);
+                    rec[28] = 1.0f;
+                    for (int j = 0; j < 3; ++j) { rec[29 + j] = cb->tex1.value[j]; rec[32 + j] = cb->tex2.value[j]; }
+                }
+            }
         }
         if (s->areaLight != minipbrt::kInvalidIndex && s->areaLight < scene->areaLights.size()) {
             minipbrt::AreaLight* al = scene->areaLights[s->areaLight];
@@ -137,12 +165,39 @@ extern "C" int ref_minipbrt_describe(const char* path, float camera[20], int fil
                 for (int j = 0; j < 3; ++j) rec[25 + j] = dl->L[j] * dl->scale[j];
             }
         }
-        out.insert(out.end(), rec, rec + 32);
+        out.insert(out.end(), rec, rec + 40);
         ++n;
     }
     *n_shapes = n;
     *shapes = (float*)std::calloc(out.size() + 1, sizeof(float));
     if (!out.empty()) std::memcpy(*shapes, out.data(), out.size() * sizeof(float));
+    delete scene;
+    return 0;
+}
+
+// The Texture directives of a scene file in file order, 8 floats each: [0] class (1 = 2-D checkerboard, 2 = anything else)
+// [1..3] tex1  [4..6] tex2  [7] 1 = spectrum data.  (The vendored minipbrt parses them but never resolves a material's
+// "texture Kd" reference to them -- find_texture walks per-attribute lists that nothing appends to, minipbrt.cpp:8145-8172,
+// 2912-2913 -- so ref_minipbrt_describe reports [28] = 0 for every shape; tests compare the declarations instead.)
+extern "C" int ref_minipbrt_textures(const char* path, float** out, unsigned* n_textures) {
+    minipbrt::Loader loader;
+    if (!loader.load(path)) return -1;
+    minipbrt::Scene* scene = loader.take_scene();
+    if (!scene) return -2;
+    const size_t n = scene->textures.size();
+    *n_textures = (unsigned)n;
+    *out = (float*)std::calloc(n * 8 + 1, sizeof(float));
+    for (size_t k = 0; k < n; ++k) {
+        minipbrt::Texture* t = scene->textures[k];
+        float* r = *out + k * 8;
+        r[0] = 2.0f;
+        r[7] = t->dataType == minipbrt::TextureData::Spectrum ? 1.0f : 0.0f;
+        if (t->type() == minipbrt::TextureType::Checkerboard2D) {
+            auto* cb = static_cast<minipbrt::Checkerboard2DTexture*>(t);
+            r[0] = 1.0f;
+            for (int j = 0; j < 3; ++j) { r[1 + j] = cb->tex1.value[j]; r[4 + j] = cb->tex2.value[j]; }
+        }
+    }
     delete scene;
     return 0;
 }

@@ -60,7 +60,28 @@ AttributeBegin
 AttributeEnd
 AttributeBegin
   Material "uber"
-  Shape "cylinder" "float radius" 10
+  Shape "cone" "float radius" 10
+AttributeEnd
+Texture "tiles" "spectrum" "checkerboard" "rgb tex1" [ 0.8 0.7 0.2 ] "rgb tex2" [ 0.1 0.1 0.1 ] "float uscale" 4 "float vscale" 4
+Texture "veins" "spectrum" "marble"
+AttributeBegin
+  Material "matte" "texture Kd" "tiles"
+  Translate 420 0 150
+  Rotate -90 1 0 0
+  Shape "cylinder" "float radius" 40 "float zmin" 0 "float zmax" 120 "float phimax" 270
+  Translate 0 0 120
+  Shape "disk" "float radius" 40 "float innerradius" 10 "float height" 0
+AttributeEnd
+AttributeBegin
+  Material "plastic" "texture Kd" "veins"
+  Translate 100 300 400
+  Shape "sphere" "float radius" 30
+AttributeEnd
+AttributeBegin
+  Material "matte" "rgb Kd" [ 0.4 0.6 0.3 ]
+  Translate 300 200 450
+  Scale 40 40 40
+  Shape "plymesh" "string filename" "wedge.ply"
 AttributeEnd
 ObjectBegin "template"
   Shape "sphere" "float radius" 5
@@ -77,16 +98,57 @@ def ref_describe(path):
     cam, film, p, n = (C.c_float * 20)(), (C.c_int * 2)(), C.POINTER(C.c_float)(), C.c_uint()
     assert L.ref_minipbrt_describe(os.fsencode(path), cam, film, C.byref(p), C.byref(n)) == 0
     try:
-        shapes = np.ctypeslib.as_array(p, shape=(n.value, 32)).copy() if n.value else np.zeros((0, 32), np.float32)
+        shapes = np.ctypeslib.as_array(p, shape=(n.value, 40)).copy() if n.value else np.zeros((0, 40), np.float32)
     finally:
         L.ref_minipbrt_free(p)
     return np.array(cam[:], np.float32), (film[0], film[1]), shapes
+
+
+# a PLY file the scene names: two triangles and a quad, normals and uv, ascii
+WEDGE_PLY = """ply
+format ascii 1.0
+comment a wedge
+element vertex 6
+property float x
+property float y
+property float z
+property float nx
+property float ny
+property float nz
+property float u
+property float v
+element face 3
+property list uchar int vertex_indices
+end_header
+0 0 0  0 -1 0  0 0
+1 0 0  0 -1 0  1 0
+1 0 1  0 -1 0  1 1
+0 0 1  0 -1 0  0 1
+0.5 1 0  0 0 -1  0.5 0
+0.5 1 1  0 0 1  0.5 1
+4 0 1 2 3
+3 0 1 4
+3 3 2 5
+"""
+
+
+def ref_textures(path):
+    L = C.CDLL(REF_LIB)
+    L.ref_minipbrt_textures.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint)]
+    L.ref_minipbrt_free.argtypes = [C.c_void_p]
+    p, n = C.POINTER(C.c_float)(), C.c_uint()
+    assert L.ref_minipbrt_textures(os.fsencode(path), C.byref(p), C.byref(n)) == 0
+    try:
+        return np.ctypeslib.as_array(p, shape=(n.value, 8)).copy() if n.value else np.zeros((0, 8), np.float32)
+    finally:
+        L.ref_minipbrt_free(p)
 
 
 @pytest.fixture()
 def cornell_pbrt(tmp_path):
     p = tmp_path / "cornell.pbrt"
     p.write_text(CORNELL)
+    (tmp_path / "wedge.ply").write_text(WEDGE_PLY)
     return str(p)
 
 
@@ -98,15 +160,37 @@ def test_description_equals_minipbrt_field_for_field(cornell_pbrt):
     assert info.perspective == 1 == int(rcam[19])
     assert np.float32(info.fov) == rcam[16] and np.float32(info.lensradius) == rcam[17] and np.float32(info.focaldistance) == rcam[18]
     np.testing.assert_allclose(np.array(info.camera_to_world[:], np.float32), rcam[:16], rtol=0, atol=2e-4)
-    assert info.n_shapes == len(rshapes) == len(shapes) == 10          # 6 quads + 2 spheres + 1 mesh + 1 cylinder; no template
-    n_named = 0
+    # 6 quads + 2 spheres + 1 mesh + 1 cone + cylinder + disk + 1 sphere + 1 plymesh; no template
+    assert info.n_shapes == len(rshapes) == len(shapes) == 14
+    kinds = [s.kind for s in shapes]
+    assert kinds.count(abi.PBRT_SHAPE_CYLINDER) == 1 and kinds.count(abi.PBRT_SHAPE_DISK) == 1 and kinds.count(abi.PBRT_SHAPE_PLYMESH) == 1
+    rtex = ref_textures(cornell_pbrt)                                  # "tiles" (checkerboard), "veins" (marble), as minipbrt parsed them
+    assert len(rtex) == 2 and rtex[0][0] == 1 and rtex[0][7] == 1
+    n_named = n_tex = 0
     for k, (mine, ref) in enumerate(zip(shapes, rshapes)):
         assert mine.kind == int(ref[0])
         np.testing.assert_allclose(np.array(mine.shape_to_world[:], np.float32), ref[1:17], rtol=1e-6, atol=1e-4)
-        if mine.kind == abi.PRIM_SPHERE:
+        if mine.kind in (abi.PBRT_SHAPE_SPHERE, abi.PBRT_SHAPE_DISK, abi.PBRT_SHAPE_CYLINDER):
             assert np.float32(mine.radius) == ref[17]
-        if mine.kind == abi.PRIM_TRIANGLE:
-            assert (mine.n_vertices, mine.n_indices) == (int(ref[18]), int(ref[19]))
+        if mine.kind in (abi.PBRT_SHAPE_TRIANGLEMESH, abi.PBRT_SHAPE_PLYMESH):     # plymesh: what minipbrt's own PLY reader loads
+            assert (mine.n_vertices, mine.n_indices) == (int(ref[18]), int(ref[19])) and mine.n_indices > 0
+        if mine.kind in (abi.PBRT_SHAPE_DISK, abi.PBRT_SHAPE_CYLINDER):
+            assert (np.float32(mine.zmin), np.float32(mine.zmax), np.float32(mine.phimax)) == (ref[35], ref[36], ref[38])
+            assert mine.kind == abi.PBRT_SHAPE_CYLINDER or np.float32(mine.innerradius) == ref[37]
+        # what the colour parameter names: nothing, the checkerboard (tex1 / tex2), another texture class.  The vendored
+        # minipbrt parses Texture directives but never resolves a material's reference to one (find_texture walks
+        # per-attribute lists nothing appends to, minipbrt.cpp:8145-8172) -- like its named materials -- so it reports a
+        # constant for every shape; the declarations themselves are compared below
+        assert int(ref[28]) == 0
+        if mine.texture == abi.PBRT_TEX_CHECKERBOARD:
+            assert mine.kind in (abi.PBRT_SHAPE_CYLINDER, abi.PBRT_SHAPE_DISK)
+            assert np.array_equal(np.array(mine.color[:], np.float32), rtex[0][1:4]) and np.array_equal(np.array(mine.tex2[:], np.float32), rtex[0][4:7])
+            n_tex += 1
+            continue
+        if mine.texture == abi.PBRT_TEX_OTHER:
+            assert rtex[1][0] == 2 and mine.material == int(ref[20]) == abi.PBRT_PLASTIC
+            n_tex += 1
+            continue
         if k in (3, 4):
             # NamedMaterial: the vendored minipbrt never registers named materials (find_material walks a per-attribute
             # list that nothing appends to, minipbrt.cpp:8126-8139, 6121-6144), so the directive is a no-op there and
@@ -118,20 +202,42 @@ def test_description_equals_minipbrt_field_for_field(cornell_pbrt):
             n_named += 1
             continue
         assert mine.material == int(ref[20])
-        if mine.material != abi.PBRT_OTHER:
+        if mine.material != abi.PBRT_OTHER and mine.texture == abi.PBRT_TEX_NONE:
             assert np.array_equal(np.array(mine.color[:], np.float32), ref[21:24])
         assert mine.emitter == int(ref[24])
         if mine.emitter:
             assert np.array_equal(np.array(mine.L[:], np.float32), ref[25:28])
-    assert n_named == 2
+    assert n_named == 2 and n_tex == 3
 
 
 def test_mapping_onto_the_reference_primitives(cornell_pbrt):
     scene, cam, info, shapes = host.HostScene.from_pbrt(cornell_pbrt)
     v = scene.view
-    assert info.n_unsupported_shapes == 1 and info.n_unsupported_materials == 1 and info.mis_ready == 1
+    assert info.n_unsupported_shapes == 1 and info.n_unsupported_materials == 1 and info.mis_ready == 1   # the cone, "uber"
+    assert info.n_unsupported_textures == 1                                                                # "marble" on the third sphere
     # 5 walls, then the light at squareList[5] and, being the only one, again at [6] (not in the BVH twice)
-    assert v.n_square == 7 and v.n_sphere == 2 and v.n_index == 12 and v.n_vertex == 4
+    cyl, disk, ply = (next(s for s in shapes if s.kind == k) for k in (abi.PBRT_SHAPE_CYLINDER, abi.PBRT_SHAPE_DISK, abi.PBRT_SHAPE_PLYMESH))
+    assert cyl.n_indices == 6 * 48 and disk.n_indices == 6 * 64 and ply.n_indices == 12      # 270 deg = 48 of 64 steps; quad -> 2 triangles
+    assert v.n_square == 7 and v.n_sphere == 3 and v.n_index == 12 + cyl.n_indices + disk.n_indices + 12
+    assert v.n_vertex == 4 + cyl.n_vertices + disk.n_vertices + 6
+    # the tessellations lie on the quadrics: cylinder of radius 40 around the world y axis through (420, *, 150), y in [0, 120];
+    # the disk closes it at y = 120 with a hole of radius 10; normals point away from the axis / along +y
+    verts = np.ctypeslib.as_array(C.cast(v.triList, C.POINTER(C.c_float)), shape=(v.n_vertex, 8))
+    cv = verts[4:4 + cyl.n_vertices]
+    r = np.hypot(cv[:, 0] - 420, cv[:, 2] - 150)
+    assert np.allclose(r, 40, atol=1e-3) and cv[:, 1].min() > -1e-3 and cv[:, 1].max() < 120 + 1e-3
+    assert np.allclose(np.hypot(cv[:, 3], cv[:, 5]), 1, atol=1e-4) and np.allclose(cv[:, 4], 0, atol=1e-5)
+    assert np.allclose((cv[:, 0] - 420) * cv[:, 3] + (cv[:, 2] - 150) * cv[:, 5], 40, atol=1e-2)      # outward
+    dv = verts[4 + cyl.n_vertices:4 + cyl.n_vertices + disk.n_vertices]
+    rd = np.hypot(dv[:, 0] - 420, dv[:, 2] - 150)
+    assert np.allclose(dv[:, 1], 120, atol=1e-3) and np.allclose(np.sort(np.unique(np.round(rd, 2))), [10, 40])
+    assert np.allclose(dv[:, 3:6], [0, 1, 0], atol=1e-5)
+    # total area of the disk's triangles -> pi (R^2 - r^2) from below, within the chord error of 64 steps
+    tri = np.ctypeslib.as_array(C.cast(v.idxList, C.POINTER(C.c_uint32)), shape=(v.n_index,)).reshape(-1, 3)
+    dt = tri[(12 + cyl.n_indices) // 3:(12 + cyl.n_indices + disk.n_indices) // 3]
+    area = 0.5 * np.linalg.norm(np.cross(verts[dt[:, 1], :3] - verts[dt[:, 0], :3], verts[dt[:, 2], :3] - verts[dt[:, 0], :3]), axis=1).sum()
+    assert 0.995 < area / (np.pi * (40 ** 2 - 10 ** 2)) < 1.0
+    # the checkerboard became the reference's Checker texture on the cylinder / disk material (19: all triangles share it)
     mats = [v.materials[i] for i in range(v.n_material)]
     for k in (5, 6):
         m = mats[v.squareList[k].material]
@@ -148,7 +254,18 @@ def test_mapping_onto_the_reference_primitives(cornell_pbrt):
     # the tetrahedron: triangles use material 19 whatever the file says (Triangle.hh:82); 19 carries the file's material
     assert mats[19].type == abi.MAT_PLASTIC and abs(mats[19].textureInfo.albedo.z - 0.8) < 1e-6
     n_leaves = (v.n_bvh + 1) // 2
-    assert n_leaves == 6 + 2 + 4                                      # 6 squares in the tree (the duplicate light is not), 2 spheres, 4 triangles
+    # 6 squares in the tree (the duplicate light is not), 3 spheres, the triangles of the tetrahedron, cylinder, disk, PLY wedge
+    assert n_leaves == 6 + 3 + 4 + (cyl.n_indices + disk.n_indices + 12) // 3
+    # a checkerboard on a sphere keeps its own material record
+    p2 = str(os.path.dirname(cornell_pbrt)) + "/tex.pbrt"
+    open(p2, "w").write('WorldBegin\nTexture "c" "spectrum" "checkerboard" "rgb tex1" [ 0.9 0.2 0.1 ]\n'
+                        'Material "matte" "texture Kd" "c"\nShape "sphere" "float radius" 2\n'
+                        'Material "matte" "rgb Kd" [ 0.9 0.2 0.1 ]\nTranslate 5 0 0\nShape "sphere" "float radius" 2\nWorldEnd\n')
+    sc2, _, _, sh2 = host.HostScene.from_pbrt(p2)
+    m2 = [sc2.view.materials[i] for i in range(sc2.view.n_material)]
+    a, b = m2[sc2.view.sphereList[0].material], m2[sc2.view.sphereList[1].material]
+    assert a.textureInfo.type == abi.TEX_CHECKER and b.textureInfo.type == abi.TEX_CONSTANT and sh2[0].mapped_material != sh2[1].mapped_material
+    assert abs(a.textureInfo.albedo.x - 0.9) < 1e-6 and sh2[0].texture == abi.PBRT_TEX_CHECKERBOARD and list(sh2[0].tex2) == [0, 0, 0]
     # camera: MakeCamera from the LookAt triple; fov over the shorter (vertical) axis; aperture = 2 * lensradius
     assert (cam.lookFrom.x, cam.lookFrom.y, cam.lookFrom.z) == (278, 273, -800) and cam.lenRadius == 0.5
     assert abs(cam.vfov - np.deg2rad(39)) < 1e-6 and abs(cam.aspect - 160 / 120) < 1e-6 and cam.focus_dist == 1000

@@ -144,20 +144,24 @@ class GridDensityInfo(C.Structure):
 
 # enum trc_pbrt_material
 PBRT_MATTE, PBRT_PLASTIC, PBRT_METAL, PBRT_MIRROR, PBRT_GLASS, PBRT_OTHER = range(6)
+# enum trc_pbrt_shape_kind / trc_pbrt_texture
+PBRT_SHAPE_SPHERE, PBRT_SHAPE_TRIANGLEMESH, PBRT_SHAPE_DISK, PBRT_SHAPE_CYLINDER, PBRT_SHAPE_PLYMESH = 0, 3, 6, 7, 8
+PBRT_TEX_NONE, PBRT_TEX_CHECKERBOARD, PBRT_TEX_OTHER = 0, 1, 2
 
 
 class PbrtInfo(C.Structure):
     _fields_ = [("camera_to_world", C.c_float * 16), ("fov", C.c_float), ("lensradius", C.c_float),
                 ("focaldistance", C.c_float), ("perspective", C.c_uint32), ("xres", C.c_uint32), ("yres", C.c_uint32),
                 ("n_shapes", C.c_uint32), ("n_unsupported_shapes", C.c_uint32), ("n_unsupported_materials", C.c_uint32),
-                ("n_triangle_material_conflicts", C.c_uint32), ("mis_ready", C.c_uint32)]
+                ("n_triangle_material_conflicts", C.c_uint32), ("mis_ready", C.c_uint32), ("n_unsupported_textures", C.c_uint32)]
 
 
 class PbrtShape(C.Structure):
     _fields_ = [("kind", C.c_int32), ("shape_to_world", C.c_float * 16), ("radius", C.c_float),
                 ("n_vertices", C.c_uint32), ("n_indices", C.c_uint32), ("material", C.c_int32), ("color", C.c_float * 3),
                 ("emitter", C.c_int32), ("L", C.c_float * 3), ("mapped_type", C.c_int32), ("mapped_index", C.c_uint32),
-                ("mapped_material", C.c_uint32)]
+                ("mapped_material", C.c_uint32), ("zmin", C.c_float), ("zmax", C.c_float), ("innerradius", C.c_float),
+                ("phimax", C.c_float), ("texture", C.c_int32), ("tex2", C.c_float * 3)]
 
 
 class Params(C.Structure):
@@ -208,7 +212,7 @@ DEVICE_SYMBOLS = [
 HOST_SYMBOLS = [
     "trc_host_build_node", "trc_host_build_tree", "trc_host_tree_depth", "trc_host_make_camera",
     "trc_host_prepare_camera", "trc_host_fill_rng", "trc_host_scene_create", "trc_host_scene_destroy",
-    "trc_host_scene_view", "trc_host_scene_load_pbrt", "trc_host_mesh_load_obj", "trc_host_mesh_load_pbrt", "trc_host_mesh_make_ball", "trc_host_mesh_replicate", "trc_host_mesh_from_arrays",
+    "trc_host_scene_view", "trc_host_scene_load_pbrt", "trc_host_mesh_load_obj", "trc_host_mesh_load_pbrt", "trc_host_mesh_load_ply", "trc_host_load_hdr", "trc_host_mesh_make_ball", "trc_host_mesh_replicate", "trc_host_mesh_from_arrays",
     "trc_host_mesh_view", "trc_host_mesh_destroy", "trc_host_make_density_info", "trc_host_make_cloud",
     "trc_host_load_density_pbrt", "trc_host_free", "trc_host_write_png", "trc_host_sobol_matrices32",
     "trc_host_sobol_interval_tables",

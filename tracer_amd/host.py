@@ -51,6 +51,10 @@ def lib():
         L.trc_host_scene_view.restype = None
         L.trc_host_mesh_load_obj.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
         L.trc_host_mesh_load_obj.restype = C.c_int32
+        L.trc_host_mesh_load_ply.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.trc_host_mesh_load_ply.restype = C.c_int32
+        L.trc_host_load_hdr.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_float))]
+        L.trc_host_load_hdr.restype = C.c_int32
         L.trc_host_mesh_make_ball.argtypes = [C.c_uint32, C.c_uint32, C.c_float, C.POINTER(C.c_void_p)]
         L.trc_host_mesh_make_ball.restype = C.c_int32
         L.trc_host_mesh_from_arrays.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
@@ -102,6 +106,13 @@ class Mesh:
         """every `Shape "trianglemesh"` of a pbrt-v3 file, transformed to world space (trc_host_mesh_load_pbrt)"""
         h = C.c_void_p()
         _check(lib().trc_host_mesh_load_pbrt(os.fsencode(path), C.byref(h)), f"trc_host_mesh_load_pbrt({path})")
+        return cls(h)
+
+    @classmethod
+    def load_ply(cls, path):
+        """the triangles of a PLY file (trc_host_mesh_load_ply): what a pbrt-v3 `Shape "plymesh"` refers to"""
+        h = C.c_void_p()
+        _check(lib().trc_host_mesh_load_ply(os.fsencode(path), C.byref(h)), f"trc_host_mesh_load_ply({path})")
         return cls(h)
 
     @classmethod
@@ -243,6 +254,17 @@ def load_density_pbrt(path):
     try:
         n = nx.value * ny.value * nz.value
         return np.ctypeslib.as_array(p, shape=(n,)).astype(np.float32).reshape(nz.value, ny.value, nx.value).copy()
+    finally:
+        lib().trc_host_free(p)
+
+
+def load_hdr(path):
+    """Radiance RGBE file -> (h, w, 3) float32, rows bottom-up: what Tracer.set_environment_map takes (trc_host_load_hdr)."""
+    w, h = C.c_uint32(), C.c_uint32()
+    p = C.POINTER(C.c_float)()
+    _check(lib().trc_host_load_hdr(os.fsencode(path), C.byref(w), C.byref(h), C.byref(p)), f"trc_host_load_hdr({path})")
+    try:
+        return np.ctypeslib.as_array(p, shape=(h.value, w.value, 3)).astype(np.float32).copy()
     finally:
         lib().trc_host_free(p)
 

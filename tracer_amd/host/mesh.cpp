@@ -17,6 +17,7 @@
 
 #include "host_math.hpp"
 #include "pbrt_text.hpp"
+#include "ply_reader.hpp"
 
 using namespace trc;
 
@@ -269,6 +270,30 @@ trc_status trc_host_mesh_make_ball(uint32_t n_lat, uint32_t n_lon, float bump, t
             m->indices.insert(m->indices.end(), {b, d, c});
         }
     generate_normals(*m);
+    *out = m;
+    return TRC_OK;
+}
+
+// the triangles of a PLY file (ply_reader.hpp) as a mesh handle: what minipbrt's PLYMesh::triangle_mesh() hands a renderer
+// (minipbrt.cpp:4380-4450); smooth normals when the file carries none
+trc_status trc_host_mesh_load_ply(const char* path, trc_host_mesh** out) {
+    if (!path || !out) return TRC_ERR_INVALID_ARG;
+    *out = nullptr;
+    PlyMesh pm;
+    if (!read_ply(path, pm)) return TRC_ERR_INVALID_ARG;
+    trc_host_mesh* m = new (std::nothrow) trc_host_mesh();
+    if (!m) return TRC_ERR_OOM;
+    const size_t nv = pm.P.size() / 3;
+    m->vertices.resize(nv);
+    for (size_t v = 0; v < nv; ++v) {
+        trc_TriangleVertex& t = m->vertices[v];
+        std::memset(&t, 0, sizeof t);
+        for (int k = 0; k < 3; ++k) t.v[k] = pm.P[3 * v + k];
+        if (!pm.N.empty()) for (int k = 0; k < 3; ++k) t.n[k] = pm.N[3 * v + k];
+        if (!pm.UV.empty()) { t.uv[0] = pm.UV[2 * v]; t.uv[1] = pm.UV[2 * v + 1]; }
+    }
+    m->indices = pm.indices;
+    if (pm.N.empty()) generate_normals(*m);
     *out = m;
     return TRC_OK;
 }

@@ -19,6 +19,12 @@
 //                                    -> trc_Material Lambert / Plastic / Metal / Glass with albedo Kd / Kd / 1 / Kt
 //                                       (the lobes' other parameters are hard-coded in the reference, Material.hh note)
 //   AreaLightSource "diffuse" L      -> trc_Material Diffuse (the reference's emitter type) with albedo L
+//   Texture "name" .. "checkerboard" -> a material whose Kd names it gets TextureInfo{Checker, albedo = tex1}: the
+//                                       reference's only procedural pattern (Texture.hh:17-43: albedo x {1, 0.5} in a fixed
+//                                       8 x 4 grid of the surface's uv), so tex2 and u / vscale are reported, not rendered
+//   Shape "plymesh"                  -> the triangles of the PLY file (ply_reader.hpp), like a trianglemesh
+//   Shape "disk" / "cylinder"        -> tessellated (kQuadricSegments steps of phi) into triangles with the quadric's own
+//                                       normals and (phi / phimax, radial | axial) as uv, like a trianglemesh
 //
 // Squares are ordered so that emitters sit at indices 5 and 6 when the file has any (padding with unreferenced
 // degenerate squares, duplicating a lone emitter); `mis_ready` says whether traceMIS / traceVolume may be used.
@@ -30,6 +36,7 @@
 
 #include "host_scene.hpp"
 #include "pbrt_text.hpp"
+#include "ply_reader.hpp"
 
 using namespace trc;
 
@@ -38,9 +45,13 @@ namespace {
 struct GfxState {                       // what AttributeBegin / End save (pbrt-v3 GraphicsState, the part used here)
     int32_t material = TRC_PBRT_MATTE;  // pbrt's default material is matte, Kd 0.5
     float color[3] = {0.5f, 0.5f, 0.5f};
+    int32_t texture = TRC_PBRT_TEX_NONE;   // what the material's colour parameter names: nothing, a checkerboard, another texture
+    float tex2[3] = {0, 0, 0};
     bool emitter = false;
     float L[3] = {1, 1, 1};
 };
+struct NamedTexture { int32_t kind; float tex1[3], tex2[3]; };
+constexpr uint32_t kQuadricSegments = 64;     // steps of phi over a full turn
 
 const PbrtParam* find(const std::vector<PbrtParam>& ps, const char* name) {
     for (const PbrtParam& p : ps) if (p.name == name) return &p;
@@ -48,7 +59,7 @@ const PbrtParam* find(const std::vector<PbrtParam>& ps, const char* name) {
 }
 void rgb_of(const std::vector<PbrtParam>& ps, const char* name, float out[3]) {
     const PbrtParam* p = find(ps, name);
-    if (!p || p->numbers.empty()) return;
+    if (!p || p->numbers.empty() || p->type == "texture") return;
     if (p->numbers.size() >= 3) for (int k = 0; k < 3; ++k) out[k] = (float)p->numbers[k];
     else out[0] = out[1] = out[2] = (float)p->numbers[0];
 }
@@ -56,7 +67,23 @@ float float_of(const std::vector<PbrtParam>& ps, const char* name, float dflt) {
     const PbrtParam* p = find(ps, name);
     return (p && !p->numbers.empty()) ? (float)p->numbers[0] : dflt;
 }
-void set_material(GfxState& g, const std::string& type, const std::vector<PbrtParam>& ps) {
+void set_material_constant(GfxState& g, const std::string& type, const std::vector<PbrtParam>& ps);
+void set_material(GfxState& g, const std::string& type, const std::vector<PbrtParam>& ps, const std::map<std::string, std::string>& strs,
+                  const std::map<std::string, NamedTexture>& textures) {
+    g.texture = TRC_PBRT_TEX_NONE; g.tex2[0] = g.tex2[1] = g.tex2[2] = 0.0f;
+    set_material_constant(g, type, ps);
+    // "texture Kd" "name" (Kr for mirror, Kt for glass): the colour comes from a named texture
+    const char* slot = g.material == TRC_PBRT_MIRROR ? "Kr" : g.material == TRC_PBRT_GLASS ? "Kt" : "Kd";
+    const PbrtParam* p = find(ps, slot);
+    auto ref = strs.find(slot);
+    if (p && p->type == "texture" && ref != strs.end()) {
+        auto it = textures.find(ref->second);
+        if (it == textures.end()) return;                          // pbrt reports an undefined texture and keeps the default
+        g.texture = it->second.kind;
+        if (it->second.kind == TRC_PBRT_TEX_CHECKERBOARD) { std::memcpy(g.color, it->second.tex1, sizeof g.color); std::memcpy(g.tex2, it->second.tex2, sizeof g.tex2); }
+    }
+}
+void set_material_constant(GfxState& g, const std::string& type, const std::vector<PbrtParam>& ps) {
     g.color[0] = g.color[1] = g.color[2] = 1.0f;
     if (type == "matte") { g.material = TRC_PBRT_MATTE; g.color[0] = g.color[1] = g.color[2] = 0.5f; rgb_of(ps, "Kd", g.color); }
     else if (type == "plastic") { g.material = TRC_PBRT_PLASTIC; g.color[0] = g.color[1] = g.color[2] = 0.25f; rgb_of(ps, "Kd", g.color); }
@@ -76,6 +103,12 @@ int32_t material_type_of(int32_t pbrt_material) {
 }
 
 // parameter list that also keeps string values ("string type" "matte"): name -> value
+std::string dir_of(const char* path) {
+    const std::string p(path);
+    const size_t slash = p.find_last_of('/');
+    return slash == std::string::npos ? std::string() : p.substr(0, slash + 1);
+}
+
 bool read_params_with_strings(PbrtLexer& lx, std::vector<PbrtParam>& nums, std::map<std::string, std::string>& strs) {
     nums.clear(); strs.clear();
     while (lx.peek().kind == PbrtToken::String) {
@@ -172,15 +205,17 @@ extern "C" trc_status trc_host_scene_load_pbrt(const char* path, trc_host_scene*
     struct PendingSquare { Quad q; uint32_t material; bool emitter; size_t desc; };
     std::vector<PendingSquare> squares;
     std::map<std::string, uint32_t> material_index;                 // one trc_Material per distinct (type, colour)
-    auto intern_material = [&](int32_t type, const float c[3]) -> uint32_t {
-        char key[96];
-        std::snprintf(key, sizeof key, "%d/%a/%a/%a", type, c[0], c[1], c[2]);
+    std::map<std::string, NamedTexture> named_textures;
+    auto intern_material = [&](int32_t type, const float c[3], bool checker = false) -> uint32_t {
+        char key[112];
+        std::snprintf(key, sizeof key, "%d/%a/%a/%a/%d", type, c[0], c[1], c[2], checker ? 1 : 0);
         auto it = material_index.find(key);
         if (it != material_index.end()) return it->second;
         uint32_t idx = (uint32_t)s->materials.size();
         if (idx == 19) { s->materials.push_back(make_material(TRC_MAT_LAMBERT)); idx = 20; }   // 19 is the triangles' slot
         trc_Material m = make_material(type);
         m.textureInfo.albedo = f3(c[0], c[1], c[2]);
+        if (checker) m.textureInfo.type = TRC_TEX_CHECKER;           // TextureInfo::value, Texture.hh:24-28
         if (type == TRC_MAT_METAL || type == TRC_MAT_GLASS) m.specular = 1;
         if (type == TRC_MAT_GLASS) m.eta = 1.5f;
         s->materials.push_back(m);
@@ -258,19 +293,34 @@ extern "C" trc_status trc_host_scene_load_pbrt(const char* path, trc_host_scene*
             PbrtToken kind = lx.next();
             if (kind.kind != PbrtToken::String || !read_params_with_strings(lx, params, strs)) return fail();
             const bool em = g.emitter; float L[3] = {g.L[0], g.L[1], g.L[2]};
-            set_material(g, kind.text, params);
+            set_material(g, kind.text, params, strs, named_textures);
             g.emitter = em; std::memcpy(g.L, L, sizeof L);
         } else if (d == "MakeNamedMaterial") {
             PbrtToken name = lx.next();
             if (name.kind != PbrtToken::String || !read_params_with_strings(lx, params, strs)) return fail();
             GfxState m;
-            set_material(m, strs.count("type") ? strs["type"] : std::string("matte"), params);
+            set_material(m, strs.count("type") ? strs["type"] : std::string("matte"), params, strs, named_textures);
             named_materials[name.text] = m;
         } else if (d == "NamedMaterial") {
             PbrtToken name = lx.next();
             if (name.kind != PbrtToken::String) return fail();
             auto it = named_materials.find(name.text);
-            if (it != named_materials.end()) { g.material = it->second.material; std::memcpy(g.color, it->second.color, sizeof g.color); }
+            if (it != named_materials.end()) {
+                g.material = it->second.material; std::memcpy(g.color, it->second.color, sizeof g.color);
+                g.texture = it->second.texture; std::memcpy(g.tex2, it->second.tex2, sizeof g.tex2);
+            }
+        } else if (d == "Texture") {                                   // Texture "name" "spectrum|float" "class" params
+            PbrtToken name = lx.next(), data = lx.next(), cls = lx.next();
+            if (name.kind != PbrtToken::String || data.kind != PbrtToken::String || cls.kind != PbrtToken::String ||
+                !read_params_with_strings(lx, params, strs)) return fail();
+            NamedTexture nt;
+            nt.kind = TRC_PBRT_TEX_OTHER;
+            nt.tex1[0] = nt.tex1[1] = nt.tex1[2] = 1.0f; nt.tex2[0] = nt.tex2[1] = nt.tex2[2] = 0.0f;    // pbrt's defaults
+            if (cls.text == "checkerboard" && float_of(params, "dimension", 2.0f) == 2.0f) {
+                nt.kind = TRC_PBRT_TEX_CHECKERBOARD;
+                rgb_of(params, "tex1", nt.tex1); rgb_of(params, "tex2", nt.tex2);
+            }
+            named_textures[name.text] = nt;
         } else if (d == "AreaLightSource") {
             PbrtToken kind = lx.next();
             if (kind.kind != PbrtToken::String || !read_params_with_strings(lx, params, strs)) return fail();
@@ -287,6 +337,9 @@ extern "C" trc_status trc_host_scene_load_pbrt(const char* path, trc_host_scene*
             std::memcpy(ds.shape_to_world, ctm.m, sizeof ctm.m);
             ds.material = g.material; std::memcpy(ds.color, g.color, sizeof ds.color);
             ds.emitter = g.emitter ? 1 : 0; std::memcpy(ds.L, g.L, sizeof ds.L);
+            ds.texture = g.texture; std::memcpy(ds.tex2, g.tex2, sizeof ds.tex2);
+            const bool checker = !g.emitter && g.texture == TRC_PBRT_TEX_CHECKERBOARD;
+            if (g.texture == TRC_PBRT_TEX_OTHER && !g.emitter) inf.n_unsupported_textures++;
             const int32_t mtype = g.emitter ? (int32_t)TRC_MAT_DIFFUSE : material_type_of(g.material);
             const float* mcolor = g.emitter ? g.L : g.color;
             if (g.material == TRC_PBRT_OTHER && !g.emitter) inf.n_unsupported_materials++;
@@ -300,41 +353,91 @@ extern "C" trc_status trc_host_scene_load_pbrt(const char* path, trc_host_scene*
                 const float sz = length(f3(ctm.m[0][2], ctm.m[1][2], ctm.m[2][2]));
                 if (std::fabs(sx - sy) > 1e-4f * sx || std::fabs(sx - sz) > 1e-4f * sx) { inf.n_unsupported_shapes++; descs.push_back(ds); continue; }
                 ds.mapped_type = TRC_PRIM_SPHERE; ds.mapped_index = (uint32_t)s->spheres.size();
-                ds.mapped_material = intern_material(mtype, mcolor);
+                ds.mapped_material = intern_material(mtype, mcolor, checker);
                 s->spheres.push_back(make_sphere(ds.radius * sx, c, ds.mapped_material));
-            } else if (kind.text == "trianglemesh") {
-                ds.kind = TRC_PRIM_TRIANGLE;
-                const PbrtParam *P = find(params, "P"), *N = find(params, "N"), *I = find(params, "indices");
-                const PbrtParam* UV = find(params, "uv"); if (!UV) UV = find(params, "st");
-                if (!P || P->numbers.size() % 3 != 0 || P->numbers.empty()) return fail();
-                const size_t nv = P->numbers.size() / 3;
-                std::vector<double> seq;
-                if (!I) { if (nv != 3) return fail(); seq = {0, 1, 2}; }
-                const std::vector<double>& idxd = I ? I->numbers : seq;
-                if (idxd.size() % 3 != 0) return fail();
-                ds.n_vertices = (uint32_t)nv; ds.n_indices = (uint32_t)idxd.size();
-                if (N && N->numbers.size() != nv * 3) N = nullptr;
-                if (UV && UV->numbers.size() != nv * 2) UV = nullptr;
+            } else if (kind.text == "trianglemesh" || kind.text == "plymesh" || kind.text == "disk" || kind.text == "cylinder") {
+                // object-space vertices (+ normals, uv) and triangle indices of the shape, then one path for all four
+                std::vector<float> Po, No, UVo;
+                std::vector<uint32_t> idx;
+                if (kind.text == "trianglemesh") {
+                    ds.kind = TRC_PBRT_SHAPE_TRIANGLEMESH;
+                    const PbrtParam *P = find(params, "P"), *N = find(params, "N"), *I = find(params, "indices");
+                    const PbrtParam* UV = find(params, "uv"); if (!UV) UV = find(params, "st");
+                    if (!P || P->numbers.size() % 3 != 0 || P->numbers.empty()) return fail();
+                    const size_t nv = P->numbers.size() / 3;
+                    std::vector<double> seq;
+                    if (!I) { if (nv != 3) return fail(); seq = {0, 1, 2}; }
+                    const std::vector<double>& idxd = I ? I->numbers : seq;
+                    if (idxd.size() % 3 != 0) return fail();
+                    if (N && N->numbers.size() != nv * 3) N = nullptr;
+                    if (UV && UV->numbers.size() != nv * 2) UV = nullptr;
+                    for (double v : P->numbers) Po.push_back((float)v);
+                    if (N) for (double v : N->numbers) No.push_back((float)v);
+                    if (UV) for (double v : UV->numbers) UVo.push_back((float)v);
+                    for (double k : idxd) { if (!(k >= 0 && k < (double)nv)) return fail(); idx.push_back((uint32_t)k); }
+                } else if (kind.text == "plymesh") {
+                    ds.kind = TRC_PBRT_SHAPE_PLYMESH;
+                    auto fn = strs.find("filename");
+                    if (fn == strs.end()) return fail();
+                    const std::string ply_path = (!fn->second.empty() && fn->second[0] == '/') ? fn->second : dir_of(path) + fn->second;
+                    PlyMesh pm;
+                    if (!read_ply(ply_path, pm)) return fail();
+                    Po.swap(pm.P); No.swap(pm.N); UVo.swap(pm.UV); idx.swap(pm.indices);
+                } else {
+                    // Disk (z = height, innerradius <= r <= radius) and Cylinder (radius, zmin <= z <= zmax), phi in [0, phimax]:
+                    // pbrt-v3 shapes/disk.cpp, cylinder.cpp; a ring of quads, two triangles each
+                    const bool disk = kind.text == "disk";
+                    ds.kind = disk ? TRC_PBRT_SHAPE_DISK : TRC_PBRT_SHAPE_CYLINDER;
+                    ds.radius = float_of(params, "radius", 1.0f);
+                    ds.phimax = std::min(360.0f, std::max(0.0f, float_of(params, "phimax", 360.0f)));
+                    if (disk) { ds.zmin = ds.zmax = float_of(params, "height", 0.0f); ds.innerradius = float_of(params, "innerradius", 0.0f); }
+                    else {
+                        const float z0 = float_of(params, "zmin", -1.0f), z1 = float_of(params, "zmax", 1.0f);
+                        ds.zmin = std::min(z0, z1); ds.zmax = std::max(z0, z1);
+                    }
+                    if (!(ds.radius > 0.0f) || !(ds.phimax > 0.0f) || (disk && !(ds.innerradius >= 0.0f && ds.innerradius < ds.radius)) ||
+                        (!disk && !(ds.zmin < ds.zmax))) { inf.n_unsupported_shapes++; descs.push_back(ds); continue; }
+                    const uint32_t seg = std::max(3u, (uint32_t)std::ceil(kQuadricSegments * ds.phimax / 360.0f));
+                    const float phimax = ds.phimax * 3.14159265358979323846f / 180.0f;
+                    for (uint32_t k = 0; k <= seg; ++k) {
+                        const float u = (float)k / (float)seg, phi = u * phimax, c = std::cos(phi), sn = std::sin(phi);
+                        for (int side = 0; side < 2; ++side) {      // disk: inner, outer rim; cylinder: bottom, top
+                            const float r = disk ? (side ? ds.radius : ds.innerradius) : ds.radius;
+                            Po.push_back(r * c); Po.push_back(r * sn); Po.push_back(disk ? ds.zmin : (side ? ds.zmax : ds.zmin));
+                            if (disk) { No.push_back(0); No.push_back(0); No.push_back(1); }
+                            else { No.push_back(c); No.push_back(sn); No.push_back(0); }
+                            UVo.push_back(u); UVo.push_back((float)side);
+                        }
+                    }
+                    for (uint32_t k = 0; k < seg; ++k) {
+                        const uint32_t a = 2 * k, b = 2 * k + 1, c2 = 2 * k + 2, d2 = 2 * k + 3;
+                        const uint32_t tri[6] = {a, b, d2, a, d2, c2};
+                        for (uint32_t t3 : tri) idx.push_back(t3);
+                    }
+                }
+                const size_t nv = Po.size() / 3;
+                if (nv == 0 || idx.empty() || idx.size() % 3 != 0) return fail();
+                const bool hasN = No.size() == nv * 3, hasUV = UVo.size() == nv * 2;
+                ds.n_vertices = (uint32_t)nv; ds.n_indices = (uint32_t)idx.size();
                 std::vector<trc_float3> Pw(nv);
                 for (size_t v = 0; v < nv; ++v) {
-                    const float x = (float)P->numbers[3 * v], y = (float)P->numbers[3 * v + 1], z = (float)P->numbers[3 * v + 2];
+                    const float x = Po[3 * v], y = Po[3 * v + 1], z = Po[3 * v + 2];
                     float q[4];
                     for (int r = 0; r < 4; ++r) q[r] = ctm.m[r][0] * x + ctm.m[r][1] * y + ctm.m[r][2] * z + ctm.m[r][3];
                     const float w = q[3];
                     Pw[v] = f3(w == 1 ? q[0] : q[0] / w, w == 1 ? q[1] : q[1] / w, w == 1 ? q[2] : q[2] / w);
                 }
-                std::vector<uint32_t> idx;
-                for (double k : idxd) { if (!(k >= 0 && k < (double)nv)) return fail(); idx.push_back((uint32_t)k); }
                 Quad q;
-                if (as_axis_aligned_rectangle(Pw, idx, q)) {
+                if (kind.text == "trianglemesh" && as_axis_aligned_rectangle(Pw, idx, q)) {
                     ds.mapped_type = TRC_PRIM_SQUARE;
-                    ds.mapped_material = intern_material(mtype, mcolor);
+                    ds.mapped_material = intern_material(mtype, mcolor, checker);
                     squares.push_back(PendingSquare{q, ds.mapped_material, g.emitter, descs.size()});
                 } else {
                     ds.mapped_type = TRC_PRIM_TRIANGLE; ds.mapped_index = (uint32_t)(s->indices.size() / 3); ds.mapped_material = 19;
                     if (!have_tri_material) {
                         tri_material = make_material(mtype);
                         tri_material.textureInfo.albedo = f3(mcolor[0], mcolor[1], mcolor[2]);
+                        if (checker) tri_material.textureInfo.type = TRC_TEX_CHECKER;
                         if (mtype == TRC_MAT_METAL || mtype == TRC_MAT_GLASS) tri_material.specular = 1;
                         have_tri_material = true;
                     } else if (tri_material.type != mtype) inf.n_triangle_material_conflicts++;
@@ -342,7 +445,7 @@ extern "C" trc_status trc_host_scene_load_pbrt(const char* path, trc_host_scene*
                     const bool has_inv = m4_inverse(ctm, inv);
                     const uint32_t base = (uint32_t)s->vertices.size();
                     std::vector<trc_float3> acc(nv, f3(0.0f));
-                    if (!N || !has_inv)                                          // area-weighted smooth normals
+                    if (!hasN || !has_inv)                                       // area-weighted smooth normals
                         for (size_t tt = 0; tt + 2 < idx.size(); tt += 3) {
                             const trc_float3 fn = cross(Pw[idx[tt + 1]] - Pw[idx[tt]], Pw[idx[tt + 2]] - Pw[idx[tt]]);
                             acc[idx[tt]] = acc[idx[tt]] + fn; acc[idx[tt + 1]] = acc[idx[tt + 1]] + fn; acc[idx[tt + 2]] = acc[idx[tt + 2]] + fn;
@@ -350,15 +453,15 @@ extern "C" trc_status trc_host_scene_load_pbrt(const char* path, trc_host_scene*
                     for (size_t v = 0; v < nv; ++v) {
                         trc_TriangleVertex tv;
                         tv.v[0] = Pw[v].x; tv.v[1] = Pw[v].y; tv.v[2] = Pw[v].z;
-                        if (N && has_inv) {
-                            const float nx = (float)N->numbers[3 * v], ny = (float)N->numbers[3 * v + 1], nz = (float)N->numbers[3 * v + 2];
+                        if (hasN && has_inv) {
+                            const float nx = No[3 * v], ny = No[3 * v + 1], nz = No[3 * v + 2];
                             for (int r = 0; r < 3; ++r) tv.n[r] = inv.m[0][r] * nx + inv.m[1][r] * ny + inv.m[2][r] * nz;
                         } else {
                             const float len = length(acc[v]);
                             const trc_float3 n = len > 0.0f ? acc[v] / len : f3(0, 1, 0);
                             tv.n[0] = n.x; tv.n[1] = n.y; tv.n[2] = n.z;
                         }
-                        tv.uv[0] = UV ? (float)UV->numbers[2 * v] : 0.0f; tv.uv[1] = UV ? (float)UV->numbers[2 * v + 1] : 0.0f;
+                        tv.uv[0] = hasUV ? UVo[2 * v] : 0.0f; tv.uv[1] = hasUV ? UVo[2 * v + 1] : 0.0f;
                         s->vertices.push_back(tv);
                     }
                     for (uint32_t k : idx) s->indices.push_back(base + k);

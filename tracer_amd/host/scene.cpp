@@ -352,19 +352,114 @@ trc_status trc_host_load_density_pbrt(const char* path, uint32_t* nx, uint32_t* 
 }
 void trc_host_free(void* p) { std::free(p); }
 
+// Radiance RGBE (.hdr) -> float RGB.  The reference's backdrop is such a file (vulture_hide_4k.hdr through NSImage +
+// MTKTextureLoader with MTKTextureLoaderOriginFlippedVertically, AAPLRenderer.mm:352-383), sampled by direction through
+// SampleSphericalMap (Render.hh:42-48).  Published format (G. Ward, Graphics Gems II "Real Pixels"): text header up to an
+// empty line (needs FORMAT=32-bit_rle_rgbe), a resolution line "-Y H +X W", then H scanlines, each either flat (4 bytes
+// per pixel; old run-length markers 1 1 1 n are honoured) or new-style RLE (2 2 hi lo, then the four channels separately:
+// count > 128 -> a run of count - 128 copies of the next byte, else `count` literal bytes).  A pixel is
+// mantissa * 2^(e - 136), e = 0 -> black.  Rows come back BOTTOM-UP -- row 0 is the last scanline of the file -- which is
+// both what the reference's flipped texture holds and what trc_set_environment_map expects (v grows with the direction's y).
+trc_status trc_host_load_hdr(const char* path, uint32_t* width, uint32_t* height, float** rgb) {
+    if (!path || !width || !height || !rgb) return TRC_ERR_INVALID_ARG;
+    *rgb = nullptr; *width = *height = 0;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return TRC_ERR_INVALID_ARG;
+    std::vector<unsigned char> d;
+    {
+        unsigned char chunk[1 << 16];
+        size_t got;
+        while ((got = std::fread(chunk, 1, sizeof chunk, f)) > 0) d.insert(d.end(), chunk, chunk + got);
+        std::fclose(f);
+    }
+    size_t pos = 0;
+    auto line = [&](std::string& l) {
+        l.clear();
+        if (pos >= d.size()) return false;
+        while (pos < d.size() && d[pos] != '\n') l.push_back((char)d[pos++]);
+        if (pos < d.size()) ++pos;
+        if (!l.empty() && l.back() == '\r') l.pop_back();
+        return true;
+    };
+    std::string l;
+    if (!line(l) || (l.rfind("#?RADIANCE", 0) != 0 && l.rfind("#?RGBE", 0) != 0)) return TRC_ERR_INVALID_ARG;
+    bool format_ok = false;
+    for (;;) {
+        if (!line(l)) return TRC_ERR_INVALID_ARG;
+        if (l.empty()) break;
+        if (l.rfind("FORMAT=", 0) == 0) format_ok = l == "FORMAT=32-bit_rle_rgbe";
+    }
+    if (!format_ok || !line(l)) return TRC_ERR_UNSUPPORTED;
+    long H = 0, W = 0;
+    char sy = 0, sx = 0;
+    if (std::sscanf(l.c_str(), "%cY %ld %cX %ld", &sy, &H, &sx, &W) != 4 || sy != '-' || sx != '+') return TRC_ERR_UNSUPPORTED;   // the standard orientation only
+    if (W <= 0 || H <= 0 || (unsigned long long)W * (unsigned long long)H > (1ull << 28)) return TRC_ERR_INVALID_ARG;
+    float* out = (float*)std::malloc((size_t)W * H * 3 * sizeof(float));
+    if (!out) return TRC_ERR_OOM;
+    std::vector<unsigned char> scan((size_t)W * 4);
+    auto bad = [&]() { std::free(out); return TRC_ERR_INVALID_ARG; };
+    for (long y = 0; y < H; ++y) {
+        if (pos + 4 > d.size()) return bad();
+        if (W >= 8 && W < 32768 && d[pos] == 2 && d[pos + 1] == 2 && !(d[pos + 2] & 0x80)) {        // new-style RLE scanline
+            if (((long)d[pos + 2] << 8 | d[pos + 3]) != W) return bad();
+            pos += 4;
+            for (int c = 0; c < 4; ++c) {
+                long x = 0;
+                while (x < W) {
+                    if (pos >= d.size()) return bad();
+                    unsigned count = d[pos++];
+                    if (count > 128) {
+                        count -= 128;
+                        if (count == 0 || x + (long)count > W || pos >= d.size()) return bad();
+                        const unsigned char v = d[pos++];
+                        for (unsigned k = 0; k < count; ++k) scan[(size_t)(x++) * 4 + c] = v;
+                    } else {
+                        if (count == 0 || x + (long)count > W || pos + count > d.size()) return bad();
+                        for (unsigned k = 0; k < count; ++k) scan[(size_t)(x++) * 4 + c] = d[pos++];
+                    }
+                }
+            }
+        } else {                                                                                     // flat, with old-style runs
+            long x = 0;
+            int shift = 0;
+            while (x < W) {
+                if (pos + 4 > d.size()) return bad();
+                const unsigned char* px = &d[pos]; pos += 4;
+                if (px[0] == 1 && px[1] == 1 && px[2] == 1 && x > 0) {
+                    const long n = (long)px[3] << shift;
+                    if (n <= 0 || x + n > W) return bad();
+                    for (long k = 0; k < n; ++k, ++x) std::memcpy(&scan[(size_t)x * 4], &scan[(size_t)(x - 1) * 4], 4);
+                    shift += 8;
+                    if (shift > 24) return bad();
+                } else { std::memcpy(&scan[(size_t)x * 4], px, 4); ++x; shift = 0; }
+            }
+        }
+        float* row = out + (size_t)(H - 1 - y) * W * 3;                                             // bottom-up
+        for (long x = 0; x < W; ++x) {
+            const unsigned char* px = &scan[(size_t)x * 4];
+            const float scale = px[3] ? std::ldexp(1.0f, (int)px[3] - 136) : 0.0f;
+            row[3 * x] = (float)px[0] * scale; row[3 * x + 1] = (float)px[1] * scale; row[3 * x + 2] = (float)px[2] * scale;
+        }
+    }
+    *width = (uint32_t)W; *height = (uint32_t)H; *rgb = out;
+    return TRC_OK;
+}
+
 // PNG with stored deflate blocks: signature, IHDR, one IDAT (zlib stream of filter-0 scanlines), IEND
 trc_status trc_host_write_png(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height) {
     if (!path || !rgba8 || width == 0 || height == 0) return TRC_ERR_INVALID_ARG;
-    static uint32_t crc_table[256];
-    static bool crc_ready = false;
-    if (!crc_ready) {
-        for (uint32_t n = 0; n < 256; ++n) {
-            uint32_t c = n;
-            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-            crc_table[n] = c;
+    struct CrcTable {                    // built once, by whichever thread gets here first (C++11 static initialisation)
+        uint32_t t[256];
+        CrcTable() {
+            for (uint32_t n = 0; n < 256; ++n) {
+                uint32_t c = n;
+                for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+                t[n] = c;
+            }
         }
-        crc_ready = true;
-    }
+    };
+    static const CrcTable crc;
+    const uint32_t* crc_table = crc.t;
     auto be32 = [](std::vector<uint8_t>& v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); };
     auto chunk = [&](std::vector<uint8_t>& file, const char type[4], const std::vector<uint8_t>& data) {
         be32(file, (uint32_t)data.size());
