@@ -21,7 +21,7 @@ HOST_HDR  := tracer_amd/host/host_math.hpp tracer_amd/host/host_scene.hpp tracer
 HIP_SRC   := tracer_amd/csrc/trc_abi.hip tracer_amd/csrc/trc_sppm.hip tracer_amd/csrc/trc_lbvh.hip
 HIP_HDR   := $(wildcard tracer_amd/csrc/*.hpp) include/tracer_abi.h include/trc_detmath.h include/trc_sobol.h
 
-.PHONY: all host hip hip_fast oracle example clean variant
+.PHONY: all host hip hip_fast oracle example clean variant asan tsan sanitize
 all: host hip hip_fast oracle example
 
 host: $(LIBDIR)/libtrc_host.so
@@ -58,6 +58,25 @@ variant:
 example: examples/trc_render
 examples/trc_render: examples/trc_render.cpp include/tracer_abi.h $(LIBDIR)/libtrc_host.so $(LIBDIR)/libtracer_amd.so
 	$(CXX) -std=c++17 -O2 -Wall -Iinclude -o $@ examples/trc_render.cpp -L$(LIBDIR) -ltracer_amd -ltrc_host -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,$(ROCM)/lib
+
+# Sanitizers: the CPU sources of the repository -- libtrc_host and the oracle -- compiled with the
+# sanitizer into one driver (tools/sanitize/driver.cpp: threaded SAH builds, the oracle's row-band workers, every file reader
+# on well-formed and on mutated files), plus sanitized shared libraries for the Python CPU suite (tools/run_sanitizers.sh
+# preloads the runtime).  GPU code is not covered: GPU AddressSanitizer is not available on this pool.
+SAN_SRC := tools/sanitize/driver.cpp $(HOST_SRC) oracle/oracle.cpp oracle/oracle_lbvh.cpp
+build/asan/driver: $(SAN_SRC) $(HOST_HDR) oracle/oracle.h
+	@mkdir -p build/asan
+	$(CXX) -std=c++17 -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=undefined -ffp-contract=off -Iinclude -o $@ $(SAN_SRC) -lpthread
+	$(CXX) $(CXXFLAGS) -O1 -g -fsanitize=address,undefined -shared -o build/asan/libtrc_host.so $(HOST_SRC) -lpthread
+	$(CXX) $(CXXFLAGS) -O1 -g -fsanitize=address,undefined -Wno-unused-function -shared -o build/asan/liboracle.so oracle/oracle.cpp oracle/oracle_lbvh.cpp -lpthread
+	$(CXX) $(CXXFLAGS) -O1 -g -fsanitize=address,undefined -Wno-unused-function -DORACLE_USE_LIBM -shared -o build/asan/liboracle_libm.so oracle/oracle.cpp oracle/oracle_lbvh.cpp -lpthread
+build/tsan/driver: $(SAN_SRC) $(HOST_HDR) oracle/oracle.h
+	@mkdir -p build/tsan
+	$(CXX) -std=c++17 -O1 -g -fno-omit-frame-pointer -fsanitize=thread -ffp-contract=off -Iinclude -o $@ $(SAN_SRC) -lpthread
+asan: build/asan/driver
+tsan: build/tsan/driver
+sanitize:
+	bash tools/run_sanitizers.sh
 
 clean:
 	rm -f $(LIBDIR)/*.so examples/trc_render

@@ -18,7 +18,7 @@ _LIBS = {}
 def lib(libm=False):
     key = "liboracle_libm.so" if libm else "liboracle.so"
     if key not in _LIBS:
-        path = os.path.join(_HERE, key)
+        path = os.path.join(os.environ.get("TRC_ORACLE_DIR") or _HERE, key)      # TRC_ORACLE_DIR: the sanitized build (tools/run_sanitizers.sh)
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: run `make oracle`")
         L = C.CDLL(path)

@@ -15,7 +15,8 @@ _LIB = None
 
 
 def lib_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtrc_host.so")
+    """The in-tree build; TRC_HOST_LIB points tools/run_sanitizers.sh at the sanitized build of the same sources."""
+    return os.environ.get("TRC_HOST_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtrc_host.so")
 
 
 def lib():
