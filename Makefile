@@ -55,7 +55,10 @@ variant:
 	$(HIPCC) $(HIPFLAGS) $(DEFS) -shared -o build/lib$(NAME).so $(HIP_SRC) -ldl -lpthread -Wl,-rpath,$(ROCM)/lib
 
 # C++ host driving the path through the C ABI only (no Python): examples/trc_render
-example: examples/trc_render
+example: examples/trc_render examples/trc_ranks
+# N ranks started and composed without Python / PyTorch: RCCL id or the collectives themselves over TCP sockets
+examples/trc_ranks: examples/trc_ranks.cpp include/tracer_abi.h $(LIBDIR)/libtrc_host.so $(LIBDIR)/libtracer_amd.so
+	$(CXX) -std=c++17 -O2 -Wall -Iinclude -o $@ examples/trc_ranks.cpp -L$(LIBDIR) -ltracer_amd -ltrc_host -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,$(ROCM)/lib
 examples/trc_render: examples/trc_render.cpp include/tracer_abi.h $(LIBDIR)/libtrc_host.so $(LIBDIR)/libtracer_amd.so
 	$(CXX) -std=c++17 -O2 -Wall -Iinclude -o $@ examples/trc_render.cpp -L$(LIBDIR) -ltracer_amd -ltrc_host -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)' -Wl,-rpath,$(ROCM)/lib
 
@@ -79,5 +82,5 @@ sanitize:
 	bash tools/run_sanitizers.sh
 
 clean:
-	rm -f $(LIBDIR)/*.so examples/trc_render
+	rm -f $(LIBDIR)/*.so examples/trc_render examples/trc_ranks
 	$(MAKE) -C oracle clean

@@ -80,3 +80,44 @@ def test_example_ingests_pbrt_files(gpu, tmp_path):
     finally:
         gpu.upload_density(None, None)
     assert got.shape == want.shape and (got == want).all()
+
+
+RANKS_EXE = os.path.join(ROOT, "examples", "trc_ranks")
+
+
+def test_rank_example_needs_neither_python_nor_torch():
+    assert os.path.exists(RANKS_EXE), "run `make example`"
+    src = open(os.path.join(ROOT, "examples", "trc_ranks.cpp")).read()
+    assert '#include "tracer_abi.h"' in src and "oracle" not in src and "Python.h" not in src and "torch" not in src.lower().replace("pytorch", "")
+    needed = subprocess.check_output(["ldd", RANKS_EXE], text=True)
+    assert "libtracer_amd.so" in needed and "liboracle" not in needed and "libtorch" not in needed and "libpython" not in needed
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_ranks_started_and_composed_without_pytorch(gpu, tmp_path, ranks):
+    """examples/trc_ranks: fork N ranks, rendezvous on a TCP port, the collectives of trc_group_set_collectives over the same
+    sockets (N ranks on one GPU), tile-split frame + grouped SPPM composed on rank 0 == the 1-rank results (the program
+    checks that itself and exits non-zero otherwise); the PNG is the one the Python mirror tonemaps from its own render."""
+    from PIL import Image
+    W, H, spp = 480, 272, 12
+    out = tmp_path / "ranks.png"
+    log = subprocess.run([RANKS_EXE, "--ranks", str(ranks), "--host-collectives", "--size", str(W), str(H), "--spp", str(spp),
+                          "--sppm", "2", "--out", str(out)], text=True, capture_output=True, timeout=600)
+    assert log.returncode == 0, log.stdout + log.stderr
+    assert f"{ranks} ranks (collectives over TCP sockets" in log.stdout and "composed frame == the 1-rank frame" in log.stdout
+    assert f"the {ranks}-rank frame == the 1-rank frame" in log.stdout
+    got = np.asarray(Image.open(out).convert("RGBA"))
+    sc = host.HostScene(abi.SCENE_CORNELL_SPHERES)
+    gpu.upload_scene(sc.view); gpu.set_camera(host.prepare_camera(W, H)); gpu.set_environment((0.0, 0.0, 0.0)); gpu.resize(W, H)
+    gpu.seed(0x5EED0000); gpu.clear_accum(); gpu.render(spp=spp)
+    want, _ = gpu.tonemap()
+    assert got.shape == want.shape and (got == want).all()
+
+
+@pytest.mark.gpu
+def test_rccl_unique_id_travels_over_the_socket(gpu):
+    """the default path of the example with one rank: trc_group_unique_id -> trc_group_init -> ncclReduce, no Python involved"""
+    log = subprocess.run([RANKS_EXE, "--ranks", "1", "--size", "320", "200", "--spp", "8", "--out", "/dev/null"], text=True,
+                         capture_output=True, timeout=600)
+    assert log.returncode == 0 and "1 ranks (RCCL)" in log.stdout and "composed frame == the 1-rank frame" in log.stdout, log.stdout + log.stderr

@@ -3,7 +3,7 @@
 # writes gpurun_out/<round>/...; copy what is to be kept into profiles/<round>/ (tools/README.md, profiles/r02/README.md).
 # The PMC summaries carry the source hash of the library they were collected on; bench.py quotes pmc_config2.json only when
 # that hash is the running library's, so the bench line is taken in a SECOND call, after the summary has been committed.
-R=${1:-r02}; O=gpurun_out/$R; mkdir -p $O
+R=${1:-r03}; O=gpurun_out/$R; mkdir -p $O
 export TMPDIR=/tmp
 bash tools/pmc_collect.sh ${R}_c2 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-math
 python3 tools/pmc_summary.py ${R}_c2 "k_render<true, false, 0" $O/pmc_config2.json > $O/pmc_config2.txt 2>&1
@@ -16,10 +16,14 @@ for k in k_sppm_refine k_sppm_camera k_sppm_photon k_sppm_table; do python3 tool
 for c in 2 3 4 5; do for f in gpurun_out/${R}_c$c/trace/*/*_kernel_stats.csv; do cp $f $O/config${c}_kernel_stats.csv; done; done
 for c in 3 4 5 volume; do python3 tools/config_bench.py --config $c 2> $O/config$c.err; done > $O/configs_as_named.jsonl
 python3 bench.py > $O/bench_line_n1.json 2> $O/bench_n1.err
-python3 bench.py --gpus 2 --steps 2 > $O/bench_line_n2_one_gpu_no_rccl.json 2> $O/bench_n2.err
+python3 bench.py --gpus 2 --steps 2 > $O/bench_line_n2_one_gpu_plumbing.json 2> $O/bench_n2.err
+python3 bench.py --gpus 8 --steps 2 --no-other-scaling > $O/bench_line_n8_one_gpu_plumbing.json 2> $O/bench_n8.err
 python3 tools/tools_profile.py spheres > $O/cycle_profile_config2.txt 2>&1
 python3 tools/spp_sweep.py > $O/spp_sweep.txt 2>&1
-python3 tools/tile_balance.py > $O/tile_balance.txt 2>&1
+for c in 2 4 5; do python3 tools/tile_balance.py --config $c > $O/tile_balance_config$c.txt 2> $O/tile_balance_config$c.err; done
+python3 tools/tile_balance.py --config 4 --spp 64 > $O/tile_balance_config4_64spp.txt 2>&1
+python3 tools/split_trace.py --config 2 --ranks 1,2,4,8 > $O/adaptive_blocks_config2.txt 2>&1
+python3 tools/split_trace.py --config 4 --spp 64 --ranks 1,2,8 --launches 6 > $O/adaptive_blocks_config4_64spp.txt 2>&1
 python3 tools/lbvh_bench.py > $O/lbvh_bench.txt 2>&1
 python3 tools/small_blocks_bench.py > $O/small_blocks.txt 2>&1
 python3 tools/sppm_frame_sizes.py > $O/sppm_frame_sizes.txt 2>&1
