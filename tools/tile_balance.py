@@ -60,6 +60,16 @@ def path_traced(cfg):
                 ms.append(st.kernel_ms); rays.append(st.rays)
             print(f"N={N}: per-rank kernel ms {' '.join(f'{m:.2f}' for m in ms)}; max {max(ms):.2f}, ideal {full / N:.2f}, "
                   f"render-only efficiency {full / N / max(ms):.3f}; rays per rank min/max {min(rays)}/{max(rays)}")
+    if cfg == "2":
+        print("weak-scaling workload of bench.py: N views stacked into one 1920 x 1080 N frame, one view's worth of tiles per rank")
+        for N in (2, 8):
+            t.resize(W, H * N)
+            ms = []
+            for r in range(N):
+                for rep in range(4):
+                    t.seed(0x5EED0000); t.reset_stats(); t.render(spp=spp, integrator=wl["integrator"], tile_rank=r, tile_nranks=N, view_height=H); t.synchronize()
+                ms.append(t.stats().kernel_ms)
+            print(f"N={N}: per-rank kernel ms {' '.join(f'{m:.2f}' for m in ms)}; max {max(ms):.2f} vs N=1 {full:.2f}: efficiency {full / max(ms):.3f}")
     t.close()
 
 
