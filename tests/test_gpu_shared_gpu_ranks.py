@@ -136,3 +136,59 @@ def test_config5_sppm_as_an_n_rank_split_at_1080p(gpu, tmp_path, world):
         assert str(res[r]["pho_sha"]) == sha(pho) and str(res[r]["mark_sha"]) == sha(mark) and str(res[r]["count_sha"]) == sha(count), r
         assert res[r]["total"] == np.float32(cx.totalPhotonSum) and res[r]["hash_scale"] == np.float32(cx.photonHashScale)
         assert list(res[r]["calls"]) == [1, 2, frames]
+
+
+def test_device_pointer_table_and_error_propagation(gpu):
+    """host_staged = 0: the table's functions get the DEVICE buffer and the stream (what a GPU-aware transport would bind).
+    One rank, so every collective is the identity: the composed frame is the rendered one and the grouped SPPM pass the
+    ungrouped one -- and the arguments are what the header promises.  Then a function that fails: the call returns
+    TRC_ERR_RCCL with the function's code in the text, and a grouped SPPM frame that fails half-way asks for trc_sppm_init."""
+    import ctypes as C
+    from tracer_amd import device
+    from tracer_amd.gloo_collectives import ALLGATHER_FN, ALLREDUCE_FN, REDUCE_FN, Collectives
+    W, H, spp = 160, 96, 8
+    scene = host.HostScene(abi.SCENE_CORNELL_SPHERES)
+    seen = []
+
+    class Table:
+        def __init__(self, fail_allgather=0):
+            self.cb = (REDUCE_FN(lambda user, buf, count, dtype, op, root, stream: seen.append(("reduce", bool(buf), count, dtype, op, root, bool(stream))) or 0),
+                       ALLREDUCE_FN(lambda user, buf, count, dtype, op, stream: seen.append(("allreduce", bool(buf), count, dtype, op, bool(stream))) or 0),
+                       ALLGATHER_FN(lambda user, buf, per_rank, stream: seen.append(("allgather", bool(buf), per_rank, bool(stream))) or fail_allgather))
+            self.table = Collectives(None, 0, 0, *self.cb)               # host_staged = 0
+
+    t = device.Tracer(0)
+    try:
+        t.upload_scene(scene.view); t.set_camera(host.prepare_camera(W, H)); t.set_environment((0.0, 0.0, 0.0)); t.resize(W, H)
+        t.clear_accum(); t.seed(3); t.render(spp=spp)
+        alone = t.download_accum()
+        t.set_collectives(Table(), 1, 0)
+        t.clear_accum(); t.seed(3); t.render(spp=spp); t.group_reduce_accum(0)
+        assert np.array_equal(bits(t.download_accum()), bits(alone))
+        t.clear_accum(); t.seed(3); t.render(spp=spp); t.group_reduce_accum_async(0)
+        assert np.array_equal(bits(t.download_composed()), bits(alone))
+        t.synchronize(); t.clear_accum(); t.seed(8); t.sppm_init(9); t.sppm_frames(2)
+        grouped = t.download_accum()
+        t.group_finalize()
+        t.clear_accum(); t.seed(8); t.sppm_init(9); t.sppm_frames(2)
+        assert np.array_equal(bits(t.download_accum()), bits(grouped))
+        n = W * H * 4
+        assert seen[:2] == [("reduce", True, n, abi.DT_F32, abi.OP_SUM, 0, True)] * 2            # device pointer + stream
+        assert seen[2:4] == [("allreduce", True, 3, abi.DT_U32, abi.OP_MIN, True), ("allreduce", True, 3, abi.DT_U32, abi.OP_MAX, True)]
+        assert seen[4:] == [("allgather", True, abi.PHOTON_HASHN * abi.PHOTON_HASHN * 80, True)] * 2
+        # a transport that fails
+        t.set_collectives(Table(fail_allgather=7), 1, 0)
+        t.clear_accum(); t.seed(8); t.sppm_init(9)
+        with pytest.raises(device.TracerError) as e:
+            t.sppm_frames(1)
+        assert e.value.status == abi.ERR_RCCL and "returned 7" in str(e.value)
+        with pytest.raises(device.TracerError) as e:
+            t.sppm_frames(1)
+        assert "trc_sppm_init" in str(e.value)
+        t.group_finalize()
+        t.clear_accum(); t.seed(8); t.sppm_init(9); t.sppm_frames(2)                            # a fresh pass is fine again
+        assert np.array_equal(bits(t.download_accum()), bits(grouped))
+        with pytest.raises(device.TracerError):                                                   # no group: the group calls say so
+            t.group_reduce_accum(0)
+    finally:
+        t.close()
