@@ -435,8 +435,8 @@ trc_status trc_reset_stats(trc_ctx* ctx);
 trc_status trc_debug_profile(trc_ctx* ctx, uint64_t* out, uint32_t n_sites);
 /* developer diagnostic: the pixel blocks of the last trc_render (x | y << 16, in units of the block edge 1 << *blk_shift)
  * and the duration each one's wavefront measured (shader clocks / 64 -- the sort key of the adaptive launch order); with
- * strips (spp < 8) the costs are per strip; a block that ran as four 4x4 quarters reports its slowest quarter with the top
- * bit set.  Any pointer may be NULL; at most `capacity` entries are written. */
+ * strips (spp < 8) the costs are per strip; a block that ran in parts (four 4x4 quarters, some of them as four 2x2
+ * sixteenths) reports its slowest part with bit 31 set, and bit 30 when it had sixteenths.  Any pointer may be NULL; at most `capacity` entries are written. */
 trc_status trc_debug_block_costs(trc_ctx* ctx, uint32_t* tiles, uint32_t* costs, uint32_t capacity, uint32_t* n_blocks, uint32_t* blk_shift);
 
 /* device info for the bench line */

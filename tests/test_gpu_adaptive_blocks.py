@@ -17,6 +17,7 @@ def _launch(gpu, seed, **kw):
     gpu.render(**kw)
     frame, rng, rays = gpu.download_accum(), gpu.download_rng(), gpu.stats().rays
     _, costs, _ = gpu.block_costs()
+    _launch.sixteenths = int(((costs >> 30) & 1).sum())          # blocks some of whose quarters ran as 2x2 sixteenths
     return frame, rng, rays, int((costs >> 31).sum()), len(costs)
 
 
@@ -46,6 +47,25 @@ def test_quarters_on_an_lds_resident_scene(gpu, cornell_spheres):
         b = _launch(gpu, s, spp=spp, small_blocks=False, fixed_order=True)
         gpu.debug_set("no_split", 0)
         assert _same(a, b)
+
+
+def test_sixteenths_where_wavefront_slots_are_idle(gpu, cornell_spheres):
+    """second level of the plan: with fewer launch entries than wavefront slots, the quarters the launch ends on run as four
+    2x2 blocks on 4 lanes each from the next launch on -- same frame, whatever the plan picks"""
+    W, H, spp = 640, 360, 24
+    cam = host.prepare_camera(W, H)
+    gpu.upload_scene(cornell_spheres.view); gpu.set_camera(cam); gpu.set_environment((0.2, 0.3, 0.4)); gpu.resize(W, H)
+    gpu.debug_set("no_split", 0)
+    plain = _launch(gpu, 9, spp=spp, small_blocks=False, fixed_order=True)
+    gpu.debug_set("no_split", 0)
+    deep = []
+    for k in range(7):
+        r = _launch(gpu, 9, spp=spp)
+        deep.append(_launch.sixteenths)
+        assert _same(r, plain), k
+    assert deep[0] == 0 and max(deep) > 0, deep       # launch 1 is all quarters; sixteenths need a measured quarter first
+    ref, st = po.render(cornell_spheres.view, cam, W, H, host.fill_rng(9, W, H), spp=spp, env=(0.2, 0.3, 0.4))
+    assert st.rays == plain[2] and np.array_equal(plain[0].view(np.uint32), ref.view(np.uint32))
 
 
 @pytest.mark.parametrize("integrator", [abi.INTEGRATOR_PATH, abi.INTEGRATOR_MIS])

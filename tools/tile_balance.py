@@ -5,9 +5,9 @@ rank.  No hardware scaling curve exists for this repository (one GPU per box): t
 
     python3 tools/tile_balance.py --config 2|4|5 [--spp S] [--ranks 2,4,8]
 
-config 2 / 4 (path tracing): rank r renders the tiles (tx + ty) % N == r of the one named frame, every rank four times (from
-the second launch of a block list on, the adaptive expensive-first order and the cost-adaptive block size apply; the
-fourth launch is reported).
+config 2 / 4 (path tracing): rank r renders the tiles (tx + ty) % N == r of the one named frame, every rank --launches times
+(from the second launch of a block list on, the adaptive expensive-first order and the cost-adaptive block size apply and
+settle within ~8 launches; the mean of the last three is reported).
 config 5 (SPPM): rank r runs its share of every pass (camera + refine on its tiles, its photon index range, hash / table
 over ALL photons) with the collectives of trc_group_set_collectives served from a 1-rank pass running in lock step in a
 second context (bit-identical photons: tests/test_gpu_shared_gpu_ranks.py), timed per frame with the "sppm_timing" knob:
@@ -31,6 +31,7 @@ ap.add_argument("--config", default="2")
 ap.add_argument("--spp", type=int, default=0)
 ap.add_argument("--ranks", default="2,4,8")
 ap.add_argument("--frames", type=int, default=16, help="config 5: SPPM frames")
+ap.add_argument("--launches", type=int, default=10, help="configs 2 / 4: launches per rank (the plan settles within ~8); the mean of the last 3 is reported")
 ap.add_argument("--small-blocks", action="store_true", help="configs 2 / 4: also the forced 4x4-block variant")
 a = ap.parse_args()
 W, H = wlmod.W, wlmod.H
@@ -53,11 +54,13 @@ def path_traced(cfg):
         for N in ranks:
             ms, rays = [], []
             for r in range(N):
-                for rep in range(4):        # launch 1 measures the blocks, later ones run in adaptive order with the plan's quarters
+                last = []
+                for rep in range(a.launches):   # launch 1 measures the blocks, later ones run in adaptive order with the plan's parts
                     t.seed(0x5EED0000); t.reset_stats()
                     t.render(spp=spp, integrator=wl["integrator"], tile_rank=r, tile_nranks=N, small_blocks=small); t.synchronize()
-                st = t.stats()
-                ms.append(st.kernel_ms); rays.append(st.rays)
+                    st = t.stats()
+                    last.append(st.kernel_ms)
+                ms.append(sum(last[-3:]) / len(last[-3:])); rays.append(st.rays)
             print(f"N={N}: per-rank kernel ms {' '.join(f'{m:.2f}' for m in ms)}; max {max(ms):.2f}, ideal {full / N:.2f}, "
                   f"render-only efficiency {full / N / max(ms):.3f}; rays per rank min/max {min(rays)}/{max(rays)}")
     if cfg == "2":
@@ -67,7 +70,7 @@ def path_traced(cfg):
             ms = []
             for r in range(N):
                 for rep in range(4):
-                    t.seed(0x5EED0000); t.reset_stats(); t.render(spp=spp, integrator=wl["integrator"], tile_rank=r, tile_nranks=N, view_height=H); t.synchronize()
+                    t.seed(0x5EED0000); t.reset_stats(); t.render(spp=spp, integrator=wl["integrator"], tile_rank=r, tile_nranks=N, view_height=wlmod.H); t.synchronize()
                 ms.append(t.stats().kernel_ms)
             print(f"N={N}: per-rank kernel ms {' '.join(f'{m:.2f}' for m in ms)}; max {max(ms):.2f} vs N=1 {full:.2f}: efficiency {full / max(ms):.3f}")
     t.close()

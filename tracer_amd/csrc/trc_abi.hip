@@ -48,11 +48,15 @@ __device__ __forceinline__ void render_block(const KRender& kp, const DScene& sc
     const uint64_t t_start = clock64();          // this wavefront's own duration = the next launch's sort key
     const uint32_t entry = kp.order ? kp.order[slot] : slot;     // adaptive launch order / cost-adaptive block size (trc_render)
     const uint32_t index = entry & kLaunchIndexMask, code = entry >> kLaunchCodeShift;
+    if (index >= kp.n_tiles) return;                            // padding of the launch list's part region (k_pad_launch)
     const uint32_t tile = kp.tiles[index];                      // pixel block: x | y << 16 in units of the block edge
-    // 3: 8x8 pixels, all 64 lanes; 2: 4x4 pixels, lanes 0..15 -- the whole list (kp.blk_shift), or one quarter of an 8x8
-    // block whose previous launch ran long (code 1..4: quarter code - 1, x fastest)
-    const uint32_t bs = code ? 2u : kp.blk_shift;
-    const uint32_t qx = code ? ((code - 1u) & 1u) << 2 : 0u, qy = code ? ((code - 1u) >> 1) << 2 : 0u;
+    // 3: 8x8 pixels, all 64 lanes; 2: 4x4 pixels, lanes 0..15; 1: 2x2 pixels, lanes 0..3 -- the whole list (kp.blk_shift), or a part
+    // of an 8x8 block whose previous launch ran long: quarter code - 1, or sixteenth (code - 5) & 3 of quarter (code - 5) >> 2
+    const uint32_t part = code >= 5u ? code - 5u : 0u;
+    const uint32_t quarter = code >= 5u ? part >> 2 : (code ? code - 1u : 0u);
+    const uint32_t bs = code >= 5u ? 1u : (code ? 2u : kp.blk_shift);
+    const uint32_t qx = code ? ((quarter & 1u) << 2) + (code >= 5u ? (part & 1u) << 1 : 0u) : 0u;
+    const uint32_t qy = code ? ((quarter >> 1) << 2) + (code >= 5u ? ((part >> 1) & 1u) << 1 : 0u) : 0u;
     const uint32_t px = ((tile & 0xFFFFu) << kp.blk_shift) + qx + (lane & ((1u << bs) - 1u));
     const uint32_t py = ((tile >> 16) << kp.blk_shift) + qy + (lane >> bs);
     const uint32_t W = kp.fr.width, H = kp.fr.height;
@@ -457,20 +461,32 @@ __global__ void __launch_bounds__(64) k_stats_sum(const unsigned long long* rows
 }
 
 // sort keys of the adaptive launch order: descending cost (shader clocks / 64, clamped to 24 bits), ties in list order.
-// stride 4: the last launch may have run an 8x8 block as four quarters (split[i] != 0).  Its cost as ONE block is then
-// what it measured when it last ran whole (whole[i], kept by k_build_launch), or -- a first launch made of quarters only
-// -- an estimate from its slowest quarter on the high side.
+// Lists that may be split (stride kCostSlots): the last launch may have run an 8x8 block as four quarters (split[i] != 0),
+// and a quarter as four sixteenths (qsplit[4 i + q]).  A block's cost as ONE block is then what it measured when it last ran
+// whole (whole[i], kept by k_build_launch), or -- a first launch made of quarters only -- an estimate from its slowest part
+// on the high side.
 constexpr float kQuarterCost = 0.85f;        // a quarter's duration relative to its 8x8 block's: what the plan assumes for
                                              // a block it has not split yet (measured: 0.8-0.9 for the blocks that matter)
 constexpr float kQuarterEstimate = 0.65f;
-__device__ __forceinline__ uint32_t max_quarter(const uint32_t* q) { return max(max(q[0], q[1]), max(q[2], q[3])); }
-__global__ void __launch_bounds__(256) k_order_keys(const uint32_t* cost, const uint32_t* split, const uint32_t* whole, uint32_t stride, uint32_t n,
-                                                    uint32_t* keys, uint32_t* vals) {
+constexpr float kSixteenthTier = 0.8f;       // quarters within this factor of the launch's longest part go on to 2x2 blocks
+// the slowest part of block i that the last launch ran (quarters, or the sixteenths of the quarters that were split again)
+__device__ __forceinline__ uint32_t slowest_part(const uint32_t* cost, const uint32_t* qsplit, uint32_t i) {
+    const uint32_t* c = cost + (size_t)i * kCostSlots;
+    uint32_t m = 0u;
+#pragma unroll
+    for (uint32_t q = 0; q < 4u; ++q) {
+        if (qsplit[4u * i + q]) { const uint32_t* s = c + 4u + 4u * q; m = max(m, max(max(s[0], s[1]), max(s[2], s[3]))); }
+        else m = max(m, c[q]);
+    }
+    return m;
+}
+__global__ void __launch_bounds__(256) k_order_keys(const uint32_t* cost, const uint32_t* split, const uint32_t* whole, const uint32_t* qsplit,
+                                                    uint32_t stride, uint32_t n, uint32_t* keys, uint32_t* vals) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     uint32_t c = cost[(size_t)i * stride];
-    if (stride == 4u && split[i])
-        c = whole[i] ? whole[i] : (uint32_t)((float)max_quarter(cost + (size_t)i * 4u) * (1.0f / kQuarterEstimate));
+    if (stride == kCostSlots && split[i])
+        c = whole[i] ? whole[i] : (uint32_t)((float)slowest_part(cost, qsplit, i) * (1.0f / kQuarterEstimate));
     keys[i] = 0xFFFFFFu - min(c, 0xFFFFFFu);
     vals[i] = i;
 }
@@ -481,13 +497,17 @@ __global__ void __launch_bounds__(256) k_order_keys(const uint32_t* cost, const 
 // (a quarter waits for 16 pixels' branches, not 64) but occupies four slots and issues ~3x the instructions -- so only
 // the blocks that would otherwise decide the launch are split.  Input: the blocks in descending order of their cost as
 // whole blocks (keys[r] = 0xFFFFFF - cost, vals[r] = block).  Model of a launch that splits the K most expensive blocks:
-//     makespan(K) = max( cost[K], longest quarter, (sum + (4 * kQuarterCost - 1) * prefix(K)) / slots )
-// -- the longest block left whole; the longest quarter: the slowest one MEASURED in the previous launch, and
+//     makespan(K) = max( cost[K], longest part, (sum + (4 * kQuarterCost - 1) * prefix(K)) / slots )
+// -- the longest block left whole; the longest part: the slowest quarter / sixteenth MEASURED in the previous launch, and
 // kQuarterCost x the most expensive block that launch ran whole if K reaches it; the work over the wavefront slots.  One
 // workgroup picks the smallest K <= k_max that minimises it: a launch with many more blocks than slots gets K = 0 from
-// the third term, an eighth of a 1080p frame splits the few blocks above the longest quarter.
+// the third term, an eighth of a 1080p frame splits the few blocks above the longest part.
+// Second level: where wavefront slots are still idle after that (entries < slots), the quarters within kSixteenthTier of the
+// launch's longest part -- the ones the launch now ends on -- run as four 2x2 sixteenths on 4 lanes each in the next launch;
+// plan[3] = the threshold a quarter's duration must reach, plan[4] = how many do, plan[1] = the entries of the launch.
 __global__ void __launch_bounds__(1024) k_plan_split(const uint32_t* keys, const uint32_t* vals, const uint32_t* split, const uint32_t* cost,
-                                                     uint32_t n, uint32_t k_max, uint32_t slots, uint32_t* plan) {
+                                                     const uint32_t* qsplit, const uint32_t* qwhole, uint32_t n, uint32_t k_max, const uint32_t slots,
+                                                     const uint32_t max_entries, uint32_t* plan) {
     __shared__ double s_sum[1024];
     __shared__ float s_best[1024];
     __shared__ uint32_t s_k[1024];
@@ -499,7 +519,7 @@ __global__ void __launch_bounds__(1024) k_plan_split(const uint32_t* keys, const
     for (uint32_t r = lo; r < hi; ++r) {
         local += (double)(0xFFFFFFu - keys[r]);
         const uint32_t i = vals[r];
-        if (split[i]) q_max = max(q_max, max_quarter(cost + (size_t)i * 4u));
+        if (split[i]) q_max = max(q_max, slowest_part(cost, qsplit, i));
         else if (first_whole == 0xFFFFFFFFu) first_whole = r;
     }
     s_sum[t] = local; s_q[t] = q_max; s_first[t] = first_whole;
@@ -512,13 +532,12 @@ __global__ void __launch_bounds__(1024) k_plan_split(const uint32_t* keys, const
             q = max(q, s_q[i]); f = min(f, s_first[i]);
         }
         s_q[0] = q; s_first[0] = f;
-        plan[2] = (uint32_t)min(run / (double)slots, 4294967295.0);     // diagnostics: work / slots of the unsplit launch,
-        plan[3] = q;                                                    // the longest quarter of the previous launch
+        plan[2] = (uint32_t)min(run / (double)slots, 4294967295.0);     // diagnostic: work / slots of the unsplit launch
     }
     __syncthreads();
     double total = s_sum[1023];
     for (uint32_t r = min(n, 1023u * per); r < n; ++r) total += (double)(0xFFFFFFu - keys[r]);
-    const float quarter_seen = (float)s_q[0];
+    const float part_seen = (float)s_q[0];
     const uint32_t r_whole = s_first[0];            // most expensive block the previous launch ran whole
     const float quarter_new = r_whole < n ? kQuarterCost * (float)(0xFFFFFFu - keys[r_whole]) : 0.0f;
     const double extra = 4.0 * (double)kQuarterCost - 1.0;
@@ -526,11 +545,13 @@ __global__ void __launch_bounds__(1024) k_plan_split(const uint32_t* keys, const
     uint32_t best_k = 0;
     double prefix = s_sum[t];                       // cost of the blocks before rank `lo`
     auto candidate = [&](uint32_t k, float whole) {       // split ranks 0 .. k-1
-        const float quarter = k == 0u ? 0.0f : (k > r_whole ? fmaxf(quarter_seen, quarter_new) : quarter_seen);
+        const float part = k == 0u ? 0.0f : (k > r_whole ? fmaxf(part_seen, quarter_new) : part_seen);
         const float work = (float)((total + extra * prefix) / (double)slots);
-        const float m = fmaxf(fmaxf(whole, quarter), work);
+        const float m = fmaxf(fmaxf(whole, part), work);
         if (m < best) { best = m; best_k = k; }
     };
+    // fewer blocks than wavefront slots: the parts must not push the launch into a second round of wavefronts
+    if (n < slots) k_max = min(k_max, (slots - n) / 3u);
     for (uint32_t k = lo; k < hi && k <= k_max; ++k) {
         candidate(k, (float)(0xFFFFFFu - keys[k]));
         prefix += (double)(0xFFFFFFu - keys[k]);
@@ -545,31 +566,87 @@ __global__ void __launch_bounds__(1024) k_plan_split(const uint32_t* keys, const
         }
         __syncthreads();
     }
-    if (t == 0) { plan[0] = s_k[0]; plan[1] = n + 3u * s_k[0]; }
-}
-// the launch list of a plan: ranks 0 .. K-1 as four quarters each (the longest blocks first), then the other blocks whole
-__global__ void __launch_bounds__(256) k_build_launch(const uint32_t* keys, const uint32_t* vals, uint32_t n, const uint32_t* plan, uint32_t* launch,
-                                                      uint32_t* split, uint32_t* whole) {
-    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-    if (r >= n) return;
-    const uint32_t K = plan[0], i = vals[r];
-    if (r < K) {
-#pragma unroll
-        for (uint32_t j = 0; j < 4u; ++j) launch[4u * r + j] = i | ((j + 1u) << kLaunchCodeShift);
-        if (!split[i]) whole[i] = max(1u, 0xFFFFFFu - keys[r]);     // what it cost as one block, for as long as it runs as quarters
-        split[i] = 1u;
-    } else {
-        launch[3u * K + r] = i;
-        split[i] = 0u;
+    // the plan feeds back on itself (parts that end earlier lower the bar for the next launch's split): K moves by at most
+    // half of its previous value (+ 16) per launch, so the launch time settles instead of swinging
+    const uint32_t k_prev = plan[6];               // 0xFFFFFFFF: the previous launch was not planned from measurements
+    const uint32_t K = k_prev == 0xFFFFFFFFu ? s_k[0] : min(max(s_k[0], k_prev - k_prev / 2u), k_prev + k_prev / 2u + 16u);
+    __syncthreads();
+    // second level: the quarters of blocks that were quarters last launch too and lasted at least `tier`, as long as every
+    // entry of the launch still gets a wavefront slot of its own
+    // ... or, with more entries than slots, as long as the launch is bound by its longest part and not by its work
+    const uint32_t entries1 = n + 3u * K;
+    const float work_bound = (float)(total / (double)slots);           // the unsplit launch's work over the slots
+    const bool tail_bound = entries1 < slots || work_bound < 0.7f * part_seen;
+    const uint32_t tier = tail_bound && part_seen > 0.0f ? max(1u, (uint32_t)(kSixteenthTier * part_seen)) : 0xFFFFFFFFu;
+    uint32_t have = 0u, want = 0u;                  // quarters that already run as sixteenths / that would join them
+    for (uint32_t j = t; j < 4u * K; j += 1024u) {
+        const uint32_t i = vals[j >> 2], q = j & 3u;
+        if (!split[i]) continue;                                       // becomes quarters now: their durations are not known yet
+        if (qsplit[4u * i + q]) have++;
+        else if (cost[(size_t)i * kCostSlots + q] >= tier) want++;
+    }
+    s_k[t] = have; s_q[t] = want;
+    __syncthreads();
+    for (uint32_t off = 512u; off > 0u; off >>= 1) { if (t < off) { s_k[t] += s_k[t + off]; s_q[t] += s_q[t + off]; } __syncthreads(); }
+    if (t == 0) {
+        const uint32_t room = min(max_entries, max(slots, entries1 + slots / 8u)) - entries1;      // entries the sixteenths may add
+        uint32_t K2 = s_k[0] + s_q[0], use_tier = tier, keep = 1u;
+        if (12u * K2 > room) { K2 = s_k[0]; use_tier = 0xFFFFFFFFu; }                 // no new ones
+        if (12u * K2 > room) { K2 = 0u; keep = 0u; }                                  // not even the old ones: back to quarters
+        plan[0] = K; plan[3] = use_tier; plan[4] = K2; plan[7] = keep;
+        plan[5] = 0u;                                                  // k_build_launch's cursor into the part region
+        plan[6] = K;
+        plan[1] = entries1 + 12u * K2;
     }
 }
+// the launch list of a plan: first the parts of ranks 0 .. K-1 (the longest blocks: quarters, or sixteenths of the quarters
+// the second level picked), then the other blocks whole, longest first.  The parts take their places with an atomic cursor
+// (any order will do among them: they all start in the first round of wavefronts); a part region sized for more sixteenths
+// than were made is padded with entries that name no pixels.
+__global__ void __launch_bounds__(256) k_build_launch(const uint32_t* keys, const uint32_t* vals, const uint32_t* cost, uint32_t n, uint32_t* plan,
+                                                      uint32_t* launch, uint32_t* split, uint32_t* whole, uint32_t* qsplit, uint32_t* qwhole) {
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t K = plan[0], tier = plan[3], region = 4u * K + 12u * plan[4], keep = plan[7], i = vals[r];
+    if (r < K) {
+        const bool was_split = split[i] != 0u;
+        uint32_t codes[16], n_parts = 0u;          // per quarter: 1 entry or 4
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) {
+            bool again = false;
+            if (was_split) {
+                const bool was = qsplit[4u * i + q] != 0u;
+                const uint32_t cq = was ? qwhole[4u * i + q] : cost[(size_t)i * kCostSlots + q];
+                again = was ? keep != 0u : cq >= tier;
+                if (again && !was) qwhole[4u * i + q] = max(1u, cq);
+            }
+            qsplit[4u * i + q] = again ? 1u : 0u;
+            if (again) { for (uint32_t s4 = 0; s4 < 4u; ++s4) codes[n_parts++] = 5u + 4u * q + s4; }
+            else codes[n_parts++] = 1u + q;
+        }
+        const uint32_t at = atomicAdd(&plan[5], n_parts);
+        for (uint32_t j = 0; j < n_parts; ++j) if (at + j < region) launch[at + j] = i | (codes[j] << kLaunchCodeShift);
+        if (!was_split) whole[i] = max(1u, 0xFFFFFFu - keys[r]);     // what it cost as one block, for as long as it runs in parts
+        split[i] = 1u;
+    } else {
+        launch[region + (r - K)] = i;
+        split[i] = 0u;
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) qsplit[4u * i + q] = 0u;
+    }
+}
+// entries of the part region nobody claimed (the plan's count of sixteenths is an upper bound): a block index past the list
+__global__ void __launch_bounds__(256) k_pad_launch(const uint32_t* plan, uint32_t* launch) {
+    const uint32_t region = 4u * plan[0] + 12u * plan[4];
+    for (uint32_t j = plan[5] + blockIdx.x * 256u + threadIdx.x; j < region; j += gridDim.x * 256u) launch[j] = kLaunchIndexMask;
+}
 // every block as four quarters (a first launch of few blocks: nothing is known about their costs yet)
-__global__ void __launch_bounds__(256) k_build_launch_all_quarters(uint32_t n, uint32_t* plan, uint32_t* launch, uint32_t* split, uint32_t* whole) {
+__global__ void __launch_bounds__(256) k_build_launch_all_quarters(uint32_t n, uint32_t* plan, uint32_t* launch, uint32_t* split, uint32_t* whole, uint32_t* qsplit) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i == 0) { plan[0] = n; plan[1] = 4u * n; plan[2] = 0u; plan[3] = 0u; }
+    if (i == 0) { plan[0] = n; plan[1] = 4u * n; plan[2] = 0u; plan[3] = 0xFFFFFFFFu; plan[4] = 0u; plan[5] = 4u * n; plan[6] = 0xFFFFFFFFu; plan[7] = 1u; }
     if (i >= n) return;
 #pragma unroll
-    for (uint32_t j = 0; j < 4u; ++j) launch[4u * i + j] = i | ((j + 1u) << kLaunchCodeShift);
+    for (uint32_t j = 0; j < 4u; ++j) { launch[4u * i + j] = i | ((j + 1u) << kLaunchCodeShift); qsplit[4u * i + j] = 0u; }
     split[i] = 1u;
     whole[i] = 0u;            // never measured as one block: k_order_keys estimates it from the slowest quarter
 }
@@ -895,18 +972,24 @@ trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32
     (void)hipFree(ctx->d_order_hist); ctx->d_order_hist = nullptr;
     (void)hipFree(ctx->d_split); ctx->d_split = nullptr;
     (void)hipFree(ctx->d_whole); ctx->d_whole = nullptr;
+    (void)hipFree(ctx->d_qsplit); ctx->d_qsplit = nullptr;
+    (void)hipFree(ctx->d_qwhole); ctx->d_qwhole = nullptr;
     (void)hipFree(ctx->d_launch); ctx->d_launch = nullptr;
     ctx->cost_valid = false; ctx->d_last_order = nullptr; ctx->cost_quarters = false; ctx->launch_cap = 0;
     ctx->n_tiles = (uint32_t)tiles.size();
     if (ctx->n_tiles) {
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tiles, tiles.size() * 4));
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_block_cost, tiles.size() * 16));      // 4 slots per block: whole, or its quarters
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_block_cost, tiles.size() * 4 * kCostSlots));      // per block: whole / quarters / sixteenths
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_split, tiles.size() * 4));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_whole, tiles.size() * 4));
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_launch, tiles.size() * 16));
-        if (!ctx->d_plan) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_plan, 4 * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_qsplit, tiles.size() * 16));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_qwhole, tiles.size() * 16));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_launch, tiles.size() * 4 * kCostSlots));
+        if (!ctx->d_plan) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_plan, 8 * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_plan, 0, 8 * sizeof(uint32_t), ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_split, 0, tiles.size() * 4, ctx->stream));
-        ctx->launch_cap = (uint32_t)tiles.size() * 4u;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_qsplit, 0, tiles.size() * 16, ctx->stream));
+        ctx->launch_cap = (uint32_t)tiles.size() * kCostSlots;
         for (int k = 0; k < 2; ++k) {
             HIP_TRY(ctx, hipMalloc((void**)&ctx->d_order_keys[k], tiles.size() * 4));
             HIP_TRY(ctx, hipMalloc((void**)&ctx->d_order_vals[k], tiles.size() * 4));
@@ -1146,7 +1229,7 @@ void trc_destroy(trc_ctx* ctx) {
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     (void)hipFree(ctx->d_blob); (void)hipFree(ctx->d_bvh_ref); (void)hipFree(ctx->d_density); (void)hipFree(ctx->d_occupancy); (void)hipFree(ctx->d_envmap); (void)hipFree(ctx->d_sobol32); (void)hipFree(ctx->d_sobol_vdc); (void)hipFree(ctx->d_rng); (void)hipFree(ctx->d_accum);
     (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_stats); (void)hipFree(ctx->d_stats_sum); (void)hipFree(ctx->d_reduce_recv);
-    (void)hipFree(ctx->d_block_cost); (void)hipFree(ctx->d_order_hist); (void)hipFree(ctx->d_split); (void)hipFree(ctx->d_whole); (void)hipFree(ctx->d_launch); (void)hipFree(ctx->d_plan);
+    (void)hipFree(ctx->d_block_cost); (void)hipFree(ctx->d_order_hist); (void)hipFree(ctx->d_split); (void)hipFree(ctx->d_whole); (void)hipFree(ctx->d_qsplit); (void)hipFree(ctx->d_qwhole); (void)hipFree(ctx->d_launch); (void)hipFree(ctx->d_plan);
     for (int k = 0; k < 2; ++k) { (void)hipFree(ctx->d_order_keys[k]); (void)hipFree(ctx->d_order_vals[k]); }
     (void)hipFree(ctx->d_accum_alt); (void)hipFree(ctx->d_stack_ovf); (void)hipFree(ctx->d_queue);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
@@ -1412,7 +1495,7 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
     // 16.8 ms.  (2) Cost-adaptive block size (k_plan_split): the blocks that would decide the launch run as four 4x4
     // quarters.  Pixels depend on neither.
     const bool quarters_ok = kp.strip == 1 && blk_shift == 3;             // the list's blocks are 8x8: costs live in 4 slots per block
-    kp.cost_stride = quarters_ok ? 4u : 1u;
+    kp.cost_stride = quarters_ok ? kCostSlots : 1u;
     if (ctx->cost_strip != kp.strip || ctx->cost_quarters != quarters_ok) {
         ctx->cost_valid = false; ctx->cost_strip = kp.strip; ctx->cost_quarters = quarters_ok; ctx->d_last_order = nullptr;
     }
@@ -1429,7 +1512,7 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
         ctx->order_age++;                          // sort launches per 0.7 ms render are not
     } else if (ctx->cost_valid && !(p->flags & TRC_FLAG_FIXED_ORDER)) {
         const uint32_t n = (ctx->n_tiles + kp.strip - 1) / kp.strip;
-        hipLaunchKernelGGL(k_order_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_block_cost, ctx->d_split, ctx->d_whole, kp.cost_stride, n,
+        hipLaunchKernelGGL(k_order_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_block_cost, ctx->d_split, ctx->d_whole, ctx->d_qsplit, kp.cost_stride, n,
                            ctx->d_order_keys[0], ctx->d_order_vals[0]);
         int res = 0;
         trc_sort_pairs24(ctx->stream, ctx->d_order_keys, ctx->d_order_vals, ctx->d_order_hist, ctx->d_order_hist + trc_sort_hist_words(n), n, &res);
@@ -1438,13 +1521,15 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
         ctx->order_age = 0;
         if (may_split) {
             const uint32_t k_max = std::min(n, 2u * wave_slots);
+            const uint32_t max_entries = std::min(ctx->launch_cap, n + 3u * k_max + 2u * wave_slots);     // room for the second level's sixteenths
             hipLaunchKernelGGL(k_plan_split, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_order_keys[res], ctx->d_order_vals[res], ctx->d_split, ctx->d_block_cost,
-                               n, k_max, wave_slots, ctx->d_plan);
-            hipLaunchKernelGGL(k_build_launch, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_order_keys[res], ctx->d_order_vals[res], n, ctx->d_plan,
-                               ctx->d_launch, ctx->d_split, ctx->d_whole);
+                               ctx->d_qsplit, ctx->d_qwhole, n, k_max, wave_slots, max_entries, ctx->d_plan);
+            hipLaunchKernelGGL(k_build_launch, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_order_keys[res], ctx->d_order_vals[res], ctx->d_block_cost, n,
+                               ctx->d_plan, ctx->d_launch, ctx->d_split, ctx->d_whole, ctx->d_qsplit, ctx->d_qwhole);
+            hipLaunchKernelGGL(k_pad_launch, dim3(8), dim3(256), 0, ctx->stream, ctx->d_plan, ctx->d_launch);
             kp.order = ctx->d_launch;
             kp.n_launch = ctx->d_plan + 1;
-            grid_cap = n + 3u * k_max;
+            grid_cap = max_entries;
             planned = true;
         }
     } else if (may_split && !ctx->cost_valid && kAutoSmallBlocks && fits && blocks8 <= (uint64_t)ctx->cu_count * 16u &&
@@ -1452,13 +1537,16 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
         // nothing is known about the blocks yet and there are no more of them than wavefront slots (a small frame, or an
         // eighth of a 1080p frame): every block as quarters -- measured on whole small frames at 64 spp (920 / 2 040 / 3 600
         // blocks: 8.5 / 8.3 / 8.9 -> 7.0 / 7.2 / 7.4 ms); from the second launch on the plan decides block by block
-        hipLaunchKernelGGL(k_build_launch_all_quarters, dim3((ctx->n_tiles + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_tiles, ctx->d_plan, ctx->d_launch, ctx->d_split, ctx->d_whole);
+        hipLaunchKernelGGL(k_build_launch_all_quarters, dim3((ctx->n_tiles + 255) / 256), dim3(256), 0, ctx->stream, ctx->n_tiles, ctx->d_plan, ctx->d_launch, ctx->d_split, ctx->d_whole, ctx->d_qsplit);
         kp.order = ctx->d_launch;
         kp.n_launch = ctx->d_plan + 1;
         grid_cap = 4u * ctx->n_tiles;
         planned = true;
     }
-    if (!planned && ctx->split_live) HIP_TRY(ctx, hipMemsetAsync(ctx->d_split, 0, (size_t)ctx->n_tiles * 4, ctx->stream));   // this launch runs every block whole
+    if (!planned && ctx->split_live) {                                    // this launch runs every block whole
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_split, 0, (size_t)ctx->n_tiles * 4, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_qsplit, 0, (size_t)ctx->n_tiles * 16, ctx->stream));
+    }
     ctx->split_live = planned;
     ctx->cost_valid = true;
     kp.density = ctx->d_density;
@@ -1619,13 +1707,22 @@ trc_status trc_debug_block_costs(trc_ctx* ctx, uint32_t* tiles, uint32_t* costs,
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (tiles) HIP_TRY(ctx, hipMemcpy(tiles, ctx->d_tiles, (size_t)n * 4, hipMemcpyDeviceToHost));
     if (costs) {
-        const uint32_t stride = ctx->cost_quarters ? 4u : 1u;
-        std::vector<uint32_t> c((size_t)n * stride), sp(n, 0u);
+        const uint32_t stride = ctx->cost_quarters ? kCostSlots : 1u;
+        std::vector<uint32_t> c((size_t)n * stride), sp(n, 0u), qs((size_t)n * 4u, 0u);
         HIP_TRY(ctx, hipMemcpy(c.data(), ctx->d_block_cost, c.size() * 4, hipMemcpyDeviceToHost));
-        if (stride == 4u) HIP_TRY(ctx, hipMemcpy(sp.data(), ctx->d_split, (size_t)n * 4, hipMemcpyDeviceToHost));
-        for (uint32_t i = 0; i < n; ++i) {        // a block that ran as quarters: its slowest quarter, top bit set
+        if (stride != 1u) {
+            HIP_TRY(ctx, hipMemcpy(sp.data(), ctx->d_split, (size_t)n * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(ctx, hipMemcpy(qs.data(), ctx->d_qsplit, (size_t)n * 16, hipMemcpyDeviceToHost));
+        }
+        for (uint32_t i = 0; i < n; ++i) {        // a block that ran in parts: its slowest part, bit 31 set (bit 30: some of them 2x2)
             const uint32_t* q = &c[(size_t)i * stride];
-            costs[i] = sp[i] ? (std::max(std::max(q[0], q[1]), std::max(q[2], q[3])) | 0x80000000u) : q[0];
+            if (!sp[i]) { costs[i] = q[0]; continue; }
+            uint32_t m = 0u, deep = 0u;
+            for (uint32_t k = 0; k < 4u; ++k) {
+                if (qs[4u * i + k]) { deep = 0x40000000u; for (uint32_t s4 = 0; s4 < 4u; ++s4) m = std::max(m, q[4u + 4u * k + s4]); }
+                else m = std::max(m, q[k]);
+            }
+            costs[i] = std::min(m, 0xFFFFFFu) | 0x80000000u | deep;
         }
     }
     return TRC_OK;

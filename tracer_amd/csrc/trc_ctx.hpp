@@ -16,9 +16,13 @@ using namespace trcdev;
 // ======================================================================= kernels
 extern __shared__ __attribute__((aligned(16))) uint32_t trc_smem[];
 
-// launch-list entries (KRender::order): index into the block list | child code << 29
-constexpr uint32_t kLaunchCodeShift = 29u;
+// launch-list entries (KRender::order): index into the block list | part code << 27.  Code 0: the whole block; 1..4: its 4x4
+// quarter code - 1 (x fastest) on 16 lanes; 5..20: the 2x2 sixteenth (code - 5) & 3 of quarter (code - 5) >> 2 on 4 lanes.
+constexpr uint32_t kLaunchCodeShift = 27u;
 constexpr uint32_t kLaunchIndexMask = (1u << kLaunchCodeShift) - 1u;
+// duration slots per 8x8 block of a list that may be split (KRender::cost_stride): 0..3 the quarters (0 also the whole
+// block), 4..19 the sixteenths
+constexpr uint32_t kCostSlots = 20u;
 
 struct KScene {
     DScene sc;
@@ -42,12 +46,11 @@ struct KRender {
     uint32_t* queue;                    // k_render_pwg: next position of the launch order to hand out
     uint32_t blk_shift;                 // log2 of the pixel-block edge of one wavefront: 3 (8x8, 64 lanes) or 2 (4x4, 16 lanes)
     uint32_t n_tiles, strip;            // k_render_strip: blocks in `tiles`, consecutive blocks per wavefront (1: k_render)
-    const uint32_t* order;              // launch list: order[slot] = index into `tiles` | child code << 29 (null: identity).
-                                        // Child code 0: the whole block; 1..4: one 4x4 quarter of an 8x8 block on 16 lanes
-                                        // (cost-adaptive block size, plan_split).  k_render_strip: strip indices, no codes.
+    const uint32_t* order;              // launch list: order[slot] = index into `tiles` | part code << 27 (null: identity; codes
+                                        // above: cost-adaptive block size, k_plan_split).  k_render_strip: strip indices, no codes.
     const uint32_t* n_launch;           // device word: entries of `order` in this launch (null: n_tiles); workgroups past it exit
-    uint32_t* block_cost;               // duration of each block in this launch (the next launch's sort key): slot 4 * tile +
-                                        // max(code - 1, 0) when the list may hold quarters (cost_stride 4), else slot `tile`
+    uint32_t* block_cost;               // duration of each block in this launch (the next launch's sort key): slot kCostSlots * tile +
+                                        // max(code - 1, 0) when the list may be split (cost_stride = kCostSlots), else slot `tile`
     uint32_t cost_stride;
     const uint32_t* sobol32;            // TRC_FLAG_SOBOL: [40][52] generator matrices (null otherwise)
     const uint64_t* sobol_vdc;          // ... [52] VdCSobolMatrices[m - 1] + [52] VdCSobolMatricesInv[m - 1]
@@ -155,6 +158,8 @@ struct trc_ctx {
     // launch list with the quarters spliced in, and the plan {quarters' parents K, entries}
     uint32_t* d_split = nullptr;
     uint32_t* d_whole = nullptr;        // cost of a block when it last ran whole (while it runs as quarters)
+    uint32_t* d_qsplit = nullptr;       // [4 n] quarter q of block i ran as four sixteenths in the last launch ...
+    uint32_t* d_qwhole = nullptr;       // [4 n] ... and what it cost when it last ran as one quarter
     uint32_t* d_launch = nullptr;
     uint32_t* d_plan = nullptr;
     uint32_t launch_cap = 0;            // entries d_launch holds = the grid of a launch that may split
