@@ -1520,8 +1520,10 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
         ctx->d_last_order = kp.order;
         ctx->order_age = 0;
         if (may_split) {
-            const uint32_t k_max = std::min(n, 2u * wave_slots);
-            const uint32_t max_entries = std::min(ctx->launch_cap, n + 3u * k_max + 2u * wave_slots);     // room for the second level's sixteenths
+            // the grid is sized before the plan is known: half the slots' worth of split blocks is more than any plan has
+            // taken (a launch with fewer blocks than slots is capped to the slots anyway), + an eighth for sixteenths
+            const uint32_t k_max = std::min(n, wave_slots / 2u);
+            const uint32_t max_entries = std::min(ctx->launch_cap, std::max(n + 3u * k_max, wave_slots) + wave_slots / 8u);
             hipLaunchKernelGGL(k_plan_split, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_order_keys[res], ctx->d_order_vals[res], ctx->d_split, ctx->d_block_cost,
                                ctx->d_qsplit, ctx->d_qwhole, n, k_max, wave_slots, max_entries, ctx->d_plan);
             hipLaunchKernelGGL(k_build_launch, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_order_keys[res], ctx->d_order_vals[res], ctx->d_block_cost, n,
