@@ -33,7 +33,7 @@ extern "C" {
 /* 2: trc_trace_rays' last argument became a bit set (TRC_TRACE_*: 2 now means the production closest-hit walk, it used
  *    to mean any-hit); trc_build_flavor, trc_sppm_hash_cells, trc_host_scene_load_pbrt, trc_host_mesh_from_arrays added
  * 3: trc_group_set_collectives, trc_debug_set, trc_debug_block_costs; trc_pbrt_info / trc_pbrt_shape grew (textures,
- *    plymesh / disk / cylinder); trc_host_mesh_load_ply, trc_host_load_hdr */
+ *    plymesh / disk / cylinder); trc_host_mesh_load_ply, trc_host_load_hdr, trc_div_by_test */
 #define TRC_ABI_VERSION 3
 
 /* ------------------------------------------------------------------ */
@@ -460,6 +460,11 @@ trc_status trc_sppm_download(trc_ctx* ctx, trc_CameraRecord* camera_records /* W
 /* test hook like trc_trace_rays: `hash()` of Photon.hh:71-89 for n cell indices (3 floats each) at one hash scale, as
  * the hashing and refine passes evaluate it (the index into the 512 x 512 grid, before the -1 shift) */
 trc_status trc_sppm_hash_cells(trc_ctx* ctx, const float* cells /* n*3 */, size_t n, float hash_scale, float* out /* n */);
+
+/* test hook: the guarded shared-divisor division of tracer_amd/csrc/dev_vec.hpp (one refined reciprocal per divisor, the
+ * compiler's own two fused corrections per quotient, plain `/` outside [2^-60, 2^60]) against the plain division, for n
+ * operand pairs: fast / plain receive 3 quotients per pair (a / b, -a / b, (0.75 a) / b).  They must agree bit for bit. */
+trc_status trc_div_by_test(trc_ctx* ctx, const float* a, const float* b, size_t n, float* fast /* 3 n */, float* plain /* 3 n */);
 
 /* --- multi-GPU: pixel tiles sharded over ranks, one RCCL reduce -------- */
 #define TRC_UNIQUE_ID_BYTES 128

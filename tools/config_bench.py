@@ -50,10 +50,38 @@ t.synchronize()
 s = t.stats()
 ms = s.kernel_ms / a.steps
 n_leaf = s1.n_leaf_sphere + s1.n_leaf_square + s1.n_leaf_cube + s1.n_leaf_triangle
+
+
+def rooflines():
+    """the two objects of bench.py's line for this configuration: `roofline` = the binding VALU-issue bound from the newest
+    committed PMC summary of this kernel (profiles/rNN/pmc_config<c>.json: collected on a 32-spp launch of the same kernel;
+    only when its source hash is the running library's), `roofline_hbm_algorithmic` = the north_star's figure, live"""
+    import glob, re
+    sys.path.insert(0, wlmod.ROOT)
+    import bench
+    alg = {"bound": "hbm (algorithmic bytes, not a physical bound)", "achieved": round(bytes_launch / ms / 1e6, 1), "peak": bench.HBM_PEAK_GBS,
+           "unit": "GB/s", "frac": round(bytes_launch / ms / 1e6 / bench.HBM_PEAK_GBS, 4), "bytes_per_ray": round(bytes_launch / s1.rays, 1)}
+    files = sorted(glob.glob(os.path.join(wlmod.ROOT, "profiles", "r*", f"pmc_config{a.config}.json")),
+                   key=lambda f: int(re.search(r"r(\d+)$", os.path.basename(os.path.dirname(f))).group(1)))
+    mine = bench.lib_source_hash()
+    none = {"bound": "valu-issue", "achieved": None, "peak": None, "unit": "VALU wave-instructions/launch", "frac": None, "traffic": None, "lib_source_hash": mine}
+    if not files:
+        return dict(none, stale="no committed PMC summary of this configuration"), alg
+    pm = json.load(open(files[-1]))
+    rel = os.path.relpath(files[-1], wlmod.ROOT)
+    if pm.get("lib_source_hash") != mine or not str(pm.get("kernel", "")).startswith(wl["kernel"]):
+        return dict(none, stale=f"{rel} was collected on library {pm.get('lib_source_hash')} / kernel {pm.get('kernel')!r}; running {mine} / {wl['kernel']!r}"), alg
+    r = bench.valu_roofline(pm, None, rel, mine)
+    r["pmc_launch"] = f"{pm.get('workload_line', {}).get('spp')} spp"
+    return r, alg
+
+
+roof, roof_alg = rooflines()
 print(json.dumps({
     "config": wl["what"], "spp": spp, "kernel": wl["kernel"], "kernel_ms": round(ms, 3), "rays_per_launch": s1.rays,
     "mrays_per_s": round(s1.rays / ms / 1e3, 1), "mpaths_per_s": round(W * H * spp / ms / 1e3, 1),
     "bvh_nodes": wl["scene"].view.n_bvh, "triangles": wl["scene"].view.n_index // 3,
     "algorithmic_bytes_per_launch": bytes_launch, "bytes_per_ray": round(bytes_launch / s1.rays, 1),
     "algorithmic_gbs": round(bytes_launch / ms / 1e6, 1), "hbm_roofline_frac": round(bytes_launch / ms / 1e6 / 8000.0, 4),
-    "descend_per_ray": round(s1.n_descend / s1.rays, 2), "leaf_tests_per_ray": round(n_leaf / s1.rays, 2)}))
+    "descend_per_ray": round(s1.n_descend / s1.rays, 2), "leaf_tests_per_ray": round(n_leaf / s1.rays, 2),
+    "roofline": roof, "roofline_hbm_algorithmic": roof_alg}))

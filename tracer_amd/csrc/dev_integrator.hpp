@@ -212,7 +212,7 @@ TRC_DEV bool path_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, 
     F3 wiw = (nx * wi.x + ny * wi.y) + rec.sn * wi.z;                // stw * wi
     if (wi.z < 0) ps.ray = make_ray(offset_ray(hit_origin, -rec.sn), wiw);   // transmission
     else ps.ray = make_ray(_origin, wiw);
-    ps.ratio = ps.ratio * (attenuation / fmaxf(FLT_EPSILON, bxPDF));
+    ps.ratio = ps.ratio * div_shared(attenuation, fmaxf(FLT_EPSILON, bxPDF));
     {   // Russian roulette on luminance, :479-485
         float p = rgb_to_y(ps.ratio);
         if (pcg_float(rng) > p) { result = ps.color; return true; }

@@ -139,8 +139,14 @@ TRC_DEV bool box_hit_record(F3 mini, F3 maxi, F3 o, F3 d, float range_y, float& 
 #pragma unroll
     for (uint32_t i = 0; i < 3; ++i) {
         float oi = comp(o, i), di = comp(d, i);
+#if TRC_DIVBY_RENDER
+        const GuardedDivBy by = guarded_div_by(di);
+        float min_bound = guarded_div(comp(mini, i) - oi, by);
+        float max_bound = guarded_div(comp(maxi, i) - oi, by);
+#else
         float min_bound = (comp(mini, i) - oi) / di;
         float max_bound = (comp(maxi, i) - oi) / di;
+#endif
         float ts = fminf(max_bound, min_bound);
         float te = fmaxf(max_bound, min_bound);
         te *= pad;
@@ -201,7 +207,7 @@ TRC_DEV bool sphere_hit_test(const SceneRef& S, uint32_t index, const Ray& ray, 
     }
     rec.t = temp;
     rec.p = point_at(ray, temp);
-    rec.gn = (rec.p - center) / radius;
+    rec.gn = div_shared(rec.p - center, radius);
     check_face(rec, ray);
     if (EAGER_UV) rec.uv = sphere_uv(rec.gn);    // the render kernel derives it lazily from gn
     rec.material = sp[4];

@@ -41,6 +41,43 @@ TRC_DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), h
 TRC_DEV bool is_inf(float x) { return fabsf(x) == __builtin_inff(); }
 TRC_DEV bool is_nan(float x) { return x != x; }
 
+// ---------------------------------------------------------------- a / b for several a's and one b, same bits as `/`
+// hipcc's correctly rounded binary32 division is 11 instructions: v_div_scale x 2 (bring the operands into a range where
+// the arithmetic below cannot under- / overflow), v_rcp_f32, a Newton step on the reciprocal (2 fma), the product, two fused
+// residual corrections (4 fma), v_div_fmas / v_div_fixup (undo the scaling, special operands).  The reciprocal and its Newton
+// step depend on b alone: GuardedDivBy takes them once and a quotient keeps the product and the SAME two corrections.  What
+// v_div_scale / v_div_fixup do for free has to be paid here: the fast path is taken only when both operands lie in
+// [2^-60, 2^60] (no scaling would have happened: exponent difference < 96, no denormal operand, quotient or reciprocal), a
+// zero numerator is the signed zero of the product, everything else -- denormals, huge values, infinities, NaNs, a zero
+// divisor -- goes through the plain division.  tests/test_gpu_divby.py compares it with `/` bit for bit over adversarial
+// operand pairs (trc_div_by_test).  Whether it pays depends on how many quotients share a divisor: DESIGN.md section 9.
+struct GuardedDivBy { float b, y; bool ok; };
+TRC_DEV bool div_in_range(float x) { const float ax = fabsf(x); return ax >= 0x1p-60f && ax <= 0x1p60f; }
+TRC_DEV GuardedDivBy guarded_div_by(float b) {
+    GuardedDivBy d; d.b = b; d.ok = div_in_range(b);
+    const float y0 = __builtin_amdgcn_rcpf(b);
+    d.y = __builtin_fmaf(__builtin_fmaf(-b, y0, 1.0f), y0, y0);
+    return d;
+}
+TRC_DEV float guarded_div(float a, const GuardedDivBy& d) {
+    if (!(d.ok && (div_in_range(a) || a == 0.0f))) return a / d.b;
+    const float q0 = a * d.y;
+    float q = __builtin_fmaf(__builtin_fmaf(-d.b, q0, a), d.y, q0);
+    q = __builtin_fmaf(__builtin_fmaf(-d.b, q, a), d.y, q);
+    return a == 0.0f ? q0 : q;
+}
+TRC_DEV F3 guarded_div(F3 a, const GuardedDivBy& d) { return f3(guarded_div(a.x, d), guarded_div(a.y, d), guarded_div(a.z, d)); }
+#ifndef TRC_DIVBY_RENDER
+#define TRC_DIVBY_RENDER 0      // 1: the render kernels' shared-divisor sites go through GuardedDivBy (A/B variant)
+#endif
+TRC_DEV F3 div_shared(F3 a, float s) {      // vec3 / scalar at the sites that share the divisor
+#if TRC_DIVBY_RENDER
+    return guarded_div(a, guarded_div_by(s));
+#else
+    return a / s;
+#endif
+}
+
 constexpr float kPi = 3.14159265358979323846f;      // M_PI_F
 constexpr float kPi2 = 1.57079632679489661923f;     // M_PI_2_F
 

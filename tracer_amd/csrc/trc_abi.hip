@@ -119,7 +119,7 @@ __device__ __forceinline__ void render_block(const KRender& kp, const DScene& sc
                              is_inf(color.z) || is_nan(color.z);
             if (bad) color = f3(0);                                         // :537-538
             const uint32_t frame = kp.frame0 + s;
-            cached = (cached * (float)frame + color) / (float)(frame + 1);  // running mean, :540-541
+            cached = div_shared(cached * (float)frame + color, (float)(frame + 1));  // running mean, :540-541
             if (SOBOL) rng.state = state_after_cast;
             texel.y = (uint32_t)rng.state; texel.x = (uint32_t)(rng.state >> 32);
             texel.w = (uint32_t)rng.inc;   texel.z = (uint32_t)(rng.inc >> 32);
@@ -733,6 +733,18 @@ __global__ void __launch_bounds__(kBlock) k_trace(const KTrace kp) {
     o.n_return = cnt.n_return;
     o.n_leaf = cnt.leaf[0] + cnt.leaf[1] + cnt.leaf[2] + cnt.leaf[3];
     kp.hits[i] = o;
+}
+
+// trc_div_by_test: a[i] / b[i] through the guarded shared-divisor path (three numerators a, -a, a * 0.75 on one divisor) and
+// through the plain division
+__global__ void __launch_bounds__(256) k_div_by_test(const float* a, const float* b, uint32_t n, float* fast, float* plain) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float av = a[i], bv = b[i];
+    const GuardedDivBy d = guarded_div_by(bv);
+    const F3 q = guarded_div(f3(av, -av, av * 0.75f), d);
+    fast[3 * i] = q.x; fast[3 * i + 1] = q.y; fast[3 * i + 2] = q.z;
+    plain[3 * i] = av / bv; plain[3 * i + 1] = -av / bv; plain[3 * i + 2] = (av * 0.75f) / bv;
 }
 
 // ======================================================================= host side
@@ -1727,6 +1739,28 @@ trc_status trc_debug_block_costs(trc_ctx* ctx, uint32_t* tiles, uint32_t* costs,
             costs[i] = std::min(m, 0xFFFFFFu) | 0x80000000u | deep;
         }
     }
+    return TRC_OK;
+}
+
+trc_status trc_div_by_test(trc_ctx* ctx, const float* a, const float* b, size_t n, float* fast, float* plain) {
+    if (!ctx || (n && (!a || !b || !fast || !plain))) return TRC_ERR_INVALID_ARG;
+    if (n == 0) return TRC_OK;
+    if (n > 0x7FFFFFFFu / 3u) return fail(ctx, TRC_ERR_INVALID_ARG, "trc_div_by_test: too many pairs in one call");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float* d = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d, n * 8 * sizeof(float)));
+    float *d_a = d, *d_b = d + n, *d_fast = d + 2 * n, *d_plain = d + 5 * n;
+    hipError_t e = hipMemcpyAsync(d_a, a, n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_b, b, n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_div_by_test, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_a, d_b, (uint32_t)n, d_fast, d_plain);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(fast, d_fast, n * 12, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(plain, d_plain, n * 12, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream); else (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(ctx, TRC_ERR_HIP, std::string("trc_div_by_test: ") + hipGetErrorString(e));
     return TRC_OK;
 }
 

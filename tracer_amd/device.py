@@ -93,6 +93,7 @@ def _load(path):
     L.trc_group_finalize.argtypes = [vp]
     L.trc_group_set_collectives.argtypes = [vp, vp, C.c_int, C.c_int]
     L.trc_debug_set.argtypes = [vp, C.c_char_p, C.c_int]
+    L.trc_div_by_test.argtypes = [vp, vp, vp, C.c_size_t, vp, vp]
     L.trc_debug_block_costs.argtypes = [vp, vp, vp, u32, C.POINTER(u32), C.POINTER(u32)]
     for name in abi.DEVICE_SYMBOLS:
         f = getattr(L, name)
@@ -328,6 +329,14 @@ class Tracer:
     def debug_set(self, knob, value):
         """A/B and test knobs of this context (trc_debug_set): scheduling only, never a pixel."""
         self._check(self._L.trc_debug_set(self._h, knob.encode(), int(value)), "trc_debug_set")
+
+    def div_by_test(self, a, b):
+        """(fast, plain): 3 quotients per operand pair through the guarded shared-divisor division and through `/`."""
+        a = np.ascontiguousarray(a, dtype=np.float32); b = np.ascontiguousarray(b, dtype=np.float32)
+        assert a.shape == b.shape and a.ndim == 1
+        fast, plain = np.empty((len(a), 3), np.float32), np.empty((len(a), 3), np.float32)
+        self._check(self._L.trc_div_by_test(self._h, a.ctypes.data, b.ctypes.data, len(a), fast.ctypes.data, plain.ctypes.data), "trc_div_by_test")
+        return fast, plain
 
     def block_costs(self):
         """(tiles, costs, blk_shift) of the last render launch (trc_debug_block_costs)."""
