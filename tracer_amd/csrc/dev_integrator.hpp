@@ -280,10 +280,25 @@ TRC_DEV float grid_density(const trc_GridDensityInfo& info, const float* density
     const F3 ps = f3(p.x * nx - 0.5f, p.y * ny - 0.5f, p.z * nz - 0.5f);
     const int ix = grid_to_int(floorf(ps.x)), iy = grid_to_int(floorf(ps.y)), iz = grid_to_int(floorf(ps.z));
     const F3 d = f3(ps.x - (float)ix, ps.y - (float)iy, ps.z - (float)iz);
-    float d00 = lerp_f(d.x, grid_D(info, density, ix, iy, iz), grid_D(info, density, ix + 1, iy, iz));
-    float d10 = lerp_f(d.x, grid_D(info, density, ix, iy + 1, iz), grid_D(info, density, ix + 1, iy + 1, iz));
-    float d01 = lerp_f(d.x, grid_D(info, density, ix, iy, iz + 1), grid_D(info, density, ix + 1, iy, iz + 1));
-    float d11 = lerp_f(d.x, grid_D(info, density, ix, iy + 1, iz + 1), grid_D(info, density, ix + 1, iy + 1, iz + 1));
+    // the 8 corners: GridDensityMedium::D returns 0 outside the grid (Medium.hh:111-127), six compares per corner; a lookup
+    // whose cell and its +1 neighbours all lie inside -- every lookup but those in the outermost layer -- needs one range test
+    float c000, c100, c010, c110, c001, c101, c011, c111;
+    const int gx = (int)info.nx, gy = (int)info.ny, gz = (int)info.nz;
+    if (ix >= 0 && iy >= 0 && iz >= 0 && ix + 1 < gx && iy + 1 < gy && iz + 1 < gz) {
+        const float* b = density + ((size_t)iz * gy + iy) * gx + ix;
+        const size_t row = (size_t)gx, slab = (size_t)gx * gy;
+        c000 = b[0]; c100 = b[1]; c010 = b[row]; c110 = b[row + 1];
+        c001 = b[slab]; c101 = b[slab + 1]; c011 = b[slab + row]; c111 = b[slab + row + 1];
+    } else {
+        c000 = grid_D(info, density, ix, iy, iz); c100 = grid_D(info, density, ix + 1, iy, iz);
+        c010 = grid_D(info, density, ix, iy + 1, iz); c110 = grid_D(info, density, ix + 1, iy + 1, iz);
+        c001 = grid_D(info, density, ix, iy, iz + 1); c101 = grid_D(info, density, ix + 1, iy, iz + 1);
+        c011 = grid_D(info, density, ix, iy + 1, iz + 1); c111 = grid_D(info, density, ix + 1, iy + 1, iz + 1);
+    }
+    float d00 = lerp_f(d.x, c000, c100);
+    float d10 = lerp_f(d.x, c010, c110);
+    float d01 = lerp_f(d.x, c001, c101);
+    float d11 = lerp_f(d.x, c011, c111);
     float d0 = lerp_f(d.y, d00, d10);
     float d1 = lerp_f(d.y, d01, d11);
     return lerp_f(d.z, d0, d1);
