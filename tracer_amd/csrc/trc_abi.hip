@@ -480,6 +480,30 @@ __device__ __forceinline__ uint32_t slowest_part(const uint32_t* cost, const uin
     }
     return m;
 }
+// What a block's duration says about the block.  A SIMD issues from its oldest wavefronts first (tools/probe/age_probe.hip:
+// of five wavefronts on a SIMD the first two run as fast as a lone one, the fifth takes 1.8x as long), so the duration a
+// wavefront measures is its own work only if it started among the first of its SIMD; started later, the same block lasts up
+// to twice as long.  Sorting by the raw durations therefore feeds back on itself: a heavy block that ran first looks light,
+// starts late in the next launch, looks heavy again.  The order and the plan work on the SHORTEST duration seen lately
+// instead (it grows by 1/64 per launch until a measurement undercuts it, so a scene that changes is followed): config 2
+// 20.9 -> 20.4 ms, its shares of 2 / 4 / 8 ranks 12.3 -> 11.1, 8.5 -> 7.3, 5.95 -> 5.6 ms (knob no_cost_filter switches it off).
+// One thread per block filters the slots its last launch wrote (the block, its quarters or their sixteenths).
+__global__ void __launch_bounds__(256) k_filter_costs(const uint32_t* cost, const uint32_t* split, const uint32_t* qsplit, uint32_t stride, uint32_t n,
+                                                      uint32_t* filt) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    auto slot = [&](uint32_t k) {
+        const size_t at = (size_t)i * stride + k;
+        const uint32_t f = filt[at], c = cost[at];
+        filt[at] = f ? min(f + (f >> 6) + 1u, c) : c;
+    };
+    if (stride != kCostSlots || !split[i]) { slot(0u); return; }
+#pragma unroll
+    for (uint32_t q = 0; q < 4u; ++q) {
+        if (qsplit[4u * i + q]) { for (uint32_t s4 = 0; s4 < 4u; ++s4) slot(4u + 4u * q + s4); }
+        else slot(q);
+    }
+}
 __global__ void __launch_bounds__(256) k_order_keys(const uint32_t* cost, const uint32_t* split, const uint32_t* whole, const uint32_t* qsplit,
                                                     uint32_t stride, uint32_t n, uint32_t* keys, uint32_t* vals) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -507,36 +531,47 @@ __global__ void __launch_bounds__(256) k_order_keys(const uint32_t* cost, const 
 // plan[3] = the threshold a quarter's duration must reach, plan[4] = how many do, plan[1] = the entries of the launch.
 __global__ void __launch_bounds__(1024) k_plan_split(const uint32_t* keys, const uint32_t* vals, const uint32_t* split, const uint32_t* cost,
                                                      const uint32_t* qsplit, const uint32_t* qwhole, uint32_t n, uint32_t k_max, const uint32_t slots,
-                                                     const uint32_t max_entries, uint32_t* plan) {
+                                                     const uint32_t max_entries, uint32_t* plan, const uint32_t* raw) {
     __shared__ double s_sum[1024];
+    __shared__ float s_raw[1024], s_est[1024];
     __shared__ float s_best[1024];
     __shared__ uint32_t s_k[1024];
     __shared__ uint32_t s_q[1024], s_first[1024];
     const uint32_t t = threadIdx.x, per = (n + 1023u) / 1024u;
     const uint32_t lo = min(n, t * per), hi = min(n, lo + per);
     double local = 0.0;
+    float raw_sum = 0.0f, est_sum = 0.0f;          // blocks the last launch ran whole: measured durations / filtered costs
     uint32_t q_max = 0u, first_whole = 0xFFFFFFFFu;
     for (uint32_t r = lo; r < hi; ++r) {
         local += (double)(0xFFFFFFu - keys[r]);
         const uint32_t i = vals[r];
         if (split[i]) q_max = max(q_max, slowest_part(cost, qsplit, i));
-        else if (first_whole == 0xFFFFFFFFu) first_whole = r;
+        else {
+            if (first_whole == 0xFFFFFFFFu) first_whole = r;
+            raw_sum += (float)raw[(size_t)i * kCostSlots]; est_sum += (float)(0xFFFFFFu - keys[r]);
+        }
     }
-    s_sum[t] = local; s_q[t] = q_max; s_first[t] = first_whole;
+    s_sum[t] = local; s_q[t] = q_max; s_first[t] = first_whole; s_raw[t] = raw_sum; s_est[t] = est_sum;
     __syncthreads();
     if (t == 0) {                                   // exclusive scan of 1024 partial sums + two reductions: serial, a few microseconds
         double run = 0.0;
+        float rs = 0.0f, es = 0.0f;
         uint32_t q = 0u, f = 0xFFFFFFFFu;
         for (uint32_t i = 0; i < 1024u; ++i) {
             const double v = s_sum[i]; s_sum[i] = run; run += v;
             q = max(q, s_q[i]); f = min(f, s_first[i]);
+            rs += s_raw[i]; es += s_est[i];
         }
         s_q[0] = q; s_first[0] = f;
-        plan[2] = (uint32_t)min(run / (double)slots, 4294967295.0);     // diagnostic: work / slots of the unsplit launch
+        // the costs are what a block takes when it starts first on its SIMD; a wavefront slot is held for the measured
+        // duration: the work term scales by the ratio of the two over the blocks that ran whole
+        s_raw[0] = es > 0.0f ? fminf(fmaxf(rs / es, 1.0f), 4.0f) : 1.0f;
+        plan[2] = (uint32_t)min((es > 0.0f ? (double)fminf(fmaxf(rs / es, 1.0f), 4.0f) : 1.0) * run / (double)slots, 4294967295.0);   // diagnostic: work / slots of the unsplit launch
     }
     __syncthreads();
     double total = s_sum[1023];
     for (uint32_t r = min(n, 1023u * per); r < n; ++r) total += (double)(0xFFFFFFu - keys[r]);
+    const double held = (double)s_raw[0];           // slot time per unit of cost
     const float part_seen = (float)s_q[0];
     const uint32_t r_whole = s_first[0];            // most expensive block the previous launch ran whole
     const float quarter_new = r_whole < n ? kQuarterCost * (float)(0xFFFFFFu - keys[r_whole]) : 0.0f;
@@ -546,7 +581,7 @@ __global__ void __launch_bounds__(1024) k_plan_split(const uint32_t* keys, const
     double prefix = s_sum[t];                       // cost of the blocks before rank `lo`
     auto candidate = [&](uint32_t k, float whole) {       // split ranks 0 .. k-1
         const float part = k == 0u ? 0.0f : (k > r_whole ? fmaxf(part_seen, quarter_new) : part_seen);
-        const float work = (float)((total + extra * prefix) / (double)slots);
+        const float work = (float)(held * (total + extra * prefix) / (double)slots);
         const float m = fmaxf(fmaxf(whole, part), work);
         if (m < best) { best = m; best_k = k; }
     };
@@ -575,7 +610,7 @@ __global__ void __launch_bounds__(1024) k_plan_split(const uint32_t* keys, const
     // entry of the launch still gets a wavefront slot of its own
     // ... or, with more entries than slots, as long as the launch is bound by its longest part and not by its work
     const uint32_t entries1 = n + 3u * K;
-    const float work_bound = (float)(total / (double)slots);           // the unsplit launch's work over the slots
+    const float work_bound = (float)(held * total / (double)slots);    // the unsplit launch's work over the slots
     const bool tail_bound = entries1 < slots || work_bound < 0.7f * part_seen;
     const uint32_t tier = tail_bound && part_seen > 0.0f ? max(1u, (uint32_t)(kSixteenthTier * part_seen)) : 0xFFFFFFFFu;
     uint32_t have = 0u, want = 0u;                  // quarters that already run as sixteenths / that would join them
@@ -603,8 +638,8 @@ __global__ void __launch_bounds__(1024) k_plan_split(const uint32_t* keys, const
 // the second level picked), then the other blocks whole, longest first.  The parts take their places with an atomic cursor
 // (any order will do among them: they all start in the first round of wavefronts); a part region sized for more sixteenths
 // than were made is padded with entries that name no pixels.
-__global__ void __launch_bounds__(256) k_build_launch(const uint32_t* keys, const uint32_t* vals, const uint32_t* cost, uint32_t n, uint32_t* plan,
-                                                      uint32_t* launch, uint32_t* split, uint32_t* whole, uint32_t* qsplit, uint32_t* qwhole) {
+__global__ void __launch_bounds__(256) k_build_launch(const uint32_t* keys, const uint32_t* vals, uint32_t* cost, uint32_t n, uint32_t* plan,
+                                                      uint32_t* launch, uint32_t* split, uint32_t* whole, uint32_t* qsplit, uint32_t* qwhole, const bool filtered) {
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
     if (r >= n) return;
     const uint32_t K = plan[0], tier = plan[3], region = 4u * K + 12u * plan[4], keep = plan[7], i = vals[r];
@@ -618,7 +653,11 @@ __global__ void __launch_bounds__(256) k_build_launch(const uint32_t* keys, cons
                 const bool was = qsplit[4u * i + q] != 0u;
                 const uint32_t cq = was ? qwhole[4u * i + q] : cost[(size_t)i * kCostSlots + q];
                 again = was ? keep != 0u : cq >= tier;
-                if (again && !was) qwhole[4u * i + q] = max(1u, cq);
+                if (again && !was) {
+                    qwhole[4u * i + q] = max(1u, cq);
+                    if (filtered) for (uint32_t s4 = 0; s4 < 4u; ++s4) cost[(size_t)i * kCostSlots + 4u + 4u * q + s4] = 0u;   // nothing known yet
+                } else if (!again && was && filtered) cost[(size_t)i * kCostSlots + q] = qwhole[4u * i + q];    // back to one quarter: what it took as one
+
             }
             qsplit[4u * i + q] = again ? 1u : 0u;
             if (again) { for (uint32_t s4 = 0; s4 < 4u; ++s4) codes[n_parts++] = 5u + 4u * q + s4; }
@@ -626,10 +665,14 @@ __global__ void __launch_bounds__(256) k_build_launch(const uint32_t* keys, cons
         }
         const uint32_t at = atomicAdd(&plan[5], n_parts);
         for (uint32_t j = 0; j < n_parts; ++j) if (at + j < region) launch[at + j] = i | (codes[j] << kLaunchCodeShift);
-        if (!was_split) whole[i] = max(1u, 0xFFFFFFu - keys[r]);     // what it cost as one block, for as long as it runs in parts
+        if (!was_split) {
+            whole[i] = max(1u, 0xFFFFFFu - keys[r]);     // what it cost as one block, for as long as it runs in parts
+            if (filtered) for (uint32_t k = 0; k < 4u; ++k) cost[(size_t)i * kCostSlots + k] = 0u;               // the quarters: nothing known yet
+        }
         split[i] = 1u;
     } else {
         launch[region + (r - K)] = i;
+        if (filtered && split[i]) cost[(size_t)i * kCostSlots] = whole[i];                                       // back to one block: slot 0 was its first quarter's
         split[i] = 0u;
 #pragma unroll
         for (uint32_t q = 0; q < 4u; ++q) qsplit[4u * i + q] = 0u;
@@ -984,6 +1027,7 @@ trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32
     (void)hipFree(ctx->d_order_hist); ctx->d_order_hist = nullptr;
     (void)hipFree(ctx->d_split); ctx->d_split = nullptr;
     (void)hipFree(ctx->d_whole); ctx->d_whole = nullptr;
+    (void)hipFree(ctx->d_cost_est); ctx->d_cost_est = nullptr;
     (void)hipFree(ctx->d_qsplit); ctx->d_qsplit = nullptr;
     (void)hipFree(ctx->d_qwhole); ctx->d_qwhole = nullptr;
     (void)hipFree(ctx->d_launch); ctx->d_launch = nullptr;
@@ -994,6 +1038,7 @@ trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_block_cost, tiles.size() * 4 * kCostSlots));      // per block: whole / quarters / sixteenths
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_split, tiles.size() * 4));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_whole, tiles.size() * 4));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_cost_est, tiles.size() * 4 * kCostSlots));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_qsplit, tiles.size() * 16));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_qwhole, tiles.size() * 16));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_launch, tiles.size() * 4 * kCostSlots));
@@ -1241,7 +1286,7 @@ void trc_destroy(trc_ctx* ctx) {
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     (void)hipFree(ctx->d_blob); (void)hipFree(ctx->d_bvh_ref); (void)hipFree(ctx->d_density); (void)hipFree(ctx->d_occupancy); (void)hipFree(ctx->d_envmap); (void)hipFree(ctx->d_sobol32); (void)hipFree(ctx->d_sobol_vdc); (void)hipFree(ctx->d_rng); (void)hipFree(ctx->d_accum);
     (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_stats); (void)hipFree(ctx->d_stats_sum); (void)hipFree(ctx->d_reduce_recv);
-    (void)hipFree(ctx->d_block_cost); (void)hipFree(ctx->d_order_hist); (void)hipFree(ctx->d_split); (void)hipFree(ctx->d_whole); (void)hipFree(ctx->d_qsplit); (void)hipFree(ctx->d_qwhole); (void)hipFree(ctx->d_launch); (void)hipFree(ctx->d_plan);
+    (void)hipFree(ctx->d_block_cost); (void)hipFree(ctx->d_order_hist); (void)hipFree(ctx->d_split); (void)hipFree(ctx->d_whole); (void)hipFree(ctx->d_cost_est); (void)hipFree(ctx->d_qsplit); (void)hipFree(ctx->d_qwhole); (void)hipFree(ctx->d_launch); (void)hipFree(ctx->d_plan);
     for (int k = 0; k < 2; ++k) { (void)hipFree(ctx->d_order_keys[k]); (void)hipFree(ctx->d_order_vals[k]); }
     (void)hipFree(ctx->d_accum_alt); (void)hipFree(ctx->d_stack_ovf); (void)hipFree(ctx->d_queue);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
@@ -1524,7 +1569,11 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
         ctx->order_age++;                          // sort launches per 0.7 ms render are not
     } else if (ctx->cost_valid && !(p->flags & TRC_FLAG_FIXED_ORDER)) {
         const uint32_t n = (ctx->n_tiles + kp.strip - 1) / kp.strip;
-        hipLaunchKernelGGL(k_order_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_block_cost, ctx->d_split, ctx->d_whole, ctx->d_qsplit, kp.cost_stride, n,
+        // the costs the order and the plan work on: the shortest durations seen lately (k_filter_costs), or the last launch's
+        const bool filtered = !ctx->knobs.no_cost_filter;
+        uint32_t* costs = filtered ? ctx->d_cost_est : ctx->d_block_cost;
+        if (filtered) hipLaunchKernelGGL(k_filter_costs, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_block_cost, ctx->d_split, ctx->d_qsplit, kp.cost_stride, n, costs);
+        hipLaunchKernelGGL(k_order_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, costs, ctx->d_split, ctx->d_whole, ctx->d_qsplit, kp.cost_stride, n,
                            ctx->d_order_keys[0], ctx->d_order_vals[0]);
         int res = 0;
         trc_sort_pairs24(ctx->stream, ctx->d_order_keys, ctx->d_order_vals, ctx->d_order_hist, ctx->d_order_hist + trc_sort_hist_words(n), n, &res);
@@ -1536,10 +1585,10 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
             // taken (a launch with fewer blocks than slots is capped to the slots anyway), + an eighth for sixteenths
             const uint32_t k_max = std::min(n, wave_slots / 2u);
             const uint32_t max_entries = std::min(ctx->launch_cap, std::max(n + 3u * k_max, wave_slots) + wave_slots / 8u);
-            hipLaunchKernelGGL(k_plan_split, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_order_keys[res], ctx->d_order_vals[res], ctx->d_split, ctx->d_block_cost,
-                               ctx->d_qsplit, ctx->d_qwhole, n, k_max, wave_slots, max_entries, ctx->d_plan);
-            hipLaunchKernelGGL(k_build_launch, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_order_keys[res], ctx->d_order_vals[res], ctx->d_block_cost, n,
-                               ctx->d_plan, ctx->d_launch, ctx->d_split, ctx->d_whole, ctx->d_qsplit, ctx->d_qwhole);
+            hipLaunchKernelGGL(k_plan_split, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_order_keys[res], ctx->d_order_vals[res], ctx->d_split, costs,
+                               ctx->d_qsplit, ctx->d_qwhole, n, k_max, wave_slots, max_entries, ctx->d_plan, ctx->d_block_cost);
+            hipLaunchKernelGGL(k_build_launch, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_order_keys[res], ctx->d_order_vals[res], costs, n,
+                               ctx->d_plan, ctx->d_launch, ctx->d_split, ctx->d_whole, ctx->d_qsplit, ctx->d_qwhole, filtered);
             hipLaunchKernelGGL(k_pad_launch, dim3(8), dim3(256), 0, ctx->stream, ctx->d_plan, ctx->d_launch);
             kp.order = ctx->d_launch;
             kp.n_launch = ctx->d_plan + 1;
@@ -1560,8 +1609,10 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
     if (!planned && ctx->split_live) {                                    // this launch runs every block whole
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_split, 0, (size_t)ctx->n_tiles * 4, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_qsplit, 0, (size_t)ctx->n_tiles * 16, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_cost_est, 0, (size_t)ctx->n_tiles * 4 * kCostSlots, ctx->stream));   // slot 0 held first quarters
     }
     ctx->split_live = planned;
+    if (!ctx->cost_valid) HIP_TRY(ctx, hipMemsetAsync(ctx->d_cost_est, 0, (size_t)ctx->n_tiles * 4 * kCostSlots, ctx->stream));
     ctx->cost_valid = true;
     kp.density = ctx->d_density;
     kp.dinfo = ctx->dinfo;
@@ -1924,7 +1975,7 @@ trc_status trc_debug_set(trc_ctx* ctx, const char* knob, int value) {
     int* slot = k == "no_lds_fit" ? &ctx->knobs.no_lds_fit : k == "stack_lds_levels" ? &ctx->knobs.stack_lds_levels
               : k == "strip_len" ? &ctx->knobs.strip_len : k == "no_pwg" ? &ctx->knobs.no_pwg
               : k == "sppm_serial_camera" ? &ctx->knobs.sppm_serial_camera : k == "sppm_timing" ? &ctx->knobs.sppm_timing
-              : k == "force_blk_shift" ? &ctx->knobs.force_blk_shift : k == "no_split" ? &ctx->knobs.no_split : nullptr;
+              : k == "force_blk_shift" ? &ctx->knobs.force_blk_shift : k == "no_split" ? &ctx->knobs.no_split : k == "no_cost_filter" ? &ctx->knobs.no_cost_filter : nullptr;
     if (!slot) return fail(ctx, TRC_ERR_INVALID_ARG, "trc_debug_set: unknown knob " + k);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // a launch in flight keeps the plan it was made with
