@@ -92,3 +92,23 @@ def test_the_plan_leaves_a_full_frame_alone(gpu, cornell_spheres):
     runs = [_launch(gpu, 3, spp=spp) for _ in range(3)]
     assert _same(runs[0], runs[1]) and _same(runs[0], runs[2])
     assert runs[0][3] == 0 and max(r[3] for r in runs) <= 32400 // 20, [r[3] for r in runs]      # a few per cent at most: the plan works from measured durations
+
+
+def test_filtered_costs_change_the_schedule_not_the_pixels(gpu, cornell_spheres):
+    """The order and the plan work on the shortest duration a block showed lately (k_filter_costs), because the SIMD serves
+    its oldest wavefronts first and a block that started late measures up to twice its own work.  With the
+    filter and without (knob no_cost_filter), over launches that re-plan from their predecessors: the same frame, RNG
+    texture and ray count as the plain launch; the knob is reset for the tests that follow."""
+    W, H, spp = 960, 544, 12                        # a share-sized list: 8 160 blocks for 5 120 wavefront slots
+    gpu.upload_scene(cornell_spheres.view); gpu.set_camera(host.prepare_camera(W, H)); gpu.set_environment((0.2, 0.3, 0.4)); gpu.resize(W, H)
+    gpu.debug_set("no_cost_filter", 0)
+    plain = _launch(gpu, 11, spp=spp, small_blocks=False, fixed_order=True)
+    try:
+        for knob in (0, 1, 0):
+            gpu.debug_set("no_cost_filter", knob)
+            for _ in range(5):
+                assert _same(_launch(gpu, 11, spp=spp), plain)
+    finally:
+        gpu.debug_set("no_cost_filter", 0)
+    with pytest.raises(Exception):
+        gpu.debug_set("no_such_knob", 1)

@@ -44,9 +44,11 @@ def path_traced(cfg):
     t = Tracer(0)
     wlmod.setup(t, wl)
     print(f"{wl['what']}, {W}x{H}x{spp}spp; per-rank kernel ms of an N-rank tile split, emulated on one GPU")
-    for rep in range(2):
+    last = []
+    for rep in range(a.launches):                   # the same treatment as every rank below: settled order, mean of the last 3
         t.seed(0x5EED0000); t.reset_stats(); t.render(spp=spp, integrator=wl["integrator"]); t.synchronize()
-    full = t.stats().kernel_ms
+        last.append(t.stats().kernel_ms)
+    full = sum(last[-3:]) / len(last[-3:])
     print(f"N=1: {full:.2f} ms")
     variants = [(None, "default block size (trc_render decides)")] + ([(True, "4x4 pixel blocks forced (TRC_FLAG_SMALL_BLOCKS)")] if a.small_blocks else [])
     for small, label in variants:
@@ -69,9 +71,11 @@ def path_traced(cfg):
             t.resize(W, H * N)
             ms = []
             for r in range(N):
-                for rep in range(4):
+                last = []
+                for rep in range(a.launches):
                     t.seed(0x5EED0000); t.reset_stats(); t.render(spp=spp, integrator=wl["integrator"], tile_rank=r, tile_nranks=N, view_height=wlmod.H); t.synchronize()
-                ms.append(t.stats().kernel_ms)
+                    last.append(t.stats().kernel_ms)
+                ms.append(sum(last[-3:]) / len(last[-3:]))
             print(f"N={N}: per-rank kernel ms {' '.join(f'{m:.2f}' for m in ms)}; max {max(ms):.2f} vs N=1 {full:.2f}: efficiency {full / max(ms):.3f}")
     t.close()
 

@@ -1263,6 +1263,7 @@ trc_status trc_create(int device, trc_ctx** out) {
         ctx->knobs.strip_len = env_int("TRC_STRIP_LEN", false);
         ctx->knobs.no_pwg = env_int("TRC_NO_PWG", true);
         ctx->knobs.sppm_serial_camera = env_int("TRC_SPPM_SERIAL_CAMERA", true);
+        ctx->knobs.no_cost_filter = env_int("TRC_NO_COST_FILTER", true);
     }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void**)&ctx->d_stats, sizeof(unsigned long long) * kStatRows * kStatRowStride) != hipSuccess ||
