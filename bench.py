@@ -40,6 +40,7 @@ sys.path.insert(0, ROOT)
 
 W, H, SPP, DEPTH = 1920, 1080, 64, 8
 SEED = 0x5EED0000
+SETTLE_LAUNCHES = 8          # untimed launches before the W warm-up steps: the adaptive order / split plan of the block list settle
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 N_SIMD = 1024                # 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles (ibid., line 54)
 KERNEL = "k_render<true, false, 0"      # rocprof name prefix of the production tracePath kernel on an LDS-resident scene
@@ -409,6 +410,11 @@ def main(argv=None):
         bytes_per_launch = algorithmic_bytes(st1, own_pixels)
         rays_per_launch = st1.rays
 
+        # the launch order and the split plan are built from the durations of previous launches of the same block list and
+        # settle within ~8 launches: a progressive renderer is in that state from its ninth frame on, whatever
+        # W the caller picked.  Untimed, reported as config.settle_launches.
+        for _ in range(SETTLE_LAUNCHES):
+            step()
         for _ in range(warmup):
             step()
         barrier()
@@ -497,7 +503,8 @@ def main(argv=None):
                                      f"; {world} such views stacked into one 1920x{FH} frame, one view's worth of tiles per GPU")),
                        "integrator": "tracePath", "rays_per_step": primary["rays_per_step"],
                        "paths_per_step": primary["paths_per_step"], "mpaths_per_s": primary["mpaths_per_s"],
-                       "tiles": f"16x16 px, owner (tx+ty)%{world}", "device": info["name"], "compose": compose},
+                       "tiles": f"16x16 px, owner (tx+ty)%{world}", "device": info["name"], "compose": compose,
+                       "settle_launches": SETTLE_LAUNCHES},
             "vary_seed": primary["vary_seed"],
             # the BINDING bound of the dominant kernel: VALU issue (PMC counters of this library, profiles/rNN/pmc_config2.json)
             "roofline": roof,
