@@ -17,7 +17,8 @@
 //   DiffuseLight, color1 (emission)            RT_Nextweek/Tracer/Material.swift:86-101, Render.swift:327-340
 //   cornellBox scene, camera1                  RT_Nextweek/Tracer/Render.swift:171-192,59-81
 // randomFloat() = Float(arc4random())/Float(UInt32.max) (Random.swift:3-6) becomes a per-thread PCG32
-// (the reference's own pcg_basic.c algorithm) with fixed seeds.
+// (the reference's own pcg_basic.c algorithm) with fixed seeds, one stream per image row, so that the image and the ray
+// count are reproducible whatever the number of worker threads (tests/test_cpu_baseline.py).
 //
 // A "ray" here = one world.hitTest call (primary + scattered), the same unit as the GPU's Scene::hit count.
 #include <algorithm>
@@ -383,11 +384,12 @@ int main(int argc, char** argv) {
     std::vector<std::thread> pool;
     for (int index = 0; index < threads; ++index)
         pool.emplace_back([&, index] {
-            Rng rng; rng.seed(0x5EED0000ull, (uint64_t)index); t_rng = &rng; t_rays = 0;
+            Rng rng; t_rng = &rng; t_rays = 0;
             int upper = dataUnit;
             if (index == threads - 1 && remain != 0) upper += remain;     // the last band takes the remainder
             for (int value = 0; value < upper; ++value) {
                 int j = value + index * dataUnit;
+                rng.seed(0x5EED0000ull, (uint64_t)j);     // one stream per ROW: image and ray count do not depend on --threads
                 for (int i = 0; i < nx; ++i) {
                     Vec3 col;
                     for (int sidx = 0; sidx < ns; ++sidx) {
@@ -413,13 +415,15 @@ int main(int argc, char** argv) {
     double mean = 0;
     for (uint8_t b : image) mean += b;
     mean /= (double)image.size();
+    uint64_t hash = 1469598103934665603ull;                // FNV-1a over the 8-bit image (tests/test_cpu_baseline.py)
+    for (uint8_t b : image) { hash ^= b; hash *= 1099511628211ull; }
     if (!ppm.empty()) {
         FILE* f = std::fopen(ppm.c_str(), "wb");
         if (f) { std::fprintf(f, "P6\n%d %d\n255\n", nx, ny); std::fwrite(image.data(), 1, image.size(), f); std::fclose(f); }
     }
     std::printf("{\"scene\": \"%s\", \"width\": %d, \"height\": %d, \"spp\": %d, \"threads\": %d, \"seconds\": %.4f, "
-                "\"rays\": %llu, \"mrays_per_s\": %.3f, \"mpaths_per_s\": %.3f, \"mean_pixel\": %.2f}\n",
+                "\"rays\": %llu, \"mrays_per_s\": %.3f, \"mpaths_per_s\": %.3f, \"mean_pixel\": %.2f, \"image_fnv1a\": \"%016llx\"}\n",
                 scene_name.c_str(), nx, ny, ns, threads, seconds, (unsigned long long)total_rays,
-                total_rays / seconds / 1e6, (double)nx * ny * ns / seconds / 1e6, mean);
+                total_rays / seconds / 1e6, (double)nx * ny * ns / seconds / 1e6, mean, (unsigned long long)hash);
     return 0;
 }

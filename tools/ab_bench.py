@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def child(path, config, steps):
+def child(path, config, steps, spp_arg=0, warm=3):
     if "@" in path:                        # lib.so@NAME=VALUE[@NAME=VALUE]: the same build under other environment knobs
         path, *envs = path.split("@")
         for e in envs:
@@ -22,10 +22,10 @@ def child(path, config, steps):
     import workloads as wlmod
     from tracer_amd import device
     wl = wlmod.make(config)
-    spp = {"2": 64, "3": 32, "4": 32, "volume": 16}[config]
+    spp = spp_arg or {"2": 64, "3": 32, "4": 32, "volume": 16}[config]
     t = device.Tracer(0)
     wlmod.setup(t, wl)
-    for i in range(3):
+    for i in range(warm):
         t.seed(0x5EED0000 + i); t.clear_accum(); t.render(spp=spp, integrator=wl["integrator"])
     t.synchronize(); t.reset_stats()
     for i in range(steps):
@@ -41,16 +41,18 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--child", default=None)
+    ap.add_argument("--spp", type=int, default=0, help="samples per launch (default: 64 / 32 / 32 / 16 for config 2 / 3 / 4 / volume)")
+    ap.add_argument("--warm", type=int, default=3, help="untimed launches before the timed ones (the adaptive order and split plan settle)")
     ap.add_argument("libs", nargs="*")
     a = ap.parse_args()
     if a.child:
-        child(a.child, a.config, a.steps)
+        child(a.child, a.config, a.steps, a.spp, a.warm)
         return
     res = {p: [] for p in a.libs}
     for r in range(a.rounds):
         for p in a.libs:
             out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", p, "--config", a.config,
-                                  "--steps", str(a.steps)], capture_output=True, text=True, timeout=600)
+                                  "--steps", str(a.steps), "--spp", str(a.spp), "--warm", str(a.warm)], capture_output=True, text=True, timeout=600)
             if out.returncode != 0:
                 print(p, "FAILED", out.stderr[-400:]); continue
             res[p].append(float(out.stdout.split()[0]))

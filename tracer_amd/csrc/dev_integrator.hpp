@@ -347,7 +347,7 @@ TRC_DEV float grid_sample(const PathCtx& cx, const HitRec& rec, MediumHit& mi, P
 // Same for traceMIS (Render.metal:298-406) and, with VOLUME, traceVolume (Render.metal:78-275 = traceMIS + the
 // medium block :114-158).  Lights are literally squareList[5] and [6] (:320-324, B-12).
 // The shadow ray (any-hit Scene::hit) is traced here, inside the step.
-template <bool ALL_LDS, bool STATS, bool VOLUME = false, bool SOBOL = false>
+template <bool ALL_LDS, bool STATS, bool VOLUME = false, bool SOBOL = false, bool HYB = false>
 TRC_DEV bool mis_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, TravCounters& cnt, uint32_t& n_rays,
                       uint32_t& n_shaded, F3& result) {
     HitRec& rec = ps.rec;
@@ -419,9 +419,9 @@ TRC_DEV bool mis_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, T
     if (STATS || !TRC_ANYHIT_FREE) {                                  // the reference's walk (the exact counters are defined on it)
         HitRec shr;
         hit_init(shr);
-        blocked = scene_hit<ALL_LDS, STATS, true, false, false>(cx.S, cx.root_min, cx.root_max, _ray, shr, _dis, cx.stack, cx.lvstack, cnt);
+        blocked = scene_hit<ALL_LDS, STATS, true, false, false, HYB>(cx.S, cx.root_min, cx.root_max, _ray, shr, _dis, cx.stack, cx.lvstack, cnt);
     } else {                                                          // any-hit: the answer does not depend on the order (dev_intersect.hpp)
-        blocked = scene_occluded<ALL_LDS, false, false>(cx.S, cx.root_min, cx.root_max, _ray, _dis, cx.stack, cx.S.stack_lds);
+        blocked = scene_occluded<ALL_LDS, false, HYB>(cx.S, cx.root_min, cx.root_max, _ray, _dis, cx.stack, cx.S.stack_cap);
     }
     const F3 minus_d = -ps.ray.d;
     const F3 base_color = hit_color(cx.sh, rec);

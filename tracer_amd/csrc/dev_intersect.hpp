@@ -66,6 +66,7 @@ struct SceneRef {
     uint32_t off_nodes, off_spheres, off_squares, off_cubes, off_materials, off_tripos, off_triattr;
     uint32_t n_lds_nodes;
     uint32_t stack_lds;       // traversal-stack entries per lane that live in LDS ...
+    uint32_t stack_cap;       // ... of stack_cap in all (the tree's depth)
     uint32_t* ovf;            // ... deeper ones in this lane's column of the workgroup's overflow rows (global memory)
 };
 TRC_DEV float4 ld4(const uint32_t* p) { return *reinterpret_cast<const float4*>(p); }
@@ -353,6 +354,36 @@ TRC_DEV bool triangle_hit_test(const SceneRef& S, uint32_t index, const TriPos& 
     return true;
 }
 
+// The record of a triangle test that is KNOWN to be accepted (the replay of a walk's winner, trav_build_record): the same
+// expressions as triangle_hit_test above in the same order -- same bits -- without the reject exits, and with the position
+// and the attribute record requested together: one memory round trip where test-then-fetch takes two.
+TRC_DEV void triangle_record(const SceneRef& S, uint32_t index, const Ray& ray, HitRec& rec) {
+    const uint32_t* tp = S.blob + S.off_tripos + (size_t)index * kTriPosDwords;
+    const uint32_t* ta = S.blob + S.off_triattr + (size_t)index * kTriAttrDwords;
+    const float4 a4 = ld4_global(tp), b4 = ld4_global(tp + 4), c4 = ld4_global(tp + 8);
+    const float4 q0 = ld4_global(ta), q1 = ld4_global(ta + 4), q2 = ld4_global(ta + 8), q3 = ld4_global(ta + 12);
+    const F3 v0 = f3(a4.x, a4.y, a4.z), v1 = f3(b4.x, b4.y, b4.z), v2 = f3(c4.x, c4.y, c4.z);
+    F3 v0v1 = v1 - v0;
+    F3 v0v2 = v2 - v0;
+    F3 pvec = cross(ray.d, v0v2);
+    float det = dot(v0v1, pvec);
+    float invDet = 1 / det;
+    F3 tvec = ray.o - v0;
+    float u = dot(tvec, pvec) * invDet;
+    F3 qvec = cross(tvec, v0v1);
+    float v = dot(ray.d, qvec) * invDet;
+    float w = 1.0f - u - v;
+    float t = dot(v0v2, qvec) * invDet;
+    rec.p = (u * v1 + v * v2) + w * v0;
+    rec.t = t;
+    const F3 n0 = f3(q0.x, q0.y, q0.z), n1 = f3(q0.w, q1.x, q1.y), n2 = f3(q1.z, q1.w, q2.x);
+    rec.gn = (u * n1 + v * n2) + w * n0;                    // unnormalised (B-5)
+    rec.uv.x = (u * q2.w + v * q3.y) + w * q2.y;
+    rec.uv.y = (u * q3.x + v * q3.z) + w * q2.z;
+    check_face(rec, ray);
+    rec.material = 19;                                      // hard-coded, Triangle.hh:82
+}
+
 // ---------------------------------------------------------------- Scene::hit
 // Resumable traversal: the walk of one ray is a small state (Trav) advanced by trav_iter(), one "descend until a
 // leaf, test the leaf" round per call, so a kernel may interleave the rounds of its lanes with other work
@@ -364,6 +395,10 @@ struct Trav {
     float ry;                 // closest accepted t so far (test_t while nothing was hit)
     int32_t level;            // STATS only: level of the interior node being expanded / parent level of a leaf
     bool done;
+    // DEFER (below): the last accepted test -- its tag and the range_t.y it was run against.  Together with `ry` (= its t)
+    // that is all a walk has to carry: the record is a function of (ray, primitive, range_t.y) and is built after the walk.
+    uint32_t win_tag;
+    float win_ry;
 };
 
 // pops the next deferred sibling, or ends the traversal; `ret_start` = level at which the reference's first
@@ -411,6 +446,8 @@ TRC_DEV bool trav_begin(const F3 root_min, const F3 root_max, const Ray& ray, co
     tv.level = 0;
     tv.ry = test_t;
     tv.done = true;
+    tv.win_tag = kTagNone;
+    tv.win_ry = test_t;
     // a ray with a NaN / infinite component misses the scene (same rule as oracle/oracle.cpp Scene::hit: B-4/B-10);
     // without it NaN-ignoring min/max make such a ray "hit" every box of the tree
     const float finite_probe = fabsf(ray.o.x) + fabsf(ray.o.y) + fabsf(ray.o.z) + fabsf(ray.d.x) + fabsf(ray.d.y) + fabsf(ray.d.z);
@@ -421,32 +458,67 @@ TRC_DEV bool trav_begin(const F3 root_min, const F3 root_max, const Ray& ray, co
 }
 
 // leaf test of one primitive tag; returns true when the hit was accepted (tv.ry lowered).  `pre`: the triangle's positions
-// when the caller fetched them ahead (TRC_TRI_EARLY), else null
-template <bool STATS, bool EAGER_UV, bool VOL>
+// when the caller fetched them ahead (TRC_TRI_EARLY), else null.
+//
+// DEFER (production closest-hit walks): "test now, build the record for the winner afterwards".  The reference writes
+// the whole HitRecord at every accepted test (15 dwords that then stay live across the latency-bound loop: the mesh
+// kernels spilled them).  Every field of an accepted test's record is a function of (ray, primitive, the range_t.y the
+// test ran against), and the next accepted test overwrites all of them -- with two exceptions that are kept live: PDF
+// is written by squares only (Square.hh:110; a cube copies an uninitialised one, Cube.hh:21,45), so a later sphere / cube /
+// triangle hit still carries the last accepted square's, and the object-space fields of traceVolume are written by cubes
+// only (Cube.hh:30-31,39).  So the walk carries t (tv.ry), the winner's tag and the range it saw, writes through those two
+// groups when their primitive type is accepted, and trav_build_record() replays the winner once after the walk: same
+// function, same inputs, same bits.
+// DEFER = 2: everything but the cube, whose test is the most expensive one to replay (the LDS-resident kernels, where
+// instructions and not registers are what is short): an accepted cube writes the record at once as before, and the replay
+// after the walk leaves such a winner's record alone.
+template <bool STATS, bool EAGER_UV, bool VOL, int DEFER = 0>
 TRC_DEV bool trav_test_leaf(const SceneRef& S, const Ray& ray, HitRec& rec, Trav& tv, uint32_t tag, TravCounters& cnt, const TriPos* pre = nullptr) {
     const float rx = FLT_MIN;
     const uint32_t type = tag >> kTagIndexBits, index = tag & kTagIndexMask;
     bool ok;
+    HitRec scratch;                          // DEFER: what the tests write here is read by nobody (dead code), except ...
+    HitRec& out = DEFER ? scratch : rec;
+    const float ry_seen = tv.ry;
     if (type == 1u) {
         if (STATS) cnt.leaf[1]++;
         ProfScope<STATS> scope(cnt, kProfSquare);
-        ok = square_hit_test(S, index, ray, rx, tv.ry, rec);
+        ok = square_hit_test(S, index, ray, rx, tv.ry, out);
+        if (DEFER && ok) rec.PDF = scratch.PDF;                                   // ... the fields only ONE type writes
     } else if (type == 0u) {
         if (STATS) cnt.leaf[0]++;
         ProfScope<STATS> scope(cnt, kProfSphere);
-        ok = sphere_hit_test<EAGER_UV>(S, index, ray, rx, tv.ry, rec);
+        ok = sphere_hit_test<EAGER_UV>(S, index, ray, rx, tv.ry, out);
     } else if (type == 2u) {
         if (STATS) cnt.leaf[2]++;
         ProfScope<STATS> scope(cnt, kProfCube);
-        ok = cube_hit_test<STATS, VOL>(S, index, ray, tv.ry, rec, cnt);
+        ok = cube_hit_test<STATS, VOL>(S, index, ray, tv.ry, DEFER == 2 ? rec : out, cnt);
+        if (DEFER == 1 && VOL && ok) { rec.vol_o = scratch.vol_o; rec.vol_d = scratch.vol_d; rec.vol_t = scratch.vol_t; rec.vol_cube = scratch.vol_cube; }
     } else {
         if (STATS) cnt.leaf[3]++;
         ProfScope<STATS> scope(cnt, kProfTriangle);
-        ok = pre ? triangle_hit_test<STATS>(S, index, *pre, ray, rx, tv.ry, rec, cnt)
-                 : triangle_hit_test<STATS>(S, index, load_tripos(S, index), ray, rx, tv.ry, rec, cnt);
+        ok = pre ? triangle_hit_test<STATS>(S, index, *pre, ray, rx, tv.ry, out, cnt)
+                 : triangle_hit_test<STATS>(S, index, load_tripos(S, index), ray, rx, tv.ry, out, cnt);
     }
-    if (ok) rec.tag = tag;
+    if (ok) {
+        if (DEFER) { tv.win_tag = tag; tv.win_ry = ry_seen; }
+        else rec.tag = tag;
+    }
     return ok;
+}
+// DEFER: the record of the walk's winner, once.  A sphere under the lazy-uv rule (the render kernels) gets uv = 0 where the
+// eager walk leaves a stale value: hit_color() never reads a sphere's uv (it derives it from gn), so nobody can tell, and
+// the two dwords are not carried through the walk.
+template <bool EAGER_UV, bool VOL, int DEFER>
+TRC_DEV void trav_build_record(const SceneRef& S, const Ray& ray, HitRec& rec, const Trav& tv) {
+    const uint32_t type = tv.win_tag >> kTagIndexBits, index = tv.win_tag & kTagIndexMask;
+    TravCounters nocount;
+    float ry = tv.win_ry;
+    if (type == 3u) triangle_record(S, index, ray, rec);
+    else if (type == 1u) square_hit_test(S, index, ray, FLT_MIN, ry, rec);
+    else if (type == 0u) { sphere_hit_test<EAGER_UV>(S, index, ray, FLT_MIN, ry, rec); if (!EAGER_UV) { rec.uv.x = 0; rec.uv.y = 0; } }
+    else if (DEFER != 2) cube_hit_test<false, VOL>(S, index, ray, ry, rec, nocount);
+    rec.tag = tv.win_tag;
 }
 
 // one round: (1) expand interior nodes until this lane holds a leaf (or runs out of work) -- the whole wavefront
@@ -470,7 +542,7 @@ TRC_DEV bool trav_test_leaf(const SceneRef& S, const Ray& ray, HitRec& rec, Trav
 // rollback when the postponed test accepts) is exact but slower than the plain round (measured: 23.9 / 75.5 / 39.3 ms
 // against 22.6 / 77.8 / 40.9 plain and 22.7 / 70.8 / 35.7 for the threshold round); the unchecked one survives only as
 // the A/B variant TRC_SPEC_UNCHECKED, the build that must FAIL the adversarial test.
-template <bool ALL_LDS, bool STATS, bool ANY, bool EAGER_UV, bool VOL = false, bool HYB = false>
+template <bool ALL_LDS, bool STATS, bool ANY, bool EAGER_UV, bool VOL = false, bool HYB = false, int DEFER = 0>
 TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const float test_t, Trav& tv,
                        uint32_t* stack, uint32_t* lvstack, TravCounters& cnt) {
     const float rx = FLT_MIN;
@@ -505,11 +577,11 @@ TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const flo
         if (!tv.done) {
             if (pend == kTagNone && (tv.tag >> kTagIndexBits) < kTagInterior) { pend = tv.tag; pop_next(); }
             if (pend != kTagNone) {
-                trav_test_leaf<STATS, EAGER_UV, VOL>(S, ray, rec, tv, pend, cnt);
+                trav_test_leaf<STATS, EAGER_UV, VOL, DEFER>(S, ray, rec, tv, pend, cnt);
                 if (ANY && tv.ry < test_t) tv.done = true;                       // Render.hh:244
             }
             if (!tv.done && (tv.tag >> kTagIndexBits) < kTagInterior) {          // second leaf, found after the first
-                trav_test_leaf<STATS, EAGER_UV, VOL>(S, ray, rec, tv, tv.tag, cnt);
+                trav_test_leaf<STATS, EAGER_UV, VOL, DEFER>(S, ray, rec, tv, tv.tag, cnt);
                 if (ANY && tv.ry < test_t) tv.done = true;
                 else pop_next();
             }
@@ -569,19 +641,23 @@ TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const flo
         fetch_ahead();
     }
     if (!tv.done && (tv.tag >> kTagIndexBits) != kTagInterior) {
-        trav_test_leaf<STATS, EAGER_UV, VOL>(S, ray, rec, tv, tv.tag, cnt, (kTriEarly && have_pre) ? &pre : nullptr);
+        trav_test_leaf<STATS, EAGER_UV, VOL, DEFER>(S, ray, rec, tv, tv.tag, cnt, (kTriEarly && have_pre) ? &pre : nullptr);
         if (ANY && tv.ry < test_t) tv.done = true;                    // Render.hh:244
         else trav_pop_or_finish<HYB, STATS>(S, tv, tv.level, stack, lvstack, cnt);
     }
 }
 
-template <bool ALL_LDS, bool STATS, bool ANY, bool EAGER_UV, bool VOL = false, bool HYB = false>
+template <bool ALL_LDS, bool STATS, bool ANY, bool EAGER_UV, bool VOL = false, bool HYB = false, int DEFER = 0>
 TRC_DEV bool scene_hit(const SceneRef& S, const F3 root_min, const F3 root_max, const Ray& ray, HitRec& rec, const float test_t,
                        uint32_t* stack, uint32_t* lvstack, TravCounters& cnt) {
+    static_assert(!DEFER || (!STATS && !ANY), "the deferred record is the production closest-hit walk's");
     Trav tv;
     if (!trav_begin<STATS>(root_min, root_max, ray, test_t, tv, cnt)) return false;
-    while (!tv.done) trav_iter<ALL_LDS, STATS, ANY, EAGER_UV, VOL, HYB>(S, ray, rec, test_t, tv, stack, lvstack, cnt);
-    return tv.ry < test_t;
+    while (!tv.done) trav_iter<ALL_LDS, STATS, ANY, EAGER_UV, VOL, HYB, DEFER>(S, ray, rec, test_t, tv, stack, lvstack, cnt);
+    const bool hit = tv.ry < test_t;
+    // a miss ends the path (the record is re-initialised before anybody reads it), so only a hit is materialised
+    if (DEFER && hit) trav_build_record<EAGER_UV, VOL, DEFER>(S, ray, rec, tv);
+    return hit;
 }
 
 // ---------------------------------------------------------------- any-hit, order-free (production kernels)

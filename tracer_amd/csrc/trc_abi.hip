@@ -21,6 +21,25 @@
 #include "trc_ctx.hpp"
 #include "trc_scene_prep.hpp"
 
+// "test now, build the record for the winner afterwards" (dev_intersect.hpp: trav_test_leaf<DEFER>), per tree residence
+// two-level traversal stack (first entries in LDS, deeper ones in global rows: dev_intersect.hpp stack_put) per integrator, on
+// trees read from memory: it is what lets LDS admit the occupancy the registers allow
+#ifndef TRC_MIS_HYBRID
+#define TRC_MIS_HYBRID 1
+#endif
+#ifndef TRC_VOLUME_HYBRID
+#define TRC_VOLUME_HYBRID 0
+#endif
+constexpr bool hybrid_stack(int integrator) {
+    return integrator == TRC_INTEGRATOR_PATH || (integrator == TRC_INTEGRATOR_MIS ? TRC_MIS_HYBRID != 0 : TRC_VOLUME_HYBRID != 0);
+}
+#ifndef TRC_DEFER_LDS
+#define TRC_DEFER_LDS 0
+#endif
+#ifndef TRC_DEFER_GLOBAL
+#define TRC_DEFER_GLOBAL 1
+#endif
+
 // deterministic stand-in for fillRNG (AAPLRenderer.mm:296-344): texel p = 4 outputs of
 // pcg32_srandom_r(seed, p)
 __global__ void __launch_bounds__(256) k_seed(uint32_t* rng, uint32_t n_pixels, uint64_t seed) {
@@ -137,12 +156,13 @@ __device__ __forceinline__ void render_block(const KRender& kp, const DScene& sc
             ProfScope<STATS> loop_scope(cnt, kProfLoop);
             n_rays++;
             constexpr bool kVolume = INTEGRATOR == TRC_INTEGRATOR_VOLUME;
-            const bool hitted = scene_hit<LDS, STATS, false, false, kVolume, HYB>(cx.S, cx.root_min, cx.root_max, ps.ray, ps.rec, FLT_MAX,
+            constexpr int kDefer = STATS ? 0 : (LDS ? TRC_DEFER_LDS : TRC_DEFER_GLOBAL);      // dev_intersect.hpp: trav_test_leaf
+            const bool hitted = scene_hit<LDS, STATS, false, false, kVolume, HYB, kDefer>(cx.S, cx.root_min, cx.root_max, ps.ray, ps.rec, FLT_MAX,
                                                                         cx.stack, cx.lvstack, cnt);
             F3 color;
             const bool finished = (INTEGRATOR == TRC_INTEGRATOR_PATH)
                                       ? path_step<STATS, SOBOL>(cx, ps, hitted, rng, cnt, n_shaded, color)
-                                      : mis_step<LDS, STATS, kVolume, SOBOL>(cx, ps, hitted, rng, cnt, n_rays, n_shaded, color);
+                                      : mis_step<LDS, STATS, kVolume, SOBOL, HYB>(cx, ps, hitted, rng, cnt, n_rays, n_shaded, color);
             if (finished) finish_sample(color);
         }
         float4 out; out.x = cached.x; out.y = cached.y; out.z = cached.z; out.w = 1.0f;
@@ -165,26 +185,32 @@ __device__ __forceinline__ void render_block(const KRender& kp, const DScene& sc
 #define TRC_PATH_WAVES 5
 #endif
 #ifndef TRC_PATH_WAVES_GLOBAL
-#define TRC_PATH_WAVES_GLOBAL 6
+#define TRC_PATH_WAVES_GLOBAL 8
 #endif
 #ifndef TRC_MIS_WAVES
-#define TRC_MIS_WAVES 4
+#define TRC_MIS_WAVES 8
 #endif
 #ifndef TRC_VOLUME_WAVES
 #define TRC_VOLUME_WAVES 4
 #endif
 // persistent workgroups (k_render_pwg): wavefronts per workgroup x workgroups per CU = the waves per CU above
 #ifndef TRC_PWG_WAVES_PATH
-#define TRC_PWG_WAVES_PATH 12
+#define TRC_PWG_WAVES_PATH 16
 #endif
 #ifndef TRC_PWG_PER_CU_PATH
 #define TRC_PWG_PER_CU_PATH 2
 #endif
-#ifndef TRC_PWG_WAVES_OTHER
-#define TRC_PWG_WAVES_OTHER 16
+#ifndef TRC_PWG_WAVES_MIS
+#define TRC_PWG_WAVES_MIS 16
 #endif
-#ifndef TRC_PWG_PER_CU_OTHER
-#define TRC_PWG_PER_CU_OTHER 1
+#ifndef TRC_PWG_PER_CU_MIS
+#define TRC_PWG_PER_CU_MIS 2
+#endif
+#ifndef TRC_PWG_WAVES_VOLUME
+#define TRC_PWG_WAVES_VOLUME 16
+#endif
+#ifndef TRC_PWG_PER_CU_VOLUME
+#define TRC_PWG_PER_CU_VOLUME 1
 #endif
 template <bool LDS, bool STATS, int INTEGRATOR, bool SOBOL = false>
 __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRATOR_VOLUME ? TRC_VOLUME_WAVES : (INTEGRATOR == TRC_INTEGRATOR_MIS ? TRC_MIS_WAVES : (LDS ? TRC_PATH_WAVES : TRC_PATH_WAVES_GLOBAL)))) k_render(const KRender kp) {
@@ -198,7 +224,7 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
     uint32_t n_rays = 0, n_shaded = 0, n_paths = 0;
     TravCounters cnt;
     counters_zero(cnt);
-    constexpr bool kHybridStack = !LDS && !STATS && INTEGRATOR == TRC_INTEGRATOR_PATH;     // plan_launch_lds
+    constexpr bool kHybridStack = !LDS && !STATS && hybrid_stack(INTEGRATOR);     // plan_launch_lds
     uint32_t* ovf = kHybridStack ? kp.stack_ovf + (size_t)blockIdx.x * (sc.stack_depth - sc.stack_lds) * kBlock + lane : nullptr;
     render_block<LDS, STATS, INTEGRATOR, SOBOL, kHybridStack>(kp, sc, small_base, stack, lvstack, ovf, blockIdx.x, lane, n_rays, n_shaded, n_paths, cnt);
 
@@ -243,8 +269,8 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
 // lane.  Measured (profiles/r02/persistent_workgroups.txt): 2.4-3 % on configs 3 / 4 and the traceVolume scene -- most
 // of a mesh ray's steps are deep in the tree, below any prefix.  Workgroup shapes: tracePath 12 wavefronts x 2 per CU (10
 // x 2 leaves the SIMDs 3+3+2+2 and only one workgroup fits: 48 ms; 8 x 3: 36.8 against 31.1), the others 16 x 1 (8 x 2: +0.5 %).
-constexpr int pwg_waves(int integrator) { return integrator == TRC_INTEGRATOR_PATH ? TRC_PWG_WAVES_PATH : TRC_PWG_WAVES_OTHER; }
-constexpr int pwg_per_cu(int integrator) { return integrator == TRC_INTEGRATOR_PATH ? TRC_PWG_PER_CU_PATH : TRC_PWG_PER_CU_OTHER; }
+constexpr int pwg_waves(int integrator) { return integrator == TRC_INTEGRATOR_PATH ? TRC_PWG_WAVES_PATH : (integrator == TRC_INTEGRATOR_MIS ? TRC_PWG_WAVES_MIS : TRC_PWG_WAVES_VOLUME); }
+constexpr int pwg_per_cu(int integrator) { return integrator == TRC_INTEGRATOR_PATH ? TRC_PWG_PER_CU_PATH : (integrator == TRC_INTEGRATOR_MIS ? TRC_PWG_PER_CU_MIS : TRC_PWG_PER_CU_VOLUME); }
 template <int INTEGRATOR, bool SOBOL>
 __global__ void __launch_bounds__(64 * pwg_waves(INTEGRATOR), pwg_waves(INTEGRATOR) * pwg_per_cu(INTEGRATOR) / 4) k_render_pwg(const KRender kp) {
     const DScene& sc = kp.ks.sc;
@@ -256,7 +282,7 @@ __global__ void __launch_bounds__(64 * pwg_waves(INTEGRATOR), pwg_waves(INTEGRAT
         __syncthreads();
     }
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    constexpr bool kHybridStack = INTEGRATOR == TRC_INTEGRATOR_PATH;
+    constexpr bool kHybridStack = hybrid_stack(INTEGRATOR);
     uint32_t* stack = trc_smem + sc.lds_dwords + wave * sc.stack_lds * kBlock + lane;
     uint32_t* ovf = kHybridStack ? kp.stack_ovf + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * (sc.stack_depth - sc.stack_lds) * kBlock + lane : nullptr;
     uint32_t n_rays = 0, n_shaded = 0, n_paths = 0;
@@ -310,7 +336,7 @@ __global__ void __launch_bounds__(kBlock, INTEGRATOR == TRC_INTEGRATOR_VOLUME ? 
 
     PathCtx cx;
     cx.S = make_scene_ref(sc, small_base);
-    constexpr bool kHybridStack = !LDS && INTEGRATOR == TRC_INTEGRATOR_PATH;
+    constexpr bool kHybridStack = !LDS && hybrid_stack(INTEGRATOR);
     if (kHybridStack) cx.S.ovf = kp.stack_ovf + (size_t)blockIdx.x * (sc.stack_depth - sc.stack_lds) * kBlock + lane;
     cx.root_min = f3(kp.ks.root_box[0], kp.ks.root_box[1], kp.ks.root_box[2]);
     cx.root_max = f3(kp.ks.root_box[3], kp.ks.root_box[4], kp.ks.root_box[5]);
@@ -397,12 +423,13 @@ __global__ void __launch_bounds__(kBlock, INTEGRATOR == TRC_INTEGRATOR_VOLUME ? 
         if (alive) {
             n_rays++;
             constexpr bool kVolume = INTEGRATOR == TRC_INTEGRATOR_VOLUME;
-            const bool hitted = scene_hit<LDS, false, false, false, kVolume, kHybridStack>(cx.S, cx.root_min, cx.root_max, ps.ray, ps.rec, FLT_MAX,
+            constexpr int kDefer = LDS ? TRC_DEFER_LDS : TRC_DEFER_GLOBAL;
+            const bool hitted = scene_hit<LDS, false, false, false, kVolume, kHybridStack, kDefer>(cx.S, cx.root_min, cx.root_max, ps.ray, ps.rec, FLT_MAX,
                                                                       cx.stack, cx.lvstack, cnt);
             F3 color;
             const bool finished = (INTEGRATOR == TRC_INTEGRATOR_PATH)
                                       ? path_step<false, SOBOL>(cx, ps, hitted, rng, cnt, n_shaded, color)
-                                      : mis_step<LDS, false, kVolume, SOBOL>(cx, ps, hitted, rng, cnt, n_rays, n_shaded, color);
+                                      : mis_step<LDS, false, kVolume, SOBOL, kHybridStack>(cx, ps, hitted, rng, cnt, n_rays, n_shaded, color);
             if (finished) finish_sample(color);
         }
     }
@@ -756,7 +783,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(const KTrace kp) {
     const F3 root_min = f3(kp.ks.root_box[0], kp.ks.root_box[1], kp.ks.root_box[2]), root_max = f3(kp.ks.root_box[3], kp.ks.root_box[4], kp.ks.root_box[5]);
     bool h;
     if (kOrderFree) h = scene_occluded<LDS, false, false>(S, root_min, root_max, ray, in.tmax, stack, sc.stack_lds);
-    else h = scene_hit<LDS, STATS, ANY, true>(S, root_min, root_max, ray, rec, in.tmax, stack, lvstack, cnt);
+    else h = scene_hit<LDS, STATS, ANY, true, false, false, (STATS || ANY) ? 0 : (LDS ? TRC_DEFER_LDS : TRC_DEFER_GLOBAL)>(S, root_min, root_max, ray, rec, in.tmax, stack, lvstack, cnt);
     trc_hit o;
     memset(&o, 0, sizeof o);
     o.hit = h ? 1 : 0;
@@ -1636,16 +1663,17 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
     if (!stats && !ctx->lds_scene) {
         const bool strip = kp.strip > 1;
         const bool is_path = p->integrator == TRC_INTEGRATOR_PATH;
+        const bool hybrid = hybrid_stack((int)p->integrator);
         if (!ctx->knobs.no_pwg && !strip && ctx->lds_prefix_ok) {                       // no_pwg: A/B knob
             pwg_waves_n = (uint32_t)pwg_waves((int)p->integrator);
             const uint32_t per_cu = (uint32_t)pwg_per_cu((int)p->integrator);
-            pwg = plan_pwg_lds(ctx, kp.ks.sc, pwg_waves_n, per_cu, is_path);
+            pwg = plan_pwg_lds(ctx, kp.ks.sc, pwg_waves_n, per_cu, hybrid);
             pwg_grid = std::min((uint32_t)ctx->cu_count * per_cu, (grid_cap + pwg_waves_n - 1) / pwg_waves_n);   // small frames: no idle workgroups
         }
         if (!pwg) {
             const uint32_t waves = is_path ? (strip ? TRC_STRIP_PATH_WAVES : TRC_PATH_WAVES_GLOBAL)
                                  : p->integrator == TRC_INTEGRATOR_MIS ? (strip ? 4 : TRC_MIS_WAVES) : (strip ? 3 : TRC_VOLUME_WAVES);
-            plan_launch_lds(ctx, kp.ks.sc, waves, is_path);
+            plan_launch_lds(ctx, kp.ks.sc, waves, hybrid);
         }
         const size_t rows = kp.ks.sc.stack_depth - kp.ks.sc.stack_lds;
         const size_t need = rows * kBlock * sizeof(uint32_t) * (pwg ? (size_t)pwg_grid * pwg_waves_n : (size_t)grid_cap);   // rows per wavefront

@@ -88,6 +88,7 @@ __device__ __forceinline__ SceneRef make_scene_ref(const DScene& sc, const uint3
     S.off_tripos = sc.off_tripos; S.off_triattr = sc.off_triattr;
     S.n_lds_nodes = sc.n_lds_nodes;
     S.stack_lds = sc.stack_lds;
+    S.stack_cap = sc.stack_depth;
     S.ovf = nullptr;
     return S;
 }

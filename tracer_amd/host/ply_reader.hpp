@@ -168,7 +168,7 @@ inline bool read_ply(const std::string& path, PlyMesh& out) {
             for (size_t r = 0; r < e.count; ++r) {
                 for (size_t k = 0; k < e.props.size(); ++k) {
                     const Property& p = e.props[k];
-                    if (p.list) { const double n = c.scalar(p.count_type); for (double j = 0; j < n && c.ok; ++j) c.scalar(p.type); row[k] = 0; }
+                    if (p.list) { const double n = c.scalar(p.count_type); if (!c.ok || !(n >= 0 && n <= 1e6)) return false; for (double j = 0; j < n && c.ok; ++j) c.scalar(p.type); row[k] = 0; }
                     else row[k] = c.scalar(p.type);
                 }
                 if (!c.ok) return false;
@@ -190,10 +190,16 @@ inline bool read_ply(const std::string& path, PlyMesh& out) {
                     const Property& p = e.props[k];
                     if (!p.list) { c.scalar(p.type); continue; }
                     const double n = c.scalar(p.count_type);
-                    if (!c.ok || n < 0 || n > 1e6) return false;
+                    if (!c.ok || !(n >= 0 && n <= 1e6)) return false;
                     if ((int)k != il) { for (double j = 0; j < n && c.ok; ++j) c.scalar(p.type); continue; }
                     poly.clear();
-                    for (double j = 0; j < n && c.ok; ++j) poly.push_back((int64_t)c.scalar(p.type));
+                    // the index is range-checked as a double BEFORE the cast: a float-typed list (or ascii "nan" / "1e300")
+                    // converted out of range is undefined behaviour, not merely a bad index
+                    for (double j = 0; j < n && c.ok; ++j) {
+                        const double v = c.scalar(p.type);
+                        if (!(v >= 0 && v < (double)n_vertices)) return false;
+                        poly.push_back((int64_t)v);
+                    }
                 }
                 if (!c.ok) return false;
                 for (int64_t v : poly) if (v < 0 || (size_t)v >= n_vertices) return false;
@@ -207,7 +213,7 @@ inline bool read_ply(const std::string& path, PlyMesh& out) {
             if (e.count > data.size()) return false;
             for (size_t r = 0; r < e.count && c.ok; ++r)
                 for (const Property& p : e.props) {
-                    if (p.list) { const double n = c.scalar(p.count_type); if (n < 0 || n > 1e6) return false; for (double j = 0; j < n && c.ok; ++j) c.scalar(p.type); }
+                    if (p.list) { const double n = c.scalar(p.count_type); if (!c.ok || !(n >= 0 && n <= 1e6)) return false; for (double j = 0; j < n && c.ok; ++j) c.scalar(p.type); }
                     else c.scalar(p.type);
                 }
             if (!c.ok) return false;
