@@ -57,12 +57,15 @@ def test_sixteenths_where_wavefront_slots_are_idle(gpu, cornell_spheres):
     gpu.upload_scene(cornell_spheres.view); gpu.set_camera(cam); gpu.set_environment((0.2, 0.3, 0.4)); gpu.resize(W, H)
     gpu.debug_set("no_split", 0)
     plain = _launch(gpu, 9, spp=spp, small_blocks=False, fixed_order=True)
-    gpu.debug_set("no_split", 0)
-    deep = []
-    for k in range(7):
-        r = _launch(gpu, 9, spp=spp)
-        deep.append(_launch.sixteenths)
-        assert _same(r, plain), k
+    gpu.debug_set("no_cold_probe", 1)               # launch 1 as ONE cold launch (not head + rest: test_first_launch_head_and_rest)
+    try:
+        deep = []
+        for k in range(7):
+            r = _launch(gpu, 9, spp=spp)
+            deep.append(_launch.sixteenths)
+            assert _same(r, plain), k
+    finally:
+        gpu.debug_set("no_cold_probe", 0)
     assert deep[0] == 0 and max(deep) > 0, deep       # launch 1 is all quarters; sixteenths need a measured quarter first
     ref, st = po.render(cornell_spheres.view, cam, W, H, host.fill_rng(9, W, H), spp=spp, env=(0.2, 0.3, 0.4))
     assert st.rays == plain[2] and np.array_equal(plain[0].view(np.uint32), ref.view(np.uint32))
@@ -81,6 +84,27 @@ def test_quarters_on_a_tree_read_from_memory(gpu, integrator):
     for r in runs:
         assert _same(r, plain)
     assert runs[0][3] == 0 and max(r[3] for r in runs[1:]) > 0, [r[3] for r in runs]
+
+
+@pytest.mark.parametrize("integrator,mesh", [(abi.INTEGRATOR_PATH, False), (abi.INTEGRATOR_PATH, True), (abi.INTEGRATOR_MIS, True)])
+def test_first_launch_head_and_rest(gpu, cornell_spheres, integrator, mesh):
+    """The first launch of a block list has no durations to order or split by; trc_render runs it as a head of 8 samples (cold)
+    and the rest ordered and planned by the head's durations.  A pixel's samples are one chain through its RNG texel, so the
+    frame, the RNG texture, the ray count and the number of launches reported are those of one plain launch -- for a whole
+    frame and for a rank's share, with a frame counter that does not start at 0; knob no_cold_probe gives the single launch."""
+    W, H, spp = 640, 360, 20
+    scene = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.golden("teapot")) if mesh else cornell_spheres
+    for nranks, rank in ((1, 0), (4, 3)):
+        gpu.upload_scene(scene.view); gpu.set_camera(host.prepare_camera(W, H)); gpu.set_environment((0.2, 0.3, 0.4)); gpu.resize(W, H)
+        kw = dict(spp=spp, integrator=integrator, frame0=5, tile_rank=rank, tile_nranks=nranks)
+        gpu.debug_set("no_cold_probe", 1)
+        plain = _launch(gpu, 21, small_blocks=False, fixed_order=True, **kw)
+        single = _launch(gpu, 21, **kw)
+        gpu.debug_set("no_cold_probe", 0)               # forgets the block costs: the next launch is a first one again
+        split = _launch(gpu, 21, **kw)
+        assert gpu.stats().launches == 1 and gpu.stats().paths * nranks >= W * H * spp * 0.9
+        again = _launch(gpu, 21, **kw)                   # a second launch: one pass, planned from the first
+        assert _same(single, plain) and _same(split, plain) and _same(again, plain)
 
 
 def test_the_plan_leaves_a_full_frame_alone(gpu, cornell_spheres):

@@ -170,7 +170,8 @@ __device__ __forceinline__ void render_block(const KRender& kp, const DScene& sc
         reinterpret_cast<uint4*>(kp.fr.rng)[pix] = texel;
     }
 
-    if (lane == 0) kp.block_cost[canon] = (uint32_t)min((unsigned long long)((clock64() - t_start) >> 6), 0xFFFFFFull);
+    // per SAMPLE (cost_div = 4 x spp), so that launches of different lengths speak of the same quantity
+    if (lane == 0) kp.block_cost[canon] = (uint32_t)min((unsigned long long)(clock64() - t_start) / kp.cost_div, 0xFFFFFFull);
 }
 
 // kernelPathTracing, Render.metal:495-558.  One lane per pixel, one one-wavefront workgroup per 8x8 pixel block
@@ -435,7 +436,7 @@ __global__ void __launch_bounds__(kBlock, INTEGRATOR == TRC_INTEGRATOR_VOLUME ? 
     }
     uint32_t r_paths = wave_sum(n_paths), r_rays = wave_sum(n_rays), r_shaded = wave_sum(n_shaded);
     if (lane == 0) {
-        kp.block_cost[canon] = (uint32_t)min((unsigned long long)((clock64() - t_start) >> 6), 0xFFFFFFull);
+        kp.block_cost[canon] = (uint32_t)min((unsigned long long)(clock64() - t_start) / kp.cost_div, 0xFFFFFFull);
         unsigned long long* const stats = stat_row(kp.stats, blockIdx.x);
         atomicAdd(&stats[kStatPaths], (unsigned long long)r_paths);
         atomicAdd(&stats[kStatRays], (unsigned long long)r_rays);
@@ -516,13 +517,15 @@ __device__ __forceinline__ uint32_t slowest_part(const uint32_t* cost, const uin
 // 20.9 -> 20.4 ms, its shares of 2 / 4 / 8 ranks 12.3 -> 11.1, 8.5 -> 7.3, 5.95 -> 5.6 ms (knob no_cost_filter switches it off).
 // One thread per block filters the slots its last launch wrote (the block, its quarters or their sixteenths).
 __global__ void __launch_bounds__(256) k_filter_costs(const uint32_t* cost, const uint32_t* split, const uint32_t* qsplit, uint32_t stride, uint32_t n,
-                                                      uint32_t* filt) {
+                                                      uint32_t* filt, uint32_t* whole, const bool fresh) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
+    // fresh: what the filter holds are the durations of a cold HEAD (8 samples, row-major, trc_render) -- good enough to order
+    // and plan the launch that followed, but no "shortest duration seen lately" of a settled launch: that launch's replace them
     auto slot = [&](uint32_t k) {
         const size_t at = (size_t)i * stride + k;
         const uint32_t f = filt[at], c = cost[at];
-        filt[at] = f ? min(f + (f >> 6) + 1u, c) : c;
+        filt[at] = (f && !fresh) ? min(f + (f >> 6) + 1u, c) : c;
     };
     if (stride != kCostSlots || !split[i]) { slot(0u); return; }
 #pragma unroll
@@ -530,6 +533,12 @@ __global__ void __launch_bounds__(256) k_filter_costs(const uint32_t* cost, cons
         if (qsplit[4u * i + q]) { for (uint32_t s4 = 0; s4 < 4u; ++s4) slot(4u + 4u * q + s4); }
         else slot(q);
     }
+    // What the block cost when it last ran WHOLE ranks it for as long as it runs in parts (a value measured under the same
+    // conditions as its unsplit neighbours': re-estimating it from the parts every launch made the plan settle elsewhere,
+    // config 3 329 -> 344-366 ms).  It only follows the parts DOWN when they say the block is no longer what it was (a camera
+    // or a scene that moved on): a quarter lasts 0.8-0.9 of its block, so parts below half of `whole` are another picture's.
+    const uint32_t w = whole[i];
+    if (w) whole[i] = max(1u, min(w, (uint32_t)((float)slowest_part(filt, qsplit, i) * 2.0f)));
 }
 __global__ void __launch_bounds__(256) k_order_keys(const uint32_t* cost, const uint32_t* split, const uint32_t* whole, const uint32_t* qsplit,
                                                     uint32_t stride, uint32_t n, uint32_t* keys, uint32_t* vals) {
@@ -1291,6 +1300,8 @@ trc_status trc_create(int device, trc_ctx** out) {
         ctx->knobs.no_pwg = env_int("TRC_NO_PWG", true);
         ctx->knobs.sppm_serial_camera = env_int("TRC_SPPM_SERIAL_CAMERA", true);
         ctx->knobs.no_cost_filter = env_int("TRC_NO_COST_FILTER", true);
+        ctx->knobs.no_cold_probe = env_int("TRC_NO_COLD_PROBE", true);
+        ctx->knobs.probe_spp = env_int("TRC_PROBE_SPP", false);
     }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void**)&ctx->d_stats, sizeof(unsigned long long) * kStatRows * kStatRowStride) != hipSuccess ||
@@ -1347,6 +1358,7 @@ trc_status trc_upload_scene(trc_ctx* ctx, const trc_scene* scene) {
     ctx->lds_scene = ks.sc.n_lds_nodes == ks.sc.n_nodes;      // whole tree staged in LDS
     ctx->lds_prefix_ok = true;
     ctx->has_scene = true;
+    ctx->cost_valid = false; ctx->d_last_order = nullptr;      // another scene: the recorded block costs say nothing about it
     return TRC_OK;
 }
 
@@ -1388,11 +1400,14 @@ trc_status trc_upload_density(trc_ctx* ctx, const trc_GridDensityInfo* info, con
 
 trc_status trc_set_camera(trc_ctx* ctx, const trc_Camera* c) {
     if (!ctx || !c) return TRC_ERR_INVALID_ARG;
+    const DCamera before = ctx->cam;
     DCamera& d = ctx->cam;
     const trc_float3* src[6] = {&c->lookFrom, &c->u, &c->v, &c->vertical, &c->horizontal, &c->cornerLowLeft};
     float* dst[6] = {d.lookFrom, d.u, d.v, d.vertical, d.horizontal, d.cornerLowLeft};
     for (int i = 0; i < 6; ++i) { dst[i][0] = src[i]->x; dst[i][1] = src[i]->y; dst[i][2] = src[i]->z; }
     d.lenRadius = c->lenRadius;
+    // another view: the blocks' recorded costs are another picture's (the next launch measures afresh: trc_render's head)
+    if (!ctx->has_camera || std::memcmp(&before, &d, sizeof d) != 0) { ctx->cost_valid = false; ctx->d_last_order = nullptr; }
     ctx->has_camera = true;
     return TRC_OK;
 }
@@ -1510,7 +1525,22 @@ trc_status trc_tonemap(trc_ctx* ctx, uint8_t* rgba8, float* exposure_out) {
     return st;
 }
 
-trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
+// One pass of kernelPathTracing over the caller's share of the frame.  `inner`: this pass is one half of a first launch that
+// trc_render split in two (below).
+static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner);
+
+// First launch of a block list (nothing is known about its blocks: new context, frame size, share, scene, camera or
+// integrator): the launch order and the split plan come from the durations of the previous launch, and without them a launch
+// runs row-major with every block whole -- config 2 +15 %, the mesh scenes +55-65 % (their heavy blocks start last and the
+// launch ends on them; profiles/r04/cold_start.txt).  A pixel's samples are a chain through its RNG texel, so `spp` samples
+// in one launch == h samples followed by spp - h (tested: test_spp_fusion_equals_per_frame_launches): the first launch is run
+// as a HEAD of kColdHeadSpp samples, cold, and the REST ordered and planned by the head's per-block durations (costs are kept
+// per sample, KRender::cost_div, so launches of different lengths speak of the same quantity).  No probe work is thrown
+// away, no pixel changes; the only price is the head's own short tail.  Knob no_cold_probe switches it off.
+constexpr uint32_t kColdHeadSpp = 8;           // >= 8: the head must run the same kernel and block list as the rest (k_render_strip below)
+trc_status trc_render(trc_ctx* ctx, const trc_params* p) { return render_pass(ctx, p, false); }
+
+static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
     if (!ctx || !p) return TRC_ERR_INVALID_ARG;
     if (!ctx->has_scene) return fail(ctx, TRC_ERR_NO_SCENE, "trc_render before trc_upload_scene");
     if (!ctx->d_accum) return fail(ctx, TRC_ERR_NO_FRAME, "trc_render before trc_resize");
@@ -1559,6 +1589,7 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
     kp.blk_shift = blk_shift;
     kp.stats = ctx->d_stats;
     kp.block_cost = ctx->d_block_cost;
+    kp.cost_div = std::max(1u, 4u * std::min(p->spp, 1u << 28));
     kp.order = nullptr;
     // launches of few samples per pixel give every wavefront a strip of consecutive blocks (k_render_strip); the unit of the
     // adaptive order is then the strip, and durations recorded for another strip length say nothing
@@ -1584,6 +1615,21 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
     if (ctx->cost_strip != kp.strip || ctx->cost_quarters != quarters_ok) {
         ctx->cost_valid = false; ctx->cost_strip = kp.strip; ctx->cost_quarters = quarters_ok; ctx->d_last_order = nullptr;
     }
+    if (ctx->cost_integrator != p->integrator) { ctx->cost_valid = false; ctx->cost_integrator = p->integrator; ctx->d_last_order = nullptr; }
+    {
+        const uint32_t head = std::max(kColdHeadSpp, (uint32_t)ctx->knobs.probe_spp);
+        if (!inner && !ctx->cost_valid && !stats && !ctx->knobs.no_cold_probe && !(p->flags & TRC_FLAG_FIXED_ORDER) && kp.strip == 1 &&
+            p->spp >= 2u * head) {
+            trc_params h = *p, r = *p;
+            h.spp = head;
+            r.spp = p->spp - head; r.frame0 = p->frame0 + head;
+            trc_status st = render_pass(ctx, &h, true);
+            if (st != TRC_OK) return st;
+            ctx->launches--;                       // one trc_render call = one launch in trc_stats
+            ctx->cost_head_age = 1;
+            return render_pass(ctx, &r, true);
+        }
+    }
     const bool may_split = quarters_ok && !stats && p->spp >= 8 && !ctx->knobs.no_split &&
                            !(p->flags & (TRC_FLAG_LARGE_BLOCKS | TRC_FLAG_FIXED_ORDER));
     // wavefront slots of the kernel this launch runs (the plan's model; the launch bounds of k_render / k_render_pwg)
@@ -1600,7 +1646,7 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
         // the costs the order and the plan work on: the shortest durations seen lately (k_filter_costs), or the last launch's
         const bool filtered = !ctx->knobs.no_cost_filter;
         uint32_t* costs = filtered ? ctx->d_cost_est : ctx->d_block_cost;
-        if (filtered) hipLaunchKernelGGL(k_filter_costs, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_block_cost, ctx->d_split, ctx->d_qsplit, kp.cost_stride, n, costs);
+        if (filtered) hipLaunchKernelGGL(k_filter_costs, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_block_cost, ctx->d_split, ctx->d_qsplit, kp.cost_stride, n, costs, ctx->d_whole, ctx->cost_head_age == 2);
         hipLaunchKernelGGL(k_order_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, costs, ctx->d_split, ctx->d_whole, ctx->d_qsplit, kp.cost_stride, n,
                            ctx->d_order_keys[0], ctx->d_order_vals[0]);
         int res = 0;
@@ -1641,6 +1687,7 @@ trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
     }
     ctx->split_live = planned;
     if (!ctx->cost_valid) HIP_TRY(ctx, hipMemsetAsync(ctx->d_cost_est, 0, (size_t)ctx->n_tiles * 4 * kCostSlots, ctx->stream));
+    ctx->cost_head_age = (ctx->cost_valid && ctx->cost_head_age == 1) ? 2 : 0;     // head -> the launch on its costs -> settled
     ctx->cost_valid = true;
     kp.density = ctx->d_density;
     kp.dinfo = ctx->dinfo;
@@ -2004,7 +2051,8 @@ trc_status trc_debug_set(trc_ctx* ctx, const char* knob, int value) {
     int* slot = k == "no_lds_fit" ? &ctx->knobs.no_lds_fit : k == "stack_lds_levels" ? &ctx->knobs.stack_lds_levels
               : k == "strip_len" ? &ctx->knobs.strip_len : k == "no_pwg" ? &ctx->knobs.no_pwg
               : k == "sppm_serial_camera" ? &ctx->knobs.sppm_serial_camera : k == "sppm_timing" ? &ctx->knobs.sppm_timing
-              : k == "force_blk_shift" ? &ctx->knobs.force_blk_shift : k == "no_split" ? &ctx->knobs.no_split : k == "no_cost_filter" ? &ctx->knobs.no_cost_filter : nullptr;
+              : k == "force_blk_shift" ? &ctx->knobs.force_blk_shift : k == "no_split" ? &ctx->knobs.no_split : k == "no_cost_filter" ? &ctx->knobs.no_cost_filter
+              : k == "no_cold_probe" ? &ctx->knobs.no_cold_probe : k == "probe_spp" ? &ctx->knobs.probe_spp : nullptr;
     if (!slot) return fail(ctx, TRC_ERR_INVALID_ARG, "trc_debug_set: unknown knob " + k);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // a launch in flight keeps the plan it was made with

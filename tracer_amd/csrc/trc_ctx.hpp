@@ -49,6 +49,7 @@ struct KRender {
     const uint32_t* order;              // launch list: order[slot] = index into `tiles` | part code << 27 (null: identity; codes
                                         // above: cost-adaptive block size, k_plan_split).  k_render_strip: strip indices, no codes.
     const uint32_t* n_launch;           // device word: entries of `order` in this launch (null: n_tiles); workgroups past it exit
+    uint32_t cost_div;                  // a block's cost = its wavefront's duration in shader clocks / cost_div (= 4 x spp: per sample)
     uint32_t* block_cost;               // duration of each block in this launch (the next launch's sort key): slot kCostSlots * tile +
                                         // max(code - 1, 0) when the list may be split (cost_stride = kCostSlots), else slot `tile`
     uint32_t cost_stride;
@@ -168,6 +169,8 @@ struct trc_ctx {
     bool split_live = false;            // d_split holds flags of the last launch's plan (else all zero)
     bool cost_quarters = false;         // d_block_cost / d_split describe a launch made with cost_stride 4
     bool cost_valid = false; uint32_t cost_strip = 1;
+    int cost_head_age = 0;                    // 1: the costs are a cold head's (trc_render), 2: the launch after it ran on them
+    uint32_t cost_integrator = 0xFFFFFFFFu;   // integrator the recorded costs belong to
     const uint32_t* d_last_order = nullptr; uint32_t order_age = 0;     // most recent sorted order (short launches reuse it)
     int cu_count = 0;
     uint32_t n_tiles = 0, tiles_nranks = 0, tiles_rank = 0, tiles_view_height = 0, tiles_blk_shift = 3;
@@ -202,7 +205,7 @@ struct trc_ctx {
 
     // A/B and test knobs, per context: defaults from the environment at trc_create (TRC_NO_LDS_FIT, TRC_STACK_LDS_LEVELS,
     // TRC_STRIP_LEN, TRC_NO_PWG, TRC_SPPM_SERIAL_CAMERA), changed through trc_debug_set
-    struct Knobs { int no_lds_fit = 0, stack_lds_levels = 0, strip_len = 0, no_pwg = 0, sppm_serial_camera = 0, sppm_timing = 0, force_blk_shift = 0, no_split = 0, no_cost_filter = 0; } knobs;
+    struct Knobs { int no_lds_fit = 0, stack_lds_levels = 0, strip_len = 0, no_pwg = 0, sppm_serial_camera = 0, sppm_timing = 0, force_blk_shift = 0, no_split = 0, no_cost_filter = 0, no_cold_probe = 0, probe_spp = 0; } knobs;
     // k_render_pwg instantiations that were granted > 64 KB of dynamic LDS on THIS context's device (bit = integrator * 2 +
     // sobol): hipFuncSetAttribute applies to the current device only, so the grant is per context, not per process
     uint32_t pwg_lds_granted = 0;

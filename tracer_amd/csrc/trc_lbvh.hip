@@ -641,6 +641,7 @@ trc_status trc_upload_scene_lbvh(trc_ctx* ctx, const trc_scene* s) {
     ctx->lbvh_height = height;
     ctx->lbvh_build_ms = ms;
     ctx->has_scene = true;
+    ctx->cost_valid = false; ctx->d_last_order = nullptr;      // another scene: the recorded block costs say nothing about it
     return TRC_OK;
 }
 
