@@ -13,7 +13,9 @@ RCCL reduce of the accumulation buffer to rank 0.  Inputs are resident in HBM be
 
 N > 1 is launched either by the driver (python -m torch.distributed.run ... bench.py --gpus N: RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_* in the environment) or by bench.py itself: with WORLD_SIZE unset, `--gpus N` spawns N fresh
-child processes of this script (before anything touches the GPU) and relays rank 0's JSON line.
+child processes of this script (before anything touches the GPU) and relays rank 0's JSON line.  Either way the ranks
+find each other, synchronise and reduce their timings over plain TCP sockets (tracer_amd/socket_group.py): bench.py
+imports no PyTorch at any N -- the frame is composed by the library's own RCCL reduce.
 
 Two multi-GPU workloads, BOTH measured in every N > 1 run (the primary one fills the top-level fields, the other
 one is reported under "other_scaling"):
@@ -289,10 +291,10 @@ def main(argv=None):
     ap.add_argument("--no-fast-math", action="store_true",
                     help="skip the fast_math_variant leg (profiling runs: both builds name their kernels alike)")
     ap.add_argument("--force-group", action="store_true",
-                    help="exercise the gloo rendezvous + RCCL compose path even with one rank (plumbing check)")
+                    help="exercise the rendezvous + RCCL compose path even with one rank (plumbing check)")
     ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)     # test hook: this rank exits with 3 at once
     ap.add_argument("--rendezvous-only", action="store_true",
-                    help="ranks only rendezvous (gloo), exchange their ranks and print the line skeleton: the launcher "
+                    help="ranks only rendezvous (sockets), exchange their ranks and print the line skeleton: the launcher "
                          "/ relay / reduction plumbing without a GPU (tests/test_bench_helpers.py)")
     args = ap.parse_args(argv)
 
@@ -307,52 +309,41 @@ def main(argv=None):
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     grouped = world > 1 or args.force_group
-    dist = torch = None
+    group = None
     if grouped:
-        import torch  # plumbing only: rendezvous / barrier / max-over-ranks (N = 1 runs without it)
-        import torch.distributed as dist
+        from tracer_amd.socket_group import SocketGroup      # rendezvous / barrier / max-over-ranks over TCP: no PyTorch
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        _with_c_stdout_on_stderr(lambda: dist.init_process_group("gloo", rank=rank, world_size=world))
+        group = SocketGroup.from_env()
 
     def reduce_scalar(x, op):
-        if dist is None:
-            return x
-        t = torch.tensor([x], dtype=torch.float64)
-        dist.all_reduce(t, op=getattr(dist.ReduceOp, op))
-        return float(t.item())
+        return x if group is None else group.allreduce_scalar(x, op)
 
     def gather_list(x):
-        if dist is None:
-            return [x]
-        out = [None] * world
-        dist.all_gather_object(out, x)
-        return out
+        return [x] if group is None else group.gather(x)
 
     if args.rendezvous_only:
         ranks = gather_list(rank)
         total = reduce_scalar(float(rank + 1), "SUM")
         if rank == 0:
             print(json.dumps({"rendezvous_only": True, "n_gpus": world, "ranks": ranks, "sum": total,
-                              "scaling": args.scaling}), flush=True)
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
+                              "scaling": args.scaling, "torch_imported": "torch" in sys.modules}), flush=True)
+        if group is not None:
+            group.barrier()
+            group.close()
         return
 
     from tracer_amd import abi, host
     from tracer_amd.device import Tracer, group_unique_id
 
     # ranks > GPUs (plumbing run on a 1-GPU box): the ranks share the GPUs, and since RCCL refuses two ranks on one
-    # device the compose goes through the collectives table of trc_group_set_collectives (host-staged, gloo) -- the same
+    # device the compose goes through the collectives table of trc_group_set_collectives (host-staged, sockets) -- the same
     # reduce program, the same pipelined two-accumulator compose, every other part of the N-rank path as usual.  The line
     # says "plumbing": ranks time-slicing one GPU measure nothing.
     n_dev = visible_gpus() or 1
     no_rccl = os.environ.get("TRC_BENCH_NO_RCCL") == "1" or (world > n_dev)
     plumbing = grouped and no_rccl
     device = local_rank % n_dev
-    if torch is not None and torch.cuda.is_available():
-        torch.cuda.set_device(device)          # barrier()'s torch.cuda.synchronize() must not touch GPU 0 from every rank
     scene = host.HostScene(abi.SCENE_CORNELL_SPHERES)
     cam = host.prepare_camera(W, H)
     trc = Tracer(device)
@@ -361,30 +352,27 @@ def main(argv=None):
     trc.set_environment((0.0, 0.0, 0.0))
     use_rccl = grouped and not no_rccl
     if use_rccl:
-        ids = [group_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
+        uid = group.broadcast(group_unique_id() if rank == 0 else None)
         trc.resize(W, H)
 
         def init_comm():
-            trc.group_init(ids[0], world, rank)
+            trc.group_init(uid, world, rank)
             trc.clear_accum()
             trc.group_reduce_accum(0)        # first collective: RCCL finishes its lazy set-up here
             trc.synchronize()
         # RCCL prints a version banner through C stdio on fd 1; keep stdout clean for the single JSON line
         _with_c_stdout_on_stderr(init_comm)
     elif plumbing:
-        from tracer_amd.gloo_collectives import GlooCollectives
+        from tracer_amd.socket_group import SocketCollectives
         trc.resize(W, H)
-        coll = GlooCollectives()
+        coll = SocketCollectives(group)
         trc.set_collectives(coll, world, rank)
     composing = use_rccl or plumbing
 
     def barrier():
-        trc.synchronize()
-        if torch is not None and torch.cuda.is_available():
-            torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        trc.synchronize()                      # hipStreamSynchronize on the render and the compose stream of this rank's device
+        if group is not None:
+            group.barrier()
 
     def measure(mode, steps, warmup):
         """K timed steps of one workload; returns the rank-0 view of it (dict) -- every rank must call it."""
@@ -400,6 +388,29 @@ def main(argv=None):
                        tile_nranks=world, collect_stats=collect_stats, view_height=H)
             if composing:
                 trc.group_reduce_accum_async(0)   # overlaps with the next step's render (second accumulator + stream)
+
+        # COLD: the first production launch of this block list on this context -- no durations of a previous launch to order
+        # or split by.  trc_render runs it as an 8-sample head + the rest planned from the head; the same
+        # launch as ONE cold pass (knob no_cold_probe) beside it.  What a host that renders one frame, resizes or moves the
+        # camera gets; the headline below is the settled state of a progressive renderer.
+        def first_launch(no_probe):
+            trc.debug_set("no_cold_probe", 1 if no_probe else 0)      # also forgets what the context knows about the blocks
+            barrier()
+            trc.reset_stats()
+            t = time.perf_counter()
+            step()
+            barrier()
+            wall = (time.perf_counter() - t) * 1e3
+            s0 = trc.stats()
+            return {"first_launch_ms": round(reduce_scalar(wall, "MAX"), 3), "first_launch_kernel_ms": round(s0.kernel_ms, 3),
+                    "value": round(reduce_scalar(float(s0.rays), "SUM") / reduce_scalar(wall, "MAX") / 1e3, 2)}
+        cold_single = first_launch(True)
+        cold = first_launch(False)
+        cold.update({"unit": "Mrays/s", "settle_launches": 0,
+                     "single_cold_pass_ms": cold_single["first_launch_ms"], "single_cold_pass_kernel_ms": cold_single["first_launch_kernel_ms"],
+                     "what": "first launch of the block list (fresh costs): 8-sample head + rest planned from it, wall ms incl. seed + "
+                             "launch-list kernels; single_cold_pass = the same launch as one unordered pass (knob no_cold_probe)"})
+        trc.debug_set("no_cold_probe", 0)
 
         # exact algorithmic work of ONE step on this rank (instrumented kernel, untimed)
         trc.reset_stats()
@@ -428,6 +439,7 @@ def main(argv=None):
         st = trc.stats()
         assert st.rays == rays_per_launch * steps, "steps are not identical work"
         kernel_ms = st.kernel_ms / max(1, st.launches)          # HIP events on the render stream
+        shape = trc.launch_shape()                               # the two bounds no schedule of this rank's share can beat
 
         # the same K steps with a DIFFERENT seed each (a progressive renderer never replays a frame: the adaptive
         # launch order then works from the previous frame's costs, not from this frame's own)
@@ -458,7 +470,12 @@ def main(argv=None):
         rays_vary_total = reduce_scalar(float(st_vary.rays), "SUM")
         per_rank = gather_list({"rank": rank, "kernel_ms": round(kernel_ms, 3), "kernel_ms_vary_seed": round(kernel_ms_vary, 3),
                                 "compose_ms": None if compose_ms is None else round(compose_ms, 3),
-                                "rays_per_step": int(st.rays // steps), "device": device})
+                                "rays_per_step": int(st.rays // steps), "device": device,
+                                # a pixel's samples are one chain: the launch cannot end before its slowest wavefront-sized item
+                                # (block or part), nor before the items' summed durations over the GPU's wavefront slots
+                                "longest_chain_ms": round(shape["longest_entry_ms"], 3),
+                                "work_over_slots_ms": round(shape["work_over_slots_ms"], 3),
+                                "launch_entries": shape["entries"], "wave_slots": shape["wave_slots"]})
         name = "Mrays/s at 1920x1080x64spp"
         if stacked:
             name = f"Mrays/s over {world} stacked 1920x1080x64spp views, one view's worth of tiles per GPU (weak scaling)"
@@ -470,7 +487,7 @@ def main(argv=None):
             "vary_seed": {"value": round(rays_vary_total / dt_vary_max / 1e6, 2),
                           "ms_per_step": round(dt_vary_max / steps * 1e3, 3), "kernel_ms": round(kernel_ms_vary, 3),
                           "what": "the same K steps with a different RNG seed per step (frame k's block costs order frame k+1)"},
-            "per_rank": per_rank, "kernel_ms": kernel_ms, "bytes_per_launch": bytes_per_launch,
+            "per_rank": per_rank, "kernel_ms": kernel_ms, "bytes_per_launch": bytes_per_launch, "cold": cold,
             "rays_per_launch": rays_per_launch,
         }
 
@@ -490,7 +507,7 @@ def main(argv=None):
             compose = (f"ncclReduce(sum) of the {W}x{FH} RGBA32F frame to rank 0 on a second stream, overlapped with the "
                        f"next step" if use_rccl else
                        f"PLUMBING RUN, NOT A MEASUREMENT: {world} ranks share {n_dev} GPU(s); reduce(sum) of the {W}x{FH} frame "
-                       f"through trc_group_set_collectives (host-staged, gloo) because RCCL refuses two ranks on one device")
+                       f"through trc_group_set_collectives (host-staged, TCP sockets) because RCCL refuses two ranks on one device")
         line = {
             "metric": primary["metric"], "value": primary["value"], "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -506,6 +523,9 @@ def main(argv=None):
                        "tiles": f"16x16 px, owner (tx+ty)%{world}", "device": info["name"], "compose": compose,
                        "settle_launches": SETTLE_LAUNCHES},
             "vary_seed": primary["vary_seed"],
+            "cold": primary["cold"], "first_launch_ms": primary["cold"]["first_launch_ms"],
+            # parity-imposed bounds of the timed launches on rank 0 (every rank's under per_rank at N > 1)
+            "launch_bounds": {k: primary["per_rank"][0][k] for k in ("longest_chain_ms", "work_over_slots_ms", "launch_entries", "wave_slots")},
             # the BINDING bound of the dominant kernel: VALU issue (PMC counters of this library, profiles/rNN/pmc_config2.json)
             "roofline": roof,
             # the north_star's figure: bytes the REFERENCE's access pattern would move for this work over the
@@ -523,7 +543,7 @@ def main(argv=None):
             line["per_rank"] = primary["per_rank"]
             if other is not None:
                 line["other_scaling"] = {k: other[k] for k in ("mode", "metric", "value", "ms_per_step", "rays_per_step",
-                                                              "frame", "vary_seed", "per_rank")}
+                                                              "frame", "vary_seed", "cold", "per_rank")}
         if world == 1 and not args.no_fast_math:
             line["fast_math_variant"] = fast_math_leg(scene, cam, args.steps)
         if not args.no_cpu_baseline and world == 1:      # CPU baselines: rank 0 at N = 1 only
@@ -536,8 +556,8 @@ def main(argv=None):
         if grouped:
             if composing:
                 trc.group_finalize()
-            dist.barrier()
-            dist.destroy_process_group()
+            group.barrier()
+            group.close()
         trc.close()
     _with_c_stdout_on_stderr(teardown)
     os.dup2(2, 1)       # anything native code still prints at exit goes to stderr, after the JSON line

@@ -33,8 +33,10 @@ extern "C" {
 /* 2: trc_trace_rays' last argument became a bit set (TRC_TRACE_*: 2 now means the production closest-hit walk, it used
  *    to mean any-hit); trc_build_flavor, trc_sppm_hash_cells, trc_host_scene_load_pbrt, trc_host_mesh_from_arrays added
  * 3: trc_group_set_collectives, trc_debug_set, trc_debug_block_costs; trc_pbrt_info / trc_pbrt_shape grew (textures,
- *    plymesh / disk / cylinder); trc_host_mesh_load_ply, trc_host_load_hdr, trc_div_by_test */
-#define TRC_ABI_VERSION 3
+ *    plymesh / disk / cylinder); trc_host_mesh_load_ply, trc_host_load_hdr, trc_div_by_test
+ * 4: trc_debug_launch_shape; trc_debug_block_costs reports durations per SAMPLE (shader clocks / (4 spp)); knobs
+ *    no_cold_probe / probe_spp (the first launch of a block list runs as an 8-sample head + the rest, trc_render) */
+#define TRC_ABI_VERSION 4
 
 /* ------------------------------------------------------------------ */
 /* vector / matrix PODs (Apple simd layout)                            */
@@ -434,10 +436,24 @@ trc_status trc_reset_stats(trc_ctx* ctx);
  * 10 Beckmann lobe evaluation (Plastic specular + Glass), 11 path end */
 trc_status trc_debug_profile(trc_ctx* ctx, uint64_t* out, uint32_t n_sites);
 /* developer diagnostic: the pixel blocks of the last trc_render (x | y << 16, in units of the block edge 1 << *blk_shift)
- * and the duration each one's wavefront measured (shader clocks / 64 -- the sort key of the adaptive launch order); with
+ * and the duration each one's wavefront measured per sample (shader clocks / (4 spp) -- the sort key of the adaptive launch order); with
  * strips (spp < 8) the costs are per strip; a block that ran in parts (four 4x4 quarters, some of them as four 2x2
  * sixteenths) reports its slowest part with bit 31 set, and bit 30 when it had sixteenths.  Any pointer may be NULL; at most `capacity` entries are written. */
 trc_status trc_debug_block_costs(trc_ctx* ctx, uint32_t* tiles, uint32_t* costs, uint32_t capacity, uint32_t* n_blocks, uint32_t* blk_shift);
+/* developer diagnostic: the two lower bounds of the last trc_render's kernel time that no schedule can beat.  A pixel's samples
+ * are one chain through its RNG texel (Render.metal:545-557), so a launch lasts at least as long as its slowest wavefront-sized
+ * item (a whole 8x8 block, or a 4x4 / 2x2 part of one) -- the bound a strong-scaled share of a frame runs into -- and at least
+ * the items' summed durations over the wavefront slots of the GPU.  Durations are the wavefronts' own measurements (shader
+ * clocks), converted with the device's nominal shader clock. */
+typedef struct trc_launch_shape {
+    uint32_t entries;             /* wavefront-sized items of the launch: whole blocks + parts */
+    uint32_t wave_slots;          /* wavefronts the GPU holds at once for the kernel that ran */
+    double   longest_entry_ms;    /* the slowest item */
+    double   sum_entries_ms;      /* all items: slot time */
+    double   work_over_slots_ms;  /* sum_entries_ms / wave_slots */
+    double   clock_mhz;           /* hipDeviceAttributeClockRate, used for the conversion */
+} trc_launch_shape;
+trc_status trc_debug_launch_shape(trc_ctx* ctx, trc_launch_shape* out);
 
 /* device info for the bench line */
 trc_status trc_device_info(trc_ctx* ctx, char* name, size_t name_len, int* cu_count, size_t* hbm_bytes);

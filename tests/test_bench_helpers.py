@@ -69,7 +69,8 @@ def test_pmc_summary_is_chosen_by_round_number(tmp_path, monkeypatch):
 
 def test_self_launch_spawns_the_ranks_and_relays_rank0(tmp_path):
     """`python bench.py --gpus 2` with WORLD_SIZE unset: bench.py starts the two ranks itself (fresh children with RANK /
-    LOCAL_RANK / WORLD_SIZE / MASTER_*), they rendezvous over gloo and rank 0's single JSON line comes back on stdout.
+    LOCAL_RANK / WORLD_SIZE / MASTER_*), they rendezvous over TCP sockets (tracer_amd/socket_group.py: no PyTorch in any
+    rank) and rank 0's single JSON line comes back on stdout.
     --rendezvous-only stops before the first GPU call, so this runs here; the rendering part of the same path runs in
     test_two_rank_bench_path_without_rccl on the GPU box."""
     import json, subprocess, sys
@@ -80,7 +81,23 @@ def test_self_launch_spawns_the_ranks_and_relays_rank0(tmp_path):
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, out.stdout
     line = json.loads(lines[0])
-    assert line == {"rendezvous_only": True, "n_gpus": 2, "ranks": [0, 1], "sum": 3.0, "scaling": "weak"}
+    assert line == {"rendezvous_only": True, "n_gpus": 2, "ranks": [0, 1], "sum": 3.0, "scaling": "weak", "torch_imported": False}
+
+
+def test_ranks_started_the_driver_s_way_rendezvous_without_torch():
+    """the driver starts N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...`: MASTER_PORT then belongs to torchrun's own store, and bench.py's ranks must meet
+    elsewhere (a port rank 0 publishes in a file keyed by MASTER_PORT and the common parent) -- without importing torch"""
+    import json, subprocess, sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                          "--master-port", "29519", os.path.join(ROOT, "bench.py"), "--gpus", "3", "--rendezvous-only"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    assert json.loads(lines[0]) == {"rendezvous_only": True, "n_gpus": 3, "ranks": [0, 1, 2], "sum": 6.0, "scaling": "strong",
+                                    "torch_imported": False}
 
 
 def test_self_launch_does_not_hang_when_a_rank_dies():
@@ -102,7 +119,7 @@ def test_gpu_count_probe_does_not_touch_hip():
 @pytest.mark.parametrize("launcher", ["self", "torchrun"])
 def test_two_rank_bench_path_on_one_gpu(launcher):
     """bench.py with two ranks sharing cuda:0 (more ranks than GPUs: the compose goes through trc_group_set_collectives
-    with the gloo table instead of RCCL, and the line is marked plumbing), started by bench.py itself and the way the driver
+    with the socket table instead of RCCL, and the line is marked plumbing), started by bench.py itself and the way the driver
     starts N > 1 (torch.distributed.run): rendezvous, BOTH workloads (the named frame tile-sharded = strong, stacked views =
     weak), tile ownership, the pipelined compose, max-over-ranks timing, one JSON line."""
     import json, subprocess, sys
@@ -130,3 +147,8 @@ def test_two_rank_bench_path_on_one_gpu(launcher):
     assert weak["rays_per_step"] > 4.3e8                                # two views' worth of rays
     assert line["plumbing"] is True and "PLUMBING" in line["config"]["compose"]
     assert all(r["compose_ms"] is not None for r in line["per_rank"])   # the reduce really ran (host-staged)
+    # the cold leg and the parity-imposed bounds ride along for every rank
+    assert line["cold"]["settle_launches"] == 0 and line["first_launch_ms"] == line["cold"]["first_launch_ms"] > 0
+    assert line["config"]["settle_launches"] == 8
+    for r in line["per_rank"]:
+        assert 0 < r["longest_chain_ms"] and 0 < r["work_over_slots_ms"] and r["launch_entries"] >= 32400 // 2

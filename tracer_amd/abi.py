@@ -7,7 +7,7 @@ Triangle,Texture,Material,Camera}.hh (see the header for file:line).
 """
 import ctypes as C
 
-TRC_ABI_VERSION = 3
+TRC_ABI_VERSION = 4
 TRC_TILE = 16
 TRC_MAX_BVH_DEPTH = 64
 TRC_UNIQUE_ID_BYTES = 128
@@ -181,6 +181,12 @@ class Hit(C.Structure):
                 ("n_descend", C.c_uint32), ("n_return", C.c_uint32), ("n_leaf", C.c_uint32)]
 
 
+class LaunchShape(C.Structure):
+    """trc_launch_shape"""
+    _fields_ = [("entries", C.c_uint32), ("wave_slots", C.c_uint32), ("longest_entry_ms", C.c_double),
+                ("sum_entries_ms", C.c_double), ("work_over_slots_ms", C.c_double), ("clock_mhz", C.c_double)]
+
+
 class Stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("shaded", C.c_uint64),
                 ("n_descend", C.c_uint64), ("n_return", C.c_uint64),
@@ -207,7 +213,7 @@ DEVICE_SYMBOLS = [
     "trc_render", "trc_synchronize", "trc_trace_rays", "trc_get_stats", "trc_reset_stats", "trc_debug_profile",
     "trc_sppm_init", "trc_sppm_frames", "trc_sppm_download", "trc_sppm_hash_cells",
     "trc_device_info", "trc_group_unique_id", "trc_group_init", "trc_group_reduce_accum", "trc_group_reduce_accum_async", "trc_group_allreduce_mean_accum", "trc_download_composed", "trc_group_finalize",
-    "trc_group_set_collectives", "trc_debug_set", "trc_debug_block_costs", "trc_div_by_test",
+    "trc_group_set_collectives", "trc_debug_set", "trc_debug_block_costs", "trc_debug_launch_shape", "trc_div_by_test",
 ]
 HOST_SYMBOLS = [
     "trc_host_build_node", "trc_host_build_tree", "trc_host_tree_depth", "trc_host_make_camera",

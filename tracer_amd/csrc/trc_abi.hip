@@ -1636,6 +1636,7 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
     const uint32_t waves_per_simd = p->integrator == TRC_INTEGRATOR_PATH ? (ctx->lds_scene ? TRC_PATH_WAVES : TRC_PATH_WAVES_GLOBAL)
                                   : p->integrator == TRC_INTEGRATOR_MIS ? TRC_MIS_WAVES : TRC_VOLUME_WAVES;
     const uint32_t wave_slots = (uint32_t)ctx->cu_count * 4u * waves_per_simd;
+    ctx->last_cost_div = kp.cost_div; ctx->last_wave_slots = wave_slots;
     uint32_t grid_cap = ctx->n_tiles;                                     // workgroups of a one-block-per-workgroup launch
     bool planned = false;
     if (ctx->cost_valid && !(p->flags & TRC_FLAG_FIXED_ORDER) && kp.strip > 1 && ctx->d_last_order && ctx->order_age < 4) {
@@ -1836,8 +1837,46 @@ trc_status trc_debug_profile(trc_ctx* ctx, uint64_t* out, uint32_t n_sites) {
     return TRC_OK;
 }
 
+// developer diagnostic: the chain bound and the work bound of the last launch (tracer_abi.h)
+trc_status trc_debug_launch_shape(trc_ctx* ctx, trc_launch_shape* out) {
+    if (!ctx || !out) return TRC_ERR_INVALID_ARG;
+    std::memset(out, 0, sizeof *out);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, ctx->device) != hipSuccess || khz <= 0) khz = 2400000;
+    out->clock_mhz = khz / 1000.0;
+    out->wave_slots = ctx->last_wave_slots;
+    const uint32_t n = ctx->cost_strip > 1 ? (ctx->n_tiles + ctx->cost_strip - 1) / ctx->cost_strip : ctx->n_tiles;
+    if (n == 0 || !ctx->d_block_cost || !ctx->last_cost_div) return TRC_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t stride = ctx->cost_quarters ? kCostSlots : 1u;
+    std::vector<uint32_t> c((size_t)n * stride), sp(n, 0u), qs((size_t)n * 4u, 0u);
+    HIP_TRY(ctx, hipMemcpy(c.data(), ctx->d_block_cost, c.size() * 4, hipMemcpyDeviceToHost));
+    if (stride != 1u && ctx->split_live) {
+        HIP_TRY(ctx, hipMemcpy(sp.data(), ctx->d_split, (size_t)n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(qs.data(), ctx->d_qsplit, (size_t)n * 16, hipMemcpyDeviceToHost));
+    }
+    uint64_t sum = 0, longest = 0;
+    uint32_t entries = 0;
+    auto item = [&](uint32_t v) { sum += v; longest = std::max<uint64_t>(longest, v); entries++; };
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t* q = &c[(size_t)i * stride];
+        if (!sp[i]) { item(q[0]); continue; }
+        for (uint32_t k = 0; k < 4u; ++k) {
+            if (qs[4u * i + k]) { for (uint32_t s4 = 0; s4 < 4u; ++s4) item(q[4u + 4u * k + s4]); }
+            else item(q[k]);
+        }
+    }
+    const double to_ms = (double)ctx->last_cost_div / ((double)khz);      // cost units -> shader clocks -> ms
+    out->entries = entries;
+    out->longest_entry_ms = (double)longest * to_ms;
+    out->sum_entries_ms = (double)sum * to_ms;
+    out->work_over_slots_ms = out->wave_slots ? out->sum_entries_ms / out->wave_slots : 0.0;
+    return TRC_OK;
+}
+
 // developer diagnostic: the pixel blocks of the last trc_render (x | y << 16 in units of the block edge) and the duration
-// each one's wavefront measured (shader clocks / 64, the adaptive order's sort key)
+// each one's wavefront measured per sample (shader clocks / (4 spp), the adaptive order's sort key)
 trc_status trc_debug_block_costs(trc_ctx* ctx, uint32_t* tiles, uint32_t* costs, uint32_t capacity, uint32_t* n_blocks, uint32_t* blk_shift) {
     if (!ctx) return TRC_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -169,6 +169,7 @@ struct trc_ctx {
     bool split_live = false;            // d_split holds flags of the last launch's plan (else all zero)
     bool cost_quarters = false;         // d_block_cost / d_split describe a launch made with cost_stride 4
     bool cost_valid = false; uint32_t cost_strip = 1;
+    uint32_t last_cost_div = 0, last_wave_slots = 0;     // of the last render launch (trc_debug_launch_shape)
     int cost_head_age = 0;                    // 1: the costs are a cold head's (trc_render), 2: the launch after it ran on them
     uint32_t cost_integrator = 0xFFFFFFFFu;   // integrator the recorded costs belong to
     const uint32_t* d_last_order = nullptr; uint32_t order_age = 0;     // most recent sorted order (short launches reuse it)

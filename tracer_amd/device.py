@@ -95,6 +95,7 @@ def _load(path):
     L.trc_debug_set.argtypes = [vp, C.c_char_p, C.c_int]
     L.trc_div_by_test.argtypes = [vp, vp, vp, C.c_size_t, vp, vp]
     L.trc_debug_block_costs.argtypes = [vp, vp, vp, u32, C.POINTER(u32), C.POINTER(u32)]
+    L.trc_debug_launch_shape.argtypes = [vp, C.POINTER(abi.LaunchShape)]
     for name in abi.DEVICE_SYMBOLS:
         f = getattr(L, name)
         if name not in ("trc_abi_version", "trc_build_flavor", "trc_status_string", "trc_last_error", "trc_destroy"):
@@ -346,6 +347,12 @@ class Tracer:
         self._check(self._L.trc_debug_block_costs(self._h, tiles.ctypes.data, costs.ctypes.data, n.value, C.byref(n), C.byref(bs)),
                     "trc_debug_block_costs")
         return tiles, costs, bs.value
+
+    def launch_shape(self):
+        """chain bound / work bound of the last render launch (trc_debug_launch_shape) as a dict"""
+        s = abi.LaunchShape()
+        self._check(self._L.trc_debug_launch_shape(self._h, C.byref(s)), "trc_debug_launch_shape")
+        return {k: getattr(s, k) for k, _ in abi.LaunchShape._fields_}
 
     def group_finalize(self):
         self._check(self._L.trc_group_finalize(self._h), "trc_group_finalize")
