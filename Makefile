@@ -18,7 +18,7 @@ HIPFLAGS  := -std=c++17 -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-s
 
 HOST_SRC  := tracer_amd/host/bvh_builder.cpp tracer_amd/host/scene.cpp tracer_amd/host/mesh.cpp tracer_amd/host/pbrt_scene.cpp
 HOST_HDR  := tracer_amd/host/host_math.hpp tracer_amd/host/host_scene.hpp tracer_amd/host/pbrt_text.hpp include/tracer_abi.h include/trc_sobol.h
-HIP_SRC   := tracer_amd/csrc/trc_abi.hip tracer_amd/csrc/trc_sppm.hip tracer_amd/csrc/trc_lbvh.hip
+HIP_SRC   := tracer_amd/csrc/trc_abi.hip tracer_amd/csrc/trc_render_lds.hip tracer_amd/csrc/trc_render_mem.hip tracer_amd/csrc/trc_sppm.hip tracer_amd/csrc/trc_lbvh.hip
 HIP_HDR   := $(wildcard tracer_amd/csrc/*.hpp) include/tracer_abi.h include/trc_detmath.h include/trc_sobol.h
 
 .PHONY: all host hip hip_fast oracle example clean variant asan tsan sanitize
@@ -34,10 +34,16 @@ $(LIBDIR)/libtrc_host.so: $(HOST_SRC) $(HOST_HDR) Makefile
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -lpthread
 
+# One object per translation unit (make -j compiles them side by side; `make` with no -j still works), then one link.
 # RCCL is resolved at run time (dlopen in trc_group_*), so the library loads on boxes without it.
-$(LIBDIR)/libtracer_amd.so: $(HIP_SRC) $(HIP_HDR) Makefile
+HIP_OBJ      := $(patsubst tracer_amd/csrc/%.hip,build/obj/exact/%.o,$(HIP_SRC))
+HIP_OBJ_FAST := $(patsubst tracer_amd/csrc/%.hip,build/obj/fast/%.o,$(HIP_SRC))
+build/obj/exact/%.o: tracer_amd/csrc/%.hip $(HIP_HDR) Makefile
+	@mkdir -p build/obj/exact
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+$(LIBDIR)/libtracer_amd.so: $(HIP_OBJ)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC) -ldl -lpthread -Wl,-rpath,$(ROCM)/lib
+	$(HIPCC) --offload-arch=gfx950 -shared -o $@ $(HIP_OBJ) -ldl -lpthread -Wl,-rpath,$(ROCM)/lib
 
 # The same sources under fast-math rules (what the reference's shaders are compiled with: MTL_FAST_MATH): approximate
 # division / sqrt (v_rcp_f32, v_sqrt_f32), FMA contraction, denormals flushed, hardware exp / log / sin / cos
@@ -45,14 +51,19 @@ $(LIBDIR)/libtracer_amd.so: $(HIP_SRC) $(HIP_HDR) Makefile
 # kept (the integrators scrub NaN samples, Render.metal:537-538).  NOT comparable bit for bit with the oracle: parity of
 # this build is statistical (tests/test_gpu_fast_math.py); trc_build_flavor() tells a host which one it loaded.
 FASTFLAGS := -fno-hip-fp32-correctly-rounded-divide-sqrt -ffp-contract=fast -fgpu-flush-denormals-to-zero -DTRC_FAST_MATH=1
-$(LIBDIR)/libtracer_amd_fast.so: $(HIP_SRC) $(HIP_HDR) Makefile
+build/obj/fast/%.o: tracer_amd/csrc/%.hip $(HIP_HDR) Makefile
+	@mkdir -p build/obj/fast
+	$(HIPCC) $(HIPFLAGS) $(FASTFLAGS) -c -o $@ $<
+$(LIBDIR)/libtracer_amd_fast.so: $(HIP_OBJ_FAST)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) $(FASTFLAGS) -shared -o $@ $(HIP_SRC) -ldl -lpthread -Wl,-rpath,$(ROCM)/lib
+	$(HIPCC) --offload-arch=gfx950 -shared -o $@ $(HIP_OBJ_FAST) -ldl -lpthread -Wl,-rpath,$(ROCM)/lib
 
-# A/B variants of the device library for tools/ab_bench.py:  make variant NAME=unchecked DEFS=-DTRC_SPEC_UNCHECKED
-variant:
-	@mkdir -p build
-	$(HIPCC) $(HIPFLAGS) $(DEFS) -shared -o build/lib$(NAME).so $(HIP_SRC) -ldl -lpthread -Wl,-rpath,$(ROCM)/lib
+# A/B variants of the device library for tools/ab_bench.py:  make -j variant NAME=unchecked DEFS=-DTRC_SPEC_UNCHECKED
+build/obj/v_$(NAME)/%.o: tracer_amd/csrc/%.hip $(HIP_HDR) Makefile
+	@mkdir -p build/obj/v_$(NAME)
+	$(HIPCC) $(HIPFLAGS) $(DEFS) -c -o $@ $<
+variant: $(patsubst tracer_amd/csrc/%.hip,build/obj/v_$(NAME)/%.o,$(HIP_SRC))
+	$(HIPCC) --offload-arch=gfx950 -shared -o build/lib$(NAME).so $^ -ldl -lpthread -Wl,-rpath,$(ROCM)/lib
 
 # C++ host driving the path through the C ABI only (no Python): examples/trc_render
 example: examples/trc_render examples/trc_ranks

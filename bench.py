@@ -124,16 +124,26 @@ def fast_math_leg(scene, cam, steps):
         t.close()
 
 
+def _code_only(text):
+    """C / C++ source without comments and with white space collapsed: what the compiler sees of it."""
+    import re
+    pat = re.compile(r'//[^\n]*|/\*.*?\*/|"(?:\\.|[^"\\])*"|\'(?:\\.|[^\'\\])*\'', re.S)
+    text = pat.sub(lambda m: " " if m.group(0).startswith("/") else m.group(0), text)
+    return " ".join(text.split())
+
+
 def lib_source_hash():
-    """Identity of the device library: sha256 over the sources it is built from (the .so itself is not
-    byte-reproducible across builds).  tools/pmc_summary.py stores the same value next to the counters it collects."""
+    """Identity of the device library: sha256 over the CODE of the sources it is built from (the .so itself is not
+    byte-reproducible across builds).  Comments and white space are stripped first, so that a comment edit does not
+    invalidate a committed PMC summary (round 3 regenerated its profile set five times for that); anything the compiler
+    sees does.  tools/pmc_summary.py stores the same value next to the counters it collects."""
     h = hashlib.sha256()
     files = []
     for d in ("tracer_amd/csrc", "include"):
         files += [os.path.join(d, f) for f in sorted(os.listdir(os.path.join(ROOT, d)))]
     for f in files:
         h.update(f.encode())
-        h.update(open(os.path.join(ROOT, f), "rb").read())
+        h.update(_code_only(open(os.path.join(ROOT, f), "r", errors="replace").read()).encode())
     return h.hexdigest()[:16]
 
 

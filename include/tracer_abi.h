@@ -34,7 +34,7 @@ extern "C" {
  *    to mean any-hit); trc_build_flavor, trc_sppm_hash_cells, trc_host_scene_load_pbrt, trc_host_mesh_from_arrays added
  * 3: trc_group_set_collectives, trc_debug_set, trc_debug_block_costs; trc_pbrt_info / trc_pbrt_shape grew (textures,
  *    plymesh / disk / cylinder); trc_host_mesh_load_ply, trc_host_load_hdr, trc_div_by_test
- * 4: trc_debug_launch_shape; trc_debug_block_costs reports durations per SAMPLE (shader clocks / (4 spp)); knobs
+ * 4: trc_debug_launch_shape, trc_unary_test; trc_debug_block_costs reports durations per SAMPLE (shader clocks / (4 spp)); knobs
  *    no_cold_probe / probe_spp (the first launch of a block list runs as an 8-sample head + the rest, trc_render) */
 #define TRC_ABI_VERSION 4
 
@@ -481,6 +481,10 @@ trc_status trc_sppm_hash_cells(trc_ctx* ctx, const float* cells /* n*3 */, size_
  * compiler's own two fused corrections per quotient, plain `/` outside [2^-60, 2^60]) against the plain division, for n
  * operand pairs: fast / plain receive 3 quotients per pair (a / b, -a / b, (0.75 a) / b).  They must agree bit for bit. */
 trc_status trc_div_by_test(trc_ctx* ctx, const float* a, const float* b, size_t n, float* fast /* 3 n */, float* plain /* 3 n */);
+/* test hook: the render kernels' guard-free reciprocal / square root / reciprocal square root (dev_vec.hpp: rcp_cr, sqrt_cr, rsqrt_cr;
+ * op 0 / 1 / 2) against the compiler's correctly rounded 1.0f / x, sqrtf(x), 1.0f / sqrtf(x) on the `count` operands whose bit patterns
+ * start at `first_bits` (count = 2^32 covers every float): the number of operands whose results differ, and the smallest one */
+trc_status trc_unary_test(trc_ctx* ctx, uint32_t op, uint32_t first_bits, uint64_t count, uint64_t* n_mismatch, uint32_t* first_mismatch);
 
 /* --- multi-GPU: pixel tiles sharded over ranks, one RCCL reduce -------- */
 #define TRC_UNIQUE_ID_BYTES 128

@@ -152,3 +152,13 @@ def test_two_rank_bench_path_on_one_gpu(launcher):
     assert line["config"]["settle_launches"] == 8
     for r in line["per_rank"]:
         assert 0 < r["longest_chain_ms"] and 0 < r["work_over_slots_ms"] and r["launch_entries"] >= 32400 // 2
+
+
+def test_source_hash_ignores_comments_and_white_space_only():
+    a = 'int f(int x) { // add one\n    return x + 1; /* really */ }\nconst char* s = "// not a comment";\n'
+    b = 'int f(int x) {\n  return x + 1;\n}\n\nconst char* s = "// not a comment";  // trailing\n'
+    c = 'int f(int x) { return x + 2; }\nconst char* s = "// not a comment";\n'
+    d = 'int f(int x) { return x + 1; }\nconst char* s = "// not b comment";\n'
+    assert bench._code_only(a) == bench._code_only(b)
+    assert bench._code_only(a) != bench._code_only(c) and bench._code_only(a) != bench._code_only(d)
+    assert len(bench.lib_source_hash()) == 16

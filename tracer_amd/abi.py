@@ -213,7 +213,7 @@ DEVICE_SYMBOLS = [
     "trc_render", "trc_synchronize", "trc_trace_rays", "trc_get_stats", "trc_reset_stats", "trc_debug_profile",
     "trc_sppm_init", "trc_sppm_frames", "trc_sppm_download", "trc_sppm_hash_cells",
     "trc_device_info", "trc_group_unique_id", "trc_group_init", "trc_group_reduce_accum", "trc_group_reduce_accum_async", "trc_group_allreduce_mean_accum", "trc_download_composed", "trc_group_finalize",
-    "trc_group_set_collectives", "trc_debug_set", "trc_debug_block_costs", "trc_debug_launch_shape", "trc_div_by_test",
+    "trc_group_set_collectives", "trc_debug_set", "trc_debug_block_costs", "trc_debug_launch_shape", "trc_div_by_test", "trc_unary_test",
 ]
 HOST_SYMBOLS = [
     "trc_host_build_node", "trc_host_build_tree", "trc_host_tree_depth", "trc_host_make_camera",

@@ -33,7 +33,7 @@ struct Ray {
     F3 o, d, inv;     // inv = 1.0 / direction, computed once per ray (AABB.hh:75,94 recompute it per box)
 };
 TRC_DEV Ray make_ray(F3 o, F3 dir) {     // Ray::Ray normalises (Ray.hh:21-23)
-    Ray r; r.o = o; r.d = normalize(dir); r.inv = f3(1.0f) / r.d; return r;
+    Ray r; r.o = o; r.d = normalize(dir); r.inv = rcp_cr(r.d); return r;
 }
 TRC_DEV F3 point_at(const Ray& r, float t) { return r.o + r.d * t; }
 

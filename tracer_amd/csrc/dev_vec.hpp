@@ -30,8 +30,54 @@ TRC_DEV F3 operator/(F3 a, float s) { return f3(a.x / s, a.y / s, a.z / s); }
 TRC_DEV F3 operator-(F3 a) { return f3(-a.x, -a.y, -a.z); }
 TRC_DEV float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 TRC_DEV F3 cross(F3 a, F3 b) { return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-TRC_DEV float length(F3 a) { return sqrtf(dot(a, a)); }
-TRC_DEV F3 normalize(F3 a) { float inv = 1.0f / length(a); return a * inv; }
+
+// ---------------------------------------------------------------- 1 / x and sqrt(x), same bits as the compiler's, fewer instructions
+// hipcc's correctly rounded `1.0f / x` is 11 instructions and `sqrtf(x)` 16: a core (v_rcp_f32 + six fma; v_sqrt_f32, its two
+// neighbours, two fma residuals, two selects) wrapped in operand guards (v_div_scale x 2, v_div_fmas, v_div_fixup; a 2^32
+// pre-scale below 2^-96 and its undo, a class test for 0 / inf).  For an operand in [2^-60, 2^60] every guard is the identity:
+// nothing is scaled, no special value is patched, so the core ALONE returns the same bits (checked over all 2^32 operands on
+// the hardware: trc_unary_test, tests/test_gpu_unary.py).  The guards are replaced by ONE range test per site and wavefront:
+// all active lanes in range -> the core; else -> the compiler's sequence for everybody (rare: lengths of degenerate vectors).
+// The two sequences make 31 % of the static instructions of tracePath (157 divisions, 79 square roots).
+#ifndef TRC_FAST_UNARY
+#define TRC_FAST_UNARY 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && TRC_FAST_UNARY && !defined(TRC_FAST_MATH)
+TRC_DEV bool unary_in_range(float x) {            // 2^-60 <= |x| < 2^60 (exponent field 67 .. 186)
+    return ((__float_as_uint(x) & 0x7FFFFFFFu) - 0x21800000u) < (0x5D800000u - 0x21800000u);
+}
+TRC_DEV bool wave_all(bool ok) { return __builtin_amdgcn_ballot_w64(!ok) == 0ull; }
+TRC_DEV float rcp_core(float x) {                 // the compiler's sequence for 1.0f / x without v_div_scale / v_div_fmas' scaling / v_div_fixup
+    const float r0 = __builtin_amdgcn_rcpf(x);
+    const float r1 = __builtin_fmaf(__builtin_fmaf(-x, r0, 1.0f), r0, r0);
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-x, r1, 1.0f), r1, r1);
+    return __builtin_fmaf(__builtin_fmaf(-x, q1, 1.0f), r1, q1);
+}
+TRC_DEV float sqrt_core(float x) {                // ... for sqrtf(x) without the pre-scale and the class test
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
+    float r = (0.0f >= rm) ? sm : s;
+    r = (0.0f < rp) ? sp : r;
+    return r;
+}
+TRC_DEV float rcp_cr(float x) { return wave_all(unary_in_range(x)) ? rcp_core(x) : 1.0f / x; }
+TRC_DEV float sqrt_cr(float x) { return wave_all(unary_in_range(x) && x > 0.0f) ? sqrt_core(x) : sqrtf(x); }
+// 1 / sqrt(x) as two correctly rounded steps (normalize): in range, the root lies in [2^-30, 2^30] -- in range again
+TRC_DEV float rsqrt_cr(float x) { return wave_all(unary_in_range(x) && x > 0.0f) ? rcp_core(sqrt_core(x)) : 1.0f / sqrtf(x); }
+#else
+TRC_DEV float rcp_cr(float x) { return 1.0f / x; }
+TRC_DEV float sqrt_cr(float x) { return sqrtf(x); }
+TRC_DEV float rsqrt_cr(float x) { return 1.0f / sqrtf(x); }
+#endif
+TRC_DEV F3 rcp_cr(F3 a) {                         // 1 / direction: one range test for the three
+#if defined(__HIP_DEVICE_COMPILE__) && TRC_FAST_UNARY && !defined(TRC_FAST_MATH)
+    if (wave_all(unary_in_range(a.x) && unary_in_range(a.y) && unary_in_range(a.z))) return f3(rcp_core(a.x), rcp_core(a.y), rcp_core(a.z));
+#endif
+    return f3(1.0f / a.x, 1.0f / a.y, 1.0f / a.z);
+}
+TRC_DEV float length(F3 a) { return sqrt_cr(dot(a, a)); }
+TRC_DEV F3 normalize(F3 a) { float inv = rsqrt_cr(dot(a, a)); return a * inv; }
 // per-lane dynamic component access stays in registers (select chains, no scratch)
 TRC_DEV float comp(F3 a, uint32_t i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 TRC_DEV void set_comp(F3& a, uint32_t i, float v) { if (i == 0) a.x = v; else if (i == 1) a.y = v; else a.z = v; }

@@ -1,0 +1,82 @@
+// trc_render_config.hpp -- compile-time shape of the render kernels (launch bounds, persistent-workgroup geometry, stack and
+// record policy per integrator), shared by the translation units that DEFINE the kernels (trc_render_lds.hip, trc_render_mem.hip)
+// and the one that plans and launches them (trc_abi.hip).  Every value is an A/B macro: make variant NAME=x DEFS=-D...
+#pragma once
+
+#include "trc_ctx.hpp"
+
+// "test now, build the record for the winner afterwards" (dev_intersect.hpp: trav_test_leaf<DEFER>), per tree residence
+// two-level traversal stack (first entries in LDS, deeper ones in global rows: dev_intersect.hpp stack_put) per integrator, on
+// trees read from memory: it is what lets LDS admit the occupancy the registers allow
+#ifndef TRC_MIS_HYBRID
+#define TRC_MIS_HYBRID 1
+#endif
+#ifndef TRC_VOLUME_HYBRID
+#define TRC_VOLUME_HYBRID 0
+#endif
+constexpr bool hybrid_stack(int integrator) {
+    return integrator == TRC_INTEGRATOR_PATH || (integrator == TRC_INTEGRATOR_MIS ? TRC_MIS_HYBRID != 0 : TRC_VOLUME_HYBRID != 0);
+}
+#ifndef TRC_DEFER_LDS
+#define TRC_DEFER_LDS 0
+#endif
+#ifndef TRC_DEFER_GLOBAL
+#define TRC_DEFER_GLOBAL 1
+#endif
+
+// kernelPathTracing, Render.metal:495-558.  One lane per pixel, one one-wavefront workgroup per 8x8 pixel block
+// (DESIGN.md 4.1), all `spp` samples fused: RNG texel and accumulator are read and
+// written ONCE per pixel instead of once per sample (64 B/pixel/sample in the reference).
+// wavefronts per SIMD the register allocation aims at (launch bounds), each measured (profiles/r02/
+// compiler_flags_and_occupancy.txt, lds_plan_and_stack.txt): tracePath on an LDS-resident tree fits 96 VGPRs with 2
+// spilled dwords (5 waves: 21.5 -> 20.8 ms on config 2; 6 waves / 80 VGPRs: 21.3-21.6); on a tree read from memory the
+// sixth wave hides more latency than its spills cost (1 M triangles: 32.8 -> 31.8 ms; 7 waves: 33.4) -- provided LDS
+// lets it in (plan_launch_lds); traceMIS needs 128 (5 waves: 63.2 -> 63.7 ms on config 3), traceVolume 128 (5: 55 -> 84 ms)
+#ifndef TRC_PATH_WAVES
+#define TRC_PATH_WAVES 5
+#endif
+#ifndef TRC_PATH_WAVES_GLOBAL
+#define TRC_PATH_WAVES_GLOBAL 8
+#endif
+#ifndef TRC_MIS_WAVES
+#define TRC_MIS_WAVES 8
+#endif
+#ifndef TRC_VOLUME_WAVES
+#define TRC_VOLUME_WAVES 4
+#endif
+// persistent workgroups (k_render_pwg): wavefronts per workgroup x workgroups per CU = the waves per CU above
+#ifndef TRC_PWG_WAVES_PATH
+#define TRC_PWG_WAVES_PATH 16
+#endif
+#ifndef TRC_PWG_PER_CU_PATH
+#define TRC_PWG_PER_CU_PATH 2
+#endif
+#ifndef TRC_PWG_WAVES_MIS
+#define TRC_PWG_WAVES_MIS 16
+#endif
+#ifndef TRC_PWG_PER_CU_MIS
+#define TRC_PWG_PER_CU_MIS 2
+#endif
+#ifndef TRC_PWG_WAVES_VOLUME
+#define TRC_PWG_WAVES_VOLUME 16
+#endif
+#ifndef TRC_PWG_PER_CU_VOLUME
+#define TRC_PWG_PER_CU_VOLUME 1
+#endif
+#ifndef TRC_STRIP_PATH_WAVES
+#define TRC_STRIP_PATH_WAVES 4
+#endif
+constexpr int pwg_waves(int integrator) { return integrator == TRC_INTEGRATOR_PATH ? TRC_PWG_WAVES_PATH : (integrator == TRC_INTEGRATOR_MIS ? TRC_PWG_WAVES_MIS : TRC_PWG_WAVES_VOLUME); }
+constexpr int pwg_per_cu(int integrator) { return integrator == TRC_INTEGRATOR_PATH ? TRC_PWG_PER_CU_PATH : (integrator == TRC_INTEGRATOR_MIS ? TRC_PWG_PER_CU_MIS : TRC_PWG_PER_CU_VOLUME); }
+
+// The kernels themselves (trc_render_kernels.hpp) are instantiated in two translation units, so that each family is compiled
+// with its own arithmetic short cuts (dev_vec.hpp TRC_FAST_UNARY: -1.8 % on the LDS-resident tracePath kernel, +0.7 ... 1.9 % on the
+// kernels of trees read from memory, whose 64 registers it upsets) -- and in parallel:
+//   trc_render_lds.hip   k_render<true, ...>, k_render_strip<true, ...>          the whole tree staged in LDS (Cornell scenes)
+//   trc_render_mem.hip   k_render<false, ...>, k_render_strip<false, ...>, k_render_pwg<...>   trees read from memory (meshes)
+template <bool LDS, bool STATS, int INTEGRATOR, bool SOBOL = false>
+__global__ void k_render(const KRender kp);
+template <int INTEGRATOR, bool SOBOL>
+__global__ void k_render_pwg(const KRender kp);
+template <bool LDS, int INTEGRATOR, bool SOBOL>
+__global__ void k_render_strip(const KRender kp);

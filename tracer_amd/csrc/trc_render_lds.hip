@@ -1,0 +1,17 @@
+// trc_render_lds.hip -- the render kernels of scenes whose whole tree is staged in LDS (the Cornell scenes: BASELINE config 2,
+// SPPM's scene), instantiated with the guard-free reciprocal / square root of dev_vec.hpp (TRC_FAST_UNARY, bit-identical:
+// tests/test_gpu_unary.py).  Definitions: trc_render_kernels.hpp; launched from trc_abi.hip.
+#ifndef TRC_FAST_UNARY
+#define TRC_FAST_UNARY 1
+#endif
+#include "trc_render_kernels.hpp"
+
+#define TRC_INST_RENDER(S, I, B) template __global__ void k_render<true, S, I, B>(const KRender)
+#define TRC_INST_STRIP(I, B) template __global__ void k_render_strip<true, I, B>(const KRender)
+// exactly the instantiations launch_render<> picks from (trc_abi.hip)
+TRC_INST_RENDER(false, TRC_INTEGRATOR_PATH, false);   TRC_INST_RENDER(true, TRC_INTEGRATOR_PATH, false);   TRC_INST_RENDER(false, TRC_INTEGRATOR_PATH, true);
+TRC_INST_RENDER(false, TRC_INTEGRATOR_MIS, false);    TRC_INST_RENDER(true, TRC_INTEGRATOR_MIS, false);    TRC_INST_RENDER(false, TRC_INTEGRATOR_MIS, true);
+TRC_INST_RENDER(false, TRC_INTEGRATOR_VOLUME, false); TRC_INST_RENDER(true, TRC_INTEGRATOR_VOLUME, false);
+TRC_INST_STRIP(TRC_INTEGRATOR_PATH, false);  TRC_INST_STRIP(TRC_INTEGRATOR_PATH, true);
+TRC_INST_STRIP(TRC_INTEGRATOR_MIS, false);   TRC_INST_STRIP(TRC_INTEGRATOR_MIS, true);
+TRC_INST_STRIP(TRC_INTEGRATOR_VOLUME, false);

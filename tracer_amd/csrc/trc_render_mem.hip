@@ -1,0 +1,23 @@
+// trc_render_mem.hip -- the render kernels of trees read from memory (mesh scenes: BASELINE configs 3 / 4, traceVolume's scene):
+// one-wavefront workgroups, strips and the persistent workgroups.  Compiled WITHOUT dev_vec.hpp's guard-free reciprocal /
+// square root: at 64 registers per lane the extra code paths cost these kernels 0.7-1.9 % (profiles/r04/fast_unary_ab.txt).
+// Definitions: trc_render_kernels.hpp; launched from trc_abi.hip.
+#ifndef TRC_FAST_UNARY
+#define TRC_FAST_UNARY 0
+#endif
+#include "trc_render_kernels.hpp"
+
+#define TRC_INST_RENDER(S, I, B) template __global__ void k_render<false, S, I, B>(const KRender)
+#define TRC_INST_STRIP(I, B) template __global__ void k_render_strip<false, I, B>(const KRender)
+// exactly the instantiations launch_render<> picks from (trc_abi.hip)
+TRC_INST_RENDER(false, TRC_INTEGRATOR_PATH, false);   TRC_INST_RENDER(true, TRC_INTEGRATOR_PATH, false);   TRC_INST_RENDER(false, TRC_INTEGRATOR_PATH, true);
+TRC_INST_RENDER(false, TRC_INTEGRATOR_MIS, false);    TRC_INST_RENDER(true, TRC_INTEGRATOR_MIS, false);    TRC_INST_RENDER(false, TRC_INTEGRATOR_MIS, true);
+TRC_INST_RENDER(false, TRC_INTEGRATOR_VOLUME, false); TRC_INST_RENDER(true, TRC_INTEGRATOR_VOLUME, false);
+TRC_INST_STRIP(TRC_INTEGRATOR_PATH, false);  TRC_INST_STRIP(TRC_INTEGRATOR_PATH, true);
+TRC_INST_STRIP(TRC_INTEGRATOR_MIS, false);   TRC_INST_STRIP(TRC_INTEGRATOR_MIS, true);
+TRC_INST_STRIP(TRC_INTEGRATOR_VOLUME, false);
+template __global__ void k_render_pwg<TRC_INTEGRATOR_PATH, false>(const KRender);
+template __global__ void k_render_pwg<TRC_INTEGRATOR_PATH, true>(const KRender);
+template __global__ void k_render_pwg<TRC_INTEGRATOR_MIS, false>(const KRender);
+template __global__ void k_render_pwg<TRC_INTEGRATOR_MIS, true>(const KRender);
+template __global__ void k_render_pwg<TRC_INTEGRATOR_VOLUME, false>(const KRender);

@@ -96,6 +96,7 @@ def _load(path):
     L.trc_div_by_test.argtypes = [vp, vp, vp, C.c_size_t, vp, vp]
     L.trc_debug_block_costs.argtypes = [vp, vp, vp, u32, C.POINTER(u32), C.POINTER(u32)]
     L.trc_debug_launch_shape.argtypes = [vp, C.POINTER(abi.LaunchShape)]
+    L.trc_unary_test.argtypes = [vp, u32, u32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(u32)]
     for name in abi.DEVICE_SYMBOLS:
         f = getattr(L, name)
         if name not in ("trc_abi_version", "trc_build_flavor", "trc_status_string", "trc_last_error", "trc_destroy"):
@@ -347,6 +348,12 @@ class Tracer:
         self._check(self._L.trc_debug_block_costs(self._h, tiles.ctypes.data, costs.ctypes.data, n.value, C.byref(n), C.byref(bs)),
                     "trc_debug_block_costs")
         return tiles, costs, bs.value
+
+    def unary_test(self, op, first_bits=0, count=1 << 32):
+        """(mismatches, first mismatching bit pattern) of rcp_cr / sqrt_cr / rsqrt_cr (op 0 / 1 / 2) against the compiler's sequences"""
+        n, first = C.c_uint64(0), C.c_uint32(0)
+        self._check(self._L.trc_unary_test(self._h, op, first_bits, count, C.byref(n), C.byref(first)), "trc_unary_test")
+        return n.value, first.value
 
     def launch_shape(self):
         """chain bound / work bound of the last render launch (trc_debug_launch_shape) as a dict"""
