@@ -34,7 +34,7 @@ TRC_DEV F2 concentric_sample_disk(const F2 u) {                      // Sampling
 }
 TRC_DEV F3 cosine_sample_hemisphere(const F2 u) {                    // Sampling.hh:125-129
     F2 d = concentric_sample_disk(u);
-    float z = sqrtf(fmaxf(0.0f, 1.0f - d.x * d.x - d.y * d.y));
+    float z = sqrt_cr(fmaxf(0.0f, 1.0f - d.x * d.x - d.y * d.y));
     return f3(d.x, d.y, z);
 }
 TRC_DEV float power_heuristic(int nf, float fPdf, int ng, float gPdf) {   // Sampling.hh:137-140
@@ -46,11 +46,11 @@ TRC_DEV float cos_theta(F3 w) { return w.z; }
 TRC_DEV float cos2_theta(F3 w) { return w.z * w.z; }
 TRC_DEV float abs_cos_theta(F3 w) { return fabsf(w.z); }
 TRC_DEV float sin2_theta(F3 w) { return fmaxf(0.0f, 1.0f - cos2_theta(w)); }
-TRC_DEV float sin_theta(F3 w) { return sqrtf(sin2_theta(w)); }
+TRC_DEV float sin_theta(F3 w) { return sqrt_cr(sin2_theta(w)); }
 TRC_DEV float tan_theta(F3 v) {
     float temp = 1 - v.z * v.z;
     if (temp <= 0.0f || v.z == 0.0f) return 0.0f;
-    return sqrtf(temp) / v.z;
+    return sqrt_cr(temp) / v.z;
 }
 TRC_DEV float tan2_theta(F3 v) {
     float zz = v.z * v.z;
@@ -81,7 +81,7 @@ TRC_DEV float erf_inv(float x) {
         p = 0.246640727f + p * w;
         p = 1.50140941f + p * w;
     } else {
-        w = sqrtf(w) - 3;
+        w = sqrt_cr(w) - 3;
         p = -0.000200214257f;
         p = 0.000100950558f + p * w;
         p = 0.00134934322f + p * w;
@@ -112,7 +112,7 @@ TRC_DEV bool refract(F3 wo, F3 n, float eta, F3& wi) {                          
     float sin2ThetaI = fmaxf(0.0f, 1.0f - cosThetaI * cosThetaI);
     float sin2ThetaT = eta * eta * sin2ThetaI;
     if (sin2ThetaT >= 1) return false;
-    float cosThetaT = sqrtf(1 - sin2ThetaT);
+    float cosThetaT = sqrt_cr(1 - sin2ThetaT);
     wi = eta * -wo + (eta * cosThetaI - cosThetaT) * n;
     return true;
 }
@@ -123,7 +123,7 @@ TRC_DEV float fr_dielectric(float cosi, float eta) {                            
     float sin2Theta_i = 1 - cosi * cosi;
     float sin2Theta_t = sin2Theta_i / sqr(eta);
     if (sin2Theta_t >= 1) return 1.f;
-    float cosTheta_t = sqrtf(fmaxf(0.0f, 1 - sin2Theta_t));
+    float cosTheta_t = sqrt_cr(fmaxf(0.0f, 1 - sin2Theta_t));
     float r_parl = (eta * cosi - cosTheta_t) / (eta * cosi + cosTheta_t);
     float r_perp = (cosi - eta * cosTheta_t) / (cosi + eta * cosTheta_t);
     return (r_parl * r_parl + r_perp * r_perp) / 2;
@@ -162,7 +162,7 @@ struct Beckmann {
     TRC_DEV float lambda(F3 w) const {
         float absTanTheta = fabsf(tan_theta(w));
         if (is_inf(absTanTheta)) return 0.;
-        float alpha = sqrtf(cos2_phi(w) * ax() * ax() + sin2_phi(w) * ay() * ay());
+        float alpha = sqrt_cr(cos2_phi(w) * ax() * ax() + sin2_phi(w) * ay() * ay());
         float a = 1 / (alpha * absTanTheta);
         if (a >= 1.6f) return 0;
         return (1 - 1.259f * a + 0.396f * a * a) / (3.535f * a + 2.181f * a * a);
@@ -180,14 +180,14 @@ struct Beckmann {
 
     TRC_DEV static void sample11(float cosThetaI, float U1, float U2, float& slope_x, float& slope_y) {
         if (cosThetaI > .9999f) {
-            float r = sqrtf(-dm_logf(1.0f - U1));
+            float r = sqrt_cr(-dm_logf(1.0f - U1));
             float sinPhi, cosPhi;
             dm_sincosf(2 * kPi * U2, &sinPhi, &cosPhi);
             slope_x = r * cosPhi;
             slope_y = r * sinPhi;
             return;
         }
-        float sinThetaI = sqrtf(fmaxf(0.0f, 1.0f - cosThetaI * cosThetaI));
+        float sinThetaI = sqrt_cr(fmaxf(0.0f, 1.0f - cosThetaI * cosThetaI));
         float tanThetaI = sinThetaI / cosThetaI;
         float cotThetaI = 1 / tanThetaI;
         float a = -1, c = erf_approx(cotThetaI);
@@ -243,7 +243,7 @@ struct TrowbridgeReitzD {                                            // Microfac
         float tan2Theta = tan2_theta(w);
         if (is_inf(tan2Theta)) return 0.;
         float alpha2 = sqr(cos_phi(w) * ax()) + sqr(sin_phi(w) * ay());
-        return 0.5f * (sqrtf(1 + alpha2 * tan2Theta) - 1);
+        return 0.5f * (sqrt_cr(1 + alpha2 * tan2Theta) - 1);
     }
     TRC_DEV static float G1(F3 w) { return 1 / (1 + lambda(w)); }
     TRC_DEV static float G(F3 wo, F3 wi) { return 1 / (1 + lambda(wo) + lambda(wi)); }
@@ -251,7 +251,7 @@ struct TrowbridgeReitzD {                                            // Microfac
 
     TRC_DEV static void sample11(float cosTheta, float U1, float U2, float& slope_x, float& slope_y) {
         if (cosTheta > .9999f) {
-            float r = sqrtf(U1 / (1 - U1));
+            float r = sqrt_cr(U1 / (1 - U1));
             float phi = 6.28318530718f * U2;
             float s, c;
             dm_sincosf(phi, &s, &c);
@@ -259,15 +259,15 @@ struct TrowbridgeReitzD {                                            // Microfac
             slope_y = r * s;
             return;
         }
-        float sinTheta = sqrtf(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
+        float sinTheta = sqrt_cr(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
         float tanTheta = sinTheta / cosTheta;
         float a = 1 / tanTheta;
-        float G1 = 2 / (1 + sqrtf(1.f + 1.f / (a * a)));
+        float G1 = 2 / (1 + sqrt_cr(1.f + 1.f / (a * a)));
         float A = 2 * U1 / G1 - 1;
         float tmp = 1.f / (A * A - 1.f);
         if (tmp > 1e10f) tmp = 1e10f;
         float B = tanTheta;
-        float D = sqrtf(fmaxf(B * B * tmp * tmp - (A * A - B * B) * tmp, 0.0f));
+        float D = sqrt_cr(fmaxf(B * B * tmp * tmp - (A * A - B * B) * tmp, 0.0f));
         float slope_x_1 = B * tmp - D;
         float slope_x_2 = B * tmp + D;
         slope_x = (A < 0 || slope_x_2 > 1.f / tanTheta) ? slope_x_1 : slope_x_2;
@@ -276,7 +276,7 @@ struct TrowbridgeReitzD {                                            // Microfac
         else { S = -1.f; U2 = 2.f * (.5f - U2); }
         float z = (U2 * (U2 * (U2 * 0.27385f - 0.73369f) + 0.46341f)) /
                   (U2 * (U2 * (U2 * 0.093073f + 0.309420f) - 1.000000f) + 0.597999f);
-        slope_y = S * z * sqrtf(1.f + slope_x * slope_x);
+        slope_y = S * z * sqrt_cr(1.f + slope_x * slope_x);
     }
     TRC_DEV static F3 sample_wh(F3 wo, F2 u) {
         const bool flip = wo.z < 0;

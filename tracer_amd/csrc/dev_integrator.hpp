@@ -53,7 +53,7 @@ TRC_DEV Ray cast_ray(const DCamera& cam, float s, float t, Pcg& rng) {
         px = 2.0f * a - 1.0f;
         py = 2.0f * b - 1.0f;
     } while (px * px + py * py >= 1.0f);
-    float inv = 1.0f / sqrtf(px * px + py * py);
+    float inv = rsqrt_cr(px * px + py * py);
     float rdx = cam.lenRadius * (px * inv), rdy = cam.lenRadius * (py * inv);
     F3 offset = f3(cam.u[0], cam.u[1], cam.u[2]) * rdx + f3(cam.v[0], cam.v[1], cam.v[2]) * rdy;
     F3 origin = f3(cam.lookFrom[0], cam.lookFrom[1], cam.lookFrom[2]) + offset;
@@ -225,7 +225,7 @@ TRC_DEV bool path_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, 
 TRC_DEV float phase_hg(float cosTheta, float g) {                    // HitRecord.hh:45-49
     float gg = g * g;
     float denom = 1 + gg + 2 * g * cosTheta;
-    return (0.25f / kPi) * (1 - gg) / (denom * sqrtf(denom));
+    return (0.25f / kPi) * (1 - gg) / (denom * sqrt_cr(denom));
 }
 TRC_DEV void hg_sample_p(float g, F3 wo, F3& wi, F2 uu) {            // HitRecord.hh:58-77 (the returned pdf is unused)
     float cosTheta;
@@ -235,7 +235,7 @@ TRC_DEV void hg_sample_p(float g, F3 wo, F3& wi, F2 uu) {            // HitRecor
         float sqrTerm = (1 - gg) / (1 + g - 2 * g * uu.x);
         cosTheta = -(1 + gg - sqrTerm * sqrTerm) / (2 * g);
     }
-    float sinTheta = sqrtf(fmaxf(0.0f, 1 - cosTheta * cosTheta));
+    float sinTheta = sqrt_cr(fmaxf(0.0f, 1 - cosTheta * cosTheta));
     float phi = 2 * kPi * uu.y;
     F3 v1, v2;
     coordinate_system(wo, v1, v2);

@@ -200,7 +200,7 @@ TRC_DEV bool sphere_hit_test(const SceneRef& S, uint32_t index, const Ray& ray, 
     float c = dot(oc, oc) - radius * radius;
     float discriminant = half_b * half_b - a * c;
     if (discriminant <= 0) return false;
-    float root = sqrtf(discriminant);
+    float root = sqrt_cr(discriminant);
     float temp = (-half_b - root) / a;
     if (!(temp < ry && temp > rx)) {
         temp = (-half_b + root) / a;
