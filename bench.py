@@ -449,6 +449,7 @@ def main(argv=None):
         st = trc.stats()
         assert st.rays == rays_per_launch * steps, "steps are not identical work"
         kernel_ms = st.kernel_ms / max(1, st.launches)          # HIP events on the render stream
+        schedule_ms = st.schedule_ms / max(1, st.launches)      # ... and around the launch-list kernels (order, sort, plan), averaged
         shape = trc.launch_shape()                               # the two bounds no schedule of this rank's share can beat
 
         # the same K steps with a DIFFERENT seed each (a progressive renderer never replays a frame: the adaptive
@@ -479,7 +480,7 @@ def main(argv=None):
         rays_total = reduce_scalar(float(st.rays), "SUM")
         rays_vary_total = reduce_scalar(float(st_vary.rays), "SUM")
         per_rank = gather_list({"rank": rank, "kernel_ms": round(kernel_ms, 3), "kernel_ms_vary_seed": round(kernel_ms_vary, 3),
-                                "compose_ms": None if compose_ms is None else round(compose_ms, 3),
+                                "compose_ms": None if compose_ms is None else round(compose_ms, 3), "schedule_ms": round(schedule_ms, 4),
                                 "rays_per_step": int(st.rays // steps), "device": device,
                                 # a pixel's samples are one chain: the launch cannot end before its slowest wavefront-sized item
                                 # (block or part), nor before the items' summed durations over the GPU's wavefront slots
@@ -536,6 +537,7 @@ def main(argv=None):
             "cold": primary["cold"], "first_launch_ms": primary["cold"]["first_launch_ms"],
             # parity-imposed bounds of the timed launches on rank 0 (every rank's under per_rank at N > 1)
             "launch_bounds": {k: primary["per_rank"][0][k] for k in ("longest_chain_ms", "work_over_slots_ms", "launch_entries", "wave_slots")},
+            "schedule_ms": primary["per_rank"][0]["schedule_ms"],      # launch-list kernels per step (a settled list re-plans every 4th launch)
             # the BINDING bound of the dominant kernel: VALU issue (PMC counters of this library, profiles/rNN/pmc_config2.json)
             "roofline": roof,
             # the north_star's figure: bytes the REFERENCE's access pattern would move for this work over the

@@ -34,7 +34,7 @@ extern "C" {
  *    to mean any-hit); trc_build_flavor, trc_sppm_hash_cells, trc_host_scene_load_pbrt, trc_host_mesh_from_arrays added
  * 3: trc_group_set_collectives, trc_debug_set, trc_debug_block_costs; trc_pbrt_info / trc_pbrt_shape grew (textures,
  *    plymesh / disk / cylinder); trc_host_mesh_load_ply, trc_host_load_hdr, trc_div_by_test
- * 4: trc_debug_launch_shape, trc_unary_test; trc_debug_block_costs reports durations per SAMPLE (shader clocks / (4 spp)); knobs
+ * 4: trc_debug_launch_shape, trc_unary_test; trc_stats.schedule_ms; knob no_plan_reuse; trc_debug_block_costs reports durations per SAMPLE (shader clocks / (4 spp)); knobs
  *    no_cold_probe / probe_spp (the first launch of a block list runs as an 8-sample head + the rest, trc_render) */
 #define TRC_ABI_VERSION 4
 
@@ -323,6 +323,7 @@ typedef struct trc_stats {
     uint64_t n_hit_cube;         /* cube tests that reach the world transform (228 B vs 100 B) */
     uint64_t launches;           /* render kernel launches */
     double   kernel_ms;          /* sum of hipEvent durations of those launches, on the ctx stream */
+    double   schedule_ms;        /* ... and of the launch-list kernels in front of them (order, sort, split plan); not part of kernel_ms */
 } trc_stats;
 
 /* Threading contract.  A context owns its device buffers, one render stream (+ a communication stream and the SPPM
@@ -739,7 +740,7 @@ TRC_SA(sizeof(trc_Complex) == 96 && offsetof(trc_Complex, frame_count) == 20 && 
        offsetof(trc_Complex, framePhotonSum) == 92, "Complex");
 TRC_SA(sizeof(trc_ray) == 32, "trc_ray");
 TRC_SA(sizeof(trc_hit) == 80 && offsetof(trc_hit, p) == 16 && offsetof(trc_hit, uv) == 52 && offsetof(trc_hit, n_descend) == 68, "trc_hit");
-TRC_SA(sizeof(trc_params) == 32 && sizeof(trc_stats) == 104, "trc_params / trc_stats");
+TRC_SA(sizeof(trc_params) == 32 && sizeof(trc_stats) == 112, "trc_params / trc_stats");
 TRC_SA(sizeof(trc_GridDensityInfo) == 32 && offsetof(trc_GridDensityInfo, invMaxDensity) == 16 && offsetof(trc_GridDensityInfo, nx) == 20, "GridDensityInfo");
 TRC_SA(sizeof(trc_PhotonRecord) == 80 && offsetof(trc_PhotonRecord, normal) == 16 && offsetof(trc_PhotonRecord, position) == 32 &&
        offsetof(trc_PhotonRecord, direction) == 48 && offsetof(trc_PhotonRecord, step) == 64 &&

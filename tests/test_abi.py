@@ -73,7 +73,7 @@ def test_ctypes_layout_matches_header_offsets():
     assert off(abi.Camera, "cornerLowLeft") == 160
     # trc_hit / trc_params / trc_stats: the header static-asserts the same numbers
     assert C.sizeof(abi.Hit) == 80 and off(abi.Hit, "p") == 16 and off(abi.Hit, "uv") == 52 and off(abi.Hit, "n_descend") == 68
-    assert C.sizeof(abi.Params) == 32 and C.sizeof(abi.Stats) == 104
+    assert C.sizeof(abi.Params) == 32 and C.sizeof(abi.Stats) == 112
 
 
 def test_trc_create_fails_loudly_without_gpu_when_no_device():

@@ -193,7 +193,7 @@ class Stats(C.Structure):
                 ("n_leaf_sphere", C.c_uint64), ("n_leaf_square", C.c_uint64),
                 ("n_leaf_cube", C.c_uint64), ("n_leaf_triangle", C.c_uint64),
                 ("n_hit_triangle", C.c_uint64), ("n_hit_cube", C.c_uint64),
-                ("launches", C.c_uint64), ("kernel_ms", C.c_double)]
+                ("launches", C.c_uint64), ("kernel_ms", C.c_double), ("schedule_ms", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

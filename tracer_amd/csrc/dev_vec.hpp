@@ -63,10 +63,25 @@ TRC_DEV float sqrt_core(float x) {                // ... for sqrtf(x) without th
     r = (0.0f < rp) ? sp : r;
     return r;
 }
-TRC_DEV float rcp_cr(float x) { return wave_all(unary_in_range(x)) ? rcp_core(x) : 1.0f / x; }
-TRC_DEV float sqrt_cr(float x) { return wave_all(unary_in_range(x) && x > 0.0f) ? sqrt_core(x) : sqrtf(x); }
+// The core is computed FIRST and the range test decides afterwards whether everybody redoes it the long way: the test's compare
+// is independent of the core's chain, so the branch finds its condition ready instead of stalling a lone wavefront on it
+// (a chain-bound share of a frame runs at one wavefront's latency: 5.9 -> 5.x ms on an eighth of config 2).
+TRC_DEV float rcp_cr(float x) {
+    float r = rcp_core(x);
+    if (__builtin_expect(!wave_all(unary_in_range(x)), 0)) r = 1.0f / x;
+    return r;
+}
+TRC_DEV float sqrt_cr(float x) {
+    float r = sqrt_core(x);
+    if (__builtin_expect(!wave_all(unary_in_range(x) && x > 0.0f), 0)) r = sqrtf(x);
+    return r;
+}
 // 1 / sqrt(x) as two correctly rounded steps (normalize): in range, the root lies in [2^-30, 2^30] -- in range again
-TRC_DEV float rsqrt_cr(float x) { return wave_all(unary_in_range(x) && x > 0.0f) ? rcp_core(sqrt_core(x)) : 1.0f / sqrtf(x); }
+TRC_DEV float rsqrt_cr(float x) {
+    float r = rcp_core(sqrt_core(x));
+    if (__builtin_expect(!wave_all(unary_in_range(x) && x > 0.0f), 0)) r = 1.0f / sqrtf(x);
+    return r;
+}
 #else
 TRC_DEV float rcp_cr(float x) { return 1.0f / x; }
 TRC_DEV float sqrt_cr(float x) { return sqrtf(x); }
@@ -74,9 +89,12 @@ TRC_DEV float rsqrt_cr(float x) { return 1.0f / sqrtf(x); }
 #endif
 TRC_DEV F3 rcp_cr(F3 a) {                         // 1 / direction: one range test for the three
 #if defined(__HIP_DEVICE_COMPILE__) && TRC_FAST_UNARY && !defined(TRC_FAST_MATH)
-    if (wave_all(unary_in_range(a.x) && unary_in_range(a.y) && unary_in_range(a.z))) return f3(rcp_core(a.x), rcp_core(a.y), rcp_core(a.z));
-#endif
+    F3 r = f3(rcp_core(a.x), rcp_core(a.y), rcp_core(a.z));
+    if (__builtin_expect(!wave_all(unary_in_range(a.x) && unary_in_range(a.y) && unary_in_range(a.z)), 0)) r = f3(1.0f / a.x, 1.0f / a.y, 1.0f / a.z);
+    return r;
+#else
     return f3(1.0f / a.x, 1.0f / a.y, 1.0f / a.z);
+#endif
 }
 TRC_DEV float length(F3 a) { return sqrt_cr(dot(a, a)); }
 TRC_DEV F3 normalize(F3 a) { float inv = rsqrt_cr(dot(a, a)); return a * inv; }

@@ -110,10 +110,8 @@ __device__ __forceinline__ uint32_t slowest_part(const uint32_t* cost, const uin
 // instead (it grows by 1/64 per launch until a measurement undercuts it, so a scene that changes is followed): config 2
 // 20.9 -> 20.4 ms, its shares of 2 / 4 / 8 ranks 12.3 -> 11.1, 8.5 -> 7.3, 5.95 -> 5.6 ms (knob no_cost_filter switches it off).
 // One thread per block filters the slots its last launch wrote (the block, its quarters or their sixteenths).
-__global__ void __launch_bounds__(256) k_filter_costs(const uint32_t* cost, const uint32_t* split, const uint32_t* qsplit, uint32_t stride, uint32_t n,
-                                                      uint32_t* filt, uint32_t* whole, const bool fresh) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
+__device__ __forceinline__ void filter_block_costs(const uint32_t* cost, const uint32_t* split, const uint32_t* qsplit, uint32_t stride, uint32_t i,
+                                                   uint32_t* filt, uint32_t* whole, const bool fresh) {
     // fresh: what the filter holds are the durations of a cold HEAD (8 samples, row-major, trc_render) -- good enough to order
     // and plan the launch that followed, but no "shortest duration seen lately" of a settled launch: that launch's replace them
     auto slot = [&](uint32_t k) {
@@ -134,10 +132,13 @@ __global__ void __launch_bounds__(256) k_filter_costs(const uint32_t* cost, cons
     const uint32_t w = whole[i];
     if (w) whole[i] = max(1u, min(w, (uint32_t)((float)slowest_part(filt, qsplit, i) * 2.0f)));
 }
-__global__ void __launch_bounds__(256) k_order_keys(const uint32_t* cost, const uint32_t* split, const uint32_t* whole, const uint32_t* qsplit,
-                                                    uint32_t stride, uint32_t n, uint32_t* keys, uint32_t* vals) {
+// One thread per block: (1) filter the slots its last launch wrote (the block, its quarters or their sixteenths) into `filt`
+// (skipped with the knob no_cost_filter: filt == cost then), (2) the block's sort key: its cost as ONE block, descending.
+__global__ void __launch_bounds__(256) k_order_keys(const uint32_t* raw, uint32_t* cost, const uint32_t* split, uint32_t* whole, const uint32_t* qsplit,
+                                                    uint32_t stride, uint32_t n, uint32_t* keys, uint32_t* vals, const bool filtered, const bool fresh) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
+    if (filtered) filter_block_costs(raw, split, qsplit, stride, i, cost, whole, fresh);
     uint32_t c = cost[(size_t)i * stride];
     if (stride == kCostSlots && split[i])
         c = whole[i] ? whole[i] : (uint32_t)((float)slowest_part(cost, qsplit, i) * (1.0f / kQuarterEstimate));
@@ -159,60 +160,81 @@ __global__ void __launch_bounds__(256) k_order_keys(const uint32_t* cost, const 
 // Second level: where wavefront slots are still idle after that (entries < slots), the quarters within kSixteenthTier of the
 // launch's longest part -- the ones the launch now ends on -- run as four 2x2 sixteenths on 4 lanes each in the next launch;
 // plan[3] = the threshold a quarter's duration must reach, plan[4] = how many do, plan[1] = the entries of the launch.
-__global__ void __launch_bounds__(1024) k_plan_split(const uint32_t* keys, const uint32_t* vals, const uint32_t* split, const uint32_t* cost,
-                                                     const uint32_t* qsplit, const uint32_t* qwhole, uint32_t n, uint32_t k_max, const uint32_t slots,
-                                                     const uint32_t max_entries, uint32_t* plan, const uint32_t* raw) {
-    __shared__ double s_sum[1024];
-    __shared__ float s_raw[1024], s_est[1024];
+// per RANK r of the sorted order (block i = vals[r]), gathered by one thread each so that the one-workgroup planner below reads
+// dense arrays: part[r] = the slowest part the last launch ran of it (0: it ran whole), rawv[r] = its measured duration when
+// it ran whole (else -1), quart[4 r + q] = quarter q's cost when the block ran in parts and that quarter ran as ONE (else 0;
+// 0xFFFFFFFF: it already ran as sixteenths)
+__global__ void __launch_bounds__(256) k_plan_gather(const uint32_t* vals, const uint32_t* split, const uint32_t* cost, const uint32_t* qsplit,
+                                                     const uint32_t* raw, uint32_t n, uint32_t* part, float* rawv, uint32_t* quart) {
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t i = vals[r];
+    const bool sp = split[i] != 0u;
+    part[r] = sp ? slowest_part(cost, qsplit, i) : 0u;
+    rawv[r] = sp ? -1.0f : (float)raw[(size_t)i * kCostSlots];
+#pragma unroll
+    for (uint32_t q = 0; q < 4u; ++q)
+        quart[4u * r + q] = !sp ? 0u : (qsplit[4u * i + q] ? 0xFFFFFFFFu : cost[(size_t)i * kCostSlots + q]);
+}
+// exclusive prefix sum over the 1024 threads of the workgroup (wave shuffles, then the 16 wave totals); returns the total
+__device__ __forceinline__ double block_scan_1024(double v, double* s_wave /* [16] */, double& total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    double inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const double o = __shfl_up(inc, off, 64); if ((int)lane >= off) inc += o; }
+    if (lane == 63u) s_wave[wave] = inc;
+    __syncthreads();
+    double base = 0.0, tot = 0.0;
+#pragma unroll
+    for (uint32_t w = 0; w < 16u; ++w) { const double x = s_wave[w]; if (w < wave) base += x; tot += x; }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+__global__ void __launch_bounds__(1024) k_plan_split(const uint32_t* keys, const uint32_t* part, const float* rawv, const uint32_t* quart, uint32_t n,
+                                                     uint32_t k_max, const uint32_t slots, const uint32_t max_entries, uint32_t* plan, uint32_t* launch) {
+    __shared__ double s_wave[16];
     __shared__ float s_best[1024];
-    __shared__ uint32_t s_k[1024];
-    __shared__ uint32_t s_q[1024], s_first[1024];
+    __shared__ uint32_t s_k[1024], s_q[1024], s_first[1024];
+    __shared__ float s_raw[1024], s_est[1024];
     const uint32_t t = threadIdx.x, per = (n + 1023u) / 1024u;
     const uint32_t lo = min(n, t * per), hi = min(n, lo + per);
     double local = 0.0;
     float raw_sum = 0.0f, est_sum = 0.0f;          // blocks the last launch ran whole: measured durations / filtered costs
     uint32_t q_max = 0u, first_whole = 0xFFFFFFFFu;
     for (uint32_t r = lo; r < hi; ++r) {
-        local += (double)(0xFFFFFFu - keys[r]);
-        const uint32_t i = vals[r];
-        if (split[i]) q_max = max(q_max, slowest_part(cost, qsplit, i));
+        const float c = (float)(0xFFFFFFu - keys[r]);
+        local += (double)c;
+        const uint32_t pr = part[r];
+        if (pr) q_max = max(q_max, pr);
         else {
             if (first_whole == 0xFFFFFFFFu) first_whole = r;
-            raw_sum += (float)raw[(size_t)i * kCostSlots]; est_sum += (float)(0xFFFFFFu - keys[r]);
+            raw_sum += rawv[r]; est_sum += c;
         }
     }
-    s_sum[t] = local; s_q[t] = q_max; s_first[t] = first_whole; s_raw[t] = raw_sum; s_est[t] = est_sum;
+    double total = 0.0;
+    double prefix = block_scan_1024(local, s_wave, total);          // cost of the blocks before rank `lo`
+    s_q[t] = q_max; s_first[t] = first_whole; s_raw[t] = raw_sum; s_est[t] = est_sum;
     __syncthreads();
-    if (t == 0) {                                   // exclusive scan of 1024 partial sums + two reductions: serial, a few microseconds
-        double run = 0.0;
-        float rs = 0.0f, es = 0.0f;
-        uint32_t q = 0u, f = 0xFFFFFFFFu;
-        for (uint32_t i = 0; i < 1024u; ++i) {
-            const double v = s_sum[i]; s_sum[i] = run; run += v;
-            q = max(q, s_q[i]); f = min(f, s_first[i]);
-            rs += s_raw[i]; es += s_est[i];
-        }
-        s_q[0] = q; s_first[0] = f;
-        // the costs are what a block takes when it starts first on its SIMD; a wavefront slot is held for the measured
-        // duration: the work term scales by the ratio of the two over the blocks that ran whole
-        s_raw[0] = es > 0.0f ? fminf(fmaxf(rs / es, 1.0f), 4.0f) : 1.0f;
-        plan[2] = (uint32_t)min((es > 0.0f ? (double)fminf(fmaxf(rs / es, 1.0f), 4.0f) : 1.0) * run / (double)slots, 4294967295.0);   // diagnostic: work / slots of the unsplit launch
+    for (uint32_t off = 512u; off > 0u; off >>= 1) {
+        if (t < off) { s_q[t] = max(s_q[t], s_q[t + off]); s_first[t] = min(s_first[t], s_first[t + off]); s_raw[t] += s_raw[t + off]; s_est[t] += s_est[t + off]; }
+        __syncthreads();
     }
-    __syncthreads();
-    double total = s_sum[1023];
-    for (uint32_t r = min(n, 1023u * per); r < n; ++r) total += (double)(0xFFFFFFu - keys[r]);
-    const double held = (double)s_raw[0];           // slot time per unit of cost
+    // the costs are what a block takes when it starts first on its SIMD; a wavefront slot is held for the measured
+    // duration: the work term scales by the ratio of the two over the blocks that ran whole
+    const double held = s_est[0] > 0.0f ? (double)fminf(fmaxf(s_raw[0] / s_est[0], 1.0f), 4.0f) : 1.0;      // slot time per unit of cost
     const float part_seen = (float)s_q[0];
     const uint32_t r_whole = s_first[0];            // most expensive block the previous launch ran whole
+    __syncthreads();
+    if (t == 0) plan[2] = (uint32_t)min(held * total / (double)slots, 4294967295.0);   // diagnostic: work / slots of the unsplit launch
     const float quarter_new = r_whole < n ? kQuarterCost * (float)(0xFFFFFFu - keys[r_whole]) : 0.0f;
     const double extra = 4.0 * (double)kQuarterCost - 1.0;
     float best = 3.0e38f;
     uint32_t best_k = 0;
-    double prefix = s_sum[t];                       // cost of the blocks before rank `lo`
     auto candidate = [&](uint32_t k, float whole) {       // split ranks 0 .. k-1
-        const float part = k == 0u ? 0.0f : (k > r_whole ? fmaxf(part_seen, quarter_new) : part_seen);
+        const float pt = k == 0u ? 0.0f : (k > r_whole ? fmaxf(part_seen, quarter_new) : part_seen);
         const float work = (float)(held * (total + extra * prefix) / (double)slots);
-        const float m = fmaxf(fmaxf(whole, part), work);
+        const float m = fmaxf(fmaxf(whole, pt), work);
         if (m < best) { best = m; best_k = k; }
     };
     // fewer blocks than wavefront slots: the parts must not push the launch into a second round of wavefronts
@@ -245,24 +267,26 @@ __global__ void __launch_bounds__(1024) k_plan_split(const uint32_t* keys, const
     const uint32_t tier = tail_bound && part_seen > 0.0f ? max(1u, (uint32_t)(kSixteenthTier * part_seen)) : 0xFFFFFFFFu;
     uint32_t have = 0u, want = 0u;                  // quarters that already run as sixteenths / that would join them
     for (uint32_t j = t; j < 4u * K; j += 1024u) {
-        const uint32_t i = vals[j >> 2], q = j & 3u;
-        if (!split[i]) continue;                                       // becomes quarters now: their durations are not known yet
-        if (qsplit[4u * i + q]) have++;
-        else if (cost[(size_t)i * kCostSlots + q] >= tier) want++;
+        const uint32_t cq = quart[j];
+        if (cq == 0u) continue;                                        // becomes quarters now: their durations are not known yet
+        if (cq == 0xFFFFFFFFu) have++;
+        else if (cq >= tier) want++;
     }
     s_k[t] = have; s_q[t] = want;
     __syncthreads();
     for (uint32_t off = 512u; off > 0u; off >>= 1) { if (t < off) { s_k[t] += s_k[t + off]; s_q[t] += s_q[t + off]; } __syncthreads(); }
+    const uint32_t room = min(max_entries, max(slots, entries1 + slots / 8u)) - entries1;      // entries the sixteenths may add
+    uint32_t K2 = s_k[0] + s_q[0], use_tier = tier, keep = 1u;
+    if (12u * K2 > room) { K2 = s_k[0]; use_tier = 0xFFFFFFFFu; }                 // no new ones
+    if (12u * K2 > room) { K2 = 0u; keep = 0u; }                                  // not even the old ones: back to quarters
     if (t == 0) {
-        const uint32_t room = min(max_entries, max(slots, entries1 + slots / 8u)) - entries1;      // entries the sixteenths may add
-        uint32_t K2 = s_k[0] + s_q[0], use_tier = tier, keep = 1u;
-        if (12u * K2 > room) { K2 = s_k[0]; use_tier = 0xFFFFFFFFu; }                 // no new ones
-        if (12u * K2 > room) { K2 = 0u; keep = 0u; }                                  // not even the old ones: back to quarters
         plan[0] = K; plan[3] = use_tier; plan[4] = K2; plan[7] = keep;
         plan[5] = 0u;                                                  // k_build_launch's cursor into the part region
         plan[6] = K;
         plan[1] = entries1 + 12u * K2;
     }
+    // the part region is sized for more sixteenths than k_build_launch may make: entries it does not claim name no pixels
+    for (uint32_t j = t; j < 4u * K + 12u * K2; j += 1024u) launch[j] = kLaunchIndexMask;
 }
 // the launch list of a plan: first the parts of ranks 0 .. K-1 (the longest blocks: quarters, or sixteenths of the quarters
 // the second level picked), then the other blocks whole, longest first.  The parts take their places with an atomic cursor
@@ -307,11 +331,6 @@ __global__ void __launch_bounds__(256) k_build_launch(const uint32_t* keys, cons
 #pragma unroll
         for (uint32_t q = 0; q < 4u; ++q) qsplit[4u * i + q] = 0u;
     }
-}
-// entries of the part region nobody claimed (the plan's count of sixteenths is an upper bound): a block index past the list
-__global__ void __launch_bounds__(256) k_pad_launch(const uint32_t* plan, uint32_t* launch) {
-    const uint32_t region = 4u * plan[0] + 12u * plan[4];
-    for (uint32_t j = plan[5] + blockIdx.x * 256u + threadIdx.x; j < region; j += gridDim.x * 256u) launch[j] = kLaunchIndexMask;
 }
 // every block as four quarters (a first launch of few blocks: nothing is known about their costs yet)
 __global__ void __launch_bounds__(256) k_build_launch_all_quarters(uint32_t n, uint32_t* plan, uint32_t* launch, uint32_t* split, uint32_t* whole, uint32_t* qsplit) {
@@ -467,6 +486,16 @@ void collect_finished_events(trc_ctx* ctx) {
         ctx->event_pool.push_back(ctx->pending[done].second);
     }
     ctx->pending.erase(ctx->pending.begin(), ctx->pending.begin() + (ptrdiff_t)done);
+    for (done = 0; done < ctx->pending_sched.size(); ++done) {                 // the launch-list kernels' pairs: schedule_ms
+        const hipError_t q = hipEventQuery(ctx->pending_sched[done].second);
+        if (q == hipErrorNotReady) { (void)hipGetLastError(); break; }
+        if (q != hipSuccess) break;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ctx->pending_sched[done].first, ctx->pending_sched[done].second) == hipSuccess) ctx->schedule_ms += ms;
+        ctx->event_pool.push_back(ctx->pending_sched[done].first);
+        ctx->event_pool.push_back(ctx->pending_sched[done].second);
+    }
+    ctx->pending_sched.erase(ctx->pending_sched.begin(), ctx->pending_sched.begin() + (ptrdiff_t)done);
 }
 
 // drains finished per-launch event pairs into kernel_ms (call after a stream sync)
@@ -478,6 +507,13 @@ void collect_events(trc_ctx* ctx) {
         ctx->event_pool.push_back(pr.second);
     }
     ctx->pending.clear();
+    for (auto& pr : ctx->pending_sched) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) ctx->schedule_ms += ms;
+        ctx->event_pool.push_back(pr.first);
+        ctx->event_pool.push_back(pr.second);
+    }
+    ctx->pending_sched.clear();
 }
 
 
@@ -678,6 +714,8 @@ trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32
     (void)hipFree(ctx->d_qsplit); ctx->d_qsplit = nullptr;
     (void)hipFree(ctx->d_qwhole); ctx->d_qwhole = nullptr;
     (void)hipFree(ctx->d_launch); ctx->d_launch = nullptr;
+    (void)hipFree(ctx->d_plan_gather); ctx->d_plan_gather = nullptr;
+    ctx->plan_streak = 0;
     ctx->cost_valid = false; ctx->d_last_order = nullptr; ctx->cost_quarters = false; ctx->launch_cap = 0;
     ctx->n_tiles = (uint32_t)tiles.size();
     if (ctx->n_tiles) {
@@ -689,6 +727,7 @@ trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_qsplit, tiles.size() * 16));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_qwhole, tiles.size() * 16));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_launch, tiles.size() * 4 * kCostSlots));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_plan_gather, tiles.size() * 4 * 6));      // k_plan_gather: part, raw, 4 quarters per rank
         if (!ctx->d_plan) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_plan, 8 * sizeof(uint32_t)));
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_plan, 0, 8 * sizeof(uint32_t), ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_split, 0, tiles.size() * 4, ctx->stream));
@@ -913,6 +952,7 @@ trc_status trc_create(int device, trc_ctx** out) {
         ctx->knobs.no_cost_filter = env_int("TRC_NO_COST_FILTER", true);
         ctx->knobs.no_cold_probe = env_int("TRC_NO_COLD_PROBE", true);
         ctx->knobs.probe_spp = env_int("TRC_PROBE_SPP", false);
+        ctx->knobs.no_plan_reuse = env_int("TRC_NO_PLAN_REUSE", true);
     }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void**)&ctx->d_stats, sizeof(unsigned long long) * kStatRows * kStatRowStride) != hipSuccess ||
@@ -936,7 +976,7 @@ void trc_destroy(trc_ctx* ctx) {
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     (void)hipFree(ctx->d_blob); (void)hipFree(ctx->d_bvh_ref); (void)hipFree(ctx->d_density); (void)hipFree(ctx->d_occupancy); (void)hipFree(ctx->d_envmap); (void)hipFree(ctx->d_sobol32); (void)hipFree(ctx->d_sobol_vdc); (void)hipFree(ctx->d_rng); (void)hipFree(ctx->d_accum);
     (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_stats); (void)hipFree(ctx->d_stats_sum); (void)hipFree(ctx->d_reduce_recv);
-    (void)hipFree(ctx->d_block_cost); (void)hipFree(ctx->d_order_hist); (void)hipFree(ctx->d_split); (void)hipFree(ctx->d_whole); (void)hipFree(ctx->d_cost_est); (void)hipFree(ctx->d_qsplit); (void)hipFree(ctx->d_qwhole); (void)hipFree(ctx->d_launch); (void)hipFree(ctx->d_plan);
+    (void)hipFree(ctx->d_block_cost); (void)hipFree(ctx->d_order_hist); (void)hipFree(ctx->d_split); (void)hipFree(ctx->d_whole); (void)hipFree(ctx->d_cost_est); (void)hipFree(ctx->d_qsplit); (void)hipFree(ctx->d_qwhole); (void)hipFree(ctx->d_launch); (void)hipFree(ctx->d_plan); (void)hipFree(ctx->d_plan_gather);
     for (int k = 0; k < 2; ++k) { (void)hipFree(ctx->d_order_keys[k]); (void)hipFree(ctx->d_order_vals[k]); }
     (void)hipFree(ctx->d_accum_alt); (void)hipFree(ctx->d_stack_ovf); (void)hipFree(ctx->d_queue);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
@@ -1148,6 +1188,7 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner);
 // as a HEAD of kColdHeadSpp samples, cold, and the REST ordered and planned by the head's per-block durations (costs are kept
 // per sample, KRender::cost_div, so launches of different lengths speak of the same quantity).  No probe work is thrown
 // away, no pixel changes; the only price is the head's own short tail.  Knob no_cold_probe switches it off.
+constexpr uint32_t kPlanSettled = 8, kPlanReuse = 3;   // a settled list re-plans every fourth launch
 constexpr uint32_t kColdHeadSpp = 8;           // >= 8: the head must run the same kernel and block list as the rest (k_render_strip below)
 trc_status trc_render(trc_ctx* ctx, const trc_params* p) { return render_pass(ctx, p, false); }
 
@@ -1248,6 +1289,7 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
                                   : p->integrator == TRC_INTEGRATOR_MIS ? TRC_MIS_WAVES : TRC_VOLUME_WAVES;
     const uint32_t wave_slots = (uint32_t)ctx->cu_count * 4u * waves_per_simd;
     ctx->last_cost_div = kp.cost_div; ctx->last_wave_slots = wave_slots;
+    if (!ctx->cost_valid || (p->flags & TRC_FLAG_FIXED_ORDER) || kp.strip > 1) ctx->plan_streak = 0;      // nothing settled to reuse
     uint32_t grid_cap = ctx->n_tiles;                                     // workgroups of a one-block-per-workgroup launch
     bool planned = false;
     if (ctx->cost_valid && !(p->flags & TRC_FLAG_FIXED_ORDER) && kp.strip > 1 && ctx->d_last_order && ctx->order_age < 4) {
@@ -1255,12 +1297,24 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
         ctx->order_age++;                          // sort launches per 0.7 ms render are not
     } else if (ctx->cost_valid && !(p->flags & TRC_FLAG_FIXED_ORDER)) {
         const uint32_t n = (ctx->n_tiles + kp.strip - 1) / kp.strip;
-        // the costs the order and the plan work on: the shortest durations seen lately (k_filter_costs), or the last launch's
+        // the costs the order and the plan work on: the shortest durations seen lately (filter_block_costs), or the last launch's
         const bool filtered = !ctx->knobs.no_cost_filter;
         uint32_t* costs = filtered ? ctx->d_cost_est : ctx->d_block_cost;
-        if (filtered) hipLaunchKernelGGL(k_filter_costs, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_block_cost, ctx->d_split, ctx->d_qsplit, kp.cost_stride, n, costs, ctx->d_whole, ctx->cost_head_age == 2);
-        hipLaunchKernelGGL(k_order_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, costs, ctx->d_split, ctx->d_whole, ctx->d_qsplit, kp.cost_stride, n,
-                           ctx->d_order_keys[0], ctx->d_order_vals[0]);
+        // A list whose plan has settled (kPlanSettled planned launches in a row) keeps its order and plan for kPlanReuse
+        // launches: the filtered costs of a progressive render barely move from one launch to the next, and the dozen small
+        // kernels below are 0.1 ms in front of every launch (schedule_ms in trc_stats) -- 2 % of an eighth of a frame.  The
+        // launch that is reused ran with the same list, so the durations it leaves land in the same slots.
+        const bool reuse = ctx->plan_streak >= kPlanSettled && ctx->plan_reused < kPlanReuse && ctx->plan_n == n && ctx->plan_split_mode == may_split &&
+                           ctx->plan_wave_slots == wave_slots && !ctx->knobs.no_plan_reuse;
+        if (reuse) {
+            ctx->plan_reused++;
+            if (may_split) { kp.order = ctx->d_launch; kp.n_launch = ctx->d_plan + 1; grid_cap = ctx->plan_grid_cap; planned = true; }
+            else kp.order = ctx->d_last_order;
+        } else {
+        hipEvent_t s0 = get_event(ctx), s1 = get_event(ctx);
+        if (s0) (void)hipEventRecord(s0, ctx->stream);
+        hipLaunchKernelGGL(k_order_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_block_cost, costs, ctx->d_split, ctx->d_whole, ctx->d_qsplit,
+                           kp.cost_stride, n, ctx->d_order_keys[0], ctx->d_order_vals[0], filtered, ctx->cost_head_age == 2);
         int res = 0;
         trc_sort_pairs24(ctx->stream, ctx->d_order_keys, ctx->d_order_vals, ctx->d_order_hist, ctx->d_order_hist + trc_sort_hist_words(n), n, &res);
         kp.order = ctx->d_order_vals[res];
@@ -1271,15 +1325,24 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
             // taken (a launch with fewer blocks than slots is capped to the slots anyway), + an eighth for sixteenths
             const uint32_t k_max = std::min(n, wave_slots / 2u);
             const uint32_t max_entries = std::min(ctx->launch_cap, std::max(n + 3u * k_max, wave_slots) + wave_slots / 8u);
-            hipLaunchKernelGGL(k_plan_split, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_order_keys[res], ctx->d_order_vals[res], ctx->d_split, costs,
-                               ctx->d_qsplit, ctx->d_qwhole, n, k_max, wave_slots, max_entries, ctx->d_plan, ctx->d_block_cost);
+            uint32_t* g_part = ctx->d_plan_gather;
+            float* g_raw = reinterpret_cast<float*>(ctx->d_plan_gather + n);
+            uint32_t* g_quart = ctx->d_plan_gather + 2 * (size_t)n;
+            hipLaunchKernelGGL(k_plan_gather, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_order_vals[res], ctx->d_split, costs, ctx->d_qsplit,
+                               ctx->d_block_cost, n, g_part, g_raw, g_quart);
+            hipLaunchKernelGGL(k_plan_split, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_order_keys[res], g_part, g_raw, g_quart, n, k_max, wave_slots,
+                               max_entries, ctx->d_plan, ctx->d_launch);
             hipLaunchKernelGGL(k_build_launch, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_order_keys[res], ctx->d_order_vals[res], costs, n,
                                ctx->d_plan, ctx->d_launch, ctx->d_split, ctx->d_whole, ctx->d_qsplit, ctx->d_qwhole, filtered);
-            hipLaunchKernelGGL(k_pad_launch, dim3(8), dim3(256), 0, ctx->stream, ctx->d_plan, ctx->d_launch);
             kp.order = ctx->d_launch;
             kp.n_launch = ctx->d_plan + 1;
             grid_cap = max_entries;
             planned = true;
+        }
+        if (s0 && s1 && hipEventRecord(s1, ctx->stream) == hipSuccess) ctx->pending_sched.emplace_back(s0, s1);
+        else { if (s0) ctx->event_pool.push_back(s0); if (s1) ctx->event_pool.push_back(s1); }
+        ctx->plan_streak = (ctx->plan_n == n && ctx->plan_split_mode == may_split && ctx->plan_wave_slots == wave_slots) ? ctx->plan_streak + 1 : 1;
+        ctx->plan_reused = 0; ctx->plan_n = n; ctx->plan_split_mode = may_split; ctx->plan_wave_slots = wave_slots; ctx->plan_grid_cap = grid_cap;
         }
     } else if (may_split && !ctx->cost_valid && kAutoSmallBlocks && fits && blocks8 <= (uint64_t)ctx->cu_count * 16u &&
                p->integrator == TRC_INTEGRATOR_PATH && ctx->lds_scene) {
@@ -1432,6 +1495,7 @@ trc_status trc_get_stats(trc_ctx* ctx, trc_stats* out) {
     out->n_hit_triangle = h[kStatHitTriangle]; out->n_hit_cube = h[kStatHitCube];
     out->launches = ctx->launches;
     out->kernel_ms = ctx->kernel_ms;
+    out->schedule_ms = ctx->schedule_ms;
     return TRC_OK;
 }
 
@@ -1570,6 +1634,7 @@ trc_status trc_reset_stats(trc_ctx* ctx) {
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long) * kStatRows * kStatRowStride, ctx->stream));
     ctx->launches = 0;
     ctx->kernel_ms = 0.0;
+    ctx->schedule_ms = 0.0;
     return TRC_OK;
 }
 
@@ -1723,12 +1788,14 @@ trc_status trc_debug_set(trc_ctx* ctx, const char* knob, int value) {
               : k == "strip_len" ? &ctx->knobs.strip_len : k == "no_pwg" ? &ctx->knobs.no_pwg
               : k == "sppm_serial_camera" ? &ctx->knobs.sppm_serial_camera : k == "sppm_timing" ? &ctx->knobs.sppm_timing
               : k == "force_blk_shift" ? &ctx->knobs.force_blk_shift : k == "no_split" ? &ctx->knobs.no_split : k == "no_cost_filter" ? &ctx->knobs.no_cost_filter
-              : k == "no_cold_probe" ? &ctx->knobs.no_cold_probe : k == "probe_spp" ? &ctx->knobs.probe_spp : nullptr;
+              : k == "no_cold_probe" ? &ctx->knobs.no_cold_probe : k == "probe_spp" ? &ctx->knobs.probe_spp
+              : k == "no_plan_reuse" ? &ctx->knobs.no_plan_reuse : nullptr;
     if (!slot) return fail(ctx, TRC_ERR_INVALID_ARG, "trc_debug_set: unknown knob " + k);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // a launch in flight keeps the plan it was made with
     *slot = value < 0 ? 0 : value;
     ctx->cost_valid = false;                               // block costs recorded under another launch geometry say nothing
+    ctx->plan_streak = 0;
     return TRC_OK;
 }
 

@@ -165,6 +165,8 @@ struct trc_ctx {
     uint32_t* d_qwhole = nullptr;       // [4 n] ... and what it cost when it last ran as one quarter
     uint32_t* d_launch = nullptr;
     uint32_t* d_plan = nullptr;
+    uint32_t* d_plan_gather = nullptr;  // k_plan_gather's dense per-rank arrays (6 words per block)
+    uint32_t plan_streak = 0, plan_reused = 0, plan_n = 0, plan_wave_slots = 0, plan_grid_cap = 0; bool plan_split_mode = false;   // plan reuse (trc_render)
     uint32_t launch_cap = 0;            // entries d_launch holds = the grid of a launch that may split
     bool split_live = false;            // d_split holds flags of the last launch's plan (else all zero)
     bool cost_quarters = false;         // d_block_cost / d_split describe a launch made with cost_stride 4
@@ -181,6 +183,8 @@ struct trc_ctx {
     unsigned long long* d_stats_sum = nullptr;   // their sum, made by trc_get_stats / trc_debug_profile
     uint64_t launches = 0;
     double kernel_ms = 0.0;
+    double schedule_ms = 0.0;                                   // launch-list kernels (order, sort, plan) of those launches
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_sched;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // per-launch event pairs not yet read
     std::vector<hipEvent_t> event_pool;
 
@@ -206,7 +210,7 @@ struct trc_ctx {
 
     // A/B and test knobs, per context: defaults from the environment at trc_create (TRC_NO_LDS_FIT, TRC_STACK_LDS_LEVELS,
     // TRC_STRIP_LEN, TRC_NO_PWG, TRC_SPPM_SERIAL_CAMERA), changed through trc_debug_set
-    struct Knobs { int no_lds_fit = 0, stack_lds_levels = 0, strip_len = 0, no_pwg = 0, sppm_serial_camera = 0, sppm_timing = 0, force_blk_shift = 0, no_split = 0, no_cost_filter = 0, no_cold_probe = 0, probe_spp = 0; } knobs;
+    struct Knobs { int no_lds_fit = 0, stack_lds_levels = 0, strip_len = 0, no_pwg = 0, sppm_serial_camera = 0, sppm_timing = 0, force_blk_shift = 0, no_split = 0, no_cost_filter = 0, no_cold_probe = 0, probe_spp = 0, no_plan_reuse = 0; } knobs;
     // k_render_pwg instantiations that were granted > 64 KB of dynamic LDS on THIS context's device (bit = integrator * 2 +
     // sobol): hipFuncSetAttribute applies to the current device only, so the grant is per context, not per process
     uint32_t pwg_lds_granted = 0;
