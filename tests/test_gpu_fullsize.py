@@ -64,16 +64,21 @@ def test_headline_frame_with_the_sobol_sampler(gpu):
     _check_subsample(gpu, host.HostScene(abi.SCENE_CORNELL_SPHERES), abi.INTEGRATOR_PATH, 4, 32, sobol=True, frame0=100)
 
 
-def test_one_sample_per_launch_like_the_reference(gpu):
-    """the reference's own pattern: one sample per dispatch.  At this frame size such launches run k_render_strip (a strip
-    of 4 blocks per wavefront) and reuse the launch order for a few launches; six of them == six fused samples"""
+@pytest.mark.parametrize("coalesce", [True, False])
+def test_one_sample_per_launch_like_the_reference(gpu, coalesce):
+    """the reference's own pattern: one sample per dispatch.  Launched one by one (knob no_coalesce) such launches run
+    k_render_strip (a strip of blocks per wavefront) and reuse the launch order for a few launches; by default trc_render keeps a
+    launch of few samples back and extends it with the calls that continue it, so the six calls become one launch of six
+    samples at the first download.  Either way: six of them == six fused samples, and trc_stats counts six launches"""
     scene = host.HostScene(abi.SCENE_CORNELL_SPHERES)
     cam = host.prepare_camera(W, H)
     gpu.upload_scene(scene.view); gpu.set_camera(cam); gpu.set_environment((0.0, 0.0, 0.0)); gpu.resize(W, H)
+    gpu.debug_set("no_coalesce", 0 if coalesce else 1)
     gpu.seed(0xABCD); gpu.clear_accum(); gpu.reset_stats()
     for f in range(6):
         gpu.render(spp=1, frame0=f)
     one_by_one, rng_a, st = gpu.download_accum(), gpu.download_rng(), gpu.stats()
+    gpu.debug_set("no_coalesce", 0)
     assert st.paths == W * H * 6 and st.launches == 6
     gpu.seed(0xABCD); gpu.clear_accum()
     gpu.render(spp=6)
@@ -82,6 +87,42 @@ def test_one_sample_per_launch_like_the_reference(gpu):
     ref, _ = po.render(scene.view, cam, W, H, host.fill_rng(0xABCD, W, H), spp=6, tile_rank=0, tile_nranks=64)
     mine = _tile_mask(64)
     assert np.array_equal(one_by_one[mine].view(np.uint32), ref[mine].view(np.uint32))
+
+
+def test_kept_launches_are_flushed_by_everything_that_could_see_them(gpu):
+    """coalescing must be invisible: a run of 1-sample calls interrupted by a call that does not continue it (another frame
+    counter, another depth, a tonemap, a camera, a seed, a clear) gives the frames of launching every call at once; 20 calls in a
+    row are launched as 16 + 4"""
+    Ws, Hs = 320, 200
+    scene = host.HostScene(abi.SCENE_CORNELL_SPHERES)
+    cam, cam2 = host.prepare_camera(Ws, Hs), host.make_camera((278, 278, -700), (278, 260, 0), (0, 1, 0), 0.0, Ws / Hs, 0.7, 10.0)
+
+    def program(t):
+        out = []
+        t.seed(77); t.clear_accum()
+        t.render(spp=1, frame0=0); t.render(spp=2, frame0=1); t.render(spp=1, frame0=3)          # continues: 4 samples
+        t.render(spp=1, frame0=9)                                                                  # frame counter jumps: new launch
+        t.render(spp=1, frame0=10, max_depth=3)                                                    # other depth: new launch
+        out.append(t.tonemap()[0].copy())                                                          # flushes
+        t.render(spp=3, frame0=11)
+        t.set_camera(cam2)                                                                         # flushes BEFORE the camera changes
+        t.render(spp=3, frame0=14)
+        out.append(t.download_accum())
+        t.set_camera(cam); t.seed(78); t.clear_accum(); t.reset_stats()
+        for f in range(20):
+            t.render(spp=1, frame0=f)
+        out.append(t.download_accum()); out.append(t.download_rng())
+        st = t.stats()
+        assert st.launches == 20 and st.paths == Ws * Hs * 20
+        return out
+
+    gpu.upload_scene(scene.view); gpu.set_camera(cam); gpu.set_environment((0.1, 0.1, 0.1)); gpu.resize(Ws, Hs)
+    gpu.debug_set("no_coalesce", 1)
+    want = program(gpu)
+    gpu.debug_set("no_coalesce", 0)
+    got = program(gpu)
+    for a, b in zip(want, got):
+        assert np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
 
 
 def test_config4_as_named_million_triangles_256spp(gpu):

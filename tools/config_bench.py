@@ -30,9 +30,29 @@ if a.config == "5":
     t.synchronize()
     dt = time.perf_counter() - t0
     s = t.stats()
+    # rooflines of the SPPM frame: one object per pass, from the newest committed PMC summaries (profiles/rNN/pmc_config5_*.json;
+    # numbers only when they were collected on the running library), the dominant pass (refine) as `roofline`
+    import glob, re
+    sys.path.insert(0, wlmod.ROOT)
+    import bench
+    mine = bench.lib_source_hash()
+    passes = {}
+    for k in ("k_sppm_refine", "k_sppm_camera", "k_sppm_photon", "k_sppm_table"):
+        files = sorted(glob.glob(os.path.join(wlmod.ROOT, "profiles", "r*", f"pmc_config5_{k}.json")),
+                       key=lambda f: int(re.search(r"r(\d+)$", os.path.basename(os.path.dirname(f))).group(1)))
+        if not files:
+            passes[k] = {"bound": "valu-issue", "frac": None, "stale": "no committed PMC summary of this pass", "lib_source_hash": mine}
+            continue
+        pm = json.load(open(files[-1])); rel = os.path.relpath(files[-1], wlmod.ROOT)
+        if pm.get("lib_source_hash") != mine:
+            passes[k] = {"bound": "valu-issue", "frac": None, "lib_source_hash": mine,
+                         "stale": f"{rel} was collected on library {pm.get('lib_source_hash')}; running {mine}"}
+        else:
+            passes[k] = bench.valu_roofline(pm, None, rel, mine)
     print(json.dumps({"config": "config 5: SPPM, Cornell + 12 spheres, 512^2 photons per frame", "frames": a.frames * a.steps,
                       "wall_ms_per_frame": round(dt / (a.frames * a.steps) * 1e3, 4), "rays": s.rays,
-                      "mrays_per_s": round(s.rays / dt / 1e6, 1), "kernel": "k_sppm_"}))
+                      "mrays_per_s": round(s.rays / dt / 1e6, 1), "kernel": "k_sppm_",
+                      "roofline": passes["k_sppm_refine"], "roofline_per_pass": passes}))
     sys.exit(0)
 wl = wlmod.make(a.config)
 spp = a.spp or wl["spp"]
@@ -61,7 +81,7 @@ def rooflines():
     import bench
     alg = {"bound": "hbm (algorithmic bytes, not a physical bound)", "achieved": round(bytes_launch / ms / 1e6, 1), "peak": bench.HBM_PEAK_GBS,
            "unit": "GB/s", "frac": round(bytes_launch / ms / 1e6 / bench.HBM_PEAK_GBS, 4), "bytes_per_ray": round(bytes_launch / s1.rays, 1)}
-    files = sorted(glob.glob(os.path.join(wlmod.ROOT, "profiles", "r*", f"pmc_config{a.config}.json")),
+    files = sorted(glob.glob(os.path.join(wlmod.ROOT, "profiles", "r*", f"pmc_{'volume' if a.config == 'volume' else 'config' + a.config}.json")),
                    key=lambda f: int(re.search(r"r(\d+)$", os.path.basename(os.path.dirname(f))).group(1)))
     mine = bench.lib_source_hash()
     none = {"bound": "valu-issue", "achieved": None, "peak": None, "unit": "VALU wave-instructions/launch", "frac": None, "traffic": None, "lib_source_hash": mine}

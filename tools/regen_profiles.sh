@@ -3,7 +3,7 @@
 # writes gpurun_out/<round>/...; copy what is to be kept into profiles/<round>/ (tools/README.md, profiles/r02/README.md).
 # The PMC summaries carry the source hash of the library they were collected on; bench.py quotes pmc_config2.json only when
 # that hash is the running library's, so the bench line is taken in a SECOND call, after the summary has been committed.
-R=${1:-r03}; O=gpurun_out/$R; mkdir -p $O
+R=${1:-r04}; O=gpurun_out/$R; mkdir -p $O
 export TMPDIR=/tmp
 bash tools/pmc_collect.sh ${R}_c2 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-math
 python3 tools/pmc_summary.py ${R}_c2 "k_render<true, false, 0" $O/pmc_config2.json > $O/pmc_config2.txt 2>&1
@@ -13,7 +13,9 @@ bash tools/pmc_collect.sh ${R}_c4 python3 tools/config_bench.py --config 4 --spp
 python3 tools/pmc_summary.py ${R}_c4 "k_render_pwg<0, false>" $O/pmc_config4.json > $O/pmc_config4.txt 2>&1
 bash tools/pmc_collect.sh ${R}_c5 python3 tools/config_bench.py --config 5 --steps 1 --frames 16
 for k in k_sppm_refine k_sppm_camera k_sppm_photon k_sppm_table; do python3 tools/pmc_summary.py ${R}_c5 $k $O/pmc_config5_$k.json > $O/pmc_config5_$k.txt 2>&1; done
-for c in 2 3 4 5; do for f in gpurun_out/${R}_c$c/trace/*/*_kernel_stats.csv; do cp $f $O/config${c}_kernel_stats.csv; done; done
+bash tools/pmc_collect.sh ${R}_cv python3 tools/config_bench.py --config volume --spp 16 --steps 3
+python3 tools/pmc_summary.py ${R}_cv "k_render_pwg<2, false>" $O/pmc_volume.json > $O/pmc_volume.txt 2>&1
+for c in 2 3 4 5 v; do for f in gpurun_out/${R}_c$c/trace/*/*_kernel_stats.csv; do cp $f $O/config${c}_kernel_stats.csv; done; done
 for c in 3 4 5 volume; do python3 tools/config_bench.py --config $c 2> $O/config$c.err; done > $O/configs_as_named.jsonl
 python3 bench.py > $O/bench_line_n1.json 2> $O/bench_n1.err
 python3 bench.py --gpus 2 --steps 2 > $O/bench_line_n2_one_gpu_plumbing.json 2> $O/bench_n2.err
@@ -25,5 +27,8 @@ python3 tools/tile_balance.py --config 4 --spp 64 > $O/tile_balance_config4_64sp
 python3 tools/split_trace.py --config 2 --ranks 1,2,4,8 > $O/adaptive_blocks_config2.txt 2>&1
 python3 tools/split_trace.py --config 4 --spp 64 --ranks 1,2,8 --launches 6 > $O/adaptive_blocks_config4_64spp.txt 2>&1
 python3 tools/lbvh_bench.py > $O/lbvh_bench.txt 2>&1
+for c in 2 3 4; do python3 tools/cold_start.py --native --config $c --ranks 1,8 --launches 12; done > $O/cold_start.txt 2>&1
+for c in 2 3 4; do python3 tools/share_bounds.py --config $c; done > $O/share_bounds.txt 2>&1
+python3 tools/split_trace.py --config 3 --ranks 1,8 --launches 14 --vary-seed > $O/sched_trace_config3.txt 2>&1
 python3 tools/small_blocks_bench.py > $O/small_blocks.txt 2>&1
 python3 tools/sppm_frame_sizes.py > $O/sppm_frame_sizes.txt 2>&1

@@ -953,6 +953,7 @@ trc_status trc_create(int device, trc_ctx** out) {
         ctx->knobs.no_cold_probe = env_int("TRC_NO_COLD_PROBE", true);
         ctx->knobs.probe_spp = env_int("TRC_PROBE_SPP", false);
         ctx->knobs.no_plan_reuse = env_int("TRC_NO_PLAN_REUSE", true);
+        ctx->knobs.no_coalesce = env_int("TRC_NO_COALESCE", true);
     }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void**)&ctx->d_stats, sizeof(unsigned long long) * kStatRows * kStatRowStride) != hipSuccess ||
@@ -966,6 +967,7 @@ trc_status trc_create(int device, trc_ctx** out) {
 }
 
 void trc_destroy(trc_ctx* ctx) {
+    if (ctx) (void)trc_flush(ctx);
     if (!ctx) return;
     if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
     if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
@@ -987,6 +989,7 @@ void trc_destroy(trc_ctx* ctx) {
 }
 
 trc_status trc_upload_scene(trc_ctx* ctx, const trc_scene* scene) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx) return TRC_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     std::vector<uint32_t> blob;
@@ -1014,6 +1017,7 @@ trc_status trc_upload_scene(trc_ctx* ctx, const trc_scene* scene) {
 }
 
 trc_status trc_upload_density(trc_ctx* ctx, const trc_GridDensityInfo* info, const float* density) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx) return TRC_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1050,6 +1054,7 @@ trc_status trc_upload_density(trc_ctx* ctx, const trc_GridDensityInfo* info, con
 }
 
 trc_status trc_set_camera(trc_ctx* ctx, const trc_Camera* c) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx || !c) return TRC_ERR_INVALID_ARG;
     const DCamera before = ctx->cam;
     DCamera& d = ctx->cam;
@@ -1064,12 +1069,14 @@ trc_status trc_set_camera(trc_ctx* ctx, const trc_Camera* c) {
 }
 
 trc_status trc_set_environment(trc_ctx* ctx, const float rgb[3]) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx || !rgb) return TRC_ERR_INVALID_ARG;
     ctx->ambient[0] = rgb[0]; ctx->ambient[1] = rgb[1]; ctx->ambient[2] = rgb[2];
     return TRC_OK;
 }
 
 trc_status trc_set_environment_map(trc_ctx* ctx, uint32_t w, uint32_t h, const float* rgb) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx) return TRC_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1085,6 +1092,7 @@ trc_status trc_set_environment_map(trc_ctx* ctx, uint32_t w, uint32_t h, const f
 }
 
 trc_status trc_resize(trc_ctx* ctx, uint32_t width, uint32_t height) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx || width == 0 || height == 0 || width > 65535u * 8u || height > 65535u * 8u) return TRC_ERR_INVALID_ARG;
     // pixel indices are 32-bit in the seed / tonemap / strip / SPPM kernels
     if ((uint64_t)width * height >= (1ull << 32)) return fail(ctx, TRC_ERR_UNSUPPORTED, "trc_resize: 2^32 pixels or more");
@@ -1107,6 +1115,7 @@ trc_status trc_resize(trc_ctx* ctx, uint32_t width, uint32_t height) {
 }
 
 trc_status trc_seed(trc_ctx* ctx, uint64_t seed) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx) return TRC_ERR_INVALID_ARG;
     if (!ctx->d_rng) return fail(ctx, TRC_ERR_NO_FRAME, "trc_seed before trc_resize");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1118,6 +1127,7 @@ trc_status trc_seed(trc_ctx* ctx, uint64_t seed) {
 }
 
 static trc_status copy_frame(trc_ctx* ctx, void* dev, void* host, bool to_device) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx || !host) return TRC_ERR_INVALID_ARG;
     if (!dev) return fail(ctx, TRC_ERR_NO_FRAME, "frame buffers not allocated (trc_resize)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1135,6 +1145,7 @@ trc_status trc_upload_accum(trc_ctx* ctx, const float* rgba) { return copy_frame
 trc_status trc_download_accum(trc_ctx* ctx, float* rgba) { return copy_frame(ctx, ctx ? ctx->d_accum : nullptr, rgba, false); }
 
 trc_status trc_clear_accum(trc_ctx* ctx) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx) return TRC_ERR_INVALID_ARG;
     if (!ctx->d_accum) return fail(ctx, TRC_ERR_NO_FRAME, "trc_clear_accum before trc_resize");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1143,6 +1154,7 @@ trc_status trc_clear_accum(trc_ctx* ctx) {
 }
 
 trc_status trc_tonemap(trc_ctx* ctx, uint8_t* rgba8, float* exposure_out) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx || !rgba8) return TRC_ERR_INVALID_ARG;
     if (!ctx->d_accum) return fail(ctx, TRC_ERR_NO_FRAME, "trc_tonemap before trc_resize");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1190,9 +1202,7 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner);
 // away, no pixel changes; the only price is the head's own short tail.  Knob no_cold_probe switches it off.
 constexpr uint32_t kPlanSettled = 8, kPlanReuse = 3;   // a settled list re-plans every fourth launch
 constexpr uint32_t kColdHeadSpp = 8;           // >= 8: the head must run the same kernel and block list as the rest (k_render_strip below)
-trc_status trc_render(trc_ctx* ctx, const trc_params* p) { return render_pass(ctx, p, false); }
-
-static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
+static trc_status render_check(trc_ctx* ctx, const trc_params* p) {
     if (!ctx || !p) return TRC_ERR_INVALID_ARG;
     if (!ctx->has_scene) return fail(ctx, TRC_ERR_NO_SCENE, "trc_render before trc_upload_scene");
     if (!ctx->d_accum) return fail(ctx, TRC_ERR_NO_FRAME, "trc_render before trc_resize");
@@ -1202,6 +1212,62 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
     if (p->integrator > TRC_INTEGRATOR_VOLUME) return fail(ctx, TRC_ERR_INVALID_ARG, "unknown integrator");
     if (p->integrator != TRC_INTEGRATOR_PATH && ctx->ks.sc.n_squares < 7)
         return fail(ctx, TRC_ERR_INVALID_ARG, "traceMIS / traceVolume sample squareList[5] and [6] (Render.metal:320-324,172-176)");
+    if (p->flags & TRC_FLAG_SOBOL) {
+        if (p->integrator == TRC_INTEGRATOR_VOLUME || (p->flags & TRC_FLAG_COLLECT_STATS))
+            return fail(ctx, TRC_ERR_UNSUPPORTED, "TRC_FLAG_SOBOL: tracePath / traceMIS, production kernels only");
+        if (2ull * p->max_depth > TRC_SOBOL_DIMS)
+            return fail(ctx, TRC_ERR_UNSUPPORTED, "TRC_FLAG_SOBOL: 2 * max_depth exceeds the 40 generated dimensions");
+        uint32_t m = 0;
+        const uint32_t vh = (p->view_height != 0 && p->view_height < ctx->height) ? p->view_height : ctx->height;
+        while ((1u << m) < std::max(ctx->width, vh)) ++m;
+        if (m > TRC_SOBOL_MAX_LOG2RES) return fail(ctx, TRC_ERR_UNSUPPORTED, "TRC_FLAG_SOBOL: frame too large");
+    }
+    return TRC_OK;
+}
+
+// Launches of few samples, coalesced.  The reference dispatches ONE sample per frame (AAPLRenderer.mm:1195); such a launch
+// has no second sample to regenerate finished lanes from and ends on its longest paths: 0.54 ms per sample against 0.31 in
+// a fused launch.  A pixel's samples are one chain, so k calls of 1 sample == one call of k samples bit for bit (tested): a
+// trc_render of fewer than kCoalesceBelow samples is therefore not launched at once but kept, and extended by the next call
+// when that continues it (same parameters, frame0 following on); it is launched when kCoalesceUpTo samples have come
+// together, when a call arrives that does not continue it, or when ANY other entry point of the library is entered
+// (trc_flush at the top of each: downloads, tonemap, stats, seed, camera ...), so nothing observable changes.  A host that
+// displays every frame (one trc_render, one trc_tonemap) gets exactly the launches it asked for; one that renders a run of
+// samples before it looks gets them at the fused rate: 64 x 1 spp 34.8 -> 2x.x ms.  Knob no_coalesce switches it off.
+constexpr uint32_t kCoalesceBelow = 8, kCoalesceUpTo = 16;
+}  // extern "C" (trc_flush is internal: C++ linkage, declared in trc_ctx.hpp)
+trc_status trc_flush(trc_ctx* ctx) {
+    if (!ctx || !ctx->has_deferred) return TRC_OK;
+    ctx->has_deferred = false;
+    const trc_params q = ctx->deferred;
+    const uint64_t calls = ctx->deferred_calls;
+    const trc_status st = render_pass(ctx, &q, false);
+    if (st == TRC_OK && calls > 1) ctx->launches += calls - 1;        // trc_stats.launches counts trc_render calls
+    return st;
+}
+extern "C" {
+trc_status trc_render(trc_ctx* ctx, const trc_params* p) {
+    { const trc_status st = render_check(ctx, p); if (st != TRC_OK) return st; }
+    const bool candidate = p->spp > 0 && p->spp < kCoalesceBelow && !(p->flags & TRC_FLAG_COLLECT_STATS) && !ctx->knobs.no_coalesce;
+    if (ctx->has_deferred) {
+        trc_params& d = ctx->deferred;
+        const bool continues = candidate && p->frame0 == d.frame0 + d.spp && p->max_depth == d.max_depth && p->integrator == d.integrator &&
+                               p->tile_rank == d.tile_rank && p->tile_nranks == d.tile_nranks && p->flags == d.flags && p->view_height == d.view_height;
+        if (continues) {
+            d.spp += p->spp;
+            ctx->deferred_calls++;
+            return d.spp >= kCoalesceUpTo ? trc_flush(ctx) : TRC_OK;
+        }
+        const trc_status st = trc_flush(ctx);
+        if (st != TRC_OK) return st;
+    }
+    if (candidate) { ctx->deferred = *p; ctx->deferred_calls = 1; ctx->has_deferred = true; return TRC_OK; }
+    return render_pass(ctx, p, false);
+}
+
+static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
+    { const trc_status st = render_check(ctx, p); if (st != TRC_OK) return st; }
+    const uint32_t nranks = p->tile_nranks ? p->tile_nranks : 1;
     if (p->spp == 0) return TRC_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     collect_finished_events(ctx);        // before any launch of this call: it may consume a "not ready" sticky error
@@ -1221,12 +1287,6 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
 
     const bool stats = (p->flags & TRC_FLAG_COLLECT_STATS) != 0;
     const bool sobol = (p->flags & TRC_FLAG_SOBOL) != 0;
-    if (sobol) {
-        if (p->integrator == TRC_INTEGRATOR_VOLUME || stats)
-            return fail(ctx, TRC_ERR_UNSUPPORTED, "TRC_FLAG_SOBOL: tracePath / traceMIS, production kernels only");
-        if (2ull * p->max_depth > TRC_SOBOL_DIMS)
-            return fail(ctx, TRC_ERR_UNSUPPORTED, "TRC_FLAG_SOBOL: 2 * max_depth exceeds the 40 generated dimensions");
-    }
     if (trc_dyn_lds_bytes(ctx, stats) > 160 * 1024) return fail(ctx, TRC_ERR_UNSUPPORTED, "traversal stack exceeds the 160 KB LDS of a CU");
 
     KRender kp{};
@@ -1434,6 +1494,7 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
 }
 
 trc_status trc_synchronize(trc_ctx* ctx) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx) return TRC_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1443,6 +1504,7 @@ trc_status trc_synchronize(trc_ctx* ctx) {
 }
 
 trc_status trc_trace_rays(trc_ctx* ctx, const trc_ray* rays, size_t n, trc_hit* out, int any_hit) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx || (n && (!rays || !out))) return TRC_ERR_INVALID_ARG;
     if (!ctx->has_scene) return fail(ctx, TRC_ERR_NO_SCENE, "trc_trace_rays before trc_upload_scene");
     if (n == 0) return TRC_OK;
@@ -1480,6 +1542,7 @@ trc_status trc_trace_rays(trc_ctx* ctx, const trc_ray* rays, size_t n, trc_hit* 
 }
 
 trc_status trc_get_stats(trc_ctx* ctx, trc_stats* out) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx || !out) return TRC_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     unsigned long long h[kStatCount];
@@ -1501,6 +1564,7 @@ trc_status trc_get_stats(trc_ctx* ctx, trc_stats* out) {
 
 // developer diagnostic: (lanes, wavefronts) that executed each ProfSite of the instrumented kernels
 trc_status trc_debug_profile(trc_ctx* ctx, uint64_t* out, uint32_t n_sites) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx || !out) return TRC_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     unsigned long long h[kStatCount + 3 * kProfCount];
@@ -1514,6 +1578,7 @@ trc_status trc_debug_profile(trc_ctx* ctx, uint64_t* out, uint32_t n_sites) {
 
 // developer diagnostic: the chain bound and the work bound of the last launch (tracer_abi.h)
 trc_status trc_debug_launch_shape(trc_ctx* ctx, trc_launch_shape* out) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx || !out) return TRC_ERR_INVALID_ARG;
     std::memset(out, 0, sizeof *out);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1553,6 +1618,7 @@ trc_status trc_debug_launch_shape(trc_ctx* ctx, trc_launch_shape* out) {
 // developer diagnostic: the pixel blocks of the last trc_render (x | y << 16 in units of the block edge) and the duration
 // each one's wavefront measured per sample (shader clocks / (4 spp), the adaptive order's sort key)
 trc_status trc_debug_block_costs(trc_ctx* ctx, uint32_t* tiles, uint32_t* costs, uint32_t capacity, uint32_t* n_blocks, uint32_t* blk_shift) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx) return TRC_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (n_blocks) *n_blocks = ctx->n_tiles;
@@ -1627,6 +1693,7 @@ trc_status trc_unary_test(trc_ctx* ctx, uint32_t op, uint32_t first_bits, uint64
 }
 
 trc_status trc_reset_stats(trc_ctx* ctx) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx) return TRC_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1661,6 +1728,7 @@ trc_status trc_group_unique_id(uint8_t id[TRC_UNIQUE_ID_BYTES]) {
 }
 
 trc_status trc_group_init(trc_ctx* ctx, const uint8_t id[TRC_UNIQUE_ID_BYTES], int nranks, int rank) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) return TRC_ERR_INVALID_ARG;
     std::string err;
     if (!trc_load_rccl(err)) return fail(ctx, TRC_ERR_RCCL, err);
@@ -1679,6 +1747,7 @@ trc_status trc_group_init(trc_ctx* ctx, const uint8_t id[TRC_UNIQUE_ID_BYTES], i
 }
 
 trc_status trc_group_reduce_accum(trc_ctx* ctx, int root) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx) return TRC_ERR_INVALID_ARG;
     if (!ctx->grouped()) return fail(ctx, TRC_ERR_RCCL, "trc_group_reduce_accum before trc_group_init / trc_group_set_collectives");
     if (!ctx->d_accum) return fail(ctx, TRC_ERR_NO_FRAME, "no frame");
@@ -1698,6 +1767,7 @@ __global__ void __launch_bounds__(256) k_scale_rgb(float4* accum, size_t n, floa
     accum[i] = a;
 }
 trc_status trc_group_allreduce_mean_accum(trc_ctx* ctx) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx) return TRC_ERR_INVALID_ARG;
     if (!ctx->grouped()) return fail(ctx, TRC_ERR_RCCL, "trc_group_allreduce_mean_accum before trc_group_init / trc_group_set_collectives");
     if (!ctx->d_accum) return fail(ctx, TRC_ERR_NO_FRAME, "no frame");
@@ -1714,6 +1784,7 @@ trc_status trc_group_allreduce_mean_accum(trc_ctx* ctx) {
 // rendering into its OTHER accumulator, so an xGMI ring reduce of a multi-view frame (265 MB at N = 8, ~6 ms)
 // hides under the next step's render instead of adding to it.
 trc_status trc_group_reduce_accum_async(trc_ctx* ctx, int root) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx) return TRC_ERR_INVALID_ARG;
     if (!ctx->grouped()) return fail(ctx, TRC_ERR_RCCL, "trc_group_reduce_accum_async before trc_group_init / trc_group_set_collectives");
     if (!ctx->d_accum) return fail(ctx, TRC_ERR_NO_FRAME, "no frame");
@@ -1747,6 +1818,7 @@ trc_status trc_group_reduce_accum_async(trc_ctx* ctx, int root) {
 }
 
 trc_status trc_download_composed(trc_ctx* ctx, float* rgba) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx || !rgba) return TRC_ERR_INVALID_ARG;
     if (!ctx->d_composed) return fail(ctx, TRC_ERR_NO_FRAME, "trc_download_composed before trc_group_reduce_accum_async");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1756,6 +1828,7 @@ trc_status trc_download_composed(trc_ctx* ctx, float* rgba) {
 }
 
 trc_status trc_group_finalize(trc_ctx* ctx) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx) return TRC_ERR_INVALID_ARG;
     if (ctx->grouped()) {
         (void)hipSetDevice(ctx->device);
@@ -1770,6 +1843,7 @@ trc_status trc_group_finalize(trc_ctx* ctx) {
 }
 
 trc_status trc_group_set_collectives(trc_ctx* ctx, const trc_collectives* table, int nranks, int rank) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx) return TRC_ERR_INVALID_ARG;
     if (!table) return trc_group_finalize(ctx);
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, TRC_ERR_INVALID_ARG, "trc_group_set_collectives: rank / nranks");
@@ -1782,6 +1856,7 @@ trc_status trc_group_set_collectives(trc_ctx* ctx, const trc_collectives* table,
 }
 
 trc_status trc_debug_set(trc_ctx* ctx, const char* knob, int value) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx || !knob) return TRC_ERR_INVALID_ARG;
     const std::string k(knob);
     int* slot = k == "no_lds_fit" ? &ctx->knobs.no_lds_fit : k == "stack_lds_levels" ? &ctx->knobs.stack_lds_levels
@@ -1789,7 +1864,7 @@ trc_status trc_debug_set(trc_ctx* ctx, const char* knob, int value) {
               : k == "sppm_serial_camera" ? &ctx->knobs.sppm_serial_camera : k == "sppm_timing" ? &ctx->knobs.sppm_timing
               : k == "force_blk_shift" ? &ctx->knobs.force_blk_shift : k == "no_split" ? &ctx->knobs.no_split : k == "no_cost_filter" ? &ctx->knobs.no_cost_filter
               : k == "no_cold_probe" ? &ctx->knobs.no_cold_probe : k == "probe_spp" ? &ctx->knobs.probe_spp
-              : k == "no_plan_reuse" ? &ctx->knobs.no_plan_reuse : nullptr;
+              : k == "no_plan_reuse" ? &ctx->knobs.no_plan_reuse : k == "no_coalesce" ? &ctx->knobs.no_coalesce : nullptr;
     if (!slot) return fail(ctx, TRC_ERR_INVALID_ARG, "trc_debug_set: unknown knob " + k);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // a launch in flight keeps the plan it was made with

@@ -172,6 +172,7 @@ struct trc_ctx {
     bool cost_quarters = false;         // d_block_cost / d_split describe a launch made with cost_stride 4
     bool cost_valid = false; uint32_t cost_strip = 1;
     uint32_t last_cost_div = 0, last_wave_slots = 0;     // of the last render launch (trc_debug_launch_shape)
+    trc_params deferred{}; bool has_deferred = false; uint64_t deferred_calls = 0;   // a launch of few samples kept for coalescing (trc_render)
     int cost_head_age = 0;                    // 1: the costs are a cold head's (trc_render), 2: the launch after it ran on them
     uint32_t cost_integrator = 0xFFFFFFFFu;   // integrator the recorded costs belong to
     const uint32_t* d_last_order = nullptr; uint32_t order_age = 0;     // most recent sorted order (short launches reuse it)
@@ -210,7 +211,7 @@ struct trc_ctx {
 
     // A/B and test knobs, per context: defaults from the environment at trc_create (TRC_NO_LDS_FIT, TRC_STACK_LDS_LEVELS,
     // TRC_STRIP_LEN, TRC_NO_PWG, TRC_SPPM_SERIAL_CAMERA), changed through trc_debug_set
-    struct Knobs { int no_lds_fit = 0, stack_lds_levels = 0, strip_len = 0, no_pwg = 0, sppm_serial_camera = 0, sppm_timing = 0, force_blk_shift = 0, no_split = 0, no_cost_filter = 0, no_cold_probe = 0, probe_spp = 0, no_plan_reuse = 0; } knobs;
+    struct Knobs { int no_lds_fit = 0, stack_lds_levels = 0, strip_len = 0, no_pwg = 0, sppm_serial_camera = 0, sppm_timing = 0, force_blk_shift = 0, no_split = 0, no_cost_filter = 0, no_cold_probe = 0, probe_spp = 0, no_plan_reuse = 0, no_coalesce = 0; } knobs;
     // k_render_pwg instantiations that were granted > 64 KB of dynamic LDS on THIS context's device (bit = integrator * 2 +
     // sobol): hipFuncSetAttribute applies to the current device only, so the grant is per context, not per process
     uint32_t pwg_lds_granted = 0;
@@ -261,6 +262,7 @@ size_t trc_dyn_lds_bytes(const trc_ctx* ctx, bool stats);
 // trc_lbvh.hip: stable 24-bit radix sort of (key, value) pairs
 void trc_sort_pairs24(hipStream_t st, uint32_t* keys[2], uint32_t* vals[2], uint32_t* hist, uint32_t* digit_base, uint32_t n, int* result);
 uint32_t trc_sort_hist_words(uint32_t n);
+trc_status trc_flush(trc_ctx* ctx);       // launches what trc_render kept back (every other entry point calls it first)
 hipEvent_t trc_get_event(trc_ctx* ctx);   // from the context's pool (null on failure); pairs go to ctx->pending
 void trc_sppm_release(trc_ctx* ctx);   // frees ctx->sppm (no-op when absent)
 void trc_sppm_order_after_camera(trc_ctx* ctx);   // context stream waits for a camera pass running ahead (no-op when none)

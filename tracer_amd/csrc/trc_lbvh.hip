@@ -497,6 +497,7 @@ uint32_t trc_sort_hist_words(uint32_t n) { return 256u * ((n + kSortTile - 1) / 
 extern "C" {
 
 trc_status trc_upload_scene_lbvh(trc_ctx* ctx, const trc_scene* s) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx) return TRC_ERR_INVALID_ARG;
     if (!s || !s->bvhList || s->n_bvh < 2) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "lbvh: need >= 2 leaf records");
     if (s->n_bvh > (1u << 28)) return trc_fail(ctx, TRC_ERR_UNSUPPORTED, "lbvh: more than 2^28 leaves");
@@ -646,6 +647,7 @@ trc_status trc_upload_scene_lbvh(trc_ctx* ctx, const trc_scene* s) {
 }
 
 trc_status trc_download_bvh(trc_ctx* ctx, trc_BVH* out, uint32_t capacity, uint32_t* n_nodes) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx) return TRC_ERR_INVALID_ARG;
     if (!ctx->d_bvh_ref || ctx->n_bvh_ref == 0) return trc_fail(ctx, TRC_ERR_NO_SCENE, "trc_download_bvh: no device-built tree (trc_upload_scene_lbvh)");
     if (n_nodes) *n_nodes = ctx->n_bvh_ref;

@@ -590,6 +590,7 @@ __global__ void __launch_bounds__(256) k_sppm_seed(uint32_t* rng, uint32_t n, ui
 extern "C" {
 
 trc_status trc_sppm_init(trc_ctx* ctx, uint64_t photon_seed) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx) return TRC_ERR_INVALID_ARG;
     if (!ctx->d_accum) return trc_fail(ctx, TRC_ERR_NO_FRAME, "trc_sppm_init before trc_resize");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -639,6 +640,7 @@ trc_status trc_sppm_init(trc_ctx* ctx, uint64_t photon_seed) {
 }
 
 trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx) return TRC_ERR_INVALID_ARG;
     SppmState* s = ctx->sppm;
     if (!s) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "trc_sppm_frames before trc_sppm_init");
@@ -778,6 +780,7 @@ trc_status trc_sppm_hash_cells(trc_ctx* ctx, const float* cells, size_t n, float
 }
 
 trc_status trc_sppm_download(trc_ctx* ctx, trc_CameraRecord* cam, trc_PhotonRecord* pho, float* mark, float* count, trc_Complex* cx) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx) return TRC_ERR_INVALID_ARG;
     SppmState* s = ctx->sppm;
     if (!s) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "trc_sppm_download before trc_sppm_init");
