@@ -300,6 +300,9 @@ def main(argv=None):
     ap.add_argument("--no-other-scaling", action="store_true", help="N > 1: measure only the primary workload")
     ap.add_argument("--no-fast-math", action="store_true",
                     help="skip the fast_math_variant leg (profiling runs: both builds name their kernels alike)")
+    ap.add_argument("--no-cold", action="store_true",
+                    help="profiling runs: skip the cold legs and launch the first frame as ONE pass (knob no_cold_probe), so that "
+                         "every launch of the render kernel in a rocprofv3 trace is a whole 64-spp launch")
     ap.add_argument("--force-group", action="store_true",
                     help="exercise the rendezvous + RCCL compose path even with one rank (plumbing check)")
     ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)     # test hook: this rank exits with 3 at once
@@ -414,13 +417,17 @@ def main(argv=None):
             s0 = trc.stats()
             return {"first_launch_ms": round(reduce_scalar(wall, "MAX"), 3), "first_launch_kernel_ms": round(s0.kernel_ms, 3),
                     "value": round(reduce_scalar(float(s0.rays), "SUM") / reduce_scalar(wall, "MAX") / 1e3, 2)}
-        cold_single = first_launch(True)
-        cold = first_launch(False)
-        cold.update({"unit": "Mrays/s", "settle_launches": 0,
-                     "single_cold_pass_ms": cold_single["first_launch_ms"], "single_cold_pass_kernel_ms": cold_single["first_launch_kernel_ms"],
-                     "what": "first launch of the block list (fresh costs): 8-sample head + rest planned from it, wall ms incl. seed + "
-                             "launch-list kernels; single_cold_pass = the same launch as one unordered pass (knob no_cold_probe)"})
-        trc.debug_set("no_cold_probe", 0)
+        if args.no_cold:
+            trc.debug_set("no_cold_probe", 1)
+            cold = {"first_launch_ms": None, "skipped": "--no-cold"}
+        else:
+            cold_single = first_launch(True)
+            cold = first_launch(False)
+            cold.update({"unit": "Mrays/s", "settle_launches": 0,
+                         "single_cold_pass_ms": cold_single["first_launch_ms"], "single_cold_pass_kernel_ms": cold_single["first_launch_kernel_ms"],
+                         "what": "first launch of the block list (fresh costs): 8-sample head + rest planned from it, wall ms incl. seed + "
+                                 "launch-list kernels; single_cold_pass = the same launch as one unordered pass (knob no_cold_probe)"})
+            trc.debug_set("no_cold_probe", 0)
 
         # exact algorithmic work of ONE step on this rank (instrumented kernel, untimed)
         trc.reset_stats()

@@ -16,6 +16,7 @@ ap.add_argument("--spp", type=int, default=0)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--warmup", type=int, default=1)
 ap.add_argument("--frames", type=int, default=64, help="config 5: SPPM frames per step")
+ap.add_argument("--no-cold", action="store_true", help="profiling runs: the first launch as ONE pass (knob no_cold_probe), so every launch of the kernel in a trace is a whole one")
 a = ap.parse_args()
 W, H = wlmod.W, wlmod.H
 t = Tracer(0)
@@ -57,6 +58,8 @@ if a.config == "5":
 wl = wlmod.make(a.config)
 spp = a.spp or wl["spp"]
 wlmod.setup(t, wl)
+if a.no_cold:
+    t.debug_set("no_cold_probe", 1)
 t.seed(0x5EED0000); t.reset_stats()
 t.render(spp=spp, integrator=wl["integrator"], collect_stats=True); t.synchronize()
 s1 = t.stats()

@@ -11,6 +11,9 @@ doubled; GRBM_GUI_ACTIVE is summed over the 8 XCDs; a wave64 VALU instruction is
 import collections, csv, glob, hashlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, sub, out_path = sys.argv[1], sys.argv[2], sys.argv[3]
+# only the LAST n launches of the kernel count (the program's timed, settled steps: a first launch runs as an 8-sample head + the
+# rest, an instrumented or cold launch is another workload); 0 = all of them
+last_n = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 
 
 def lib_source_hash():
@@ -33,8 +36,12 @@ if kernel is None:
 vals = collections.defaultdict(list)
 meta = {}
 for f in glob.glob(f"gpurun_out/{tag}/pmc_*/*/*_counter_collection.csv"):
-    for r in csv.DictReader(open(f)):
-        if r["Kernel_Name"] == kernel:
+    rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"] == kernel]
+    if last_n:
+        ids = sorted({int(r["Dispatch_Id"]) for r in rows})[-last_n:]
+        rows = [r for r in rows if int(r["Dispatch_Id"]) in ids]
+    for r in rows:
+        if True:
             vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta = {"VGPR_Count": int(r["VGPR_Count"]), "LDS_Block_Size": int(r["LDS_Block_Size"]),
                     "Scratch_Size": int(r.get("Scratch_Size", 0) or 0), "Workgroup_Size": int(r["Workgroup_Size"]),
@@ -45,6 +52,12 @@ for c, v in sorted(vals.items()):
     res[c] = sum(v) / len(v)
 res["launches_sampled"] = {c: len(v) for c, v in vals.items()}
 res["kernel_ms"] = float(stats_row["AverageNs"]) / 1e6
+if last_n:                                  # the same launches' durations from the kernel trace
+    for f in glob.glob(f"gpurun_out/{tag}/trace/*/*_kernel_trace.csv"):
+        tr = sorted([r for r in csv.DictReader(open(f)) if r["Kernel_Name"] == kernel], key=lambda r: int(r["Start_Timestamp"]))[-last_n:]
+        if tr:
+            res["kernel_ms"] = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr) / len(tr) / 1e6
+            res["kernel_ms_launches"] = len(tr)
 res["kernel_stats_row"] = stats_row
 if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
     res["hbm_bytes_per_launch"] = int((2 * res["FETCH_SIZE"] + res["WRITE_SIZE"]) * 1024)

@@ -5,18 +5,19 @@
 # that hash is the running library's, so the bench line is taken in a SECOND call, after the summary has been committed.
 R=${1:-r04}; O=gpurun_out/$R; mkdir -p $O
 export TMPDIR=/tmp
-bash tools/pmc_collect.sh ${R}_c2 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-math
-python3 tools/pmc_summary.py ${R}_c2 "k_render<true, false, 0" $O/pmc_config2.json > $O/pmc_config2.txt 2>&1
-bash tools/pmc_collect.sh ${R}_c3 python3 tools/config_bench.py --config 3 --spp 32 --steps 3
-python3 tools/pmc_summary.py ${R}_c3 "k_render_pwg<1, false>" $O/pmc_config3.json > $O/pmc_config3.txt 2>&1
-bash tools/pmc_collect.sh ${R}_c4 python3 tools/config_bench.py --config 4 --spp 32 --steps 3
-python3 tools/pmc_summary.py ${R}_c4 "k_render_pwg<0, false>" $O/pmc_config4.json > $O/pmc_config4.txt 2>&1
+bash tools/pmc_collect.sh ${R}_c2 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-math --no-cold
+python3 tools/pmc_summary.py ${R}_c2 "k_render<true, false, 0" $O/pmc_config2.json 6 > $O/pmc_config2.txt 2>&1      # 3 timed + 3 vary-seed steps
+bash tools/pmc_collect.sh ${R}_c3 python3 tools/config_bench.py --config 3 --spp 32 --steps 3 --warmup 8 --no-cold
+python3 tools/pmc_summary.py ${R}_c3 "k_render_pwg<1, false>" $O/pmc_config3.json 3 > $O/pmc_config3.txt 2>&1
+bash tools/pmc_collect.sh ${R}_c4 python3 tools/config_bench.py --config 4 --spp 32 --steps 3 --warmup 8 --no-cold
+python3 tools/pmc_summary.py ${R}_c4 "k_render_pwg<0, false>" $O/pmc_config4.json 3 > $O/pmc_config4.txt 2>&1
 bash tools/pmc_collect.sh ${R}_c5 python3 tools/config_bench.py --config 5 --steps 1 --frames 16
 for k in k_sppm_refine k_sppm_camera k_sppm_photon k_sppm_table; do python3 tools/pmc_summary.py ${R}_c5 $k $O/pmc_config5_$k.json > $O/pmc_config5_$k.txt 2>&1; done
-bash tools/pmc_collect.sh ${R}_cv python3 tools/config_bench.py --config volume --spp 16 --steps 3
-python3 tools/pmc_summary.py ${R}_cv "k_render_pwg<2, false>" $O/pmc_volume.json > $O/pmc_volume.txt 2>&1
+bash tools/pmc_collect.sh ${R}_cv python3 tools/config_bench.py --config volume --spp 16 --steps 3 --warmup 8 --no-cold
+python3 tools/pmc_summary.py ${R}_cv "k_render_pwg<2, false>" $O/pmc_volume.json 3 > $O/pmc_volume.txt 2>&1
 for c in 2 3 4 5 v; do for f in gpurun_out/${R}_c$c/trace/*/*_kernel_stats.csv; do cp $f $O/config${c}_kernel_stats.csv; done; done
-for c in 3 4 5 volume; do python3 tools/config_bench.py --config $c 2> $O/config$c.err; done > $O/configs_as_named.jsonl
+for c in 3 4 volume; do python3 tools/config_bench.py --config $c --warmup 8 2> $O/config$c.err; done > $O/configs_as_named.jsonl
+python3 tools/config_bench.py --config 5 2> $O/config5.err >> $O/configs_as_named.jsonl
 python3 bench.py > $O/bench_line_n1.json 2> $O/bench_n1.err
 python3 bench.py --gpus 2 --steps 2 > $O/bench_line_n2_one_gpu_plumbing.json 2> $O/bench_n2.err
 python3 bench.py --gpus 8 --steps 2 --no-other-scaling > $O/bench_line_n8_one_gpu_plumbing.json 2> $O/bench_n8.err
