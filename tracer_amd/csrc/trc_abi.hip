@@ -715,6 +715,7 @@ trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32
     (void)hipFree(ctx->d_qwhole); ctx->d_qwhole = nullptr;
     (void)hipFree(ctx->d_launch); ctx->d_launch = nullptr;
     (void)hipFree(ctx->d_plan_gather); ctx->d_plan_gather = nullptr;
+    (void)hipFree(ctx->d_cost_scratch); ctx->d_cost_scratch = nullptr;
     ctx->plan_streak = 0;
     ctx->cost_valid = false; ctx->d_last_order = nullptr; ctx->cost_quarters = false; ctx->launch_cap = 0;
     ctx->n_tiles = (uint32_t)tiles.size();
@@ -727,7 +728,8 @@ trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_qsplit, tiles.size() * 16));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_qwhole, tiles.size() * 16));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_launch, tiles.size() * 4 * kCostSlots));
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_plan_gather, tiles.size() * 4 * 6));      // k_plan_gather: part, raw, 4 quarters per rank
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_plan_gather, tiles.size() * 4 * 6));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_cost_scratch, tiles.size() * 4 * kCostSlots));   // where instrumented launches leave their durations      // k_plan_gather: part, raw, 4 quarters per rank
         if (!ctx->d_plan) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_plan, 8 * sizeof(uint32_t)));
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_plan, 0, 8 * sizeof(uint32_t), ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_split, 0, tiles.size() * 4, ctx->stream));
@@ -978,7 +980,7 @@ void trc_destroy(trc_ctx* ctx) {
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     (void)hipFree(ctx->d_blob); (void)hipFree(ctx->d_bvh_ref); (void)hipFree(ctx->d_density); (void)hipFree(ctx->d_occupancy); (void)hipFree(ctx->d_envmap); (void)hipFree(ctx->d_sobol32); (void)hipFree(ctx->d_sobol_vdc); (void)hipFree(ctx->d_rng); (void)hipFree(ctx->d_accum);
     (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_stats); (void)hipFree(ctx->d_stats_sum); (void)hipFree(ctx->d_reduce_recv);
-    (void)hipFree(ctx->d_block_cost); (void)hipFree(ctx->d_order_hist); (void)hipFree(ctx->d_split); (void)hipFree(ctx->d_whole); (void)hipFree(ctx->d_cost_est); (void)hipFree(ctx->d_qsplit); (void)hipFree(ctx->d_qwhole); (void)hipFree(ctx->d_launch); (void)hipFree(ctx->d_plan); (void)hipFree(ctx->d_plan_gather);
+    (void)hipFree(ctx->d_block_cost); (void)hipFree(ctx->d_order_hist); (void)hipFree(ctx->d_split); (void)hipFree(ctx->d_whole); (void)hipFree(ctx->d_cost_est); (void)hipFree(ctx->d_qsplit); (void)hipFree(ctx->d_qwhole); (void)hipFree(ctx->d_launch); (void)hipFree(ctx->d_plan); (void)hipFree(ctx->d_plan_gather); (void)hipFree(ctx->d_cost_scratch);
     for (int k = 0; k < 2; ++k) { (void)hipFree(ctx->d_order_keys[k]); (void)hipFree(ctx->d_order_vals[k]); }
     (void)hipFree(ctx->d_accum_alt); (void)hipFree(ctx->d_stack_ovf); (void)hipFree(ctx->d_queue);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
@@ -1300,7 +1302,9 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
     kp.tiles = ctx->d_tiles;
     kp.blk_shift = blk_shift;
     kp.stats = ctx->d_stats;
-    kp.block_cost = ctx->d_block_cost;
+    // An instrumented launch (one wavefront per SIMD, counters in every loop) is no measurement of the production kernels'
+    // blocks: its durations go to a scratch array, and it neither reads nor changes what the context knows about block costs.
+    kp.block_cost = (p->flags & TRC_FLAG_COLLECT_STATS) ? ctx->d_cost_scratch : ctx->d_block_cost;
     kp.cost_div = std::max(1u, 4u * std::min(p->spp, 1u << 28));
     kp.order = nullptr;
     // launches of few samples per pixel give every wavefront a strip of consecutive blocks (k_render_strip); the unit of the
@@ -1324,10 +1328,10 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
     // quarters.  Pixels depend on neither.
     const bool quarters_ok = kp.strip == 1 && blk_shift == 3;             // the list's blocks are 8x8: costs live in 4 slots per block
     kp.cost_stride = quarters_ok ? kCostSlots : 1u;
-    if (ctx->cost_strip != kp.strip || ctx->cost_quarters != quarters_ok) {
+    if (!stats && (ctx->cost_strip != kp.strip || ctx->cost_quarters != quarters_ok)) {
         ctx->cost_valid = false; ctx->cost_strip = kp.strip; ctx->cost_quarters = quarters_ok; ctx->d_last_order = nullptr;
     }
-    if (ctx->cost_integrator != p->integrator) { ctx->cost_valid = false; ctx->cost_integrator = p->integrator; ctx->d_last_order = nullptr; }
+    if (!stats && ctx->cost_integrator != p->integrator) { ctx->cost_valid = false; ctx->cost_integrator = p->integrator; ctx->d_last_order = nullptr; }
     {
         const uint32_t head = std::max(kColdHeadSpp, (uint32_t)ctx->knobs.probe_spp);
         if (!inner && !ctx->cost_valid && !stats && !ctx->knobs.no_cold_probe && !(p->flags & TRC_FLAG_FIXED_ORDER) && kp.strip == 1 &&
@@ -1348,11 +1352,13 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
     const uint32_t waves_per_simd = p->integrator == TRC_INTEGRATOR_PATH ? (ctx->lds_scene ? TRC_PATH_WAVES : TRC_PATH_WAVES_GLOBAL)
                                   : p->integrator == TRC_INTEGRATOR_MIS ? TRC_MIS_WAVES : TRC_VOLUME_WAVES;
     const uint32_t wave_slots = (uint32_t)ctx->cu_count * 4u * waves_per_simd;
-    ctx->last_cost_div = kp.cost_div; ctx->last_wave_slots = wave_slots;
-    if (!ctx->cost_valid || (p->flags & TRC_FLAG_FIXED_ORDER) || kp.strip > 1) ctx->plan_streak = 0;      // nothing settled to reuse
+    if (!stats) { ctx->last_cost_div = kp.cost_div; ctx->last_wave_slots = wave_slots; }
+    if (stats) {} else if (!ctx->cost_valid || (p->flags & TRC_FLAG_FIXED_ORDER) || kp.strip > 1) ctx->plan_streak = 0;      // nothing settled to reuse
     uint32_t grid_cap = ctx->n_tiles;                                     // workgroups of a one-block-per-workgroup launch
     bool planned = false;
-    if (ctx->cost_valid && !(p->flags & TRC_FLAG_FIXED_ORDER) && kp.strip > 1 && ctx->d_last_order && ctx->order_age < 4) {
+    if (stats) {
+        // row-major, every block whole, nothing recorded
+    } else if (ctx->cost_valid && !(p->flags & TRC_FLAG_FIXED_ORDER) && kp.strip > 1 && ctx->d_last_order && ctx->order_age < 4) {
         kp.order = ctx->d_last_order;              // short launches: the order of a few launches ago is as good, and 13 tiny
         ctx->order_age++;                          // sort launches per 0.7 ms render are not
     } else if (ctx->cost_valid && !(p->flags & TRC_FLAG_FIXED_ORDER)) {
@@ -1415,15 +1421,17 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
         grid_cap = 4u * ctx->n_tiles;
         planned = true;
     }
-    if (!planned && ctx->split_live) {                                    // this launch runs every block whole
+    if (!stats && !planned && ctx->split_live) {                          // this launch runs every block whole
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_split, 0, (size_t)ctx->n_tiles * 4, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_qsplit, 0, (size_t)ctx->n_tiles * 16, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_cost_est, 0, (size_t)ctx->n_tiles * 4 * kCostSlots, ctx->stream));   // slot 0 held first quarters
     }
-    ctx->split_live = planned;
-    if (!ctx->cost_valid) HIP_TRY(ctx, hipMemsetAsync(ctx->d_cost_est, 0, (size_t)ctx->n_tiles * 4 * kCostSlots, ctx->stream));
-    ctx->cost_head_age = (ctx->cost_valid && ctx->cost_head_age == 1) ? 2 : 0;     // head -> the launch on its costs -> settled
-    ctx->cost_valid = true;
+    if (!stats) ctx->split_live = planned;
+    if (!stats && !ctx->cost_valid) HIP_TRY(ctx, hipMemsetAsync(ctx->d_cost_est, 0, (size_t)ctx->n_tiles * 4 * kCostSlots, ctx->stream));
+    if (!stats) {
+        ctx->cost_head_age = (ctx->cost_valid && ctx->cost_head_age == 1) ? 2 : 0;     // head -> the launch on its costs -> settled
+        ctx->cost_valid = true;
+    }
     kp.density = ctx->d_density;
     kp.dinfo = ctx->dinfo;
     kp.occupancy = ctx->d_occupancy;

@@ -165,6 +165,7 @@ struct trc_ctx {
     uint32_t* d_qwhole = nullptr;       // [4 n] ... and what it cost when it last ran as one quarter
     uint32_t* d_launch = nullptr;
     uint32_t* d_plan = nullptr;
+    uint32_t* d_cost_scratch = nullptr;  // durations of instrumented launches (never read)
     uint32_t* d_plan_gather = nullptr;  // k_plan_gather's dense per-rank arrays (6 words per block)
     uint32_t plan_streak = 0, plan_reused = 0, plan_n = 0, plan_wave_slots = 0, plan_grid_cap = 0; bool plan_split_mode = false;   // plan reuse (trc_render)
     uint32_t launch_cap = 0;            // entries d_launch holds = the grid of a launch that may split
