@@ -413,7 +413,16 @@ trc_status trc_tonemap(trc_ctx* ctx, uint8_t* rgba8, float* exposure_out);
 /* replaces -[AAPLRenderer render:] + kernelPathTracing dispatch
  * (AAPLRenderer.mm:1134-1196, Render.metal:495-558); asynchronous on the
  * context stream; spp samples are fused into one launch with bit-identical
- * results to spp launches of 1 sample. */
+ * results to spp launches of 1 sample.
+ * Coalesced launches: a call of fewer than 8 samples (without TRC_FLAG_COLLECT_STATS) is not launched at once but kept, and
+ * extended by following calls that continue it (identical parameters, frame0 = where it ends); it is launched when 16 samples
+ * have come together, when a call arrives that does not continue it, or when ANY other trc_* entry point taking this context is
+ * entered (each launches what was kept before it does anything else).  Results, statistics (trc_stats.launches counts
+ * calls) and error behaviour of parameter checks are those of launching every call at once; a HIP error of a kept launch
+ * is returned by the call that launches it.  Knob "no_coalesce" (trc_debug_set) launches every call at once.
+ * First launch of a block list (new context, frame size, tile share, scene, camera, integrator), >= 16 samples: run as a
+ * head of 8 samples followed by the rest, which is ordered and split by the head's per-block durations -- the same pixels
+ * (a pixel's samples are one chain through its RNG texel); knob "no_cold_probe" runs it as one pass. */
 trc_status trc_render(trc_ctx* ctx, const trc_params* params);
 trc_status trc_synchronize(trc_ctx* ctx);
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """SPPM frame time against the frame size (one frame per call: even / odd frames; odd frames re-run the camera pass).
-A pass bound by its slowest wavefront would cost the same on a 64x36 frame; the camera pass did not."""
+A pass bound by its slowest wavefront would cost the same on a 64x36 frame; the camera pass did not (docs/HISTORY.md section 9)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tracer_amd import abi, host

@@ -532,7 +532,7 @@ TRC_DEV void trav_build_record(const SceneRef& S, const Ray& ray, HitRec& rec, c
 //     TRC_DESCEND_MIN_GLOBAL lanes are still descending while others wait with a leaf: a few lanes of a mesh ray
 //     batch walk 50-300 nodes while their neighbours need 10, and a dependent L2 round trip per step makes waiting
 //     for them the dominant cost (config 3: 77.8 -> 70.7 ms, config 4: 40.9 -> 35.7 ms with 8; 2 / 4 / 6 / 12 / 16 /
-//     24 / 40 measured: tools/ab_bench.py).  The stragglers resume in the next round;
+//     24 / 40 measured: tools/ab_bench.py, docs/HISTORY.md 4.1).  The stragglers resume in the next round;
 //   * on an LDS-resident tree the plain round is the fastest (22.7 ms; thresholds 2..40: 24.0-25.5 ms).
 // Round 1 shipped a SPECULATIVE round instead (Aila & Laine 2009: a lane that reaches a leaf early postpones it and keeps
 // descending against its not-yet-updated closest hit).  That visits a superset of the reference's boxes and can test a

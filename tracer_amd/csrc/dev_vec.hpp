@@ -116,7 +116,7 @@ TRC_DEV bool is_nan(float x) { return x != x; }
 // [2^-60, 2^60] (no scaling would have happened: exponent difference < 96, no denormal operand, quotient or reciprocal), a
 // zero numerator is the signed zero of the product, everything else -- denormals, huge values, infinities, NaNs, a zero
 // divisor -- goes through the plain division.  tests/test_gpu_divby.py compares it with `/` bit for bit over adversarial
-// operand pairs (trc_div_by_test).  Whether it pays depends on how many quotients share a divisor: DESIGN.md section 9.
+// operand pairs (trc_div_by_test).  Whether it pays depends on how many quotients share a divisor: docs/HISTORY.md section 9.
 struct GuardedDivBy { float b, y; bool ok; };
 TRC_DEV bool div_in_range(float x) { const float ax = fabsf(x); return ax >= 0x1p-60f && ax <= 0x1p60f; }
 TRC_DEV GuardedDivBy guarded_div_by(float b) {

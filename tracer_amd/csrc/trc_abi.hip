@@ -1350,7 +1350,7 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
                            !(p->flags & (TRC_FLAG_LARGE_BLOCKS | TRC_FLAG_FIXED_ORDER));
     // wavefront slots of the kernel this launch runs (the plan's model; the launch bounds of k_render / k_render_pwg)
     const uint32_t waves_per_simd = p->integrator == TRC_INTEGRATOR_PATH ? (ctx->lds_scene ? TRC_PATH_WAVES : TRC_PATH_WAVES_GLOBAL)
-                                  : p->integrator == TRC_INTEGRATOR_MIS ? TRC_MIS_WAVES : TRC_VOLUME_WAVES;
+                                  : p->integrator == TRC_INTEGRATOR_MIS ? (ctx->lds_scene ? TRC_MIS_WAVES_LDS : TRC_MIS_WAVES) : TRC_VOLUME_WAVES;
     const uint32_t wave_slots = (uint32_t)ctx->cu_count * 4u * waves_per_simd;
     if (!stats) { ctx->last_cost_div = kp.cost_div; ctx->last_wave_slots = wave_slots; }
     if (stats) {} else if (!ctx->cost_valid || (p->flags & TRC_FLAG_FIXED_ORDER) || kp.strip > 1) ctx->plan_streak = 0;      // nothing settled to reuse

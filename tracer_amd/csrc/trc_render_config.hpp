@@ -39,7 +39,10 @@ constexpr bool hybrid_stack(int integrator) {
 #define TRC_PATH_WAVES_GLOBAL 8
 #endif
 #ifndef TRC_MIS_WAVES
-#define TRC_MIS_WAVES 8
+#define TRC_MIS_WAVES 8              // traceMIS on a tree read from memory (latency-bound: occupancy pays, round 4)
+#endif
+#ifndef TRC_MIS_WAVES_LDS
+#define TRC_MIS_WAVES_LDS 8          // ... and on an LDS-resident one (Cornell + spheres, 32 spp: 16.7 ms at 4 waves and 128 registers, 15.9 at 5, 15.6 at 8 with 64)
 #endif
 #ifndef TRC_VOLUME_WAVES
 #define TRC_VOLUME_WAVES 4

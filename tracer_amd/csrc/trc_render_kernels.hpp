@@ -125,7 +125,7 @@ __device__ __forceinline__ void render_block(const KRender& kp, const DScene& sc
 }
 
 template <bool LDS, bool STATS, int INTEGRATOR, bool SOBOL>
-__global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRATOR_VOLUME ? TRC_VOLUME_WAVES : (INTEGRATOR == TRC_INTEGRATOR_MIS ? TRC_MIS_WAVES : (LDS ? TRC_PATH_WAVES : TRC_PATH_WAVES_GLOBAL)))) k_render(const KRender kp) {
+__global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRATOR_VOLUME ? TRC_VOLUME_WAVES : (INTEGRATOR == TRC_INTEGRATOR_MIS ? (LDS ? TRC_MIS_WAVES_LDS : TRC_MIS_WAVES) : (LDS ? TRC_PATH_WAVES : TRC_PATH_WAVES_GLOBAL)))) k_render(const KRender kp) {
     if (kp.n_launch && blockIdx.x >= *kp.n_launch) return;      // the grid is sized for the most quarters a plan may splice in
     const DScene& sc = kp.ks.sc;
     const uint32_t* small_base = stage_scene(sc);
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
 // per CU leave room for ~45 nodes (5 levels) each.  Here a workgroup is as many wavefronts as one (tracePath: half a) CU
 // holds, they stage ONE prefix -- 30-60 KB, the top 9-10 levels -- and then every wavefront on its own pulls pixel
 // blocks from a device-wide queue in the launch order (longest first) until it is empty, so no wavefront slot waits
-// for a sibling (what cost the 4-wavefront workgroups of DESIGN section 9 their 20 %).  Same blocks, same arithmetic per
+// for a sibling (what cost the 4-wavefront workgroups of docs/HISTORY.md section 9 their 20 %).  Same blocks, same arithmetic per
 // lane.  Measured (profiles/r02/persistent_workgroups.txt): 2.4-3 % on configs 3 / 4 and the traceVolume scene -- most
 // of a mesh ray's steps are deep in the tree, below any prefix.  Workgroup shapes: tracePath 12 wavefronts x 2 per CU (10
 // x 2 leaves the SIMDs 3+3+2+2 and only one workgroup fits: 48 ms; 8 x 3: 36.8 against 31.1), the others 16 x 1 (8 x 2: +0.5 %).

@@ -687,7 +687,7 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
     };
     // The camera pass of an odd frame depends on nothing the photon / refine passes produce (its RNG texels, the scene,
     // the copy of the visible points it reads), and it lasts as long as its slowest wavefront -- an 8-bounce specular
-    // chain, 0.4 ms at 1080p with the GPU 90 % idle.  So it runs on its own stream, reading copy
+    // chain, 0.4 ms at 1080p with the GPU 90 % idle (docs/HISTORY.md section 9).  So it runs on its own stream, reading copy
     // `cur` of the visible points and writing copy `cur ^ 1`, after everything queued so far on the context stream (the
     // refines that still read the copy it overwrites); the refine of ITS frame waits for it and switches copies.  Within
     // one call it is started a whole frame early, at the top of the even frame before.
