@@ -34,7 +34,7 @@ extern "C" {
  *    to mean any-hit); trc_build_flavor, trc_sppm_hash_cells, trc_host_scene_load_pbrt, trc_host_mesh_from_arrays added
  * 3: trc_group_set_collectives, trc_debug_set, trc_debug_block_costs; trc_pbrt_info / trc_pbrt_shape grew (textures,
  *    plymesh / disk / cylinder); trc_host_mesh_load_ply, trc_host_load_hdr, trc_div_by_test
- * 4: trc_debug_launch_shape, trc_unary_test; trc_stats.schedule_ms; knob no_plan_reuse; trc_debug_block_costs reports durations per SAMPLE (shader clocks / (4 spp)); knobs
+ * 4: trc_debug_launch_shape, trc_unary_test; grouped trc_sppm_download of the photon records is collective; trc_stats.schedule_ms; knob no_plan_reuse; trc_debug_block_costs reports durations per SAMPLE (shader clocks / (4 spp)); knobs
  *    no_cold_probe / probe_spp (the first launch of a block list runs as an 8-sample head + the rest, trc_render) */
 #define TRC_ABI_VERSION 4
 
@@ -478,7 +478,10 @@ trc_status trc_sppm_init(trc_ctx* ctx, uint64_t photon_seed);
  * photon bounce, hashing, mark/count grid, photon sum, progressive refine into the accumulator) */
 trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames);
 /* any pointer may be NULL.  mark: 4 floats per cell as texturePhotonMark (x, y of the winning photon,
- * cell x, y; -1 when empty), count: 1 float per cell as texturePhotonCount */
+ * cell x, y; -1 when empty), count: 1 float per cell as texturePhotonCount.
+ * With a communicator / collectives table and photon_records != NULL the call is COLLECTIVE (every rank makes it): the
+ * per-frame exchange moves only the 40 bytes of a photon the hash / table / refine passes read, the whole 80-byte records
+ * of the other ranks' photons are all-gathered here, on demand. */
 trc_status trc_sppm_download(trc_ctx* ctx, trc_CameraRecord* camera_records /* W*H */,
                              trc_PhotonRecord* photon_records /* 512*512 */, float* mark /* 512*512*4 */,
                              float* count /* 512*512 */, trc_Complex* complex);

@@ -28,19 +28,17 @@ def _n_gpus():
 WORKER = textwrap.dedent("""
     import os, sys
     import numpy as np
-    import torch.distributed as dist
     sys.path.insert(0, os.environ["TRC_ROOT"])
     from tracer_amd import abi, host
     from tracer_amd.device import Tracer, group_unique_id
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tracer_amd.socket_group import SocketGroup
+    group = SocketGroup.from_env()
+    rank, world = group.rank, group.world
     W, H, spp = 320, 192, 6
     scene = host.HostScene(abi.SCENE_CORNELL_SPHERES)
     t = Tracer(rank)
     t.upload_scene(scene.view); t.set_camera(host.prepare_camera(W, H)); t.set_environment((0.0, 0.0, 0.0)); t.resize(W, H)
-    ids = [group_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(ids, src=0)
-    t.group_init(ids[0], world, rank)
+    t.group_init(group.broadcast(group_unique_id() if rank == 0 else None), world, rank)
     out = {}
     # path-traced frame, synchronous and pipelined compose (three steps in flight)
     t.clear_accum(); t.seed(31); t.render(spp=spp, tile_rank=rank, tile_nranks=world); t.group_reduce_accum(0)
@@ -57,7 +55,7 @@ WORKER = textwrap.dedent("""
         out["sppm"] = t.download_accum(); out["pho"] = pho.view(np.uint8); out["count"] = count
         out["total"] = np.float32(cx.totalPhotonSum)
         np.savez(os.environ["TRC_OUT"], **out)
-    t.group_finalize(); dist.barrier(); dist.destroy_process_group(); t.close()
+    t.group_finalize(); group.barrier(); group.close(); t.close()
 """)
 
 

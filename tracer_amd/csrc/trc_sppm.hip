@@ -358,12 +358,38 @@ __global__ void __launch_bounds__(kBlock, TRC_SPPM_PHOTON_WAVES) k_sppm_photon(c
     if ((threadIdx.x & 63u) == 0 && r) atomicAdd(&stat_row(kp.stats, blockIdx.x)[kStatRays], (unsigned long long)r);
 }
 
+// What the passes AFTER the photon pass read of a photon: position, direction, flux and whether it is active -- 40 of the
+// record's 80 bytes (normal and step belong to the photon's own bounce chain, i.e. to the rank that owns it).  With several
+// ranks that is what crosses the links every frame: rank r packs its own photon range into `wire`, ONE in-place all-gather
+// moves 10.5 MB instead of 21 MB, and the hash / table passes read the wire records; the full records are gathered only
+// when a host asks for them (trc_sppm_download).  One rank: no wire, the passes read the records themselves.
+struct PhotonWire { float position[3], direction[3], flux[3]; uint32_t active; };
+static_assert(sizeof(PhotonWire) == 40, "wire record");
+__global__ void __launch_bounds__(256) k_sppm_pack_wire(const trc_PhotonRecord* pho, PhotonWire* wire, uint32_t first, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const trc_PhotonRecord& r = pho[first + i];
+    PhotonWire w;
+    w.position[0] = r.position.x; w.position[1] = r.position.y; w.position[2] = r.position.z;
+    w.direction[0] = r.direction.x; w.direction[1] = r.direction.y; w.direction[2] = r.direction.z;
+    w.flux[0] = r.flux.x; w.flux[1] = r.flux.y; w.flux[2] = r.flux.z;
+    w.active = r.active ? 1u : 0u;
+    wire[first + i] = w;
+}
+struct PhotonView {                      // one of the two is null
+    const trc_PhotonRecord* pho; const PhotonWire* wire;
+    __device__ __forceinline__ bool active(uint32_t i) const { return wire ? wire[i].active != 0u : pho[i].active != 0; }
+    __device__ __forceinline__ F3 position(uint32_t i) const { return wire ? f3(wire[i].position[0], wire[i].position[1], wire[i].position[2]) : ld3(pho[i].position); }
+    __device__ __forceinline__ F3 direction(uint32_t i) const { return wire ? f3(wire[i].direction[0], wire[i].direction[1], wire[i].direction[2]) : ld3(pho[i].direction); }
+    __device__ __forceinline__ F3 flux(uint32_t i) const { return wire ? f3(wire[i].flux[0], wire[i].flux[1], wire[i].flux[2]) : ld3(pho[i].flux); }
+};
+
 // kernelPhotonHashing + point raster (PhotonMarkVS/FS), Photon.metal:386-456
-__global__ void __launch_bounds__(256) k_sppm_hash(const trc_PhotonRecord* pho, uint32_t* mark, uint32_t* count, const DComplex* cx) {
+__global__ void __launch_bounds__(256) k_sppm_hash(const PhotonView pv, uint32_t* mark, uint32_t* count, const DComplex* cx) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= kHashN * kHashN) return;
-    if (!pho[idx].active) return;            // z = -1: clipped
-    const F3 position = ld3(pho[idx].position);
+    if (!pv.active(idx)) return;            // z = -1: clipped
+    const F3 position = pv.position(idx);
     const float scale = cx->hash_scale;
     F3 hi = (position - f3(cx->box_min[0], cx->box_min[1], cx->box_min[2])) * scale;
     hi = f3(floorf(hi.x), floorf(hi.y), floorf(hi.z));
@@ -387,7 +413,7 @@ __global__ void __launch_bounds__(256) k_sppm_hash(const trc_PhotonRecord* pho, 
 //                                                                      photon that passed the distance test
 // Record 512*512 stands for the reference's out-of-range texture read (returns 0: photon (0,0), count 0,
 // Photon.metal:556-558).  (grid-stride: 128 workgroups, so the single counter sees 512 atomics per frame, not 4096)
-__global__ void __launch_bounds__(256) k_sppm_table(const uint32_t* mark, const uint32_t* count, const trc_PhotonRecord* pho,
+__global__ void __launch_bounds__(256) k_sppm_table(const uint32_t* mark, const uint32_t* count, const PhotonView pv,
                                                     float4* cells, DComplex* cx) {
     uint32_t v = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= kHashN * kHashN; i += gridDim.x * blockDim.x) {
@@ -396,10 +422,10 @@ __global__ void __launch_bounds__(256) k_sppm_table(const uint32_t* mark, const 
         v += c > 0 ? (c > 1u ? c : 1u) : 0u;
         float4 q0 = make_float4(0, 0, 0, -1.0f), q1 = make_float4(0, 0, 0, 0), q2 = q1;
         if (mk != 0u) {
-            const trc_PhotonRecord& ph = pho[mk - 1u];
-            q0 = make_float4(ph.position.x, ph.position.y, ph.position.z, (float)c);
-            q1 = make_float4(ph.direction.x, ph.direction.y, ph.direction.z, 0.0f);
-            q2 = make_float4(ph.flux.x, ph.flux.y, ph.flux.z, 0.0f);
+            const F3 pp = pv.position(mk - 1u), pd = pv.direction(mk - 1u), pf = pv.flux(mk - 1u);
+            q0 = make_float4(pp.x, pp.y, pp.z, (float)c);
+            q1 = make_float4(pd.x, pd.y, pd.z, 0.0f);
+            q2 = make_float4(pf.x, pf.y, pf.z, 0.0f);
         }
         cells[i] = q0; cells[kCellsB + 2u * i] = q1; cells[kCellsB + 2u * i + 1u] = q2;
     }
@@ -552,6 +578,8 @@ struct SppmState {
     uint32_t cam_ahead = 0;          // frame whose camera pass is already in flight on cam_stream (0 = none)
     bool poisoned = false;           // a frame failed half-way (collective / HIP error): the pass state is undefined
     trc_PhotonRecord* d_pho = nullptr;
+    PhotonWire* d_wire = nullptr;        // grouped runs: what the other ranks see of a photon (allocated on first use)
+    bool pho_partial = false;            // grouped runs: d_pho holds only this rank's records up to date
     uint32_t* d_mark = nullptr;
     uint32_t* d_count = nullptr;
     float4* d_cells = nullptr;       // gather table of k_sppm_table
@@ -572,7 +600,7 @@ void trc_sppm_release(trc_ctx* ctx) {
     if (s->cam_stream) { (void)hipStreamSynchronize(s->cam_stream); (void)hipStreamDestroy(s->cam_stream); }
     if (s->ev_main) (void)hipEventDestroy(s->ev_main);
     if (s->ev_cam) (void)hipEventDestroy(s->ev_cam);
-    (void)hipFree(s->d_photon_rng); (void)hipFree(s->d_vp); (void)hipFree(s->d_pho);
+    (void)hipFree(s->d_photon_rng); (void)hipFree(s->d_vp); (void)hipFree(s->d_pho); (void)hipFree(s->d_wire);
     (void)hipFree(s->d_mark); (void)hipFree(s->d_count); (void)hipFree(s->d_cells); (void)hipFree(s->d_cx);
     delete s;
     ctx->sppm = nullptr;
@@ -736,15 +764,21 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
         if (all_lds) hipLaunchKernelGGL((k_sppm_photon<true>), dim3(chunk / kBlock), dim3(kBlock), lds, ctx->stream, kp);
         else hipLaunchKernelGGL((k_sppm_photon<false>), dim3(chunk / kBlock), dim3(kBlock), lds, ctx->stream, kp);
         if (timing) (void)hipEventRecord(seg[1], ctx->stream);
-        if (grouped) {                                  // every rank needs every photon for hashing + refine
-            trc_status cs = trc_coll_allgather(ctx, s->d_pho, (size_t)chunk * sizeof(trc_PhotonRecord), ctx->stream, "allgather of the photon records");
+        PhotonView pv{s->d_pho, nullptr};
+        if (grouped) {                                  // every rank needs every photon for hashing + refine: 40 bytes of each
+            if (!s->d_wire && hipMalloc((void**)&s->d_wire, (size_t)nph * sizeof(PhotonWire)) != hipSuccess)
+                return frame_failed(trc_fail(ctx, TRC_ERR_OOM, "hipMalloc photon wire records"));
+            hipLaunchKernelGGL(k_sppm_pack_wire, dim3((chunk + 255) / 256), dim3(256), 0, ctx->stream, s->d_pho, s->d_wire, kp.photon_first, chunk);
+            trc_status cs = trc_coll_allgather(ctx, s->d_wire, (size_t)chunk * sizeof(PhotonWire), ctx->stream, "allgather of the photon wire records");
             if (cs != TRC_OK) return frame_failed(cs);
+            pv = PhotonView{nullptr, s->d_wire};
+            s->pho_partial = nranks > 1;
         }
         if (timing) (void)hipEventRecord(seg[2], ctx->stream);
         if (hipMemsetAsync(s->d_mark, 0, (size_t)nph * 4, ctx->stream) != hipSuccess ||     // loadAction clear, :785-790
             hipMemsetAsync(s->d_count, 0, (size_t)nph * 4, ctx->stream) != hipSuccess) return frame_failed(trc_fail(ctx, TRC_ERR_HIP, "SPPM grid clear"));
-        hipLaunchKernelGGL(k_sppm_hash, dim3(nph / 256), dim3(256), 0, ctx->stream, s->d_pho, s->d_mark, s->d_count, s->d_cx);
-        hipLaunchKernelGGL(k_sppm_table, dim3(128), dim3(256), 0, ctx->stream, s->d_mark, s->d_count, s->d_pho, s->d_cells, s->d_cx);
+        hipLaunchKernelGGL(k_sppm_hash, dim3(nph / 256), dim3(256), 0, ctx->stream, pv, s->d_mark, s->d_count, s->d_cx);
+        hipLaunchKernelGGL(k_sppm_table, dim3(128), dim3(256), 0, ctx->stream, s->d_mark, s->d_count, pv, s->d_cells, s->d_cx);
         if (camera_frame) {                             // this frame's visible points: wait for them, switch copies
             if (hipStreamWaitEvent(ctx->stream, s->ev_cam, 0) != hipSuccess) return frame_failed(trc_fail(ctx, TRC_ERR_HIP, "SPPM camera event"));
             s->cur ^= 1; s->cam_ahead = 0;
@@ -795,7 +829,15 @@ trc_status trc_sppm_download(trc_ctx* ctx, trc_CameraRecord* cam, trc_PhotonReco
         (void)hipFree(d_packed);
         if (ce != hipSuccess) return trc_fail(ctx, TRC_ERR_HIP, std::string("trc_sppm_download: camera records: ") + hipGetErrorString(ce));
     }
-    if (pho) HIP_TRY(ctx, hipMemcpyAsync(pho, s->d_pho, nph * sizeof(trc_PhotonRecord), hipMemcpyDeviceToHost, ctx->stream));
+    if (pho) {
+        if (s->pho_partial && ctx->grouped()) {           // the per-frame gather moves 40 bytes per photon: the whole records, now (collective)
+            const size_t chunk = nph / (size_t)ctx->nranks;
+            trc_status cs = trc_coll_allgather(ctx, s->d_pho, chunk * sizeof(trc_PhotonRecord), ctx->stream, "allgather of the photon records (download)");
+            if (cs != TRC_OK) return cs;
+            s->pho_partial = false;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(pho, s->d_pho, nph * sizeof(trc_PhotonRecord), hipMemcpyDeviceToHost, ctx->stream));
+    }
     std::vector<uint32_t> hm, hc;
     if (mark) { hm.resize(nph); HIP_TRY(ctx, hipMemcpyAsync(hm.data(), s->d_mark, nph * 4, hipMemcpyDeviceToHost, ctx->stream)); }
     if (count) { hc.resize(nph); HIP_TRY(ctx, hipMemcpyAsync(hc.data(), s->d_count, nph * 4, hipMemcpyDeviceToHost, ctx->stream)); }
