@@ -45,7 +45,8 @@ SEED = 0x5EED0000
 SETTLE_LAUNCHES = 8          # untimed launches before the W warm-up steps: the adaptive order / split plan of the block list settle
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 N_SIMD = 1024                # 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles (ibid., line 54)
-KERNEL = "k_render<true, false, 0"      # rocprof name prefix of the production tracePath kernel on an LDS-resident scene
+KERNEL = ("k_render_dense", "k_render<true, false, 0")   # rocprof name prefixes of the production tracePath kernel on an LDS-resident
+                                                         # scene: whole-frame launch lists run it at 6 waves/SIMD (k_render_dense), shares at 5
 
 
 def algorithmic_bytes(st, n_pixels):

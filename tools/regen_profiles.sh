@@ -6,7 +6,7 @@
 R=${1:-r04}; O=gpurun_out/$R; mkdir -p $O
 export TMPDIR=/tmp
 bash tools/pmc_collect.sh ${R}_c2 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-math --no-cold
-python3 tools/pmc_summary.py ${R}_c2 "k_render<true, false, 0" $O/pmc_config2.json 6 > $O/pmc_config2.txt 2>&1      # 3 timed + 3 vary-seed steps
+python3 tools/pmc_summary.py ${R}_c2 "k_render_dense" $O/pmc_config2.json 6 > $O/pmc_config2.txt 2>&1      # 3 timed + 3 vary-seed steps
 bash tools/pmc_collect.sh ${R}_c3 python3 tools/config_bench.py --config 3 --spp 32 --steps 3 --warmup 8 --no-cold
 python3 tools/pmc_summary.py ${R}_c3 "k_render_pwg<1, false>" $O/pmc_config3.json 3 > $O/pmc_config3.txt 2>&1
 bash tools/pmc_collect.sh ${R}_c4 python3 tools/config_bench.py --config 4 --spp 32 --steps 3 --warmup 8 --no-cold

@@ -31,7 +31,7 @@ def make(config):
         raise SystemExit(f"unknown config {config}")
     lds = scene.view.n_bvh <= 255          # every Cornell-only scene fits LDS; mesh scenes read nodes through L2
     # production kernels: one-wavefront workgroups on an LDS-resident tree, persistent workgroups on a tree read from memory
-    kernel = f"k_render<true, false, {integ}" if lds else f"k_render_pwg<{integ}, false>"
+    kernel = ("k_render_dense" if integ == abi.INTEGRATOR_PATH else f"k_render<true, false, {integ}") if lds else f"k_render_pwg<{integ}, false>"
     return {"scene": scene, "integrator": integ, "spp": spp, "kernel": kernel, "density": density, "what": what}
 
 

@@ -771,8 +771,9 @@ trc_status ensure_sobol_tables(trc_ctx* ctx, uint32_t m) {
 }
 
 template <bool LDS>
-void launch_render(trc_ctx* ctx, const KRender& kp, bool stats, uint32_t integrator, size_t lds, uint32_t n_workgroups) {
+void launch_render(trc_ctx* ctx, const KRender& kp, bool stats, uint32_t integrator, size_t lds, uint32_t n_workgroups, bool dense = false) {
     dim3 grid(n_workgroups), block(kBlock);
+    if (dense) { hipLaunchKernelGGL(k_render_dense, grid, block, lds, ctx->stream, kp); return; }
     if (kp.strip > 1) {                      // few samples per pixel: a strip of blocks per wavefront (production kernels)
         dim3 sgrid((ctx->n_tiles + kp.strip - 1) / kp.strip);
         if (kp.sobol32) {
@@ -956,6 +957,7 @@ trc_status trc_create(int device, trc_ctx** out) {
         ctx->knobs.probe_spp = env_int("TRC_PROBE_SPP", false);
         ctx->knobs.no_plan_reuse = env_int("TRC_NO_PLAN_REUSE", true);
         ctx->knobs.no_coalesce = env_int("TRC_NO_COALESCE", true);
+        ctx->knobs.no_dense = env_int("TRC_NO_DENSE", true);
     }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void**)&ctx->d_stats, sizeof(unsigned long long) * kStatRows * kStatRowStride) != hipSuccess ||
@@ -1349,7 +1351,11 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
     const bool may_split = quarters_ok && !stats && p->spp >= 8 && !ctx->knobs.no_split &&
                            !(p->flags & (TRC_FLAG_LARGE_BLOCKS | TRC_FLAG_FIXED_ORDER));
     // wavefront slots of the kernel this launch runs (the plan's model; the launch bounds of k_render / k_render_pwg)
-    const uint32_t waves_per_simd = p->integrator == TRC_INTEGRATOR_PATH ? (ctx->lds_scene ? TRC_PATH_WAVES : TRC_PATH_WAVES_GLOBAL)
+    // a whole frame's worth of blocks per wavefront slot: the LDS-resident tracePath kernel at one more wavefront per SIMD
+    const bool dense = ctx->lds_scene && p->integrator == TRC_INTEGRATOR_PATH && !stats && !sobol && kp.strip == 1 && !ctx->knobs.no_dense &&
+                       ctx->n_tiles >= (uint32_t)TRC_DENSE_MIN_BLOCKS_PER_SLOT * (uint32_t)ctx->cu_count * 4u * TRC_PATH_WAVES_DENSE &&
+                       dyn_lds_bytes(kp.ks.sc, false) * 4u * TRC_PATH_WAVES_DENSE <= 160u * 1024u;
+    const uint32_t waves_per_simd = dense ? TRC_PATH_WAVES_DENSE : p->integrator == TRC_INTEGRATOR_PATH ? (ctx->lds_scene ? TRC_PATH_WAVES : TRC_PATH_WAVES_GLOBAL)
                                   : p->integrator == TRC_INTEGRATOR_MIS ? (ctx->lds_scene ? TRC_MIS_WAVES_LDS : TRC_MIS_WAVES) : TRC_VOLUME_WAVES;
     const uint32_t wave_slots = (uint32_t)ctx->cu_count * 4u * waves_per_simd;
     if (!stats) { ctx->last_cost_div = kp.cost_div; ctx->last_wave_slots = wave_slots; }
@@ -1490,7 +1496,7 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
     hipError_t le = hipEventRecord(e0, ctx->stream);
     if (le == hipSuccess) {
         if (pwg) le = launch_render_pwg(ctx, kp, p->integrator, pwg_grid, lds);
-        else if (ctx->lds_scene) launch_render<true>(ctx, kp, stats, p->integrator, lds, grid_cap);
+        else if (ctx->lds_scene) launch_render<true>(ctx, kp, stats, p->integrator, lds, grid_cap, dense);
         else launch_render<false>(ctx, kp, stats, p->integrator, lds, grid_cap);
         if (le == hipSuccess) le = hipGetLastError();
     }
@@ -1872,7 +1878,7 @@ trc_status trc_debug_set(trc_ctx* ctx, const char* knob, int value) {
               : k == "sppm_serial_camera" ? &ctx->knobs.sppm_serial_camera : k == "sppm_timing" ? &ctx->knobs.sppm_timing
               : k == "force_blk_shift" ? &ctx->knobs.force_blk_shift : k == "no_split" ? &ctx->knobs.no_split : k == "no_cost_filter" ? &ctx->knobs.no_cost_filter
               : k == "no_cold_probe" ? &ctx->knobs.no_cold_probe : k == "probe_spp" ? &ctx->knobs.probe_spp
-              : k == "no_plan_reuse" ? &ctx->knobs.no_plan_reuse : k == "no_coalesce" ? &ctx->knobs.no_coalesce : nullptr;
+              : k == "no_plan_reuse" ? &ctx->knobs.no_plan_reuse : k == "no_coalesce" ? &ctx->knobs.no_coalesce : k == "no_dense" ? &ctx->knobs.no_dense : nullptr;
     if (!slot) return fail(ctx, TRC_ERR_INVALID_ARG, "trc_debug_set: unknown knob " + k);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // a launch in flight keeps the plan it was made with

@@ -35,6 +35,15 @@ constexpr bool hybrid_stack(int integrator) {
 #ifndef TRC_PATH_WAVES
 #define TRC_PATH_WAVES 5
 #endif
+// ... and at 6 when the launch list is many times the wavefront slots (a whole 1080p frame: 19.85 -> 19.63 ms; its 25-52 spilled
+// dwords lengthen a lone block's chain, so shares of a frame -- which end on their slowest block -- keep the 5-wave kernel:
+// an eighth of config 2 5.6 against 5.9 ms).  k_render_dense: tracePath, LDS-resident tree, production, no Sobol'.
+#ifndef TRC_PATH_WAVES_DENSE
+#define TRC_PATH_WAVES_DENSE 6
+#endif
+#ifndef TRC_DENSE_MIN_BLOCKS_PER_SLOT
+#define TRC_DENSE_MIN_BLOCKS_PER_SLOT 4
+#endif
 #ifndef TRC_PATH_WAVES_GLOBAL
 #define TRC_PATH_WAVES_GLOBAL 8
 #endif
@@ -79,6 +88,7 @@ constexpr int pwg_per_cu(int integrator) { return integrator == TRC_INTEGRATOR_P
 //   trc_render_mem.hip   k_render<false, ...>, k_render_strip<false, ...>, k_render_pwg<...>   trees read from memory (meshes)
 template <bool LDS, bool STATS, int INTEGRATOR, bool SOBOL = false>
 __global__ void k_render(const KRender kp);
+__global__ void k_render_dense(const KRender kp);      // trc_render_lds.hip
 template <int INTEGRATOR, bool SOBOL>
 __global__ void k_render_pwg(const KRender kp);
 template <bool LDS, int INTEGRATOR, bool SOBOL>

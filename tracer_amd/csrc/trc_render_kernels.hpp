@@ -124,8 +124,9 @@ __device__ __forceinline__ void render_block(const KRender& kp, const DScene& sc
     if (lane == 0) kp.block_cost[canon] = (uint32_t)min((unsigned long long)(clock64() - t_start) / kp.cost_div, 0xFFFFFFull);
 }
 
+// the body of k_render (one one-wavefront workgroup = one entry of the launch list)
 template <bool LDS, bool STATS, int INTEGRATOR, bool SOBOL>
-__global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRATOR_VOLUME ? TRC_VOLUME_WAVES : (INTEGRATOR == TRC_INTEGRATOR_MIS ? (LDS ? TRC_MIS_WAVES_LDS : TRC_MIS_WAVES) : (LDS ? TRC_PATH_WAVES : TRC_PATH_WAVES_GLOBAL)))) k_render(const KRender kp) {
+__device__ __forceinline__ void render_workgroup(const KRender& kp) {
     if (kp.n_launch && blockIdx.x >= *kp.n_launch) return;      // the grid is sized for the most quarters a plan may splice in
     const DScene& sc = kp.ks.sc;
     const uint32_t* small_base = stage_scene(sc);
@@ -171,6 +172,8 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
         }
     }
 }
+template <bool LDS, bool STATS, int INTEGRATOR, bool SOBOL>
+__global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRATOR_VOLUME ? TRC_VOLUME_WAVES : (INTEGRATOR == TRC_INTEGRATOR_MIS ? (LDS ? TRC_MIS_WAVES_LDS : TRC_MIS_WAVES) : (LDS ? TRC_PATH_WAVES : TRC_PATH_WAVES_GLOBAL)))) k_render(const KRender kp) { render_workgroup<LDS, STATS, INTEGRATOR, SOBOL>(kp); }
 
 // kernelPathTracing on a tree that is READ FROM MEMORY (mesh scenes), production launches of >= 8 spp: persistent
 // workgroups.  With one wavefront per workgroup every wavefront stages its own copy of the top of the tree, and 16-24 copies

@@ -6,6 +6,11 @@
 #endif
 #include "trc_render_kernels.hpp"
 
+// tracePath on an LDS-resident tree at one more wavefront per SIMD, for launch lists many times the wavefront slots (trc_render_config.hpp)
+__global__ void __launch_bounds__(kBlock, TRC_PATH_WAVES_DENSE) k_render_dense(const KRender kp) {
+    render_workgroup<true, false, TRC_INTEGRATOR_PATH, false>(kp);
+}
+
 #define TRC_INST_RENDER(S, I, B) template __global__ void k_render<true, S, I, B>(const KRender)
 #define TRC_INST_STRIP(I, B) template __global__ void k_render_strip<true, I, B>(const KRender)
 // exactly the instantiations launch_render<> picks from (trc_abi.hip)
