@@ -667,7 +667,8 @@ enum trc_pbrt_material { TRC_PBRT_MATTE = 0, TRC_PBRT_PLASTIC = 1, TRC_PBRT_META
                          TRC_PBRT_GLASS = 4, TRC_PBRT_OTHER = 5 };
 /* what the file's Shape directive was (sphere / trianglemesh keep the primitive-type ordinals they map to) */
 enum trc_pbrt_shape_kind { TRC_PBRT_SHAPE_SPHERE = 0, TRC_PBRT_SHAPE_TRIANGLEMESH = 3, TRC_PBRT_SHAPE_DISK = 6,
-                           TRC_PBRT_SHAPE_CYLINDER = 7, TRC_PBRT_SHAPE_PLYMESH = 8 };
+                           TRC_PBRT_SHAPE_CYLINDER = 7, TRC_PBRT_SHAPE_PLYMESH = 8, TRC_PBRT_SHAPE_CONE = 9,
+                           TRC_PBRT_SHAPE_PARABOLOID = 10, TRC_PBRT_SHAPE_HYPERBOLOID = 11 };
 /* what the material's colour parameter names ("texture Kd" "name"): nothing, a 2-D checkerboard (rendered through the
  * reference's TextureInfo{Checker}, Texture.hh:17-43, with albedo = tex1), any other texture class (not rendered) */
 enum trc_pbrt_texture { TRC_PBRT_TEX_NONE = 0, TRC_PBRT_TEX_CHECKERBOARD = 1, TRC_PBRT_TEX_OTHER = 2 };
@@ -684,8 +685,8 @@ typedef struct trc_pbrt_info {
 typedef struct trc_pbrt_shape {
     int32_t  kind;                  /* enum trc_pbrt_shape_kind, or -1 (a shape class that is not handled) */
     float    shape_to_world[16];    /* row-major CTM at the Shape directive */
-    float    radius;                /* spheres, disks, cylinders */
-    uint32_t n_vertices, n_indices; /* triangle meshes, PLY meshes; disks / cylinders: of their tessellation */
+    float    radius;                /* spheres, disks, cylinders, cones, paraboloids */
+    uint32_t n_vertices, n_indices; /* triangle meshes, PLY meshes; quadrics (disk ... hyperboloid): of their tessellation */
     int32_t  material;              /* enum trc_pbrt_material of the graphics state */
     float    color[3];              /* Kd (matte, plastic, other), Kr (mirror), Kt (glass), 1 (metal) */
     int32_t  emitter;               /* inside an AreaLightSource "diffuse" */
@@ -693,10 +694,11 @@ typedef struct trc_pbrt_shape {
     int32_t  mapped_type;           /* TRC_PRIM_SPHERE / _SQUARE / _TRIANGLE it became, -1 if dropped */
     uint32_t mapped_index;          /* index in that primitive list (first triangle for a mesh) */
     uint32_t mapped_material;       /* index into the scene's material table */
-    float    zmin, zmax;            /* cylinder; disk: both = height */
-    float    innerradius, phimax;   /* disk; disk and cylinder (degrees) */
+    float    zmin, zmax;            /* cylinder, paraboloid; disk: both = height; cone: 0, height; hyperboloid: the z range of p1, p2 */
+    float    innerradius, phimax;   /* disk; every quadric (degrees) */
     int32_t  texture;               /* enum trc_pbrt_texture of the material's colour parameter */
     float    tex2[3];               /* checkerboard: the second colour (color[] holds tex1) */
+    float    p1[3], p2[3];          /* hyperboloid: the swept segment's end points */
 } trc_pbrt_shape;
 trc_status trc_host_scene_load_pbrt(const char* path, trc_host_scene** out_scene, trc_Camera* out_camera,
                                     trc_pbrt_info* info, trc_pbrt_shape* shapes, uint32_t capacity);

@@ -79,15 +79,16 @@ extern "C" void ref_minipbrt_free(void* p) { std::free(p); }
 // What the REFERENCE's parser makes of a whole scene file, flattened for tests/test_pbrt_scene.py (the yardstick of
 // trc_host_scene_load_pbrt): camera (cameraToWorld, fov, lensradius, focaldistance), film resolution, and per world
 // shape in file order: type, shapeToWorld (row-major), sphere radius, mesh sizes, material type + its colour
-// (Kd / Kr / Kt), area light L.  `shapes` holds 40 floats per shape:
-//   [0] type (0 sphere, 3 trianglemesh, 6 disk, 7 cylinder, 8 plymesh, -1 other)  [1..16] shapeToWorld
+// (Kd / Kr / Kt), area light L.  `shapes` holds 48 floats per shape:
+//   [0] type (0 sphere, 3 trianglemesh, 6 disk, 7 cylinder, 8 plymesh, 9 cone, 10 paraboloid, 11 hyperboloid, -1 other)  [1..16] shapeToWorld
 //   [17] radius (sphere, disk, cylinder)  [18] n_vertices  [19] n_indices (trianglemesh; plymesh: of the PLY file as
 //   minipbrt's PLYMesh::triangle_mesh() loads it)
 //   [20] material (0 matte 1 plastic 2 metal 3 mirror 4 glass 5 other, -1 none)  [21..23] colour
 //   [24] has area light  [25..27] L * scale
 //   [28] what the colour parameter names: 0 a constant, 1 a 2-D checkerboard texture, 2 another texture
 //   [29..31] / [32..34] the checkerboard's tex1 / tex2 values
-//   [35] zmin (cylinder) / height (disk)  [36] zmax / height  [37] innerradius (disk)  [38] phimax (disk, cylinder)
+//   [35] zmin (cylinder, paraboloid) / height (disk) / 0 (cone)  [36] zmax / height  [37] innerradius (disk)  [38] phimax (quadrics)
+//   [39..41] p1  [42..44] p2 (hyperboloid)
 extern "C" int ref_minipbrt_describe(const char* path, float camera[20], int film[2], float** shapes, unsigned* n_shapes) {
     minipbrt::Loader loader;
     if (!loader.load(path)) return -1;
@@ -112,7 +113,7 @@ extern "C" int ref_minipbrt_describe(const char* path, float camera[20], int fil
     for (size_t k = 0; k < scene->shapes.size(); ++k) {
         if (in_object[k]) continue;
         minipbrt::Shape* s = scene->shapes[k];
-        float rec[40] = {0};
+        float rec[48] = {0};
         rec[0] = -1.0f;
         std::memcpy(rec + 1, &s->shapeToWorld.start[0][0], 16 * sizeof(float));
         if (s->type() == minipbrt::ShapeType::Sphere) { rec[0] = 0.0f; rec[17] = static_cast<minipbrt::Sphere*>(s)->radius; }
@@ -125,6 +126,16 @@ extern "C" int ref_minipbrt_describe(const char* path, float camera[20], int fil
         } else if (s->type() == minipbrt::ShapeType::Cylinder) {
             auto* c = static_cast<minipbrt::Cylinder*>(s);
             rec[0] = 7.0f; rec[17] = c->radius; rec[35] = c->zmin; rec[36] = c->zmax; rec[38] = c->phimax;
+        } else if (s->type() == minipbrt::ShapeType::Cone) {
+            auto* c = static_cast<minipbrt::Cone*>(s);
+            rec[0] = 9.0f; rec[17] = c->radius; rec[35] = 0.0f; rec[36] = c->height; rec[38] = c->phimax;
+        } else if (s->type() == minipbrt::ShapeType::Paraboloid) {
+            auto* c = static_cast<minipbrt::Paraboloid*>(s);
+            rec[0] = 10.0f; rec[17] = c->radius; rec[35] = c->zmin; rec[36] = c->zmax; rec[38] = c->phimax;
+        } else if (s->type() == minipbrt::ShapeType::Hyperboloid) {
+            auto* h = static_cast<minipbrt::Hyperboloid*>(s);
+            rec[0] = 11.0f; rec[38] = h->phimax;
+            for (int k = 0; k < 3; ++k) { rec[39 + k] = h->p1[k]; rec[42 + k] = h->p2[k]; }
         } else if (s->type() == minipbrt::ShapeType::PLYMesh) {
             rec[0] = 8.0f;
             if (minipbrt::TriangleMesh* m = s->triangle_mesh()) {        // reads the PLY file (minipbrt.cpp:4380-4450)
@@ -165,7 +176,7 @@ extern "C" int ref_minipbrt_describe(const char* path, float camera[20], int fil
                 for (int j = 0; j < 3; ++j) rec[25 + j] = dl->L[j] * dl->scale[j];
             }
         }
-        out.insert(out.end(), rec, rec + 40);
+        out.insert(out.end(), rec, rec + 48);
         ++n;
     }
     *n_shapes = n;

@@ -60,7 +60,7 @@ AttributeBegin
 AttributeEnd
 AttributeBegin
   Material "uber"
-  Shape "cone" "float radius" 10
+  Shape "loopsubdiv" "integer levels" 1 "integer indices" [ 0 1 2 ] "point P" [ 0 0 0  10 0 0  0 10 0 ]
 AttributeEnd
 Texture "tiles" "spectrum" "checkerboard" "rgb tex1" [ 0.8 0.7 0.2 ] "rgb tex2" [ 0.1 0.1 0.1 ] "float uscale" 4 "float vscale" 4
 Texture "veins" "spectrum" "marble"
@@ -98,7 +98,7 @@ def ref_describe(path):
     cam, film, p, n = (C.c_float * 20)(), (C.c_int * 2)(), C.POINTER(C.c_float)(), C.c_uint()
     assert L.ref_minipbrt_describe(os.fsencode(path), cam, film, C.byref(p), C.byref(n)) == 0
     try:
-        shapes = np.ctypeslib.as_array(p, shape=(n.value, 40)).copy() if n.value else np.zeros((0, 40), np.float32)
+        shapes = np.ctypeslib.as_array(p, shape=(n.value, 48)).copy() if n.value else np.zeros((0, 48), np.float32)
     finally:
         L.ref_minipbrt_free(p)
     return np.array(cam[:], np.float32), (film[0], film[1]), shapes
@@ -160,7 +160,7 @@ def test_description_equals_minipbrt_field_for_field(cornell_pbrt):
     assert info.perspective == 1 == int(rcam[19])
     assert np.float32(info.fov) == rcam[16] and np.float32(info.lensradius) == rcam[17] and np.float32(info.focaldistance) == rcam[18]
     np.testing.assert_allclose(np.array(info.camera_to_world[:], np.float32), rcam[:16], rtol=0, atol=2e-4)
-    # 6 quads + 2 spheres + 1 mesh + 1 cone + cylinder + disk + 1 sphere + 1 plymesh; no template
+    # 6 quads + 2 spheres + 1 mesh + 1 subdivision surface (not handled) + cylinder + disk + 1 sphere + 1 plymesh; no template
     assert info.n_shapes == len(rshapes) == len(shapes) == 14
     kinds = [s.kind for s in shapes]
     assert kinds.count(abi.PBRT_SHAPE_CYLINDER) == 1 and kinds.count(abi.PBRT_SHAPE_DISK) == 1 and kinds.count(abi.PBRT_SHAPE_PLYMESH) == 1
@@ -213,7 +213,7 @@ def test_description_equals_minipbrt_field_for_field(cornell_pbrt):
 def test_mapping_onto_the_reference_primitives(cornell_pbrt):
     scene, cam, info, shapes = host.HostScene.from_pbrt(cornell_pbrt)
     v = scene.view
-    assert info.n_unsupported_shapes == 1 and info.n_unsupported_materials == 1 and info.mis_ready == 1   # the cone, "uber"
+    assert info.n_unsupported_shapes == 1 and info.n_unsupported_materials == 1 and info.mis_ready == 1   # the loopsubdiv, "uber"
     assert info.n_unsupported_textures == 1                                                                # "marble" on the third sphere
     # 5 walls, then the light at squareList[5] and, being the only one, again at [6] (not in the BVH twice)
     cyl, disk, ply = (next(s for s in shapes if s.kind == k) for k in (abi.PBRT_SHAPE_CYLINDER, abi.PBRT_SHAPE_DISK, abi.PBRT_SHAPE_PLYMESH))
@@ -296,3 +296,88 @@ def test_rejects_and_reports(tmp_path):
         host.HostScene.from_pbrt(str(p))
     with pytest.raises(RuntimeError):
         host.HostScene.from_pbrt(str(tmp_path / "missing.pbrt"))
+
+
+QUADRICS = """LookAt 0 5 -20  0 2 0  0 1 0
+Camera "perspective" "float fov" [ 45 ]
+Film "image" "integer xresolution" [ 64 ] "integer yresolution" [ 48 ]
+WorldBegin
+Material "matte" "rgb Kd" [ 0.5 0.5 0.5 ]
+AttributeBegin
+  Translate -6 0 0
+  Rotate -90 1 0 0
+  Shape "cone" "float radius" 2 "float height" 5 "float phimax" 180
+AttributeEnd
+AttributeBegin
+  Translate 0 0 0
+  Rotate -90 1 0 0
+  Shape "paraboloid" "float radius" 3 "float zmin" 1 "float zmax" 4
+AttributeEnd
+AttributeBegin
+  Translate 6 0 0
+  Rotate -90 1 0 0
+  Shape "hyperboloid" "point p1" [ 1 0 0 ] "point p2" [ 2 1 3 ] "float phimax" 270
+AttributeEnd
+Shape "cone" "float radius" 0
+WorldEnd
+"""
+
+
+@pytest.fixture()
+def quadrics_pbrt(tmp_path):
+    p = tmp_path / "quadrics.pbrt"
+    p.write_text(QUADRICS)
+    return str(p)
+
+
+@needs_ref
+def test_quadrics_equal_minipbrt_field_for_field(quadrics_pbrt):
+    scene, cam, info, shapes = host.HostScene.from_pbrt(quadrics_pbrt)
+    rcam, rfilm, rshapes = ref_describe(quadrics_pbrt)
+    assert info.n_shapes == len(rshapes) == len(shapes) == 4
+    assert [s.kind for s in shapes] == [abi.PBRT_SHAPE_CONE, abi.PBRT_SHAPE_PARABOLOID, abi.PBRT_SHAPE_HYPERBOLOID, abi.PBRT_SHAPE_CONE]
+    for mine, ref in zip(shapes, rshapes):
+        assert mine.kind == int(ref[0])
+        np.testing.assert_allclose(np.array(mine.shape_to_world[:], np.float32), ref[1:17], rtol=1e-6, atol=1e-4)
+        assert np.float32(mine.phimax) == ref[38]
+        if mine.kind == abi.PBRT_SHAPE_HYPERBOLOID:
+            assert np.array_equal(np.array(mine.p1[:], np.float32), ref[39:42]) and np.array_equal(np.array(mine.p2[:], np.float32), ref[42:45])
+        else:
+            assert (np.float32(mine.radius), np.float32(mine.zmin), np.float32(mine.zmax)) == (ref[17], ref[35], ref[36])
+    assert info.n_unsupported_shapes == 1 and shapes[3].mapped_type == -1               # a cone of radius 0 is no surface
+
+
+def test_quadric_tessellations_lie_on_their_surfaces(quadrics_pbrt):
+    """pbrt-v3 shapes/cone.cpp, paraboloid.cpp, hyperboloid.cpp: every vertex satisfies the quadric's equation in object space,
+    the normals are unit and perpendicular to the surface's tangents, the vertex counts follow the grid"""
+    scene, cam, info, shapes = host.HostScene.from_pbrt(quadrics_pbrt)
+    v = scene.view
+    verts = np.ctypeslib.as_array(C.cast(v.triList, C.POINTER(C.c_float)), shape=(v.n_vertex, 8)).copy()
+    cone, par, hyp = shapes[0], shapes[1], shapes[2]
+    assert cone.n_vertices == (32 + 1) * 2 and cone.n_indices == 3 * 32                       # 180 deg = 32 of 64 steps, apex cells are one triangle
+    assert par.n_vertices == 65 * 17 and par.n_indices == 6 * 64 * 16 and hyp.n_vertices == 49 * 9 and hyp.n_indices == 6 * 48 * 8
+    assert v.n_vertex == cone.n_vertices + par.n_vertices + hyp.n_vertices and v.n_index == cone.n_indices + par.n_indices + hyp.n_indices
+    off = 0
+    for sh in (cone, par, hyp):
+        M = np.array(sh.shape_to_world[:], np.float64).reshape(4, 4)
+        W = verts[off:off + sh.n_vertices]; off += sh.n_vertices
+        P = (np.linalg.inv(M) @ np.c_[W[:, :3], np.ones(len(W))].T).T[:, :3]               # back to object space
+        N = (M[:3, :3].T @ W[:, 3:6].T).T                                                   # normals transform by the inverse transpose
+        N /= np.linalg.norm(N, axis=1, keepdims=True)
+        r = np.hypot(P[:, 0], P[:, 1])
+        if sh is cone:
+            assert np.allclose(r, 2.0 * (1.0 - P[:, 2] / 5.0), atol=1e-4) and P[:, 2].min() >= -1e-5 and P[:, 2].max() <= 5 + 1e-4
+            assert np.allclose(N[:, 2], 2.0 / np.hypot(2.0, 5.0), atol=1e-4)                  # constant slope
+            assert P[:, 1].min() >= -1e-4 and P[:, 0].min() < -1.9 and P[:, 0].max() > 1.9     # phimax 180: the y >= 0 half, all of it
+        elif sh is par:
+            assert np.allclose(P[:, 2], 4.0 * (r / 3.0) ** 2, atol=2e-4) and abs(P[:, 2].min() - 1) < 1e-5 and abs(P[:, 2].max() - 4) < 1e-5
+            g = np.c_[2 * 4.0 * P[:, 0] / 9.0, 2 * 4.0 * P[:, 1] / 9.0, -np.ones(len(P))]
+            assert np.allclose(N, g / np.linalg.norm(g, axis=1, keepdims=True), atol=1e-4)
+        else:
+            # a point of the swept segment: undo the rotation -> it lies on p1 + v (p2 - p1); x^2 + y^2 = |p(v).xy|^2 at its z
+            vpar = P[:, 2] / 3.0
+            want = np.hypot(1.0 + vpar * 1.0, vpar * 1.0)
+            assert np.allclose(r, want, atol=2e-4) and P[:, 2].min() >= -1e-5 and P[:, 2].max() <= 3 + 1e-4
+            assert np.allclose(np.linalg.norm(N, axis=1), 1.0, atol=1e-5)
+    # the tessellations render: the scene builds a tree over 3 x their triangles
+    assert scene.tree_depth() > 3

@@ -146,6 +146,7 @@ class GridDensityInfo(C.Structure):
 PBRT_MATTE, PBRT_PLASTIC, PBRT_METAL, PBRT_MIRROR, PBRT_GLASS, PBRT_OTHER = range(6)
 # enum trc_pbrt_shape_kind / trc_pbrt_texture
 PBRT_SHAPE_SPHERE, PBRT_SHAPE_TRIANGLEMESH, PBRT_SHAPE_DISK, PBRT_SHAPE_CYLINDER, PBRT_SHAPE_PLYMESH = 0, 3, 6, 7, 8
+PBRT_SHAPE_CONE, PBRT_SHAPE_PARABOLOID, PBRT_SHAPE_HYPERBOLOID = 9, 10, 11
 PBRT_TEX_NONE, PBRT_TEX_CHECKERBOARD, PBRT_TEX_OTHER = 0, 1, 2
 
 
@@ -161,7 +162,7 @@ class PbrtShape(C.Structure):
                 ("n_vertices", C.c_uint32), ("n_indices", C.c_uint32), ("material", C.c_int32), ("color", C.c_float * 3),
                 ("emitter", C.c_int32), ("L", C.c_float * 3), ("mapped_type", C.c_int32), ("mapped_index", C.c_uint32),
                 ("mapped_material", C.c_uint32), ("zmin", C.c_float), ("zmax", C.c_float), ("innerradius", C.c_float),
-                ("phimax", C.c_float), ("texture", C.c_int32), ("tex2", C.c_float * 3)]
+                ("phimax", C.c_float), ("texture", C.c_int32), ("tex2", C.c_float * 3), ("p1", C.c_float * 3), ("p2", C.c_float * 3)]
 
 
 class Params(C.Structure):

@@ -23,7 +23,7 @@
 //                                       reference's only procedural pattern (Texture.hh:17-43: albedo x {1, 0.5} in a fixed
 //                                       8 x 4 grid of the surface's uv), so tex2 and u / vscale are reported, not rendered
 //   Shape "plymesh"                  -> the triangles of the PLY file (ply_reader.hpp), like a trianglemesh
-//   Shape "disk" / "cylinder"        -> tessellated (kQuadricSegments steps of phi) into triangles with the quadric's own
+//   Shape "disk" / "cylinder" / "cone" / "paraboloid" / "hyperboloid" -> tessellated (kQuadricSegments steps of phi) into triangles with the quadric's own
 //                                       normals and (phi / phimax, radial | axial) as uv, like a trianglemesh
 //
 // Squares are ordered so that emitters sit at indices 5 and 6 when the file has any (padding with unreferenced
@@ -355,7 +355,8 @@ extern "C" trc_status trc_host_scene_load_pbrt(const char* path, trc_host_scene*
                 ds.mapped_type = TRC_PRIM_SPHERE; ds.mapped_index = (uint32_t)s->spheres.size();
                 ds.mapped_material = intern_material(mtype, mcolor, checker);
                 s->spheres.push_back(make_sphere(ds.radius * sx, c, ds.mapped_material));
-            } else if (kind.text == "trianglemesh" || kind.text == "plymesh" || kind.text == "disk" || kind.text == "cylinder") {
+            } else if (kind.text == "trianglemesh" || kind.text == "plymesh" || kind.text == "disk" || kind.text == "cylinder" ||
+                       kind.text == "cone" || kind.text == "paraboloid" || kind.text == "hyperboloid") {
                 // object-space vertices (+ normals, uv) and triangle indices of the shape, then one path for all four
                 std::vector<float> Po, No, UVo;
                 std::vector<uint32_t> idx;
@@ -384,36 +385,85 @@ extern "C" trc_status trc_host_scene_load_pbrt(const char* path, trc_host_scene*
                     if (!read_ply(ply_path, pm)) return fail();
                     Po.swap(pm.P); No.swap(pm.N); UVo.swap(pm.UV); idx.swap(pm.indices);
                 } else {
-                    // Disk (z = height, innerradius <= r <= radius) and Cylinder (radius, zmin <= z <= zmax), phi in [0, phimax]:
-                    // pbrt-v3 shapes/disk.cpp, cylinder.cpp; a ring of quads, two triangles each
-                    const bool disk = kind.text == "disk";
-                    ds.kind = disk ? TRC_PBRT_SHAPE_DISK : TRC_PBRT_SHAPE_CYLINDER;
+                    // The quadrics of pbrt-v3 (shapes/disk.cpp, cylinder.cpp, cone.cpp, paraboloid.cpp, hyperboloid.cpp), each a
+                    // surface P(u, v) with phi = u * phimax: tessellated into a grid of kQuadricSegments steps of phi over a full
+                    // turn x `rows` steps of v (1 where P is linear in v), two triangles per cell, with the surface's own normals
+                    //   disk        z = height, r from innerradius (v = 0) to radius (v = 1)
+                    //   cylinder    r = radius, z from zmin to zmax
+                    //   cone        r = radius (1 - v), z = v height                      (apex cells: one triangle)
+                    //   paraboloid  z from zmin to zmax, r = radius sqrt(z / zmax)
+                    //   hyperboloid the segment p1 -> p2 swept about z: p = (1 - v) p1 + v p2 rotated by phi
+                    enum { QDisk, QCylinder, QCone, QParaboloid, QHyperboloid } q =
+                        kind.text == "disk" ? QDisk : kind.text == "cylinder" ? QCylinder : kind.text == "cone" ? QCone :
+                        kind.text == "paraboloid" ? QParaboloid : QHyperboloid;
+                    ds.kind = q == QDisk ? TRC_PBRT_SHAPE_DISK : q == QCylinder ? TRC_PBRT_SHAPE_CYLINDER : q == QCone ? TRC_PBRT_SHAPE_CONE :
+                              q == QParaboloid ? TRC_PBRT_SHAPE_PARABOLOID : TRC_PBRT_SHAPE_HYPERBOLOID;
                     ds.radius = float_of(params, "radius", 1.0f);
                     ds.phimax = std::min(360.0f, std::max(0.0f, float_of(params, "phimax", 360.0f)));
-                    if (disk) { ds.zmin = ds.zmax = float_of(params, "height", 0.0f); ds.innerradius = float_of(params, "innerradius", 0.0f); }
-                    else {
-                        const float z0 = float_of(params, "zmin", -1.0f), z1 = float_of(params, "zmax", 1.0f);
+                    float p1[3] = {0, 0, 0}, p2[3] = {1, 1, 1};
+                    if (q == QDisk) { ds.zmin = ds.zmax = float_of(params, "height", 0.0f); ds.innerradius = float_of(params, "innerradius", 0.0f); }
+                    else if (q == QCone) { ds.zmin = 0.0f; ds.zmax = float_of(params, "height", 1.0f); }
+                    else if (q == QHyperboloid) {
+                        if (const PbrtParam* a1 = find(params, "p1")) if (a1->numbers.size() == 3) for (int k = 0; k < 3; ++k) p1[k] = (float)a1->numbers[k];
+                        if (const PbrtParam* a2 = find(params, "p2")) if (a2->numbers.size() == 3) for (int k = 0; k < 3; ++k) p2[k] = (float)a2->numbers[k];
+                        std::memcpy(ds.p1, p1, sizeof p1); std::memcpy(ds.p2, p2, sizeof p2);
+                        ds.radius = 0.0f; ds.zmin = std::min(p1[2], p2[2]); ds.zmax = std::max(p1[2], p2[2]);
+                    } else {
+                        const float z0 = float_of(params, "zmin", q == QParaboloid ? 0.0f : -1.0f), z1 = float_of(params, "zmax", 1.0f);
                         ds.zmin = std::min(z0, z1); ds.zmax = std::max(z0, z1);
                     }
-                    if (!(ds.radius > 0.0f) || !(ds.phimax > 0.0f) || (disk && !(ds.innerradius >= 0.0f && ds.innerradius < ds.radius)) ||
-                        (!disk && !(ds.zmin < ds.zmax))) { inf.n_unsupported_shapes++; descs.push_back(ds); continue; }
+                    const bool bad = !(ds.phimax > 0.0f) ||
+                        (q == QDisk && (!(ds.radius > 0.0f) || !(ds.innerradius >= 0.0f && ds.innerradius < ds.radius))) ||
+                        (q == QCylinder && (!(ds.radius > 0.0f) || !(ds.zmin < ds.zmax))) ||
+                        (q == QCone && (!(ds.radius > 0.0f) || !(ds.zmax > 0.0f))) ||
+                        (q == QParaboloid && (!(ds.radius > 0.0f) || !(ds.zmin >= 0.0f) || !(ds.zmin < ds.zmax))) ||
+                        (q == QHyperboloid && p1[0] == p2[0] && p1[1] == p2[1] && p1[2] == p2[2]);
+                    if (bad) { inf.n_unsupported_shapes++; descs.push_back(ds); continue; }
                     const uint32_t seg = std::max(3u, (uint32_t)std::ceil(kQuadricSegments * ds.phimax / 360.0f));
+                    const uint32_t rows = q == QParaboloid ? 16u : q == QHyperboloid ? 8u : 1u;
                     const float phimax = ds.phimax * 3.14159265358979323846f / 180.0f;
                     for (uint32_t k = 0; k <= seg; ++k) {
                         const float u = (float)k / (float)seg, phi = u * phimax, c = std::cos(phi), sn = std::sin(phi);
-                        for (int side = 0; side < 2; ++side) {      // disk: inner, outer rim; cylinder: bottom, top
-                            const float r = disk ? (side ? ds.radius : ds.innerradius) : ds.radius;
-                            Po.push_back(r * c); Po.push_back(r * sn); Po.push_back(disk ? ds.zmin : (side ? ds.zmax : ds.zmin));
-                            if (disk) { No.push_back(0); No.push_back(0); No.push_back(1); }
-                            else { No.push_back(c); No.push_back(sn); No.push_back(0); }
-                            UVo.push_back(u); UVo.push_back((float)side);
+                        for (uint32_t r = 0; r <= rows; ++r) {
+                            const float v = (float)r / (float)rows;
+                            float P[3], N[3];
+                            if (q == QDisk) {
+                                const float rr = ds.innerradius + v * (ds.radius - ds.innerradius);
+                                P[0] = rr * c; P[1] = rr * sn; P[2] = ds.zmin; N[0] = 0; N[1] = 0; N[2] = 1;
+                            } else if (q == QCylinder) {
+                                P[0] = ds.radius * c; P[1] = ds.radius * sn; P[2] = r ? ds.zmax : ds.zmin; N[0] = c; N[1] = sn; N[2] = 0;
+                            } else if (q == QCone) {
+                                const float rr = ds.radius * (1.0f - v);
+                                P[0] = rr * c; P[1] = rr * sn; P[2] = v * ds.zmax;
+                                const float len = std::sqrt(ds.zmax * ds.zmax + ds.radius * ds.radius);
+                                N[0] = ds.zmax * c / len; N[1] = ds.zmax * sn / len; N[2] = ds.radius / len;
+                            } else if (q == QParaboloid) {
+                                const float z = ds.zmin + v * (ds.zmax - ds.zmin), rr = ds.radius * std::sqrt(z / ds.zmax);
+                                P[0] = rr * c; P[1] = rr * sn; P[2] = z;
+                                // gradient of zmax (x^2 + y^2) / radius^2 - z: outward, away from the axis and downwards
+                                const float gx = 2.0f * ds.zmax * P[0] / (ds.radius * ds.radius), gy = 2.0f * ds.zmax * P[1] / (ds.radius * ds.radius);
+                                const float len = std::sqrt(gx * gx + gy * gy + 1.0f);
+                                N[0] = gx / len; N[1] = gy / len; N[2] = -1.0f / len;
+                            } else {
+                                const float px = (1 - v) * p1[0] + v * p2[0], py = (1 - v) * p1[1] + v * p2[1], pz = (1 - v) * p1[2] + v * p2[2];
+                                P[0] = px * c - py * sn; P[1] = px * sn + py * c; P[2] = pz;
+                                const float dx = p2[0] - p1[0], dy = p2[1] - p1[1], dz = p2[2] - p1[2];
+                                const float du[3] = {-P[1], P[0], 0.0f}, dv[3] = {dx * c - dy * sn, dx * sn + dy * c, dz};      // dP/dphi, dP/dv
+                                float n[3] = {du[1] * dv[2] - du[2] * dv[1], du[2] * dv[0] - du[0] * dv[2], du[0] * dv[1] - du[1] * dv[0]};
+                                const float len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                                if (len > 0.0f) { N[0] = n[0] / len; N[1] = n[1] / len; N[2] = n[2] / len; } else { N[0] = 0; N[1] = 0; N[2] = 1; }
+                            }
+                            for (int a3 = 0; a3 < 3; ++a3) { Po.push_back(P[a3]); No.push_back(N[a3]); }
+                            UVo.push_back(u); UVo.push_back(v);
                         }
                     }
-                    for (uint32_t k = 0; k < seg; ++k) {
-                        const uint32_t a = 2 * k, b = 2 * k + 1, c2 = 2 * k + 2, d2 = 2 * k + 3;
-                        const uint32_t tri[6] = {a, b, d2, a, d2, c2};
-                        for (uint32_t t3 : tri) idx.push_back(t3);
-                    }
+                    for (uint32_t k = 0; k < seg; ++k)
+                        for (uint32_t r = 0; r < rows; ++r) {
+                            const uint32_t a = k * (rows + 1) + r, b = a + 1, c2 = a + rows + 1, d2 = c2 + 1;
+                            const bool apex = q == QCone && r + 1 == rows;                 // b and d2 are the apex: one triangle
+                            if (!apex) { idx.push_back(a); idx.push_back(b); idx.push_back(d2); }
+                            idx.push_back(a); idx.push_back(d2); idx.push_back(c2);
+                        }
                 }
                 const size_t nv = Po.size() / 3;
                 if (nv == 0 || idx.empty() || idx.size() % 3 != 0) return fail();
