@@ -86,13 +86,16 @@ def test_quarters_on_a_tree_read_from_memory(gpu, integrator):
     assert runs[0][3] == 0 and max(r[3] for r in runs[1:]) > 0, [r[3] for r in runs]
 
 
-@pytest.mark.parametrize("integrator,mesh", [(abi.INTEGRATOR_PATH, False), (abi.INTEGRATOR_PATH, True), (abi.INTEGRATOR_MIS, True)])
-def test_first_launch_head_and_rest(gpu, cornell_spheres, integrator, mesh):
+@pytest.mark.parametrize("integrator,mesh,spp", [(abi.INTEGRATOR_PATH, False, 20), (abi.INTEGRATOR_PATH, True, 20), (abi.INTEGRATOR_MIS, True, 20),
+                                                 (abi.INTEGRATOR_PATH, False, 72), (abi.INTEGRATOR_MIS, True, 136)])
+def test_first_launch_head_and_rest(gpu, cornell_spheres, integrator, mesh, spp):
     """The first launch of a block list has no durations to order or split by; trc_render runs it as a head of 8 samples (cold)
     and the rest ordered and planned by the head's durations.  A pixel's samples are one chain through its RNG texel, so the
     frame, the RNG texture, the ray count and the number of launches reported are those of one plain launch -- for a whole
-    frame and for a rank's share, with a frame counter that does not start at 0; knob no_cold_probe gives the single launch."""
-    W, H, spp = 640, 360, 20
+    frame and for a rank's share, with a frame counter that does not start at 0; knob no_cold_probe gives the single launch.
+    20 samples = 8 + 12; 72 = 8 + 16 + 48 and 136 = 8 + 16 + 32 + 80 (further passes of doubling length where four times their
+    samples remain, each planned by its predecessor)."""
+    W, H = (640, 360) if spp <= 72 else (320, 192)
     scene = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.golden("teapot")) if mesh else cornell_spheres
     for nranks, rank in ((1, 0), (4, 3)):
         gpu.upload_scene(scene.view); gpu.set_camera(host.prepare_camera(W, H)); gpu.set_environment((0.2, 0.3, 0.4)); gpu.resize(W, H)

@@ -958,6 +958,7 @@ trc_status trc_create(int device, trc_ctx** out) {
         ctx->knobs.no_plan_reuse = env_int("TRC_NO_PLAN_REUSE", true);
         ctx->knobs.no_coalesce = env_int("TRC_NO_COALESCE", true);
         ctx->knobs.no_dense = env_int("TRC_NO_DENSE", true);
+        ctx->knobs.head_stages = env_int("TRC_HEAD_STAGES", false);
     }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void**)&ctx->d_stats, sizeof(unsigned long long) * kStatRows * kStatRowStride) != hipSuccess ||
@@ -1338,13 +1339,24 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
         const uint32_t head = std::max(kColdHeadSpp, (uint32_t)ctx->knobs.probe_spp);
         if (!inner && !ctx->cost_valid && !stats && !ctx->knobs.no_cold_probe && !(p->flags & TRC_FLAG_FIXED_ORDER) && kp.strip == 1 &&
             p->spp >= 2u * head) {
-            trc_params h = *p, r = *p;
-            h.spp = head;
-            r.spp = p->spp - head; r.frame0 = p->frame0 + head;
-            trc_status st = render_pass(ctx, &h, true);
-            if (st != TRC_OK) return st;
-            ctx->launches--;                       // one trc_render call = one launch in trc_stats
-            ctx->cost_head_age = 1;
+            // Stages: the cold head, then -- where plenty of samples remain (four times the stage's) -- up to two more passes of
+            // doubling length, each ordered and planned by its predecessor, then the rest.  A 64-sample launch is head + rest
+            // (a third pass costs its drain: 21.8 -> 22.1 ms); a 256-sample launch is 8 + 16 + 32 + 200, which lets the split
+            // plan's K ramp 16 -> 40 -> 76 INSIDE the first launch: config 3 431 -> 362 ms (and 331 at the second launch
+            // instead of 368), config 4 220 -> 210, an eighth of config 3 290 -> 221 (knob head_stages = n caps the passes)
+            trc_params r = *p;
+            uint32_t stage = head, done = 0;
+            const uint32_t max_stages = ctx->knobs.head_stages > 0 ? (uint32_t)ctx->knobs.head_stages : 3u;
+            for (uint32_t k = 0; k < max_stages && p->spp - done >= (k == 0 ? 2u : 4u) * stage; ++k, stage *= 2u) {
+                trc_params h = *p;
+                h.spp = stage; h.frame0 = p->frame0 + done;
+                trc_status st = render_pass(ctx, &h, true);
+                if (st != TRC_OK) return st;
+                ctx->launches--;                   // one trc_render call = one launch in trc_stats
+                if (k == 0) ctx->cost_head_age = 1;
+                done += stage;
+            }
+            r.spp = p->spp - done; r.frame0 = p->frame0 + done;
             return render_pass(ctx, &r, true);
         }
     }
@@ -1878,7 +1890,7 @@ trc_status trc_debug_set(trc_ctx* ctx, const char* knob, int value) {
               : k == "sppm_serial_camera" ? &ctx->knobs.sppm_serial_camera : k == "sppm_timing" ? &ctx->knobs.sppm_timing
               : k == "force_blk_shift" ? &ctx->knobs.force_blk_shift : k == "no_split" ? &ctx->knobs.no_split : k == "no_cost_filter" ? &ctx->knobs.no_cost_filter
               : k == "no_cold_probe" ? &ctx->knobs.no_cold_probe : k == "probe_spp" ? &ctx->knobs.probe_spp
-              : k == "no_plan_reuse" ? &ctx->knobs.no_plan_reuse : k == "no_coalesce" ? &ctx->knobs.no_coalesce : k == "no_dense" ? &ctx->knobs.no_dense : nullptr;
+              : k == "no_plan_reuse" ? &ctx->knobs.no_plan_reuse : k == "no_coalesce" ? &ctx->knobs.no_coalesce : k == "no_dense" ? &ctx->knobs.no_dense : k == "head_stages" ? &ctx->knobs.head_stages : nullptr;
     if (!slot) return fail(ctx, TRC_ERR_INVALID_ARG, "trc_debug_set: unknown knob " + k);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // a launch in flight keeps the plan it was made with
