@@ -717,7 +717,7 @@ trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32
     (void)hipFree(ctx->d_plan_gather); ctx->d_plan_gather = nullptr;
     (void)hipFree(ctx->d_cost_scratch); ctx->d_cost_scratch = nullptr;
     ctx->plan_streak = 0;
-    ctx->cost_valid = false; ctx->d_last_order = nullptr; ctx->cost_quarters = false; ctx->launch_cap = 0;
+    ctx->cost_valid = false; ctx->d_last_order = nullptr; ctx->d_stale_order = nullptr; ctx->cost_quarters = false; ctx->launch_cap = 0;
     ctx->n_tiles = (uint32_t)tiles.size();
     if (ctx->n_tiles) {
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_tiles, tiles.size() * 4));
@@ -1017,7 +1017,7 @@ trc_status trc_upload_scene(trc_ctx* ctx, const trc_scene* scene) {
     ctx->lds_scene = ks.sc.n_lds_nodes == ks.sc.n_nodes;      // whole tree staged in LDS
     ctx->lds_prefix_ok = true;
     ctx->has_scene = true;
-    ctx->cost_valid = false; ctx->d_last_order = nullptr;      // another scene: the recorded block costs say nothing about it
+    ctx->cost_valid = false; ctx->d_last_order = nullptr; ctx->d_stale_order = nullptr;      // another scene: the recorded block costs say nothing about it
     return TRC_OK;
 }
 
@@ -1068,7 +1068,8 @@ trc_status trc_set_camera(trc_ctx* ctx, const trc_Camera* c) {
     for (int i = 0; i < 6; ++i) { dst[i][0] = src[i]->x; dst[i][1] = src[i]->y; dst[i][2] = src[i]->z; }
     d.lenRadius = c->lenRadius;
     // another view: the blocks' recorded costs are another picture's (the next launch measures afresh: trc_render's head)
-    if (!ctx->has_camera || std::memcmp(&before, &d, sizeof d) != 0) { ctx->cost_valid = false; ctx->d_last_order = nullptr; }
+    // (the old view's launch order survives as a PRIOR for the head of the next launch: a camera usually moves a little)
+    if (!ctx->has_camera || std::memcmp(&before, &d, sizeof d) != 0) { if (ctx->cost_valid) ctx->d_stale_order = ctx->d_last_order; ctx->cost_valid = false; ctx->d_last_order = nullptr; }
     ctx->has_camera = true;
     return TRC_OK;
 }
@@ -1332,9 +1333,9 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
     const bool quarters_ok = kp.strip == 1 && blk_shift == 3;             // the list's blocks are 8x8: costs live in 4 slots per block
     kp.cost_stride = quarters_ok ? kCostSlots : 1u;
     if (!stats && (ctx->cost_strip != kp.strip || ctx->cost_quarters != quarters_ok)) {
-        ctx->cost_valid = false; ctx->cost_strip = kp.strip; ctx->cost_quarters = quarters_ok; ctx->d_last_order = nullptr;
+        ctx->cost_valid = false; ctx->cost_strip = kp.strip; ctx->cost_quarters = quarters_ok; ctx->d_last_order = nullptr; ctx->d_stale_order = nullptr;
     }
-    if (!stats && ctx->cost_integrator != p->integrator) { ctx->cost_valid = false; ctx->cost_integrator = p->integrator; ctx->d_last_order = nullptr; }
+    if (!stats && ctx->cost_integrator != p->integrator) { ctx->cost_valid = false; ctx->cost_integrator = p->integrator; ctx->d_last_order = nullptr; ctx->d_stale_order = nullptr; }
     {
         const uint32_t head = std::max(kColdHeadSpp, (uint32_t)ctx->knobs.probe_spp);
         if (!inner && !ctx->cost_valid && !stats && !ctx->knobs.no_cold_probe && !(p->flags & TRC_FLAG_FIXED_ORDER) && kp.strip == 1 &&
@@ -1439,6 +1440,9 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
         grid_cap = 4u * ctx->n_tiles;
         planned = true;
     }
+    if (!stats && !ctx->cost_valid && !planned && !kp.order && ctx->d_stale_order && kp.strip == 1 && !(p->flags & TRC_FLAG_FIXED_ORDER))
+        kp.order = ctx->d_stale_order;              // a cold pass after a camera move: the previous view's order beats row-major
+    if (!stats) ctx->d_stale_order = nullptr;       // (the buffer belongs to the next sort)
     if (!stats && !planned && ctx->split_live) {                          // this launch runs every block whole
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_split, 0, (size_t)ctx->n_tiles * 4, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_qsplit, 0, (size_t)ctx->n_tiles * 16, ctx->stream));
@@ -1896,7 +1900,7 @@ trc_status trc_debug_set(trc_ctx* ctx, const char* knob, int value) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // a launch in flight keeps the plan it was made with
     *slot = value < 0 ? 0 : value;
     ctx->cost_valid = false;                               // block costs recorded under another launch geometry say nothing
-    ctx->plan_streak = 0;
+    ctx->plan_streak = 0; ctx->d_stale_order = nullptr;
     return TRC_OK;
 }
 

@@ -176,6 +176,7 @@ struct trc_ctx {
     trc_params deferred{}; bool has_deferred = false; uint64_t deferred_calls = 0;   // a launch of few samples kept for coalescing (trc_render)
     int cost_head_age = 0;                    // 1: the costs are a cold head's (trc_render), 2: the launch after it ran on them
     uint32_t cost_integrator = 0xFFFFFFFFu;   // integrator the recorded costs belong to
+    const uint32_t* d_stale_order = nullptr;     // the launch order of the view before the camera moved: the next cold pass's prior
     const uint32_t* d_last_order = nullptr; uint32_t order_age = 0;     // most recent sorted order (short launches reuse it)
     int cu_count = 0;
     uint32_t n_tiles = 0, tiles_nranks = 0, tiles_rank = 0, tiles_view_height = 0, tiles_blk_shift = 3;
