@@ -421,8 +421,9 @@ trc_status trc_tonemap(trc_ctx* ctx, uint8_t* rgba8, float* exposure_out);
  * calls) and error behaviour of parameter checks are those of launching every call at once; a HIP error of a kept launch
  * is returned by the call that launches it.  Knob "no_coalesce" (trc_debug_set) launches every call at once.
  * First launch of a block list (new context, frame size, tile share, scene, camera, integrator), >= 16 samples: run as a
- * head of 8 samples followed by the rest, which is ordered and split by the head's per-block durations -- the same pixels
- * (a pixel's samples are one chain through its RNG texel); knob "no_cold_probe" runs it as one pass. */
+ * head of 8 samples (then passes of 16 and 32 samples where at least four times as many remain) followed by the rest, each
+ * pass ordered and split by its predecessor's per-block durations -- the same pixels (a pixel's samples are one chain
+ * through its RNG texel); knob "no_cold_probe" runs it as one pass, "head_stages" = n caps the passes before the rest. */
 trc_status trc_render(trc_ctx* ctx, const trc_params* params);
 trc_status trc_synchronize(trc_ctx* ctx);
 
