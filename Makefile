@@ -77,13 +77,13 @@ examples/trc_render: examples/trc_render.cpp include/tracer_abi.h $(LIBDIR)/libt
 # sanitizer into one driver (tools/sanitize/driver.cpp: threaded SAH builds, the oracle's row-band workers, every file reader
 # on well-formed and on mutated files), plus sanitized shared libraries for the Python CPU suite (tools/run_sanitizers.sh
 # preloads the runtime).  GPU code is not covered: GPU AddressSanitizer is not available on this pool.
-SAN_SRC := tools/sanitize/driver.cpp $(HOST_SRC) oracle/oracle.cpp oracle/oracle_lbvh.cpp
+SAN_SRC := tools/sanitize/driver.cpp $(HOST_SRC) oracle/oracle.cpp oracle/oracle_lbvh.cpp oracle/oracle_sah.cpp
 build/asan/driver: $(SAN_SRC) $(HOST_HDR) oracle/oracle.h
 	@mkdir -p build/asan
 	$(CXX) -std=c++17 -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined,float-cast-overflow -fno-sanitize-recover=undefined,float-cast-overflow -ffp-contract=off -Iinclude -o $@ $(SAN_SRC) -lpthread
 	$(CXX) $(CXXFLAGS) -O1 -g -fsanitize=address,undefined,float-cast-overflow -shared -o build/asan/libtrc_host.so $(HOST_SRC) -lpthread
-	$(CXX) $(CXXFLAGS) -O1 -g -fsanitize=address,undefined -Wno-unused-function -shared -o build/asan/liboracle.so oracle/oracle.cpp oracle/oracle_lbvh.cpp -lpthread
-	$(CXX) $(CXXFLAGS) -O1 -g -fsanitize=address,undefined -Wno-unused-function -DORACLE_USE_LIBM -shared -o build/asan/liboracle_libm.so oracle/oracle.cpp oracle/oracle_lbvh.cpp -lpthread
+	$(CXX) $(CXXFLAGS) -O1 -g -fsanitize=address,undefined -Wno-unused-function -shared -o build/asan/liboracle.so oracle/oracle.cpp oracle/oracle_lbvh.cpp oracle/oracle_sah.cpp -lpthread
+	$(CXX) $(CXXFLAGS) -O1 -g -fsanitize=address,undefined -Wno-unused-function -DORACLE_USE_LIBM -shared -o build/asan/liboracle_libm.so oracle/oracle.cpp oracle/oracle_lbvh.cpp oracle/oracle_sah.cpp -lpthread
 build/tsan/driver: $(SAN_SRC) $(HOST_HDR) oracle/oracle.h
 	@mkdir -p build/tsan
 	$(CXX) -std=c++17 -O1 -g -fno-omit-frame-pointer -fsanitize=thread -ffp-contract=off -Iinclude -o $@ $(SAN_SRC) -lpthread

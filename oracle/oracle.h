@@ -93,6 +93,12 @@ float     orc_photon_hash(const float idx[3], float hash_scale);                
  * BVH::buildTree (BVH.hh:246-269): [root, leaf 0..n-1, interior 1..n-2].  *out_height = depth of the deepest leaf. */
 void orc_lbvh_build(const trc_BVH* leaves, uint32_t n, trc_BVH* out, uint32_t* out_height);
 
+/* The reference's host SAH build restated on its own data structure (oracle_sah.cpp): BVH::buildNode
+ * (BVH.hh:273-314) and BVH::buildTree + BVH::make (BVH.hh:35-269), serial schedule.  The checker of
+ * trc_host_build_node / trc_host_build_tree, which share no code with it. */
+void orc_sah_leaf(const trc_AABB* box, const trc_float4x4* model_matrix, int32_t pType, uint32_t pIndex, trc_BVH* out);
+void orc_sah_build(const trc_BVH* leaves, uint32_t n, trc_BVH* out);
+
 /* output stage, Render.metal:29-75 + Render.hh:78-95 (see trc_tonemap in tracer_abi.h for the exact definition) */
 void orc_tonemap(const float* accum_rgba, uint32_t W, uint32_t H, uint8_t* rgba8, float* exposure_out);
 

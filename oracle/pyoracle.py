@@ -95,6 +95,10 @@ def lib(libm=False):
         L.orc_set_density.restype = None
         L.orc_lbvh_build.argtypes = [C.POINTER(abi.BVH), C.c_uint32, C.POINTER(abi.BVH), C.POINTER(C.c_uint32)]
         L.orc_lbvh_build.restype = None
+        L.orc_sah_build.argtypes = [C.POINTER(abi.BVH), C.c_uint32, C.POINTER(abi.BVH)]
+        L.orc_sah_build.restype = None
+        L.orc_sah_leaf.argtypes = [C.POINTER(abi.AABB), C.POINTER(abi.float4x4), C.c_int32, C.c_uint32, C.POINTER(abi.BVH)]
+        L.orc_sah_leaf.restype = None
         L.orc_math.argtypes = [C.c_int, C.c_float, C.c_float]
         L.orc_math.restype = C.c_float
         _LIBS[key] = L
@@ -194,6 +198,20 @@ def lbvh_build(leaves, n):
     h = C.c_uint32(0)
     lib().orc_lbvh_build(leaves, n, out, C.byref(h))
     return out, h.value
+
+
+def sah_build(leaves, n):
+    """The reference's SAH build (BVH.hh:35-269) over `n` leaf records -> abi.BVH * (2n-1), root first."""
+    out = (abi.BVH * (2 * n - 1))()
+    lib().orc_sah_build(leaves, n, out)
+    return out
+
+
+def sah_leaf(box, model_matrix, ptype, pindex):
+    """BVH::buildNode (BVH.hh:273-314) -> abi.BVH leaf record."""
+    out = abi.BVH()
+    lib().orc_sah_leaf(C.byref(box), C.byref(model_matrix), ptype, pindex, C.byref(out))
+    return out
 
 
 CAMREC_DTYPE = np.dtype([("ratio", np.float32, 4), ("position", np.float32, 4), ("direction", np.float32, 4),

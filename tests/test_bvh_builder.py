@@ -1,5 +1,6 @@
 """Host SAH BVH builder (BVH.hh:35-314): structural invariants, agreement with brute force,
 determinism under the parallel build, and the reference's array layout after buildTree."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -121,3 +122,72 @@ def test_reference_teapot_obj_loads_and_traces():
     b = po.trace_rays(v, rays, brute=True)
     assert (h["pType"] == abi.PRIM_TRIANGLE).sum() > 500
     assert np.array_equal(h["hit"], b["hit"]) and (np.abs(h["t"] - b["t"])[h["hit"] == 1] == 0).mean() > 0.999
+
+
+# ---- the product's builder against the oracle's restatement of BVH::make (oracle/oracle_sah.cpp): no shared code ----
+
+def _records(nodes, n):
+    a = (C.c_uint32 * (16 * n)).from_address(C.addressof(nodes))
+    return np.frombuffer(a, dtype=np.uint32).reshape(-1, 16).copy()
+
+
+def _same_tree(scene):
+    n = scene.n_leaves
+    want = _records(po.sah_build(scene.leaves(), n), 2 * n - 1)
+    got = scene.bvh_array()
+    bad = np.nonzero((want != got).any(axis=1))[0]
+    assert bad.size == 0, f"{bad.size} of {2 * n - 1} records differ, first at {bad[:5]}"
+
+
+@pytest.mark.parametrize("scene_name", ["cornell", "cornell_spheres", "ball_mesh_scene"])
+def test_host_tree_equals_the_restated_reference_build(request, scene_name):
+    _same_tree(request.getfixturevalue(scene_name))
+
+
+@pytest.mark.parametrize("mesh_name", ["teapot", "coatball"])
+def test_host_tree_equals_the_restated_reference_build_on_the_reference_meshes(mesh_name):
+    _same_tree(host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.golden(mesh_name)))           # configs 3 and 4's assets
+
+
+def test_host_tree_equals_the_restated_reference_build_on_config_4():
+    # 1 005 056 triangles: the parallel build (forks above 4096 leaves) against the serial restatement
+    _same_tree(host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.golden("teapot").replicate(8, 80.0)))
+
+
+def test_host_tree_equals_the_restated_reference_build_on_awkward_leaf_sets():
+    rng = np.random.default_rng(11)
+    cases = []
+    cases.append([host.build_node((0, 0, 0), (1, 1, 1), abi.PRIM_SPHERE, i) for i in range(37)])        # one centroid
+    cases.append([host.build_node((i % 2, 0, 0), (i % 2 + 1, 1, 1), abi.PRIM_SPHERE, i) for i in range(64)])   # two centroids
+    cases.append([host.build_node((i, 0, 0), (i + 0.5, 1, 1), abi.PRIM_SQUARE, i) for i in range(3)])   # span 3
+    pts = rng.uniform(-50, 50, (3000, 3)).astype(np.float32)
+    pts[:, 1] = np.round(pts[:, 1])                                                                      # many ties on y
+    pts[:, 2] = 7.0                                                                                      # flat in z
+    ext = rng.uniform(0.0, 3.0, (3000, 3)).astype(np.float32)
+    cases.append([host.build_node(tuple(p), tuple(p + e), abi.PRIM_TRIANGLE, i) for i, (p, e) in enumerate(zip(pts, ext))])
+    clustered = np.concatenate([rng.normal(0, 0.01, (500, 3)), rng.normal(1000, 200, (20, 3))]).astype(np.float32)
+    cases.append([host.build_node(tuple(p), tuple(p + np.float32(0.001)), abi.PRIM_SPHERE, i) for i, p in enumerate(clustered)])
+    for leaves in cases:
+        n = len(leaves)
+        arr = (abi.BVH * n)(*leaves)
+        want = _records(po.sah_build(arr, n), 2 * n - 1)
+        got = _records(host.build_tree(leaves), 2 * n - 1)
+        assert np.array_equal(want, got)
+
+
+def test_host_leaf_record_equals_the_restated_buildnode():
+    rng = np.random.default_rng(5)
+    for i in range(200):
+        lo = rng.uniform(-100, 100, 3).astype(np.float32)
+        hi = lo + rng.uniform(0, 50, 3).astype(np.float32)
+        m = rng.uniform(-2, 2, (4, 4)).astype(np.float32)
+        m[3] = (0, 0, 0, 1)
+        got = host.build_node(tuple(lo), tuple(hi), abi.PRIM_CUBE, i, model=m.tolist())
+        box = abi.AABB()
+        box.mini.x, box.mini.y, box.mini.z = lo
+        box.maxi.x, box.maxi.y, box.maxi.z = hi
+        mm = abi.float4x4()
+        for c in range(4):
+            mm.columns[c].x, mm.columns[c].y, mm.columns[c].z, mm.columns[c].w = m[0][c], m[1][c], m[2][c], m[3][c]
+        want = po.sah_leaf(box, mm, abi.PRIM_CUBE, i)
+        assert bytes(got) == bytes(want)
