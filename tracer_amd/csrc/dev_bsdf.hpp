@@ -63,6 +63,36 @@ TRC_DEV float sin_phi(F3 w) { float s = sin_theta(w); return (s == 0) ? 0 : clam
 TRC_DEV float cos2_phi(F3 w) { float r = cos_phi(w); return r * r; }
 TRC_DEV float sin2_phi(F3 w) { float r = sin_phi(w); return r * r; }
 TRC_DEV float sqr(float v) { return v * v; }
+// cos_phi and sin_phi of one direction: two quotients by the same sin_theta.  TRC_PHI_PAIR: reciprocal + Newton step once,
+// the quotients' own corrections, operand guards as one wave-uniform range test (dev_vec.hpp: GuardedDivBy / div_core) --
+// the same bits as the two divisions (tests/test_gpu_divby.py), which is what everybody computes when some lane's operand is
+// outside [2^-60, 2^60] (a direction along the normal: sin_theta == 0)
+#ifndef TRC_PHI_PAIR
+#define TRC_PHI_PAIR 1
+#endif
+struct Phi { float c, s; };
+// st = sin_theta(w), which the callers share with tan_theta (the same square root: 1 - z * z where that is positive)
+TRC_DEV float tan_theta_st(F3 v, float st) {
+    float temp = 1 - v.z * v.z;
+    if (temp <= 0.0f || v.z == 0.0f) return 0.0f;
+    return st / v.z;
+}
+TRC_DEV Phi phi_of(F3 w, float st) {
+    Phi ph;
+#if TRC_PHI_PAIR && TRC_WAVE_GUARDS
+    const GuardedDivBy by = guarded_div_by(st);
+    float qc = div_core(w.x, by), qs = div_core(w.y, by);
+    const float small = fmin3(fabsf(w.x), fabsf(w.y), st), large = fmax3(fabsf(w.x), fabsf(w.y), st);
+    if (__builtin_expect(!wave_all(small >= 0x1p-60f && large <= 0x1p60f), 0)) { qc = w.x / st; qs = w.y / st; }
+    ph.c = (st == 0) ? 1 : clampf(qc, -1.0f, 1.0f);
+    ph.s = (st == 0) ? 0 : clampf(qs, -1.0f, 1.0f);
+#else
+    ph.c = (st == 0) ? 1 : clampf(w.x / st, -1.0f, 1.0f);
+    ph.s = (st == 0) ? 0 : clampf(w.y / st, -1.0f, 1.0f);
+#endif
+    return ph;
+}
+TRC_DEV Phi phi_of(F3 w) { return phi_of(w, sin_theta(w)); }
 
 // ---------------------------------------------------------------- Math.hh:118-167
 TRC_DEV float erf_inv(float x) {
@@ -100,7 +130,7 @@ TRC_DEV float erf_approx(float x) {
     int sign = 1;
     if (x < 0) sign = -1;
     x = fabsf(x);
-    float t = 1 / (1 + p * x);
+    float t = rcp1(1 + p * x);
     float y = 1 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * dm_expf(-x * x);
     return sign * y;
 }
@@ -119,7 +149,7 @@ TRC_DEV bool refract(F3 wo, F3 n, float eta, F3& wi) {                          
 TRC_DEV float fr_dielectric(float cosi, float eta) {                              // BXDF.metal:3-22
     cosi = clampf(cosi, -1.0f, 1.0f);
     bool entering = cosi > 0.f;
-    if (!entering) { eta = 1 / eta; cosi = -cosi; }
+    if (!entering) { eta = rcp1(eta); cosi = -cosi; }
     float sin2Theta_i = 1 - cosi * cosi;
     float sin2Theta_t = sin2Theta_i / sqr(eta);
     if (sin2Theta_t >= 1) return 1.f;
@@ -160,10 +190,12 @@ struct Beckmann {
     TRC_DEV float ay() const { return alpha_y; }
 
     TRC_DEV float lambda(F3 w) const {
-        float absTanTheta = fabsf(tan_theta(w));
+        const float st = sin_theta(w);
+        float absTanTheta = fabsf(tan_theta_st(w, st));
         if (is_inf(absTanTheta)) return 0.;
-        float alpha = sqrt_cr(cos2_phi(w) * ax() * ax() + sin2_phi(w) * ay() * ay());
-        float a = 1 / (alpha * absTanTheta);
+        const Phi ph = phi_of(w, st);
+        float alpha = sqrt_cr((ph.c * ph.c) * ax() * ax() + (ph.s * ph.s) * ay() * ay());
+        float a = rcp1(alpha * absTanTheta);
         if (a >= 1.6f) return 0;
         return (1 - 1.259f * a + 0.396f * a * a) / (3.535f * a + 2.181f * a * a);
     }
@@ -171,14 +203,15 @@ struct Beckmann {
         float tan2Theta = tan2_theta(wh);
         if (is_inf(tan2Theta)) return 0.;
         float cos4Theta = cos2_theta(wh) * cos2_theta(wh);
-        return dm_expf(-tan2Theta * (cos2_phi(wh) / (ax() * ax()) + sin2_phi(wh) / (ay() * ay()))) /
+        const Phi ph = phi_of(wh);
+        return dm_expf(-tan2Theta * ((ph.c * ph.c) / (ax() * ax()) + (ph.s * ph.s) / (ay() * ay()))) /
                (kPi * ax() * ay() * cos4Theta);
     }
-    TRC_DEV float G1(F3 w) const { return 1 / (1 + lambda(w)); }
-    TRC_DEV float G(F3 wo, F3 wi) const { return 1 / (1 + lambda(wo) + lambda(wi)); }
+    TRC_DEV float G1(F3 w) const { return rcp1(1 + lambda(w)); }
+    TRC_DEV float G(F3 wo, F3 wi) const { return rcp1(1 + lambda(wo) + lambda(wi)); }
     TRC_DEV float pdf(F3 wo, F3 wh) const { return D(wh) * G1(wo) * fabsf(dot(wo, wh)) / abs_cos_theta(wo); }
 
-    TRC_DEV static void sample11(float cosThetaI, float U1, float U2, float& slope_x, float& slope_y) {
+    TRC_DEV static void sample11(float cosThetaI, float sinThetaI, float U1, float U2, float& slope_x, float& slope_y) {
         if (cosThetaI > .9999f) {
             float r = sqrt_cr(-dm_logf(1.0f - U1));
             float sinPhi, cosPhi;
@@ -187,16 +220,15 @@ struct Beckmann {
             slope_y = r * sinPhi;
             return;
         }
-        float sinThetaI = sqrt_cr(fmaxf(0.0f, 1.0f - cosThetaI * cosThetaI));
-        float tanThetaI = sinThetaI / cosThetaI;
-        float cotThetaI = 1 / tanThetaI;
+        float tanThetaI = sinThetaI / cosThetaI;          // sinThetaI = sqrt(max(0, 1 - cosThetaI^2)) = sin_theta of the caller's vector
+        float cotThetaI = rcp1(tanThetaI);
         float a = -1, c = erf_approx(cotThetaI);
         float sample_x = fmaxf(U1, 1e-6f);
         float thetaI = dm_acosf(cosThetaI);
         float fit = 1 + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
         float b = c - (1 + c) * dm_powf(1 - sample_x, fit);
         const float SQRT_PI_INV = 1.f / sqrtf(kPi);
-        float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * dm_expf(-cotThetaI * cotThetaI));
+        float normalization = rcp1(1 + c + SQRT_PI_INV * tanThetaI * dm_expf(-cotThetaI * cotThetaI));
         int it = 0;
         while (++it < 10) {
             if (!(b >= a && b <= c)) b = 0.5f * (a + c);
@@ -215,9 +247,11 @@ struct Beckmann {
         const F3 wi = flip ? -wo : wo;
         F3 wiStretched = normalize(f3(ax() * wi.x, ay() * wi.y, wi.z));
         float slope_x, slope_y;
-        sample11(cos_theta(wiStretched), u.x, u.y, slope_x, slope_y);
-        float tmp = cos_phi(wiStretched) * slope_x - sin_phi(wiStretched) * slope_y;
-        slope_y = sin_phi(wiStretched) * slope_x + cos_phi(wiStretched) * slope_y;
+        const float st = sin_theta(wiStretched);
+        sample11(cos_theta(wiStretched), st, u.x, u.y, slope_x, slope_y);
+        const Phi ph = phi_of(wiStretched, st);
+        float tmp = ph.c * slope_x - ph.s * slope_y;
+        slope_y = ph.s * slope_x + ph.c * slope_y;
         slope_x = tmp;
         slope_x = ax() * slope_x;
         slope_y = ay() * slope_y;
@@ -236,20 +270,22 @@ struct TrowbridgeReitzD {                                            // Microfac
         if (is_inf(tan2Theta)) return 0.;
         const float cos4Theta = cos2_theta(wh) * cos2_theta(wh);
         if (cos4Theta < 1e-16f) return 0;
-        float e = (cos2_phi(wh) / sqr(ax()) + sin2_phi(wh) / sqr(ay())) * tan2Theta;
-        return 1 / (kPi * ax() * ay() * sqr(1 + e) * cos4Theta);
+        const Phi ph = phi_of(wh);
+        float e = ((ph.c * ph.c) / sqr(ax()) + (ph.s * ph.s) / sqr(ay())) * tan2Theta;
+        return rcp1(kPi * ax() * ay() * sqr(1 + e) * cos4Theta);
     }
     TRC_DEV static float lambda(F3 w) {
         float tan2Theta = tan2_theta(w);
         if (is_inf(tan2Theta)) return 0.;
-        float alpha2 = sqr(cos_phi(w) * ax()) + sqr(sin_phi(w) * ay());
+        const Phi ph = phi_of(w);
+        float alpha2 = sqr(ph.c * ax()) + sqr(ph.s * ay());
         return 0.5f * (sqrt_cr(1 + alpha2 * tan2Theta) - 1);
     }
-    TRC_DEV static float G1(F3 w) { return 1 / (1 + lambda(w)); }
-    TRC_DEV static float G(F3 wo, F3 wi) { return 1 / (1 + lambda(wo) + lambda(wi)); }
+    TRC_DEV static float G1(F3 w) { return rcp1(1 + lambda(w)); }
+    TRC_DEV static float G(F3 wo, F3 wi) { return rcp1(1 + lambda(wo) + lambda(wi)); }
     TRC_DEV static float pdf(F3 wo, F3 wh) { return D(wh) * G1(wo) * fabsf(dot(wo, wh) / cos_theta(wo)); }
 
-    TRC_DEV static void sample11(float cosTheta, float U1, float U2, float& slope_x, float& slope_y) {
+    TRC_DEV static void sample11(float cosTheta, float sinTheta, float U1, float U2, float& slope_x, float& slope_y) {
         if (cosTheta > .9999f) {
             float r = sqrt_cr(U1 / (1 - U1));
             float phi = 6.28318530718f * U2;
@@ -259,18 +295,17 @@ struct TrowbridgeReitzD {                                            // Microfac
             slope_y = r * s;
             return;
         }
-        float sinTheta = sqrt_cr(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
-        float tanTheta = sinTheta / cosTheta;
-        float a = 1 / tanTheta;
-        float G1 = 2 / (1 + sqrt_cr(1.f + 1.f / (a * a)));
+        float tanTheta = sinTheta / cosTheta;             // sinTheta = sqrt(max(0, 1 - cosTheta^2)) = sin_theta of the caller's vector
+        float a = rcp1(tanTheta);
+        float G1 = 2 * rcp1(1 + sqrt_cr(1.f + rcp1(a * a)));     // 2 / x == 2 * (1 / x) bit for bit: x is 1 + a root, so 1 / x is never denormal and the doubling is exact
         float A = 2 * U1 / G1 - 1;
-        float tmp = 1.f / (A * A - 1.f);
+        float tmp = rcp1(A * A - 1.f);
         if (tmp > 1e10f) tmp = 1e10f;
         float B = tanTheta;
         float D = sqrt_cr(fmaxf(B * B * tmp * tmp - (A * A - B * B) * tmp, 0.0f));
         float slope_x_1 = B * tmp - D;
         float slope_x_2 = B * tmp + D;
-        slope_x = (A < 0 || slope_x_2 > 1.f / tanTheta) ? slope_x_1 : slope_x_2;
+        slope_x = (A < 0 || slope_x_2 > rcp1(tanTheta)) ? slope_x_1 : slope_x_2;
         float S;
         if (U2 > 0.5f) { S = 1.f; U2 = 2.f * (U2 - .5f); }
         else { S = -1.f; U2 = 2.f * (.5f - U2); }
@@ -283,9 +318,11 @@ struct TrowbridgeReitzD {                                            // Microfac
         const F3 wi = flip ? -wo : wo;
         F3 wiStretched = normalize(f3(ax() * wi.x, ay() * wi.y, wi.z));
         float slope_x, slope_y;
-        sample11(cos_theta(wiStretched), u.x, u.y, slope_x, slope_y);
-        float tmp = cos_phi(wiStretched) * slope_x - sin_phi(wiStretched) * slope_y;
-        slope_y = sin_phi(wiStretched) * slope_x + cos_phi(wiStretched) * slope_y;
+        const float st = sin_theta(wiStretched);
+        sample11(cos_theta(wiStretched), st, u.x, u.y, slope_x, slope_y);
+        const Phi ph = phi_of(wiStretched, st);
+        float tmp = ph.c * slope_x - ph.s * slope_y;
+        slope_y = ph.s * slope_x + ph.c * slope_y;
         slope_x = tmp;
         slope_x = ax() * slope_x;
         slope_y = ay() * slope_y;
@@ -467,8 +504,8 @@ TRC_DEV F3 beckmann_finish(const Beckmann& d, bool refl, float R, F3 wo, F3 wh, 
     F3 out = f3(0);
     if (live) {
         wi_out = wi;
-        const float G1 = 1 / (1 + lam_o);
-        const float G = 1 / (1 + lam_o + lam_i);
+        const float G1 = rcp1(1 + lam_o);
+        const float G = rcp1(1 + lam_o + lam_i);
         if (refl) {
             const float dist_pdf = D_A * G1 * fabsf(dot(wo, wh)) / abs_cos_theta(wo);
             pdf_out = dist_pdf / (4 * dot(wo, wh));

@@ -216,7 +216,7 @@ TRC_DEV bool path_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, 
     {   // Russian roulette on luminance, :479-485
         float p = rgb_to_y(ps.ratio);
         if (pcg_float(rng) > p) { result = ps.color; return true; }
-        ps.ratio = ps.ratio * (1.0f / p);
+        ps.ratio = ps.ratio * rcp1(p);
     }
     return false;
 }
@@ -458,7 +458,7 @@ TRC_DEV bool mis_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, T
     {
         float p = rgb_to_y(ps.ratio);
         if (pcg_float(rng) > p) { result = ps.color; return true; }
-        ps.ratio = ps.ratio * (1.0f / p);
+        ps.ratio = ps.ratio * rcp1(p);
     }
     return false;
 }

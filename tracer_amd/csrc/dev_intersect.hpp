@@ -129,6 +129,9 @@ TRC_DEV bool box_hit_t(F3 mn, F3 mx, const Ray& r, float rx, float ry, float& t)
 // Math.hh:51-55: gamma(3) with MachineEpsilon = FLT_EPSILON * 0.5 (unparenthesised macro)
 TRC_DEV float box_pad() { return 1 + 2 * ((3 * FLT_EPSILON * 0.5f) / (1 - 3 * FLT_EPSILON * 0.5f)); }
 
+#ifndef TRC_CUBE_DIV
+#define TRC_CUBE_DIV 1
+#endif
 // AABB.hh:114-209: object-space box test of Cube; o/d are the object-space ray (d normalised)
 TRC_DEV bool box_hit_record(F3 mini, F3 maxi, F3 o, F3 d, float range_y, float& out_t, F3& out_gn, F3& out_p, F2& out_uv) {
     float tmin = -FLT_MAX;
@@ -137,10 +140,31 @@ TRC_DEV bool box_hit_record(F3 mini, F3 maxi, F3 o, F3 d, float range_y, float& 
     const F3 ddd = o - mini, bbb = o - maxi;
     const float pad = box_pad();
     const bool inside = (ddd.x > 0 && ddd.y > 0 && ddd.z > 0) && (bbb.x < 0 && bbb.y < 0 && bbb.z < 0);
+#if TRC_CUBE_DIV && TRC_WAVE_GUARDS
+    // the six slab quotients share three divisors: reciprocal + Newton step once per axis, the quotients' own corrections,
+    // no operand guards -- unless some lane's operand is outside [2^-60, 2^60] (a direction component that is 0 or tiny, an
+    // origin ON a slab plane), then everybody divides the long way.  Same bits either way (tests/test_gpu_divby.py).
+    const F3 nlo = mini - o, nhi = maxi - o;
+    F3 qlo, qhi;
+    {
+        const GuardedDivBy bx = guarded_div_by(d.x), by = guarded_div_by(d.y), bz = guarded_div_by(d.z);
+        qlo = f3(div_core(nlo.x, bx), div_core(nlo.y, by), div_core(nlo.z, bz));
+        qhi = f3(div_core(nhi.x, bx), div_core(nhi.y, by), div_core(nhi.z, bz));
+        const float small = fminf(fmin3(fmin3(fabsf(nlo.x), fabsf(nlo.y), fabsf(nlo.z)), fmin3(fabsf(nhi.x), fabsf(nhi.y), fabsf(nhi.z)),
+                                        fmin3(fabsf(d.x), fabsf(d.y), fabsf(d.z))), 0x1p60f);
+        const float large = fmax3(fmax3(fabsf(nlo.x), fabsf(nlo.y), fabsf(nlo.z)), fmax3(fabsf(nhi.x), fabsf(nhi.y), fabsf(nhi.z)),
+                                  fmax3(fabsf(d.x), fabsf(d.y), fabsf(d.z)));
+        if (__builtin_expect(!wave_all(small >= 0x1p-60f && large <= 0x1p60f), 0)) { qlo = nlo / d; qhi = nhi / d; }
+    }
+#endif
 #pragma unroll
     for (uint32_t i = 0; i < 3; ++i) {
         float oi = comp(o, i), di = comp(d, i);
-#if TRC_DIVBY_RENDER
+#if TRC_CUBE_DIV && TRC_WAVE_GUARDS
+        (void)oi; (void)di;
+        float min_bound = comp(qlo, i);
+        float max_bound = comp(qhi, i);
+#elif TRC_DIVBY_RENDER
         const GuardedDivBy by = guarded_div_by(di);
         float min_bound = guarded_div(comp(mini, i) - oi, by);
         float max_bound = guarded_div(comp(maxi, i) - oi, by);

@@ -43,15 +43,33 @@ TRC_DEV F3 cross(F3 a, F3 b) { return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x 
 #define TRC_FAST_UNARY 1
 #endif
 #if defined(__HIP_DEVICE_COMPILE__) && TRC_FAST_UNARY && !defined(TRC_FAST_MATH)
+#define TRC_WAVE_GUARDS 1
+#ifndef TRC_RANGE_CMP2
+#define TRC_RANGE_CMP2 1
+#endif
 TRC_DEV bool unary_in_range(float x) {            // 2^-60 <= |x| < 2^60 (exponent field 67 .. 186)
+#if TRC_RANGE_CMP2
+    return fabsf(x) >= 0x1p-60f && fabsf(x) < 0x1p60f;      // two compares with |x| as a source modifier (NaN fails both)
+#else
     return ((__float_as_uint(x) & 0x7FFFFFFFu) - 0x21800000u) < (0x5D800000u - 0x21800000u);
+#endif
 }
 TRC_DEV bool wave_all(bool ok) { return __builtin_amdgcn_ballot_w64(!ok) == 0ull; }
-TRC_DEV float rcp_core(float x) {                 // the compiler's sequence for 1.0f / x without v_div_scale / v_div_fmas' scaling / v_div_fixup
+#ifndef TRC_RCP_STEPS
+#define TRC_RCP_STEPS 1
+#endif
+// the compiler's sequence for 1.0f / x without v_div_scale / v_div_fmas' scaling / v_div_fixup -- and without its LAST residual
+// correction: over every operand of the guarded range the Newton step and ONE correction already give the correctly rounded
+// reciprocal (exhaustive test, op 0; TRC_RCP_STEPS=2 keeps both)
+TRC_DEV float rcp_core(float x) {
     const float r0 = __builtin_amdgcn_rcpf(x);
     const float r1 = __builtin_fmaf(__builtin_fmaf(-x, r0, 1.0f), r0, r0);
     const float q1 = __builtin_fmaf(__builtin_fmaf(-x, r1, 1.0f), r1, r1);
+#if TRC_RCP_STEPS >= 2
     return __builtin_fmaf(__builtin_fmaf(-x, q1, 1.0f), r1, q1);
+#else
+    return q1;
+#endif
 }
 // (both corrections are needed on this hardware: over the 2^30 in-range operands v_sqrt_f32 alone is wrong 152 127 120 times,
 // one ulp low in all but 58 920 of them -- measured with the test hook)
@@ -71,26 +89,62 @@ TRC_DEV float rcp_cr(float x) {
     if (__builtin_expect(!wave_all(unary_in_range(x)), 0)) r = 1.0f / x;
     return r;
 }
+// sqrt_core is exact for every operand from 2^-60 up, +inf included (exhaustive test; below ~2^-100 the residuals of the two
+// candidates underflow): ONE compare, which a NaN fails.  1 / sqrt needs the upper bound as well (1 / sqrt(inf) is not the core's).
+#ifndef TRC_SQRT_GUARD1
+#define TRC_SQRT_GUARD1 1
+#endif
+TRC_DEV bool sqrt_in_range(float x) {
+#if TRC_SQRT_GUARD1
+    return x >= 0x1p-60f;
+#else
+    return unary_in_range(x) && x > 0.0f;
+#endif
+}
+TRC_DEV bool rsqrt_in_range(float x) {
+#if TRC_SQRT_GUARD1
+    return x >= 0x1p-60f && x < 0x1p60f;
+#else
+    return unary_in_range(x) && x > 0.0f;
+#endif
+}
 TRC_DEV float sqrt_cr(float x) {
     float r = sqrt_core(x);
-    if (__builtin_expect(!wave_all(unary_in_range(x) && x > 0.0f), 0)) r = sqrtf(x);
+    if (__builtin_expect(!wave_all(sqrt_in_range(x)), 0)) r = sqrtf(x);
     return r;
 }
 // 1 / sqrt(x) as two correctly rounded steps (normalize): in range, the root lies in [2^-30, 2^30] -- in range again
 TRC_DEV float rsqrt_cr(float x) {
     float r = rcp_core(sqrt_core(x));
-    if (__builtin_expect(!wave_all(unary_in_range(x) && x > 0.0f), 0)) r = 1.0f / sqrtf(x);
+    if (__builtin_expect(!wave_all(rsqrt_in_range(x)), 0)) r = 1.0f / sqrtf(x);
     return r;
 }
 #else
+#define TRC_WAVE_GUARDS 0
 TRC_DEV float rcp_cr(float x) { return 1.0f / x; }
 TRC_DEV float sqrt_cr(float x) { return sqrtf(x); }
 TRC_DEV float rsqrt_cr(float x) { return 1.0f / sqrtf(x); }
 #endif
+#ifndef TRC_RCP_SITES
+#define TRC_RCP_SITES 1
+#endif
+TRC_DEV float rcp1(float x) {                     // the shading code's `1 / x`
+#if TRC_RCP_SITES
+    return rcp_cr(x);
+#else
+    return 1.0f / x;
+#endif
+}
 TRC_DEV F3 rcp_cr(F3 a) {                         // 1 / direction: one range test for the three
 #if defined(__HIP_DEVICE_COMPILE__) && TRC_FAST_UNARY && !defined(TRC_FAST_MATH)
     F3 r = f3(rcp_core(a.x), rcp_core(a.y), rcp_core(a.z));
-    if (__builtin_expect(!wave_all(unary_in_range(a.x) && unary_in_range(a.y) && unary_in_range(a.z)), 0)) r = f3(1.0f / a.x, 1.0f / a.y, 1.0f / a.z);
+#if TRC_RANGE_CMP2
+    const float small = __builtin_fminf(__builtin_fminf(fabsf(a.x), fabsf(a.y)), fabsf(a.z)), large = __builtin_fmaxf(__builtin_fmaxf(fabsf(a.x), fabsf(a.y)), fabsf(a.z));
+    const bool ok = small >= 0x1p-60f && large < 0x1p60f;      // (min / max skip a NaN component: its reciprocal is a NaN by either sequence, and 1 / direction only ever meets min, max and compares)
+#else
+    const bool ok = unary_in_range(a.x) && unary_in_range(a.y) && unary_in_range(a.z);
+#endif
+    if (__builtin_expect(!wave_all(ok), 0)) r = f3(1.0f / a.x, 1.0f / a.y, 1.0f / a.z);
     return r;
 #else
     return f3(1.0f / a.x, 1.0f / a.y, 1.0f / a.z);
@@ -131,6 +185,13 @@ TRC_DEV float guarded_div(float a, const GuardedDivBy& d) {
     float q = __builtin_fmaf(__builtin_fmaf(-d.b, q0, a), d.y, q0);
     q = __builtin_fmaf(__builtin_fmaf(-d.b, q, a), d.y, q);
     return a == 0.0f ? q0 : q;
+}
+// the quotient's arithmetic alone (operands known to be in range, numerator not zero): the wave-uniform form of the guard
+// lives at the call site (cube slab: nine operands, one ballot)
+TRC_DEV float div_core(float a, const GuardedDivBy& d) {
+    const float q0 = a * d.y;
+    const float q = __builtin_fmaf(__builtin_fmaf(-d.b, q0, a), d.y, q0);
+    return __builtin_fmaf(__builtin_fmaf(-d.b, q, a), d.y, q);
 }
 TRC_DEV F3 guarded_div(F3 a, const GuardedDivBy& d) { return f3(guarded_div(a.x, d), guarded_div(a.y, d), guarded_div(a.z, d)); }
 #ifndef TRC_DIVBY_RENDER
