@@ -497,7 +497,9 @@ trc_status trc_sppm_hash_cells(trc_ctx* ctx, const float* cells /* n*3 */, size_
 trc_status trc_div_by_test(trc_ctx* ctx, const float* a, const float* b, size_t n, float* fast /* 3 n */, float* plain /* 3 n */);
 /* test hook: the render kernels' guard-free reciprocal / square root / reciprocal square root (dev_vec.hpp: rcp_cr, sqrt_cr, rsqrt_cr;
  * op 0 / 1 / 2) against the compiler's correctly rounded 1.0f / x, sqrtf(x), 1.0f / sqrtf(x) on the `count` operands whose bit patterns
- * start at `first_bits` (count = 2^32 covers every float): the number of operands whose results differ, and the smallest one */
+ * start at `first_bits` (count = 2^32 covers every float): the number of operands whose results differ, and the smallest one.
+ * op 3 .. 6: x / c for the divisors known when the kernels are written (pi, 0.01^2, 0.02^2, 0.1^2), computed as the product with
+ * RN(1 / c) and one residual correction, against the compiler's x / c */
 trc_status trc_unary_test(trc_ctx* ctx, uint32_t op, uint32_t first_bits, uint64_t count, uint64_t* n_mismatch, uint32_t* first_mismatch);
 
 /* --- multi-GPU: pixel tiles sharded over ranks, one RCCL reduce -------- */

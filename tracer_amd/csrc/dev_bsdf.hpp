@@ -135,6 +135,9 @@ TRC_DEV float erf_approx(float x) {
     return sign * y;
 }
 
+#ifndef TRC_FRCOND_RANGE
+#define TRC_FRCOND_RANGE 1
+#endif
 // ---------------------------------------------------------------- BXDF.hh / BXDF.metal
 TRC_DEV F3 reflect(F3 wo, F3 n) { return -wo + 2 * dot(wo, n) * n; }             // BXDF.hh:24-26
 TRC_DEV bool refract(F3 wo, F3 n, float eta, F3& wi) {                            // BXDF.hh:28-41 (cos from wo.z, B-6)
@@ -158,17 +161,29 @@ TRC_DEV float fr_dielectric(float cosi, float eta) {                            
     float r_perp = (cosi - eta * cosTheta_t) / (cosi + eta * cosTheta_t);
     return (r_parl * r_parl + r_perp * r_perp) / 2;
 }
+template <bool METAL_CONSTANTS = false>
 TRC_DEV F3 fr_conductor(float cosi, F3 eta, F3 k) {                               // BXDF.metal:24-34
     F3 tmp = (eta * eta + k * k) * cosi * cosi;
-    F3 Rparl2 = (tmp - (2.f * eta * cosi) + f3(1)) / (tmp + (2.f * eta * cosi) + f3(1));
+    const F3 n1 = tmp - (2.f * eta * cosi) + f3(1), d1 = tmp + (2.f * eta * cosi) + f3(1);
     F3 tmp_f = eta * eta + k * k;
-    F3 Rperp2 = (tmp_f - (2.f * eta * cosi) + f3(cosi * cosi)) / (tmp_f + (2.f * eta * cosi) + f3(cosi * cosi));
+    const F3 n2 = tmp_f - (2.f * eta * cosi) + f3(cosi * cosi), d2 = tmp_f + (2.f * eta * cosi) + f3(cosi * cosi);
+#if TRC_FRCOND_RANGE && TRC_WAVE_GUARDS
+    if (METAL_CONSTANTS) {
+    // MetalMaterial's constants (eta <= 0.81, k = 1) and 0 <= cosi <= 2 put all twelve operands into [0.5, 16]:
+    // n1 = (eta^2 + 1) c^2 - 2 eta c + 1 >= 1 / (eta^2 + 1), n2 = (c - eta)^2 + 1 >= 1, the denominators are sums of
+    // non-negative terms and 1 -- the six quotients need no operand guard beyond that ONE compare (which a NaN fails)
+    F3 Rparl2 = div_core(n1, d1), Rperp2 = div_core(n2, d2);
+    if (__builtin_expect(!wave_all(cosi >= 0.0f && cosi <= 2.0f), 0)) { Rparl2 = n1 / d1; Rperp2 = n2 / d2; }
+    return 0.5f * (Rparl2 + Rperp2);
+    }
+#endif
+    F3 Rparl2 = n1 / d1, Rperp2 = n2 / d2;
     return 0.5f * (Rparl2 + Rperp2);
 }
 
 // Fresnel policies
 struct FrCond {   // BXDF.hh:59-70; MetalMaterial: eta = (0.18, 0.15, 0.81), k = 1 (MicrofacetBXDF.h:445-449)
-    TRC_DEV static F3 eval(float cosThetaI) { return fr_conductor(fabsf(cosThetaI), f3(0.18f, 0.15f, 0.81f), f3(1.0f)); }
+    TRC_DEV static F3 eval(float cosThetaI) { return fr_conductor<true>(fabsf(cosThetaI), f3(0.18f, 0.15f, 0.81f), f3(1.0f)); }
 };
 struct FrDiel15 { // BXDF.hh:72-81 with eta = 1.5 (Plastic, Glass reflection)
     TRC_DEV static F3 eval(float cosThetaI) { return f3(fr_dielectric(cosThetaI, 1.5f)); }
@@ -177,7 +192,12 @@ struct FrDiel15 { // BXDF.hh:72-81 with eta = 1.5 (Plastic, Glass reflection)
 // ---------------------------------------------------------------- microfacet distributions
 // alpha is already clamped to >= 0.001 by the constructors (MicrofacetBXDF.h:164,306-309)
 // roughness pairs as types (float literals must match the reference's exactly)
-struct Alpha_01_02 { TRC_DEV static float x() { return 0.01f; } TRC_DEV static float y() { return 0.02f; } };
+struct Alpha_01_02 {
+    TRC_DEV static float x() { return 0.01f; }
+    TRC_DEV static float y() { return 0.02f; }
+    TRC_DEV static DivConst by_x2() { return div_by_sqr001(); }      // max(0.001, x)^2 and its reciprocal
+    TRC_DEV static DivConst by_y2() { return div_by_sqr002(); }
+};
 
 // Beckmann distribution, MicrofacetBXDF.h:137-290.  The roughness pair is a run-time value (not a template
 // parameter) on purpose: Plastic's specular lobe (0.01, 0.1) and Glass's reflection and transmission lobes
@@ -185,7 +205,15 @@ struct Alpha_01_02 { TRC_DEV static float x() { return 0.01f; } TRC_DEV static f
 // the expensive visible-normal sampling (a Newton iteration over erf^-1 / exp) once instead of once per lobe.
 struct Beckmann {
     float alpha_x, alpha_y;
-    TRC_DEV static Beckmann make(float x, float y) { Beckmann d; d.alpha_x = fmaxf(0.001f, x); d.alpha_y = fmaxf(0.001f, y); return d; }
+    DivConst by_ax2, by_ay2;         // alpha^2 and its reciprocal (D divides by them)
+    // the two roughness pairs the materials use: Plastic's specular lobe (0.01, 0.1), Glass's lobes (0.01, 0.01)
+    TRC_DEV static Beckmann make_lobe(bool plastic) {
+        Beckmann d; d.alpha_x = fmaxf(0.001f, 0.01f); d.alpha_y = fmaxf(0.001f, plastic ? 0.1f : 0.01f);
+        d.by_ax2 = div_by_sqr001();
+        const DivConst rough = div_by_sqr01(), smooth = div_by_sqr001();
+        d.by_ay2.c = plastic ? rough.c : smooth.c; d.by_ay2.y = plastic ? rough.y : smooth.y;
+        return d;
+    }
     TRC_DEV float ax() const { return alpha_x; }
     TRC_DEV float ay() const { return alpha_y; }
 
@@ -204,7 +232,9 @@ struct Beckmann {
         if (is_inf(tan2Theta)) return 0.;
         float cos4Theta = cos2_theta(wh) * cos2_theta(wh);
         const Phi ph = phi_of(wh);
-        return dm_expf(-tan2Theta * ((ph.c * ph.c) / (ax() * ax()) + (ph.s * ph.s) / (ay() * ay()))) /
+        float qc, qs;                                     // cos2_phi / (ax * ax), sin2_phi / (ay * ay)
+        div_const2(ph.c * ph.c, by_ax2, ph.s * ph.s, by_ay2, qc, qs);
+        return dm_expf(-tan2Theta * (qc + qs)) /
                (kPi * ax() * ay() * cos4Theta);
     }
     TRC_DEV float G1(F3 w) const { return rcp1(1 + lambda(w)); }
@@ -271,7 +301,9 @@ struct TrowbridgeReitzD {                                            // Microfac
         const float cos4Theta = cos2_theta(wh) * cos2_theta(wh);
         if (cos4Theta < 1e-16f) return 0;
         const Phi ph = phi_of(wh);
-        float e = ((ph.c * ph.c) / sqr(ax()) + (ph.s * ph.s) / sqr(ay())) * tan2Theta;
+        float qc, qs;                                     // cos2_phi / ax^2, sin2_phi / ay^2
+        div_const2(ph.c * ph.c, Alpha::by_x2(), ph.s * ph.s, Alpha::by_y2(), qc, qs);
+        float e = (qc + qs) * tan2Theta;
         return rcp1(kPi * ax() * ay() * sqr(1 + e) * cos4Theta);
     }
     TRC_DEV static float lambda(F3 w) {
@@ -335,10 +367,12 @@ struct TrowbridgeReitzD {                                            // Microfac
 struct Lambert {                                                     // MatteBXDF.hh:6-22 (F folds in the cosine)
     TRC_DEV static float F(F3, F3 wi) { return wi.z / kPi; }
     TRC_DEV static float pdf(F3 wo, F3 wi) { return wo.z * wi.z > 0 ? fabsf(wi.z) / kPi : 0; }
+    // value and pdf are the same quotient: wi.z comes out of a square root (never negative), so |wi.z| / pi == wi.z / pi
     TRC_DEV static float S_F(F3 wo, F3& wi, F2 uu, float& pdf_out) {
         wi = cosine_sample_hemisphere(uu);
-        pdf_out = pdf(wo, wi);
-        return wi.z / kPi;
+        const float v = div_pi(wi.z);
+        pdf_out = wo.z * wi.z > 0 ? fabsf(v) : 0;
+        return v;
     }
 };
 
@@ -361,14 +395,28 @@ struct MicroRefl {                                                   // Microfac
         F3 wh = normalize(wo + wi);
         return Dist::pdf(wo, wh) / (4 * dot(wo, wh));
     }
+    // pdf(wo, wh) and F(wo, wi) both need Lambda(wo): written out so that it is computed ONCE (the guarded square roots and
+    // reciprocals inside carry wave-level branches, which the compiler will not merge across the two calls).  Every
+    // expression is the one pdf() and F() above evaluate, on the same operands in the same order.
     TRC_DEV static F3 S_F(float R, F3 wo, F3& wi, F2 uu, float& pdf_out) {
         if (wo.z == 0) return f3(0);
         F3 wh = Dist::sample_wh(wo, uu);
         if (dot(wo, wh) <= 0) return f3(0);
         wi = reflect(wo, wh);
         if (wo.z * wi.z <= 0) return f3(0);
-        pdf_out = Dist::pdf(wo, wh) / (4 * dot(wo, wh));
-        return F(R, wo, wi);
+        const float lam_o = Dist::lambda(wo);
+        const float dist_pdf = Dist::D(wh) * rcp1(1 + lam_o) * fabsf(dot(wo, wh) / cos_theta(wo));      // Dist::pdf(wo, wh)
+        pdf_out = dist_pdf / (4 * dot(wo, wh));
+        float cosThetaO = abs_cos_theta(wo), cosThetaI = abs_cos_theta(wi);                                // F(R, wo, wi)
+        if (cosThetaI == 0 || cosThetaO == 0) return f3(0);
+        F3 wh2 = wi + wo;
+        if (wh2.x == 0 && wh2.y == 0 && wh2.z == 0) return f3(0);
+        wh2 = normalize(wh2);
+        const float d001 = wh2.x * 0.0f + wh2.y * 0.0f + wh2.z * 1.0f;
+        const F3 whf = (d001 < 0.f) ? -wh2 : wh2;
+        F3 Fres = Fr::eval(dot(wi, whf));
+        const float G = rcp1(1 + lam_o + Dist::lambda(wi));                                               // Dist::G(wo, wi)
+        return f3(R) * Dist::D(wh2) * G * Fres / (4 * cosThetaI * cosThetaO);
     }
 };
 
@@ -579,7 +627,7 @@ TRC_DEV F3 material_S_F(int type, F3 color, F3 wo, F3& wi, F2 uu, float& pdf, Tr
         if (plastic) { u2.x -= 0.5f; u2.x *= 2.0f; }
         else if (refl) u2.x = uu.x / ratio;
         else u2.x = (uu.x - ratio) / (1.0f - ratio);
-        const Beckmann d = Beckmann::make(0.01f, plastic ? 0.1f : 0.01f);
+        const Beckmann d = Beckmann::make_lobe(plastic);
         F3 lobe = f3(0);
         if (wo.z != 0) {
             F3 wh;
@@ -610,7 +658,7 @@ TRC_DEV F3 material_F(int type, F3 color, F3 wo, F3 wi, F2 uu, float& pdf) {
     }
     if (plastic || glass) {                                          // GlassMaterial::F/PDF, :543-562
         const float ratio = 0.25f;
-        const Beckmann d = Beckmann::make(0.01f, plastic ? 0.1f : 0.01f);
+        const Beckmann d = Beckmann::make_lobe(plastic);
         if (plastic || uu.x < ratio) {
             const float p = BeckRefl::pdf(d, wo, wi);
             pdf = plastic ? p : ratio * p;

@@ -135,6 +135,38 @@ TRC_DEV float rcp1(float x) {                     // the shading code's `1 / x`
     return 1.0f / x;
 #endif
 }
+// x / c for a divisor known when the code is written (pi in the cosine lobe, the squared roughnesses in the microfacet
+// distributions): the reciprocal is a constant too, so the quotient is the product and ONE residual correction -- 3 instructions
+// for the compiler's 11.  y must be RN(1 / c).  Exactness is not argued but TESTED, pair by pair, over every one of the 2^32
+// numerators (tests/test_gpu_unary.py, ops 3 ..): only the pairs listed here may be used.
+struct DivConst { float c, y; };
+TRC_DEV DivConst div_by_pi()     { DivConst d; d.c = 3.14159265358979323846f; d.y = 0x1.45f306p-2f; return d; }
+TRC_DEV DivConst div_by_sqr001() { DivConst d; d.c = 0.01f * 0.01f; d.y = 10000.0f; return d; }            // alpha 0.01, squared
+TRC_DEV DivConst div_by_sqr002() { DivConst d; d.c = 0.02f * 0.02f; d.y = 2500.0f; return d; }             // alpha 0.02
+TRC_DEV DivConst div_by_sqr01()  { DivConst d; d.c = 0.1f * 0.1f; d.y = 0x1.8ffffep+6f; return d; }        // alpha 0.1
+TRC_DEV float div_const_core(float x, const DivConst& d) {
+    const float q0 = x * d.y;
+    return __builtin_fmaf(__builtin_fmaf(-d.c, q0, x), d.y, q0);
+}
+TRC_DEV float div_const(float x, const DivConst& d) {
+#if TRC_WAVE_GUARDS
+    float q = div_const_core(x, d);
+    if (__builtin_expect(!wave_all(unary_in_range(x)), 0)) q = x / d.c;
+    return q;
+#else
+    return x / d.c;
+#endif
+}
+// two numerators, two constant divisors, one guard
+TRC_DEV void div_const2(float x0, const DivConst& d0, float x1, const DivConst& d1, float& q0, float& q1) {
+#if TRC_WAVE_GUARDS
+    q0 = div_const_core(x0, d0); q1 = div_const_core(x1, d1);
+    if (__builtin_expect(!wave_all(unary_in_range(x0) && unary_in_range(x1)), 0)) { q0 = x0 / d0.c; q1 = x1 / d1.c; }
+#else
+    q0 = x0 / d0.c; q1 = x1 / d1.c;
+#endif
+}
+TRC_DEV float div_pi(float x) { return div_const(x, div_by_pi()); }
 TRC_DEV F3 rcp_cr(F3 a) {                         // 1 / direction: one range test for the three
 #if defined(__HIP_DEVICE_COMPILE__) && TRC_FAST_UNARY && !defined(TRC_FAST_MATH)
     F3 r = f3(rcp_core(a.x), rcp_core(a.y), rcp_core(a.z));
@@ -193,6 +225,8 @@ TRC_DEV float div_core(float a, const GuardedDivBy& d) {
     const float q = __builtin_fmaf(__builtin_fmaf(-d.b, q0, a), d.y, q0);
     return __builtin_fmaf(__builtin_fmaf(-d.b, q, a), d.y, q);
 }
+TRC_DEV float div_core(float a, float b) { return div_core(a, guarded_div_by(b)); }      // one quotient, no guard at all
+TRC_DEV F3 div_core(F3 a, F3 b) { return f3(div_core(a.x, b.x), div_core(a.y, b.y), div_core(a.z, b.z)); }
 TRC_DEV F3 guarded_div(F3 a, const GuardedDivBy& d) { return f3(guarded_div(a.x, d), guarded_div(a.y, d), guarded_div(a.z, d)); }
 #ifndef TRC_DIVBY_RENDER
 #define TRC_DIVBY_RENDER 0      // 1: the render kernels' shared-divisor sites go through GuardedDivBy (A/B variant)

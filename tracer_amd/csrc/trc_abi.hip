@@ -449,6 +449,12 @@ __global__ void __launch_bounds__(256) k_unary_test(uint32_t op, uint32_t first,
         float a, b;
         if (op == 0u) { a = rcp_cr(x); b = 1.0f / x; }
         else if (op == 1u) { a = sqrt_cr(x); b = sqrtf(x); }
+#if TRC_WAVE_GUARDS
+        else if (op == 3u) { a = div_const(x, div_by_pi()); b = x / kPi; }
+        else if (op == 4u) { a = div_const(x, div_by_sqr001()); b = x / (0.01f * 0.01f); }
+        else if (op == 5u) { a = div_const(x, div_by_sqr002()); b = x / (0.02f * 0.02f); }
+        else if (op == 6u) { a = div_const(x, div_by_sqr01()); b = x / (0.1f * 0.1f); }
+#endif
         else { a = rsqrt_cr(x); b = 1.0f / sqrtf(x); }
         const bool same = __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b);
         if (!same) { bad++; first_bad = min(first_bad, (unsigned long long)bits); }
@@ -1702,7 +1708,7 @@ trc_status trc_div_by_test(trc_ctx* ctx, const float* a, const float* b, size_t 
 }
 
 trc_status trc_unary_test(trc_ctx* ctx, uint32_t op, uint32_t first_bits, uint64_t count, uint64_t* n_mismatch, uint32_t* first_mismatch) {
-    if (!ctx || !n_mismatch || op > 2u || count > (1ull << 32)) return TRC_ERR_INVALID_ARG;
+    if (!ctx || !n_mismatch || op > 6u || count > (1ull << 32)) return TRC_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     unsigned long long* d = nullptr;
     HIP_TRY(ctx, hipMalloc((void**)&d, 16));

@@ -350,7 +350,7 @@ class Tracer:
         return tiles, costs, bs.value
 
     def unary_test(self, op, first_bits=0, count=1 << 32):
-        """(mismatches, first mismatching bit pattern) of rcp_cr / sqrt_cr / rsqrt_cr (op 0 / 1 / 2) against the compiler's sequences"""
+        """(mismatches, first mismatching bit pattern) of rcp_cr / sqrt_cr / rsqrt_cr (op 0 / 1 / 2) and the constant-divisor quotients (op 3 .. 6) against the compiler's sequences"""
         n, first = C.c_uint64(0), C.c_uint32(0)
         self._check(self._L.trc_unary_test(self._h, op, first_bits, count, C.byref(n), C.byref(first)), "trc_unary_test")
         return n.value, first.value
