@@ -32,6 +32,12 @@
 #define TRC_HD static inline
 #endif
 
+/* the correctly rounded square root: sqrtf, or the including file's own statement of it (the HIP kernels' guard-free form,
+ * tracer_amd/csrc/dev_vec.hpp -- the same bits for every operand, tests/test_gpu_unary.py) */
+#ifndef DM_SQRTF
+#define DM_SQRTF(x) sqrtf(x)
+#endif
+
 #define DM_PI_F      3.14159265358979323846f   /* M_PI_F */
 #define DM_PIO2_F    1.57079632679489661923f
 #define DM_PIO4_F    0.78539816339744830962f
@@ -84,20 +90,14 @@ TRC_HD void dm_sincosf(float xx, float* s_out, float* c_out) {
 TRC_HD float dm_sinf(float x) { float s, c; dm_sincosf(x, &s, &c); return s; }
 TRC_HD float dm_cosf(float x) { float s, c; dm_sincosf(x, &s, &c); return c; }
 
-TRC_HD float dm_expf(float xx) {
+/* e^x for MINLOGF <= x <= MAXLOGF (the caller knows: no NaN, no overflow, no underflow to zero) */
+TRC_HD float dm_expf_fin(float x) {
 #if DM_FAST_DEVICE
-    return __expf(xx);
+    return __expf(x);
 #endif
-    const float MAXLOGF = 88.72283905206835f;
-    const float MINLOGF = -103.278929903431851103f;   /* log(2^-149) */
     const float LOG2EF = 1.44269504088896341f;
     const float C1 = 0.693359375f;
     const float C2 = -2.12194440e-4f;
-
-    float x = xx;
-    if (x != x) return x;
-    if (x > MAXLOGF) return DM_INF_F;
-    if (x < MINLOGF) return 0.0f;
 
     /* e^x = e^g 2^n */
     float z = floorf(LOG2EF * x + 0.5f);
@@ -111,16 +111,25 @@ TRC_HD float dm_expf(float xx) {
     return ldexpf(z, n);
 }
 
-TRC_HD float dm_logf(float xx) {
+TRC_HD float dm_expf(float xx) {
 #if DM_FAST_DEVICE
-    return __logf(xx);
+    return __expf(xx);
 #endif
-    const float SQRTHF = 0.707106781186547524f;
+    const float MAXLOGF = 88.72283905206835f;
+    const float MINLOGF = -103.278929903431851103f;   /* log(2^-149) */
     float x = xx;
     if (x != x) return x;
-    if (x <= 0.0f) return (x == 0.0f) ? -DM_INF_F : DM_NAN_F;
-    if (x == DM_INF_F) return x;
+    if (x > MAXLOGF) return DM_INF_F;
+    if (x < MINLOGF) return 0.0f;
+    return dm_expf_fin(x);
+}
 
+/* log(x) for finite x > 0 (the caller knows) */
+TRC_HD float dm_logf_pos(float x) {
+#if DM_FAST_DEVICE
+    return __logf(x);
+#endif
+    const float SQRTHF = 0.707106781186547524f;
     int e;
     x = frexpf(x, &e);
     if (x < SQRTHF) { e -= 1; x = x + x - 1.0f; } else { x = x - 1.0f; }
@@ -136,6 +145,17 @@ TRC_HD float dm_logf(float xx) {
     return z;
 }
 
+TRC_HD float dm_logf(float xx) {
+#if DM_FAST_DEVICE
+    return __logf(xx);
+#endif
+    float x = xx;
+    if (x != x) return x;
+    if (x <= 0.0f) return (x == 0.0f) ? -DM_INF_F : DM_NAN_F;
+    if (x == DM_INF_F) return x;
+    return dm_logf_pos(x);
+}
+
 /* x^y for x >= 0 (the path only raises [0,1] bases to positive powers) */
 TRC_HD float dm_powf(float x, float y) {
 #if DM_FAST_DEVICE
@@ -146,26 +166,31 @@ TRC_HD float dm_powf(float x, float y) {
     return dm_expf(y * dm_logf(x));
 }
 
+/* asin and acos are written without early returns: every operand runs the SAME instruction stream (a wavefront whose lanes
+ * fall into different branches would otherwise run them one after the other -- acos used to inline asin three times), and the
+ * special operands are patched in at the end.  Per operand the operations and their order are those of the Cephes routines. */
 TRC_HD float dm_asinf(float xx) {
-    float x = xx;
-    float a = fabsf(x);
-    if (a > 1.0f) return DM_NAN_F;
-    if (a != a) return a;
-    if (a < 1.0e-4f) return x;
-    int flag = 0;
-    float z;
-    if (a > 0.5f) { z = 0.5f * (1.0f - a); x = sqrtf(z); flag = 1; }
-    else { x = a; z = x * x; }
+    const float a = fabsf(xx);
+    const int big = a > 0.5f;
+    float z = big ? 0.5f * (1.0f - a) : a * a;
+    const float x = big ? DM_SQRTF(z) : a;
     z = ((((4.2163199048E-2f * z + 2.4181311049E-2f) * z + 4.5470025998E-2f) * z
           + 7.4953002686E-2f) * z + 1.6666752422E-1f) * z * x + x;
-    if (flag) { z = z + z; z = DM_PIO2_F - z; }
-    return (xx < 0.0f) ? -z : z;
+    if (big) { z = z + z; z = DM_PIO2_F - z; }
+    float r = (xx < 0.0f) ? -z : z;
+    if (a < 1.0e-4f) r = xx;
+    if (a != a) r = a;
+    if (a > 1.0f) r = DM_NAN_F;
+    return r;
 }
 
 TRC_HD float dm_acosf(float x) {
-    if (x < -0.5f) return DM_PI_F - 2.0f * dm_asinf(sqrtf(0.5f * (1.0f + x)));
-    if (x > 0.5f) return 2.0f * dm_asinf(sqrtf(0.5f * (1.0f - x)));
-    return DM_PIO2_F - dm_asinf(x);
+    const int lo = x < -0.5f, hi = x > 0.5f;
+    const float t = lo ? x : -x;                       /* 0.5 (1 + x) below -0.5, 0.5 (1 - x) above 0.5 */
+    const float s = dm_asinf((lo || hi) ? DM_SQRTF(0.5f * (1.0f + t)) : x);
+    if (lo) return DM_PI_F - 2.0f * s;
+    if (hi) return 2.0f * s;
+    return DM_PIO2_F - s;
 }
 
 TRC_HD float dm_atanf(float xx) {

@@ -72,3 +72,18 @@ def test_special_values():
 
 def test_libm_variant_is_really_libm():
     assert po.lib().orc_uses_libm() == 0 and po.lib(libm=True).orc_uses_libm() == 1
+
+
+def test_asin_acos_keep_the_bits_of_the_branching_form():
+    """asin / acos were rewritten without early returns (one instruction stream for all lanes of a wavefront); the committed
+    CRCs come from the header BEFORE that (tests/golden/make_detmath_crc.py): every 10001st float, all exponents and specials."""
+    import json, os, zlib
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "detmath_crc.json")))
+    L = po.lib()
+    bits = np.arange(0, 1 << 32, gold["stride"], dtype=np.uint64).astype(np.uint32)
+    x = bits.view(np.float32)
+    x = x[~np.isnan(x)]
+    assert len(x) == gold["operands"]
+    for fn, key in ((ASIN, "asin_crc32"), (ACOS, "acos_crc32")):
+        out = np.fromiter((L.orc_math(fn, float(v), 0.0) for v in x), dtype=np.float32, count=len(x))
+        assert f"{zlib.crc32(out.tobytes()) & 0xFFFFFFFF:08x}" == gold[key]

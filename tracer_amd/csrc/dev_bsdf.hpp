@@ -98,7 +98,7 @@ TRC_DEV Phi phi_of(F3 w) { return phi_of(w, sin_theta(w)); }
 TRC_DEV float erf_inv(float x) {
     float w, p;
     x = clampf(x, -.99999f, .99999f);
-    w = -dm_logf((1 - x) * (1 + x));
+    w = -dm_logf_pos((1 - x) * (1 + x));             // the clamp above leaves (1 - x)(1 + x) in [2e-5, 1], whatever x was
     if (w < 5) {
         w = w - 2.5f;
         p = 2.81022636e-08f;
@@ -256,14 +256,19 @@ struct Beckmann {
         float sample_x = fmaxf(U1, 1e-6f);
         float thetaI = dm_acosf(cosThetaI);
         float fit = 1 + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
-        float b = c - (1 + c) * dm_powf(1 - sample_x, fit);
+        // dm_powf(1 - sample_x, fit) with its operands' ranges used: the base lies in {0} U [2^-24, 1), the exponent in [0.44, 1]
+        // (fit's minimum over [0, pi]), so log and exp need none of their special cases; a NaN here is replaced by the
+        // bisection step below before anybody sees it
+        const float base = 1 - sample_x;
+        const float pw = dm_expf_fin(fit * dm_logf_pos(base == 0.0f ? 1.0f : base));
+        float b = c - (1 + c) * (base == 0.0f ? 0.0f : pw);
         const float SQRT_PI_INV = 1.f / sqrtf(kPi);
         float normalization = rcp1(1 + c + SQRT_PI_INV * tanThetaI * dm_expf(-cotThetaI * cotThetaI));
         int it = 0;
         while (++it < 10) {
             if (!(b >= a && b <= c)) b = 0.5f * (a + c);
             float invErf = erf_inv(b);
-            float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * dm_expf(-invErf * invErf)) - sample_x;
+            float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * dm_expf_fin(-invErf * invErf)) - sample_x;      // |erf_inv| < 3.2
             float derivative = normalization * (1 - invErf * tanThetaI);
             if (fabsf(value) < 1e-5f) break;
             if (value > 0) c = b; else a = b;

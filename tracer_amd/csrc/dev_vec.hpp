@@ -9,9 +9,14 @@
 #include <float.h>
 #include <stdint.h>
 
-#include "trc_detmath.h"
-
 #define TRC_DEV __device__ __forceinline__
+
+// trc_detmath.h's square roots (asin, acos) go through the kernels' own statement of sqrtf (sqrt_cr below: the same bits)
+#if defined(__HIP_DEVICE_COMPILE__)
+namespace trcdev { TRC_DEV float sqrt_cr(float x); }
+#define DM_SQRTF(x) trcdev::sqrt_cr(x)
+#endif
+#include "trc_detmath.h"
 
 namespace trcdev {
 
