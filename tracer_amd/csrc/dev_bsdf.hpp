@@ -24,9 +24,11 @@ TRC_DEV F2 concentric_sample_disk(const F2 u) {                      // Sampling
     F2 r0; r0.x = 0; r0.y = 0;
     if (uo.x == 0 && uo.y == 0) return r0;
     const float PiOver2 = kPi / 2.0f, PiOver4 = kPi / 4.0f;
-    float theta, r;
-    if (fabsf(uo.x) > fabsf(uo.y)) { r = uo.x; theta = PiOver4 * (uo.y / uo.x); }
-    else { r = uo.y; theta = PiOver2 - PiOver4 * (uo.x / uo.y); }
+    // one quotient for both cases (half the lanes of a wavefront take each: as two branches they ran one after the other)
+    const bool wide = fabsf(uo.x) > fabsf(uo.y);
+    const float r = wide ? uo.x : uo.y;
+    const float q = (wide ? uo.y : uo.x) / r;
+    const float theta = wide ? PiOver4 * q : PiOver2 - PiOver4 * q;
     float s, c;
     dm_sincosf(theta, &s, &c);
     F2 out; out.x = r * c; out.y = r * s;
