@@ -89,10 +89,24 @@ TRC_DEV float sqrt_core(float x) {                // ... for sqrtf(x) without th
 // The core is computed FIRST and the range test decides afterwards whether everybody redoes it the long way: the test's compare
 // is independent of the core's chain, so the branch finds its condition ready instead of stalling a lone wavefront on it
 // (a chain-bound share of a frame runs at one wavefront's latency: 5.9 -> 5.x ms on an eighth of config 2).
+// TRC_RCP_GUARD_CLASS: the guard reads v_rcp_f32's own result -- "a normal number" is ONE v_cmp_class, and it is false exactly
+// for the operands the core cannot serve (0 and denormals: inf; inf: 0; above 2^126: a denormal, flushed; NaN: NaN).  It hangs
+// on the core's FIRST instruction only, so the branch still finds its condition long before the chain ends.
+#ifndef TRC_RCP_GUARD_CLASS
+#define TRC_RCP_GUARD_CLASS 1
+#endif
 TRC_DEV float rcp_cr(float x) {
+#if TRC_RCP_GUARD_CLASS
+    const float r0 = __builtin_amdgcn_rcpf(x);
+    const float r1 = __builtin_fmaf(__builtin_fmaf(-x, r0, 1.0f), r0, r0);
+    float r = __builtin_fmaf(__builtin_fmaf(-x, r1, 1.0f), r1, r1);
+    if (__builtin_expect(!wave_all(__builtin_amdgcn_classf(r0, 0x108)), 0)) r = 1.0f / x;
+    return r;
+#else
     float r = rcp_core(x);
     if (__builtin_expect(!wave_all(unary_in_range(x)), 0)) r = 1.0f / x;
     return r;
+#endif
 }
 // sqrt_core is exact for every operand from 2^-60 up, +inf included (exhaustive test; below ~2^-100 the residuals of the two
 // candidates underflow): ONE compare, which a NaN fails.  1 / sqrt needs the upper bound as well (1 / sqrt(inf) is not the core's).
@@ -153,10 +167,24 @@ TRC_DEV float div_const_core(float x, const DivConst& d) {
     const float q0 = x * d.y;
     return __builtin_fmaf(__builtin_fmaf(-d.c, q0, x), d.y, q0);
 }
+// (TRC_DIVCONST_GUARD_CLASS=1 -- "the product x * y is a normal number", one v_cmp_class -- is NOT enough: the exhaustive test
+// finds numerators whose product is normal but whose residual underflows; the range test stays)
+#ifndef TRC_DIVCONST_GUARD_CLASS
+#define TRC_DIVCONST_GUARD_CLASS 0
+#endif
+#if TRC_WAVE_GUARDS
+TRC_DEV bool div_const_ok(float x, const DivConst& d) {
+#if TRC_DIVCONST_GUARD_CLASS
+    return __builtin_amdgcn_classf(x * d.y, 0x108);
+#else
+    return unary_in_range(x);
+#endif
+}
+#endif
 TRC_DEV float div_const(float x, const DivConst& d) {
 #if TRC_WAVE_GUARDS
     float q = div_const_core(x, d);
-    if (__builtin_expect(!wave_all(unary_in_range(x)), 0)) q = x / d.c;
+    if (__builtin_expect(!wave_all(div_const_ok(x, d)), 0)) q = x / d.c;
     return q;
 #else
     return x / d.c;
@@ -166,20 +194,30 @@ TRC_DEV float div_const(float x, const DivConst& d) {
 TRC_DEV void div_const2(float x0, const DivConst& d0, float x1, const DivConst& d1, float& q0, float& q1) {
 #if TRC_WAVE_GUARDS
     q0 = div_const_core(x0, d0); q1 = div_const_core(x1, d1);
-    if (__builtin_expect(!wave_all(unary_in_range(x0) && unary_in_range(x1)), 0)) { q0 = x0 / d0.c; q1 = x1 / d1.c; }
+    if (__builtin_expect(!wave_all(div_const_ok(x0, d0) && div_const_ok(x1, d1)), 0)) { q0 = x0 / d0.c; q1 = x1 / d1.c; }
 #else
     q0 = x0 / d0.c; q1 = x1 / d1.c;
 #endif
 }
 TRC_DEV float div_pi(float x) { return div_const(x, div_by_pi()); }
-TRC_DEV F3 rcp_cr(F3 a) {                         // 1 / direction: one range test for the three
+TRC_DEV F3 rcp_cr(F3 a) {                         // 1 / direction: one wave-level branch for the three
 #if defined(__HIP_DEVICE_COMPILE__) && TRC_FAST_UNARY && !defined(TRC_FAST_MATH)
+#if TRC_RCP_GUARD_CLASS
+    const F3 r0 = f3(__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y), __builtin_amdgcn_rcpf(a.z));
+    auto finish = [](float x, float e0) {
+        const float r1 = __builtin_fmaf(__builtin_fmaf(-x, e0, 1.0f), e0, e0);
+        return __builtin_fmaf(__builtin_fmaf(-x, r1, 1.0f), r1, r1);
+    };
+    F3 r = f3(finish(a.x, r0.x), finish(a.y, r0.y), finish(a.z, r0.z));
+    const bool ok = __builtin_amdgcn_classf(r0.x, 0x108) && __builtin_amdgcn_classf(r0.y, 0x108) && __builtin_amdgcn_classf(r0.z, 0x108);
+#else
     F3 r = f3(rcp_core(a.x), rcp_core(a.y), rcp_core(a.z));
 #if TRC_RANGE_CMP2
     const float small = __builtin_fminf(__builtin_fminf(fabsf(a.x), fabsf(a.y)), fabsf(a.z)), large = __builtin_fmaxf(__builtin_fmaxf(fabsf(a.x), fabsf(a.y)), fabsf(a.z));
     const bool ok = small >= 0x1p-60f && large < 0x1p60f;      // (min / max skip a NaN component: its reciprocal is a NaN by either sequence, and 1 / direction only ever meets min, max and compares)
 #else
     const bool ok = unary_in_range(a.x) && unary_in_range(a.y) && unary_in_range(a.z);
+#endif
 #endif
     if (__builtin_expect(!wave_all(ok), 0)) r = f3(1.0f / a.x, 1.0f / a.y, 1.0f / a.z);
     return r;
