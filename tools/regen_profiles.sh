@@ -2,9 +2,16 @@
 # Regenerates the per-round profile set on the GPU box:  gpurun -- 'bash tools/regen_profiles.sh r02'
 # writes gpurun_out/<round>/...; copy what is to be kept into profiles/<round>/ (tools/README.md, profiles/r02/README.md).
 # The PMC summaries carry the source hash of the library they were collected on; bench.py quotes pmc_config2.json only when
-# that hash is the running library's, so the bench line is taken in a SECOND call, after the summary has been committed.
+# that hash is the running library's, so the bench line and the as-named lines are taken in a SECOND call, after the summaries
+# have been committed:  gpurun -- 'bash tools/regen_profiles.sh r04 lines'
 R=${1:-r04}; O=gpurun_out/$R; mkdir -p $O
 export TMPDIR=/tmp
+if [ "$2" = "lines" ]; then      # second call, after the PMC summaries of the first have been copied to profiles/<round>/ and committed
+  python3 bench.py --steps 20 --warmup 5 > $O/bench_line_n1.json 2> $O/bench_n1.err
+  for c in 3 4 volume; do python3 tools/config_bench.py --config $c --warmup 8 2> $O/config$c.err; done > $O/configs_as_named.jsonl
+  python3 tools/config_bench.py --config 5 2> $O/config5.err >> $O/configs_as_named.jsonl
+  exit 0
+fi
 bash tools/pmc_collect.sh ${R}_c2 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-math --no-cold
 python3 tools/pmc_summary.py ${R}_c2 "k_render_dense" $O/pmc_config2.json 6 > $O/pmc_config2.txt 2>&1      # 3 timed + 3 vary-seed steps
 bash tools/pmc_collect.sh ${R}_c3 python3 tools/config_bench.py --config 3 --spp 32 --steps 3 --warmup 8 --no-cold
