@@ -344,7 +344,7 @@ struct TrowbridgeReitzD {                                            // Microfac
         float D = sqrt_cr(fmaxf(B * B * tmp * tmp - (A * A - B * B) * tmp, 0.0f));
         float slope_x_1 = B * tmp - D;
         float slope_x_2 = B * tmp + D;
-        slope_x = (A < 0 || slope_x_2 > rcp1(tanTheta)) ? slope_x_1 : slope_x_2;
+        slope_x = (A < 0 || slope_x_2 > a) ? slope_x_1 : slope_x_2;              // a = 1 / tanTheta
         float S;
         if (U2 > 0.5f) { S = 1.f; U2 = 2.f * (U2 - .5f); }
         else { S = -1.f; U2 = 2.f * (.5f - U2); }

@@ -35,10 +35,15 @@ TRC_DEV F3 mat_albedo(const Shade& sh, uint32_t m) {
 }
 // texture colour of a hit; the sphere's uv (atan2 + asin, Sphere.hh:19-31) is only materialised here,
 // and only when a texture consumes it -- same value as computing it inside hit_test
-TRC_DEV F3 hit_color(const Shade& sh, const HitRec& rec) {
+// ... and so is a square's (two divisions of rec.p's in-plane coordinates, Square.hh; square_uv)
+TRC_DEV F3 hit_color(const SceneRef& S, const Shade& sh, const HitRec& rec) {
     const int tex = mat_tex(sh, rec.material);
     F2 uv = rec.uv;
-    if (tex == kTexChecker && (rec.tag >> kTagIndexBits) == 0u) uv = sphere_uv(rec.gn);
+    if (tex == kTexChecker) {
+        const uint32_t type = rec.tag >> kTagIndexBits;
+        if (type == 0u) uv = sphere_uv(rec.gn);
+        else if (type == 1u) uv = square_uv(S, rec.tag & kTagIndexMask, rec.p);
+    }
     return texture_value(tex, mat_albedo(sh, rec.material), uv);
 }
 
@@ -207,7 +212,7 @@ TRC_DEV bool path_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, 
     float bxPDF = 0;                                                 // uninitialised in the reference (B-3)
     n_shaded++;
     prof<STATS>(cnt, kProfShade);
-    F3 attenuation = material_S_F<STATS>(mtype, hit_color(cx.sh, rec), wo, wi, uu, bxPDF, cnt);
+    F3 attenuation = material_S_F<STATS>(mtype, hit_color(cx.S, cx.sh, rec), wo, wi, uu, bxPDF, cnt);
     if (bxPDF <= 0) { result = ps.color; return true; }
     F3 wiw = (nx * wi.x + ny * wi.y) + rec.sn * wi.z;                // stw * wi
     if (wi.z < 0) ps.ray = make_ray(offset_ray(hit_origin, -rec.sn), wiw);   // transmission
@@ -424,7 +429,7 @@ TRC_DEV bool mis_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, T
         blocked = scene_occluded<ALL_LDS, false, HYB>(cx.S, cx.root_min, cx.root_max, _ray, _dis, cx.stack, cx.S.stack_cap);
     }
     const F3 minus_d = -ps.ray.d;
-    const F3 base_color = hit_color(cx.sh, rec);
+    const F3 base_color = hit_color(cx.S, cx.sh, rec);
     if (!blocked) {                                                  // light sampling, :339-356
         F3 wo = f3(dot(nx, minus_d), dot(ny, minus_d), dot(rec.sn, minus_d));
         F3 wi = f3(dot(nx, _ray.d), dot(ny, _ray.d), dot(rec.sn, _ray.d));

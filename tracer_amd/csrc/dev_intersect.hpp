@@ -240,6 +240,20 @@ TRC_DEV bool sphere_hit_test(const SceneRef& S, uint32_t index, const Ray& ray, 
     return true;
 }
 
+// uv of a point on square `index` (Square.hh: the two quotients of the accepted test).  The render kernels take it from here at
+// shading time, and only when a texture consumes it: rec.p holds a and b exactly (set_comp below), so the value is the one the
+// test would have stored -- and the two divisions leave the traversal loop.
+TRC_DEV F2 square_uv(const SceneRef& S, uint32_t index, F3 p) {
+    const uint32_t* sq = S.small_base + S.off_squares + index * kSquareDwords;
+    const float4 rg = ld4(sq);
+    const uint32_t axes = sq[6];
+    const uint32_t axis_i = axes & 3u, axis_j = (axes >> 2) & 3u;
+    F2 uv;
+    uv.x = (comp(p, axis_i) - rg.x) / (rg.y - rg.x);
+    uv.y = (comp(p, axis_j) - rg.z) / (rg.w - rg.z);
+    return uv;
+}
+template <bool EAGER_UV = true>
 TRC_DEV bool square_hit_test(const SceneRef& S, uint32_t index, const Ray& ray, float rx, float& ry, HitRec& rec) {
     const uint32_t* sq = S.small_base + S.off_squares + index * kSquareDwords;
     const float4 rg = ld4(sq);          // range_i.x, range_i.y, range_j.x, range_j.y
@@ -254,8 +268,10 @@ TRC_DEV bool square_hit_test(const SceneRef& S, uint32_t index, const Ray& ray, 
     if (a < rg.x || a > rg.y) return false;
     float b = comp(ray.o, axis_j) + t * comp(ray.d, axis_j);
     if (b < rg.z || b > rg.w) return false;
-    rec.uv.x = (a - rg.x) / (rg.y - rg.x);
-    rec.uv.y = (b - rg.z) / (rg.w - rg.z);
+    if (EAGER_UV) {
+        rec.uv.x = (a - rg.x) / (rg.y - rg.x);
+        rec.uv.y = (b - rg.z) / (rg.w - rg.z);
+    }
     rec.t = t;
     F3 gn = f3(0);
     set_comp(gn, axis_k, 1.0f);
@@ -507,7 +523,7 @@ TRC_DEV bool trav_test_leaf(const SceneRef& S, const Ray& ray, HitRec& rec, Trav
     if (type == 1u) {
         if (STATS) cnt.leaf[1]++;
         ProfScope<STATS> scope(cnt, kProfSquare);
-        ok = square_hit_test(S, index, ray, rx, tv.ry, out);
+        ok = square_hit_test<EAGER_UV>(S, index, ray, rx, tv.ry, out);
         if (DEFER && ok) rec.PDF = scratch.PDF;                                   // ... the fields only ONE type writes
     } else if (type == 0u) {
         if (STATS) cnt.leaf[0]++;
@@ -539,7 +555,7 @@ TRC_DEV void trav_build_record(const SceneRef& S, const Ray& ray, HitRec& rec, c
     TravCounters nocount;
     float ry = tv.win_ry;
     if (type == 3u) triangle_record(S, index, ray, rec);
-    else if (type == 1u) square_hit_test(S, index, ray, FLT_MIN, ry, rec);
+    else if (type == 1u) { square_hit_test<EAGER_UV>(S, index, ray, FLT_MIN, ry, rec); if (!EAGER_UV) { rec.uv.x = 0; rec.uv.y = 0; } }
     else if (type == 0u) { sphere_hit_test<EAGER_UV>(S, index, ray, FLT_MIN, ry, rec); if (!EAGER_UV) { rec.uv.x = 0; rec.uv.y = 0; } }
     else if (DEFER != 2) cube_hit_test<false, VOL>(S, index, ray, ry, rec, nocount);
     rec.tag = tv.win_tag;

@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(kBlock, TRC_SPPM_CAMERA_WAVES) k_sppm_camera(c
             F3 minus_d = -ray.d;
             F3 wo = f3(dot(nx, minus_d), dot(ny, minus_d), dot(rec.sn, minus_d));
             F2 uu; uu.x = pcg_float(rng); uu.y = pcg_float(rng);
-            F3 attenuation = material_S_F(mtype, hit_color(cx.sh, rec), wo, wi, uu, bxPDF);
+            F3 attenuation = material_S_F(mtype, hit_color(cx.S, cx.sh, rec), wo, wi, uu, bxPDF);
             if (bxPDF <= 0) break;
             F3 pn = rec.sn * copysignf(1.0f, wi.z);
             F3 _origin = offset_ray(rec.p, pn);
@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(kBlock, TRC_SPPM_PHOTON_WAVES) k_sppm_photon(c
             F3 minus_d = -ray.d;
             F3 wo = f3(dot(nx, minus_d), dot(ny, minus_d), dot(rec.sn, minus_d));
             F2 uu; uu.x = pcg_float(rng); uu.y = pcg_float(rng);
-            F3 attenuation = material_S_F(mtype, hit_color(cx.sh, rec), wo, wi, uu, bxPDF);
+            F3 attenuation = material_S_F(mtype, hit_color(cx.S, cx.sh, rec), wo, wi, uu, bxPDF);
             if (bxPDF <= 0) alive = false;
             else {
                 ratio = ratio * (attenuation / fmaxf(FLT_EPSILON, bxPDF));
