@@ -26,7 +26,7 @@ LD_PRELOAD="$ASAN_RT" ASAN_OPTIONS=detect_leaks=0 TRC_HOST_LIB="$PWD/build/asan/
   python -m pytest -q -p no:cacheprovider -m "not gpu" tests/test_bvh_builder.py tests/test_host_scene.py tests/test_oracle_kat.py \
   tests/test_oracle_lbvh.py tests/test_oracle_volume.py tests/test_oracle_sppm.py tests/test_output_stage.py tests/test_sobol.py \
   tests/test_pbrt_scene.py tests/test_pbrt_reader.py tests/test_ply_hdr_readers.py tests/test_envmap.py tests/test_oracle_render.py \
-  tests/test_cpu_baseline.py tests/test_capture_layout.py > "$LOGS/pytest.log" 2>&1
+  tests/test_cpu_baseline.py tests/test_capture_layout.py tests/test_detmath.py > "$LOGS/pytest.log" 2>&1
 rc_py=$?
 
 PATTERN='ERROR: \|WARNING: ThreadSanitizer\|runtime error\|SUMMARY: .*Sanitizer'
