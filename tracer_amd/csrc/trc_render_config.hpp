@@ -81,9 +81,8 @@ constexpr bool hybrid_stack(int integrator) {
 constexpr int pwg_waves(int integrator) { return integrator == TRC_INTEGRATOR_PATH ? TRC_PWG_WAVES_PATH : (integrator == TRC_INTEGRATOR_MIS ? TRC_PWG_WAVES_MIS : TRC_PWG_WAVES_VOLUME); }
 constexpr int pwg_per_cu(int integrator) { return integrator == TRC_INTEGRATOR_PATH ? TRC_PWG_PER_CU_PATH : (integrator == TRC_INTEGRATOR_MIS ? TRC_PWG_PER_CU_MIS : TRC_PWG_PER_CU_VOLUME); }
 
-// The kernels themselves (trc_render_kernels.hpp) are instantiated in two translation units, so that each family is compiled
-// with its own arithmetic short cuts (dev_vec.hpp TRC_FAST_UNARY: -1.8 % on the LDS-resident tracePath kernel, +0.7 ... 1.9 % on the
-// kernels of trees read from memory, whose 64 registers it upsets) -- and in parallel:
+// The kernels themselves (trc_render_kernels.hpp) are instantiated in two translation units, so that each family can be compiled
+// with its own arithmetic short cuts (dev_vec.hpp TRC_FAST_UNARY; both have them since the guards became cheap) -- and in parallel:
 //   trc_render_lds.hip   k_render<true, ...>, k_render_strip<true, ...>          the whole tree staged in LDS (Cornell scenes)
 //   trc_render_mem.hip   k_render<false, ...>, k_render_strip<false, ...>, k_render_pwg<...>   trees read from memory (meshes)
 template <bool LDS, bool STATS, int INTEGRATOR, bool SOBOL = false>

@@ -1,9 +1,10 @@
 // trc_render_mem.hip -- the render kernels of trees read from memory (mesh scenes: BASELINE configs 3 / 4, traceVolume's scene):
-// one-wavefront workgroups, strips and the persistent workgroups.  Compiled WITHOUT dev_vec.hpp's guard-free reciprocal /
-// square root: at 64 registers per lane the extra code paths cost these kernels 0.7-1.9 % (profiles/r04/fast_unary_ab.txt).
-// Definitions: trc_render_kernels.hpp; launched from trc_abi.hip.
+// one-wavefront workgroups, strips and the persistent workgroups.  Compiled WITH dev_vec.hpp's guard-free forms since their
+// guards became one or two instructions (the first version, with three-instruction range tests and a seven-instruction reciprocal,
+// cost these kernels 0.7-1.9 % at 64 registers per lane: profiles/r04/fast_unary_ab.txt; now config 3 -1.2 %, traceVolume -0.7 %,
+// config 4 unchanged: profiles/r04/guard_cost_ab.txt).  Definitions: trc_render_kernels.hpp; launched from trc_abi.hip.
 #ifndef TRC_FAST_UNARY
-#define TRC_FAST_UNARY 0
+#define TRC_FAST_UNARY 1
 #endif
 #include "trc_render_kernels.hpp"
 
