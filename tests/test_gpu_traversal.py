@@ -60,6 +60,38 @@ def test_production_walk_matches_the_reference_walk(gpu, request, scene_name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scene_name", ["cornell", "cornell_spheres"])
+def test_lanes_outside_the_guarded_ranges_share_wavefronts_with_lanes_inside(gpu, request, scene_name):
+    """The short division / square-root forms of dev_vec.hpp run behind ONE wave-uniform guard per site: if any lane's operand
+    is outside the proven range, the whole wavefront redoes the site with the compiler's sequence.  Batches that put such lanes
+    among ordinary ones, inside the kernels: directions with exact zero components (the Cornell blocks are rotated about y, so
+    a ray with d.y == 0 has an object-space direction component of exactly 0: the cube slab divides by it; the square test
+    and 1 / direction likewise), denormal and huge components, origins exactly ON the planes of the walls."""
+    scene = request.getfixturevalue(scene_name)
+    gpu.upload_scene(scene.view)
+    base = random_rays(64 * 1500, 77, inside_only=True)
+    o, d = np.array(base["origin"], F32), np.array(base["direction"], F32)
+    n = len(o)
+    lane = np.arange(n) % 64
+    d[lane == 3, 1] = 0.0                       # d.y == 0 exactly
+    d[lane == 11, 0] = 0.0
+    d[lane == 12, 2] = -0.0
+    d[lane == 20, 1] = F32(1e-42)               # a denormal component
+    d[lane == 21, 0] = F32(-3e-39)
+    d[lane == 33] = np.array([0.0, 0.0, 1.0], F32)      # along an axis: two zeros
+    d[lane == 34] = np.array([0.0, -1.0, 0.0], F32)
+    o[lane == 40, 1] = 0.0                      # on the floor / a wall plane, exactly
+    o[lane == 41, 0] = 555.0
+    o[lane == 42, 2] = 555.0
+    o[lane == 50] *= F32(1e12)                  # far outside: huge numerators
+    rays = make_rays(o, d)
+    ref = po.trace_rays(scene.view, rays)
+    assert_records_equal(gpu.trace_rays(rays, production=True), ref, what="closest, production walk")
+    assert_records_equal(gpu.trace_rays(rays), ref, what="closest, instrumented walk")
+    assert (ref["pType"][ref["hit"] != 0] == abi.PRIM_CUBE).sum() > 2000     # the cube slab is exercised
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("scene_name", ["cornell_spheres", "ball_mesh_scene"])
 def test_shadow_rays_that_end_exactly_on_a_surface(gpu, request, scene_name):
     """tmax == the t of the surface the ray ends on (a light sample ON a square, a mesh vertex): Square / Triangle::hit_test
