@@ -367,6 +367,13 @@ trc_status trc_upload_scene(trc_ctx* ctx, const trc_scene* scene);
  * centroids, stable radix sort, Karras' binary radix tree, bottom-up boxes) and used by every later
  * trc_render / trc_trace_rays exactly like an uploaded tree. */
 trc_status trc_upload_scene_lbvh(trc_ctx* ctx, const trc_scene* scene);
+/* BVH::buildTree itself on the device (RT_Metal/Metal/BVH.hh:35-269; the host builder of this package is
+ * trc_host_build_tree): same input as trc_upload_scene_lbvh -- the n_bvh LEAF records -- and the tree the reference's
+ * 10-bucket SAH recursion builds from them, record for record (post-order interior numbering, the partition's own leaf
+ * order, median split of identical centroids, pairs ordered by centroid): rendering through it is rendering through the
+ * host-built tree.  Leaf boxes must be finite with |coordinates| <= 1e37 (TRC_ERR_BVH_INVALID otherwise).
+ * trc_download_bvh / trc_lbvh_info report on it like on an LBVH tree. */
+trc_status trc_upload_scene_sah(trc_ctx* ctx, const trc_scene* scene);
 /* the device-built tree in the reference's array layout (BVH.hh:246-269): [root, leaf 0..n-1, interior
  * 1..n-2], 2n-1 records.  out == NULL: only *n_nodes is written. */
 trc_status trc_download_bvh(trc_ctx* ctx, trc_BVH* out, uint32_t capacity, uint32_t* n_nodes);

@@ -1,0 +1,164 @@
+"""BVH::buildTree on the device (trc_upload_scene_sah, tracer_amd/csrc/trc_sah_build.hpp) against the two CPU statements of
+the reference's SAH build (RT_Metal/Metal/BVH.hh:35-269): oracle/oracle_sah.cpp (serial recursion on the reference's growing
+list) and the host builder of libtrc_host (parallel, slots assigned up front).  All 2n-1 records, bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from tracer_amd import abi, host
+from conftest import random_rays, camera_rays
+
+pytestmark = pytest.mark.gpu
+
+
+def raw(nodes):
+    return np.frombuffer(bytes(memoryview(nodes)), dtype=np.uint32).reshape(-1, 16)
+
+
+def first_difference(got, want):
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    return f"{len(bad)} of {len(want)} records differ, first at {bad[0]}: got {got[bad[0]]}, want {want[bad[0]]}" if len(bad) else ""
+
+
+def build_and_compare(gpu, view, leaves, n):
+    want = pyoracle.sah_build(leaves, n)
+    gpu.upload_scene_sah(view)
+    got = gpu.download_bvh()
+    n_nodes, height, ms = gpu.lbvh_info()
+    assert n_nodes == 2 * n - 1 and ms > 0
+    assert not first_difference(raw(got), raw(want))
+    return want, height, ms
+
+
+@pytest.mark.parametrize("kind", ["cornell", "spheres", "mesh", "mesh_large"])
+def test_device_sah_tree_is_the_reference_s_tree(gpu, kind):
+    if kind == "mesh":
+        sc = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.ball(60, 60, 1.0))            # 7 209 leaves: a few level rounds
+    elif kind == "mesh_large":
+        sc = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.ball(160, 160, 0.05))         # 51 209 leaves: many tasks per node
+    else:
+        sc = host.HostScene(abi.SCENE_CORNELL if kind == "cornell" else abi.SCENE_CORNELL_SPHERES)
+    want, height, _ = build_and_compare(gpu, sc.leaves_view(), sc.leaves(), sc.n_leaves)
+    assert not first_difference(raw(want), sc.bvh_array())          # ... which is also what the host builder made
+    assert height == sc.tree_depth()
+    # Scene::hit through the device-built tree == the oracle through the host-built tree, record for record
+    rays = random_rays(20000, 12)
+    got = gpu.trace_rays(rays)
+    ref = pyoracle.trace_rays(sc.view, rays)
+    for f in ref.dtype.names:
+        assert (got[f].view(np.uint32) == ref[f].view(np.uint32)).all(), f
+
+
+def leaf_records(boxes, n_sphere):
+    n = len(boxes)
+    leaves = (abi.BVH * n)()
+    for k, (lo, hi) in enumerate(boxes):
+        leaves[k].pType = abi.PRIM_SPHERE; leaves[k].pIndex = k % n_sphere
+        leaves[k].bBOX.mini.x, leaves[k].bBOX.mini.y, leaves[k].bBOX.mini.z = (float(v) for v in lo)
+        leaves[k].bBOX.maxi.x, leaves[k].bBOX.maxi.y, leaves[k].bBOX.maxi.z = (float(v) for v in hi)
+    return leaves
+
+
+def cases():
+    rng = np.random.default_rng(7)
+    out = {}
+    for n in (2, 3, 5, 17, 64, 65, 66, 129, 300, 5000):
+        out[f"identical_{n}"] = [((0, 0, 0), (1, 1, 1))] * n                                 # every split is the median split
+        out[f"nested_{n}"] = [((-1.0 - k,) * 3, (1.0 + k,) * 3) for k in range(n)]           # identical centroids, growing boxes
+    for n in (2, 3, 4, 9, 63, 64, 65, 257, 4097, 30000):
+        c = rng.uniform(-50, 50, (n, 3)).astype(np.float32); r = rng.uniform(0.01, 3.0, (n, 3)).astype(np.float32)
+        out[f"random_{n}"] = list(zip(c - r, c + r))
+    out["collinear_3000"] = [((k * 0.5, 0, 0), (k * 0.5 + 1, 1, 1)) for k in range(3000)]
+    out["two_clusters_9000"] = [((0, 0, 0), (1, 1, 1))] * 4500 + [((100, 0, 0), (101, 1, 1))] * 4500   # one real split, then medians
+    out["geometric_400"] = [((2.0 ** (k / 8), 0, 0), (2.0 ** (k / 8) + 0.001, 1, 1)) for k in range(400)]   # one-leaf splits near the top
+    grid = [((x, y, 0), (x + 0.5, y + 0.5, 0.5)) for y in range(120) for x in range(120)]      # many ties in bucket boundaries
+    out["grid_14400"] = grid
+    pairs = rng.integers(0, 4, (6000, 3)).astype(np.float32)                                    # many identical centroids
+    out["lattice_6000"] = [(p, p + 1) for p in pairs]
+    return out
+
+
+CASES = cases()
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_degenerate_and_ragged_leaf_sets(gpu, name):
+    sc = host.HostScene(abi.SCENE_CORNELL_SPHERES)
+    boxes = CASES[name]
+    n = len(boxes)
+    leaves = leaf_records(boxes, sc.view.n_sphere)
+    v = abi.Scene.from_buffer_copy(sc.leaves_view()); v.bvhList = C.cast(leaves, C.POINTER(abi.BVH)); v.n_bvh = n
+    want = pyoracle.sah_build(leaves, n)
+    depth = tree_depth(want)
+    if depth > abi.TRC_MAX_BVH_DEPTH:
+        from tracer_amd.device import TracerError
+        with pytest.raises(TracerError):
+            gpu.upload_scene_sah(v)
+        return
+    gpu.upload_scene_sah(v)
+    assert not first_difference(raw(gpu.download_bvh()), raw(want))
+    assert gpu.lbvh_info()[1] == depth
+
+
+def tree_depth(nodes):
+    a = raw(nodes)
+    depth = np.zeros(len(a), dtype=np.int64)
+    order = [0]
+    for i in order:
+        if a[i, 4] == np.uint32(abi.PRIM_BVH & 0xFFFFFFFF):
+            for c in (a[i, 1], a[i, 2]):
+                depth[c] = depth[i] + 1
+                order.append(int(c))
+    return int(depth.max())
+
+
+def test_rejected_inputs(gpu):
+    from tracer_amd.device import TracerError
+    sc = host.HostScene(abi.SCENE_CORNELL_SPHERES)
+    with pytest.raises(TracerError):
+        gpu.upload_scene_sah(sc.view)                               # bvhList[0] is the root, an interior record
+    for bad in (float("nan"), float("inf"), 3e37):
+        boxes = [((k, 0, 0), (k + 1, 1, 1)) for k in range(100)]
+        boxes[37] = ((0, 0, 0), (bad, 1, 1))
+        leaves = leaf_records(boxes, sc.view.n_sphere)
+        v = abi.Scene.from_buffer_copy(sc.leaves_view()); v.bvhList = C.cast(leaves, C.POINTER(abi.BVH)); v.n_bvh = 100
+        with pytest.raises(TracerError):
+            gpu.upload_scene_sah(v)
+    gpu.upload_scene_sah(sc.leaves_view())                          # the context is still usable
+    assert not first_difference(raw(gpu.download_bvh()), sc.bvh_array())
+
+
+def test_render_through_device_sah_tree(gpu):
+    sc = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.ball(40, 40, 1.0))
+    W, H = 96, 64
+    cam = host.prepare_camera(W, H)
+    gpu.set_camera(cam); gpu.resize(W, H)
+    rng = host.fill_rng(99, W, H)
+    frames = []
+    for upload in (lambda: gpu.upload_scene(sc.view), lambda: gpu.upload_scene_sah(sc.leaves_view())):
+        upload()
+        gpu.upload_rng(rng); gpu.clear_accum()
+        gpu.render(spp=4, integrator=abi.INTEGRATOR_MIS)
+        frames.append(gpu.download_accum().copy())
+    assert (frames[0].view(np.uint32) == frames[1].view(np.uint32)).all()
+    r = rng.copy()
+    ref, _ = pyoracle.render(sc.view, cam, W, H, r, spp=4, integrator=abi.INTEGRATOR_MIS)
+    assert (frames[1].view(np.uint32) == ref.view(np.uint32)).all()
+
+
+def test_million_triangle_sah_build(gpu):
+    mesh = host.Mesh.golden("teapot").replicate(8, 80.0)           # BASELINE config 4's scene: 1 005 056 triangles
+    sc = host.HostScene(abi.SCENE_CORNELL_MESH, mesh)
+    gpu.upload_scene_sah(sc.leaves_view())
+    n_nodes, height, ms = gpu.lbvh_info()
+    print(f"device SAH build of {sc.n_leaves} leaves: {ms:.2f} ms on the GPU, depth {height}")
+    assert not first_difference(raw(gpu.download_bvh()), sc.bvh_array())     # the host builder's 2 010 111 records
+    assert height == sc.tree_depth() and ms < 100.0
+    W, H = 1920, 1080
+    rays = camera_rays(host.prepare_camera(W, H), W, H, step=8)
+    got = gpu.trace_rays(rays)
+    ref = pyoracle.trace_rays(sc.view, rays)
+    for f in ref.dtype.names:
+        assert (got[f].view(np.uint32) == ref[f].view(np.uint32)).all(), f

@@ -209,7 +209,7 @@ for _t, _n in _EXPECTED_SIZES.items():
 # every symbol include/tracer_abi.h declares, by library (checked by tests/test_abi_symbols.py)
 DEVICE_SYMBOLS = [
     "trc_abi_version", "trc_build_flavor", "trc_status_string", "trc_last_error", "trc_create", "trc_destroy",
-    "trc_upload_scene", "trc_upload_density", "trc_upload_scene_lbvh", "trc_download_bvh", "trc_lbvh_info", "trc_set_camera", "trc_set_environment", "trc_set_environment_map", "trc_resize", "trc_seed",
+    "trc_upload_scene", "trc_upload_density", "trc_upload_scene_lbvh", "trc_upload_scene_sah", "trc_download_bvh", "trc_lbvh_info", "trc_set_camera", "trc_set_environment", "trc_set_environment_map", "trc_resize", "trc_seed",
     "trc_upload_rng", "trc_download_rng", "trc_upload_accum", "trc_download_accum", "trc_clear_accum", "trc_tonemap",
     "trc_render", "trc_synchronize", "trc_trace_rays", "trc_get_stats", "trc_reset_stats", "trc_debug_profile",
     "trc_sppm_init", "trc_sppm_frames", "trc_sppm_download", "trc_sppm_hash_cells",

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cfloat>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -475,6 +476,8 @@ struct Buffers {
     }
 };
 
+#include "trc_sah_build.hpp"
+
 }  // namespace
 
 // stable LSD sort of (key, value) pairs on the 24 low key bits, 3 passes of the radix kernels above; the result is in
@@ -494,9 +497,10 @@ void trc_sort_pairs24(hipStream_t st, uint32_t* keys[2], uint32_t* vals[2], uint
 }
 uint32_t trc_sort_hist_words(uint32_t n) { return 256u * ((n + kSortTile - 1) / kSortTile); }
 
-extern "C" {
-
-trc_status trc_upload_scene_lbvh(trc_ctx* ctx, const trc_scene* s) {
+// trc_upload_scene_lbvh (sah = false: Morton order, radix tree, rotations) and trc_upload_scene_sah (sah = true: the
+// reference's own binned-SAH build, trc_sah_build.hpp) share everything around the topology: leaf intake, boxes bottom-up,
+// fat nodes by depth, the tree in the reference's array layout.
+static trc_status upload_device_tree(trc_ctx* ctx, const trc_scene* s, bool sah) {
     { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx) return TRC_ERR_INVALID_ARG;
     if (!s || !s->bvhList || s->n_bvh < 2) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "lbvh: need >= 2 leaf records");
@@ -560,18 +564,23 @@ trc_status trc_upload_scene_lbvh(trc_ctx* ctx, const trc_scene* s) {
     LeafLimits lim;
     lim.n[0] = s->n_sphere; lim.n[1] = s->n_square; lim.n[2] = s->n_cube; lim.n[3] = s->n_index / 3;
     hipLaunchKernelGGL(k_lbvh_prepare, g_leaf, b256, 0, st, ctx->d_bvh_ref + 1, n, lim, d_leaves, d_bounds + 6);
-    hipLaunchKernelGGL(k_lbvh_bounds, dim3(std::min<uint32_t>((n + 255) / 256, 1024u)), b256, 0, st, d_leaves, n, d_bounds);
-    hipLaunchKernelGGL(k_lbvh_keys, g_leaf, b256, 0, st, d_leaves, n, d_bounds, d_keys[0], d_vals[0]);
     int cur = 0;
-    for (uint32_t shift = 0; shift < 32; shift += 8) {
-        hipLaunchKernelGGL(k_radix_hist, dim3(n_sort_blocks), dim3(kSortBlock), 0, st, d_keys[cur], n, shift, d_hist, n_sort_blocks);
-        hipLaunchKernelGGL(k_radix_row_scan, dim3(256), b256, 0, st, d_hist, n_sort_blocks, d_digit_base);
-        hipLaunchKernelGGL(k_radix_digit_base, dim3(1), b256, 0, st, d_digit_base);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(n_sort_blocks), dim3(kSortBlock), 0, st, d_keys[cur], d_vals[cur], d_keys[cur ^ 1],
-                           d_vals[cur ^ 1], n, shift, d_hist, d_digit_base, n_sort_blocks);
-        cur ^= 1;
+    if (!sah) {
+        hipLaunchKernelGGL(k_lbvh_bounds, dim3(std::min<uint32_t>((n + 255) / 256, 1024u)), b256, 0, st, d_leaves, n, d_bounds);
+        hipLaunchKernelGGL(k_lbvh_keys, g_leaf, b256, 0, st, d_leaves, n, d_bounds, d_keys[0], d_vals[0]);
+        for (uint32_t shift = 0; shift < 32; shift += 8) {
+            hipLaunchKernelGGL(k_radix_hist, dim3(n_sort_blocks), dim3(kSortBlock), 0, st, d_keys[cur], n, shift, d_hist, n_sort_blocks);
+            hipLaunchKernelGGL(k_radix_row_scan, dim3(256), b256, 0, st, d_hist, n_sort_blocks, d_digit_base);
+            hipLaunchKernelGGL(k_radix_digit_base, dim3(1), b256, 0, st, d_digit_base);
+            hipLaunchKernelGGL(k_radix_scatter, dim3(n_sort_blocks), dim3(kSortBlock), 0, st, d_keys[cur], d_vals[cur], d_keys[cur ^ 1],
+                               d_vals[cur ^ 1], n, shift, d_hist, d_digit_base, n_sort_blocks);
+            cur ^= 1;
+        }
+        hipLaunchKernelGGL(k_lbvh_hierarchy, g_int, b256, 0, st, d_keys[cur], d_vals[cur], n, tp);
+    } else {
+        const trc_status bs = sah_build_topology(ctx, buf, d_leaves, n, d_bounds + 6, tp, d_vals[0]);
+        if (bs != TRC_OK) return bs;
     }
-    hipLaunchKernelGGL(k_lbvh_hierarchy, g_int, b256, 0, st, d_keys[cur], d_vals[cur], n, tp);
     // refit passes: a tree of height h needs h passes; check the root every few passes beyond the usual depth
     uint32_t root_done = 0, bad_leaves = 0;
     const uint32_t pass_limit = TRC_MAX_BVH_DEPTH + 1;
@@ -588,12 +597,13 @@ trc_status trc_upload_scene_lbvh(trc_ctx* ctx, const trc_scene* s) {
             if (bad_leaves & 1u) return trc_fail(ctx, TRC_ERR_BVH_INVALID, "lbvh: input must be leaf records only");
             if (bad_leaves & 2u) return trc_fail(ctx, TRC_ERR_BVH_INVALID, "bvh: leaf with bad primitive type/index");
             if (bad_leaves & 4u) return trc_fail(ctx, TRC_ERR_UNSUPPORTED, "bvh: primitive index exceeds 29 bits");
+            if (bad_leaves & 8u) return trc_fail(ctx, TRC_ERR_BVH_INVALID, "sah: leaf box not finite or beyond 1e37");
         }
         if (!root_done) return trc_fail(ctx, TRC_ERR_BVH_INVALID, "lbvh: tree deeper than TRC_MAX_BVH_DEPTH");
         return TRC_OK;
     };
     { trc_status rs = refit(); if (rs != TRC_OK) return rs; }
-    for (int sweep = 0; sweep < kRotationSweeps; ++sweep) {
+    for (int sweep = 0; sweep < (sah ? 0 : kRotationSweeps); ++sweep) {
         // d_arrived[i] = pass in which i was fitted = its height; the root's is the height of the tree.  Nodes of
         // height 1 have two leaf children and nothing to rotate.
         const uint32_t h = root_done;
@@ -645,6 +655,11 @@ trc_status trc_upload_scene_lbvh(trc_ctx* ctx, const trc_scene* s) {
     ctx->cost_valid = false; ctx->d_last_order = nullptr;      // another scene: the recorded block costs say nothing about it
     return TRC_OK;
 }
+
+extern "C" {
+
+trc_status trc_upload_scene_lbvh(trc_ctx* ctx, const trc_scene* s) { return upload_device_tree(ctx, s, false); }
+trc_status trc_upload_scene_sah(trc_ctx* ctx, const trc_scene* s) { return upload_device_tree(ctx, s, true); }
 
 trc_status trc_download_bvh(trc_ctx* ctx, trc_BVH* out, uint32_t capacity, uint32_t* n_nodes) {
     { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)

@@ -1,0 +1,553 @@
+// trc_sah_build.hpp -- the reference's binned-SAH tree build on the device (included by trc_lbvh.hip, inside its
+// unnamed namespace, after the kernels it shares: DLeaf, DTopo, ordered_of / float_of, the wave scan).
+//
+// What is built is BVH::buildTree / BVH::make of RT_Metal/Metal/BVH.hh:35-269 -- centroid bounds, widest axis, 10 buckets,
+// cost_i = 1 + (n0 A0 + n1 A1) / A(centroid box), first minimum, partition by bucket <= split with the two-ended swap
+// loop of BVH.hh:154-168, median split where the partition is one-sided, two leaves ordered by centroid -- so the tree is
+// the one tracer_amd/host/bvh_builder.cpp builds on the host and oracle/oracle_sah.cpp restates, record for record (same
+// post-order interior numbering, same leaf order inside every node).  The host recursion becomes:
+//
+//   large nodes (more than kFinishSpan leaves), one LEVEL per round of four launches over the leaf records, which are kept
+//   in tree order (32 B each, moved when a partition moves them: every pass streams contiguous memory):
+//     k_sah_bins     per task (<= kChunk consecutive records of one node): bucket counts and boxes in LDS, one set of
+//                    atomics per task into the node's row; the task's bucket histogram is kept
+//     k_sah_split    one wavefront per node: the nine costs, the split, a scan of the task histograms (how many records
+//                    below the split precede each task), the node's topology record and its children's rows
+//     k_sah_scatter  per task: the two-ended swap loop in closed form -- the k-th misplaced record from the left changes
+//                    places with the k-th misplaced record from the right -- misplaced records go to a side array by rank;
+//                    the children's centroid bounds are accumulated on the way
+//     k_sah_apply    misplaced positions take their partner's record
+//   small nodes: k_sah_finish, one wavefront per subtree of <= 64 leaves, one lane per leaf, the whole subtree in LDS.
+//
+// Integer / min-max work on 32-B records: streaming passes bound by HBM and launch latency, nothing for MFMA.
+// Preconditions checked on the device: finite boxes with |coordinates| <= 1e37 (then a one-sided partition can only
+// come from identical centroids, where the reference's stable sort leaves the order alone).
+
+constexpr uint32_t kSahBuckets = 10;
+constexpr uint32_t kFinishSpan = 64;        // subtrees of at most this many leaves are finished by one wavefront
+constexpr uint32_t kChunk = 2048;           // records per task of the level passes
+constexpr uint32_t kNoNode = 0xFFFFFFFFu;
+
+struct SNode {                              // a node of the level being split; 88 dwords
+    uint32_t first, last, qbase, task0;     // record range, first post-order slot of its subtree, first task
+    uint32_t cb[6];                         // centroid bounds as ordered uints (min xyz, max xyz)
+    uint32_t split, mid, fallback, n_below; // written by k_sah_split
+    uint32_t child[2];                      // rows of the children in the next level's table, or kNoNode
+    uint32_t axis, _pad;
+    uint32_t count[kSahBuckets];
+    uint32_t bb[kSahBuckets][6];            // bucket boxes as ordered uints
+};
+struct SFinish { uint32_t first, last, qbase, _pad; };
+
+struct SahBufs {
+    DLeaf* elems; DLeaf* tmp;               // records in tree order; side array of the partition
+    uint32_t* mv;                           // per position: 0 = stays, else (rank + 1) | side << 31
+    SNode* nodes[2]; uint32_t* task_node[2];
+    uint32_t* task_hist; uint32_t* task_prefix;
+    SFinish* finish;
+    uint32_t* counters;                     // [0] finish entries, [1] error bits, [2 + 2 * level ...] nodes / tasks of a level
+    uint32_t n;
+};
+
+__device__ __forceinline__ uint32_t sah_id_of(uint32_t q, uint32_t n) { return q + 2u == n ? 0u : q + 1u; }   // post-order slot -> interior index (root = 0)
+__device__ __forceinline__ float sah_centroid1(float mn, float mx) { return mn + (mx - mn) / 2.0f; }           // AABB.hh:22-25
+__device__ __forceinline__ uint32_t sah_widest(float dx, float dy, float dz) {                                   // AABB.hh:42-49
+    if (dx > dy && dx > dz) return 0u;
+    return dy > dz ? 1u : 2u;
+}
+__device__ __forceinline__ uint32_t sah_bucket(float c, float lo, float extent) {                                // BVH.hh:99-100
+    const float rel = (c - lo) / extent;
+    const float fb = (float)kSahBuckets * rel;
+    const uint32_t b = (fb >= 0.0f) ? (uint32_t)fb : 0u;
+    return b < kSahBuckets - 1u ? b : kSahBuckets - 1u;
+}
+__device__ __forceinline__ float sah_area(const float mn[3], const float mx[3]) {                               // AABB.hh:27-30
+    const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+    return 2 * (dx * dy + dx * dz + dy * dz);
+}
+
+// records in tree order start as the leaves in input order; _pad carries the leaf index.  bad bit 8: a box the build
+// does not take (non-finite, or beyond 1e37).
+__global__ void __launch_bounds__(256) k_sah_init(const DLeaf* leaves, uint32_t n, DLeaf* elems, uint32_t* bad) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    DLeaf d = leaves[i];
+    d._pad = i;
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) ok = ok && fabsf(d.mn[a]) <= 1e37f && fabsf(d.mx[a]) <= 1e37f;      // false for NaN too
+    if (!ok) atomicOr(bad, 8u);
+    elems[i] = d;
+}
+
+// centroid bounds of records [0, n) into row 0 of the level table (grid-stride, wave reduction, 6 atomics per workgroup)
+__global__ void __launch_bounds__(256) k_sah_root_bounds(const DLeaf* elems, uint32_t n, SNode* nodes) {
+    __shared__ uint32_t part[4][6];
+    uint32_t lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const DLeaf d = elems[i];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const uint32_t o = ordered_of(sah_centroid1(d.mn[a], d.mx[a]));
+            lo[a] = min(lo[a], o); hi[a] = max(hi[a], o);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[a] = min(lo[a], (uint32_t)__shfl_xor((int)lo[a], off, 64));
+            hi[a] = max(hi[a], (uint32_t)__shfl_xor((int)hi[a], off, 64));
+        }
+    }
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { part[wave][a] = lo[a]; part[wave][3 + a] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const uint32_t a = threadIdx.x;
+        atomicMin(&nodes[0].cb[a], min(min(part[0][a], part[1][a]), min(part[2][a], part[3][a])));
+        atomicMax(&nodes[0].cb[3 + a], max(max(part[0][3 + a], part[1][3 + a]), max(part[2][3 + a], part[3][3 + a])));
+    }
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off, 64));
+    return v;
+}
+struct SahAxis { uint32_t axis; float lo, extent; };
+__device__ __forceinline__ SahAxis sah_axis_of(const uint32_t cb[6]) {
+    float lo[3], hi[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { lo[a] = float_of(cb[a]); hi[a] = float_of(cb[3 + a]); }
+    SahAxis r;
+    r.axis = sah_widest(hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]);
+    r.lo = r.axis == 0 ? lo[0] : (r.axis == 1 ? lo[1] : lo[2]);
+    r.extent = (r.axis == 0 ? hi[0] : (r.axis == 1 ? hi[1] : hi[2])) - r.lo;
+    return r;
+}
+__device__ __forceinline__ float sah_axis_centroid(const DLeaf& d, uint32_t axis) {
+    return axis == 0 ? sah_centroid1(d.mn[0], d.mx[0]) : (axis == 1 ? sah_centroid1(d.mn[1], d.mx[1]) : sah_centroid1(d.mn[2], d.mx[2]));
+}
+
+__global__ void __launch_bounds__(256) k_sah_bins(const DLeaf* elems, SNode* nodes, const uint32_t* task_node, uint32_t* task_hist) {
+    __shared__ uint32_t s_cnt[kSahBuckets];
+    __shared__ uint32_t s_bb[kSahBuckets * 6];
+    const uint32_t t = blockIdx.x, node = task_node[t];
+    SNode& N = nodes[node];
+    const uint32_t p0 = N.first + (t - N.task0) * kChunk, p1 = min(N.last, p0 + kChunk);
+    const SahAxis ax = sah_axis_of(N.cb);
+    if (threadIdx.x < kSahBuckets) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x < kSahBuckets * 6) s_bb[threadIdx.x] = (threadIdx.x % 6u) < 3u ? 0xFFFFFFFFu : 0u;
+    __syncthreads();
+    for (uint32_t p = p0 + threadIdx.x; p < p1; p += 256u) {
+        const DLeaf d = elems[p];
+        const uint32_t b = sah_bucket(sah_axis_centroid(d, ax.axis), ax.lo, ax.extent);
+        atomicAdd(&s_cnt[b], 1u);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&s_bb[b * 6 + a], ordered_of(d.mn[a]));
+            atomicMax(&s_bb[b * 6 + 3 + a], ordered_of(d.mx[a]));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kSahBuckets) {
+        const uint32_t c = s_cnt[threadIdx.x];
+        task_hist[t * kSahBuckets + threadIdx.x] = c;
+        if (c) atomicAdd(&N.count[threadIdx.x], c);
+    }
+    if (threadIdx.x < kSahBuckets * 6 && s_cnt[threadIdx.x / 6u]) {
+        const uint32_t b = threadIdx.x / 6u, a = threadIdx.x % 6u;
+        if (a < 3u) atomicMin(&N.bb[b][a], s_bb[threadIdx.x]); else atomicMax(&N.bb[b][a], s_bb[threadIdx.x]);
+    }
+}
+
+// the nine costs of BVH.hh:112-140 from bucket counts and boxes; returns the split (first minimum)
+__device__ uint32_t sah_choose_split(const uint32_t count[kSahBuckets], const float bmn[kSahBuckets][3], const float bmx[kSahBuckets][3],
+                                     float denom) {
+    float best = 0.0f;
+    uint32_t best_i = 0;
+    for (uint32_t i = 0; i + 1 < kSahBuckets; ++i) {
+        float mn0[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx0[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        float mn1[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx1[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        int c0 = 0, c1 = 0;
+        for (uint32_t j = 0; j < kSahBuckets; ++j) {
+            if (j <= i) { for (int a = 0; a < 3; ++a) { mn0[a] = fminf(mn0[a], bmn[j][a]); mx0[a] = fmaxf(mx0[a], bmx[j][a]); } c0 += (int)count[j]; }
+            else        { for (int a = 0; a < 3; ++a) { mn1[a] = fminf(mn1[a], bmn[j][a]); mx1[a] = fmaxf(mx1[a], bmx[j][a]); } c1 += (int)count[j]; }
+        }
+        const float cost = 1 + ((float)c0 * sah_area(mn0, mx0) + (float)c1 * sah_area(mn1, mx1)) / denom;
+        if (i == 0 || cost < best) { best = cost; best_i = i; }
+    }
+    return best_i;
+}
+
+// One wavefront per node of the level.  Lane 0 decides; all lanes scan the task histograms and fill the children's rows.
+__global__ void __launch_bounds__(64) k_sah_split(SNode* nodes, const uint32_t* task_hist, uint32_t* task_prefix, SNode* next_nodes,
+                                                 uint32_t* next_task_node, uint32_t* next_counts /* [2]: nodes, tasks */, SFinish* finish,
+                                                 uint32_t* counters, DTopo tp, uint32_t n) {
+    __shared__ uint32_t s_split, s_child_row[2], s_child_task0[2], s_child_tasks[2];
+    const uint32_t lane = threadIdx.x;
+    SNode& N = nodes[blockIdx.x];
+    const uint32_t first = N.first, last = N.last, span = last - first;
+    const uint32_t n_tasks = (span + kChunk - 1) / kChunk;
+    if (lane == 0) {
+        const SahAxis ax = sah_axis_of(N.cb);
+        uint32_t split = 0, n_below = 0, mid = first;
+        bool fallback = !(ax.extent > 0.0f);
+        if (!fallback) {
+            float bmn[kSahBuckets][3], bmx[kSahBuckets][3], cmn[3], cmx[3];
+            uint32_t count[kSahBuckets];
+            for (uint32_t b = 0; b < kSahBuckets; ++b) {
+                count[b] = N.count[b];
+                for (int a = 0; a < 3; ++a) {
+                    bmn[b][a] = count[b] ? float_of(N.bb[b][a]) : FLT_MAX;
+                    bmx[b][a] = count[b] ? float_of(N.bb[b][3 + a]) : -FLT_MAX;
+                }
+            }
+            for (int a = 0; a < 3; ++a) { cmn[a] = float_of(N.cb[a]); cmx[a] = float_of(N.cb[3 + a]); }
+            split = sah_choose_split(count, bmn, bmx, sah_area(cmn, cmx));
+            for (uint32_t b = 0; b <= split; ++b) n_below += count[b];
+            mid = first + n_below;
+            fallback = mid <= first || mid >= last;
+            if (fallback) atomicOr(&counters[1], 16u);          // cannot happen with a positive finite extent (header)
+        }
+        if (fallback) mid = first + span / 2;
+        N.split = split; N.mid = mid; N.fallback = fallback ? 1u : 0u; N.n_below = n_below; N.axis = ax.axis;
+        s_split = split;
+        // topology of this node and the rows of its children
+        const uint32_t self = sah_id_of(N.qbase + span - 2u, n);
+        uint32_t link[2];
+        for (int side = 0; side < 2; ++side) {
+            const uint32_t cf = side ? mid : first, cl = side ? last : mid, cs = cl - cf;
+            const uint32_t cq = side ? N.qbase + (mid - first) - 1u : N.qbase;
+            s_child_row[side] = kNoNode; s_child_tasks[side] = 0; s_child_task0[side] = 0;
+            if (cs == 1u) { link[side] = kChildLeaf | cf; tp.parent_leaf[cf] = self; continue; }
+            const uint32_t ci = sah_id_of(cq + cs - 2u, n);
+            link[side] = ci; tp.parent_interior[ci] = self;
+            if (cs <= kFinishSpan) {
+                const uint32_t k = atomicAdd(&counters[0], 1u);
+                SFinish f; f.first = cf; f.last = cl; f.qbase = cq; f._pad = 0;
+                finish[k] = f;
+            } else {
+                const uint32_t nt = (cs + kChunk - 1) / kChunk;
+                const uint32_t row = atomicAdd(&next_counts[0], 1u), t0 = atomicAdd(&next_counts[1], nt);
+                SNode& c = next_nodes[row];
+                c.first = cf; c.last = cl; c.qbase = cq; c.task0 = t0;
+                s_child_row[side] = row; s_child_task0[side] = t0; s_child_tasks[side] = nt;
+            }
+        }
+        N.child[0] = s_child_row[0]; N.child[1] = s_child_row[1];
+        tp.child_l[self] = link[0]; tp.child_r[self] = link[1]; tp.axis[self] = ax.axis;
+        if (self == 0u) tp.parent_interior[0] = 0u;
+    }
+    __syncthreads();
+    // records below the split in the tasks before each task
+    const uint32_t split = s_split;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n_tasks; base += 64u) {
+        const uint32_t k = base + lane;
+        uint32_t v = 0;
+        if (k < n_tasks) { const uint32_t* h = task_hist + (size_t)(N.task0 + k) * kSahBuckets; for (uint32_t b = 0; b <= split; ++b) v += h[b]; }
+        const uint32_t inc = wave_inclusive_scan(v, lane);
+        if (k < n_tasks) task_prefix[N.task0 + k] = carry + inc - v;
+        carry += (uint32_t)__shfl((int)inc, 63, 64);
+    }
+    // children's rows: identity bounds and bins, and their tasks
+    for (int side = 0; side < 2; ++side) {
+        const uint32_t row = s_child_row[side];
+        if (row == kNoNode) continue;
+        SNode& c = next_nodes[row];
+        if (lane < 6u) c.cb[lane] = lane < 3u ? 0xFFFFFFFFu : 0u;
+        if (lane < kSahBuckets) c.count[lane] = 0u;
+        if (lane < kSahBuckets * 6u) c.bb[lane / 6u][lane % 6u] = (lane % 6u) < 3u ? 0xFFFFFFFFu : 0u;
+        for (uint32_t k = lane; k < s_child_tasks[side]; k += 64u) next_task_node[s_child_task0[side] + k] = row;
+    }
+}
+
+// exclusive scan of a predicate over the 256 threads of a workgroup; wave_tot: 4 words of LDS
+__device__ __forceinline__ uint32_t block_pred_scan256(bool pred, uint32_t* wave_tot, uint32_t& total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(pred);
+    if (lane == 0) wave_tot[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < wave; ++w) before += wave_tot[w];
+    total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    __syncthreads();
+    return before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+__global__ void __launch_bounds__(256) k_sah_scatter(const DLeaf* elems, DLeaf* tmp, uint32_t* mv, const SNode* nodes, SNode* next_nodes,
+                                                    const uint32_t* task_node, const uint32_t* task_prefix) {
+    __shared__ uint32_t wave_tot[4];
+    __shared__ uint32_t s_cb[2][6];
+    const uint32_t t = blockIdx.x, node = task_node[t];
+    const SNode& N = nodes[node];
+    const uint32_t first = N.first, last = N.last, mid = N.mid, split = N.split, n_below = N.n_below;
+    const bool fallback = N.fallback != 0u;
+    const uint32_t p0 = first + (t - N.task0) * kChunk, p1 = min(last, p0 + kChunk);
+    const SahAxis ax = sah_axis_of(N.cb);
+    if (threadIdx.x < 12u) s_cb[threadIdx.x / 6u][threadIdx.x % 6u] = (threadIdx.x % 6u) < 3u ? 0xFFFFFFFFu : 0u;
+    uint32_t lo[2][3] = {{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}}, hi[2][3] = {{0u, 0u, 0u}, {0u, 0u, 0u}};
+    uint32_t running = task_prefix[t];
+    for (uint32_t base = p0; base < p1; base += 256u) {
+        const uint32_t p = base + threadIdx.x;
+        const bool valid = p < p1;
+        DLeaf d{};
+        if (valid) d = elems[p];
+        float c[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) c[a] = sah_centroid1(d.mn[a], d.mx[a]);
+        const float ca = ax.axis == 0 ? c[0] : (ax.axis == 1 ? c[1] : c[2]);
+        const bool below = valid && (fallback ? p < mid : sah_bucket(ca, ax.lo, ax.extent) <= split);
+        uint32_t total;
+        const uint32_t bp = running + block_pred_scan256(below, wave_tot, total);
+        running += total;
+        if (valid) {
+            uint32_t m = 0;
+            if (p < mid && !below) { const uint32_t k = (p - first) - bp; tmp[first + k] = d; m = k + 1u; }
+            else if (p >= mid && below) { const uint32_t k = n_below - bp - 1u; tmp[last - 1u - k] = d; m = (k + 1u) | 0x80000000u; }
+            mv[p] = m;
+            const int s = below ? 0 : 1;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const uint32_t o = ordered_of(c[a]);
+                if (s == 0) { lo[0][a] = min(lo[0][a], o); hi[0][a] = max(hi[0][a], o); }
+                else        { lo[1][a] = min(lo[1][a], o); hi[1][a] = max(hi[1][a], o); }
+            }
+        }
+    }
+    // children's centroid bounds (only children that are split on the next level have a row)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if (N.child[s] == kNoNode) continue;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            uint32_t l = lo[s][a], h = hi[s][a];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                l = min(l, (uint32_t)__shfl_xor((int)l, off, 64));
+                h = max(h, (uint32_t)__shfl_xor((int)h, off, 64));
+            }
+            if ((threadIdx.x & 63u) == 0u) { atomicMin(&s_cb[s][a], l); atomicMax(&s_cb[s][3 + a], h); }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 12u) {
+        const uint32_t s = threadIdx.x / 6u, a = threadIdx.x % 6u;
+        if (N.child[s] != kNoNode) {
+            if (a < 3u) atomicMin(&next_nodes[N.child[s]].cb[a], s_cb[s][a]); else atomicMax(&next_nodes[N.child[s]].cb[a], s_cb[s][a]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_sah_apply(DLeaf* elems, const DLeaf* tmp, const uint32_t* mv, const SNode* nodes, const uint32_t* task_node) {
+    const uint32_t t = blockIdx.x;
+    const SNode& N = nodes[task_node[t]];
+    if (N.fallback) return;
+    const uint32_t first = N.first, last = N.last;
+    const uint32_t p0 = first + (t - N.task0) * kChunk, p1 = min(last, p0 + kChunk);
+    for (uint32_t p = p0 + threadIdx.x; p < p1; p += 256u) {
+        const uint32_t m = mv[p];
+        if (!m) continue;
+        const uint32_t k = (m & 0x7FFFFFFFu) - 1u;
+        elems[p] = (m >> 31) ? tmp[first + k] : tmp[last - 1u - k];       // a position on the right takes the k-th record from the left
+    }
+}
+
+__global__ void __launch_bounds__(256) k_sah_vals(const DLeaf* elems, uint32_t n, uint32_t* vals) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) vals[i] = elems[i]._pad;
+}
+
+// One wavefront per subtree of <= 64 leaves: lane p = position p of the subtree's range.  Every level of the subtree is one
+// trip of the loop, all of its nodes side by side (a lane works for the node its position is in).
+__global__ void __launch_bounds__(64) k_sah_finish(const DLeaf* elems, const SFinish* finish, uint32_t* vals, uint32_t* counters, DTopo tp, uint32_t n) {
+    __shared__ float s_c[3][64], s_mn[3][64], s_mx[3][64];      // by record (the lane that loaded it)
+    __shared__ uint32_t s_ord[64], s_bk[64], s_x[64];            // by position: record, its bucket; exchange
+    __shared__ float s_cost[64 * 9];                             // by first position of a node
+    const uint32_t lane = threadIdx.x;
+    const SFinish f = finish[blockIdx.x];
+    const uint32_t F = f.first, S = f.last - f.first;
+    uint32_t leaf = 0;
+    if (lane < S) {
+        const DLeaf d = elems[F + lane];
+        leaf = d._pad;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { s_mn[a][lane] = d.mn[a]; s_mx[a][lane] = d.mx[a]; s_c[a][lane] = sah_centroid1(d.mn[a], d.mx[a]); }
+    }
+    s_ord[lane] = lane;
+    uint32_t nf = 0, nl = S, nq = f.qbase;
+    __syncthreads();
+    for (;;) {
+        const uint32_t span = nl - nf;
+        const bool active = lane < S && span >= 2u;
+        if (__ballot(active) == 0ull) break;
+        const uint32_t maxspan = wave_max_u32(active ? span : 0u);
+        // centroid bounds of the node (every lane of a node computes the same thing)
+        float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (uint32_t k = 0; k < maxspan; ++k) {
+            if (active && k < span) {
+                const uint32_t e = s_ord[nf + k];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], s_c[a][e]); hi[a] = fmaxf(hi[a], s_c[a][e]); }
+            }
+        }
+        const uint32_t axis = sah_widest(hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]);
+        const float alo = axis == 0 ? lo[0] : (axis == 1 ? lo[1] : lo[2]);
+        const float extent = (axis == 0 ? hi[0] : (axis == 1 ? hi[1] : hi[2])) - alo;
+        const uint32_t me = s_ord[lane < S ? lane : 0u];
+        const float my_key = axis == 0 ? s_c[0][me] : (axis == 1 ? s_c[1][me] : s_c[2][me]);
+        uint32_t mid = nf + 1u;
+        bool below = false, moved = false;
+        uint32_t rank = 0;
+        if (active && span == 2u) {                                                        // BVH.hh:59-77
+            const uint32_t ea = s_ord[nf], eb = s_ord[nf + 1u];
+            const float ka = axis == 0 ? s_c[0][ea] : (axis == 1 ? s_c[1][ea] : s_c[2][ea]);
+            const float kb = axis == 0 ? s_c[0][eb] : (axis == 1 ? s_c[1][eb] : s_c[2][eb]);
+            if (!(ka < kb)) { moved = true; rank = 0; below = lane != nf; }                // the two change places
+        }
+        const bool wide = active && span > 2u;
+        const bool degenerate = !(extent > 0.0f);
+        if (wide && !degenerate) s_bk[lane] = sah_bucket(my_key, alo, extent);
+        __syncthreads();
+        // the nine costs: the lane at offset o of a node takes candidates o, o + span, ...
+        {
+            const float denom = sah_area(lo, hi);
+            for (uint32_t i = lane - nf; wide && !degenerate && i < kSahBuckets - 1u; i += span) {
+                float mn0[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx0[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+                float mn1[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx1[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+                int c0 = 0, c1 = 0;
+                for (uint32_t k = nf; k < nl; ++k) {
+                    const uint32_t e = s_ord[k];
+                    if (s_bk[k] <= i) { for (int a = 0; a < 3; ++a) { mn0[a] = fminf(mn0[a], s_mn[a][e]); mx0[a] = fmaxf(mx0[a], s_mx[a][e]); } ++c0; }
+                    else              { for (int a = 0; a < 3; ++a) { mn1[a] = fminf(mn1[a], s_mn[a][e]); mx1[a] = fmaxf(mx1[a], s_mx[a][e]); } ++c1; }
+                }
+                s_cost[nf * 9u + i] = 1 + ((float)c0 * sah_area(mn0, mx0) + (float)c1 * sah_area(mn1, mx1)) / denom;
+            }
+        }
+        __syncthreads();
+        uint32_t split = 0;
+        if (wide && !degenerate) {
+            float best = 0.0f;
+            for (uint32_t i = 0; i + 1 < kSahBuckets; ++i) {
+                const float cost = s_cost[nf * 9u + i];
+                if (i == 0 || cost < best) { best = cost; split = i; }
+            }
+            below = s_bk[lane] <= split;
+        }
+        const unsigned long long node_mask = (span >= 64u ? ~0ull : ((1ull << span) - 1ull)) << nf;
+        const unsigned long long bm = __ballot(wide && !degenerate && below) & node_mask;
+        if (wide) {
+            const uint32_t n_below = (uint32_t)__popcll(bm);
+            mid = nf + n_below;
+            bool fallback = degenerate || mid <= nf || mid >= nl;
+            if (fallback) {
+                if (!degenerate && lane == nf) atomicOr(&counters[1], 16u);                // see the header: cannot happen
+                mid = nf + span / 2u;
+            } else {
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                if (lane < mid && !below) { moved = true; rank = (uint32_t)__popcll(~bm & node_mask & lt); }
+                else if (lane >= mid && below) { moved = true; rank = (uint32_t)__popcll(bm & ~lt & ~(1ull << lane)); }
+            }
+        }
+        // the k-th misplaced record from the left changes places with the k-th from the right (BVH.hh:154-168)
+        const bool from_right = moved && below;
+        if (moved && !from_right) s_x[nf + rank] = me;
+        if (from_right) s_x[nl - 1u - rank] = me;
+        __syncthreads();
+        if (moved) s_ord[lane] = from_right ? s_x[nf + rank] : s_x[nl - 1u - rank];
+        __syncthreads();
+        if (active && lane == nf) {
+            const uint32_t self = sah_id_of(nq + span - 2u, n);
+            const uint32_t sl = mid - nf, sr = nl - mid, rq = nq + sl - 1u;
+            uint32_t l, r;
+            if (sl == 1u) { l = kChildLeaf | (F + nf); tp.parent_leaf[F + nf] = self; }
+            else { l = sah_id_of(nq + sl - 2u, n); tp.parent_interior[l] = self; }
+            if (sr == 1u) { r = kChildLeaf | (F + mid); tp.parent_leaf[F + mid] = self; }
+            else { r = sah_id_of(rq + sr - 2u, n); tp.parent_interior[r] = self; }
+            tp.child_l[self] = l; tp.child_r[self] = r; tp.axis[self] = axis;
+            if (self == 0u) tp.parent_interior[0] = 0u;
+        }
+        if (active) {
+            if (lane < mid) nl = mid; else { nq = nq + (mid - nf) - 1u; nf = mid; }
+        }
+    }
+    // leaf indices in their final order
+    __shared__ uint32_t s_leaf[64];
+    s_leaf[lane] = leaf;
+    __syncthreads();
+    if (lane < S) vals[F + lane] = s_leaf[s_ord[lane]];
+}
+
+// Topology (tp) and leaf order (vals[position] = leaf index) of the SAH tree over leaves[0, n).  bad = the leaf-intake flag word.
+static trc_status sah_build_topology(trc_ctx* ctx, Buffers& buf, const DLeaf* d_leaves, uint32_t n, uint32_t* d_bad, DTopo tp, uint32_t* d_vals) {
+    hipStream_t st = ctx->stream;
+    const uint32_t max_rows = n / kFinishSpan + 2u, max_tasks = n / kChunk + max_rows + 2u;
+    const uint32_t n_counters = 2u + 2u * (TRC_MAX_BVH_DEPTH + 3u);
+    SahBufs b{};
+    b.n = n;
+    HIP_TRY(ctx, buf.alloc(&b.elems, n)); HIP_TRY(ctx, buf.alloc(&b.tmp, n)); HIP_TRY(ctx, buf.alloc(&b.mv, n));
+    for (int k = 0; k < 2; ++k) { HIP_TRY(ctx, buf.alloc(&b.nodes[k], max_rows)); HIP_TRY(ctx, buf.alloc(&b.task_node[k], max_tasks)); }
+    HIP_TRY(ctx, buf.alloc(&b.task_hist, (size_t)max_tasks * kSahBuckets)); HIP_TRY(ctx, buf.alloc(&b.task_prefix, max_tasks));
+    HIP_TRY(ctx, buf.alloc(&b.finish, n / 2u + 2u));
+    HIP_TRY(ctx, buf.alloc(&b.counters, n_counters));
+    HIP_TRY(ctx, hipMemsetAsync(b.counters, 0, sizeof(uint32_t) * n_counters, st));
+    HIP_TRY(ctx, hipMemsetAsync(tp.parent_interior, 0, sizeof(uint32_t), st));
+    const dim3 g_leaf((n + 255) / 256), b256(256);
+    hipLaunchKernelGGL(k_sah_init, g_leaf, b256, 0, st, d_leaves, n, b.elems, d_bad);
+
+    uint32_t n_rows = 0, n_tasks = 0;
+    if (n <= kFinishSpan) {
+        const SFinish f{0u, n, 0u, 0u};
+        const uint32_t one = 1u;
+        HIP_TRY(ctx, hipMemcpyAsync(b.finish, &f, sizeof f, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(b.counters, &one, sizeof one, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));          // f and one are on this frame
+    } else {
+        SNode root;
+        std::memset(&root, 0, sizeof root);
+        root.first = 0; root.last = n; root.qbase = 0; root.task0 = 0;
+        for (int a = 0; a < 6; ++a) root.cb[a] = a < 3 ? 0xFFFFFFFFu : 0u;
+        for (uint32_t k = 0; k < kSahBuckets; ++k) for (int a = 0; a < 6; ++a) root.bb[k][a] = a < 3 ? 0xFFFFFFFFu : 0u;
+        n_rows = 1; n_tasks = (n + kChunk - 1) / kChunk;
+        HIP_TRY(ctx, hipMemcpyAsync(b.nodes[0], &root, sizeof root, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemsetAsync(b.task_node[0], 0, sizeof(uint32_t) * n_tasks, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));          // root is on this frame
+        hipLaunchKernelGGL(k_sah_root_bounds, dim3(std::min<uint32_t>((n + 255) / 256, 1024u)), b256, 0, st, b.elems, n, b.nodes[0]);
+    }
+    int cur = 0;
+    for (uint32_t level = 0; n_rows > 0; ++level, cur ^= 1) {
+        if (level > TRC_MAX_BVH_DEPTH) return trc_fail(ctx, TRC_ERR_BVH_INVALID, "sah: tree deeper than TRC_MAX_BVH_DEPTH");
+        uint32_t* next_counts = b.counters + 2u + 2u * (level + 1u);
+        hipLaunchKernelGGL(k_sah_bins, dim3(n_tasks), b256, 0, st, b.elems, b.nodes[cur], b.task_node[cur], b.task_hist);
+        hipLaunchKernelGGL(k_sah_split, dim3(n_rows), dim3(64), 0, st, b.nodes[cur], b.task_hist, b.task_prefix, b.nodes[cur ^ 1], b.task_node[cur ^ 1],
+                           next_counts, b.finish, b.counters, tp, n);
+        uint32_t next[2] = {0, 0}, flags[2] = {0, 0}, bad = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(next, next_counts, sizeof next, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(flags, b.counters, sizeof flags, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(k_sah_scatter, dim3(n_tasks), b256, 0, st, b.elems, b.tmp, b.mv, b.nodes[cur], b.nodes[cur ^ 1], b.task_node[cur], b.task_prefix);
+        hipLaunchKernelGGL(k_sah_apply, dim3(n_tasks), b256, 0, st, b.elems, b.tmp, b.mv, b.nodes[cur], b.task_node[cur]);
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (bad & 8u) return trc_fail(ctx, TRC_ERR_BVH_INVALID, "sah: leaf box not finite or beyond 1e37");
+        if (bad) break;                                   // the other intake errors are reported by the caller's refit
+        if (flags[1] & 16u) return trc_fail(ctx, TRC_ERR_BVH_INVALID, "sah: one-sided partition on a positive extent");
+        n_rows = next[0]; n_tasks = next[1];
+        if (n_rows > max_rows || n_tasks > max_tasks) return trc_fail(ctx, TRC_ERR_BVH_INVALID, "sah: level table overflow");
+    }
+    hipLaunchKernelGGL(k_sah_vals, g_leaf, b256, 0, st, b.elems, n, d_vals);
+    uint32_t flags[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(flags, b.counters, sizeof flags, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (flags[0] > n / 2u + 2u) return trc_fail(ctx, TRC_ERR_BVH_INVALID, "sah: finish list overflow");
+    if (flags[0]) hipLaunchKernelGGL(k_sah_finish, dim3(flags[0]), dim3(64), 0, st, b.elems, b.finish, d_vals, b.counters, tp, n);
+    HIP_TRY(ctx, hipMemcpyAsync(flags, b.counters, sizeof flags, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (flags[1] & 16u) return trc_fail(ctx, TRC_ERR_BVH_INVALID, "sah: one-sided partition on a positive extent");
+    HIP_TRY(ctx, hipGetLastError());
+    return TRC_OK;
+}
