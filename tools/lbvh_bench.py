@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""LBVH vs host SAH on config 4's scene (teapot.obj x 64 = 1.0 M triangles): build / upload times and render throughput
+"""LBVH and the device-built SAH tree vs the host SAH tree on config 4's scene (teapot.obj x 64 = 1.0 M triangles): build / upload times and render throughput
 through either tree.  Both trees are measured the same way: a first launch (head + rest: trc_render's cold path), then SETTLE
 launches with a new seed each so that order and split plan settle, then the mean of K timed launches at 32 spp."""
 import os, sys, time
@@ -34,3 +34,9 @@ for i in range(3):
     print(f"trc_upload_scene_lbvh {up_s:.3f} s wall, GPU build {ms:.2f} ms, {n} nodes, height {h}")
 lb = run("LBVH tree")
 print(f"LBVH / SAH render time: {lb / sah:.3f}")
+for i in range(3):
+    t0 = time.time(); t.upload_scene_sah(sc.leaves_view()); up_s = time.time() - t0
+    n, h, ms = t.lbvh_info()
+    print(f"trc_upload_scene_sah {up_s:.3f} s wall, GPU build {ms:.2f} ms, {n} nodes, height {h}")
+ds = run("device SAH tree")
+print(f"device SAH / host SAH render time: {ds / sah:.3f}")

@@ -993,6 +993,7 @@ void trc_destroy(trc_ctx* ctx) {
     for (int k = 0; k < 2; ++k) { (void)hipFree(ctx->d_order_keys[k]); (void)hipFree(ctx->d_order_vals[k]); }
     (void)hipFree(ctx->d_accum_alt); (void)hipFree(ctx->d_stack_ovf); (void)hipFree(ctx->d_queue);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    if (ctx->h_readback) (void)hipHostFree(ctx->h_readback);
     for (hipEvent_t e : {ctx->ev_rendered, ctx->ev_busy, ctx->ev_busy_alt}) if (e) (void)hipEventDestroy(e);
     if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

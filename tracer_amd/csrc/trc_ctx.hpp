@@ -210,6 +210,7 @@ struct trc_ctx {
     bool coll_active = false;
     void* h_stage = nullptr;            // pinned staging buffer of host-staged collectives
     size_t h_stage_bytes = 0;
+    uint32_t* h_readback = nullptr;     // 1 KB of pinned host memory for the per-level counter read-back of trc_upload_scene_sah
 
     // A/B and test knobs, per context: defaults from the environment at trc_create (TRC_NO_LDS_FIT, TRC_STACK_LDS_LEVELS,
     // TRC_STRIP_LEN, TRC_NO_PWG, TRC_SPPM_SERIAL_CAMERA), changed through trc_debug_set
