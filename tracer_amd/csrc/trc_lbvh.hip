@@ -565,6 +565,7 @@ static trc_status upload_device_tree(trc_ctx* ctx, const trc_scene* s, bool sah)
     lim.n[0] = s->n_sphere; lim.n[1] = s->n_square; lim.n[2] = s->n_cube; lim.n[3] = s->n_index / 3;
     hipLaunchKernelGGL(k_lbvh_prepare, g_leaf, b256, 0, st, ctx->d_bvh_ref + 1, n, lim, d_leaves, d_bounds + 6);
     int cur = 0;
+    uint32_t first_chunk = 40;                  // refit passes before the root is looked at for the first time
     if (!sah) {
         hipLaunchKernelGGL(k_lbvh_bounds, dim3(std::min<uint32_t>((n + 255) / 256, 1024u)), b256, 0, st, d_leaves, n, d_bounds);
         hipLaunchKernelGGL(k_lbvh_keys, g_leaf, b256, 0, st, d_leaves, n, d_bounds, d_keys[0], d_vals[0]);
@@ -578,8 +579,9 @@ static trc_status upload_device_tree(trc_ctx* ctx, const trc_scene* s, bool sah)
         }
         hipLaunchKernelGGL(k_lbvh_hierarchy, g_int, b256, 0, st, d_keys[cur], d_vals[cur], n, tp);
     } else {
-        const trc_status bs = sah_build_topology(ctx, buf, d_leaves, n, d_bounds + 6, tp, d_vals[0]);
+        const trc_status bs = sah_build_topology(ctx, buf, d_leaves, n, d_bounds + 6, tp, d_vals[0], &first_chunk);
         if (bs != TRC_OK) return bs;
+        first_chunk = std::min(std::max(first_chunk, 1u), TRC_MAX_BVH_DEPTH + 1u);      // the builder knows the tree's height: that many refit passes
     }
     // refit passes: a tree of height h needs h passes; check the root every few passes beyond the usual depth
     uint32_t root_done = 0, bad_leaves = 0;
@@ -588,7 +590,7 @@ static trc_status upload_device_tree(trc_ctx* ctx, const trc_scene* s, bool sah)
         uint32_t pass = 0;
         root_done = 0;
         HIP_TRY(ctx, hipMemsetAsync(d_arrived, 0, sizeof(uint32_t) * n_interior, st));
-        for (uint32_t chunk = 40; pass < pass_limit && !root_done; chunk = 8) {
+        for (uint32_t chunk = first_chunk; pass < pass_limit && !root_done; chunk = 8) {
             for (uint32_t k = 0; k < chunk && pass < pass_limit; ++k)
                 hipLaunchKernelGGL(k_lbvh_refit_pass, g_int, b256, 0, st, d_leaves, d_vals[cur], n, tp, d_boxes, d_height, d_arrived, ++pass);
             HIP_TRY(ctx, hipMemcpyAsync(&root_done, d_arrived, 4, hipMemcpyDeviceToHost, st));

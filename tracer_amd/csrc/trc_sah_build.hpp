@@ -39,7 +39,7 @@ struct SNode {                              // a node of the level being split; 
     uint32_t bb[kSahBuckets][6];            // bucket boxes as ordered uints
 };
 static_assert(sizeof(SNode) == 88 * 4 && offsetof(SNode, cb) == 16, "row layout");
-struct SFinish { uint32_t first, last, qbase, _pad; };
+struct SFinish { uint32_t first, last, qbase, depth; };      // depth of the subtree's root
 
 struct SahBufs {
     DLeaf* elems; DLeaf* tmp;               // records in tree order; side array of the partition
@@ -47,7 +47,7 @@ struct SahBufs {
     SNode* nodes[2]; uint32_t* task_node[2];
     uint32_t* task_hist;
     SFinish* finish;
-    uint32_t* counters;                     // [0] finish entries, [1] error bits, [2 + 2 * level ...] nodes / tasks of a level
+    uint32_t* counters;                     // [0] finish entries, [1] error bits, [2] depth of the deepest leaf, [2 + 2 * level ...] nodes / tasks of level >= 1
     uint32_t n;
 };
 
@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(256) k_sah_bins(const DLeaf* elems, SNode* nod
 // addresses); what needs many words per node -- identity bins of the children's rows, their task lists, the scan
 // of a many-task node's histograms -- is left to the passes that have a workgroup per task (k_sah_scatter, k_sah_apply).
 __global__ void __launch_bounds__(64) k_sah_split(SNode* nodes, uint32_t n_rows, SNode* next_nodes, uint32_t* next_counts /* [2]: nodes, tasks */, SFinish* finish,
-                                                 uint32_t* counters, DTopo tp, uint32_t n) {
+                                                 uint32_t* counters, DTopo tp, uint32_t n, uint32_t level) {
     const uint32_t lane = threadIdx.x, row = blockIdx.x * 64u + lane;
     const bool has = row < n_rows;
     uint32_t first = 0, last = 0, qbase = 0, split = 0, mid = 0;
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(64) k_sah_split(SNode* nodes, uint32_t n_rows,
             const uint32_t cf = side ? mid : first, cl = side ? last : mid, cs = cl - cf;
             const uint32_t cq = side ? qbase + (mid - first) - 1u : qbase;
             c_first[side] = cf; c_last[side] = cl; c_q[side] = cq;
-            if (cs == 1u) { link[side] = kChildLeaf | cf; tp.parent_leaf[cf] = self; continue; }
+            if (cs == 1u) { link[side] = kChildLeaf | cf; tp.parent_leaf[cf] = self; atomicMax(&counters[2], level + 1u); continue; }
             const uint32_t ci = sah_id_of(cq + cs - 2u, n);
             link[side] = ci; tp.parent_interior[ci] = self;
             if (cs <= kFinishSpan) { c_fin[side] = true; ++need_finish; }
@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(64) k_sah_split(SNode* nodes, uint32_t n_rows,
     uint32_t child_row[2] = {kNoNode, kNoNode}, child_t0[2] = {0, 0};
 #pragma unroll
     for (int side = 0; side < 2; ++side) {
-        if (c_fin[side]) { SFinish f; f.first = c_first[side]; f.last = c_last[side]; f.qbase = c_q[side]; f._pad = 0; finish[my_fin++] = f; }
+        if (c_fin[side]) { SFinish f; f.first = c_first[side]; f.last = c_last[side]; f.qbase = c_q[side]; f.depth = level + 1u; finish[my_fin++] = f; }
         if (c_row[side]) {
             child_row[side] = my_row++; child_t0[side] = my_task; my_task += c_tasks[side];
             SNode& c = next_nodes[child_row[side]];        // header and identity centroid bounds (k_sah_scatter accumulates them);
@@ -425,9 +425,11 @@ __global__ void __launch_bounds__(256) k_sah_vals(const DLeaf* elems, uint32_t n
 // One wavefront per subtree of <= 64 leaves: lane p = position p of the subtree's range.  Every level of the subtree is one
 // trip of the loop, all of its nodes side by side (a lane works for the node its position is in).
 __global__ void __launch_bounds__(64) k_sah_finish(const DLeaf* elems, const SFinish* finish, uint32_t* vals, uint32_t* counters, DTopo tp, uint32_t n) {
+    constexpr uint32_t kWideNodes = 21;                          // nodes of >= 3 leaves among 64 positions
     __shared__ float s_c[3][64], s_mn[3][64], s_mx[3][64];      // by record (the lane that loaded it)
-    __shared__ uint32_t s_ord[64], s_bk[64], s_x[64];            // by position: record, its bucket; exchange
-    __shared__ float s_cost[64 * 9];                             // by first position of a node
+    __shared__ uint32_t s_ord[64], s_x[64];                      // by position: the record there; exchange
+    __shared__ uint32_t s_bins[kWideNodes * 70];                 // per node of >= 3 leaves: 10 counts, 10 x 6 ordered bounds
+    __shared__ float s_cost[kWideNodes * 9];
     const uint32_t lane = threadIdx.x;
     const SFinish f = finish[blockIdx.x];
     const uint32_t F = f.first, S = f.last - f.first;
@@ -439,64 +441,84 @@ __global__ void __launch_bounds__(64) k_sah_finish(const DLeaf* elems, const SFi
         for (int a = 0; a < 3; ++a) { s_mn[a][lane] = d.mn[a]; s_mx[a][lane] = d.mx[a]; s_c[a][lane] = sah_centroid1(d.mn[a], d.mx[a]); }
     }
     s_ord[lane] = lane;
-    uint32_t nf = 0, nl = S, nq = f.qbase;
+    uint32_t nf = 0, nl = S, nq = f.qbase, depth = f.depth;
     __syncthreads();
-    for (;;) {
+    for (;; ++depth) {
         const uint32_t span = nl - nf;
         const bool active = lane < S && span >= 2u;
         if (__ballot(active) == 0ull) break;
-        const uint32_t maxspan = wave_max_u32(active ? span : 0u);
-        // centroid bounds of the node (every lane of a node computes the same thing)
-        float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-        for (uint32_t k = 0; k < maxspan; ++k) {
-            if (active && k < span) {
-                const uint32_t e = s_ord[nf + k];
+        // centroid bounds of the node: a scan that stops at the node's first position, then the last position's value
+        const uint32_t me = s_ord[lane < S ? lane : 0u];
+        float c[3], lo[3], hi[3];
 #pragma unroll
-                for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], s_c[a][e]); hi[a] = fmaxf(hi[a], s_c[a][e]); }
+        for (int a = 0; a < 3; ++a) { c[a] = s_c[a][me]; lo[a] = c[a]; hi[a] = c[a]; }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const bool take = lane >= nf + (uint32_t)off;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float tl = __shfl_up(lo[a], off, 64), th = __shfl_up(hi[a], off, 64);
+                if (take) { lo[a] = fminf(lo[a], tl); hi[a] = fmaxf(hi[a], th); }
             }
         }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { lo[a] = __shfl(lo[a], (int)((nl - 1u) & 63u), 64); hi[a] = __shfl(hi[a], (int)((nl - 1u) & 63u), 64); }
         const uint32_t axis = sah_widest(hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]);
         const float alo = axis == 0 ? lo[0] : (axis == 1 ? lo[1] : lo[2]);
         const float extent = (axis == 0 ? hi[0] : (axis == 1 ? hi[1] : hi[2])) - alo;
-        const uint32_t me = s_ord[lane < S ? lane : 0u];
-        const float my_key = axis == 0 ? s_c[0][me] : (axis == 1 ? s_c[1][me] : s_c[2][me]);
+        const float my_key = axis == 0 ? c[0] : (axis == 1 ? c[1] : c[2]);
         uint32_t mid = nf + 1u;
         bool below = false, moved = false;
         uint32_t rank = 0;
-        if (active && span == 2u) {                                                        // BVH.hh:59-77
-            const uint32_t ea = s_ord[nf], eb = s_ord[nf + 1u];
-            const float ka = axis == 0 ? s_c[0][ea] : (axis == 1 ? s_c[1][ea] : s_c[2][ea]);
-            const float kb = axis == 0 ? s_c[0][eb] : (axis == 1 ? s_c[1][eb] : s_c[2][eb]);
-            if (!(ka < kb)) { moved = true; rank = 0; below = lane != nf; }                // the two change places
+        {                                                                                  // two leaves, BVH.hh:59-77
+            const float ka = __shfl(my_key, (int)(nf & 63u), 64), kb = __shfl(my_key, (int)((nf + 1u) & 63u), 64);
+            if (active && span == 2u && !(ka < kb)) { moved = true; rank = 0; below = lane != nf; }      // the two change places
         }
         const bool wide = active && span > 2u;
         const bool degenerate = !(extent > 0.0f);
-        if (wide && !degenerate) s_bk[lane] = sah_bucket(my_key, alo, extent);
+        const bool binned = wide && !degenerate;
+        // bucket rows of the nodes that are split by cost: slot = wide nodes before this one
+        const unsigned long long heads = __ballot(wide && lane == nf);
+        const uint32_t slot = (uint32_t)__popcll(heads & ((1ull << nf) - 1ull));
+        uint32_t* bins = s_bins + slot * 70u;
+        const uint32_t bk = binned ? sah_bucket(my_key, alo, extent) : 0u;
+        if (binned)
+            for (uint32_t w = lane - nf; w < 70u; w += span) bins[w] = (w >= kSahBuckets && ((w - kSahBuckets) % 6u) < 3u) ? 0xFFFFFFFFu : 0u;
+        __syncthreads();
+        if (binned) {
+            atomicAdd(&bins[bk], 1u);
+            uint32_t* bb = bins + kSahBuckets + bk * 6u;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { atomicMin(&bb[a], ordered_of(s_mn[a][me])); atomicMax(&bb[3 + a], ordered_of(s_mx[a][me])); }
+        }
         __syncthreads();
         // the nine costs: the lane at offset o of a node takes candidates o, o + span, ...
         {
             const float denom = sah_area(lo, hi);
-            for (uint32_t i = lane - nf; wide && !degenerate && i < kSahBuckets - 1u; i += span) {
+            for (uint32_t i = lane - nf; binned && i < kSahBuckets - 1u; i += span) {
                 float mn0[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx0[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
                 float mn1[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx1[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
                 int c0 = 0, c1 = 0;
-                for (uint32_t k = nf; k < nl; ++k) {
-                    const uint32_t e = s_ord[k];
-                    if (s_bk[k] <= i) { for (int a = 0; a < 3; ++a) { mn0[a] = fminf(mn0[a], s_mn[a][e]); mx0[a] = fmaxf(mx0[a], s_mx[a][e]); } ++c0; }
-                    else              { for (int a = 0; a < 3; ++a) { mn1[a] = fminf(mn1[a], s_mn[a][e]); mx1[a] = fmaxf(mx1[a], s_mx[a][e]); } ++c1; }
+#pragma unroll
+                for (uint32_t j = 0; j < kSahBuckets; ++j) {
+                    const uint32_t cnt = bins[j];
+                    if (!cnt) continue;
+                    const uint32_t* bb = bins + kSahBuckets + j * 6u;
+                    if (j <= i) { for (int a = 0; a < 3; ++a) { mn0[a] = fminf(mn0[a], float_of(bb[a])); mx0[a] = fmaxf(mx0[a], float_of(bb[3 + a])); } c0 += (int)cnt; }
+                    else        { for (int a = 0; a < 3; ++a) { mn1[a] = fminf(mn1[a], float_of(bb[a])); mx1[a] = fmaxf(mx1[a], float_of(bb[3 + a])); } c1 += (int)cnt; }
                 }
-                s_cost[nf * 9u + i] = 1 + ((float)c0 * sah_area(mn0, mx0) + (float)c1 * sah_area(mn1, mx1)) / denom;
+                s_cost[slot * 9u + i] = 1 + ((float)c0 * sah_area(mn0, mx0) + (float)c1 * sah_area(mn1, mx1)) / denom;
             }
         }
         __syncthreads();
         uint32_t split = 0;
-        if (wide && !degenerate) {
+        if (binned) {
             float best = 0.0f;
             for (uint32_t i = 0; i + 1 < kSahBuckets; ++i) {
-                const float cost = s_cost[nf * 9u + i];
+                const float cost = s_cost[slot * 9u + i];
                 if (i == 0 || cost < best) { best = cost; split = i; }
             }
-            below = s_bk[lane] <= split;
+            below = bk <= split;
         }
         const unsigned long long node_mask = (span >= 64u ? ~0ull : ((1ull << span) - 1ull)) << nf;
         const unsigned long long bm = __ballot(wide && !degenerate && below) & node_mask;
@@ -535,6 +557,7 @@ __global__ void __launch_bounds__(64) k_sah_finish(const DLeaf* elems, const SFi
             if (lane < mid) nl = mid; else { nq = nq + (mid - nf) - 1u; nf = mid; }
         }
     }
+    if (lane == 0u) atomicMax(&counters[2], depth);      // every trip put its nodes' children one level further down
     // leaf indices in their final order
     __shared__ uint32_t s_leaf[64];
     s_leaf[lane] = leaf;
@@ -543,7 +566,7 @@ __global__ void __launch_bounds__(64) k_sah_finish(const DLeaf* elems, const SFi
 }
 
 // Topology (tp) and leaf order (vals[position] = leaf index) of the SAH tree over leaves[0, n).  bad = the leaf-intake flag word.
-static trc_status sah_build_topology(trc_ctx* ctx, Buffers& buf, const DLeaf* d_leaves, uint32_t n, uint32_t* d_bad, DTopo tp, uint32_t* d_vals) {
+static trc_status sah_build_topology(trc_ctx* ctx, Buffers& buf, const DLeaf* d_leaves, uint32_t n, uint32_t* d_bad, DTopo tp, uint32_t* d_vals, uint32_t* out_height) {
     hipStream_t st = ctx->stream;
     const uint32_t max_rows = n / kFinishSpan + 2u, max_tasks = n / kChunk + max_rows + 2u;
     const uint32_t n_counters = 2u + 2u * (TRC_MAX_BVH_DEPTH + 3u);
@@ -559,7 +582,7 @@ static trc_status sah_build_topology(trc_ctx* ctx, Buffers& buf, const DLeaf* d_
     const dim3 g_leaf((n + 255) / 256), b256(256);
     uint32_t n_rows = 0, n_tasks = 0;
     if (n <= kFinishSpan) {
-        const SFinish f{0u, n, 0u, 0u};
+        const SFinish f{0u, n, 0u, 0u};                 // the root, depth 0
         const uint32_t one = 1u;
         HIP_TRY(ctx, hipMemcpyAsync(b.finish, &f, sizeof f, hipMemcpyHostToDevice, st));
         HIP_TRY(ctx, hipMemcpyAsync(b.counters, &one, sizeof one, hipMemcpyHostToDevice, st));
@@ -581,7 +604,7 @@ static trc_status sah_build_topology(trc_ctx* ctx, Buffers& buf, const DLeaf* d_
         if (level > TRC_MAX_BVH_DEPTH) return trc_fail(ctx, TRC_ERR_BVH_INVALID, "sah: tree deeper than TRC_MAX_BVH_DEPTH");
         uint32_t* next_counts = b.counters + 2u + 2u * (level + 1u);
         hipLaunchKernelGGL(k_sah_bins, dim3(n_tasks), b256, 0, st, b.elems, b.nodes[cur], b.task_node[cur], b.task_hist);
-        hipLaunchKernelGGL(k_sah_split, dim3((n_rows + 63u) / 64u), dim3(64), 0, st, b.nodes[cur], n_rows, b.nodes[cur ^ 1], next_counts, b.finish, b.counters, tp, n);
+        hipLaunchKernelGGL(k_sah_split, dim3((n_rows + 63u) / 64u), dim3(64), 0, st, b.nodes[cur], n_rows, b.nodes[cur ^ 1], next_counts, b.finish, b.counters, tp, n, level);
         // one read-back per level: the whole counter block (next level's rows / tasks, error bits)
         HIP_TRY(ctx, hipMemcpyAsync(hc, b.counters, sizeof(uint32_t) * n_counters, hipMemcpyDeviceToHost, st));
         hc[n_counters] = 0;
@@ -603,8 +626,9 @@ static trc_status sah_build_topology(trc_ctx* ctx, Buffers& buf, const DLeaf* d_
     if (n_finish > n / 2u + 2u) return trc_fail(ctx, TRC_ERR_BVH_INVALID, "sah: finish list overflow");
     if (n_finish) hipLaunchKernelGGL(k_sah_finish, dim3(n_finish), dim3(64), 0, st, b.elems, b.finish, d_vals, b.counters, tp, n);
     uint32_t* flags = hc;
-    HIP_TRY(ctx, hipMemcpyAsync(flags, b.counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(flags, b.counters, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    *out_height = flags[2];
     if (flags[1] & 16u) return trc_fail(ctx, TRC_ERR_BVH_INVALID, "sah: one-sided partition on a positive extent");
     HIP_TRY(ctx, hipGetLastError());
     return TRC_OK;
