@@ -35,6 +35,7 @@ python3 tools/tile_balance.py --config 4 --spp 64 > $O/tile_balance_config4_64sp
 python3 tools/split_trace.py --config 2 --ranks 1,2,4,8 > $O/adaptive_blocks_config2.txt 2>&1
 python3 tools/split_trace.py --config 4 --spp 64 --ranks 1,2,8 --launches 6 > $O/adaptive_blocks_config4_64spp.txt 2>&1
 python3 tools/lbvh_bench.py > $O/lbvh_bench.txt 2>&1
+python3 tools/sah_build_bench.py 6 > $O/sah_build_bench.txt 2>&1
 for c in 2 3 4; do python3 tools/cold_start.py --native --config $c --ranks 1,8 --launches 12; done > $O/cold_start.txt 2>&1
 for c in 2 3 4; do python3 tools/share_bounds.py --config $c; done > $O/share_bounds.txt 2>&1
 python3 tools/split_trace.py --config 3 --ranks 1,8 --launches 14 --vary-seed > $O/sched_trace_config3.txt 2>&1
