@@ -3,7 +3,7 @@
 // output stage, PNG.  Nothing but the two shared libraries is involved.
 //
 //   trc_render [--scene cornell|spheres|volume] [--integrator path|mis|volume] [--size W H] [--spp N]
-//              [--mesh file.obj|file.pbrt] [--density cloud.pbrt] [--lbvh] [--sobol] [--out frame.png]
+//              [--mesh file.obj|file.pbrt] [--density cloud.pbrt] [--lbvh | --device-sah] [--sobol] [--out frame.png]
 //   trc_render --pbrt scene.pbrt [--integrator path|mis] [--spp N] [--size W H] [--out frame.png]
 //              a whole pbrt-v3 scene (camera, film, lights, materials, spheres, meshes: trc_host_scene_load_pbrt)
 #include <chrono>
@@ -27,7 +27,7 @@
 int main(int argc, char** argv) {
     std::string scene_name = "spheres", integ_name = "path", out = "frame.png", mesh_path, density_path, pbrt_path, hdr_path;
     uint32_t W = 640, H = 360, spp = 64;
-    bool lbvh = false, sobol = false, size_given = false;
+    bool lbvh = false, device_sah = false, sobol = false, size_given = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--scene" && i + 1 < argc) scene_name = argv[++i];
@@ -39,6 +39,7 @@ int main(int argc, char** argv) {
         else if (a == "--hdr" && i + 1 < argc) hdr_path = argv[++i];            // Radiance .hdr backdrop (the reference's texHDR)
         else if (a == "--density" && i + 1 < argc) density_path = argv[++i];    // pbrt-v3 heterogeneous medium
         else if (a == "--lbvh") lbvh = true;
+        else if (a == "--device-sah") device_sah = true;
         else if (a == "--sobol") sobol = true;
         else if (a == "--out" && i + 1 < argc) out = argv[++i];
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
@@ -85,11 +86,12 @@ int main(int argc, char** argv) {
     trc_host_scene_view(hs, &scene);
 
     CHECK(trc_create(0, &ctx));
-    if (lbvh) {                                   // hand over the leaf records only; the tree is built on the GPU
+    if (lbvh || device_sah) {                     // hand over the leaf records only; the tree is built on the GPU
         trc_scene leaves = scene;
         leaves.bvhList = scene.bvhList + 1;       // BVH::buildTree keeps the leaves at [1, n]
         leaves.n_bvh = (scene.n_bvh + 1) / 2;
-        CHECK(trc_upload_scene_lbvh(ctx, &leaves));
+        if (device_sah) CHECK(trc_upload_scene_sah(ctx, &leaves));       // BVH::buildTree itself, on the device
+        else CHECK(trc_upload_scene_lbvh(ctx, &leaves));
     } else {
         CHECK(trc_upload_scene(ctx, &scene));
     }
