@@ -153,7 +153,9 @@ extern "C" void orc_lbvh_build(const trc_BVH* leaves, uint32_t n, trc_BVH* out, 
             out[down].parent = X;
             out[X].bBOX = merged(out[down].bBOX, out[keep].bBOX);
         }
-        // the tree changed: BFS order and height again
+        // the tree changed: BFS order and height again, and every box again from its children as they are now (left, right) --
+        // what the device's refit after a sweep does; the values are the ones the rotations left, but which of a -0 and a +0
+        // a box keeps depends on the order of its operands
         order.clear(); order.push_back(0);
         height = 0;
         std::fill(depth.begin(), depth.end(), 0u);
@@ -163,6 +165,10 @@ extern "C" void orc_lbvh_build(const trc_BVH* leaves, uint32_t n, trc_BVH* out, 
                 depth[c] = depth[i] + 1;
                 if (out[c].pType == TRC_PRIM_BVH) order.push_back(c); else height = std::max(height, depth[c]);
             }
+        }
+        for (size_t h = order.size(); h-- > 0;) {
+            trc_BVH& nd = out[order[h]];
+            nd.bBOX = merged(out[nd.left].bBOX, out[nd.right].bBOX);
         }
     }
     if (out_height) *out_height = height;

@@ -104,3 +104,23 @@ def test_million_triangle_build(gpu):
     assert (got["hit"] == sah["hit"]).all()
     hit = got["hit"] != 0
     assert (got["t"][hit] == sah["t"][hit]).all()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_signed_zeros_in_leaf_boxes(gpu, seed):
+    """-0 and +0 are equal bounds with different bits: the merged boxes keep the oracle's (std::min / std::max: the first operand
+    on a tie), not whatever a hardware min would pick."""
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.choice([3, 64, 300, 2500]))
+    c = rng.choice([-0.0, 0.0, 1e-30, -1e-30, 1.0, -1.0], (n, 3)); r = rng.choice([0.0, 0.5], (n, 3))
+    lo, hi = (c - r).astype(np.float32), (c + r).astype(np.float32)
+    sc = host.HostScene(abi.SCENE_CORNELL_SPHERES)
+    leaves = (abi.BVH * n)()
+    for k in range(n):
+        leaves[k].pType = abi.PRIM_SPHERE; leaves[k].pIndex = k % sc.view.n_sphere
+        leaves[k].bBOX.mini.x, leaves[k].bBOX.mini.y, leaves[k].bBOX.mini.z = (float(v) for v in lo[k])
+        leaves[k].bBOX.maxi.x, leaves[k].bBOX.maxi.y, leaves[k].bBOX.maxi.z = (float(v) for v in hi[k])
+    v = abi.Scene.from_buffer_copy(sc.leaves_view()); v.bvhList = C.cast(leaves, C.POINTER(abi.BVH)); v.n_bvh = n
+    want, height = pyoracle.lbvh_build(leaves, n)
+    gpu.upload_scene_lbvh(v)
+    assert (raw(gpu.download_bvh()) == raw(want)).all() and gpu.lbvh_info()[1] == height

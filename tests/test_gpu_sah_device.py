@@ -102,6 +102,47 @@ def test_degenerate_and_ragged_leaf_sets(gpu, name):
     assert gpu.lbvh_info()[1] == depth
 
 
+def fuzz_boxes(seed):
+    """a leaf set mixing what real scenes mix: clusters of duplicates, lattices, points, planar sheets, signed zeros, scales"""
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([2, 3, 7, 31, 64, 65, 100, 257, 1000, 2049, 5000, 12000]))
+    scale = float(10.0 ** rng.integers(-12, 13))
+    kind = seed % 6
+    if kind == 0:      # clusters of exact duplicates
+        centres = rng.uniform(-1, 1, (max(1, n // 50), 3))
+        c = centres[rng.integers(0, len(centres), n)]
+        r = np.full((n, 3), 0.01)
+    elif kind == 1:    # integer lattice: many equal centroids per axis, bucket boundaries hit exactly
+        c = rng.integers(-8, 9, (n, 3)).astype(np.float64); r = rng.integers(0, 3, (n, 3)) * 0.5
+    elif kind == 2:    # a planar sheet (one axis degenerate) with points (zero-size boxes)
+        c = rng.uniform(-1, 1, (n, 3)); c[:, rng.integers(0, 3)] = 0.25; r = np.zeros((n, 3))
+    elif kind == 3:    # signed zeros and tiny values around the origin
+        c = rng.choice([-0.0, 0.0, 1e-30, -1e-30, 1.0, -1.0], (n, 3)); r = rng.choice([0.0, 0.5], (n, 3))
+    elif kind == 4:    # long thin boxes, wildly different sizes
+        c = rng.normal(0, 1, (n, 3)); r = 10.0 ** rng.uniform(-6, 1, (n, 3))
+    else:              # uniform
+        c = rng.uniform(-1, 1, (n, 3)); r = rng.uniform(0, 0.2, (n, 3))
+    lo = ((c - r) * scale).astype(np.float32); hi = ((c + r) * scale).astype(np.float32)
+    return list(zip(lo, hi))
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_fuzzed_leaf_sets(gpu, seed):
+    sc = host.HostScene(abi.SCENE_CORNELL_SPHERES)
+    boxes = fuzz_boxes(seed)
+    n = len(boxes)
+    leaves = leaf_records(boxes, sc.view.n_sphere)
+    v = abi.Scene.from_buffer_copy(sc.leaves_view()); v.bvhList = C.cast(leaves, C.POINTER(abi.BVH)); v.n_bvh = n
+    want = pyoracle.sah_build(leaves, n)
+    if tree_depth(want) > abi.TRC_MAX_BVH_DEPTH:
+        pytest.skip("deeper than TRC_MAX_BVH_DEPTH")
+    gpu.upload_scene_sah(v)
+    assert not first_difference(raw(gpu.download_bvh()), raw(want)), (seed, n)
+    # ... and the host builder agrees with both
+    built = host.build_tree([leaves[k] for k in range(n)])
+    assert not first_difference(raw((abi.BVH * len(built))(*built)), raw(want))
+
+
 def tree_depth(nodes):
     a = raw(nodes)
     depth = np.zeros(len(a), dtype=np.int64)

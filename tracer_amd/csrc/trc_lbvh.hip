@@ -286,6 +286,13 @@ __global__ void __launch_bounds__(256) k_lbvh_hierarchy(const uint32_t* keys, co
 // fitted in a pass < p (done[i] = pass of fitting, 0 = not yet).  Launch boundaries are the only synchronisation:
 // the usual single-kernel climb with one atomic counter per node needs two device-scope fences per level, and on
 // the 8-XCD part each fence writes back / invalidates an L2 (measured 6.6 ms for 1 M leaves vs 0.4 ms like this).
+// Which of two EQUAL bounds a merged box keeps matters when they are -0 and +0 (the record is compared bit for bit): the
+// oracle of the LBVH build merges with std::min / std::max (the FIRST operand on a tie), the reference's SAH build and its
+// restatements with fminf / fmaxf, which on the host compile to minss / maxss (the SECOND operand on a tie).  v_min_f32 would
+// pick -0 whatever its position.
+template <bool SECOND_ON_TIE> __device__ __forceinline__ float tie_min(float a, float b) { return SECOND_ON_TIE ? (a < b ? a : b) : (b < a ? b : a); }
+template <bool SECOND_ON_TIE> __device__ __forceinline__ float tie_max(float a, float b) { return SECOND_ON_TIE ? (a > b ? a : b) : (a < b ? b : a); }
+template <bool SAH>
 __global__ void __launch_bounds__(256) k_lbvh_refit_pass(const DLeaf* leaves, const uint32_t* vals, uint32_t n, DTopo tp,
                                                         float* boxes, uint32_t* height, uint32_t* done, uint32_t pass) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -310,7 +317,7 @@ __global__ void __launch_bounds__(256) k_lbvh_refit_pass(const DLeaf* leaves, co
             hc = height[ch[k]] + 1;
         }
         if (k == 0) { for (int a = 0; a < 3; ++a) { mn[a] = cmn[a]; mx[a] = cmx[a]; } h = hc; }
-        else { for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], cmn[a]); mx[a] = fmaxf(mx[a], cmx[a]); } h = max(h, hc); }
+        else { for (int a = 0; a < 3; ++a) { mn[a] = tie_min<SAH>(mn[a], cmn[a]); mx[a] = tie_max<SAH>(mx[a], cmx[a]); } h = max(h, hc); }
     }
     float* b = boxes + (size_t)i * 6;
     b[0] = mn[0]; b[1] = mn[1]; b[2] = mn[2]; b[3] = mx[0]; b[4] = mx[1]; b[5] = mx[2];
@@ -399,7 +406,7 @@ __global__ void __launch_bounds__(256) k_lbvh_rotate_pass(const DLeaf* leaves, c
     lbvh_child_box(leaves, vals, boxes, keep, bk);
     float* q = boxes + (size_t)X * 6;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { q[k] = fminf(bd[k], bk[k]); q[3 + k] = fmaxf(bd[3 + k], bk[3 + k]); }
+    for (int k = 0; k < 3; ++k) { q[k] = tie_min<false>(bd[k], bk[k]); q[3 + k] = tie_max<false>(bd[3 + k], bk[3 + k]); }      // merged(down, keep)
 }
 
 // depth of interior node i (root 0): a walk up the parent links, <= TRC_MAX_BVH_DEPTH steps
@@ -592,7 +599,8 @@ static trc_status upload_device_tree(trc_ctx* ctx, const trc_scene* s, bool sah)
         HIP_TRY(ctx, hipMemsetAsync(d_arrived, 0, sizeof(uint32_t) * n_interior, st));
         for (uint32_t chunk = first_chunk; pass < pass_limit && !root_done; chunk = 8) {
             for (uint32_t k = 0; k < chunk && pass < pass_limit; ++k)
-                hipLaunchKernelGGL(k_lbvh_refit_pass, g_int, b256, 0, st, d_leaves, d_vals[cur], n, tp, d_boxes, d_height, d_arrived, ++pass);
+                if (sah) hipLaunchKernelGGL(k_lbvh_refit_pass<true>, g_int, b256, 0, st, d_leaves, d_vals[cur], n, tp, d_boxes, d_height, d_arrived, ++pass);
+                else hipLaunchKernelGGL(k_lbvh_refit_pass<false>, g_int, b256, 0, st, d_leaves, d_vals[cur], n, tp, d_boxes, d_height, d_arrived, ++pass);
             HIP_TRY(ctx, hipMemcpyAsync(&root_done, d_arrived, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(ctx, hipMemcpyAsync(&bad_leaves, d_bounds + 6, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(ctx, hipStreamSynchronize(st));
