@@ -374,6 +374,14 @@ trc_status trc_upload_scene_lbvh(trc_ctx* ctx, const trc_scene* scene);
  * host-built tree.  Leaf boxes must be finite with |coordinates| <= 1e37 (TRC_ERR_BVH_INVALID otherwise).
  * trc_download_bvh / trc_lbvh_info report on it like on an LBVH tree. */
 trc_status trc_upload_scene_sah(trc_ctx* ctx, const trc_scene* scene);
+/* Both device builds behind one call.  flags: TRC_TREE_SAH (else the LBVH); TRC_TREE_TRIANGLE_LEAVES: `scene->bvhList` holds the leaf
+ * records of the analytic primitives only (n_bvh of them, possibly none) and one leaf per triangle of (idxList, triList) follows them
+ * in index order, written on the device exactly as the reference's loop writes it (AAPLRenderer.mm:575-589: the box of the three
+ * vertices through BVH::buildNode under the identity matrix) -- a host with a mesh of a million triangles neither loops over them
+ * nor uploads 64 bytes per triangle.  The tree is the one trc_host_build_tree builds from the same leaves. */
+#define TRC_TREE_SAH              1u
+#define TRC_TREE_TRIANGLE_LEAVES  2u
+trc_status trc_upload_scene_device(trc_ctx* ctx, const trc_scene* scene, uint32_t flags);
 /* the device-built tree in the reference's array layout (BVH.hh:246-269): [root, leaf 0..n-1, interior
  * 1..n-2], 2n-1 records.  out == NULL: only *n_nodes is written. */
 trc_status trc_download_bvh(trc_ctx* ctx, trc_BVH* out, uint32_t capacity, uint32_t* n_nodes);
@@ -617,6 +625,13 @@ trc_status trc_host_scene_create(int32_t kind,
                                  const trc_TriangleVertex* mesh_vertices, uint32_t n_vertices,
                                  const uint32_t* mesh_indices, uint32_t n_indices,
                                  trc_host_scene** out);
+/* analytic_leaves_only != 0: the same scene without the per-triangle leaf records and without the tree -- bvhList = the leaf
+ * records of the analytic primitives, the input of trc_upload_scene_device(TRC_TREE_SAH | TRC_TREE_TRIANGLE_LEAVES), which
+ * writes the triangles' leaves and builds the reference's tree on the GPU */
+trc_status trc_host_scene_create_leaves(int32_t kind,
+                                        const trc_TriangleVertex* mesh_vertices, uint32_t n_vertices,
+                                        const uint32_t* mesh_indices, uint32_t n_indices,
+                                        int32_t analytic_leaves_only, trc_host_scene** out);
 void       trc_host_scene_destroy(trc_host_scene* s);
 /* view of the assembled arrays (valid until destroy) */
 void       trc_host_scene_view(const trc_host_scene* s, trc_scene* out);

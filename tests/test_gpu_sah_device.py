@@ -203,3 +203,47 @@ def test_million_triangle_sah_build(gpu):
     ref = pyoracle.trace_rays(sc.view, rays)
     for f in ref.dtype.names:
         assert (got[f].view(np.uint32) == ref[f].view(np.uint32)).all(), f
+
+
+def analytic_leaves_view(sc):
+    """`sc`'s scene with bvhList = the leaf records of the analytic primitives only (they come first, scene.cpp)."""
+    n_tri = sc.view.n_index // 3
+    v = abi.Scene.from_buffer_copy(sc.leaves_view())
+    v.n_bvh = sc.n_leaves - n_tri
+    return v
+
+
+@pytest.mark.parametrize("mesh", ["ball", "teapot", "teapots_1m"])
+def test_triangle_leaves_written_on_the_device(gpu, mesh):
+    """trc_upload_scene_device(TRC_TREE_TRIANGLE_LEAVES): the host hands over its handful of analytic leaves and the mesh; the
+    triangles' leaf records (AAPLRenderer.mm:575-589 + BVH::buildNode) are written on the GPU.  Whole tree == the host's."""
+    m = {"ball": lambda: host.Mesh.ball(60, 60, 1.0), "teapot": lambda: host.Mesh.golden("teapot"),
+         "teapots_1m": lambda: host.Mesh.golden("teapot").replicate(8, 80.0)}[mesh]()
+    sc = host.HostScene(abi.SCENE_CORNELL_MESH, m)
+    gpu.upload_scene_device(analytic_leaves_view(sc), abi.TREE_SAH | abi.TREE_TRIANGLE_LEAVES)
+    assert not first_difference(raw(gpu.download_bvh()), sc.bvh_array())
+    if mesh != "teapots_1m":
+        want, height = pyoracle.lbvh_build(sc.leaves(), sc.n_leaves)
+        gpu.upload_scene_device(analytic_leaves_view(sc), abi.TREE_TRIANGLE_LEAVES)
+        assert not first_difference(raw(gpu.download_bvh()), raw(want))
+    # without the flag the same view is a tree over the analytic primitives alone; unknown flags are refused
+    from tracer_amd.device import TracerError
+    with pytest.raises(TracerError):
+        gpu.upload_scene_device(sc.leaves_view(), 8)
+    rays = random_rays(5000, 3)
+    gpu.upload_scene_device(analytic_leaves_view(sc), abi.TREE_SAH | abi.TREE_TRIANGLE_LEAVES)
+    got = gpu.trace_rays(rays)
+    ref = pyoracle.trace_rays(sc.view, rays)
+    for f in ref.dtype.names:
+        assert (got[f].view(np.uint32) == ref[f].view(np.uint32)).all(), f
+
+
+def test_host_without_leaf_loop_and_tree(gpu):
+    """trc_host_scene_create_leaves(analytic_leaves_only): the host neither writes a leaf per triangle nor builds a tree; the
+    device does both and ends with the tree of the host that did."""
+    m = host.Mesh.golden("teapot").replicate(2, 80.0)
+    full = host.HostScene(abi.SCENE_CORNELL_MESH, m)
+    lean = host.HostScene(abi.SCENE_CORNELL_MESH, m, analytic_leaves_only=True)
+    assert lean.view.n_bvh == full.n_leaves - full.view.n_index // 3 and lean.view.n_index == full.view.n_index
+    gpu.upload_scene_device(lean.view, abi.TREE_SAH | abi.TREE_TRIANGLE_LEAVES)
+    assert not first_difference(raw(gpu.download_bvh()), full.bvh_array())

@@ -14,6 +14,14 @@ for i in range(K):
     t0 = time.time(); t.upload_scene_sah(sc.leaves_view()); wall = time.time() - t0
     n, h, ms = t.lbvh_info()
     print(f"trc_upload_scene_sah: {wall * 1e3:.1f} ms wall (leaf upload + triangle repack included), GPU build {ms:.2f} ms, depth {h}")
+# the whole way from a mesh to a scene on the GPU, host work included: the host that does everything / the host that hands over
+# its analytic leaves and the mesh (trc_host_scene_create_leaves + trc_upload_scene_device)
+for i in range(3):
+    t0 = time.time(); full = host.HostScene(abi.SCENE_CORNELL_MESH, mesh); t1 = time.time(); t.upload_scene(full.view); t.synchronize(); t2 = time.time()
+    lean = host.HostScene(abi.SCENE_CORNELL_MESH, mesh, analytic_leaves_only=True); t3 = time.time()
+    t.upload_scene_device(lean.view, abi.TREE_SAH | abi.TREE_TRIANGLE_LEAVES); t.synchronize(); t4 = time.time()
+    print(f"mesh -> scene on the GPU: host leaves + host tree {1e3 * (t1 - t0):.0f} ms + trc_upload_scene {1e3 * (t2 - t1):.0f} ms = {1e3 * (t2 - t0):.0f} ms;  "
+          f"analytic leaves {1e3 * (t3 - t2):.0f} ms + trc_upload_scene_device {1e3 * (t4 - t3):.0f} ms = {1e3 * (t4 - t2):.0f} ms (GPU build {t.lbvh_info()[2]:.2f} ms)")
 for i in range(2):
     t0 = time.time(); t.upload_scene_lbvh(sc.leaves_view()); wall = time.time() - t0
     n, h, ms = t.lbvh_info()

@@ -10,6 +10,7 @@ import ctypes as C
 TRC_ABI_VERSION = 4
 TRC_TILE = 16
 TRC_MAX_BVH_DEPTH = 64
+TREE_SAH, TREE_TRIANGLE_LEAVES = 1, 2
 TRC_UNIQUE_ID_BYTES = 128
 # enum trc_coll_dtype / trc_coll_op (ncclDataType_t / ncclRedOp_t ordinals)
 DT_U8, DT_U32, DT_F32 = 1, 3, 7
@@ -209,7 +210,7 @@ for _t, _n in _EXPECTED_SIZES.items():
 # every symbol include/tracer_abi.h declares, by library (checked by tests/test_abi_symbols.py)
 DEVICE_SYMBOLS = [
     "trc_abi_version", "trc_build_flavor", "trc_status_string", "trc_last_error", "trc_create", "trc_destroy",
-    "trc_upload_scene", "trc_upload_density", "trc_upload_scene_lbvh", "trc_upload_scene_sah", "trc_download_bvh", "trc_lbvh_info", "trc_set_camera", "trc_set_environment", "trc_set_environment_map", "trc_resize", "trc_seed",
+    "trc_upload_scene", "trc_upload_density", "trc_upload_scene_lbvh", "trc_upload_scene_sah", "trc_upload_scene_device", "trc_download_bvh", "trc_lbvh_info", "trc_set_camera", "trc_set_environment", "trc_set_environment_map", "trc_resize", "trc_seed",
     "trc_upload_rng", "trc_download_rng", "trc_upload_accum", "trc_download_accum", "trc_clear_accum", "trc_tonemap",
     "trc_render", "trc_synchronize", "trc_trace_rays", "trc_get_stats", "trc_reset_stats", "trc_debug_profile",
     "trc_sppm_init", "trc_sppm_frames", "trc_sppm_download", "trc_sppm_hash_cells",
@@ -218,7 +219,7 @@ DEVICE_SYMBOLS = [
 ]
 HOST_SYMBOLS = [
     "trc_host_build_node", "trc_host_build_tree", "trc_host_tree_depth", "trc_host_make_camera",
-    "trc_host_prepare_camera", "trc_host_fill_rng", "trc_host_scene_create", "trc_host_scene_destroy",
+    "trc_host_prepare_camera", "trc_host_fill_rng", "trc_host_scene_create", "trc_host_scene_create_leaves", "trc_host_scene_destroy",
     "trc_host_scene_view", "trc_host_scene_load_pbrt", "trc_host_mesh_load_obj", "trc_host_mesh_load_pbrt", "trc_host_mesh_load_ply", "trc_host_load_hdr", "trc_host_mesh_make_ball", "trc_host_mesh_replicate", "trc_host_mesh_from_arrays",
     "trc_host_mesh_view", "trc_host_mesh_destroy", "trc_host_make_density_info", "trc_host_make_cloud",
     "trc_host_load_density_pbrt", "trc_host_free", "trc_host_write_png", "trc_host_sobol_matrices32",

@@ -54,7 +54,44 @@ __global__ void __launch_bounds__(256) k_repack_triangles(const trc_TriangleVert
     triattr[4 * (size_t)t + 3] = make_float4(b.uv[1], c.uv[0], c.uv[1], 0.0f);
 }
 
-trc_status trc_repack_triangles(trc_ctx* ctx, const trc_scene* s, const DScene& sc, uint32_t* d_blob) {
+// BVH::buildNode for the triangles (AAPLRenderer.mm:575-589 + BVH.hh:273-314): the box of the three vertices -- std::max({a, b, c}) /
+// std::min({a, b, c}) keep the first of equals -- taken corner by corner through the identity matrix (column sums in the reference's
+// order, so a -0 comes out as the host's arithmetic leaves it) into fmin / fmax from +-FLT_MAX (the second operand on a tie, as the
+// host's minss / maxss).  One thread per triangle, one 64-byte leaf record out.
+__global__ void __launch_bounds__(256) k_triangle_leaves(const trc_TriangleVertex* __restrict__ verts, const uint32_t* __restrict__ idx,
+                                                         uint32_t n_tri, trc_BVH* __restrict__ leaves) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_tri) return;
+    const trc_TriangleVertex a = verts[idx[3 * t]], b = verts[idx[3 * t + 1]], c = verts[idx[3 * t + 2]];
+    float ele[2][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float hi = a.v[k]; if (hi < b.v[k]) hi = b.v[k]; if (hi < c.v[k]) hi = c.v[k];
+        float lo = a.v[k]; if (b.v[k] < lo) lo = b.v[k]; if (c.v[k] < lo) lo = c.v[k];
+        ele[0][k] = lo; ele[1][k] = hi;
+    }
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float x = ele[i][0], y = ele[j][1], z = ele[k][2];
+                const float w[3] = {1.0f * x + 0.0f * y + 0.0f * z + 0.0f * 1.0f, 0.0f * x + 1.0f * y + 0.0f * z + 0.0f * 1.0f,
+                                    0.0f * x + 0.0f * y + 1.0f * z + 0.0f * 1.0f};
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { mn[q] = mn[q] < w[q] ? mn[q] : w[q]; mx[q] = mx[q] > w[q] ? mx[q] : w[q]; }
+            }
+    trc_BVH r;
+    memset(&r, 0, sizeof r);
+    r.pType = TRC_PRIM_TRIANGLE; r.pIndex = t;
+    r.bBOX.mini.x = mn[0]; r.bBOX.mini.y = mn[1]; r.bBOX.mini.z = mn[2];
+    r.bBOX.maxi.x = mx[0]; r.bBOX.maxi.y = mx[1]; r.bBOX.maxi.z = mx[2];
+    leaves[t] = r;
+}
+
+trc_status trc_repack_triangles(trc_ctx* ctx, const trc_scene* s, const DScene& sc, uint32_t* d_blob, trc_BVH* d_tri_leaves) {
     const uint32_t n_tri = s->n_index / 3;
     if (n_tri == 0) return TRC_OK;
     trc_TriangleVertex* d_verts = nullptr;
@@ -67,6 +104,7 @@ trc_status trc_repack_triangles(trc_ctx* ctx, const trc_scene* s, const DScene& 
             hipMemcpyAsync(d_idx, s->idxList, (size_t)s->n_index * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { st = trc_fail(ctx, TRC_ERR_HIP, "H2D triangles"); break; }
         hipLaunchKernelGGL(k_repack_triangles, dim3((n_tri + 255) / 256), dim3(256), 0, ctx->stream, d_verts, d_idx, n_tri,
                            reinterpret_cast<float4*>(d_blob + sc.off_tripos), reinterpret_cast<float4*>(d_blob + sc.off_triattr));
+        if (d_tri_leaves) hipLaunchKernelGGL(k_triangle_leaves, dim3((n_tri + 255) / 256), dim3(256), 0, ctx->stream, d_verts, d_idx, n_tri, d_tri_leaves);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { st = trc_fail(ctx, TRC_ERR_HIP, "k_repack_triangles"); break; }
     } while (0);
     (void)hipFree(d_verts); (void)hipFree(d_idx);
@@ -1017,7 +1055,7 @@ trc_status trc_upload_scene(trc_ctx* ctx, const trc_scene* scene) {
     ctx->blob_bytes = (size_t)blob_total * 4;
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_blob, ctx->blob_bytes));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_blob, blob.data(), blob.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    { trc_status rs = trc_repack_triangles(ctx, scene, ks.sc, ctx->d_blob); if (rs != TRC_OK) return rs; }
+    { trc_status rs = trc_repack_triangles(ctx, scene, ks.sc, ctx->d_blob, nullptr); if (rs != TRC_OK) return rs; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ks.sc.blob = ctx->d_blob;
     ctx->ks = ks;

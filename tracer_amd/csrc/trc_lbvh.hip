@@ -507,14 +507,17 @@ uint32_t trc_sort_hist_words(uint32_t n) { return 256u * ((n + kSortTile - 1) / 
 // trc_upload_scene_lbvh (sah = false: Morton order, radix tree, rotations) and trc_upload_scene_sah (sah = true: the
 // reference's own binned-SAH build, trc_sah_build.hpp) share everything around the topology: leaf intake, boxes bottom-up,
 // fat nodes by depth, the tree in the reference's array layout.
-static trc_status upload_device_tree(trc_ctx* ctx, const trc_scene* s, bool sah) {
+static trc_status upload_device_tree(trc_ctx* ctx, const trc_scene* s, bool sah, bool triangle_leaves) {
     { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx) return TRC_ERR_INVALID_ARG;
-    if (!s || !s->bvhList || s->n_bvh < 2) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "lbvh: need >= 2 leaf records");
-    if (s->n_bvh > (1u << 28)) return trc_fail(ctx, TRC_ERR_UNSUPPORTED, "lbvh: more than 2^28 leaves");
+    if (!s) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "device tree: no scene");
+    // triangle_leaves: bvhList holds the analytic primitives' leaves only; one leaf per triangle follows them, written on the device
+    const uint64_t n_given = s->bvhList ? s->n_bvh : 0u, n_all = n_given + (triangle_leaves ? s->n_index / 3 : 0u);
+    if ((!s->bvhList && !triangle_leaves) || n_all < 2) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "lbvh: need >= 2 leaf records");
+    if (n_all > (1u << 28)) return trc_fail(ctx, TRC_ERR_UNSUPPORTED, "lbvh: more than 2^28 leaves");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     { trc_status st = validate_primitives(ctx, s); if (st != TRC_OK) return st; }
-    const uint32_t n = s->n_bvh, n_interior = n - 1, n_nodes = 2 * n - 1;
+    const uint32_t n = (uint32_t)n_all, n_interior = n - 1, n_nodes = 2 * n - 1;
 
     DScene sc{};
     uint64_t total = 0;
@@ -535,10 +538,10 @@ static trc_status upload_device_tree(trc_ctx* ctx, const trc_scene* s, bool sah)
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_bvh_ref, sizeof(trc_BVH) * n_nodes));
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_blob, blob.get(), (size_t)sc.off_nodes * 4, hipMemcpyHostToDevice, st));
-    { trc_status rs = trc_repack_triangles(ctx, s, sc, ctx->d_blob); if (rs != TRC_OK) return rs; }
-    // the caller's leaf records go straight to slots 1..n of the reference-layout array (BVH.hh:246-269)
+    // the caller's leaf records go straight to slots 1..n of the reference-layout array (BVH.hh:246-269), the triangles' behind them
+    { trc_status rs = trc_repack_triangles(ctx, s, sc, ctx->d_blob, triangle_leaves ? ctx->d_bvh_ref + 1 + n_given : nullptr); if (rs != TRC_OK) return rs; }
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_bvh_ref, 0, sizeof(trc_BVH), st));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bvh_ref + 1, s->bvhList, sizeof(trc_BVH) * n, hipMemcpyHostToDevice, st));
+    if (n_given) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bvh_ref + 1, s->bvhList, sizeof(trc_BVH) * n_given, hipMemcpyHostToDevice, st));
 
     Buffers buf;
     DLeaf* d_leaves; uint32_t *d_keys[2], *d_vals[2], *d_hist, *d_bounds, *d_height, *d_arrived;
@@ -668,8 +671,12 @@ static trc_status upload_device_tree(trc_ctx* ctx, const trc_scene* s, bool sah)
 
 extern "C" {
 
-trc_status trc_upload_scene_lbvh(trc_ctx* ctx, const trc_scene* s) { return upload_device_tree(ctx, s, false); }
-trc_status trc_upload_scene_sah(trc_ctx* ctx, const trc_scene* s) { return upload_device_tree(ctx, s, true); }
+trc_status trc_upload_scene_lbvh(trc_ctx* ctx, const trc_scene* s) { return upload_device_tree(ctx, s, false, false); }
+trc_status trc_upload_scene_sah(trc_ctx* ctx, const trc_scene* s) { return upload_device_tree(ctx, s, true, false); }
+trc_status trc_upload_scene_device(trc_ctx* ctx, const trc_scene* s, uint32_t flags) {
+    if (flags & ~(uint32_t)(TRC_TREE_SAH | TRC_TREE_TRIANGLE_LEAVES)) return ctx ? trc_fail(ctx, TRC_ERR_INVALID_ARG, "trc_upload_scene_device: unknown flag") : TRC_ERR_INVALID_ARG;
+    return upload_device_tree(ctx, s, (flags & TRC_TREE_SAH) != 0, (flags & TRC_TREE_TRIANGLE_LEAVES) != 0);
+}
 
 trc_status trc_download_bvh(trc_ctx* ctx, trc_BVH* out, uint32_t capacity, uint32_t* n_nodes) {
     { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)

@@ -146,4 +146,5 @@ inline void fill_primitives(const trc_scene* s, const DScene& sc, uint32_t* blob
 // caller's vertex and index arrays: 32 B per vertex + 12 B per triangle cross PCIe instead of 112 B per triangle of
 // host-staged records, and the gather runs at HBM speed (1 M triangles: 29 MB up + 0.1 ms, against 112 MB staged by the
 // host).  Queued on the context stream; the temporary copies are freed after the stream has drained.
-trc_status trc_repack_triangles(trc_ctx* ctx, const trc_scene* s, const DScene& sc, uint32_t* d_blob);
+// d_tri_leaves != nullptr: also one leaf record per triangle (BVH::buildNode under the identity matrix), for the device-built trees
+trc_status trc_repack_triangles(trc_ctx* ctx, const trc_scene* s, const DScene& sc, uint32_t* d_blob, trc_BVH* d_tri_leaves);

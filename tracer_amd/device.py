@@ -65,6 +65,7 @@ def _load(path):
     L.trc_upload_density.argtypes = [vp, C.POINTER(abi.GridDensityInfo), vp]
     L.trc_upload_scene_lbvh.argtypes = [vp, C.POINTER(abi.Scene)]
     L.trc_upload_scene_sah.argtypes = [vp, C.POINTER(abi.Scene)]
+    L.trc_upload_scene_device.argtypes = [vp, C.POINTER(abi.Scene), u32]
     L.trc_download_bvh.argtypes = [vp, C.POINTER(abi.BVH), u32, C.POINTER(u32)]
     L.trc_lbvh_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_float)]
     L.trc_set_camera.argtypes = [vp, C.POINTER(abi.Camera)]
@@ -179,6 +180,10 @@ class Tracer:
     def upload_scene_sah(self, leaves_view):
         """Same input as upload_scene_lbvh; the reference's binned-SAH tree (BVH::buildTree), built on the GPU."""
         self._check(self._L.trc_upload_scene_sah(self._h, C.byref(leaves_view)), "trc_upload_scene_sah")
+
+    def upload_scene_device(self, view, flags):
+        """trc_upload_scene_device: abi.TREE_SAH | abi.TREE_TRIANGLE_LEAVES (bvhList = the analytic primitives' leaves only)."""
+        self._check(self._L.trc_upload_scene_device(self._h, C.byref(view), flags), "trc_upload_scene_device")
 
     def download_bvh(self):
         """The device-built tree in the reference's array layout: ctypes array of abi.BVH (2n-1 records)."""

@@ -43,6 +43,8 @@ def lib():
         L.trc_host_scene_create.argtypes = [C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                             C.POINTER(C.c_void_p)]
         L.trc_host_scene_create.restype = C.c_int32
+        L.trc_host_scene_create_leaves.argtypes = [C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int32, C.POINTER(C.c_void_p)]
+        L.trc_host_scene_create_leaves.restype = C.c_int32
         L.trc_host_scene_load_pbrt.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(abi.Camera),
                                                C.POINTER(abi.PbrtInfo), C.POINTER(abi.PbrtShape), C.c_uint32]
         L.trc_host_scene_load_pbrt.restype = C.c_int32
@@ -173,14 +175,17 @@ class Mesh:
 class HostScene:
     """Scene arrays in the reference's layouts + the built BVH (root at index 0)."""
 
-    def __init__(self, kind=abi.SCENE_CORNELL_SPHERES, mesh=None):
+    def __init__(self, kind=abi.SCENE_CORNELL_SPHERES, mesh=None, analytic_leaves_only=False):
+        """analytic_leaves_only: no per-triangle leaves and no tree -- view.bvhList holds the analytic primitives' leaf records,
+        the input of Tracer.upload_scene_device(view, TREE_SAH | TREE_TRIANGLE_LEAVES)."""
         self._h = C.c_void_p()
         self._mesh = mesh
+        L = lib()
         if mesh is not None:
-            st = lib().trc_host_scene_create(kind, mesh.vertices_ptr, mesh.n_vertices, mesh.indices_ptr,
-                                             mesh.n_indices, C.byref(self._h))
+            st = L.trc_host_scene_create_leaves(kind, mesh.vertices_ptr, mesh.n_vertices, mesh.indices_ptr,
+                                                mesh.n_indices, int(analytic_leaves_only), C.byref(self._h))
         else:
-            st = lib().trc_host_scene_create(kind, None, 0, None, 0, C.byref(self._h))
+            st = L.trc_host_scene_create_leaves(kind, None, 0, None, 0, int(analytic_leaves_only), C.byref(self._h))
         _check(st, "trc_host_scene_create")
         self.view = abi.Scene()
         lib().trc_host_scene_view(self._h, C.byref(self.view))

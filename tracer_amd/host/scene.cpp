@@ -176,6 +176,11 @@ void trc_host_fill_rng(uint64_t seed, uint32_t width, uint32_t height, uint32_t*
 
 trc_status trc_host_scene_create(int32_t kind, const trc_TriangleVertex* mesh_vertices, uint32_t n_vertices,
                                  const uint32_t* mesh_indices, uint32_t n_indices, trc_host_scene** out) {
+    return trc_host_scene_create_leaves(kind, mesh_vertices, n_vertices, mesh_indices, n_indices, 0, out);
+}
+
+trc_status trc_host_scene_create_leaves(int32_t kind, const trc_TriangleVertex* mesh_vertices, uint32_t n_vertices,
+                                        const uint32_t* mesh_indices, uint32_t n_indices, int32_t analytic_leaves_only, trc_host_scene** out) {
     if (!out) return TRC_ERR_INVALID_ARG;
     if (kind < TRC_SCENE_CORNELL || kind > TRC_SCENE_CORNELL_VOLUME) return TRC_ERR_INVALID_ARG;
     const bool with_mesh = kind == TRC_SCENE_CORNELL_MESH || (kind == TRC_SCENE_CORNELL_VOLUME && mesh_vertices != nullptr);
@@ -239,7 +244,7 @@ trc_status trc_host_scene_create(int32_t kind, const trc_TriangleVertex* mesh_ve
             e.v[0] += -200;
         }
         const trc_float4x4 ident = identity4x4();
-        const uint32_t n_tri = n_indices / 3;
+        const uint32_t n_tri = analytic_leaves_only ? 0u : n_indices / 3;      // else: trc_upload_scene_device writes them on the GPU
         leaves.reserve(leaves.size() + n_tri);
         for (uint32_t t = 0; t < n_tri; ++t) {
             const trc_TriangleVertex& a = s->vertices[s->indices[3 * t]];
@@ -255,6 +260,11 @@ trc_status trc_host_scene_create(int32_t kind, const trc_TriangleVertex* mesh_ve
         }
     }
 
+    if (analytic_leaves_only) {                // no tree either: bvhList = the analytic primitives' leaf records
+        s->bvh = leaves;
+        *out = s;
+        return TRC_OK;
+    }
     const uint32_t n_leaves = (uint32_t)leaves.size();
     s->bvh.resize(2 * (size_t)n_leaves - 1);
     std::copy(leaves.begin(), leaves.end(), s->bvh.begin());
