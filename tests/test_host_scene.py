@@ -1,4 +1,5 @@
 """Host scene construction against the reference's constants."""
+import ctypes as C
 import math
 
 import numpy as np
@@ -76,3 +77,21 @@ def test_ball_and_replicate():
     grid = ball.replicate(3, 2.5)
     assert grid.n_triangles == 9 * ball.n_triangles and grid.n_vertices == 9 * ball.n_vertices
     assert grid.indices().max() == grid.n_vertices - 1
+
+
+def test_scene_with_analytic_leaves_only():
+    """trc_host_scene_create_leaves(analytic_leaves_only): the same arrays, bvhList = the analytic primitives' leaf records (the
+    first leaves of the full scene), no per-triangle leaves, no tree -- the input of trc_upload_scene_device."""
+    mesh = host.Mesh.ball(20, 20, 1.0)
+    full = host.HostScene(abi.SCENE_CORNELL_MESH, mesh)
+    lean = host.HostScene(abi.SCENE_CORNELL_MESH, mesh, analytic_leaves_only=True)
+    n_tri = full.view.n_index // 3
+    assert lean.view.n_bvh == full.n_leaves - n_tri == 9 and lean.view.n_index == full.view.n_index
+    want = full.bvh_array()[1:1 + lean.view.n_bvh].copy()
+    want[:, 0] = 0                                                   # the full scene's leaves carry their parents
+    assert np.array_equal(lean.bvh_array(), want)
+    a = np.frombuffer((C.c_char * (32 * full.view.n_vertex)).from_address(C.addressof(full.view.triList.contents)), dtype=np.uint8)
+    b = np.frombuffer((C.c_char * (32 * lean.view.n_vertex)).from_address(C.addressof(lean.view.triList.contents)), dtype=np.uint8)
+    assert np.array_equal(a, b)                                      # the placed mesh is the same
+    plain = host.HostScene(abi.SCENE_CORNELL_SPHERES, analytic_leaves_only=True)
+    assert plain.view.n_bvh == 21
