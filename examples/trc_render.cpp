@@ -79,18 +79,21 @@ int main(int argc, char** argv) {
         std::fprintf(stderr, "%s: %u shapes (%u not handled), %u materials and %u textures not handled\n", pbrt_path.c_str(), info.n_shapes,
                      info.n_unsupported_shapes, info.n_unsupported_materials, info.n_unsupported_textures);
     } else {
-        if (trc_host_scene_create(kind, mv, n_mv, mi, n_mi, &hs) != TRC_OK) { std::fprintf(stderr, "scene prep failed\n"); return 1; }
+        // --device-sah: the host prepares its analytic primitives and the mesh only -- no leaf record per triangle, no tree
+        if (trc_host_scene_create_leaves(kind, mv, n_mv, mi, n_mi, device_sah ? 1 : 0, &hs) != TRC_OK) { std::fprintf(stderr, "scene prep failed\n"); return 1; }
         trc_host_prepare_camera(&cam, (float)W, (float)H);
     }
     trc_scene scene;
     trc_host_scene_view(hs, &scene);
 
     CHECK(trc_create(0, &ctx));
-    if (lbvh || device_sah) {                     // hand over the leaf records only; the tree is built on the GPU
+    if (device_sah && pbrt_path.empty()) {        // triangle leaves + BVH::buildTree itself, both on the device
+        CHECK(trc_upload_scene_device(ctx, &scene, TRC_TREE_SAH | TRC_TREE_TRIANGLE_LEAVES));
+    } else if (lbvh || device_sah) {              // hand over the leaf records only; the tree is built on the GPU
         trc_scene leaves = scene;
         leaves.bvhList = scene.bvhList + 1;       // BVH::buildTree keeps the leaves at [1, n]
         leaves.n_bvh = (scene.n_bvh + 1) / 2;
-        if (device_sah) CHECK(trc_upload_scene_sah(ctx, &leaves));       // BVH::buildTree itself, on the device
+        if (device_sah) CHECK(trc_upload_scene_sah(ctx, &leaves));
         else CHECK(trc_upload_scene_lbvh(ctx, &leaves));
     } else {
         CHECK(trc_upload_scene(ctx, &scene));

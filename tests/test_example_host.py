@@ -21,7 +21,7 @@ def test_example_is_built_against_the_abi_only():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("args", [["--scene", "spheres", "--integrator", "path"],
-                                  ["--scene", "spheres", "--integrator", "path", "--device-sah"],      # the same tree, built on the GPU
+                                  ["--scene", "spheres", "--integrator", "path", "--device-sah"],      # the same tree, built on the GPU from the analytic leaves
                                   ["--scene", "volume", "--integrator", "volume", "--lbvh"]])
 def test_example_renders_the_same_png_as_the_python_mirror(gpu, tmp_path, args):
     from PIL import Image
