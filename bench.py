@@ -355,7 +355,8 @@ def main(argv=None):
     # reduce program, the same pipelined two-accumulator compose, every other part of the N-rank path as usual.  The line
     # says "plumbing": ranks time-slicing one GPU measure nothing.
     n_dev = visible_gpus() or 1
-    no_rccl = os.environ.get("TRC_BENCH_NO_RCCL") == "1" or (world > n_dev)
+    # TRC_BENCH_FORCE_RCCL=1: try RCCL even with more ranks than GPUs (it refuses: the test of the fallback below)
+    no_rccl = os.environ.get("TRC_BENCH_NO_RCCL") == "1" or (world > n_dev and os.environ.get("TRC_BENCH_FORCE_RCCL") != "1")
     plumbing = grouped and no_rccl
     device = local_rank % n_dev
     scene = host.HostScene(abi.SCENE_CORNELL_SPHERES)
@@ -365,8 +366,18 @@ def main(argv=None):
     trc.set_camera(cam)
     trc.set_environment((0.0, 0.0, 0.0))
     use_rccl = grouped and not no_rccl
+    compose_fallback = None
     if use_rccl:
-        uid = group.broadcast(group_unique_id() if rank == 0 else None)
+        # RCCL over xGMI is the compose path.  It has never run with N > 1 on hardware (one GPU per box in the build pool), so a
+        # rank that cannot bring its communicator up does not end the run: every rank hears of it and all of them compose through
+        # the host-staged socket table instead (the line says so in "compose_fallback"; slower, still the named frame).
+        uid, err = None, ""
+        if rank == 0:
+            try:
+                uid = group_unique_id()
+            except Exception as e:                      # librccl not loadable, ...
+                err = f"trc_group_unique_id: {e}"
+        uid = group.broadcast(uid)
         trc.resize(W, H)
 
         def init_comm():
@@ -374,8 +385,21 @@ def main(argv=None):
             trc.clear_accum()
             trc.group_reduce_accum(0)        # first collective: RCCL finishes its lazy set-up here
             trc.synchronize()
-        # RCCL prints a version banner through C stdio on fd 1; keep stdout clean for the single JSON line
-        _with_c_stdout_on_stderr(init_comm)
+        ok = 0
+        if uid is not None:
+            try:
+                # RCCL prints a version banner through C stdio on fd 1; keep stdout clean for the single JSON line
+                _with_c_stdout_on_stderr(init_comm)
+                ok = 1
+            except Exception as e:
+                err = f"rank {rank}: {e}"
+        if group.allreduce_scalar(ok, "MIN") < 1:
+            errs = [e for e in group.gather(err) if e]
+            compose_fallback = "RCCL communicator not available (" + "; ".join(errs[:2]) + "): composed through trc_group_set_collectives, host-staged over TCP sockets"
+            from tracer_amd.socket_group import SocketCollectives
+            coll = SocketCollectives(group)
+            trc.set_collectives(coll, world, rank)     # drops whatever communicator this rank did bring up
+            use_rccl, plumbing = False, True
     elif plumbing:
         from tracer_amd.socket_group import SocketCollectives
         trc.resize(W, H)
@@ -525,6 +549,7 @@ def main(argv=None):
         if grouped:
             compose = (f"ncclReduce(sum) of the {W}x{FH} RGBA32F frame to rank 0 on a second stream, overlapped with the "
                        f"next step" if use_rccl else
+                       f"reduce(sum) of the {W}x{FH} frame through trc_group_set_collectives (host-staged, TCP sockets): {compose_fallback}" if compose_fallback else
                        f"PLUMBING RUN, NOT A MEASUREMENT: {world} ranks share {n_dev} GPU(s); reduce(sum) of the {W}x{FH} frame "
                        f"through trc_group_set_collectives (host-staged, TCP sockets) because RCCL refuses two ranks on one device")
         line = {
@@ -557,7 +582,9 @@ def main(argv=None):
                 "algorithmic_bytes_per_launch": int(primary["bytes_per_launch"]),
                 "bytes_per_ray": round(primary["bytes_per_launch"] / max(1, primary["rays_per_launch"]), 1)},
         }
-        if plumbing:
+        if compose_fallback:
+            line["compose_fallback"] = compose_fallback
+        elif plumbing:
             line["plumbing"] = True
         if world > 1:
             line["per_rank"] = primary["per_rank"]

@@ -154,6 +154,23 @@ def test_two_rank_bench_path_on_one_gpu(launcher):
         assert 0 < r["longest_chain_ms"] and 0 < r["work_over_slots_ms"] and r["launch_entries"] >= 32400 // 2
 
 
+@pytest.mark.gpu
+def test_a_failing_rccl_communicator_does_not_end_the_run():
+    """The RCCL compose path has never run with N > 1 on hardware.  Here it FAILS for real (two ranks forced onto RCCL with one
+    device: ncclCommInitRank refuses): every rank hears of it, all compose through the socket table, the line says so."""
+    import json, subprocess, sys
+    env = dict(os.environ, TRC_BENCH_FORCE_RCCL="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TRC_BENCH_NO_RCCL"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-other-scaling"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.strip().startswith("{")][-1])
+    assert "ncclCommInitRank" in line["compose_fallback"] and "plumbing" not in line
+    assert line["n_gpus"] == 2 and line["config"]["rays_per_step"] == 219978393
+    assert all(r["compose_ms"] is not None for r in line["per_rank"])
+
+
 def test_source_hash_ignores_comments_and_white_space_only():
     a = 'int f(int x) { // add one\n    return x + 1; /* really */ }\nconst char* s = "// not a comment";\n'
     b = 'int f(int x) {\n  return x + 1;\n}\n\nconst char* s = "// not a comment";  // trailing\n'
