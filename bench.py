@@ -315,6 +315,7 @@ def main(argv=None):
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus, argv))
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL across processes); before anything loads HIP
     rank = int(os.environ.get("RANK", "0"))
     if rank == args.fail_rank:
         raise SystemExit(3)
