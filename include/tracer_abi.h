@@ -702,10 +702,12 @@ typedef struct trc_pbrt_info {
     float    fov, lensradius, focaldistance;
     uint32_t perspective;           /* Camera "perspective" */
     uint32_t xres, yres;            /* Film "image" */
-    uint32_t n_shapes;              /* world shapes in file order (object templates excluded) */
+    uint32_t n_shapes;              /* world shapes in file order (object templates excluded), then the shapes of every instance */
     uint32_t n_unsupported_shapes, n_unsupported_materials, n_triangle_material_conflicts;
     uint32_t mis_ready;             /* squareList[5] and [6] are emitters: TRC_INTEGRATOR_MIS / _VOLUME are usable */
     uint32_t n_unsupported_textures;/* shapes whose colour names a texture other than a 2-D checkerboard */
+    uint32_t n_instances;           /* ObjectInstance directives: each placed as a flat copy of its template's shapes, after the
+                                       world's own shapes, in file order (the reference's scene arrays have no instance level) */
 } trc_pbrt_info;
 typedef struct trc_pbrt_shape {
     int32_t  kind;                  /* enum trc_pbrt_shape_kind, or -1 (a shape class that is not handled) */

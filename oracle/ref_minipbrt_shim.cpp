@@ -76,6 +76,73 @@ extern "C" int ref_minipbrt_triangle_meshes(const char* path, unsigned* n_vertic
 
 extern "C" void ref_minipbrt_free(void* p) { std::free(p); }
 
+// one shape of the parsed scene as the 48 floats documented at ref_minipbrt_describe
+static void describe_shape(minipbrt::Scene* scene, minipbrt::Shape* s, float rec[48]) {
+    std::memset(rec, 0, 48 * sizeof(float));
+    rec[0] = -1.0f;
+    std::memcpy(rec + 1, &s->shapeToWorld.start[0][0], 16 * sizeof(float));
+    if (s->type() == minipbrt::ShapeType::Sphere) { rec[0] = 0.0f; rec[17] = static_cast<minipbrt::Sphere*>(s)->radius; }
+    else if (s->type() == minipbrt::ShapeType::TriangleMesh) {
+        auto* m = static_cast<minipbrt::TriangleMesh*>(s);
+        rec[0] = 3.0f; rec[18] = (float)m->num_vertices; rec[19] = (float)m->num_indices;
+    } else if (s->type() == minipbrt::ShapeType::Disk) {
+        auto* d = static_cast<minipbrt::Disk*>(s);
+        rec[0] = 6.0f; rec[17] = d->radius; rec[35] = rec[36] = d->height; rec[37] = d->innerradius; rec[38] = d->phimax;
+    } else if (s->type() == minipbrt::ShapeType::Cylinder) {
+        auto* c = static_cast<minipbrt::Cylinder*>(s);
+        rec[0] = 7.0f; rec[17] = c->radius; rec[35] = c->zmin; rec[36] = c->zmax; rec[38] = c->phimax;
+    } else if (s->type() == minipbrt::ShapeType::Cone) {
+        auto* c = static_cast<minipbrt::Cone*>(s);
+        rec[0] = 9.0f; rec[17] = c->radius; rec[35] = 0.0f; rec[36] = c->height; rec[38] = c->phimax;
+    } else if (s->type() == minipbrt::ShapeType::Paraboloid) {
+        auto* c = static_cast<minipbrt::Paraboloid*>(s);
+        rec[0] = 10.0f; rec[17] = c->radius; rec[35] = c->zmin; rec[36] = c->zmax; rec[38] = c->phimax;
+    } else if (s->type() == minipbrt::ShapeType::Hyperboloid) {
+        auto* h = static_cast<minipbrt::Hyperboloid*>(s);
+        rec[0] = 11.0f; rec[38] = h->phimax;
+        for (int k = 0; k < 3; ++k) { rec[39 + k] = h->p1[k]; rec[42 + k] = h->p2[k]; }
+    } else if (s->type() == minipbrt::ShapeType::PLYMesh) {
+        rec[0] = 8.0f;
+        if (minipbrt::TriangleMesh* m = s->triangle_mesh()) {        // reads the PLY file (minipbrt.cpp:4380-4450)
+            rec[18] = (float)m->num_vertices; rec[19] = (float)m->num_indices;
+            delete m;
+        }
+    }
+    rec[20] = -1.0f;
+    if (s->material != minipbrt::kInvalidIndex && s->material < scene->materials.size()) {
+        minipbrt::Material* m = scene->materials[s->material];
+        const float* c = nullptr;
+        const float one[3] = {1, 1, 1};
+        uint32_t tex = minipbrt::kInvalidIndex;
+        switch (m->type()) {
+            case minipbrt::MaterialType::Matte: { auto& k = static_cast<minipbrt::MatteMaterial*>(m)->Kd; rec[20] = 0; c = k.value; tex = k.texture; break; }
+            case minipbrt::MaterialType::Plastic: { auto& k = static_cast<minipbrt::PlasticMaterial*>(m)->Kd; rec[20] = 1; c = k.value; tex = k.texture; break; }
+            case minipbrt::MaterialType::Metal: rec[20] = 2; c = one; break;
+            case minipbrt::MaterialType::Mirror: { auto& k = static_cast<minipbrt::MirrorMaterial*>(m)->Kr; rec[20] = 3; c = k.value; tex = k.texture; break; }
+            case minipbrt::MaterialType::Glass: { auto& k = static_cast<minipbrt::GlassMaterial*>(m)->Kt; rec[20] = 4; c = k.value; tex = k.texture; break; }
+            default: rec[20] = 5; c = nullptr; break;
+        }
+        if (c) { rec[21] = c[0]; rec[22] = c[1]; rec[23] = c[2]; }
+        if (tex != minipbrt::kInvalidIndex && tex < scene->textures.size()) {
+            minipbrt::Texture* t = scene->textures[tex];
+            rec[28] = 2.0f;
+            if (t->type() == minipbrt::TextureType::Checkerboard2D) {
+                auto* cb = static_cast<minipbrt::Checkerboard2DTexture*>(t);
+                rec[28] = 1.0f;
+                for (int j = 0; j < 3; ++j) { rec[29 + j] = cb->tex1.value[j]; rec[32 + j] = cb->tex2.value[j]; }
+            }
+        }
+    }
+    if (s->areaLight != minipbrt::kInvalidIndex && s->areaLight < scene->areaLights.size()) {
+        minipbrt::AreaLight* al = scene->areaLights[s->areaLight];
+        rec[24] = 1.0f;
+        if (al->type() == minipbrt::AreaLightType::Diffuse) {
+            auto* dl = static_cast<minipbrt::DiffuseAreaLight*>(al);
+            for (int j = 0; j < 3; ++j) rec[25 + j] = dl->L[j] * dl->scale[j];
+        }
+    }
+}
+
 // What the REFERENCE's parser makes of a whole scene file, flattened for tests/test_pbrt_scene.py (the yardstick of
 // trc_host_scene_load_pbrt): camera (cameraToWorld, fov, lensradius, focaldistance), film resolution, and per world
 // shape in file order: type, shapeToWorld (row-major), sphere radius, mesh sizes, material type + its colour
@@ -112,70 +179,8 @@ extern "C" int ref_minipbrt_describe(const char* path, float camera[20], int fil
     unsigned n = 0;
     for (size_t k = 0; k < scene->shapes.size(); ++k) {
         if (in_object[k]) continue;
-        minipbrt::Shape* s = scene->shapes[k];
-        float rec[48] = {0};
-        rec[0] = -1.0f;
-        std::memcpy(rec + 1, &s->shapeToWorld.start[0][0], 16 * sizeof(float));
-        if (s->type() == minipbrt::ShapeType::Sphere) { rec[0] = 0.0f; rec[17] = static_cast<minipbrt::Sphere*>(s)->radius; }
-        else if (s->type() == minipbrt::ShapeType::TriangleMesh) {
-            auto* m = static_cast<minipbrt::TriangleMesh*>(s);
-            rec[0] = 3.0f; rec[18] = (float)m->num_vertices; rec[19] = (float)m->num_indices;
-        } else if (s->type() == minipbrt::ShapeType::Disk) {
-            auto* d = static_cast<minipbrt::Disk*>(s);
-            rec[0] = 6.0f; rec[17] = d->radius; rec[35] = rec[36] = d->height; rec[37] = d->innerradius; rec[38] = d->phimax;
-        } else if (s->type() == minipbrt::ShapeType::Cylinder) {
-            auto* c = static_cast<minipbrt::Cylinder*>(s);
-            rec[0] = 7.0f; rec[17] = c->radius; rec[35] = c->zmin; rec[36] = c->zmax; rec[38] = c->phimax;
-        } else if (s->type() == minipbrt::ShapeType::Cone) {
-            auto* c = static_cast<minipbrt::Cone*>(s);
-            rec[0] = 9.0f; rec[17] = c->radius; rec[35] = 0.0f; rec[36] = c->height; rec[38] = c->phimax;
-        } else if (s->type() == minipbrt::ShapeType::Paraboloid) {
-            auto* c = static_cast<minipbrt::Paraboloid*>(s);
-            rec[0] = 10.0f; rec[17] = c->radius; rec[35] = c->zmin; rec[36] = c->zmax; rec[38] = c->phimax;
-        } else if (s->type() == minipbrt::ShapeType::Hyperboloid) {
-            auto* h = static_cast<minipbrt::Hyperboloid*>(s);
-            rec[0] = 11.0f; rec[38] = h->phimax;
-            for (int k = 0; k < 3; ++k) { rec[39 + k] = h->p1[k]; rec[42 + k] = h->p2[k]; }
-        } else if (s->type() == minipbrt::ShapeType::PLYMesh) {
-            rec[0] = 8.0f;
-            if (minipbrt::TriangleMesh* m = s->triangle_mesh()) {        // reads the PLY file (minipbrt.cpp:4380-4450)
-                rec[18] = (float)m->num_vertices; rec[19] = (float)m->num_indices;
-                delete m;
-            }
-        }
-        rec[20] = -1.0f;
-        if (s->material != minipbrt::kInvalidIndex && s->material < scene->materials.size()) {
-            minipbrt::Material* m = scene->materials[s->material];
-            const float* c = nullptr;
-            const float one[3] = {1, 1, 1};
-            uint32_t tex = minipbrt::kInvalidIndex;
-            switch (m->type()) {
-                case minipbrt::MaterialType::Matte: { auto& k = static_cast<minipbrt::MatteMaterial*>(m)->Kd; rec[20] = 0; c = k.value; tex = k.texture; break; }
-                case minipbrt::MaterialType::Plastic: { auto& k = static_cast<minipbrt::PlasticMaterial*>(m)->Kd; rec[20] = 1; c = k.value; tex = k.texture; break; }
-                case minipbrt::MaterialType::Metal: rec[20] = 2; c = one; break;
-                case minipbrt::MaterialType::Mirror: { auto& k = static_cast<minipbrt::MirrorMaterial*>(m)->Kr; rec[20] = 3; c = k.value; tex = k.texture; break; }
-                case minipbrt::MaterialType::Glass: { auto& k = static_cast<minipbrt::GlassMaterial*>(m)->Kt; rec[20] = 4; c = k.value; tex = k.texture; break; }
-                default: rec[20] = 5; c = nullptr; break;
-            }
-            if (c) { rec[21] = c[0]; rec[22] = c[1]; rec[23] = c[2]; }
-            if (tex != minipbrt::kInvalidIndex && tex < scene->textures.size()) {
-                minipbrt::Texture* t = scene->textures[tex];
-                rec[28] = 2.0f;
-                if (t->type() == minipbrt::TextureType::Checkerboard2D) {
-                    auto* cb = static_cast<minipbrt::Checkerboard2DTexture*>(t);
-                    rec[28] = 1.0f;
-                    for (int j = 0; j < 3; ++j) { rec[29 + j] = cb->tex1.value[j]; rec[32 + j] = cb->tex2.value[j]; }
-                }
-            }
-        }
-        if (s->areaLight != minipbrt::kInvalidIndex && s->areaLight < scene->areaLights.size()) {
-            minipbrt::AreaLight* al = scene->areaLights[s->areaLight];
-            rec[24] = 1.0f;
-            if (al->type() == minipbrt::AreaLightType::Diffuse) {
-                auto* dl = static_cast<minipbrt::DiffuseAreaLight*>(al);
-                for (int j = 0; j < 3; ++j) rec[25 + j] = dl->L[j] * dl->scale[j];
-            }
-        }
+        float rec[48];
+        describe_shape(scene, scene->shapes[k], rec);
         out.insert(out.end(), rec, rec + 48);
         ++n;
     }
@@ -209,6 +214,36 @@ extern "C" int ref_minipbrt_textures(const char* path, float** out, unsigned* n_
             for (int j = 0; j < 3; ++j) { r[1 + j] = cb->tex1.value[j]; r[4 + j] = cb->tex2.value[j]; }
         }
     }
+    delete scene;
+    return 0;
+}
+
+// The ObjectInstance directives of a scene file in file order, one record of 64 floats per (instance, shape of its object):
+// [0..47] the template's shape as ref_minipbrt_describe writes a shape (its own shapeToWorld: the CTM at its Shape directive),
+// [48..63] the instance's instanceToWorld (row-major).  pbrt-v3 places the copy at instanceToWorld x shapeToWorld (api.cpp
+// pbrtObjectInstance: TransformedPrimitive); the test multiplies.
+extern "C" int ref_minipbrt_instances(const char* path, float** out, unsigned* n_records) {
+    minipbrt::Loader loader;
+    if (!loader.load(path)) return -1;
+    minipbrt::Scene* scene = loader.take_scene();
+    if (!scene) return -2;
+    std::vector<float> recs;
+    unsigned n = 0;
+    for (minipbrt::Instance* in : scene->instances) {
+        if (!in || in->object == minipbrt::kInvalidIndex || in->object >= scene->objects.size()) continue;
+        minipbrt::Object* o = scene->objects[in->object];
+        if (!o || o->firstShape == minipbrt::kInvalidIndex) continue;
+        for (unsigned k = 0; k < o->numShapes; ++k) {
+            float rec[64];
+            describe_shape(scene, scene->shapes[o->firstShape + k], rec);
+            std::memcpy(rec + 48, &in->instanceToWorld.start[0][0], 16 * sizeof(float));
+            recs.insert(recs.end(), rec, rec + 64);
+            ++n;
+        }
+    }
+    *n_records = n;
+    *out = (float*)std::calloc(recs.size() + 1, sizeof(float));
+    if (!recs.empty()) std::memcpy(*out, recs.data(), recs.size() * sizeof(float));
     delete scene;
     return 0;
 }

@@ -381,3 +381,102 @@ def test_quadric_tessellations_lie_on_their_surfaces(quadrics_pbrt):
             assert np.allclose(np.linalg.norm(N, axis=1), 1.0, atol=1e-5)
     # the tessellations render: the scene builds a tree over 3 x their triangles
     assert scene.tree_depth() > 3
+
+
+INSTANCED = '''
+LookAt 278 278 -800  278 278 0  0 1 0
+Camera "perspective" "float fov" 40
+Film "image" "integer xresolution" 160 "integer yresolution" 120
+WorldBegin
+AttributeBegin
+  AreaLightSource "diffuse" "rgb L" [ 15 15 15 ]
+  Shape "trianglemesh" "integer indices" [ 0 1 2 0 2 3 ] "point P" [ 213 554 227  343 554 227  343 554 332  213 554 332 ]
+AttributeEnd
+AttributeBegin
+  Translate 7 0 0
+  ObjectBegin "gadget"
+    Material "glass" "rgb Kt" [ 0.9 0.9 0.9 ]
+    Shape "sphere" "float radius" 5
+    AttributeBegin
+      Material "matte" "rgb Kd" [ 0.2 0.4 0.6 ]
+      Translate 0 10 0
+      Scale 2 3 4
+      Shape "trianglemesh" "integer indices" [ 0 1 2 ] "point P" [ 0 0 0  1 0 0  0 1 1 ] "normal N" [ 0 0 1  0 0 1  0 0 1 ]
+    AttributeEnd
+  ObjectEnd
+AttributeEnd
+Material "matte" "rgb Kd" [ 0.7 0.7 0.7 ]
+AttributeBegin
+  Translate 100 50 200
+  ObjectInstance "gadget"
+AttributeEnd
+Shape "trianglemesh" "integer indices" [ 0 1 2 0 2 3 ] "point P" [ 0 0 0  555 0 0  555 0 555  0 0 555 ]
+AttributeBegin
+  Translate 300 80 300
+  Rotate 90 0 1 0
+  Scale 4 4 4
+  ObjectInstance "gadget"
+AttributeEnd
+ObjectInstance "nothing of that name"
+WorldEnd
+'''
+
+
+def ref_instances(path):
+    L = C.CDLL(REF_LIB)
+    L.ref_minipbrt_instances.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint)]
+    L.ref_minipbrt_free.argtypes = [C.c_void_p]
+    p, n = C.POINTER(C.c_float)(), C.c_uint()
+    assert L.ref_minipbrt_instances(os.fsencode(path), C.byref(p), C.byref(n)) == 0
+    try:
+        return np.ctypeslib.as_array(p, shape=(n.value, 64)).copy() if n.value else np.zeros((0, 64), np.float32)
+    finally:
+        L.ref_minipbrt_free(p)
+
+
+@needs_ref
+def test_object_instances_are_placed_as_flat_copies(tmp_path):
+    """ObjectBegin / ObjectInstance (pbrt-v3 api.cpp; minipbrt.h:1417-1436 Object / Instance): every instance becomes a copy of
+    its template's shapes at instanceToWorld x shapeToWorld, after the world's own shapes, in file order -- field for field
+    against what the reference's parser holds for the templates and the instances."""
+    path = tmp_path / "instanced.pbrt"
+    path.write_text(INSTANCED)
+    scene, cam, info, shapes = host.HostScene.from_pbrt(str(path))
+    _, _, rworld = ref_describe(str(path))
+    rinst = ref_instances(str(path))
+    assert len(rworld) == 2 and len(rinst) == 4                       # 2 world meshes; 2 instances x (sphere + mesh)
+    assert info.n_instances == 3 and info.n_shapes == len(shapes) == 6 and info.n_unsupported_shapes == 1    # the instance of nothing
+    for mine, ref in zip(shapes[:2], rworld):
+        assert mine.kind == int(ref[0])
+        np.testing.assert_allclose(np.array(mine.shape_to_world[:], np.float32), ref[1:17], rtol=1e-6, atol=1e-4)
+    for mine, ref in zip(shapes[2:], rinst):
+        assert mine.kind == int(ref[0])
+        want = ref[48:64].reshape(4, 4).astype(np.float64) @ ref[1:17].reshape(4, 4).astype(np.float64)
+        np.testing.assert_allclose(np.array(mine.shape_to_world[:], np.float64).reshape(4, 4), want, rtol=1e-5, atol=1e-3)
+        assert mine.material == int(ref[20]) and np.array_equal(np.array(mine.color[:], np.float32), ref[21:24])
+        if mine.kind == abi.PBRT_SHAPE_SPHERE:
+            assert np.float32(mine.radius) == ref[17] == 5
+        else:
+            assert (mine.n_vertices, mine.n_indices) == (int(ref[18]), int(ref[19])) == (3, 3)
+    v = scene.view
+    # the spheres: centre = the placed origin, radius scaled by the instance (1 and 4)
+    assert v.n_sphere == 2
+    c0, c1 = v.sphereList[0], v.sphereList[1]
+    m0 = rinst[0][48:64].reshape(4, 4).astype(np.float64) @ rinst[0][1:17].reshape(4, 4).astype(np.float64)
+    m1 = rinst[2][48:64].reshape(4, 4).astype(np.float64) @ rinst[2][1:17].reshape(4, 4).astype(np.float64)
+    np.testing.assert_allclose([c0.center.x, c0.center.y, c0.center.z], m0[:3, 3], atol=1e-3)
+    np.testing.assert_allclose([c1.center.x, c1.center.y, c1.center.z], m1[:3, 3], atol=1e-3)
+    assert abs(c0.radius - 5.0) < 1e-3 and abs(c1.radius - 20.0) < 1e-2
+    # the template's triangle, placed twice: vertices = instanceToWorld x shapeToWorld x P of the source text
+    P = np.array([[0, 0, 0, 1], [1, 0, 0, 1], [0, 1, 1, 1]], np.float64)
+    tri = [s for s in shapes[2:] if s.kind == abi.PBRT_SHAPE_TRIANGLEMESH]
+    for s, ref in zip(tri, (rinst[1], rinst[3])):
+        m = ref[48:64].reshape(4, 4).astype(np.float64) @ ref[1:17].reshape(4, 4).astype(np.float64)
+        first = 3 * s.mapped_index
+        got = np.array([[v.triList[v.idxList[first + k]].v[a] for a in range(3)] for k in range(3)])
+        np.testing.assert_allclose(got, (P @ m.T)[:, :3], rtol=1e-5, atol=1e-3)
+    # and the whole thing is a scene the oracle can walk: a ray down onto the second copy's sphere hits it
+    from oracle import pyoracle as po
+    rays = po.make_rays(np.array([[m1[0, 3], m1[1, 3] + 100.0, m1[2, 3]]], np.float32), np.array([[0, -1, 0]], np.float32))
+    h = po.trace_rays(v, rays)
+    assert h["hit"][0] == 1 and h["pType"][0] == abi.PRIM_SPHERE and abs(h["t"][0] - 80.0) < 1e-2

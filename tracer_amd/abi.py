@@ -155,7 +155,8 @@ class PbrtInfo(C.Structure):
     _fields_ = [("camera_to_world", C.c_float * 16), ("fov", C.c_float), ("lensradius", C.c_float),
                 ("focaldistance", C.c_float), ("perspective", C.c_uint32), ("xres", C.c_uint32), ("yres", C.c_uint32),
                 ("n_shapes", C.c_uint32), ("n_unsupported_shapes", C.c_uint32), ("n_unsupported_materials", C.c_uint32),
-                ("n_triangle_material_conflicts", C.c_uint32), ("mis_ready", C.c_uint32), ("n_unsupported_textures", C.c_uint32)]
+                ("n_triangle_material_conflicts", C.c_uint32), ("mis_ready", C.c_uint32), ("n_unsupported_textures", C.c_uint32),
+                ("n_instances", C.c_uint32)]
 
 
 class PbrtShape(C.Structure):

@@ -197,6 +197,18 @@ extern "C" trc_status trc_host_scene_load_pbrt(const char* path, trc_host_scene*
     std::map<std::string, M4> named;
     std::map<std::string, GfxState> named_materials;
     int object_depth = 0;
+    // object instancing (pbrt-v3 api.cpp pbrtObjectBegin / pbrtObjectInstance): the body of an ObjectBegin .. ObjectEnd block is
+    // a template; every ObjectInstance places a copy of its shapes, world = InstanceToWorld (the CTM at the ObjectInstance) x
+    // the shape's own ObjectToWorld (the CTM at its Shape directive).  The instances are expanded after the world's own
+    // shapes, in file order, by reading the template's body again with that prefix -- flat triangles / spheres, since the
+    // reference's scene arrays have no instance level (Render.hh:135-252 walks ONE tree of primitives).
+    struct ObjectDef { size_t body; M4 ctm; GfxState g; };
+    struct InstanceRef { std::string name; M4 to_world; };
+    std::map<std::string, ObjectDef> objects;
+    std::vector<InstanceRef> instances;
+    size_t next_instance = 0;
+    bool replaying = false;
+    M4 inst_prefix = m4_identity();
     std::vector<float> a;
     std::vector<PbrtParam> params;
     std::map<std::string, std::string> strs;
@@ -229,9 +241,25 @@ extern "C" trc_status trc_host_scene_load_pbrt(const char* path, trc_host_scene*
     auto fail = [&](trc_status st = TRC_ERR_INVALID_ARG) { delete s; return st; };
     for (;;) {
         PbrtToken t = lx.next();
-        if (t.kind == PbrtToken::End) break;
+        if (t.kind == PbrtToken::End) {
+            // the file is read: now the instances, one template body each
+            bool again = false;
+            while (!replaying && next_instance < instances.size()) {
+                const InstanceRef& in = instances[next_instance++];
+                auto it = objects.find(in.name);
+                if (it == objects.end()) { inf.n_unsupported_shapes++; continue; }       // an instance of nothing
+                lx.i = it->second.body; ctm = it->second.ctm; g = it->second.g;
+                tstack.clear(); gstack.clear(); object_depth = 0;
+                inst_prefix = in.to_world; replaying = true; again = true;
+                break;
+            }
+            if (again) continue;
+            break;
+        }
         if (t.kind != PbrtToken::Word) continue;
         const std::string& d = t.text;
+        if (replaying && d == "ObjectEnd") { replaying = false; lx.i = text.size(); continue; }      // this copy is placed
+        if (replaying && (d == "ObjectBegin" || d == "ObjectInstance" || d == "WorldEnd")) return fail();
         if (d == "Identity") ctm = m4_identity();
         else if (d == "Translate") {
             if (!read_numbers(lx, 3, a)) return fail();
@@ -285,7 +313,16 @@ extern "C" trc_status trc_host_scene_load_pbrt(const char* path, trc_host_scene*
             ctm = tstack.back(); tstack.pop_back(); g = gstack.back(); gstack.pop_back();
         } else if (d == "TransformBegin") tstack.push_back(ctm);
         else if (d == "TransformEnd") { if (tstack.empty()) return fail(); ctm = tstack.back(); tstack.pop_back(); }
-        else if (d == "ObjectBegin") { lx.next(); ++object_depth; tstack.push_back(ctm); gstack.push_back(g); }
+        else if (d == "ObjectBegin") {
+            const PbrtToken name = lx.next();
+            if (name.kind != PbrtToken::String || object_depth > 0) return fail();
+            ++object_depth; tstack.push_back(ctm); gstack.push_back(g);
+            objects[name.text] = ObjectDef{lx.i, ctm, g};
+        } else if (d == "ObjectInstance") {
+            const PbrtToken name = lx.next();
+            if (name.kind != PbrtToken::String) return fail();
+            if (object_depth == 0) { instances.push_back(InstanceRef{name.text, ctm}); inf.n_instances++; }
+        }
         else if (d == "ObjectEnd") {
             if (object_depth == 0 || tstack.empty() || gstack.empty()) return fail();
             --object_depth; ctm = tstack.back(); tstack.pop_back(); g = gstack.back(); gstack.pop_back();
@@ -331,10 +368,11 @@ extern "C" trc_status trc_host_scene_load_pbrt(const char* path, trc_host_scene*
             PbrtToken kind = lx.next();
             if (kind.kind != PbrtToken::String || !read_params_with_strings(lx, params, strs)) return fail();
             if (object_depth > 0) continue;                         // templates of object instancing: not part of the world
+            const M4 world = replaying ? m4_mul(inst_prefix, ctm) : ctm;      // a template's copy: InstanceToWorld x ObjectToWorld
             trc_pbrt_shape ds;
             std::memset(&ds, 0, sizeof ds);
             ds.kind = -1; ds.mapped_type = -1;
-            std::memcpy(ds.shape_to_world, ctm.m, sizeof ctm.m);
+            std::memcpy(ds.shape_to_world, world.m, sizeof world.m);
             ds.material = g.material; std::memcpy(ds.color, g.color, sizeof ds.color);
             ds.emitter = g.emitter ? 1 : 0; std::memcpy(ds.L, g.L, sizeof ds.L);
             ds.texture = g.texture; std::memcpy(ds.tex2, g.tex2, sizeof ds.tex2);
@@ -347,10 +385,10 @@ extern "C" trc_status trc_host_scene_load_pbrt(const char* path, trc_host_scene*
                 ds.kind = TRC_PRIM_SPHERE;
                 ds.radius = float_of(params, "radius", 1.0f);
                 // centre = shapeToWorld * origin; the matrix must be a similarity (uniform scale) for a sphere to stay one
-                const trc_float3 c = f3(ctm.m[0][3], ctm.m[1][3], ctm.m[2][3]);
-                const float sx = length(f3(ctm.m[0][0], ctm.m[1][0], ctm.m[2][0]));
-                const float sy = length(f3(ctm.m[0][1], ctm.m[1][1], ctm.m[2][1]));
-                const float sz = length(f3(ctm.m[0][2], ctm.m[1][2], ctm.m[2][2]));
+                const trc_float3 c = f3(world.m[0][3], world.m[1][3], world.m[2][3]);
+                const float sx = length(f3(world.m[0][0], world.m[1][0], world.m[2][0]));
+                const float sy = length(f3(world.m[0][1], world.m[1][1], world.m[2][1]));
+                const float sz = length(f3(world.m[0][2], world.m[1][2], world.m[2][2]));
                 if (std::fabs(sx - sy) > 1e-4f * sx || std::fabs(sx - sz) > 1e-4f * sx) { inf.n_unsupported_shapes++; descs.push_back(ds); continue; }
                 ds.mapped_type = TRC_PRIM_SPHERE; ds.mapped_index = (uint32_t)s->spheres.size();
                 ds.mapped_material = intern_material(mtype, mcolor, checker);
@@ -473,7 +511,7 @@ extern "C" trc_status trc_host_scene_load_pbrt(const char* path, trc_host_scene*
                 for (size_t v = 0; v < nv; ++v) {
                     const float x = Po[3 * v], y = Po[3 * v + 1], z = Po[3 * v + 2];
                     float q[4];
-                    for (int r = 0; r < 4; ++r) q[r] = ctm.m[r][0] * x + ctm.m[r][1] * y + ctm.m[r][2] * z + ctm.m[r][3];
+                    for (int r = 0; r < 4; ++r) q[r] = world.m[r][0] * x + world.m[r][1] * y + world.m[r][2] * z + world.m[r][3];
                     const float w = q[3];
                     Pw[v] = f3(w == 1 ? q[0] : q[0] / w, w == 1 ? q[1] : q[1] / w, w == 1 ? q[2] : q[2] / w);
                 }
@@ -492,7 +530,7 @@ extern "C" trc_status trc_host_scene_load_pbrt(const char* path, trc_host_scene*
                         have_tri_material = true;
                     } else if (tri_material.type != mtype) inf.n_triangle_material_conflicts++;
                     M4 inv;
-                    const bool has_inv = m4_inverse(ctm, inv);
+                    const bool has_inv = m4_inverse(world, inv);
                     const uint32_t base = (uint32_t)s->vertices.size();
                     std::vector<trc_float3> acc(nv, f3(0.0f));
                     if (!hasN || !has_inv)                                       // area-weighted smooth normals
