@@ -158,8 +158,32 @@ def test_generated_scene(gpu, seed):
         gpu.upload_rng(rng); gpu.clear_accum(); gpu.render(spp=3, integrator=abi.INTEGRATOR_MIS, max_depth=6)
         ref, _ = po.render(tv, cam, W, H, rng, spp=3, integrator=abi.INTEGRATOR_MIS, max_depth=6, env=(0.3, 0.4, 0.6))
         assert np.array_equal(gpu.download_accum().view(np.uint32), ref.view(np.uint32)), (seed, "lbvh")
+        # ... and through the reference's own SAH tree built on the GPU: the oracle's restatement of BVH::buildTree record for
+        # record, the frame the oracle renders through it
+        want = po.sah_build(lv.bvhList, n_leaves)
+        if max_leaf_depth(want) <= abi.TRC_MAX_BVH_DEPTH:
+            gpu.upload_scene_sah(lv)
+            tree = gpu.download_bvh()
+            assert bytes(memoryview(tree)) == bytes(memoryview(want)), (seed, "device sah tree")
+            tv = abi.Scene.from_buffer_copy(sv); tv.bvhList = C.cast(tree, C.POINTER(abi.BVH)); tv.n_bvh = len(tree)
+            rng = host.fill_rng(95 + seed, W, H)
+            gpu.upload_rng(rng); gpu.clear_accum(); gpu.render(spp=3, integrator=abi.INTEGRATOR_PATH, max_depth=6)
+            ref, _ = po.render(tv, cam, W, H, rng, spp=3, integrator=abi.INTEGRATOR_PATH, max_depth=6, env=(0.3, 0.4, 0.6))
+            assert np.array_equal(gpu.download_accum().view(np.uint32), ref.view(np.uint32)), (seed, "device sah")
     finally:
         po.set_density(None, None); gpu.upload_density(None, None); gpu.set_environment((0.0, 0.0, 0.0))
+
+
+def max_leaf_depth(nodes):
+    a = np.frombuffer(bytes(memoryview(nodes)), dtype=np.uint32).reshape(-1, 16)
+    depth = np.zeros(len(a), dtype=np.int64)
+    order = [0]
+    for i in order:
+        if a[i, 4] == abi.PRIM_BVH:
+            for c in (a[i, 1], a[i, 2]):
+                depth[c] = depth[i] + 1
+                order.append(int(c))
+    return int(depth.max())
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
