@@ -434,7 +434,10 @@ struct Trav {
     uint32_t tag, sp;
     float ry;                 // closest accepted t so far (test_t while nothing was hit)
     int32_t level;            // STATS only: level of the interior node being expanded / parent level of a leaf
-    bool done;
+    // "the walk is over" is tag == kTagNone, not a flag of its own: a lane-divergent bool carried around the traversal loop costs
+    // three scalar mask instructions at every join of the loop's control flow (a third of the loop's instructions were those)
+    TRC_DEV bool is_done() const { return tag == kTagNone; }
+    TRC_DEV void finish() { tag = kTagNone; }
     // DEFER (below): the last accepted test -- its tag and the range_t.y it was run against.  Together with `ry` (= its t)
     // that is all a walk has to carry: the record is a function of (ray, primitive, range_t.y) and is built after the walk.
     uint32_t win_tag;
@@ -463,7 +466,7 @@ template <bool HYB, bool STATS>
 TRC_DEV void trav_pop_or_finish(const SceneRef& S, Trav& tv, int32_t ret_start, const uint32_t* stack, const uint32_t* lvstack, TravCounters& cnt) {
     if (tv.sp == 0) {
         if (STATS) cnt.n_return += (uint32_t)(ret_start + 1);
-        tv.done = true;
+        tv.finish();
         return;
     }
     tv.sp--;
@@ -477,15 +480,14 @@ TRC_DEV void trav_pop_or_finish(const SceneRef& S, Trav& tv, int32_t ret_start, 
 }
 
 // Render.hh:135-153: counts the ray, rejects non-finite rays and rays that miss the root box.  Returns false
-// (tv.done = true) when the traversal is over before it starts.
+// (the walk over: tv.is_done()) when the traversal is over before it starts.
 template <bool STATS>
 TRC_DEV bool trav_begin(const F3 root_min, const F3 root_max, const Ray& ray, const float test_t, Trav& tv, TravCounters& cnt) {
     if (STATS) cnt.rays++;
-    tv.tag = kTagInterior << kTagIndexBits;   // root
+    tv.tag = kTagNone;
     tv.sp = 0;
     tv.level = 0;
     tv.ry = test_t;
-    tv.done = true;
     tv.win_tag = kTagNone;
     tv.win_ry = test_t;
     // a ray with a NaN / infinite component misses the scene (same rule as oracle/oracle.cpp Scene::hit: B-4/B-10);
@@ -493,7 +495,7 @@ TRC_DEV bool trav_begin(const F3 root_min, const F3 root_max, const Ray& ray, co
     const float finite_probe = fabsf(ray.o.x) + fabsf(ray.o.y) + fabsf(ray.o.z) + fabsf(ray.d.x) + fabsf(ray.d.y) + fabsf(ray.d.z);
     if (!(finite_probe < __builtin_inff())) return false;
     if (!box_hit(root_min, root_max, ray, FLT_MIN, test_t)) return false;
-    tv.done = false;
+    tv.tag = kTagInterior << kTagIndexBits;   // root
     return true;
 }
 
@@ -562,7 +564,7 @@ TRC_DEV void trav_build_record(const SceneRef& S, const Ray& ray, HitRec& rec, c
 }
 
 // one round: (1) expand interior nodes until this lane holds a leaf (or runs out of work) -- the whole wavefront
-// does box tests here; (2) test the leaf.  Lanes with tv.done set idle through the call.
+// does box tests here; (2) test the leaf.  Lanes whose walk is over idle through the call.
 //
 // Every lane performs exactly ITS OWN sequence of the reference's steps (box tests against its own running closest
 // hit, near child first, far child deferred without a re-test, primitive tests in that order); what a production
@@ -595,7 +597,7 @@ TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const flo
             tv.tag = stack_get<HYB>(S, stack, tv.sp);
         };
         for (;;) {
-            const bool interior = !tv.done && (tv.tag >> kTagIndexBits) == kTagInterior;
+            const bool interior = (tv.tag >> kTagIndexBits) == kTagInterior;
             if (__ballot(interior) == 0ull) break;
             if (interior) {
                 float4 q0, q1, q2, q3;
@@ -614,18 +616,17 @@ TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const flo
                 if (pend == kTagNone && (tv.tag >> kTagIndexBits) < kTagInterior) { pend = tv.tag; pop_next(); }
             }
         }
-        if (!tv.done) {
+        if (!tv.is_done() || pend != kTagNone) {
             if (pend == kTagNone && (tv.tag >> kTagIndexBits) < kTagInterior) { pend = tv.tag; pop_next(); }
             if (pend != kTagNone) {
                 trav_test_leaf<STATS, EAGER_UV, VOL, DEFER>(S, ray, rec, tv, pend, cnt);
-                if (ANY && tv.ry < test_t) tv.done = true;                       // Render.hh:244
+                if (ANY && tv.ry < test_t) tv.finish();                          // Render.hh:244
             }
-            if (!tv.done && (tv.tag >> kTagIndexBits) < kTagInterior) {          // second leaf, found after the first
+            if ((tv.tag >> kTagIndexBits) < kTagInterior) {                      // second leaf, found after the first
                 trav_test_leaf<STATS, EAGER_UV, VOL, DEFER>(S, ray, rec, tv, tv.tag, cnt);
-                if (ANY && tv.ry < test_t) tv.done = true;
+                if (ANY && tv.ry < test_t) tv.finish();
                 else pop_next();
             }
-            if (tv.tag == kTagNone) tv.done = true;                              // stack exhausted
         }
         return;
     }
@@ -647,15 +648,15 @@ TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const flo
     TriPos pre;
     bool have_pre = false;
     auto fetch_ahead = [&]() {
-        if (kTriEarly && !tv.done && (tv.tag >> kTagIndexBits) == 3u) { pre = load_tripos(S, tv.tag & kTagIndexMask); have_pre = true; }
+        if (kTriEarly && (tv.tag >> kTagIndexBits) == 3u) { pre = load_tripos(S, tv.tag & kTagIndexMask); have_pre = true; }
     };
     fetch_ahead();                 // a leaf popped at the end of the previous round
     for (;;) {
-        const bool interior = !tv.done && (tv.tag >> kTagIndexBits) == kTagInterior;
+        const bool interior = (tv.tag >> kTagIndexBits) == kTagInterior;
         if (!STATS && kDescendMin > 1) {
             const unsigned long long m = __ballot(interior);
             if (m == 0ull) break;
-            if (__popcll(m) < kDescendMin && __ballot(!tv.done && !interior) != 0ull) break;
+            if (__popcll(m) < kDescendMin && __ballot((tv.tag >> kTagIndexBits) < kTagInterior) != 0ull) break;      // somebody waits with a leaf
             if (!interior) continue;
         } else if (!interior) break;
         float4 q0, q1, q2, q3;
@@ -680,9 +681,9 @@ TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const flo
         }
         fetch_ahead();
     }
-    if (!tv.done && (tv.tag >> kTagIndexBits) != kTagInterior) {
+    if ((tv.tag >> kTagIndexBits) < kTagInterior) {
         trav_test_leaf<STATS, EAGER_UV, VOL, DEFER>(S, ray, rec, tv, tv.tag, cnt, (kTriEarly && have_pre) ? &pre : nullptr);
-        if (ANY && tv.ry < test_t) tv.done = true;                    // Render.hh:244
+        if (ANY && tv.ry < test_t) tv.finish();                       // Render.hh:244
         else trav_pop_or_finish<HYB, STATS>(S, tv, tv.level, stack, lvstack, cnt);
     }
 }
@@ -693,7 +694,7 @@ TRC_DEV bool scene_hit(const SceneRef& S, const F3 root_min, const F3 root_max, 
     static_assert(!DEFER || (!STATS && !ANY), "the deferred record is the production closest-hit walk's");
     Trav tv;
     if (!trav_begin<STATS>(root_min, root_max, ray, test_t, tv, cnt)) return false;
-    while (!tv.done) trav_iter<ALL_LDS, STATS, ANY, EAGER_UV, VOL, HYB, DEFER>(S, ray, rec, test_t, tv, stack, lvstack, cnt);
+    while (!tv.is_done()) trav_iter<ALL_LDS, STATS, ANY, EAGER_UV, VOL, HYB, DEFER>(S, ray, rec, test_t, tv, stack, lvstack, cnt);
     const bool hit = tv.ry < test_t;
     // a miss ends the path (the record is re-initialised before anybody reads it), so only a hit is materialised
     if (DEFER && hit) trav_build_record<EAGER_UV, VOL, DEFER>(S, ray, rec, tv);
