@@ -451,14 +451,21 @@ struct Trav {
 // the first S.stack_lds entries live in LDS, deeper ones in the workgroup's rows in global memory.  The other kernels
 // keep the whole stack in LDS (measured: the second level costs traceMIS / traceVolume 2.7 % and buys them nothing at 4
 // waves/SIMD).
+// Almost every access of a wavefront is below stack_lds in all of its lanes: ONE wave-uniform test (a ballot) keeps the
+// per-lane if / else -- six scalar mask instructions and two branches per access -- out of the box-step loop.
+#ifndef TRC_STACK_UNIFORM
+#define TRC_STACK_UNIFORM 1
+#endif
 template <bool HYB>
 TRC_DEV void stack_put(const SceneRef& S, uint32_t* stack, uint32_t e, uint32_t v) {
-    if (!HYB || e < S.stack_lds) stack[e * kBlock] = v;
+    if (!HYB || (TRC_STACK_UNIFORM && __builtin_expect(__builtin_amdgcn_ballot_w64(e >= S.stack_lds) == 0ull, 1))) { stack[e * kBlock] = v; return; }
+    if (e < S.stack_lds) stack[e * kBlock] = v;
     else st1_global(S.ovf + (e - S.stack_lds) * kBlock, v);
 }
 template <bool HYB>
 TRC_DEV uint32_t stack_get(const SceneRef& S, const uint32_t* stack, uint32_t e) {
-    if (!HYB || e < S.stack_lds) return stack[e * kBlock];
+    if (!HYB || (TRC_STACK_UNIFORM && __builtin_expect(__builtin_amdgcn_ballot_w64(e >= S.stack_lds) == 0ull, 1))) return stack[e * kBlock];
+    if (e < S.stack_lds) return stack[e * kBlock];
     return ld1_global(S.ovf + (e - S.stack_lds) * kBlock);
 }
 
