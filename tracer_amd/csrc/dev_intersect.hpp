@@ -642,7 +642,7 @@ TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const flo
 #define TRC_DESCEND_MIN_LDS 1
 #endif
 #ifndef TRC_DESCEND_MIN_GLOBAL
-#define TRC_DESCEND_MIN_GLOBAL 8
+#define TRC_DESCEND_MIN_GLOBAL 12     // 8 until the loop lost its done flag; with the leaner step: 8 / 12 / 16 / 24 / 32 = 23.54 / 23.22 / 23.32 / 23.63 / 24.07 ms (config 4), 40.85 / 40.49 / 40.56 / 40.90 / 41.19 (config 3)
 #endif
     constexpr int kDescendMin = ALL_LDS ? TRC_DESCEND_MIN_LDS : TRC_DESCEND_MIN_GLOBAL;
     // TRC_TRI_EARLY (trees read from memory, production walk): the moment a lane's next stop becomes a triangle, its 48
