@@ -2,6 +2,7 @@
 #   make            host library + HIP library (gfx950) + oracle (+ oracle/_ref when the reference is present)
 #   make host       libtrc_host.so      C++17, CPU only
 #   make hip        libtracer_amd.so    hand-written HIP for gfx950 (hipcc cross-compiles without a GPU)
+#   make hip_hooks  libtracer_amd_hooks.so  the same sources + the test hooks of include/tracer_test_hooks.h (tests/, tools/)
 #   make oracle     oracle/liboracle.so (test infrastructure, see oracle/README.md)
 ROCM      ?= /opt/rocm
 HIPCC     ?= $(ROCM)/bin/hipcc
@@ -19,14 +20,15 @@ HIPFLAGS  := -std=c++17 -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-s
 HOST_SRC  := tracer_amd/host/bvh_builder.cpp tracer_amd/host/scene.cpp tracer_amd/host/mesh.cpp tracer_amd/host/pbrt_scene.cpp
 HOST_HDR  := tracer_amd/host/host_math.hpp tracer_amd/host/host_scene.hpp tracer_amd/host/pbrt_text.hpp include/tracer_abi.h include/trc_sobol.h
 HIP_SRC   := tracer_amd/csrc/trc_abi.hip tracer_amd/csrc/trc_render_lds.hip tracer_amd/csrc/trc_render_mem.hip tracer_amd/csrc/trc_sppm.hip tracer_amd/csrc/trc_lbvh.hip
-HIP_HDR   := $(wildcard tracer_amd/csrc/*.hpp) include/tracer_abi.h include/trc_detmath.h include/trc_sobol.h
+HIP_HDR   := $(wildcard tracer_amd/csrc/*.hpp) include/tracer_abi.h include/tracer_test_hooks.h include/trc_detmath.h include/trc_sobol.h
 
-.PHONY: all host hip hip_fast oracle example clean variant asan tsan sanitize
-all: host hip hip_fast oracle example
+.PHONY: all host hip hip_fast hip_hooks oracle example clean variant asan tsan sanitize
+all: host hip hip_fast hip_hooks oracle example
 
 host: $(LIBDIR)/libtrc_host.so
 hip: $(LIBDIR)/libtracer_amd.so
 hip_fast: $(LIBDIR)/libtracer_amd_fast.so
+hip_hooks: $(LIBDIR)/libtracer_amd_hooks.so
 oracle:
 	$(MAKE) -C oracle
 
@@ -45,6 +47,18 @@ $(LIBDIR)/libtracer_amd.so: $(HIP_OBJ)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=gfx950 -shared -o $@ $(HIP_OBJ) -ldl -lpthread -Wl,-rpath,$(ROCM)/lib
 
+# Product and laboratory apart: the entry points of include/tracer_test_hooks.h (exhaustive arithmetic checks, the SPPM hash,
+# the per-site cycle profile) exist only in this build of the SAME sources.  Only the two translation units that define them are
+# compiled again; the render kernels are the product's objects, byte for byte.
+HOOK_TU      := trc_abi trc_sppm
+HIP_OBJ_HOOKS := $(foreach o,$(HIP_OBJ),$(if $(filter $(HOOK_TU),$(basename $(notdir $(o)))),build/obj/hooks/$(notdir $(o)),$(o)))
+build/obj/hooks/%.o: tracer_amd/csrc/%.hip $(HIP_HDR) Makefile
+	@mkdir -p build/obj/hooks
+	$(HIPCC) $(HIPFLAGS) -DTRC_TEST_HOOKS=1 -c -o $@ $<
+$(LIBDIR)/libtracer_amd_hooks.so: $(HIP_OBJ_HOOKS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=gfx950 -shared -o $@ $(HIP_OBJ_HOOKS) -ldl -lpthread -Wl,-rpath,$(ROCM)/lib
+
 # The same sources under fast-math rules (what the reference's shaders are compiled with: MTL_FAST_MATH): approximate
 # division / sqrt (v_rcp_f32, v_sqrt_f32), FMA contraction, denormals flushed, hardware exp / log / sin / cos
 # (include/trc_detmath.h under TRC_FAST_MATH).  NaN / Inf semantics and signed zeros are
@@ -58,11 +72,14 @@ $(LIBDIR)/libtracer_amd_fast.so: $(HIP_OBJ_FAST)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=gfx950 -shared -o $@ $(HIP_OBJ_FAST) -ldl -lpthread -Wl,-rpath,$(ROCM)/lib
 
-# A/B variants of the device library for tools/ab_bench.py:  make -j variant NAME=unchecked DEFS=-DTRC_SPEC_UNCHECKED
-build/obj/v_$(NAME)/%.o: tracer_amd/csrc/%.hip $(HIP_HDR) Makefile
-	@mkdir -p build/obj/v_$(NAME)
+# A/B variants of the device library for tools/ab_bench.py:  make -j variant NAME=pwg12 DEFS=-DTRC_PWG_WAVES_PATH=12
+# The object directory is keyed on the definitions as well as the name: the same NAME with other DEFS compiles afresh instead of
+# relinking the objects of the earlier definitions (an A/B table must never measure a stale build).
+VDIR := build/obj/v_$(NAME)_$(shell printf '%s' '$(DEFS)' | md5sum | cut -c1-8)
+$(VDIR)/%.o: tracer_amd/csrc/%.hip $(HIP_HDR) Makefile
+	@mkdir -p $(VDIR)
 	$(HIPCC) $(HIPFLAGS) $(DEFS) -c -o $@ $<
-variant: $(patsubst tracer_amd/csrc/%.hip,build/obj/v_$(NAME)/%.o,$(HIP_SRC))
+variant: $(patsubst tracer_amd/csrc/%.hip,$(VDIR)/%.o,$(HIP_SRC))
 	$(HIPCC) --offload-arch=gfx950 -shared -o build/lib$(NAME).so $^ -ldl -lpthread -Wl,-rpath,$(ROCM)/lib
 
 # C++ host driving the path through the C ABI only (no Python): examples/trc_render

@@ -9,7 +9,7 @@ work), render all 64 samples of this rank's pixel tiles, and -- for N > 1 -- com
 RCCL reduce of the accumulation buffer to rank 0.  Inputs are resident in HBM before the timed region.
 `rays` = Scene::hit invocations, counted exactly by the kernel.
 
-  python bench.py [--gpus N --steps K --warmup W] [--scaling strong|weak]
+  python bench.py [--gpus N --steps K --warmup W] [--scaling strong|weak|samples]
 
 N > 1 is launched either by the driver (python -m torch.distributed.run ... bench.py --gpus N: RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_* in the environment) or by bench.py itself: with WORLD_SIZE unset, `--gpus N` spawns N fresh
@@ -17,14 +17,20 @@ child processes of this script (before anything touches the GPU) and relays rank
 find each other, synchronise and reduce their timings over plain TCP sockets (tracer_amd/socket_group.py): bench.py
 imports no PyTorch at any N -- the frame is composed by the library's own RCCL reduce.
 
-Two multi-GPU workloads, BOTH measured in every N > 1 run (the primary one fills the top-level fields, the other
-one is reported under "other_scaling"):
+Three multi-GPU workloads, ALL measured in every N > 1 run (the primary one fills the top-level fields, the others
+are reported under "other_scaling"):
   strong (default; the metric as BASELINE.json names it): the ONE 1920x1080x64spp frame, its 16x16 pixel tiles owned
       round-robin (tx + ty) % N, every rank renders all 64 samples of its tiles, one ncclReduce(sum) composes the
       frame on rank 0.  A pixel's 64 samples are a sequential RNG chain (Render.metal:545-557), so the GPU drains on
       its slowest 8x8 blocks however few blocks it owns: expect well below linear.
   weak: N such views stacked into one 1920 x (1080 N) frame (trc_params.view_height), same ownership rule, i.e. one
       view's worth of tiles per GPU -- the N = 1 work per GPU; metric string says so.
+  samples: the split that shortens the chains (include/tracer_abi.h, "sample sharding"): every GPU renders the WHOLE
+      1920x1080 frame with 64 / N samples per pixel from its own seed trc_shard_seed(seed, rank); the frame is the
+      rank-ordered sum of the N accumulators / N (all-to-all of pixel slices + ordered fold + gather to rank 0:
+      trc_group_compose_samples_async) -- 64 samples per pixel like the named frame, but another sample set than one
+      GPU's (bit-defined: oracle/pyoracle.py::render_sample_sharded).  --sample-groups S < N makes it S seeds x N / S
+      tile ranks.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the roofline definitions).
 """
@@ -247,6 +253,23 @@ def visible_gpus():
     return n
 
 
+def pick_device(local_rank, n_visible):
+    """HIP device index of a rank: its own GPU when the rank sees all of the node's, index 0 when the launcher isolated it
+    with a HIP_VISIBLE_DEVICES of one id, round-robin when there are more ranks than GPUs"""
+    return local_rank % max(1, n_visible)
+
+
+def compose_transport(bus_ids):
+    """How the ranks compose, decided from what they actually HOLD: every rank publishes the PCI bus id of the device its
+    context sits on (trc_device_pci_bus_id).  All different -> each rank has a GPU of its own: RCCL over xGMI.  Any two equal
+    -> ranks share a device, where RCCL refuses the second rank: the host-staged collectives table.  (Counting
+    HIP_VISIBLE_DEVICES entries cannot tell: a launcher that hands every rank ONE id makes each rank see one device.)"""
+    ids = [str(b).strip().lower() for b in bus_ids]
+    if not ids or any(not b for b in ids):
+        return "table"
+    return "rccl" if len(set(ids)) == len(ids) else "table"
+
+
 def launch_ranks(n, argv, timeout_s=1800.0):
     """`python bench.py --gpus N` without a launcher: N fresh children of this script, one per rank, started before
     this process has touched the GPU (never an exec from a process that has).  Rank 0's stdout is relayed.  A rank that
@@ -295,8 +318,12 @@ def main(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
-                    help="which N > 1 workload fills the top-level fields (the other one goes to other_scaling)")
+    ap.add_argument("--scaling", choices=("strong", "weak", "samples"), default="strong",
+                    help="which N > 1 workload fills the top-level fields (the others go to other_scaling)")
+    ap.add_argument("--sample-groups", type=int, default=0,
+                    help="--scaling samples: number of seeds S the 64 samples are split over (default N); N / S tile ranks share each seed's frame")
+    ap.add_argument("--rccl-timeout", type=float, default=300.0,
+                    help="seconds a rank waits inside the RCCL bring-up before it exits non-zero (a peer that died would leave it there for ever)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-scaling", action="store_true", help="N > 1: measure only the primary workload")
     ap.add_argument("--no-fast-math", action="store_true",
@@ -351,18 +378,27 @@ def main(argv=None):
     from tracer_amd import abi, host
     from tracer_amd.device import Tracer, group_unique_id
 
-    # ranks > GPUs (plumbing run on a 1-GPU box): the ranks share the GPUs, and since RCCL refuses two ranks on one
-    # device the compose goes through the collectives table of trc_group_set_collectives (host-staged, sockets) -- the same
-    # reduce program, the same pipelined two-accumulator compose, every other part of the N-rank path as usual.  The line
-    # says "plumbing": ranks time-slicing one GPU measure nothing.
+    # Which transport composes: decided from the devices the ranks actually hold (compose_transport), not from counting
+    # environment entries.  Ranks sharing a GPU (plumbing run on a 1-GPU box): RCCL refuses two ranks on one device, the compose
+    # goes through the collectives table of trc_group_set_collectives (host-staged, sockets) -- the same collective program, the
+    # same pipelined two-accumulator compose, every other part of the N-rank path as usual.  The line says "plumbing": ranks
+    # time-slicing one GPU measure nothing.
     n_dev = visible_gpus() or 1
-    # TRC_BENCH_FORCE_RCCL=1: try RCCL even with more ranks than GPUs (it refuses: the test of the fallback below)
-    no_rccl = os.environ.get("TRC_BENCH_NO_RCCL") == "1" or (world > n_dev and os.environ.get("TRC_BENCH_FORCE_RCCL") != "1")
-    plumbing = grouped and no_rccl
-    device = local_rank % n_dev
+    device = pick_device(local_rank, n_dev)
     scene = host.HostScene(abi.SCENE_CORNELL_SPHERES)
     cam = host.prepare_camera(W, H)
     trc = Tracer(device)
+    bus_id = trc.pci_bus_id()
+    devices = gather_list(bus_id)
+    transport = compose_transport(devices) if grouped else "none"
+    # TRC_BENCH_NO_RCCL=1: the table even on distinct devices; TRC_BENCH_FORCE_RCCL=1: try RCCL even on a shared device (it
+    # refuses: the test of the fallback below)
+    if os.environ.get("TRC_BENCH_NO_RCCL") == "1":
+        transport = "table"
+    elif os.environ.get("TRC_BENCH_FORCE_RCCL") == "1" and grouped:
+        transport = "rccl"
+    no_rccl = transport != "rccl"
+    plumbing = grouped and no_rccl
     trc.upload_scene(scene.view)
     trc.set_camera(cam)
     trc.set_environment((0.0, 0.0, 0.0))
@@ -370,14 +406,29 @@ def main(argv=None):
     compose_fallback = None
     if use_rccl:
         # RCCL over xGMI is the compose path.  It has never run with N > 1 on hardware (one GPU per box in the build pool), so a
-        # rank that cannot bring its communicator up does not end the run: every rank hears of it and all of them compose through
-        # the host-staged socket table instead (the line says so in "compose_fallback"; slower, still the named frame).
+        # run whose communicators do not come up is not lost: every rank hears of it and all of them compose through the
+        # host-staged socket table instead (the line says so in "compose_fallback"; slower, still the named frame).
+        # Order matters: ncclCommInitRank and the first collective BLOCK until every rank has entered them, so (1) the ranks
+        # agree over the socket group that each of them can load librccl BEFORE any of them enters RCCL, and (2) the bring-up
+        # runs under a watchdog that makes a rank EXIT non-zero when it is still inside after --rccl-timeout seconds -- a peer
+        # that died in there (device fault, ...) would otherwise leave the others blocked until the launcher's own timeout.
+        import threading
         uid, err = None, ""
-        if rank == 0:
-            try:
+        try:
+            import ctypes
+            for name in ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"):
+                try:
+                    ctypes.CDLL(name)
+                    break
+                except OSError:
+                    continue
+            else:
+                raise OSError("librccl not loadable")
+            if rank == 0:
                 uid = group_unique_id()
-            except Exception as e:                      # librccl not loadable, ...
-                err = f"trc_group_unique_id: {e}"
+        except Exception as e:
+            err = f"rank {rank}: {e}"
+        ready = group.allreduce_scalar(0 if err else 1, "MIN") >= 1
         uid = group.broadcast(uid)
         trc.resize(W, H)
 
@@ -387,13 +438,23 @@ def main(argv=None):
             trc.group_reduce_accum(0)        # first collective: RCCL finishes its lazy set-up here
             trc.synchronize()
         ok = 0
-        if uid is not None:
+        if ready and uid is not None:
+            def give_up():
+                sys.stderr.write(f"bench.py: rank {rank} still inside the RCCL bring-up after {args.rccl_timeout:.0f} s "
+                                 f"(a peer failed in there?): exiting so that the launcher ends the job\n")
+                sys.stderr.flush()
+                os._exit(86)
+            dog = threading.Timer(args.rccl_timeout, give_up)
+            dog.daemon = True
+            dog.start()
             try:
                 # RCCL prints a version banner through C stdio on fd 1; keep stdout clean for the single JSON line
                 _with_c_stdout_on_stderr(init_comm)
                 ok = 1
             except Exception as e:
                 err = f"rank {rank}: {e}"
+            finally:
+                dog.cancel()
         if group.allreduce_scalar(ok, "MIN") < 1:
             errs = [e for e in group.gather(err) if e]
             compose_fallback = "RCCL communicator not available (" + "; ".join(errs[:2]) + "): composed through trc_group_set_collectives, host-staged over TCP sockets"
@@ -416,17 +477,28 @@ def main(argv=None):
     def measure(mode, steps, warmup):
         """K timed steps of one workload; returns the rank-0 view of it (dict) -- every rank must call it."""
         stacked = mode == "weak" and world > 1
+        sharded = mode == "samples" and world > 1
         FH = H * world if stacked else H
         trc.resize(W, FH)
+        # samples: S seeds x T tile ranks; rank r is tile rank r % T of sample group r // T (tracer_abi.h)
+        S = (args.sample_groups or world) if sharded else 1
+        if sharded and (world % S or SPP % S):
+            raise SystemExit(f"--sample-groups {S}: must divide both the {world} ranks and the {SPP} samples")
+        T = world // S if sharded else world
+        group_of, tile_rank = (rank // T, rank % T) if sharded else (0, rank)
+        spp_rank = SPP // S
 
         def step(seed=SEED, collect_stats=False):
             if grouped:
                 trc.clear_accum()            # non-owned tiles must be zero for the sum-compose
-            trc.seed(seed)
-            trc.render(spp=SPP, max_depth=DEPTH, integrator=abi.INTEGRATOR_PATH, frame0=0, tile_rank=rank,
-                       tile_nranks=world, collect_stats=collect_stats, view_height=H)
-            if composing:
-                trc.group_reduce_accum_async(0)   # overlaps with the next step's render (second accumulator + stream)
+            trc.seed(abi.shard_seed(seed, group_of))
+            trc.render(spp=spp_rank, max_depth=DEPTH, integrator=abi.INTEGRATOR_PATH, frame0=0, tile_rank=tile_rank,
+                       tile_nranks=T, collect_stats=collect_stats, view_height=H)
+            if composing:                    # overlaps with the next step's render (second accumulator + stream)
+                if sharded:
+                    trc.group_compose_samples_async(0, S)
+                else:
+                    trc.group_reduce_accum_async(0)
 
         # COLD: the first production launch of this block list on this context -- no durations of a previous launch to order
         # or split by.  trc_render runs it as an 8-sample head + the rest planned from the head (DESIGN 4.1); the same
@@ -460,7 +532,7 @@ def main(argv=None):
         step(collect_stats=True)
         trc.synchronize()
         st1 = trc.stats()
-        own_pixels = st1.paths // SPP
+        own_pixels = st1.paths // spp_rank
         bytes_per_launch = algorithmic_bytes(st1, own_pixels)
         rays_per_launch = st1.rays
 
@@ -504,7 +576,10 @@ def main(argv=None):
             barrier()
             t2 = time.perf_counter()
             for _ in range(steps):
-                trc.group_reduce_accum(0)
+                if sharded:
+                    trc.group_compose_samples(0, S)
+                else:
+                    trc.group_reduce_accum(0)
             barrier()
             compose_ms = (time.perf_counter() - t2) / steps * 1e3
 
@@ -514,7 +589,8 @@ def main(argv=None):
         rays_vary_total = reduce_scalar(float(st_vary.rays), "SUM")
         per_rank = gather_list({"rank": rank, "kernel_ms": round(kernel_ms, 3), "kernel_ms_vary_seed": round(kernel_ms_vary, 3),
                                 "compose_ms": None if compose_ms is None else round(compose_ms, 3), "schedule_ms": round(schedule_ms, 4),
-                                "rays_per_step": int(st.rays // steps), "device": device,
+                                "rays_per_step": int(st.rays // steps), "device": device, "pci_bus_id": bus_id,
+                                "sample_group": group_of, "tile_rank": tile_rank, "spp": spp_rank,
                                 # a pixel's samples are one chain: the launch cannot end before its slowest wavefront-sized item
                                 # (block or part), nor before the items' summed durations over the GPU's wavefront slots
                                 "longest_chain_ms": round(shape["longest_entry_ms"], 3),
@@ -523,6 +599,9 @@ def main(argv=None):
         name = "Mrays/s at 1920x1080x64spp"
         if stacked:
             name = f"Mrays/s over {world} stacked 1920x1080x64spp views, one view's worth of tiles per GPU (weak scaling)"
+        if sharded:
+            name = (f"Mrays/s at 1920x1080x64spp, the 64 samples per pixel split over {S} seeds ({spp_rank} per seed"
+                    + (f", each seed's frame tiled over {T} GPUs" if T > 1 else "") + "; sample sharding)")
         return {
             "mode": mode if world > 1 else "single", "metric": name, "value": round(rays_total / dt_max / 1e6, 2),
             "ms_per_step": round(dt_max / steps * 1e3, 3), "rays_per_step": int(rays_total / steps),
@@ -532,13 +611,15 @@ def main(argv=None):
                           "ms_per_step": round(dt_vary_max / steps * 1e3, 3), "kernel_ms": round(kernel_ms_vary, 3),
                           "what": "the same K steps with a different RNG seed per step (frame k's block costs order frame k+1)"},
             "per_rank": per_rank, "kernel_ms": kernel_ms, "bytes_per_launch": bytes_per_launch, "cold": cold,
-            "rays_per_launch": rays_per_launch,
+            "rays_per_launch": rays_per_launch, "sample_groups": S, "tile_ranks": T,
         }
 
     primary = measure(args.scaling, args.steps, args.warmup)
-    other = None
+    others = {}
     if world > 1 and not args.no_other_scaling:
-        other = measure("weak" if args.scaling == "strong" else "strong", args.steps, args.warmup)
+        for m in ("strong", "weak", "samples"):
+            if m != args.scaling:
+                others[m] = measure(m, args.steps, args.warmup)
 
     if rank == 0:
         kernel_ms = primary["kernel_ms"]
@@ -547,8 +628,11 @@ def main(argv=None):
         info = trc.device_info()
         FH = primary["frame"][1]
         compose = "none"
+        sharded = primary["mode"] == "samples"
         if grouped:
-            compose = (f"ncclReduce(sum) of the {W}x{FH} RGBA32F frame to rank 0 on a second stream, overlapped with the "
+            what = (f"sample shards: all-to-all of the accumulators' {world} pixel slices (ncclSend / ncclRecv), rank-ordered fold, gather "
+                    f"to rank 0" if sharded else f"ncclReduce(sum) of the {W}x{FH} RGBA32F frame to rank 0")
+            compose = (f"{what} on a second stream, overlapped with the "
                        f"next step" if use_rccl else
                        f"reduce(sum) of the {W}x{FH} frame through trc_group_set_collectives (host-staged, TCP sockets): {compose_fallback}" if compose_fallback else
                        f"PLUMBING RUN, NOT A MEASUREMENT: {world} ranks share {n_dev} GPU(s); reduce(sum) of the {W}x{FH} frame "
@@ -562,10 +646,12 @@ def main(argv=None):
                                    "tracePath depth 8, 21 leaves / 41 BVH nodes" +
                                    ("" if world == 1 else
                                     (f"; ONE frame, its 16x16 tiles sharded over {world} GPUs" if primary["mode"] == "strong" else
+                                     f"; ONE frame, its 64 samples per pixel split over {primary['sample_groups']} seeds x {primary['tile_ranks']} tile ranks "
+                                     f"(rank-ordered mean of the shards; another sample set than one GPU's)" if sharded else
                                      f"; {world} such views stacked into one 1920x{FH} frame, one view's worth of tiles per GPU")),
                        "integrator": "tracePath", "rays_per_step": primary["rays_per_step"],
                        "paths_per_step": primary["paths_per_step"], "mpaths_per_s": primary["mpaths_per_s"],
-                       "tiles": f"16x16 px, owner (tx+ty)%{world}", "device": info["name"], "compose": compose,
+                       "tiles": f"16x16 px, owner (tx+ty)%{primary['tile_ranks'] if world > 1 else 1}", "device": info["name"], "compose": compose,
                        "settle_launches": SETTLE_LAUNCHES},
             "vary_seed": primary["vary_seed"],
             "cold": primary["cold"], "first_launch_ms": primary["cold"]["first_launch_ms"],
@@ -587,11 +673,15 @@ def main(argv=None):
             line["compose_fallback"] = compose_fallback
         elif plumbing:
             line["plumbing"] = True
+        if grouped:
+            line["devices"] = devices               # PCI bus id per rank: what decided the transport
+            line["transport"] = "rccl" if use_rccl else "table"
         if world > 1:
             line["per_rank"] = primary["per_rank"]
-            if other is not None:
-                line["other_scaling"] = {k: other[k] for k in ("mode", "metric", "value", "ms_per_step", "rays_per_step",
-                                                              "frame", "vary_seed", "cold", "per_rank")}
+            if others:
+                line["other_scaling"] = {m: {k: o[k] for k in ("mode", "metric", "value", "ms_per_step", "rays_per_step", "frame",
+                                                               "vary_seed", "cold", "per_rank", "sample_groups", "tile_ranks")}
+                                         for m, o in others.items()}
         if world == 1 and not args.no_fast_math:
             line["fast_math_variant"] = fast_math_leg(scene, cam, args.steps)
         if not args.no_cpu_baseline and world == 1:      # CPU baselines: rank 0 at N = 1 only

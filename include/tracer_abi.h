@@ -35,8 +35,11 @@ extern "C" {
  * 3: trc_group_set_collectives, trc_debug_set, trc_debug_block_costs; trc_pbrt_info / trc_pbrt_shape grew (textures,
  *    plymesh / disk / cylinder); trc_host_mesh_load_ply, trc_host_load_hdr, trc_div_by_test
  * 4: trc_debug_launch_shape, trc_unary_test; grouped trc_sppm_download of the photon records is collective; trc_stats.schedule_ms; knob no_plan_reuse; trc_debug_block_costs reports durations per SAMPLE (shader clocks / (4 spp)); knobs
- *    no_cold_probe / probe_spp (the first launch of a block list runs as an 8-sample head + the rest, trc_render) */
-#define TRC_ABI_VERSION 4
+ *    no_cold_probe / probe_spp (the first launch of a block list runs as an 8-sample head + the rest, trc_render)
+ * 5: sample sharding with a bit-level definition: trc_shard_seed, trc_group_compose_samples[_async]; trc_collectives grew
+ *    (alltoall, gather); trc_group_allreduce_mean_accum is that compose delivered to every rank (rank-ordered sum, no longer an
+ *    all-reduce); trc_device_pci_bus_id; the test hooks moved to include/tracer_test_hooks.h and libtracer_amd_hooks.so */
+#define TRC_ABI_VERSION 5
 
 /* ------------------------------------------------------------------ */
 /* vector / matrix PODs (Apple simd layout)                            */
@@ -348,6 +351,10 @@ uint32_t    trc_abi_version(void);
  * (MTL_FAST_MATH): approximate division / sqrt, FMA contraction, denormals flushed; results agree with the exact build
  * statistically, not bit for bit */
 const char* trc_build_flavor(void);
+/* 1 in libtracer_amd_hooks.so -- the same sources compiled with -DTRC_TEST_HOOKS, which additionally exports the
+ * entry points of include/tracer_test_hooks.h (exhaustive arithmetic checks, the SPPM hash, the per-site cycle profile) for
+ * tests/ and tools/; 0 in the product libraries, which do not carry them */
+int         trc_has_test_hooks(void);
 const char* trc_status_string(trc_status s);
 /* last error text of this context (HIP error string etc.), never NULL */
 const char* trc_last_error(const trc_ctx* ctx);
@@ -455,12 +462,6 @@ trc_status trc_trace_rays(trc_ctx* ctx, const trc_ray* rays, size_t n, trc_hit* 
 
 trc_status trc_get_stats(trc_ctx* ctx, trc_stats* out);   /* synchronises the stream */
 trc_status trc_reset_stats(trc_ctx* ctx);
-/* developer diagnostic (divergence / cycle profile of the instrumented kernels), per site i since the
- * last trc_reset_stats: out[3*i] = lanes, out[3*i+1] = wavefronts that executed the site, out[3*i+2] =
- * shader-clock cycles those wavefronts spent inside it; sites: 0 loop iteration, 1 box step, 2 square,
- * 3 sphere, 4 cube, 5 triangle, 6 shade, 7 cosine lobe, 8 Metal, 9 Beckmann sampling,
- * 10 Beckmann lobe evaluation (Plastic specular + Glass), 11 path end */
-trc_status trc_debug_profile(trc_ctx* ctx, uint64_t* out, uint32_t n_sites);
 /* developer diagnostic: the pixel blocks of the last trc_render (x | y << 16, in units of the block edge 1 << *blk_shift)
  * and the duration each one's wavefront measured per sample (shader clocks / (4 spp) -- the sort key of the adaptive launch order); with
  * strips (spp < 8) the costs are per strip; a block that ran in parts (four 4x4 quarters, some of them as four 2x2
@@ -483,6 +484,10 @@ trc_status trc_debug_launch_shape(trc_ctx* ctx, trc_launch_shape* out);
 
 /* device info for the bench line */
 trc_status trc_device_info(trc_ctx* ctx, char* name, size_t name_len, int* cu_count, size_t* hbm_bytes);
+/* which physical GPU this context sits on: "domain:bus:device.function" (hipDeviceGetPCIBusId).  Ranks exchange it to learn
+ * whether they hold DIFFERENT devices (then RCCL composes) or share one (RCCL refuses a second rank on a device: the
+ * collectives table composes) -- counting HIP_VISIBLE_DEVICES entries cannot tell, a launcher may give every rank its own */
+trc_status trc_device_pci_bus_id(trc_ctx* ctx, char* out, size_t out_len);
 
 /* --- SPPM pass (RT_Metal/Metal/Photon.metal, host sequencing AAPLRenderer.mm:860-1086) ------------
  * Uses the scene / camera / frame (canvas RNG + accumulator) of the context. */
@@ -502,21 +507,6 @@ trc_status trc_sppm_download(trc_ctx* ctx, trc_CameraRecord* camera_records /* W
                              trc_PhotonRecord* photon_records /* 512*512 */, float* mark /* 512*512*4 */,
                              float* count /* 512*512 */, trc_Complex* complex);
 
-/* test hook like trc_trace_rays: `hash()` of Photon.hh:71-89 for n cell indices (3 floats each) at one hash scale, as
- * the hashing and refine passes evaluate it (the index into the 512 x 512 grid, before the -1 shift) */
-trc_status trc_sppm_hash_cells(trc_ctx* ctx, const float* cells /* n*3 */, size_t n, float hash_scale, float* out /* n */);
-
-/* test hook: the guarded shared-divisor division of tracer_amd/csrc/dev_vec.hpp (one refined reciprocal per divisor, the
- * compiler's own two fused corrections per quotient, plain `/` outside [2^-60, 2^60]) against the plain division, for n
- * operand pairs: fast / plain receive 3 quotients per pair (a / b, -a / b, (0.75 a) / b).  They must agree bit for bit. */
-trc_status trc_div_by_test(trc_ctx* ctx, const float* a, const float* b, size_t n, float* fast /* 3 n */, float* plain /* 3 n */);
-/* test hook: the render kernels' guard-free reciprocal / square root / reciprocal square root (dev_vec.hpp: rcp_cr, sqrt_cr, rsqrt_cr;
- * op 0 / 1 / 2) against the compiler's correctly rounded 1.0f / x, sqrtf(x), 1.0f / sqrtf(x) on the `count` operands whose bit patterns
- * start at `first_bits` (count = 2^32 covers every float): the number of operands whose results differ, and the smallest one.
- * op 3 .. 6: x / c for the divisors known when the kernels are written (pi, 0.01^2, 0.02^2, 0.1^2), computed as the product with
- * RN(1 / c) and one residual correction, against the compiler's x / c */
-trc_status trc_unary_test(trc_ctx* ctx, uint32_t op, uint32_t first_bits, uint64_t count, uint64_t* n_mismatch, uint32_t* first_mismatch);
-
 /* --- multi-GPU: pixel tiles sharded over ranks, one RCCL reduce -------- */
 #define TRC_UNIQUE_ID_BYTES 128
 /* rank 0 creates the id, every rank gets the same bytes out-of-band */
@@ -525,10 +515,31 @@ trc_status trc_group_init(trc_ctx* ctx, const uint8_t id[TRC_UNIQUE_ID_BYTES], i
 /* ncclReduce(sum) of the full-frame accum buffer to `root` on the ctx stream:
  * every rank holds zeros outside its own tiles, so sum == gather */
 trc_status trc_group_reduce_accum(trc_ctx* ctx, int root);
-/* sample sharding instead of tile sharding (every rank rendered the WHOLE frame from frame0 = 0 with its own seed and
- * the same spp): ncclAllReduce(sum) of the accumulators, then / nranks -- every rank ends up with the mean of the
- * ranks' running means, i.e. nranks * spp samples per pixel.  Unlike tile sharding the result is not the 1-GPU
- * frame (other sample set) and, floating-point sums being order-dependent in a ring, not bit-reproducible. */
+/* --- sample sharding: the split that scales (SURVEY 8e "alternative") -------------------------------------------
+ * A pixel's samples are ONE chain through its RNG texel (Render.metal:511-519,545-557), so a rank that owns a share of
+ * the TILES still runs every owned pixel's whole chain: its launch ends on its slowest 8x8 block however few blocks it
+ * owns.  Splitting the SAMPLES shortens the chains instead.  Definition (bit-level; oracle/pyoracle.py::render_sample_sharded
+ * restates it and the GPU tests hold the composed frame to it bit for bit):
+ *   - the nranks ranks are S sample groups x T tile ranks, nranks == S * T; rank r is tile rank r % T of group g = r / T;
+ *   - group g renders the WHOLE frame (its T ranks share the tiles as usual: trc_params.tile_rank = r % T, tile_nranks = T,
+ *     zeros elsewhere) with spp / S samples per pixel, frame0 counting from 0 within the group, from the RNG texture
+ *     trc_seed(trc_shard_seed(seed, g)) -- group 0 keeps the seed, so S == 1 is the unsharded frame;
+ *   - composed pixel = (((A_0 + A_1) + A_2) + ... + A_{nranks-1}) / (float)S per channel in binary32, A_r = rank r's
+ *     accumulator texel: a rank-ORDERED sum (zeros of the other tile ranks are exact identities), one IEEE division.
+ * Every group must have rendered the same number of samples (the mean of running means is the running mean only then).
+ * How it moves: each rank owns the r-th of nranks equal pixel slices; an all-to-all brings that slice of every rank's
+ * accumulator (ncclSend / ncclRecv in one group call; at N = 8 and 1080p 29 MB in and out per rank, every pair on its own
+ * xGMI link), a small kernel folds them in rank order, and a gather (root >= 0) brings the N slices (4 MB each) to the
+ * root.  The ranks' accumulators are left untouched -- a progressive host goes on rendering and composes again. */
+uint64_t   trc_shard_seed(uint64_t seed, uint32_t sample_group);   /* seed + sample_group * 0x9E3779B97F4A7C15 (mod 2^64) */
+/* on the context stream; the composed frame is read with trc_download_composed (root only).  sample_groups == 0: nranks
+ * (every rank its own group, no tile split) */
+trc_status trc_group_compose_samples(trc_ctx* ctx, int root, uint32_t sample_groups);
+/* pipelined like trc_group_reduce_accum_async: the exchange runs on the communication stream once the work queued so far
+ * has finished, the context switches to its other accumulator, the next trc_clear_accum / trc_seed / trc_render overlap */
+trc_status trc_group_compose_samples_async(trc_ctx* ctx, int root, uint32_t sample_groups);
+/* the same compose with sample_groups = nranks, delivered into EVERY rank's accumulator (all-gather instead of the gather).
+ * Until ABI 4 this was ncclAllReduce(sum) / nranks, whose sum order is the ring's; it is the rank-ordered sum now. */
 trc_status trc_group_allreduce_mean_accum(trc_ctx* ctx);
 /* same compose, pipelined: the reduce runs on a second stream as soon as the work queued so far has finished,
  * and the context switches to its OTHER accumulator (allocated on first use, zero-filled), so the next
@@ -543,7 +554,8 @@ trc_status trc_group_finalize(trc_ctx* ctx);
  * ranks on ONE GPU (where RCCL refuses a second rank on a device) installs its own with trc_group_set_collectives and
  * needs no communicator.  The program of collectives is the same either way:
  *   compose          reduce(sum, f32, 4*W*H) of the accumulator to the root           (trc_group_reduce_accum[_async])
- *   sample sharding  allreduce(sum, f32, 4*W*H)                                        (trc_group_allreduce_mean_accum)
+ *   sample sharding  alltoall of the accumulator's nranks pixel slices, then gather of the composed slices to the root
+ *                    (or allgather to every rank)            (trc_group_compose_samples[_async], trc_group_allreduce_mean_accum)
  *   SPPM frame 0     allreduce(min, u32, 3) + allreduce(max, u32, 3) of the bound keys (Photon.metal:169-218's reduction)
  *   SPPM every frame allgather of the photon records, 512*512/N * 80 bytes per rank    (so that kernelPhotonSumming,
  *                    Photon.metal:458-496, sees every photon on every rank)
@@ -555,7 +567,10 @@ trc_status trc_group_finalize(trc_ctx* ctx);
  *                    with that host pointer (stream = NULL; it may block), and copies the result back -- slow,
  *                    meant for tests, 1-GPU plumbing runs and hosts without a GPU-aware transport.
  * reduce: the result is defined on `root` only.  allgather: rank r's contribution sits at buf + r * bytes_per_rank on
- * entry, all of them on return.  dtype / op use ncclDataType_t / ncclRedOp_t ordinals. */
+ * entry, all of them on return.  alltoall: `buf` holds nranks slices of bytes_per_rank; on return slice p holds what rank
+ * p had in ITS slice r (r = the caller's rank; slice r stays).  gather: like allgather, the result is defined on `root`
+ * only.  alltoall / gather may be NULL in a table whose host never composes sample shards (TRC_ERR_UNSUPPORTED then).
+ * dtype / op use ncclDataType_t / ncclRedOp_t ordinals. */
 enum trc_coll_dtype { TRC_DT_U8 = 1, TRC_DT_U32 = 3, TRC_DT_F32 = 7 };
 enum trc_coll_op { TRC_OP_SUM = 0, TRC_OP_MAX = 2, TRC_OP_MIN = 3 };
 typedef struct trc_collectives {
@@ -565,6 +580,8 @@ typedef struct trc_collectives {
     int (*reduce)(void* user, void* buf, size_t count, int dtype, int op, int root, void* stream);
     int (*allreduce)(void* user, void* buf, size_t count, int dtype, int op, void* stream);
     int (*allgather)(void* user, void* buf, size_t bytes_per_rank, void* stream);
+    int (*alltoall)(void* user, void* buf, size_t bytes_per_rank, void* stream);
+    int (*gather)(void* user, void* buf, size_t bytes_per_rank, int root, void* stream);
 } trc_collectives;
 /* installs `table` (copied) and makes the context rank `rank` of `nranks`; replaces a communicator made by
  * trc_group_init.  trc_group_finalize removes it.  table == NULL: same as trc_group_finalize. */

@@ -150,6 +150,28 @@ def render(scene_view, camera, width, height, rng, accum=None, spp=1, max_depth=
     return accum, stats
 
 
+def shard_seed(seed, sample_group):
+    """Seed of sample group g of a sample-sharded frame (include/tracer_abi.h, "sample sharding"): the golden-ratio
+    stride 0x9E3779B97F4A7C15 times g is added modulo 2^64, so group 0 renders the unsharded frame's first samples."""
+    return (seed + sample_group * 0x9E3779B97F4A7C15) % (1 << 64)
+
+
+def render_sample_sharded(scene_view, camera, width, height, rngs, spp, **kw):
+    """The sample-sharded frame as include/tracer_abi.h defines it, on the CPU: group g renders the whole frame with
+    spp / S samples (frame0 = 0) from ITS RNG texture rngs[g] (= fillRNG of shard_seed(seed, g), S = len(rngs)); the
+    composed texel is (((A_0 + A_1) + A_2) + ...) / float32(S) in binary32, channel by channel.  kw: render()'s
+    (integrator, max_depth, env, tile_rank / tile_nranks to restrict the pixels, n_threads ...).
+    Returns (composed, [stats per group])."""
+    S = len(rngs)
+    assert S >= 1 and spp % S == 0, "every group renders the same number of samples"
+    total, stats = None, []
+    for g in range(S):
+        a, st = render(scene_view, camera, width, height, rngs[g], spp=spp // S, frame0=0, **kw)
+        stats.append(st)
+        total = a if total is None else np.add(total, a, dtype=np.float32)
+    return np.divide(total, np.float32(S), dtype=np.float32), stats
+
+
 def tonemap(accum):
     """fragmentShader's exposure + ACES on an (H, W, 4) float32 accumulator -> ((H, W, 4) uint8 top-down, exposure)."""
     assert accum.dtype == np.float32 and accum.ndim == 3 and accum.shape[2] == 4 and accum.flags.c_contiguous

@@ -2,7 +2,8 @@
 supplied through trc_group_set_collectives (host-staged, gloo between the processes) instead of RCCL, which refuses two
 ranks on one device.  Started by tests/test_gpu_shared_gpu_ranks.py; not a test module itself.
 
-env: RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT, TRC_ROOT, TRC_OUT (directory), TRC_CASE = small | config4 | config5
+env: RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT, TRC_ROOT, TRC_OUT (directory),
+     TRC_CASE = small | config4 | config5 | samples2 | samples4 (sample sharding at 1080p on BASELINE configs 2 / 4)
 """
 import hashlib
 import os
@@ -48,9 +49,24 @@ def main():
             t.group_reduce_accum_async(0)
             if rank == 0:
                 out[f"async{step}"] = t.download_composed()
-        # sample sharding: every rank the whole frame with its own seed, allreduce + 1/N
-        t.synchronize(); t.clear_accum(); t.seed(100 + rank); t.render(spp=spp); t.group_allreduce_mean_accum()
+        # sample sharding (tracer_abi.h): every rank the whole frame with 16 / N samples from ITS seed; all-to-all of the
+        # pixel slices, rank-ordered fold, gather to the root -- then the same compose delivered to every rank
+        t.synchronize(); t.clear_accum(); t.seed(abi.shard_seed(100, rank)); t.render(spp=16 // world)
+        mine = t.download_accum()
+        t.group_compose_samples(0)
+        if rank == 0:
+            out["samples"] = t.download_composed()
+        out["untouched"] = np.array(np.array_equal(mine.view(np.uint32), t.download_accum().view(np.uint32)))   # a progressive host renders on
+        t.group_allreduce_mean_accum()
         out["mean"] = t.download_accum()
+        # seeds x tiles: S = N / 2 seeds, each seed's frame tiled over 2 ranks; pipelined, two steps in flight
+        if world >= 4:
+            S, T = world // 2, 2
+            for step in range(2):
+                t.clear_accum(); t.seed(abi.shard_seed(200 + step, rank // T)); t.render(spp=16 // S, tile_rank=rank % T, tile_nranks=T)
+                t.group_compose_samples_async(0, S)
+                if rank == 0:
+                    out[f"hybrid{step}"] = t.download_composed()
         # SPPM: bound keys all-reduced, photon records all-gathered, frame composed
         t.synchronize(); t.clear_accum(); t.seed(8); t.sppm_init(9); t.sppm_frames(3)
         cam, pho, mark, count, cx = t.sppm_download()
@@ -62,7 +78,26 @@ def main():
                                                                               cx.photonBox.maxi.x, cx.photonBox.maxi.y, cx.photonBox.maxi.z], np.float32)
         if rank == 0:
             out["sppm"] = t.download_accum()
-        out["calls"] = np.array([coll.calls["reduce"], coll.calls["allreduce"], coll.calls["allgather"]])
+        out["calls"] = np.array([coll.calls[k] for k in ("reduce", "allreduce", "allgather", "alltoall", "gather")])
+    elif case in ("samples2", "samples4"):
+        # the split that scales, at the named size: every rank the WHOLE 1920x1080 frame, 64 / N samples from seed
+        # trc_shard_seed(seed, rank), composed by trc_group_compose_samples_async (the bench's --scaling samples step)
+        W, H, total = 1920, 1080, 64
+        if case == "samples2":
+            scene, seed = host.HostScene(abi.SCENE_CORNELL_SPHERES), 0x5EED0000
+        else:
+            scene, seed = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.golden("teapot").replicate(8, 80.0)), 0x5EED0004
+        t.upload_scene(scene.view); t.set_camera(host.prepare_camera(W, H)); t.set_environment((0.0, 0.0, 0.0)); t.resize(W, H)
+        t.set_collectives(coll, world, rank)
+        for launch in range(2):                              # the second launch runs in adaptive order, on the other accumulator
+            t.reset_stats()
+            t.clear_accum(); t.seed(abi.shard_seed(seed, rank)); t.render(spp=total // world)
+            t.group_compose_samples_async(0, world)
+        st = t.stats()
+        out["rays"] = np.uint64(st.rays); out["paths"] = np.uint64(st.paths)
+        if rank == 0:
+            out["frame"] = t.download_composed()
+        out["calls"] = np.array([coll.calls[k] for k in ("reduce", "allreduce", "allgather", "alltoall", "gather")])
     elif case == "config4":
         # BASELINE config 4 as an N-rank tile split at the named size: Cornell + teapot.obj x 64 (1 005 056 triangles), tracePath
         W, H, spp = 1920, 1080, 2
@@ -98,7 +133,7 @@ def main():
         out["rng_own_sha"] = np.array(sha(rng[own]))
         if rank == 0:
             out["frame"] = t.download_accum()
-        out["calls"] = np.array([coll.calls["reduce"], coll.calls["allreduce"], coll.calls["allgather"]])
+        out["calls"] = np.array([coll.calls[k] for k in ("reduce", "allreduce", "allgather", "alltoall", "gather")])
     else:
         raise SystemExit(f"unknown case {case}")
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)

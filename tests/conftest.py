@@ -23,6 +23,7 @@ def _ensure_built():
     need = [os.path.join(ROOT, "tracer_amd", "lib", "libtrc_host.so"),
             os.path.join(ROOT, "tracer_amd", "lib", "libtracer_amd.so"),
             os.path.join(ROOT, "tracer_amd", "lib", "libtracer_amd_fast.so"),
+            os.path.join(ROOT, "tracer_amd", "lib", "libtracer_amd_hooks.so"),
             os.path.join(ROOT, "oracle", "liboracle.so"),
             os.path.join(ROOT, "oracle", "liboracle_libm.so")]
     if not all(os.path.exists(p) for p in need):
@@ -78,6 +79,15 @@ def gpu():
     """A Tracer on cuda:0; fails (not skips) when the HIP path is unusable on a GPU run."""
     from tracer_amd import device
     t = device.Tracer(0)
+    yield t
+    t.close()
+
+
+@pytest.fixture(scope="session")
+def gpu_hooks():
+    """A Tracer on libtracer_amd_hooks.so: the product's sources + the entry points of include/tracer_test_hooks.h"""
+    from tracer_amd import device
+    t = device.Tracer(0, hooks=True)
     yield t
     t.close()
 

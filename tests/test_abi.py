@@ -9,19 +9,20 @@ from conftest import ROOT
 from tracer_amd import abi, device, host
 
 HEADER = os.path.join(ROOT, "include", "tracer_abi.h")
+HOOKS_HEADER = os.path.join(ROOT, "include", "tracer_test_hooks.h")
 
 
 def test_header_compiles_as_c_and_cxx(tmp_path):
     # the static asserts inside the header lock SURVEY.md Appendix A's sizes/offsets
     for cc, std, name in (("gcc", "-std=c11", "t.c"), ("g++", "-std=c++17", "t.cpp")):
         src = tmp_path / name
-        src.write_text('#include "tracer_abi.h"\nint main(void){return (int)sizeof(trc_scene) * 0;}\n')
+        src.write_text('#include "tracer_abi.h"\n#include "tracer_test_hooks.h"\nint main(void){return (int)sizeof(trc_scene) * 0;}\n')
         subprocess.check_call([cc, std, "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
                                str(src)])
 
 
-def _declared(prefix_re):
-    text = open(HEADER).read()
+def _declared(prefix_re, header=HEADER):
+    text = open(header).read()
     return sorted(set(re.findall(r"\b(" + prefix_re + r"\w+)\s*\(", text)))
 
 
@@ -43,6 +44,23 @@ def test_device_library_exports_every_declared_symbol():
     fast = _exported(device.fast_lib_path())
     assert not [s for s in declared if s not in fast]
     assert device.lib(fast_math=True).trc_build_flavor() == b"fast-math"
+
+
+def test_test_hooks_are_exported_by_the_hooks_build_only():
+    """Product and laboratory apart: the entry points of include/tracer_test_hooks.h -- exhaustive arithmetic
+    checks, the SPPM hash, the per-site cycle profile -- exist in libtracer_amd_hooks.so (the same sources + -DTRC_TEST_HOOKS)
+    and in NEITHER product library; the hooks build still exports the whole product ABI, so the tests that need a hook run the
+    product's own kernels."""
+    hooks = _declared(r"trc_", HOOKS_HEADER)
+    assert set(hooks) == set(abi.HOOK_SYMBOLS), set(hooks) ^ set(abi.HOOK_SYMBOLS)
+    assert not set(hooks) & set(_declared(r"trc_"))                       # declared in one header only
+    product, fast, lab = _exported(device.lib_path()), _exported(device.fast_lib_path()), _exported(device.hooks_lib_path())
+    assert not [s for s in hooks if s in product or s in fast]
+    assert not [s for s in hooks + abi.DEVICE_SYMBOLS if s not in lab]
+    # nothing but the declared ABI leaves the product library under the trc_ prefix
+    assert {s for s in product if s.startswith("trc_")} == set(abi.DEVICE_SYMBOLS)
+    assert device.lib().trc_has_test_hooks() == 0 and device.lib(fast_math=True).trc_has_test_hooks() == 0
+    assert device.lib(hooks=True).trc_has_test_hooks() == 1 and device.lib(hooks=True).trc_build_flavor() == b"exact"
 
 
 def test_host_library_exports_every_declared_symbol():

@@ -115,6 +115,27 @@ def test_gpu_count_probe_does_not_touch_hip():
     assert isinstance(bench.visible_gpus(), int) and bench.visible_gpus() >= 0
 
 
+def test_transport_is_decided_from_the_devices_the_ranks_hold():
+    """`world > visible_gpus()` took a launcher that isolates every rank with its own
+    HIP_VISIBLE_DEVICES=<one id> for "8 ranks on 1 GPU" and sent a real 8-GPU node over TCP sockets.  The decision is now made
+    from the PCI bus ids the ranks publish.  Three layouts of 8 ranks on a node whose GPUs sit at these bus ids:"""
+    node = [f"0000:{b:02x}:00.0" for b in (0x05, 0x15, 0x65, 0x75, 0x85, 0x95, 0xe5, 0xf5)]
+
+    def ranks(visible_of_rank):
+        # what each rank's context reports: the bus id of device pick_device(local_rank, #visible) among the GPUs it can see
+        return [node[vis[bench.pick_device(r, len(vis))]] for r, vis in enumerate(visible_of_rank)]
+    all_visible = ranks([list(range(8))] * 8)                        # torchrun as the driver starts it: every rank sees 8 devices
+    isolated = ranks([[r] for r in range(8)])                        # one HIP_VISIBLE_DEVICES id per rank: every rank sees ONE device
+    shared = ranks([[0]] * 8)                                        # 8 ranks on a 1-GPU box
+    assert all_visible == node and isolated == node and shared == [node[0]] * 8
+    assert bench.compose_transport(all_visible) == "rccl"
+    assert bench.compose_transport(isolated) == "rccl"               # the case the environment count got wrong
+    assert bench.compose_transport(shared) == "table"
+    assert bench.compose_transport(node[:3] + [node[1].upper()]) == "table"      # two ranks on one GPU among distinct ones; case-insensitive
+    assert bench.compose_transport(["", node[0]]) == "table" and bench.compose_transport([]) == "table"   # unknown devices: never RCCL blindly
+    assert bench.compose_transport([node[0]]) == "rccl"              # a 1-rank group (--force-group) is distinct by definition
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("launcher", ["self", "torchrun"])
 def test_two_rank_bench_path_on_one_gpu(launcher):
@@ -142,10 +163,17 @@ def test_two_rank_bench_path_on_one_gpu(launcher):
     assert "cpu_baseline" not in line                                   # rank 0 at N = 1 only
     assert line["config"]["rays_per_step"] == 219978393                 # the ONE named frame, whatever N
     assert len(line["per_rank"]) == 2 and sum(r["rays_per_step"] for r in line["per_rank"]) == 219978393
-    weak = line["other_scaling"]
+    weak = line["other_scaling"]["weak"]
     assert weak["mode"] == "weak" and "2 stacked" in weak["metric"] and weak["frame"] == [1920, 2160]
     assert weak["rays_per_step"] > 4.3e8                                # two views' worth of rays
+    # sample sharding: the same 64 samples per pixel, 32 from each of two seeds; every rank renders the whole frame
+    smp = line["other_scaling"]["samples"]
+    assert smp["mode"] == "samples" and "split over 2 seeds" in smp["metric"] and smp["frame"] == [1920, 1080]
+    assert smp["sample_groups"] == 2 and smp["tile_ranks"] == 1 and [r["spp"] for r in smp["per_rank"]] == [32, 32]
+    assert abs(smp["rays_per_step"] / 219978393 - 1) < 0.01             # another sample set of the same frame: the same work to 1 %
+    assert all(r["compose_ms"] is not None for r in smp["per_rank"])
     assert line["plumbing"] is True and "PLUMBING" in line["config"]["compose"]
+    assert line["transport"] == "table" and len(line["devices"]) == 2 and line["devices"][0] == line["devices"][1]   # one GPU, seen by both ranks
     assert all(r["compose_ms"] is not None for r in line["per_rank"])   # the reduce really ran (host-staged)
     # the cold leg and the parity-imposed bounds ride along for every rank
     assert line["cold"]["settle_launches"] == 0 and line["first_launch_ms"] == line["cold"]["first_launch_ms"] > 0

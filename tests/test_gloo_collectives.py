@@ -1,6 +1,7 @@
-"""The harness side of trc_group_set_collectives on CPU: two gloo processes call the table's three functions directly on
+"""The harness side of trc_group_set_collectives on CPU: two gloo processes call the table's five functions directly on
 host buffers (what the library does after staging a device buffer), for exactly the shapes the path uses -- f32 sum to a
-root, u32 min / max of order-preserving keys, in-place all-gather of byte ranges."""
+root, u32 min / max of order-preserving keys, in-place all-gather of byte ranges, and the all-to-all / gather of pixel
+slices the sample-sharded compose makes."""
 import os
 import socket
 import subprocess
@@ -37,8 +38,17 @@ WORKER = textwrap.dedent("""
     pho = np.full(per * world, 0xEE, np.uint8)
     pho[rank * per:(rank + 1) * per] = (np.arange(per) * (rank + 3)) & 0xFF
     assert T.allgather(None, ptr(pho), per, None) == 0
-    np.savez(os.path.join(os.environ["TRC_OUT"], f"r{rank}.npz"), frame=frame, kmin=kmin, kmax=kmax, pho=pho,
-             calls=np.array([g.calls["reduce"], g.calls["allreduce"], g.calls["allgather"]]))
+    # sample-sharded compose: all-to-all of the accumulator's slices, gather of the composed slices to a root
+    sl = 4099 * 16
+    a2a = np.empty(sl * world, np.uint8)
+    for p in range(world):
+        a2a[p * sl:(p + 1) * sl] = (np.arange(sl) * 7 + 31 * rank + 5 * p) & 0xFF
+    assert T.alltoall(None, ptr(a2a), sl, None) == 0
+    gat = np.full(sl * world, 0xAB, np.uint8)
+    gat[rank * sl:(rank + 1) * sl] = (np.arange(sl) * 3 + rank) & 0xFF
+    assert T.gather(None, ptr(gat), sl, 1, None) == 0
+    np.savez(os.path.join(os.environ["TRC_OUT"], f"r{rank}.npz"), frame=frame, kmin=kmin, kmax=kmax, pho=pho, a2a=a2a, gat=gat,
+             calls=np.array([g.calls[k] for k in ("reduce", "allreduce", "allgather", "alltoall", "gather")]))
     dist.barrier(); dist.destroy_process_group()
 """)
 
@@ -64,4 +74,9 @@ def test_gloo_table_runs_the_path_s_three_collectives(tmp_path):
         assert list(res[r]["kmin"]) == [0xFFFFFFF0 - (world - 1), 5, 0x80000000]
         assert list(res[r]["kmax"]) == [0xFFFFFFF0, 5 + world - 1, 0x80000000 + world - 1]
         assert np.array_equal(res[r]["pho"], pho)
-        assert list(res[r]["calls"]) == [1, 2, 1]
+        assert list(res[r]["calls"]) == [1, 2, 1, 1, 1]
+    sl = 4099 * 16
+    for r in range(world):
+        for p in range(world):
+            assert np.array_equal(res[r]["a2a"][p * sl:(p + 1) * sl], ((np.arange(sl) * 7 + 31 * p + 5 * r) & 0xFF).astype(np.uint8)), (r, p)
+    assert np.array_equal(res[1]["gat"], np.concatenate([((np.arange(sl) * 3 + r) & 0xFF).astype(np.uint8) for r in range(world)]))

@@ -291,30 +291,53 @@ def test_rccl_group_single_rank_roundtrip(gpu, cornell_spheres):
     last = gpu.download_composed()
     gpu.clear_accum(); gpu.seed(24); gpu.render(spp=1)
     assert np.array_equal(gpu.download_accum().view(np.uint32), last.view(np.uint32))
-    # sample sharding: ncclAllReduce(sum) / nranks; with one rank the frame must come back unchanged
+    # sample sharding over the same 1-rank communicator (ncclGroupStart / End with no peer inside, the fold kernel, the
+    # all-gather): one rank's sum over one group is the frame itself, on the root, pipelined, and delivered to every rank
     gpu.clear_accum(); gpu.seed(31); gpu.render(spp=3)
     before = gpu.download_accum()
+    gpu.group_compose_samples(0)
+    assert np.array_equal(gpu.download_composed().view(np.uint32), before.view(np.uint32))
+    gpu.group_compose_samples_async(0, 1)
+    assert np.array_equal(gpu.download_composed().view(np.uint32), before.view(np.uint32))
+    gpu.synchronize(); gpu.clear_accum(); gpu.seed(31); gpu.render(spp=3)
     gpu.group_allreduce_mean_accum()
     assert np.array_equal(gpu.download_accum().view(np.uint32), before.view(np.uint32))
+    with pytest.raises(Exception):
+        gpu.group_compose_samples(0, 3)                      # 1 rank is not 3 sample groups x tile ranks
     gpu.group_finalize()
 
 
-def test_sample_sharding_is_the_mean_of_the_shards(gpu, cornell_spheres):
-    """what trc_group_allreduce_mean_accum composes: N whole-frame renders with different seeds, averaged -- an N * spp
-    sample estimate of the same image (emulated on one GPU; the collective itself is covered with a 1-rank group)"""
-    W, H, spp, N = 96, 64, 16, 4
-    gpu.upload_scene(cornell_spheres.view); gpu.set_camera(host.prepare_camera(W, H)); gpu.set_environment((0.0, 0.0, 0.0))
-    gpu.resize(W, H)
-    shards = []
-    for r in range(N):
-        gpu.clear_accum(); gpu.seed(100 + r); gpu.render(spp=spp)
-        shards.append(gpu.download_accum().astype(np.float64))
-    mean = sum(shards) / N
-    gpu.clear_accum(); gpu.seed(999); gpu.render(spp=spp * N)
-    full = gpu.download_accum().astype(np.float64)
-    assert (mean[..., 3] == 1).all()
-    # both are N * spp sample estimates: their frame means agree far better than single shards do
-    assert abs(mean[..., :3].mean() - full[..., :3].mean()) < 0.1 * full[..., :3].mean()
+def test_sample_sharding_is_bit_defined(gpu, cornell_spheres):
+    """Sample sharding has a bit-level definition (include/tracer_abi.h): group g renders the whole frame with
+    spp / S samples from trc_seed(trc_shard_seed(seed, g)); composed texel = rank-ordered binary32 sum / S.  The shards rendered
+    one after the other on this GPU and folded in numpy == oracle/pyoracle.py::render_sample_sharded, bit for bit, for both
+    integrators; group 0 keeps the seed, so one group IS the unsharded frame; the library's seed function is the documented one.
+    (The collective itself: 2 and 8 ranks on one GPU in test_gpu_shared_gpu_ranks.py, a 1-rank group below.)"""
+    import ctypes as C
+    from tracer_amd import device
+    W, H, spp, S = 96, 64, 16, 4
+    cam = host.prepare_camera(W, H)
+    gpu.upload_scene(cornell_spheres.view); gpu.set_camera(cam); gpu.set_environment((0.0, 0.0, 0.0)); gpu.resize(W, H)
+    L = device.lib()
+    rs = np.random.RandomState(5)
+    for seed, g in [(0, 0), (0x5EED0000, 7), (2 ** 64 - 1, 1), (2 ** 63, 2 ** 32 - 1)] + [(int(rs.randint(0, 2 ** 62)) * 3, int(rs.randint(0, 2 ** 31))) for _ in range(32)]:
+        assert L.trc_shard_seed(C.c_uint64(seed), C.c_uint32(g)) == abi.shard_seed(seed, g) == po.shard_seed(seed, g)
+    assert abi.shard_seed(0x5EED0000, 0) == 0x5EED0000 and abi.shard_seed(1, 1) == 0x9E3779B97F4A7C16
+    for integ in (abi.INTEGRATOR_PATH, abi.INTEGRATOR_MIS):
+        shards = []
+        for g in range(S):
+            gpu.clear_accum(); gpu.seed(abi.shard_seed(321, g)); gpu.render(spp=spp // S, integrator=integ)
+            shards.append(gpu.download_accum())
+        acc = shards[0]
+        for a in shards[1:]:
+            acc = np.add(acc, a, dtype=np.float32)
+        got = np.divide(acc, np.float32(S), dtype=np.float32)
+        want, _ = po.render_sample_sharded(cornell_spheres.view, cam, W, H, [host.fill_rng(po.shard_seed(321, g), W, H) for g in range(S)],
+                                           spp, integrator=integ)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) and (want[..., 3] == 1).all()
+    one, _ = po.render_sample_sharded(cornell_spheres.view, cam, W, H, [host.fill_rng(321, W, H)], spp)
+    plain, _ = po.render(cornell_spheres.view, cam, W, H, host.fill_rng(321, W, H), spp=spp)
+    assert np.array_equal(one.view(np.uint32), plain.view(np.uint32))
 
 
 def test_stacked_views_sharded_over_ranks(gpu, cornell_spheres):

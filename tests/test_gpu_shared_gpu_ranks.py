@@ -4,6 +4,8 @@ trc_group_set_collectives (host-staged, gloo between the processes) instead of R
 device.  Everything else is the code an 8-GPU run executes: tile ownership, photon index ranges, the reduce / allreduce /
 allgather program, the pipelined two-accumulator compose.  Bar: N ranks == 1 rank, bit for bit -- at a small
 size for 2 and 8 ranks, and at 1920x1080 for BASELINE configs 4 (teapot x 64, 2 spp + 8 spp) and 5 (4 SPPM frames).
+Sample sharding (another sample set than one rank's by definition) is held to the ORACLE rendering the same definition
+(oracle/pyoracle.py::render_sample_sharded): small, and at 1920x1080x64spp for BASELINE configs 2 and 4.
 The reference has no counterpart (multi-device is commented out, AAPLRenderer.mm:139-146)."""
 import hashlib
 import os
@@ -15,6 +17,7 @@ import numpy as np
 import pytest
 
 from conftest import ROOT
+from oracle import pyoracle as po
 from tracer_amd import abi, host
 
 pytestmark = pytest.mark.gpu
@@ -72,17 +75,27 @@ def test_every_group_call_with_n_ranks_on_one_gpu(gpu, tmp_path, world):
     for step in range(3):
         gpu.clear_accum(); gpu.seed(40 + step); gpu.render(spp=spp)
         assert np.array_equal(bits(res[0][f"async{step}"]), bits(gpu.download_accum())), step
-    # sample sharding: mean of the ranks' whole frames; every rank holds the same result.  The float sum over ranks is
-    # order-dependent in general -- gloo's is not specified -- so compare with the float64 mean to a few ulp
-    frames = []
+    # sample sharding against the oracle's statement of the definition: group g's frame from seed shard_seed(seed, g),
+    # rank-ordered float32 sum, one division -- bit for bit, on the root and (trc_group_allreduce_mean_accum) on every rank
+    cam = host.prepare_camera(W, H)
+    want, _ = po.render_sample_sharded(scene.view, cam, W, H, [host.fill_rng(po.shard_seed(100, g), W, H) for g in range(world)], 16)
+    assert np.array_equal(bits(res[0]["samples"]), bits(want))
     for r in range(world):
-        gpu.clear_accum(); gpu.seed(100 + r); gpu.render(spp=spp)
-        frames.append(gpu.download_accum()[..., :3].astype(np.float64))
-    want = np.mean(frames, axis=0)
-    for r in range(world):
-        got = res[r]["mean"][..., :3].astype(np.float64)
-        assert np.allclose(got, want, rtol=2e-6, atol=1e-7)
-        assert np.array_equal(bits(res[r]["mean"]), bits(res[0]["mean"]))
+        assert np.array_equal(bits(res[r]["mean"]), bits(want)) and bool(res[r]["untouched"]), r
+    # ... and against this GPU rendering the shards one after the other (the seeds are the documented function of the rank)
+    shards = []
+    for g in range(world):
+        gpu.clear_accum(); gpu.seed(abi.shard_seed(100, g)); gpu.render(spp=16 // world)
+        shards.append(gpu.download_accum())
+    acc = shards[0]
+    for a in shards[1:]:
+        acc = np.add(acc, a, dtype=np.float32)
+    assert np.array_equal(bits(np.divide(acc, np.float32(world), dtype=np.float32)), bits(want))
+    if world >= 4:                                           # S seeds x 2 tile ranks: the zeros of the other tile rank are exact identities
+        S = world // 2
+        for step in range(2):
+            want, _ = po.render_sample_sharded(scene.view, cam, W, H, [host.fill_rng(po.shard_seed(200 + step, g), W, H) for g in range(S)], 16)
+            assert np.array_equal(bits(res[0][f"hybrid{step}"]), bits(want)), step
     # SPPM
     gpu.clear_accum(); gpu.seed(8); gpu.sppm_init(9); gpu.sppm_frames(3)
     cam, pho, mark, count, cx = gpu.sppm_download()
@@ -96,8 +109,11 @@ def test_every_group_call_with_n_ranks_on_one_gpu(gpu, tmp_path, world):
         box = np.array([cx.photonBox.mini.x, cx.photonBox.mini.y, cx.photonBox.mini.z,
                         cx.photonBox.maxi.x, cx.photonBox.maxi.y, cx.photonBox.maxi.z], np.float32)
         assert np.array_equal(bits(res[r]["box"]), bits(box))
-        # the collective program of SURVEY 8e: 1 + 3 + 1 reduces, 1 + 2 all-reduces, 3 all-gathers
-        assert list(res[r]["calls"]) == [5, 3, 4]          # 3 per-frame gathers of the 40-byte wire records + the whole records at the download
+        # the collective program of SURVEY 8e: 1 + 3 + 1 reduces, 2 all-reduces (SPPM bound keys), 3 per-frame all-gathers of the
+        # 40-byte wire records + the whole records at the download + the every-rank sample compose; one all-to-all per sample
+        # compose (root, every rank, 2 pipelined hybrids), one gather per compose to a root
+        hybrid = 2 if world >= 4 else 0
+        assert list(res[r]["calls"]) == [5, 2, 5, 2 + hybrid, 1 + hybrid]
 
 
 @pytest.mark.parametrize("world", [2, 8])
@@ -135,7 +151,39 @@ def test_config5_sppm_as_an_n_rank_split_at_1080p(gpu, tmp_path, world):
         assert str(res[r]["rng_own_sha"]) == sha(rng[own]), r
         assert str(res[r]["pho_sha"]) == sha(pho) and str(res[r]["mark_sha"]) == sha(mark) and str(res[r]["count_sha"]) == sha(count), r
         assert res[r]["total"] == np.float32(cx.totalPhotonSum) and res[r]["hash_scale"] == np.float32(cx.photonHashScale)
-        assert list(res[r]["calls"]) == [1, 2, frames + 1]
+        assert list(res[r]["calls"]) == [1, 2, frames + 1, 0, 0]
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_config2_sample_sharded_at_1080p_is_the_oracle_s_frame(gpu, tmp_path, world):
+    """bench.py --scaling samples, step for step: N ranks, each the WHOLE 1920x1080 frame with 64 / N samples from seed
+    trc_shard_seed(0x5EED0000, rank), composed on rank 0 == the oracle rendering that definition, every pixel"""
+    res = run_ranks("samples2", world, tmp_path / f"s2_{world}", timeout=1500)
+    W, H = 1920, 1080
+    scene = host.HostScene(abi.SCENE_CORNELL_SPHERES)
+    want, sts = po.render_sample_sharded(scene.view, host.prepare_camera(W, H), W, H,
+                                         [host.fill_rng(po.shard_seed(0x5EED0000, g), W, H) for g in range(world)], 64)
+    assert np.array_equal(bits(res[0]["frame"]), bits(want))
+    for r in range(world):
+        assert int(res[r]["rays"]) == sts[r].rays and int(res[r]["paths"]) == W * H * (64 // world), r
+        assert list(res[r]["calls"]) == [0, 0, 0, 2, 2]
+    assert (want[..., 3] == 1).all()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_config4_sample_sharded_at_1080p_is_the_oracle_s_frame(gpu, tmp_path, world):
+    """the same on BASELINE config 4's scene (teapot.obj x 64, 1 005 056 triangles, the tree read from memory): 64 / N samples
+    per rank through the persistent-workgroup kernel; 1 tile in 64 of the composed frame re-rendered by the oracle"""
+    res = run_ranks("samples4", world, tmp_path / f"s4_{world}", timeout=1500)
+    W, H = 1920, 1080
+    scene = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.golden("teapot").replicate(8, 80.0))
+    want, _ = po.render_sample_sharded(scene.view, host.prepare_camera(W, H), W, H,
+                                       [host.fill_rng(po.shard_seed(0x5EED0004, g), W, H) for g in range(world)], 64,
+                                       tile_rank=0, tile_nranks=64)
+    mine = owner_mask(W, H, 64, 0)
+    got = res[0]["frame"]
+    assert mine.sum() > 5000 and np.array_equal(bits(got[mine]), bits(want[mine]))
+    assert np.isfinite(got).all() and (got[..., 3] == 1).all() and sum(int(r["paths"]) for r in res) == W * H * 64
 
 
 def test_device_pointer_table_and_error_propagation(gpu):

@@ -102,7 +102,7 @@ def test_sppm_through_a_one_rank_communicator(gpu, cornell_spheres):
 
 
 @pytest.mark.parametrize("scale", [0.37, 1.0, 1.5, 2.0, 3.999, 17.3, 250.0, 1.0e-3])
-def test_hash_equals_the_oracle_cell_for_cell(gpu, scale):
+def test_hash_equals_the_oracle_cell_for_cell(gpu_hooks, scale):
     """The device evaluates the divisions of `hash()` (Photon.hh:71-89) with one refined reciprocal per shared divisor and
     the compiler's two fused corrections per quotient (trc_sppm.hip::DivBy).  That must be the IEEE quotient, i.e. the
     oracle's `/`: compared here directly, cell for cell, over the grid's own index range, large indices, non-integers,
@@ -117,7 +117,7 @@ def test_hash_equals_the_oracle_cell_for_cell(gpu, scale):
         np.zeros((4, 3), np.float32),
         np.array([[0, 0, 599], [599, 0, 0], [1, 1, 2], [0, 0, 1]], np.float32),   # x + y - z <= 0
     ])
-    dev = gpu.sppm_hash_cells(cells, scale)
+    dev = gpu_hooks.sppm_hash_cells(cells, scale)
     L = po.lib()
     f3 = C.c_float * 3
     ref = np.array([L.orc_photon_hash(f3(*c), C.c_float(scale)) for c in cells], np.float32)

@@ -11,7 +11,7 @@ integ = 1 if (len(sys.argv) > 2 and sys.argv[2] == "mis") else 0
 if kind == "spheres": sc, spp = host.HostScene(abi.SCENE_CORNELL_SPHERES), 64
 elif kind == "mesh": sc, spp = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.ball(152, 154, 1.0)), 16
 else: sc, spp = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.ball(60, 60, 0.08).replicate(12, 2.4)), 16
-t = Tracer(0); t.upload_scene(sc.view); t.set_camera(host.prepare_camera(W, H)); t.resize(W, H); t.seed(0x5EED0000)
+t = Tracer(0, hooks=True); t.upload_scene(sc.view); t.set_camera(host.prepare_camera(W, H)); t.resize(W, H); t.seed(0x5EED0000)
 t.reset_stats(); t.render(spp=spp, integrator=integ, collect_stats=True); t.synchronize()
 st = t.stats(); prof = t.debug_profile(); total = prof["loop"][3]
 print(f"# {kind} integrator {integ} {spp} spp: instrumented kernel {st.kernel_ms:.1f} ms, {st.rays} rays")

@@ -7,7 +7,7 @@ Triangle,Texture,Material,Camera}.hh (see the header for file:line).
 """
 import ctypes as C
 
-TRC_ABI_VERSION = 4
+TRC_ABI_VERSION = 5
 TRC_TILE = 16
 TRC_MAX_BVH_DEPTH = 64
 TREE_SAH, TREE_TRIANGLE_LEAVES = 1, 2
@@ -34,6 +34,14 @@ FLAG_SOBOL = 4
 FLAG_SMALL_BLOCKS, FLAG_LARGE_BLOCKS = 8, 16
 TRACE_ANY_HIT, TRACE_PRODUCTION = 1, 2
 SOBOL_DIMS, SOBOL_MATRIX_SIZE = 40, 52
+
+SHARD_SEED_STRIDE = 0x9E3779B97F4A7C15
+
+
+def shard_seed(seed, sample_group):
+    """trc_shard_seed: the RNG seed of sample group g of a sample-sharded frame (group 0 keeps the seed)"""
+    return (int(seed) + int(sample_group) * SHARD_SEED_STRIDE) & 0xFFFFFFFFFFFFFFFF
+
 
 # status codes
 OK = 0
@@ -210,14 +218,16 @@ for _t, _n in _EXPECTED_SIZES.items():
 
 # every symbol include/tracer_abi.h declares, by library (checked by tests/test_abi_symbols.py)
 DEVICE_SYMBOLS = [
-    "trc_abi_version", "trc_build_flavor", "trc_status_string", "trc_last_error", "trc_create", "trc_destroy",
+    "trc_abi_version", "trc_build_flavor", "trc_has_test_hooks", "trc_status_string", "trc_last_error", "trc_create", "trc_destroy",
     "trc_upload_scene", "trc_upload_density", "trc_upload_scene_lbvh", "trc_upload_scene_sah", "trc_upload_scene_device", "trc_download_bvh", "trc_lbvh_info", "trc_set_camera", "trc_set_environment", "trc_set_environment_map", "trc_resize", "trc_seed",
     "trc_upload_rng", "trc_download_rng", "trc_upload_accum", "trc_download_accum", "trc_clear_accum", "trc_tonemap",
-    "trc_render", "trc_synchronize", "trc_trace_rays", "trc_get_stats", "trc_reset_stats", "trc_debug_profile",
-    "trc_sppm_init", "trc_sppm_frames", "trc_sppm_download", "trc_sppm_hash_cells",
-    "trc_device_info", "trc_group_unique_id", "trc_group_init", "trc_group_reduce_accum", "trc_group_reduce_accum_async", "trc_group_allreduce_mean_accum", "trc_download_composed", "trc_group_finalize",
-    "trc_group_set_collectives", "trc_debug_set", "trc_debug_block_costs", "trc_debug_launch_shape", "trc_div_by_test", "trc_unary_test",
+    "trc_render", "trc_synchronize", "trc_trace_rays", "trc_get_stats", "trc_reset_stats",
+    "trc_sppm_init", "trc_sppm_frames", "trc_sppm_download",
+    "trc_device_info", "trc_device_pci_bus_id", "trc_shard_seed", "trc_group_compose_samples", "trc_group_compose_samples_async", "trc_group_unique_id", "trc_group_init", "trc_group_reduce_accum", "trc_group_reduce_accum_async", "trc_group_allreduce_mean_accum", "trc_download_composed", "trc_group_finalize",
+    "trc_group_set_collectives", "trc_debug_set", "trc_debug_block_costs", "trc_debug_launch_shape",
 ]
+# include/tracer_test_hooks.h: exported by libtracer_amd_hooks.so only (the product's sources + -DTRC_TEST_HOOKS)
+HOOK_SYMBOLS = ["trc_debug_profile", "trc_sppm_hash_cells", "trc_div_by_test", "trc_unary_test"]
 HOST_SYMBOLS = [
     "trc_host_build_node", "trc_host_build_tree", "trc_host_tree_depth", "trc_host_make_camera",
     "trc_host_prepare_camera", "trc_host_fill_rng", "trc_host_scene_create", "trc_host_scene_create_leaves", "trc_host_scene_destroy",

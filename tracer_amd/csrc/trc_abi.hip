@@ -465,6 +465,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(const KTrace kp) {
     kp.hits[i] = o;
 }
 
+#ifdef TRC_TEST_HOOKS      // libtracer_amd_hooks.so only (include/tracer_test_hooks.h)
 // trc_div_by_test: a[i] / b[i] through the guarded shared-divisor path (three numerators a, -a, a * 0.75 on one divisor) and
 // through the plain division
 __global__ void __launch_bounds__(256) k_div_by_test(const float* a, const float* b, uint32_t n, float* fast, float* plain) {
@@ -499,6 +500,7 @@ __global__ void __launch_bounds__(256) k_unary_test(uint32_t op, uint32_t first,
     }
     if (bad) { atomicAdd(&out[0], bad); atomicMin(&out[1], first_bad); }
 }
+#endif  // TRC_TEST_HOOKS
 
 // ======================================================================= host side
 namespace {
@@ -684,6 +686,10 @@ bool trc_load_rccl(std::string& err) {
     r.Reduce = (int (*)(const void*, void*, size_t, int, int, int, void*, hipStream_t))dlsym(r.handle, "ncclReduce");
     r.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(r.handle, "ncclAllReduce");
     r.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(r.handle, "ncclAllGather");
+    r.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(r.handle, "ncclSend");
+    r.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))dlsym(r.handle, "ncclRecv");
+    r.GroupStart = (int (*)())dlsym(r.handle, "ncclGroupStart");
+    r.GroupEnd = (int (*)())dlsym(r.handle, "ncclGroupEnd");
     r.CommDestroy = (int (*)(void*))dlsym(r.handle, "ncclCommDestroy");
     r.GetErrorString = (const char* (*)(int))dlsym(r.handle, "ncclGetErrorString");
     if (!r.GetUniqueId || !r.CommInitRank || !r.Reduce || !r.AllReduce || !r.AllGather || !r.CommDestroy) {
@@ -956,6 +962,14 @@ const char* trc_build_flavor(void) {
 #endif
 }
 
+int trc_has_test_hooks(void) {
+#ifdef TRC_TEST_HOOKS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 const char* trc_status_string(trc_status s) {
     switch (s) {
         case TRC_OK: return "ok";
@@ -1030,6 +1044,7 @@ void trc_destroy(trc_ctx* ctx) {
     (void)hipFree(ctx->d_block_cost); (void)hipFree(ctx->d_order_hist); (void)hipFree(ctx->d_split); (void)hipFree(ctx->d_whole); (void)hipFree(ctx->d_cost_est); (void)hipFree(ctx->d_qsplit); (void)hipFree(ctx->d_qwhole); (void)hipFree(ctx->d_launch); (void)hipFree(ctx->d_plan); (void)hipFree(ctx->d_plan_gather); (void)hipFree(ctx->d_cost_scratch);
     for (int k = 0; k < 2; ++k) { (void)hipFree(ctx->d_order_keys[k]); (void)hipFree(ctx->d_order_vals[k]); }
     (void)hipFree(ctx->d_accum_alt); (void)hipFree(ctx->d_stack_ovf); (void)hipFree(ctx->d_queue);
+    (void)hipFree(ctx->d_shard_in); (void)hipFree(ctx->d_shard_out);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->h_readback) (void)hipHostFree(ctx->h_readback);
     for (hipEvent_t e : {ctx->ev_rendered, ctx->ev_busy, ctx->ev_busy_alt}) if (e) (void)hipEventDestroy(e);
@@ -1152,6 +1167,8 @@ trc_status trc_resize(trc_ctx* ctx, uint32_t width, uint32_t height) {
     if (ctx->comm_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->comm_stream));
     (void)hipFree(ctx->d_rng); (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_accum_alt); (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_reduce_recv);
     ctx->d_rng = nullptr; ctx->d_accum = nullptr; ctx->d_accum_alt = nullptr; ctx->d_composed = nullptr; ctx->d_tiles = nullptr; ctx->d_reduce_recv = nullptr;
+    (void)hipFree(ctx->d_shard_in); (void)hipFree(ctx->d_shard_out);
+    ctx->d_shard_in = ctx->d_shard_out = nullptr; ctx->shard_px = 0; ctx->shard_nranks = 0;
     ctx->busy = ctx->busy_alt = false;
     trc_sppm_release(ctx);          // per-pixel camera records depend on the frame size
     ctx->n_tiles = 0; ctx->tiles_nranks = 0;
@@ -1637,6 +1654,7 @@ trc_status trc_get_stats(trc_ctx* ctx, trc_stats* out) {
     return TRC_OK;
 }
 
+#ifdef TRC_TEST_HOOKS
 // developer diagnostic: (lanes, wavefronts) that executed each ProfSite of the instrumented kernels
 trc_status trc_debug_profile(trc_ctx* ctx, uint64_t* out, uint32_t n_sites) {
     { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
@@ -1650,6 +1668,7 @@ trc_status trc_debug_profile(trc_ctx* ctx, uint64_t* out, uint32_t n_sites) {
         for (int k = 0; k < 3; ++k) out[3 * i + k] = h[kStatCount + 3 * i + k];
     return TRC_OK;
 }
+#endif  // TRC_TEST_HOOKS
 
 // developer diagnostic: the chain bound and the work bound of the last launch (tracer_abi.h)
 trc_status trc_debug_launch_shape(trc_ctx* ctx, trc_launch_shape* out) {
@@ -1724,6 +1743,7 @@ trc_status trc_debug_block_costs(trc_ctx* ctx, uint32_t* tiles, uint32_t* costs,
     return TRC_OK;
 }
 
+#ifdef TRC_TEST_HOOKS
 trc_status trc_div_by_test(trc_ctx* ctx, const float* a, const float* b, size_t n, float* fast, float* plain) {
     if (!ctx || (n && (!a || !b || !fast || !plain))) return TRC_ERR_INVALID_ARG;
     if (n == 0) return TRC_OK;
@@ -1766,6 +1786,7 @@ trc_status trc_unary_test(trc_ctx* ctx, uint32_t op, uint32_t first_bits, uint64
     if (first_mismatch) *first_mismatch = (uint32_t)h[1];
     return TRC_OK;
 }
+#endif  // TRC_TEST_HOOKS
 
 trc_status trc_reset_stats(trc_ctx* ctx) {
     { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
@@ -1787,6 +1808,12 @@ trc_status trc_device_info(trc_ctx* ctx, char* name, size_t name_len, int* cu_co
     if (name && name_len) { std::snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName); }
     if (cu_count) *cu_count = prop.multiProcessorCount;
     if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    return TRC_OK;
+}
+
+trc_status trc_device_pci_bus_id(trc_ctx* ctx, char* out, size_t out_len) {
+    if (!ctx || !out || out_len < 16) return TRC_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipDeviceGetPCIBusId(out, (int)out_len, ctx->device));
     return TRC_OK;
 }
 
@@ -1832,39 +1859,151 @@ trc_status trc_group_reduce_accum(trc_ctx* ctx, int root) {
     return trc_coll_reduce(ctx, ctx->d_accum, count, kNcclFloat, kNcclSum, root, ctx->stream, "reduce(sum) of the accumulator");
 }
 
-// Sample sharding (the alternative to tile sharding): every rank has rendered ALL pixels with its own share
-// of the samples (its own seed) from frame0 = 0; the composed frame is the mean of the ranks' running means.
-__global__ void __launch_bounds__(256) k_scale_rgb(float4* accum, size_t n, float inv) {
-    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    float4 a = accum[i];
-    a.x *= inv; a.y *= inv; a.z *= inv; a.w = 1.0f;
-    accum[i] = a;
+// Sample sharding (the alternative to tile sharding; the definition is in tracer_abi.h): the composed pixel is
+// the rank-ORDERED sum of the ranks' accumulator texels over the number of sample groups.  Rank r owns the r-th of nranks
+// equal pixel slices: all-to-all of the slices, k_fold_shards, gather (root) or all-gather (every rank) of the results.
+__global__ void __launch_bounds__(256) k_fold_shards(const float4* __restrict__ in, float4* __restrict__ out, uint32_t n_px,
+                                                     uint32_t slice_px, uint32_t nranks, float groups) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_px) return;
+    float4 a = in[i];                                        // rank 0's texel starts the sum (not 0 + it: -0 stays -0)
+    for (uint32_t p = 1; p < nranks; ++p) {
+        const float4 b = in[(size_t)p * slice_px + i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    a.x /= groups; a.y /= groups; a.z /= groups; a.w /= groups;
+    out[i] = a;
 }
+
+extern "C++" {
+namespace {
+
+// pixels of slice p when n_px pixels are cut into nranks slices of slice_px (the last ones may be short or empty)
+inline size_t slice_count(size_t n_px, size_t slice_px, int p) {
+    const size_t lo = std::min(n_px, (size_t)p * slice_px), hi = std::min(n_px, (size_t)(p + 1) * slice_px);
+    return hi - lo;
+}
+
+// root >= 0: the composed frame lands in ctx->d_shard_out on the root; root < 0: on every rank.  `src` is left untouched.
+trc_status compose_samples(trc_ctx* ctx, const float* src, int root, uint32_t groups, hipStream_t st, const char* what) {
+    const int N = ctx->nranks, me = ctx->rank;
+    const size_t n_px = (size_t)ctx->width * ctx->height;
+    const size_t slice_px = (n_px + (size_t)N - 1) / (size_t)N;
+    const size_t slice_f = slice_px * 4, slice_bytes = slice_px * 16, total_bytes = slice_bytes * (size_t)N;
+    if (!ctx->d_shard_in || ctx->shard_px != slice_px || ctx->shard_nranks != N) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->comm_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->comm_stream));
+        (void)hipFree(ctx->d_shard_in); (void)hipFree(ctx->d_shard_out); ctx->d_shard_in = ctx->d_shard_out = nullptr;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_shard_in, total_bytes));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_shard_out, total_bytes));
+        HIP_TRY(ctx, hipMemset(ctx->d_shard_in, 0, total_bytes));
+        HIP_TRY(ctx, hipMemset(ctx->d_shard_out, 0, total_bytes));
+        ctx->shard_px = slice_px; ctx->shard_nranks = N;
+    }
+    const size_t mine = slice_count(n_px, slice_px, me);
+    // 1. slice `me` of every rank's accumulator -> d_shard_in[p]
+    if (ctx->coll_active) {
+        const trc_collectives& c = ctx->coll;
+        if (!c.alltoall || (root >= 0 ? !c.gather : !c.allgather))
+            return trc_fail(ctx, TRC_ERR_UNSUPPORTED, std::string(what) + ": the collectives table has no alltoall / gather");
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_shard_in, src, n_px * 16, hipMemcpyDeviceToDevice, st));
+        if (total_bytes > n_px * 16) HIP_TRY(ctx, hipMemsetAsync(reinterpret_cast<char*>(ctx->d_shard_in) + n_px * 16, 0, total_bytes - n_px * 16, st));
+        if (!c.host_staged) {
+            const int rc = c.alltoall(c.user, ctx->d_shard_in, slice_bytes, (void*)st);
+            if (rc != 0) return trc_fail(ctx, TRC_ERR_RCCL, std::string(what) + ": the caller's alltoall returned " + std::to_string(rc));
+        } else {
+            trc_status cs = staged(ctx, ctx->d_shard_in, total_bytes, true, st, what, [&](void* h) { return c.alltoall(c.user, h, slice_bytes, nullptr); });
+            if (cs != TRC_OK) return cs;
+        }
+    } else {
+        if (!ctx->comm) return trc_fail(ctx, TRC_ERR_RCCL, std::string(what) + " before trc_group_init / trc_group_set_collectives");
+        if (!g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd)
+            return trc_fail(ctx, TRC_ERR_UNSUPPORTED, std::string(what) + ": librccl has no ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd");
+        if (mine) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_shard_in + (size_t)me * slice_f, src + (size_t)me * slice_f, mine * 16, hipMemcpyDeviceToDevice, st));
+        int rc = g_rccl.GroupStart();
+        for (int p = 0; p < N && rc == 0; ++p) {
+            if (p == me) continue;
+            const size_t theirs = slice_count(n_px, slice_px, p);
+            if (theirs) rc = g_rccl.Send(src + (size_t)p * slice_f, theirs * 4, kNcclFloat, p, ctx->comm, st);
+            if (rc == 0 && mine) rc = g_rccl.Recv(ctx->d_shard_in + (size_t)p * slice_f, mine * 4, kNcclFloat, p, ctx->comm, st);
+        }
+        const int rc_end = g_rccl.GroupEnd();
+        if (rc != 0 || rc_end != 0) return trc_fail(ctx, TRC_ERR_RCCL, rccl_error(what, rc != 0 ? rc : rc_end));
+    }
+    // 2. fold the N texels of every pixel of the slice in rank order, divide by the number of sample groups
+    if (mine) {
+        hipLaunchKernelGGL(k_fold_shards, dim3((unsigned)((mine + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float4*>(ctx->d_shard_in),
+                           reinterpret_cast<float4*>(ctx->d_shard_out + (size_t)me * slice_f), (uint32_t)mine, (uint32_t)slice_px, (uint32_t)N, (float)groups);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    // 3. the composed slices to the root, or to everybody
+    if (root < 0) return trc_coll_allgather(ctx, ctx->d_shard_out, slice_bytes, st, what);
+    if (ctx->coll_active) {
+        const trc_collectives& c = ctx->coll;
+        if (!c.host_staged) {
+            const int rc = c.gather(c.user, ctx->d_shard_out, slice_bytes, root, (void*)st);
+            return rc == 0 ? TRC_OK : trc_fail(ctx, TRC_ERR_RCCL, std::string(what) + ": the caller's gather returned " + std::to_string(rc));
+        }
+        return staged(ctx, ctx->d_shard_out, total_bytes, me == root, st, what, [&](void* h) { return c.gather(c.user, h, slice_bytes, root, nullptr); });
+    }
+    int rc = g_rccl.GroupStart();
+    if (me == root) {
+        for (int p = 0; p < N && rc == 0; ++p) {
+            const size_t theirs = slice_count(n_px, slice_px, p);
+            if (p != me && theirs) rc = g_rccl.Recv(ctx->d_shard_out + (size_t)p * slice_f, theirs * 4, kNcclFloat, p, ctx->comm, st);
+        }
+    } else if (mine) {
+        rc = g_rccl.Send(ctx->d_shard_out + (size_t)me * slice_f, mine * 4, kNcclFloat, root, ctx->comm, st);
+    }
+    const int rc_end = g_rccl.GroupEnd();
+    if (rc != 0 || rc_end != 0) return trc_fail(ctx, TRC_ERR_RCCL, rccl_error(what, rc != 0 ? rc : rc_end));
+    return TRC_OK;
+}
+
+trc_status check_compose(trc_ctx* ctx, int root, uint32_t groups, const char* what) {
+    if (!ctx->grouped()) return fail(ctx, TRC_ERR_RCCL, std::string(what) + " before trc_group_init / trc_group_set_collectives");
+    if (!ctx->d_accum) return fail(ctx, TRC_ERR_NO_FRAME, "no frame");
+    if (root >= ctx->nranks) return fail(ctx, TRC_ERR_INVALID_ARG, std::string(what) + ": root");
+    if (groups < 1 || (uint32_t)ctx->nranks % groups != 0) return fail(ctx, TRC_ERR_INVALID_ARG, std::string(what) + ": nranks is not sample_groups x tile ranks");
+    return TRC_OK;
+}
+
+}  // namespace
+}  // extern "C++"
+
+uint64_t trc_shard_seed(uint64_t seed, uint32_t sample_group) { return seed + (uint64_t)sample_group * 0x9E3779B97F4A7C15ull; }
+
+trc_status trc_group_compose_samples(trc_ctx* ctx, int root, uint32_t sample_groups) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
+    if (!ctx || root < 0) return TRC_ERR_INVALID_ARG;
+    if (sample_groups == 0) sample_groups = (uint32_t)ctx->nranks;
+    { trc_status cs = check_compose(ctx, root, sample_groups, "trc_group_compose_samples"); if (cs != TRC_OK) return cs; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->comm_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->comm_stream));    // an earlier pipelined compose still owns the slice buffers
+    { trc_status cs = compose_samples(ctx, ctx->d_accum, root, sample_groups, ctx->stream, "compose of the sample shards"); if (cs != TRC_OK) return cs; }
+    ctx->d_composed = ctx->d_shard_out;
+    return TRC_OK;
+}
+
 trc_status trc_group_allreduce_mean_accum(trc_ctx* ctx) {
     { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx) return TRC_ERR_INVALID_ARG;
-    if (!ctx->grouped()) return fail(ctx, TRC_ERR_RCCL, "trc_group_allreduce_mean_accum before trc_group_init / trc_group_set_collectives");
-    if (!ctx->d_accum) return fail(ctx, TRC_ERR_NO_FRAME, "no frame");
+    { trc_status cs = check_compose(ctx, -1, (uint32_t)ctx->nranks, "trc_group_allreduce_mean_accum"); if (cs != TRC_OK) return cs; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t pixels = (size_t)ctx->width * ctx->height;
-    { trc_status cs = trc_coll_allreduce(ctx, ctx->d_accum, pixels * 4, kNcclFloat, kNcclSum, ctx->stream, "allreduce(sum) of the accumulator"); if (cs != TRC_OK) return cs; }
-    hipLaunchKernelGGL(k_scale_rgb, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, ctx->stream,
-                       reinterpret_cast<float4*>(ctx->d_accum), pixels, 1.0f / (float)ctx->nranks);
-    HIP_TRY(ctx, hipGetLastError());
+    if (ctx->comm_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->comm_stream));
+    { trc_status cs = compose_samples(ctx, ctx->d_accum, -1, (uint32_t)ctx->nranks, ctx->stream, "compose of the sample shards"); if (cs != TRC_OK) return cs; }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_accum, ctx->d_shard_out, (size_t)ctx->width * ctx->height * 16, hipMemcpyDeviceToDevice, ctx->stream));
     return TRC_OK;
 }
 
 // Pipelined variant: the reduce of the frame just rendered runs on a second stream while the context goes on
 // rendering into its OTHER accumulator, so an xGMI ring reduce of a multi-view frame (265 MB at N = 8, ~6 ms)
 // hides under the next step's render instead of adding to it.
-trc_status trc_group_reduce_accum_async(trc_ctx* ctx, int root) {
-    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
-    if (!ctx) return TRC_ERR_INVALID_ARG;
-    if (!ctx->grouped()) return fail(ctx, TRC_ERR_RCCL, "trc_group_reduce_accum_async before trc_group_init / trc_group_set_collectives");
-    if (!ctx->d_accum) return fail(ctx, TRC_ERR_NO_FRAME, "no frame");
-    if (root < 0 || root >= ctx->nranks) return TRC_ERR_INVALID_ARG;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+extern "C++" {
+namespace {
+// the frame just rendered goes to the communication stream (`collective` is queued there), the context to its other accumulator
+template <typename Collective>
+trc_status compose_async(trc_ctx* ctx, Collective&& collective) {
     const size_t count = (size_t)ctx->width * ctx->height * 4;
     if (!ctx->comm_stream) {
         HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
@@ -1877,27 +2016,55 @@ trc_status trc_group_reduce_accum_async(trc_ctx* ctx, int root) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_accum_alt, 0, count * sizeof(float), ctx->stream));
         ctx->busy_alt = false;
     }
-    // reduce the current accumulator once everything queued so far on the render stream has finished
+    // compose the current accumulator once everything queued so far on the render stream has finished
     HIP_TRY(ctx, hipEventRecord(ctx->ev_rendered, ctx->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_rendered, 0));
-    { trc_status cs = trc_coll_reduce(ctx, ctx->d_accum, count, kNcclFloat, kNcclSum, root, ctx->comm_stream, "reduce(sum) of the accumulator"); if (cs != TRC_OK) return cs; }
+    { trc_status cs = collective(); if (cs != TRC_OK) return cs; }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_busy, ctx->comm_stream));
     ctx->busy = true;
-    ctx->d_composed = ctx->d_accum;
-    // swap accumulators (and their events); the render stream may touch the new current one only after ITS last reduce
+    // swap accumulators (and their events); the render stream may touch the new current one only after ITS last compose
     std::swap(ctx->d_accum, ctx->d_accum_alt);
     std::swap(ctx->ev_busy, ctx->ev_busy_alt);
     std::swap(ctx->busy, ctx->busy_alt);
     if (ctx->busy) { HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_busy, 0)); ctx->busy = false; }
     return TRC_OK;
 }
+}  // namespace
+}  // extern "C++"
+
+trc_status trc_group_reduce_accum_async(trc_ctx* ctx, int root) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
+    if (!ctx) return TRC_ERR_INVALID_ARG;
+    if (!ctx->grouped()) return fail(ctx, TRC_ERR_RCCL, "trc_group_reduce_accum_async before trc_group_init / trc_group_set_collectives");
+    if (!ctx->d_accum) return fail(ctx, TRC_ERR_NO_FRAME, "no frame");
+    if (root < 0 || root >= ctx->nranks) return TRC_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t count = (size_t)ctx->width * ctx->height * 4;
+    float* frame = ctx->d_accum;
+    trc_status s = compose_async(ctx, [&] { return trc_coll_reduce(ctx, frame, count, kNcclFloat, kNcclSum, root, ctx->comm_stream, "reduce(sum) of the accumulator"); });
+    if (s == TRC_OK) ctx->d_composed = frame;
+    return s;
+}
+
+trc_status trc_group_compose_samples_async(trc_ctx* ctx, int root, uint32_t sample_groups) {
+    { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
+    if (!ctx || root < 0) return TRC_ERR_INVALID_ARG;
+    if (sample_groups == 0) sample_groups = (uint32_t)ctx->nranks;
+    { trc_status cs = check_compose(ctx, root, sample_groups, "trc_group_compose_samples_async"); if (cs != TRC_OK) return cs; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float* frame = ctx->d_accum;
+    trc_status s = compose_async(ctx, [&] { return compose_samples(ctx, frame, root, sample_groups, ctx->comm_stream, "compose of the sample shards"); });
+    if (s == TRC_OK) ctx->d_composed = ctx->d_shard_out;
+    return s;
+}
 
 trc_status trc_download_composed(trc_ctx* ctx, float* rgba) {
     { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)
     if (!ctx || !rgba) return TRC_ERR_INVALID_ARG;
-    if (!ctx->d_composed) return fail(ctx, TRC_ERR_NO_FRAME, "trc_download_composed before trc_group_reduce_accum_async");
+    if (!ctx->d_composed) return fail(ctx, TRC_ERR_NO_FRAME, "trc_download_composed before trc_group_reduce_accum_async / trc_group_compose_samples");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->comm_stream));
+    if (ctx->comm_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->comm_stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(rgba, ctx->d_composed, (size_t)ctx->width * ctx->height * 16, hipMemcpyDeviceToHost));
     return TRC_OK;
 }
@@ -1922,7 +2089,7 @@ trc_status trc_group_set_collectives(trc_ctx* ctx, const trc_collectives* table,
     if (!ctx) return TRC_ERR_INVALID_ARG;
     if (!table) return trc_group_finalize(ctx);
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, TRC_ERR_INVALID_ARG, "trc_group_set_collectives: rank / nranks");
-    if (!table->reduce || !table->allreduce || !table->allgather) return fail(ctx, TRC_ERR_INVALID_ARG, "trc_group_set_collectives: the table needs reduce, allreduce and allgather");
+    if (!table->reduce || !table->allreduce || !table->allgather) return fail(ctx, TRC_ERR_INVALID_ARG, "trc_group_set_collectives: the table needs reduce, allreduce and allgather (alltoall / gather: only for sample shards)");
     { trc_status fs = trc_group_finalize(ctx); if (fs != TRC_OK) return fs; }
     ctx->coll = *table;
     ctx->coll_active = true;

@@ -9,6 +9,9 @@
 #include <vector>
 
 #include "tracer_abi.h"
+#ifdef TRC_TEST_HOOKS
+#include "tracer_test_hooks.h"      // libtracer_amd_hooks.so: the product's sources + the test hooks
+#endif
 #include "dev_integrator.hpp"
 
 using namespace trcdev;
@@ -202,6 +205,8 @@ struct trc_ctx {
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_rendered = nullptr, ev_busy = nullptr, ev_busy_alt = nullptr;
     bool busy = false, busy_alt = false;
+    // sample-sharded compose (trc_group_compose_samples): the slices received from the ranks, and the composed slices
+    float* d_shard_in = nullptr; float* d_shard_out = nullptr; size_t shard_px = 0; int shard_nranks = 0;
 
     SppmState* sppm = nullptr;       // trc_sppm.hip
 
@@ -245,6 +250,11 @@ struct Rccl {
     int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    // point-to-point (the sample-sharded compose): optional, a library without them still composes tiles
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };

@@ -551,12 +551,14 @@ __global__ void __launch_bounds__(256) k_sppm_pack_records(const VisiblePoints v
     out[i] = r;
 }
 
+#ifdef TRC_TEST_HOOKS      // libtracer_amd_hooks.so only (include/tracer_test_hooks.h)
 // trc_sppm_hash_cells
 __global__ void __launch_bounds__(256) k_sppm_hash_cells(const float* cells, uint32_t n, float scale, float* out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     out[i] = ph_hash(f3(cells[3 * i], cells[3 * i + 1], cells[3 * i + 2]), hash_div(scale), (float)kHashN);
 }
+#endif
 
 // completion handler, AAPLRenderer.mm:1031-1036
 __global__ void k_sppm_end_frame(DComplex* x) {
@@ -793,6 +795,7 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
     return TRC_OK;
 }
 
+#ifdef TRC_TEST_HOOKS
 trc_status trc_sppm_hash_cells(trc_ctx* ctx, const float* cells, size_t n, float hash_scale, float* out) {
     if (!ctx || (n && (!cells || !out))) return TRC_ERR_INVALID_ARG;
     if (n == 0) return TRC_OK;
@@ -812,6 +815,7 @@ trc_status trc_sppm_hash_cells(trc_ctx* ctx, const float* cells, size_t n, float
     if (e != hipSuccess) return trc_fail(ctx, TRC_ERR_HIP, std::string("trc_sppm_hash_cells: ") + hipGetErrorString(e));
     return TRC_OK;
 }
+#endif  // TRC_TEST_HOOKS
 
 trc_status trc_sppm_download(trc_ctx* ctx, trc_CameraRecord* cam, trc_PhotonRecord* pho, float* mark, float* count, trc_Complex* cx) {
     { const trc_status fs_ = trc_flush(ctx); if (fs_ != TRC_OK) return fs_; }      // a kept launch of few samples goes first (trc_render)

@@ -13,6 +13,7 @@ from . import abi
 
 _LIB = None
 _LIB_FAST = None
+_LIB_HOOKS = None
 
 
 class TracerError(RuntimeError):
@@ -30,10 +31,20 @@ def fast_lib_path():
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtracer_amd_fast.so")
 
 
-def lib(fast_math=False):
+def hooks_lib_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtracer_amd_hooks.so")
+
+
+def lib(fast_math=False, hooks=False):
     """Load libtracer_amd.so (fails loudly when the HIP extension has not been built); fast_math=True loads the
-    fast-math build of the same sources (libtracer_amd_fast.so) instead."""
-    global _LIB, _LIB_FAST
+    fast-math build of the same sources (libtracer_amd_fast.so) instead; hooks=True the build that also exports the test
+    hooks of include/tracer_test_hooks.h (libtracer_amd_hooks.so: tests and tools only)."""
+    global _LIB, _LIB_FAST, _LIB_HOOKS
+    if hooks:
+        if _LIB_HOOKS is None:
+            _LIB_HOOKS = _load(hooks_lib_path(), hooks=True)
+            assert _LIB_HOOKS.trc_has_test_hooks() == 1
+        return _LIB_HOOKS
     if fast_math:
         if _LIB_FAST is None:
             _LIB_FAST = _load(fast_lib_path())
@@ -44,7 +55,7 @@ def lib(fast_math=False):
     return _LIB
 
 
-def _load(path):
+def _load(path, hooks=False):
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: the HIP extension is not built "
                            f"(run `make hip` or __graft_entry__.build()); there is no CPU fallback")
@@ -80,29 +91,38 @@ def _load(path):
     L.trc_trace_rays.argtypes = [vp, vp, C.c_size_t, vp, C.c_int]
     L.trc_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
     L.trc_reset_stats.argtypes = [vp]
-    L.trc_debug_profile.argtypes = [vp, C.POINTER(C.c_uint64), u32]
     L.trc_sppm_init.argtypes = [vp, u64]
     L.trc_sppm_frames.argtypes = [vp, u32]
     L.trc_sppm_download.argtypes = [vp, vp, vp, vp, vp, C.POINTER(abi.Complex)]
-    L.trc_sppm_hash_cells.argtypes = [vp, vp, C.c_size_t, C.c_float, vp]
     L.trc_device_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
     L.trc_group_unique_id.argtypes = [C.POINTER(C.c_uint8)]
     L.trc_group_init.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int, C.c_int]
     L.trc_group_reduce_accum.argtypes = [vp, C.c_int]
     L.trc_group_reduce_accum_async.argtypes = [vp, C.c_int]
     L.trc_group_allreduce_mean_accum.argtypes = [vp]
+    L.trc_group_compose_samples.argtypes = [vp, C.c_int, u32]
+    L.trc_group_compose_samples_async.argtypes = [vp, C.c_int, u32]
+    L.trc_shard_seed.argtypes = [u64, u32]
+    L.trc_device_pci_bus_id.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.trc_download_composed.argtypes = [vp, vp]
     L.trc_group_finalize.argtypes = [vp]
     L.trc_group_set_collectives.argtypes = [vp, vp, C.c_int, C.c_int]
     L.trc_debug_set.argtypes = [vp, C.c_char_p, C.c_int]
-    L.trc_div_by_test.argtypes = [vp, vp, vp, C.c_size_t, vp, vp]
     L.trc_debug_block_costs.argtypes = [vp, vp, vp, u32, C.POINTER(u32), C.POINTER(u32)]
     L.trc_debug_launch_shape.argtypes = [vp, C.POINTER(abi.LaunchShape)]
-    L.trc_unary_test.argtypes = [vp, u32, u32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(u32)]
+    if hooks:
+        L.trc_debug_profile.argtypes = [vp, C.POINTER(C.c_uint64), u32]
+        L.trc_sppm_hash_cells.argtypes = [vp, vp, C.c_size_t, C.c_float, vp]
+        L.trc_div_by_test.argtypes = [vp, vp, vp, C.c_size_t, vp, vp]
+        L.trc_unary_test.argtypes = [vp, u32, u32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(u32)]
+        for name in abi.HOOK_SYMBOLS:
+            getattr(L, name).restype = i32
+    L.trc_has_test_hooks.restype = C.c_int
     for name in abi.DEVICE_SYMBOLS:
         f = getattr(L, name)
-        if name not in ("trc_abi_version", "trc_build_flavor", "trc_status_string", "trc_last_error", "trc_destroy"):
+        if name not in ("trc_abi_version", "trc_build_flavor", "trc_has_test_hooks", "trc_status_string", "trc_last_error", "trc_destroy", "trc_shard_seed"):
             f.restype = i32
+    L.trc_shard_seed.restype = u64
     if L.trc_abi_version() != abi.TRC_ABI_VERSION:
         raise RuntimeError("libtracer_amd.so ABI version mismatch")
     return L
@@ -119,8 +139,8 @@ def group_unique_id():
 class Tracer:
     """One context per GPU (single-threaded, one HIP stream)."""
 
-    def __init__(self, device=0, fast_math=False):
-        self._L = lib(fast_math)
+    def __init__(self, device=0, fast_math=False, hooks=False):
+        self._L = lib(fast_math, hooks)
         self._h = C.c_void_p()
         st = self._L.trc_create(device, C.byref(self._h))
         if st != abi.OK:
@@ -319,8 +339,22 @@ class Tracer:
         self._check(self._L.trc_group_reduce_accum(self._h, root), "trc_group_reduce_accum")
 
     def group_allreduce_mean_accum(self):
-        """Sample sharding: mean over the ranks of their whole-frame accumulators (trc_group_allreduce_mean_accum)."""
+        """Sample sharding composed into EVERY rank's accumulator: rank-ordered sum of the ranks' whole-frame accumulators
+        over the number of ranks (trc_group_allreduce_mean_accum)."""
         self._check(self._L.trc_group_allreduce_mean_accum(self._h), "trc_group_allreduce_mean_accum")
+
+    def group_compose_samples(self, root=0, sample_groups=None):
+        """Sample sharding (tracer_abi.h): rank-ordered sum of the ranks' accumulators / sample_groups, to `root`
+        (download_composed); sample_groups defaults to the number of ranks (no tile split inside a group)."""
+        self._check(self._L.trc_group_compose_samples(self._h, root, sample_groups or 0), "trc_group_compose_samples")
+
+    def group_compose_samples_async(self, root=0, sample_groups=None):
+        self._check(self._L.trc_group_compose_samples_async(self._h, root, sample_groups or 0), "trc_group_compose_samples_async")
+
+    def pci_bus_id(self):
+        buf = C.create_string_buffer(64)
+        self._check(self._L.trc_device_pci_bus_id(self._h, buf, 64), "trc_device_pci_bus_id")
+        return buf.value.decode()
 
     def group_reduce_accum_async(self, root=0):
         """Compose on a second stream and switch to the other accumulator (see trc_group_reduce_accum_async)."""

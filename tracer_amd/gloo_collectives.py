@@ -11,18 +11,8 @@ import numpy as np
 
 from . import abi
 
-REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p)
-ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p)
-ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
-
-
-class Collectives(C.Structure):
-    """trc_collectives"""
-    _fields_ = [("user", C.c_void_p), ("host_staged", C.c_int32), ("_pad", C.c_int32),
-                ("reduce", REDUCE_FN), ("allreduce", ALLREDUCE_FN), ("allgather", ALLGATHER_FN)]
-
-
-_NP = {abi.DT_U8: np.uint8, abi.DT_U32: np.uint32, abi.DT_F32: np.float32}
+from .socket_group import (ALLGATHER_FN, ALLREDUCE_FN, ALLTOALL_FN, GATHER_FN, REDUCE_FN, Collectives,  # noqa: F401  (one ctypes mirror
+                           _NP)                                                                       # of trc_collectives)
 
 
 class GlooCollectives:
@@ -35,8 +25,9 @@ class GlooCollectives:
         self._torch, self._dist, self._group = torch, dist, group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.calls = {"reduce": 0, "allreduce": 0, "allgather": 0}
-        self._cb = (REDUCE_FN(self._reduce), ALLREDUCE_FN(self._allreduce), ALLGATHER_FN(self._allgather))
+        self.calls = {"reduce": 0, "allreduce": 0, "allgather": 0, "alltoall": 0, "gather": 0}
+        self._cb = (REDUCE_FN(self._reduce), ALLREDUCE_FN(self._allreduce), ALLGATHER_FN(self._allgather),
+                    ALLTOALL_FN(self._alltoall), GATHER_FN(self._gather))
         self.table = Collectives(None, 1, 0, *self._cb)
 
     def _view(self, buf, count, dtype):
@@ -90,4 +81,43 @@ class GlooCollectives:
             return 0
         except Exception as e:
             print(f"GlooCollectives.allgather: {e!r}", flush=True)
+            return 1
+
+    def _alltoall(self, user, buf, bytes_per_rank, stream):
+        try:
+            a = self._view(buf, bytes_per_rank * self.world, abi.DT_U8)
+            send = [self._torch.from_numpy(a[r * bytes_per_rank:(r + 1) * bytes_per_rank].copy()) for r in range(self.world)]
+            recv = [self._torch.empty(bytes_per_rank, dtype=self._torch.uint8) for _ in range(self.world)]
+            # gloo has no all_to_all: one all_gather per destination slice would move N times the data; pairwise send / recv
+            # in a fixed order (lower rank sends first) cannot deadlock
+            reqs = []
+            for p in range(self.world):
+                if p == self.rank:
+                    recv[p] = send[p]
+                    continue
+                reqs.append(self._dist.isend(send[p], dst=p, group=self._group))
+                reqs.append(self._dist.irecv(recv[p], src=p, group=self._group))
+            for q in reqs:
+                q.wait()
+            for r, t in enumerate(recv):
+                a[r * bytes_per_rank:(r + 1) * bytes_per_rank] = t.numpy()
+            self.calls["alltoall"] += 1
+            return 0
+        except Exception as e:
+            print(f"GlooCollectives.alltoall: {e!r}", flush=True)
+            return 1
+
+    def _gather(self, user, buf, bytes_per_rank, root, stream):
+        try:
+            a = self._view(buf, bytes_per_rank * self.world, abi.DT_U8)
+            mine = self._torch.from_numpy(a[self.rank * bytes_per_rank:(self.rank + 1) * bytes_per_rank].copy())
+            parts = [self._torch.empty(bytes_per_rank, dtype=self._torch.uint8) for _ in range(self.world)] if self.rank == root else None
+            self._dist.gather(mine, parts, dst=root, group=self._group)
+            if self.rank == root:
+                for r, t in enumerate(parts):
+                    a[r * bytes_per_rank:(r + 1) * bytes_per_rank] = t.numpy()
+            self.calls["gather"] += 1
+            return 0
+        except Exception as e:
+            print(f"GlooCollectives.gather: {e!r}", flush=True)
             return 1
