@@ -1896,8 +1896,11 @@ trc_status compose_samples(trc_ctx* ctx, const float* src, int root, uint32_t gr
         (void)hipFree(ctx->d_shard_in); (void)hipFree(ctx->d_shard_out); ctx->d_shard_in = ctx->d_shard_out = nullptr;
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_shard_in, total_bytes));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_shard_out, total_bytes));
-        HIP_TRY(ctx, hipMemset(ctx->d_shard_in, 0, total_bytes));
-        HIP_TRY(ctx, hipMemset(ctx->d_shard_out, 0, total_bytes));
+        // zero-filled in stream order with the first use (hipMemset runs on the NULL stream, which the context's
+        // non-blocking streams do not wait for: it could land on top of the slices copied in below)
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_shard_in, 0, total_bytes, st));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_shard_out, 0, total_bytes, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
         ctx->shard_px = slice_px; ctx->shard_nranks = N;
     }
     const size_t mine = slice_count(n_px, slice_px, me);
