@@ -3,7 +3,7 @@
 smallest normals, zeros of both signs, infinities, NaNs, operands at the edges of the guarded range, quotients that round
 up / down / to even.  The SPPM hash uses the unguarded form on operands it knows (test_gpu_sppm.py); this is the general
 one.  It is NOT wired into the render kernels: with the guards it saves 2-4 of 22 instructions per pair of
-quotients (docs/HISTORY.md section 9); `make variant DEFS=-DTRC_DIVBY_RENDER=1` builds the variant that was measured."""
+quotients (docs/HISTORY.md section 9); profiles/r05/exp_removed_variants.patch + -DTRC_DIVBY_RENDER=1 is the variant that was measured."""
 import numpy as np
 import pytest
 

@@ -53,6 +53,32 @@ def teapot_grid_scene():
     return host.HostScene(abi.SCENE_CORNELL_MESH, mesh)
 
 
+def test_scene_beyond_the_infinity_cache_4m_triangles(gpu):
+    """The operating point where "HBM" means HBM: teapot.obj x 256 = 4 020 224 triangles, 8.0 M BVH records --
+    ~0.7 GB of fat nodes and triangles against the 256 MiB Infinity Cache (profiles/r05/size_sweep.txt).  The host hands over
+    its analytic leaves and the mesh, the tree is built on the device (the reference's SAH build, trc_upload_scene_device) and
+    must be the host builder's record for record; 1920x1080 x 8 spp through it, 1 tile in 128 re-rendered by the oracle."""
+    mesh = host.Mesh.golden("teapot").replicate(16, 80.0)
+    assert mesh.n_triangles == 256 * 15704
+    scene = host.HostScene(abi.SCENE_CORNELL_MESH, mesh)                      # host leaves + host tree: the oracle's input
+    lean = host.HostScene(abi.SCENE_CORNELL_MESH, mesh, analytic_leaves_only=True)
+    gpu.upload_scene_device(lean.view, abi.TREE_SAH | abi.TREE_TRIANGLE_LEAVES)
+    got = np.frombuffer(bytes(memoryview(gpu.download_bvh())), dtype=np.uint32).reshape(-1, 16)
+    want = scene.bvh_array()
+    assert got.shape == want.shape == (2 * scene.n_leaves - 1, 16) and scene.n_leaves > 4_000_000
+    assert np.array_equal(got, want)
+    cam = host.prepare_camera(W, H)
+    gpu.set_camera(cam); gpu.set_environment((0.0, 0.0, 0.0)); gpu.resize(W, H)
+    for launch in range(2):                      # 8 spp: the persistent-workgroup kernel; the second launch in adaptive order
+        gpu.seed(0xB16); gpu.clear_accum(); gpu.reset_stats(); gpu.render(spp=8)
+    dev, st = gpu.download_accum(), gpu.stats()
+    assert st.paths == W * H * 8 and np.isfinite(dev).all() and (dev[..., 3] == 1.0).all()
+    ref, rst = po.render(scene.view, cam, W, H, host.fill_rng(0xB16, W, H), spp=8, tile_rank=0, tile_nranks=128)
+    mine = _tile_mask(128)
+    assert mine.sum() > 5000 and rst.rays > 0
+    assert np.array_equal(dev[mine].view(np.uint32), ref[mine].view(np.uint32))
+
+
 def test_config3_as_named_coatball_mis_256spp(gpu):
     """BASELINE config 3 as named: coatball.obj, traceMIS, 1920x1080 x 256 spp; 1 tile in 64 re-rendered by the oracle"""
     _check_subsample(gpu, coatball_scene(), abi.INTEGRATOR_MIS, 256, 64)

@@ -4,8 +4,8 @@ Scene::hit test hook: trc_trace_rays(..., TRC_TRACE_PRODUCTION) against the orac
 Counters are not produced by the production walk; the whole HitRecord is compared bit for bit.  The adversarial
 batches aim at the one place where a walk that reorders work across lanes could leave the reference's order: a
 primitive that is tested although the reference would already have culled its box with a freshly lowered closest hit
-(round 1's speculative round does exactly that: built as `make variant NAME=unchecked DEFS=-DTRC_SPEC_UNCHECKED` it
-fails test_adversarial_batches, 6 of 6 seeds -- profiles/r02/traversal_teeth.txt).
+(round 1's speculative round does exactly that: profiles/r05/exp_removed_variants.patch puts it back behind
+-DTRC_SPEC_UNCHECKED; built that way it fails test_adversarial_batches, 6 of 6 seeds -- profiles/r02/traversal_teeth.txt).
   * spheres LARGER than their boxes (MakeSphere inflates the radius by 1e-4, not the AABB, Tracer.mm:165-172) with an
     occluder placed between the sphere surface and the box face,
   * rays that start inside many nested / overlapping boxes,

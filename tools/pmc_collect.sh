@@ -13,4 +13,8 @@ pass sq3 SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_IFETCH SQ_C
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
+# the fabric-side requests by size (FETCH_SIZE's expression counts 128-byte requests through TCC_BUBBLE, which reads 0 on gfx950:
+# tools/probe/gather_probe.hip, profiles/r05/fetch_size_calibration.txt) and the writes the same way
+pass ea TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum
+pass eaw TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
 tail -n 1 gpurun_out/$T/trace.log | cut -c1-400

@@ -5,8 +5,13 @@ kernel, the derived figures, the workload's own JSON line and the source hash of
 
     python3 tools/pmc_summary.py <tag> <kernel-substring> <out.json>
 
-Derived (MI355X_MICROARCH.md): FETCH_SIZE / WRITE_SIZE are KB; FETCH_SIZE counts 128-B requests at 64 B on gfx950 ->
-doubled; GRBM_GUI_ACTIVE is summed over the 8 XCDs; a wave64 VALU instruction issues over 2 cycles of a SIMD-32.
+Derived (MI355X_MICROARCH.md): FETCH_SIZE / WRITE_SIZE are KB; GRBM_GUI_ACTIVE is summed over the 8 XCDs; a wave64 VALU
+instruction issues over 2 cycles of a SIMD-32.
+L2-miss traffic (`l2_miss_*`): bytes the L2s request from / write to the fabric -- Infinity-Cache hits INCLUDED (the counters sit
+on the L2's memory side; TCC_EA0_RDREQ_DRAM counts the same requests whether the table fits the Infinity Cache or not,
+profiles/r05/fetch_size_calibration.txt), so it bounds HBM traffic from above and equals it only for working sets far beyond
+256 MiB.  Reads = 32 / 64 / 128 bytes x the sized request counters when they were collected (on gfx950 every read request of
+this path's gathers is 128 bytes, and FETCH_SIZE tallies them at 64: TCC_BUBBLE reads 0), else 2 x FETCH_SIZE.
 """
 import collections, csv, glob, hashlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -59,10 +64,20 @@ if last_n:                                  # the same launches' durations from 
             res["kernel_ms"] = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr) / len(tr) / 1e6
             res["kernel_ms_launches"] = len(tr)
 res["kernel_stats_row"] = stats_row
-if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
-    res["hbm_bytes_per_launch"] = int((2 * res["FETCH_SIZE"] + res["WRITE_SIZE"]) * 1024)
-    res["hbm_gbs"] = res["hbm_bytes_per_launch"] / res["kernel_ms"] / 1e6
-    res["hbm_physical_frac"] = res["hbm_gbs"] / 8000.0
+rd = None
+if all(k in res for k in ("TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum")):
+    rd = 32 * res["TCC_EA0_RDREQ_32B_sum"] + 64 * res["TCC_EA0_RDREQ_64B_sum"] + 128 * res["TCC_EA0_RDREQ_128B_sum"]
+    res["l2_miss_read_source"] = "TCC_EA0_RDREQ_{32B,64B,128B}_sum"
+elif "FETCH_SIZE" in res:
+    rd = 2 * res["FETCH_SIZE"] * 1024
+    res["l2_miss_read_source"] = "2 x FETCH_SIZE"
+if rd is not None and "WRITE_SIZE" in res:
+    res["l2_miss_read_bytes_per_launch"] = int(rd)
+    res["l2_miss_write_bytes_per_launch"] = int(res["WRITE_SIZE"] * 1024)
+    res["l2_miss_bytes_per_launch"] = int(rd + res["WRITE_SIZE"] * 1024)
+    res["l2_miss_gbs"] = res["l2_miss_bytes_per_launch"] / res["kernel_ms"] / 1e6
+    res["l2_miss_frac_of_hbm_peak"] = res["l2_miss_gbs"] / 8000.0
+    res["hbm_bytes_per_launch"] = res["l2_miss_bytes_per_launch"]      # the name rounds 1-4 used (an upper bound of HBM traffic: Infinity-Cache hits included)
 if "GRBM_GUI_ACTIVE" in res and "SQ_INSTS_VALU" in res:
     cyc = res["GRBM_GUI_ACTIVE"] / 8.0
     res["shader_cycles_per_launch"] = cyc

@@ -69,9 +69,6 @@ TRC_DEV float sqr(float v) { return v * v; }
 // the quotients' own corrections, operand guards as one wave-uniform range test (dev_vec.hpp: GuardedDivBy / div_core) --
 // the same bits as the two divisions (tests/test_gpu_divby.py), which is what everybody computes when some lane's operand is
 // outside [2^-60, 2^60] (a direction along the normal: sin_theta == 0)
-#ifndef TRC_PHI_PAIR
-#define TRC_PHI_PAIR 1
-#endif
 struct Phi { float c, s; };
 // st = sin_theta(w), which the callers share with tan_theta (the same square root: 1 - z * z where that is positive)
 TRC_DEV float tan_theta_st(F3 v, float st) {
@@ -81,7 +78,7 @@ TRC_DEV float tan_theta_st(F3 v, float st) {
 }
 TRC_DEV Phi phi_of(F3 w, float st) {
     Phi ph;
-#if TRC_PHI_PAIR && TRC_WAVE_GUARDS
+#if TRC_WAVE_GUARDS
     const GuardedDivBy by = guarded_div_by(st);
     float qc = div_core(w.x, by), qs = div_core(w.y, by);
     const float small = fmin3(fabsf(w.x), fabsf(w.y), st), large = fmax3(fabsf(w.x), fabsf(w.y), st);
@@ -137,9 +134,6 @@ TRC_DEV float erf_approx(float x) {
     return sign * y;
 }
 
-#ifndef TRC_FRCOND_RANGE
-#define TRC_FRCOND_RANGE 1
-#endif
 // ---------------------------------------------------------------- BXDF.hh / BXDF.metal
 TRC_DEV F3 reflect(F3 wo, F3 n) { return -wo + 2 * dot(wo, n) * n; }             // BXDF.hh:24-26
 TRC_DEV bool refract(F3 wo, F3 n, float eta, F3& wi) {                            // BXDF.hh:28-41 (cos from wo.z, B-6)
@@ -169,7 +163,7 @@ TRC_DEV F3 fr_conductor(float cosi, F3 eta, F3 k) {                             
     const F3 n1 = tmp - (2.f * eta * cosi) + f3(1), d1 = tmp + (2.f * eta * cosi) + f3(1);
     F3 tmp_f = eta * eta + k * k;
     const F3 n2 = tmp_f - (2.f * eta * cosi) + f3(cosi * cosi), d2 = tmp_f + (2.f * eta * cosi) + f3(cosi * cosi);
-#if TRC_FRCOND_RANGE && TRC_WAVE_GUARDS
+#if TRC_WAVE_GUARDS
     if (METAL_CONSTANTS) {
     // MetalMaterial's constants (eta <= 0.81, k = 1) and 0 <= cosi <= 2 put all twelve operands into [0.5, 16]:
     // n1 = (eta^2 + 1) c^2 - 2 eta c + 1 >= 1 / (eta^2 + 1), n2 = (c - eta)^2 + 1 >= 1, the denominators are sums of
@@ -647,8 +641,8 @@ TRC_DEV F3 material_S_F(int type, F3 color, F3 wo, F3& wi, F2 uu, float& pdf, Tr
     return out;
 }
 TRC_DEV F3 material_S_F(int type, F3 color, F3 wo, F3& wi, F2 uu, float& pdf) {
-    TravCounters* none = nullptr;
-    return material_S_F<false>(type, color, wo, wi, uu, pdf, *none);     // never dereferenced when STATS = false
+    TravCounters none;                                                    // STATS = false: nobody touches it, the compiler drops it
+    return material_S_F<false>(type, color, wo, wi, uu, pdf, none);
 }
 
 // Material::F, Material.hh:77-99 (pdf = bx.PDF, value = color * bx.F)

@@ -421,7 +421,7 @@ TRC_DEV bool mis_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, T
     const Ray _ray = make_ray(_origin, _nor);
     n_rays++;
     bool blocked;
-    if (STATS || !TRC_ANYHIT_FREE) {                                  // the reference's walk (the exact counters are defined on it)
+    if (STATS) {                                  // the reference's walk (the exact counters are defined on it)
         HitRec shr;
         hit_init(shr);
         blocked = scene_hit<ALL_LDS, STATS, true, false, false, HYB>(cx.S, cx.root_min, cx.root_max, _ray, shr, _dis, cx.stack, cx.lvstack, cnt);

@@ -129,9 +129,6 @@ TRC_DEV bool box_hit_t(F3 mn, F3 mx, const Ray& r, float rx, float ry, float& t)
 // Math.hh:51-55: gamma(3) with MachineEpsilon = FLT_EPSILON * 0.5 (unparenthesised macro)
 TRC_DEV float box_pad() { return 1 + 2 * ((3 * FLT_EPSILON * 0.5f) / (1 - 3 * FLT_EPSILON * 0.5f)); }
 
-#ifndef TRC_CUBE_DIV
-#define TRC_CUBE_DIV 1
-#endif
 // AABB.hh:114-209: object-space box test of Cube; o/d are the object-space ray (d normalised)
 TRC_DEV bool box_hit_record(F3 mini, F3 maxi, F3 o, F3 d, float range_y, float& out_t, F3& out_gn, F3& out_p, F2& out_uv) {
     float tmin = -FLT_MAX;
@@ -140,7 +137,7 @@ TRC_DEV bool box_hit_record(F3 mini, F3 maxi, F3 o, F3 d, float range_y, float& 
     const F3 ddd = o - mini, bbb = o - maxi;
     const float pad = box_pad();
     const bool inside = (ddd.x > 0 && ddd.y > 0 && ddd.z > 0) && (bbb.x < 0 && bbb.y < 0 && bbb.z < 0);
-#if TRC_CUBE_DIV && TRC_WAVE_GUARDS
+#if TRC_WAVE_GUARDS
     // the six slab quotients share three divisors: reciprocal + Newton step once per axis, the quotients' own corrections,
     // no operand guards -- unless some lane's operand is outside [2^-60, 2^60] (a direction component that is 0 or tiny, an
     // origin ON a slab plane), then everybody divides the long way.  Same bits either way (tests/test_gpu_divby.py).
@@ -160,14 +157,10 @@ TRC_DEV bool box_hit_record(F3 mini, F3 maxi, F3 o, F3 d, float range_y, float& 
 #pragma unroll
     for (uint32_t i = 0; i < 3; ++i) {
         float oi = comp(o, i), di = comp(d, i);
-#if TRC_CUBE_DIV && TRC_WAVE_GUARDS
+#if TRC_WAVE_GUARDS
         (void)oi; (void)di;
         float min_bound = comp(qlo, i);
         float max_bound = comp(qhi, i);
-#elif TRC_DIVBY_RENDER
-        const GuardedDivBy by = guarded_div_by(di);
-        float min_bound = guarded_div(comp(mini, i) - oi, by);
-        float max_bound = guarded_div(comp(maxi, i) - oi, by);
 #else
         float min_bound = (comp(mini, i) - oi) / di;
         float max_bound = (comp(maxi, i) - oi) / di;
@@ -453,18 +446,15 @@ struct Trav {
 // waves/SIMD).
 // Almost every access of a wavefront is below stack_lds in all of its lanes: ONE wave-uniform test (a ballot) keeps the
 // per-lane if / else -- six scalar mask instructions and two branches per access -- out of the box-step loop.
-#ifndef TRC_STACK_UNIFORM
-#define TRC_STACK_UNIFORM 1
-#endif
 template <bool HYB>
 TRC_DEV void stack_put(const SceneRef& S, uint32_t* stack, uint32_t e, uint32_t v) {
-    if (!HYB || (TRC_STACK_UNIFORM && __builtin_expect(__builtin_amdgcn_ballot_w64(e >= S.stack_lds) == 0ull, 1))) { stack[e * kBlock] = v; return; }
+    if (!HYB || (__builtin_expect(__builtin_amdgcn_ballot_w64(e >= S.stack_lds) == 0ull, 1))) { stack[e * kBlock] = v; return; }
     if (e < S.stack_lds) stack[e * kBlock] = v;
     else st1_global(S.ovf + (e - S.stack_lds) * kBlock, v);
 }
 template <bool HYB>
 TRC_DEV uint32_t stack_get(const SceneRef& S, const uint32_t* stack, uint32_t e) {
-    if (!HYB || (TRC_STACK_UNIFORM && __builtin_expect(__builtin_amdgcn_ballot_w64(e >= S.stack_lds) == 0ull, 1))) return stack[e * kBlock];
+    if (!HYB || (__builtin_expect(__builtin_amdgcn_ballot_w64(e >= S.stack_lds) == 0ull, 1))) return stack[e * kBlock];
     if (e < S.stack_lds) return stack[e * kBlock];
     return ld1_global(S.ovf + (e - S.stack_lds) * kBlock);
 }
@@ -506,8 +496,7 @@ TRC_DEV bool trav_begin(const F3 root_min, const F3 root_max, const Ray& ray, co
     return true;
 }
 
-// leaf test of one primitive tag; returns true when the hit was accepted (tv.ry lowered).  `pre`: the triangle's positions
-// when the caller fetched them ahead (TRC_TRI_EARLY), else null.
+// leaf test of one primitive tag; returns true when the hit was accepted (tv.ry lowered).
 //
 // DEFER (production closest-hit walks): "test now, build the record for the winner afterwards".  The reference writes
 // the whole HitRecord at every accepted test (15 dwords that then stay live across the latency-bound loop: the mesh
@@ -522,7 +511,7 @@ TRC_DEV bool trav_begin(const F3 root_min, const F3 root_max, const Ray& ray, co
 // instructions and not registers are what is short): an accepted cube writes the record at once as before, and the replay
 // after the walk leaves such a winner's record alone.
 template <bool STATS, bool EAGER_UV, bool VOL, int DEFER = 0>
-TRC_DEV bool trav_test_leaf(const SceneRef& S, const Ray& ray, HitRec& rec, Trav& tv, uint32_t tag, TravCounters& cnt, const TriPos* pre = nullptr) {
+TRC_DEV bool trav_test_leaf(const SceneRef& S, const Ray& ray, HitRec& rec, Trav& tv, uint32_t tag, TravCounters& cnt) {
     const float rx = FLT_MIN;
     const uint32_t type = tag >> kTagIndexBits, index = tag & kTagIndexMask;
     bool ok;
@@ -546,8 +535,7 @@ TRC_DEV bool trav_test_leaf(const SceneRef& S, const Ray& ray, HitRec& rec, Trav
     } else {
         if (STATS) cnt.leaf[3]++;
         ProfScope<STATS> scope(cnt, kProfTriangle);
-        ok = pre ? triangle_hit_test<STATS>(S, index, *pre, ray, rx, tv.ry, out, cnt)
-                 : triangle_hit_test<STATS>(S, index, load_tripos(S, index), ray, rx, tv.ry, out, cnt);
+        ok = triangle_hit_test<STATS>(S, index, load_tripos(S, index), ray, rx, tv.ry, out, cnt);
     }
     if (ok) {
         if (DEFER) { tv.win_tag = tag; tv.win_ry = ry_seen; }
@@ -590,54 +578,11 @@ TRC_DEV void trav_build_record(const SceneRef& S, const Ray& ray, HitRec& rec, c
 // tests/test_gpu_traversal.py constructs the case and the speculative round fails it).  A checked form (snapshot +
 // rollback when the postponed test accepts) is exact but slower than the plain round (measured: 23.9 / 75.5 / 39.3 ms
 // against 22.6 / 77.8 / 40.9 plain and 22.7 / 70.8 / 35.7 for the threshold round); the unchecked one survives only as
-// the A/B variant TRC_SPEC_UNCHECKED, the build that must FAIL the adversarial test.
+// profiles/r05/exp_removed_variants.patch, the build that must FAIL the adversarial test.
 template <bool ALL_LDS, bool STATS, bool ANY, bool EAGER_UV, bool VOL = false, bool HYB = false, int DEFER = 0>
 TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const float test_t, Trav& tv,
                        uint32_t* stack, uint32_t* lvstack, TravCounters& cnt) {
     const float rx = FLT_MIN;
-#ifdef TRC_SPEC_UNCHECKED
-    if (!STATS) {
-        uint32_t pend = kTagNone;                      // postponed leaf
-        auto pop_next = [&]() {                        // next deferred sibling, or "exhausted" (kTagNone)
-            if (tv.sp == 0) { tv.tag = kTagNone; return; }
-            tv.sp--;
-            tv.tag = stack_get<HYB>(S, stack, tv.sp);
-        };
-        for (;;) {
-            const bool interior = (tv.tag >> kTagIndexBits) == kTagInterior;
-            if (__ballot(interior) == 0ull) break;
-            if (interior) {
-                float4 q0, q1, q2, q3;
-                load_node<ALL_LDS>(S, tv.tag & kTagIndexMask, q0, q1, q2, q3);
-                float t_left = tv.ry, t_right = tv.ry;
-                const bool left_test = box_hit_t(f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), ray, rx, tv.ry, t_left);
-                const bool right_test = box_hit_t(f3(q1.z, q1.w, q2.x), f3(q2.y, q2.z, q2.w), ray, rx, tv.ry, t_right);
-                if (left_test || right_test) {
-                    const uint32_t tagL = __float_as_uint(q3.z), tagR = __float_as_uint(q3.w);
-                    const bool left_first = t_left < t_right;
-                    if (left_test && right_test) { stack_put<HYB>(S, stack, tv.sp, left_first ? tagR : tagL); tv.sp++; }
-                    tv.tag = left_first ? tagL : tagR;
-                } else {
-                    pop_next();
-                }
-                if (pend == kTagNone && (tv.tag >> kTagIndexBits) < kTagInterior) { pend = tv.tag; pop_next(); }
-            }
-        }
-        if (!tv.is_done() || pend != kTagNone) {
-            if (pend == kTagNone && (tv.tag >> kTagIndexBits) < kTagInterior) { pend = tv.tag; pop_next(); }
-            if (pend != kTagNone) {
-                trav_test_leaf<STATS, EAGER_UV, VOL, DEFER>(S, ray, rec, tv, pend, cnt);
-                if (ANY && tv.ry < test_t) tv.finish();                          // Render.hh:244
-            }
-            if ((tv.tag >> kTagIndexBits) < kTagInterior) {                      // second leaf, found after the first
-                trav_test_leaf<STATS, EAGER_UV, VOL, DEFER>(S, ray, rec, tv, tv.tag, cnt);
-                if (ANY && tv.ry < test_t) tv.finish();
-                else pop_next();
-            }
-        }
-        return;
-    }
-#endif
 #ifndef TRC_DESCEND_MIN_LDS
 #define TRC_DESCEND_MIN_LDS 1
 #endif
@@ -645,19 +590,6 @@ TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const flo
 #define TRC_DESCEND_MIN_GLOBAL 12     // 8 until the loop lost its done flag; with the leaner step: 8 / 12 / 16 / 24 / 32 = 23.54 / 23.22 / 23.32 / 23.63 / 24.07 ms (config 4), 40.85 / 40.49 / 40.56 / 40.90 / 41.19 (config 3)
 #endif
     constexpr int kDescendMin = ALL_LDS ? TRC_DESCEND_MIN_LDS : TRC_DESCEND_MIN_GLOBAL;
-    // TRC_TRI_EARLY (trees read from memory, production walk): the moment a lane's next stop becomes a triangle, its 48
-    // bytes of positions are requested, so the fetch runs beside the box steps the rest of the wavefront still takes
-    // instead of starting when the leaf phase does.  Same data, same test.
-#ifndef TRC_TRI_EARLY
-#define TRC_TRI_EARLY 0
-#endif
-    constexpr bool kTriEarly = TRC_TRI_EARLY && !ALL_LDS && !STATS;
-    TriPos pre;
-    bool have_pre = false;
-    auto fetch_ahead = [&]() {
-        if (kTriEarly && (tv.tag >> kTagIndexBits) == 3u) { pre = load_tripos(S, tv.tag & kTagIndexMask); have_pre = true; }
-    };
-    fetch_ahead();                 // a leaf popped at the end of the previous round
     for (;;) {
         const bool interior = (tv.tag >> kTagIndexBits) == kTagInterior;
         if (!STATS && kDescendMin > 1) {
@@ -686,10 +618,9 @@ TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const flo
         } else {
             trav_pop_or_finish<HYB, STATS>(S, tv, tv.level - 1, stack, lvstack, cnt);
         }
-        fetch_ahead();
     }
     if ((tv.tag >> kTagIndexBits) < kTagInterior) {
-        trav_test_leaf<STATS, EAGER_UV, VOL, DEFER>(S, ray, rec, tv, tv.tag, cnt, (kTriEarly && have_pre) ? &pre : nullptr);
+        trav_test_leaf<STATS, EAGER_UV, VOL, DEFER>(S, ray, rec, tv, tv.tag, cnt);
         if (ANY && tv.ry < test_t) tv.finish();                       // Render.hh:244
         else trav_pop_or_finish<HYB, STATS>(S, tv, tv.level, stack, lvstack, cnt);
     }
@@ -714,25 +645,17 @@ TRC_DEV bool scene_hit(const SceneRef& S, const F3 root_min, const F3 root_max, 
 // against the same fixed range -- the set of boxes that pass and the answer do not depend on the visiting order (which
 // primitive is found first does; no caller of the any-hit form reads the record: Render.metal:335-337) -- with one
 // exception that is kept, the pick between the children when only one box passes (below).  The
-// production kernels therefore walk shadow rays in whatever order hides latency best: a lane holds up to TWO pending
-// subtrees in hand (the deepest ones, like a depth-first walk) and expands both in one step -- two independent node
-// fetches in flight per lane, four box tests, half the dependent round trips of the one-node-at-a-time walk; no hit_t,
-// no near / far ordering, no HitRecord.  The instrumented kernels keep the reference's walk (their counters are defined
-// on it), and tests/test_gpu_traversal.py compares the two on the adversarial batches.
-// Pending subtrees beyond the two in hand go to the lane's stack; two fronts can leave up to two entries per level
-// there, twice what the stack is sized for, so a lane whose stack fills up starts over one node at a time (`wide` off:
-// at most one entry per level, the depth the stack is sized for).  Same answer: the order is free.
+// production kernels therefore walk shadow rays in whatever order hides latency best: left-first, so that the shadow rays of
+// a wavefront walk together; no hit_t, no near / far ordering, no HitRecord.  (Two subtrees in hand per lane -- two independent
+// node fetches in flight, half the dependent round trips -- cost the MIS kernels 31 spilled registers and measured slower; nearest
+// child first measured the same: profiles/r05/exp_removed_variants.patch.)  The instrumented kernels keep the reference's walk
+// (their counters are defined on it), and tests/test_gpu_traversal.py compares the two on the adversarial batches.
+// Boxes that pass beyond the one in hand go to the lane's stack, one entry per level at most -- the depth it is sized for.
 // Two corners of the reference's arithmetic are kept.  A square or a triangle met at EXACTLY t == test_t is "accepted" by
 // its hit_test (Square.hh / Triangle.hh reject only t > range_t.y) but leaves range_t.y where it was, so Scene::hit does
 // not report it (range_t.y < test_t, Render.hh:244,250): not an occluder here either.  And an accepted test whose t is
 // NaN (overflowing coordinates) makes range_t.y NaN, after which every later test of the reference's walk passes and
 // the answer does depend on the order: such a ray is handed back to the reference's walk (return value 2).
-#ifndef TRC_ANYHIT_FREE
-#define TRC_ANYHIT_FREE 1        // production kernels: shadow rays through scene_occluded (0: the reference's walk everywhere)
-#endif
-#ifndef TRC_ANYHIT_WIDE
-#define TRC_ANYHIT_WIDE 0        // 1: two subtrees in hand (measured slower: the second node costs the MIS kernels 31 spilled registers)
-#endif
 enum : uint32_t { kOccludedNo = 0u, kOccludedYes = 1u, kOccludedAskReference = 2u };
 template <bool ALL_LDS, bool VOL, bool HYB>
 TRC_DEV uint32_t scene_occluded_free(const SceneRef& S, const F3 root_min, const F3 root_max, const Ray& ray, const float test_t,
@@ -742,8 +665,8 @@ TRC_DEV uint32_t scene_occluded_free(const SceneRef& S, const F3 root_min, const
     if (!trav_begin<false>(root_min, root_max, ray, test_t, tb, nocount)) return kOccludedNo;
     const float rx = FLT_MIN;
     constexpr uint32_t kRoot = kTagInterior << kTagIndexBits;
-    uint32_t cur0 = kRoot, cur1 = kTagNone, sp = 0;
-    bool wide = TRC_ANYHIT_WIDE != 0, found = false, ask_reference = false;
+    uint32_t cur0 = kRoot, sp = 0;
+    bool found = false, ask_reference = false;
     HitRec rec;                                   // written by the primitive tests, read by nobody
     hit_init(rec);
     auto is_interior = [](uint32_t tag) { return tag != kTagNone && (tag >> kTagIndexBits) == kTagInterior; };
@@ -752,29 +675,26 @@ TRC_DEV uint32_t scene_occluded_free(const SceneRef& S, const F3 root_min, const
     auto give = [&](uint32_t tag) {               // a box that passed: into the hand, else onto the stack
         if (restarted) return;
         if (cur0 == kTagNone) cur0 = tag;
-        else if (wide && cur1 == kTagNone) cur1 = tag;
         else if (sp < stack_cap) { stack_put<HYB>(S, stack, sp, tag); sp++; }
-        else { wide = false; restarted = true; sp = 0; cur0 = kRoot; cur1 = kTagNone; }      // stack full: start over, one node at a time
+        else { restarted = true; sp = 0; cur0 = kRoot; }                                      // cannot happen on a tree of the depth the stack is sized for
     };
 #ifndef TRC_OCCL_DESCEND_MIN
 #define TRC_OCCL_DESCEND_MIN 1      // plain round: shadow rays of a wavefront walk left-first, i.e. together (1 / 4 / 8 / 16 / 32: 50.9 / 50.9 / 51.3 / 52.1 / 53.1 ms on config 3)
 #endif
     constexpr int kDescendMin = ALL_LDS ? TRC_DESCEND_MIN_LDS : TRC_OCCL_DESCEND_MIN;
     for (;;) {
-        // ---- box steps: every lane with an interior node in hand expands it (both of them when it holds two)
+        // ---- box steps: every lane with an interior node in hand expands it
         for (;;) {
-            const bool i0 = is_interior(cur0), i1 = is_interior(cur1);
-            const unsigned long long m = __ballot(i0 || i1);
+            const bool i0 = is_interior(cur0);
+            const unsigned long long m = __ballot(i0);
             if (m == 0ull) break;
-            if (__popcll(m) < kDescendMin && __ballot(is_leaf(cur0) || is_leaf(cur1)) != 0ull) break;
-            if (!(i0 || i1)) continue;
-            float4 a0, a1, a2, a3, b0, b1, b2, b3;
-            const uint32_t t0 = cur0, t1 = cur1;
+            if (__popcll(m) < kDescendMin && __ballot(is_leaf(cur0)) != 0ull) break;
+            if (!i0) continue;
+            float4 a0, a1, a2, a3;
+            const uint32_t t0 = cur0;
             restarted = false;
-            if (i0) load_node<ALL_LDS>(S, t0 & kTagIndexMask, a0, a1, a2, a3);
-            if (i1) load_node<ALL_LDS>(S, t1 & kTagIndexMask, b0, b1, b2, b3);
-            if (i0) cur0 = kTagNone;
-            if (i1) cur1 = kTagNone;
+            load_node<ALL_LDS>(S, t0 & kTagIndexMask, a0, a1, a2, a3);
+            cur0 = kTagNone;
             // both children pass: both are walked, in any order.  ONE passes: the reference still picks by
             // (t_left < t_right) with the other side's t left at range_t.y (Render.hh:161-174) -- a lone child entered at
             // exactly t == range_t.y loses to its sibling, whose box did NOT pass, and is never visited.  Kept literally.
@@ -783,40 +703,27 @@ TRC_DEV uint32_t scene_occluded_free(const SceneRef& S, const F3 root_min, const
                 const bool l = box_hit_t(f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y), ray, rx, test_t, t_left);
                 const bool r = box_hit_t(f3(q1.z, q1.w, q2.x), f3(q2.y, q2.z, q2.w), ray, rx, test_t, t_right);
                 const uint32_t tagL = __float_as_uint(q3.z), tagR = __float_as_uint(q3.w);
-#if defined(TRC_ANYHIT_NEAR)
-                if (l && r) { if (t_left < t_right) { give(tagL); give(tagR); } else { give(tagR); give(tagL); } }
-#else
                 if (l && r) { give(tagL); give(tagR); }
-#endif
                 else if (l || r) give(t_left < t_right ? tagL : tagR);
             };
-            if (i0) expand(a0, a1, a2, a3);
-            if (i1 && wide) expand(b0, b1, b2, b3);
-            // refill the hand from the stack (deepest pending subtrees first)
+            expand(a0, a1, a2, a3);
+            // refill the hand from the stack (deepest pending subtree first)
             if (restarted) continue;
             if (cur0 == kTagNone && sp > 0u) { sp--; cur0 = stack_get<HYB>(S, stack, sp); }
-            if (wide && cur1 == kTagNone && sp > 0u) { sp--; cur1 = stack_get<HYB>(S, stack, sp); }
         }
-        // ---- primitive tests: the leaves in hand, one after the other
-#pragma unroll 1
-        for (int k = 0; k < 2; ++k) {
-            const uint32_t tag = k == 0 ? cur0 : cur1;
-            const bool leaf = !found && is_leaf(tag);
-            if (__ballot(leaf) == 0ull) continue;
-            if (leaf) {
-                Trav tv;
-                tv.ry = test_t;
-                if (trav_test_leaf<false, false, VOL>(S, ray, rec, tv, tag, nocount)) {
-                    if (tv.ry < test_t) found = true;                 // Render.hh:244
-                    else if (!(tv.ry == test_t)) { found = true; ask_reference = true; }      // NaN: the order matters from here on
-                }
-                if (k == 0) cur0 = kTagNone; else cur1 = kTagNone;
+        // ---- primitive test: the leaf in hand
+        if (!found && is_leaf(cur0)) {
+            Trav tv;
+            tv.ry = test_t;
+            if (trav_test_leaf<false, false, VOL>(S, ray, rec, tv, cur0, nocount)) {
+                if (tv.ry < test_t) found = true;                 // Render.hh:244
+                else if (!(tv.ry == test_t)) { found = true; ask_reference = true; }      // NaN: the order matters from here on
             }
+            cur0 = kTagNone;
         }
-        if (found) { cur0 = cur1 = kTagNone; sp = 0; }
+        if (found) { cur0 = kTagNone; sp = 0; }
         if (cur0 == kTagNone && sp > 0u) { sp--; cur0 = stack_get<HYB>(S, stack, sp); }
-        if (wide && cur1 == kTagNone && sp > 0u) { sp--; cur1 = stack_get<HYB>(S, stack, sp); }
-        if (__ballot(cur0 != kTagNone || cur1 != kTagNone) == 0ull) break;
+        if (__ballot(cur0 != kTagNone) == 0ull) break;
     }
     return ask_reference ? kOccludedAskReference : (found ? kOccludedYes : kOccludedNo);
 }

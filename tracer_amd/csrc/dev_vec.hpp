@@ -49,20 +49,10 @@ TRC_DEV F3 cross(F3 a, F3 b) { return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x 
 #endif
 #if defined(__HIP_DEVICE_COMPILE__) && TRC_FAST_UNARY && !defined(TRC_FAST_MATH)
 #define TRC_WAVE_GUARDS 1
-#ifndef TRC_RANGE_CMP2
-#define TRC_RANGE_CMP2 1
-#endif
 TRC_DEV bool unary_in_range(float x) {            // 2^-60 <= |x| < 2^60 (exponent field 67 .. 186)
-#if TRC_RANGE_CMP2
     return fabsf(x) >= 0x1p-60f && fabsf(x) < 0x1p60f;      // two compares with |x| as a source modifier (NaN fails both)
-#else
-    return ((__float_as_uint(x) & 0x7FFFFFFFu) - 0x21800000u) < (0x5D800000u - 0x21800000u);
-#endif
 }
 TRC_DEV bool wave_all(bool ok) { return __builtin_amdgcn_ballot_w64(!ok) == 0ull; }
-#ifndef TRC_RCP_STEPS
-#define TRC_RCP_STEPS 1
-#endif
 // the compiler's sequence for 1.0f / x without v_div_scale / v_div_fmas' scaling / v_div_fixup -- and without its LAST residual
 // correction: over every operand of the guarded range the Newton step and ONE correction already give the correctly rounded
 // reciprocal (exhaustive test, op 0; TRC_RCP_STEPS=2 keeps both)
@@ -70,11 +60,7 @@ TRC_DEV float rcp_core(float x) {
     const float r0 = __builtin_amdgcn_rcpf(x);
     const float r1 = __builtin_fmaf(__builtin_fmaf(-x, r0, 1.0f), r0, r0);
     const float q1 = __builtin_fmaf(__builtin_fmaf(-x, r1, 1.0f), r1, r1);
-#if TRC_RCP_STEPS >= 2
-    return __builtin_fmaf(__builtin_fmaf(-x, q1, 1.0f), r1, q1);
-#else
     return q1;
-#endif
 }
 // (both corrections are needed on this hardware: over the 2^30 in-range operands v_sqrt_f32 alone is wrong 152 127 120 times,
 // one ulp low in all but 58 920 of them -- measured with the test hook)
@@ -92,40 +78,20 @@ TRC_DEV float sqrt_core(float x) {                // ... for sqrtf(x) without th
 // TRC_RCP_GUARD_CLASS: the guard reads v_rcp_f32's own result -- "a normal number" is ONE v_cmp_class, and it is false exactly
 // for the operands the core cannot serve (0 and denormals: inf; inf: 0; above 2^126: a denormal, flushed; NaN: NaN).  It hangs
 // on the core's FIRST instruction only, so the branch still finds its condition long before the chain ends.
-#ifndef TRC_RCP_GUARD_CLASS
-#define TRC_RCP_GUARD_CLASS 1
-#endif
 TRC_DEV float rcp_cr(float x) {
-#if TRC_RCP_GUARD_CLASS
     const float r0 = __builtin_amdgcn_rcpf(x);
     const float r1 = __builtin_fmaf(__builtin_fmaf(-x, r0, 1.0f), r0, r0);
     float r = __builtin_fmaf(__builtin_fmaf(-x, r1, 1.0f), r1, r1);
     if (__builtin_expect(!wave_all(__builtin_amdgcn_classf(r0, 0x108)), 0)) r = 1.0f / x;
     return r;
-#else
-    float r = rcp_core(x);
-    if (__builtin_expect(!wave_all(unary_in_range(x)), 0)) r = 1.0f / x;
-    return r;
-#endif
 }
 // sqrt_core is exact for every operand from 2^-60 up, +inf included (exhaustive test; below ~2^-100 the residuals of the two
 // candidates underflow): ONE compare, which a NaN fails.  1 / sqrt needs the upper bound as well (1 / sqrt(inf) is not the core's).
-#ifndef TRC_SQRT_GUARD1
-#define TRC_SQRT_GUARD1 1
-#endif
 TRC_DEV bool sqrt_in_range(float x) {
-#if TRC_SQRT_GUARD1
     return x >= 0x1p-60f;
-#else
-    return unary_in_range(x) && x > 0.0f;
-#endif
 }
 TRC_DEV bool rsqrt_in_range(float x) {
-#if TRC_SQRT_GUARD1
     return x >= 0x1p-60f && x < 0x1p60f;
-#else
-    return unary_in_range(x) && x > 0.0f;
-#endif
 }
 TRC_DEV float sqrt_cr(float x) {
     float r = sqrt_core(x);
@@ -144,15 +110,8 @@ TRC_DEV float rcp_cr(float x) { return 1.0f / x; }
 TRC_DEV float sqrt_cr(float x) { return sqrtf(x); }
 TRC_DEV float rsqrt_cr(float x) { return 1.0f / sqrtf(x); }
 #endif
-#ifndef TRC_RCP_SITES
-#define TRC_RCP_SITES 1
-#endif
 TRC_DEV float rcp1(float x) {                     // the shading code's `1 / x`
-#if TRC_RCP_SITES
     return rcp_cr(x);
-#else
-    return 1.0f / x;
-#endif
 }
 // x / c for a divisor known when the code is written (pi in the cosine lobe, the squared roughnesses in the microfacet
 // distributions): the reciprocal is a constant too, so the quotient is the product and ONE residual correction -- 3 instructions
@@ -169,16 +128,9 @@ TRC_DEV float div_const_core(float x, const DivConst& d) {
 }
 // (TRC_DIVCONST_GUARD_CLASS=1 -- "the product x * y is a normal number", one v_cmp_class -- is NOT enough: the exhaustive test
 // finds numerators whose product is normal but whose residual underflows; the range test stays)
-#ifndef TRC_DIVCONST_GUARD_CLASS
-#define TRC_DIVCONST_GUARD_CLASS 0
-#endif
 #if TRC_WAVE_GUARDS
 TRC_DEV bool div_const_ok(float x, const DivConst& d) {
-#if TRC_DIVCONST_GUARD_CLASS
-    return __builtin_amdgcn_classf(x * d.y, 0x108);
-#else
     return unary_in_range(x);
-#endif
 }
 #endif
 TRC_DEV float div_const(float x, const DivConst& d) {
@@ -202,7 +154,6 @@ TRC_DEV void div_const2(float x0, const DivConst& d0, float x1, const DivConst& 
 TRC_DEV float div_pi(float x) { return div_const(x, div_by_pi()); }
 TRC_DEV F3 rcp_cr(F3 a) {                         // 1 / direction: one wave-level branch for the three
 #if defined(__HIP_DEVICE_COMPILE__) && TRC_FAST_UNARY && !defined(TRC_FAST_MATH)
-#if TRC_RCP_GUARD_CLASS
     const F3 r0 = f3(__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y), __builtin_amdgcn_rcpf(a.z));
     auto finish = [](float x, float e0) {
         const float r1 = __builtin_fmaf(__builtin_fmaf(-x, e0, 1.0f), e0, e0);
@@ -210,15 +161,6 @@ TRC_DEV F3 rcp_cr(F3 a) {                         // 1 / direction: one wave-lev
     };
     F3 r = f3(finish(a.x, r0.x), finish(a.y, r0.y), finish(a.z, r0.z));
     const bool ok = __builtin_amdgcn_classf(r0.x, 0x108) && __builtin_amdgcn_classf(r0.y, 0x108) && __builtin_amdgcn_classf(r0.z, 0x108);
-#else
-    F3 r = f3(rcp_core(a.x), rcp_core(a.y), rcp_core(a.z));
-#if TRC_RANGE_CMP2
-    const float small = __builtin_fminf(__builtin_fminf(fabsf(a.x), fabsf(a.y)), fabsf(a.z)), large = __builtin_fmaxf(__builtin_fmaxf(fabsf(a.x), fabsf(a.y)), fabsf(a.z));
-    const bool ok = small >= 0x1p-60f && large < 0x1p60f;      // (min / max skip a NaN component: its reciprocal is a NaN by either sequence, and 1 / direction only ever meets min, max and compares)
-#else
-    const bool ok = unary_in_range(a.x) && unary_in_range(a.y) && unary_in_range(a.z);
-#endif
-#endif
     if (__builtin_expect(!wave_all(ok), 0)) r = f3(1.0f / a.x, 1.0f / a.y, 1.0f / a.z);
     return r;
 #else
@@ -271,15 +213,8 @@ TRC_DEV float div_core(float a, const GuardedDivBy& d) {
 TRC_DEV float div_core(float a, float b) { return div_core(a, guarded_div_by(b)); }      // one quotient, no guard at all
 TRC_DEV F3 div_core(F3 a, F3 b) { return f3(div_core(a.x, b.x), div_core(a.y, b.y), div_core(a.z, b.z)); }
 TRC_DEV F3 guarded_div(F3 a, const GuardedDivBy& d) { return f3(guarded_div(a.x, d), guarded_div(a.y, d), guarded_div(a.z, d)); }
-#ifndef TRC_DIVBY_RENDER
-#define TRC_DIVBY_RENDER 0      // 1: the render kernels' shared-divisor sites go through GuardedDivBy (A/B variant)
-#endif
 TRC_DEV F3 div_shared(F3 a, float s) {      // vec3 / scalar at the sites that share the divisor
-#if TRC_DIVBY_RENDER
-    return guarded_div(a, guarded_div_by(s));
-#else
     return a / s;
-#endif
 }
 
 constexpr float kPi = 3.14159265358979323846f;      // M_PI_F

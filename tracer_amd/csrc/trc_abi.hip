@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(const KTrace kp) {
     hit_init(rec);
     TravCounters cnt;
     counters_zero(cnt);
-    constexpr bool kOrderFree = ANY && !STATS && TRC_ANYHIT_FREE;      // the production kernels' shadow-ray walk: only the answer is defined
+    constexpr bool kOrderFree = ANY && !STATS;      // the production kernels' shadow-ray walk: only the answer is defined
     const F3 root_min = f3(kp.ks.root_box[0], kp.ks.root_box[1], kp.ks.root_box[2]), root_max = f3(kp.ks.root_box[3], kp.ks.root_box[4], kp.ks.root_box[5]);
     bool h;
     if (kOrderFree) h = scene_occluded<LDS, false, false>(S, root_min, root_max, ray, in.tmax, stack, sc.stack_lds);
