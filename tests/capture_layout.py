@@ -112,3 +112,63 @@ def extract(rgb):
     assert tb, "no gold block found"
     facts.update({"tall_block_left": (tb[0] + bx0 - x0) / fw, "tall_block_right": (tb[1] + bx0 - x0) / fw})
     return {k: round(float(v), 4) for k, v in facts.items()}
+
+
+# ---------------------------------------------------------------- the twelve spheres (Captures/capture_o.jpg, README.md:21)
+# capture_o is the reference's BVH view of the scene with prepareSphereList's spheres inserted (Tracer.mm:306-369): the walls are
+# not drawn, the boxes of the tree are -- the outermost rectangle is the scene's front face, i.e. the painted box of capture_t --
+# and the spheres are: a row of five near the ceiling, a row of six on the floor (a bunny that the repository does not ship stands in
+# the middle and hides parts of them).  Facts: the silhouettes' centres, normalised to that rectangle.
+
+def sphere_rows_from_wireframe(rgb):
+    """rgb: (H, W, 3) uint8 of the BVH view.  Returns {"top": [(x, y, w, h), ...], "bottom": [...]} in units of the outer box;
+    silhouettes that the bunny's wireframe cuts come out narrower than the whole ones (the caller keeps both apart by width)."""
+    img = np.asarray(rgb, np.float64)
+    H, W = img.shape[:2]
+    R, G, B = img[..., 0], img[..., 1], img[..., 2]
+    white = np.minimum(np.minimum(R, G), B) > 200
+    # the outer rectangle: the first and last long white lines inside the window (rows / columns more than half white)
+    inner = white[int(0.06 * H):int(0.94 * H), int(0.04 * W):int(0.96 * W)]
+    rows = np.flatnonzero(inner.sum(axis=1) > 0.5 * inner.shape[1]) + int(0.06 * H)
+    cols = np.flatnonzero(inner.sum(axis=0) > 0.5 * inner.shape[0]) + int(0.04 * W)
+    assert len(rows) >= 2 and len(cols) >= 2, "no wireframe rectangle found"
+    y0, y1, x0, x1 = rows.min() + 1.5, rows.max() - 0.5, cols.min() + 1.5, cols.max() - 0.5
+    fw, fh = x1 - x0, y1 - y0
+    green = (G > 35) & (G > 1.25 * R) & (G > 1.25 * B)
+    red = (R > 45) & (R > 2.2 * G) & (R > 2.2 * B)
+
+    def blobs(mask, ylo, yhi, minw):
+        ya = int(y0 + ylo * fh)
+        sub = mask[ya:int(y0 + yhi * fh), int(x0):int(x1)]
+        k = int(0.004 * fw)                                   # close the gaps of the wireframe lines drawn over the spheres
+        col = np.convolve(sub.sum(axis=0) > 0.01 * fh, np.ones(2 * k + 1), mode="same") > 0
+        out, start = [], None
+        for i, v in enumerate(list(col) + [False]):
+            if v and start is None:
+                start = i
+            elif not v and start is not None:
+                a, b = start + k, i - k
+                start = None
+                if b - a < minw * fw:
+                    continue
+                r = np.flatnonzero(sub[:, a:b].sum(axis=1) > 0.2 * (b - a))
+                out.append(((a + b) / 2 / fw, ((r.min() + r.max() + 1) / 2 + ya - y0) / fh, (b - a) / fw, (r.max() + 1 - r.min()) / fh))
+        return [tuple(round(float(v), 4) for v in t) for t in out]
+    return {"box_aspect": round(float(fw / fh), 4), "top": blobs(green, 0.12, 0.36, 0.02), "bottom": blobs(red, 0.78, 0.99, 0.03)}
+
+
+def sphere_rows_from_hits(ptype, pindex, hit, sphere_type=0):
+    """The same facts from a scene: (H, W) arrays of the primary rays' Scene::hit results, row 0 = v 0 = the BOTTOM of the picture.
+    Returns {"box_aspect", "spheres": [(x, y, w, h), ...]} with y measured downwards like a picture's, normalised to the extent of
+    everything the camera sees (the front edges of the box)."""
+    any_hit = hit > 0
+    cols, rows = np.flatnonzero(any_hit.any(axis=0)), np.flatnonzero(any_hit.any(axis=1))
+    x0, x1, y0, y1 = cols.min(), cols.max() + 1, rows.min(), rows.max() + 1
+    fw, fh = float(x1 - x0), float(y1 - y0)
+    out = []
+    for s in np.unique(pindex[ptype == sphere_type]):
+        m = (ptype == sphere_type) & (pindex == s)
+        c, r = np.flatnonzero(m.any(axis=0)), np.flatnonzero(m.any(axis=1))
+        out.append(((c.min() + c.max() + 1) / 2 - x0, y1 - (r.min() + r.max() + 1) / 2, c.max() + 1 - c.min(), r.max() + 1 - r.min()))
+    return {"box_aspect": fw / fh, "spheres": [(a / fw, b / fh, c / fw, d / fh) for a, b, c, d in out]}
+

@@ -24,3 +24,17 @@ out = {"source": "Captures/capture_t.jpg (README.md:11)", "picture_size": [int(i
        "facts": facts, "tolerance": tol}
 json.dump(out, open(os.path.join(HERE, "capture_layout.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
+
+# the twelve spheres of prepareSphereList, from the BVH view of the scene (Captures/capture_o.jpg, README.md:21)
+SRC_O = "/root/reference/Captures/capture_o.jpg"
+img = np.asarray(Image.open(SRC_O).convert("RGB"))
+rows = cl.sphere_rows_from_wireframe(img)
+out = {"source": "Captures/capture_o.jpg (README.md:21): the BVH view, walls not drawn, a bunny (not in the repository) in the middle",
+       "picture_size": [int(img.shape[1]), int(img.shape[0])], "box_aspect": rows["box_aspect"],
+       "top": rows["top"], "bottom": rows["bottom"],
+       "tolerance": {"x": 0.015, "whole_silhouette": 0.006, "height": 0.015, "box_aspect": 0.03},   # the dark underside of a sphere is not "red"
+       "what": "x, y, width, height of the green (top row) and red (bottom row) silhouettes in units of the outer wireframe rectangle; "
+               "silhouettes cut by the bunny's wireframe are narrower than the whole ones and only their x counts"}
+json.dump(out, open(os.path.join(HERE, "capture_spheres.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
+

@@ -5,7 +5,14 @@ Tracer.mm:371-411) is rendered through the oracle and its output stage (Render.m
 -m gpu, through the HIP library and ITS output stage -- and the same extraction must find the same facts: red wall on the left,
 the box, its back wall, the light and the tall block at the same places, eight checker squares across the back wall and the
 ceiling.  This pins nothing numerically about radiance; it catches a flipped axis, a swapped wall, a wrong camera or a
-mirrored output stage."""
+mirrored output stage.
+
+Round 5 widens the pin to a second picture: Captures/capture_o.jpg (README.md:21) shows the scene WITH prepareSphereList's twelve
+spheres (Tracer.mm:306-369 -- BASELINE config 2's scene) in the BVH view.  Of the reference's 18 pictures it is the one whose sphere
+layout is the current source's (five near the ceiling, six on the floor, one large; capture_g / i / n show earlier revisions with
+six and six at other heights, a-d the RT_Weekend box, k-m / p-s the bunny and dragon assets the repository does not ship).
+tests/golden/capture_spheres.json holds the silhouettes' positions; the same scene's primary-ray Scene::hit results (oracle, and
+trc_trace_rays under -m gpu) must put the spheres at the same places in units of the box."""
 import json
 import os
 
@@ -13,6 +20,7 @@ import numpy as np
 import pytest
 
 import capture_layout as cl
+from conftest import camera_rays
 from oracle import pyoracle as po
 from tracer_amd import abi, host
 
@@ -54,3 +62,49 @@ def test_gpu_frame_has_the_layout_of_the_reference_screenshot(gpu):
     gpu.seed(SEED); gpu.clear_accum(); gpu.render(spp=SPP, integrator=abi.INTEGRATOR_MIS)
     out, _ = gpu.tonemap()
     check(cl.extract(out[..., :3]))
+
+
+SPHERES = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "capture_spheres.json")))
+SW, SH = 1280, 720
+
+
+def check_spheres(mine):
+    """every silhouette the screenshot shows sits where a sphere of the scene is: x of all of them, and x / y / width / height of
+    the ones the bunny's wireframe does not cut (the widest of each row)"""
+    tol = SPHERES["tolerance"]
+    assert abs(mine["box_aspect"] - SPHERES["box_aspect"]) <= tol["box_aspect"]
+    rows = {"top": sorted(s for s in mine["spheres"] if s[1] < 0.4), "bottom": sorted(s for s in mine["spheres"] if s[1] > 0.7)}
+    assert len(rows["top"]) == 5 and len(rows["bottom"]) == 6 and len(mine["spheres"]) == 12        # + the large one in between
+    for name in ("top", "bottom"):
+        shot = SPHERES[name]
+        assert len(shot) == len(rows[name]), name                      # every sphere of the row is at least partly visible in the picture
+        wmax = max(b[2] for b in shot)
+        for (x, y, w, h), (mx, my, mw, mh) in zip(sorted(shot), rows[name]):
+            assert abs(x - mx) <= tol["x"], (name, x, mx)
+            if w >= 0.97 * wmax and h >= 1.6 * w:                      # a whole silhouette (a sphere is ~1.9 times as high as wide in box units)
+                for got, want in ((mx, x), (my, y), (mw, w)):
+                    assert abs(got - want) <= tol["whole_silhouette"], (name, (x, y, w, h), (mx, my, mw, mh))
+                assert abs(mh - h) <= tol["height"], (name, h, mh)
+    whole = [b for name in ("top", "bottom") for b in SPHERES[name] if b[2] >= 0.97 * max(c[2] for c in SPHERES[name]) and b[3] >= 1.6 * b[2]]
+    assert len(whole) >= 3                                              # the check above had something to hold on to
+
+
+def test_scene_puts_the_twelve_spheres_where_the_reference_screenshot_has_them():
+    scene = host.HostScene(abi.SCENE_CORNELL_SPHERES)
+    hits = po.trace_rays(scene.view, camera_rays(host.prepare_camera(SW, SH), SW, SH))
+    mine = cl.sphere_rows_from_hits(hits["pType"].reshape(SH, SW), hits["pIndex"].reshape(SH, SW), hits["hit"].reshape(SH, SW), abi.PRIM_SPHERE)
+    check_spheres(mine)
+    # teeth: the rows one sphere spacing to the side, one radius up, or mirrored do not pass
+    sp = mine["spheres"]
+    for wrong in ([(x + 0.09, y, w, h) for x, y, w, h in sp], [(x, y - 0.05, w, h) for x, y, w, h in sp], [(1 - x, y, w, h) for x, y, w, h in sp]):
+        with pytest.raises(AssertionError):
+            check_spheres({"box_aspect": mine["box_aspect"], "spheres": wrong})
+
+
+@pytest.mark.gpu
+def test_gpu_scene_hit_puts_the_spheres_where_the_reference_screenshot_has_them(gpu):
+    scene = host.HostScene(abi.SCENE_CORNELL_SPHERES)
+    gpu.upload_scene(scene.view)
+    hits = gpu.trace_rays(camera_rays(host.prepare_camera(SW, SH), SW, SH))
+    check_spheres(cl.sphere_rows_from_hits(hits["pType"].reshape(SH, SW), hits["pIndex"].reshape(SH, SW), hits["hit"].reshape(SH, SW), abi.PRIM_SPHERE))
+
