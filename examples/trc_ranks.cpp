@@ -1,7 +1,7 @@
 // trc_ranks -- N ranks of the path-tracing hot path started and composed WITHOUT Python or PyTorch (north_star: "Host code
 // stays in the repo's own Swift/C++ calling HIP through a thin C-ABI/FFI layer (no PyTorch)").
 //
-//   trc_ranks --ranks N [--host-collectives] [--size W H] [--spp S] [--sppm FRAMES] [--out frame.png]
+//   trc_ranks --ranks N [--host-collectives] [--samples] [--size W H] [--spp S] [--sppm FRAMES] [--out frame.png]
 //
 // Without TRC_RANK in the environment the program is the LAUNCHER: it forks N children before anything has touched the
 // GPU (no exec: a child simply goes on as rank r of this same image; HIP is first used after the fork, in the child) and
@@ -11,9 +11,14 @@
 //      sockets, every rank calls trc_group_init -- one GPU per rank, RCCL over xGMI; with --host-collectives the
 //      sockets themselves carry the collectives through trc_group_set_collectives (host-staged, a star through rank 0),
 //      which is how N ranks run on ONE GPU (RCCL refuses a second rank on a device),
+//      The choice is made from the devices the ranks HOLD: every rank sends the PCI bus id of its context's device up the star
+//      (trc_device_pci_bus_id); two ranks on one device -> host collectives, whatever the command line asked for,
 //   3. renders its tiles (tx + ty) % N == rank of the BASELINE config-2 frame, composes with trc_group_reduce_accum, and --
 //      with --sppm F -- runs F frames of the SPPM pass with its all-reduce / all-gather,
 //   4. rank 0 renders the same frame alone and checks that the composed frame equals it bit for bit, writes the PNG.
+// --samples: the split that scales (tracer_abi.h "sample sharding") instead of step 3's tiles: every rank the WHOLE frame with
+// spp / N samples from trc_seed(trc_shard_seed(seed, rank)), composed by trc_group_compose_samples (all-to-all of pixel slices,
+// rank-ordered fold, gather); rank 0 then renders the N shards itself, folds them in rank order on the host and checks the bits.
 // The reference has no counterpart (its multi-device path is commented out, AAPLRenderer.mm:139-146).
 #include <arpa/inet.h>
 #include <netinet/in.h>
@@ -91,6 +96,32 @@ int star_allgather(void* user, void* buf, size_t bytes_per_rank, void*) {
     return broadcast_from_root(s, buf, bytes_per_rank * (size_t)s.world) ? 0 : 1;
 }
 
+// sample-sharded compose: slice p of every rank's buffer goes to rank p (through the hub), then the composed slices to the root
+int star_alltoall(void* user, void* buf, size_t bytes_per_rank, void*) {
+    Star& s = *static_cast<Star*>(user);
+    char* b = static_cast<char*>(buf);
+    const size_t all = bytes_per_rank * (size_t)s.world;
+    if (s.rank != 0) return send_all(s.peers[0], b, all) && recv_all(s.peers[0], b, all) ? 0 : 1;
+    std::vector<std::vector<char>> rows((size_t)s.world);             // rows[r] = rank r's buffer
+    rows[0].assign(b, b + all);
+    for (int r = 1; r < s.world; ++r) { rows[(size_t)r].resize(all); if (!recv_all(s.peers[r], rows[(size_t)r].data(), all)) return 1; }
+    std::vector<char> out(all);
+    for (int r = s.world - 1; r >= 0; --r) {                           // what rank r receives: slice r of every row
+        for (int p = 0; p < s.world; ++p) std::memcpy(out.data() + (size_t)p * bytes_per_rank, rows[(size_t)p].data() + (size_t)r * bytes_per_rank, bytes_per_rank);
+        if (r == 0) std::memcpy(b, out.data(), all);
+        else if (!send_all(s.peers[r], out.data(), all)) return 1;
+    }
+    return 0;
+}
+int star_gather(void* user, void* buf, size_t bytes_per_rank, int root, void*) {
+    Star& s = *static_cast<Star*>(user);
+    if (root != 0) return 2;                                 // this example composes on rank 0
+    char* b = static_cast<char*>(buf);
+    if (s.rank != 0) return send_all(s.peers[0], b + (size_t)s.rank * bytes_per_rank, bytes_per_rank) ? 0 : 1;
+    for (int r = 1; r < s.world; ++r) if (!recv_all(s.peers[r], b + (size_t)r * bytes_per_rank, bytes_per_rank)) return 1;
+    return 0;
+}
+
 bool meet(Star& s, int port) {
     s.peers.assign((size_t)s.world, -1);
     sockaddr_in addr{};
@@ -144,12 +175,13 @@ int free_port() {
 int main(int argc, char** argv) {
     int ranks = 2, sppm_frames = 0;
     uint32_t W = 1920, H = 1080, spp = 64;
-    bool host_collectives = false;
+    bool host_collectives = false, samples = false;
     std::string out = "ranks.png";
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--ranks" && i + 1 < argc) ranks = std::atoi(argv[++i]);
         else if (a == "--host-collectives") host_collectives = true;
+        else if (a == "--samples") samples = true;
         else if (a == "--size" && i + 2 < argc) { W = (uint32_t)std::atoi(argv[++i]); H = (uint32_t)std::atoi(argv[++i]); }
         else if (a == "--spp" && i + 1 < argc) spp = (uint32_t)std::atoi(argv[++i]);
         else if (a == "--sppm" && i + 1 < argc) sppm_frames = std::atoi(argv[++i]);
@@ -204,11 +236,26 @@ int main(int argc, char** argv) {
     CHECK(trc_upload_scene(ctx, &scene));
     CHECK(trc_set_camera(ctx, &cam));
     CHECK(trc_resize(ctx, W, H));
+    {   // RCCL only when every rank holds a device of its own: decided from the PCI bus ids, by rank 0, for everybody
+        char bus[64] = {0};
+        CHECK(trc_device_pci_bus_id(ctx, bus, sizeof bus));
+        std::vector<char> all((size_t)star.world * 64, 0);
+        std::memcpy(all.data() + (size_t)star.rank * 64, bus, 64);
+        if (star_allgather(&star, all.data(), 64, nullptr) != 0) return 1;
+        bool shared = false;
+        for (int i = 0; i < star.world; ++i)
+            for (int j = i + 1; j < star.world; ++j) shared |= std::strncmp(all.data() + (size_t)i * 64, all.data() + (size_t)j * 64, 64) == 0;
+        if (shared && !host_collectives) {
+            if (star.rank == 0) std::fprintf(stderr, "ranks share a device (%s ...): RCCL refuses a second rank on one, composing over the sockets\n", all.data());
+            host_collectives = true;
+        }
+    }
 
     trc_collectives table{};
     if (host_collectives) {
         table.user = &star; table.host_staged = 1;
         table.reduce = star_reduce; table.allreduce = star_allreduce; table.allgather = star_allgather;
+        table.alltoall = star_alltoall; table.gather = star_gather;
         CHECK(trc_group_set_collectives(ctx, &table, star.world, star.rank));
     } else {
         uint8_t id[TRC_UNIQUE_ID_BYTES] = {0};
@@ -221,24 +268,29 @@ int main(int argc, char** argv) {
     std::memset(&prm, 0, sizeof prm);
     prm.spp = spp; prm.max_depth = 8; prm.integrator = TRC_INTEGRATOR_PATH;
     prm.tile_rank = (uint32_t)star.rank; prm.tile_nranks = (uint32_t)star.world;
+    if (samples) {
+        if (spp % (uint32_t)star.world) { std::fprintf(stderr, "--samples: %u samples do not split over %d ranks\n", spp, star.world); return 2; }
+        prm.spp = spp / (uint32_t)star.world; prm.tile_rank = 0; prm.tile_nranks = 1;      // the whole frame, this rank's share of the samples
+    }
     const size_t n = (size_t)W * H * 4;
     std::vector<float> composed(n), alone(n);
     double ms[2] = {0, 0};
     for (int pass = 0; pass < 2; ++pass) {                    // second pass: adaptive order and block sizes, warm collectives
         CHECK(trc_clear_accum(ctx));
-        CHECK(trc_seed(ctx, 0x5EED0000ull));
+        CHECK(trc_seed(ctx, samples ? trc_shard_seed(0x5EED0000ull, (uint32_t)star.rank) : 0x5EED0000ull));
         CHECK(trc_synchronize(ctx));
         int32_t go = 1;
         if (!broadcast_from_root(star, &go, 4)) return 1;     // a cheap barrier: everybody starts the timed pass together
         const auto t0 = std::chrono::steady_clock::now();
         CHECK(trc_render(ctx, &prm));
-        CHECK(trc_group_reduce_accum(ctx, 0));
+        if (samples) CHECK(trc_group_compose_samples(ctx, 0, 0));
+        else CHECK(trc_group_reduce_accum(ctx, 0));
         CHECK(trc_synchronize(ctx));
         ms[pass] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     trc_stats st;
     CHECK(trc_get_stats(ctx, &st));
-    if (star.rank == 0) CHECK(trc_download_accum(ctx, composed.data()));
+    if (star.rank == 0) { if (samples) CHECK(trc_download_composed(ctx, composed.data())); else CHECK(trc_download_accum(ctx, composed.data())); }
 
     int bad = 0;
     if (sppm_frames > 0) {                                    // the grouped SPPM pass: all-reduce of the bounds, all-gather of the photons
@@ -262,12 +314,26 @@ int main(int argc, char** argv) {
     }
     if (star.rank == 0) {                                     // the same frame on one rank: must be the same bits
         prm.tile_rank = 0; prm.tile_nranks = 1;
-        CHECK(trc_clear_accum(ctx)); CHECK(trc_seed(ctx, 0x5EED0000ull)); CHECK(trc_render(ctx, &prm));
-        CHECK(trc_download_accum(ctx, alone.data()));
+        if (samples) {                                        // the definition, by hand: the N shards one after the other, folded in rank order
+            std::vector<float> shard(n);
+            for (int g = 0; g < star.world; ++g) {
+                CHECK(trc_clear_accum(ctx)); CHECK(trc_seed(ctx, trc_shard_seed(0x5EED0000ull, (uint32_t)g))); CHECK(trc_render(ctx, &prm));
+                CHECK(trc_download_accum(ctx, shard.data()));
+                if (g == 0) alone = shard;
+                else for (size_t i = 0; i < n; ++i) alone[i] += shard[i];
+            }
+            const float groups = (float)star.world;
+            for (size_t i = 0; i < n; ++i) alone[i] /= groups;
+        } else {
+            CHECK(trc_clear_accum(ctx)); CHECK(trc_seed(ctx, 0x5EED0000ull)); CHECK(trc_render(ctx, &prm));
+            CHECK(trc_download_accum(ctx, alone.data()));
+        }
         const bool same = std::memcmp(composed.data(), alone.data(), n * 4) == 0;
-        std::printf("%d ranks (%s), %ux%ux%uspp tracePath: rank 0 rendered %llu rays per pass, step %.2f ms (first %.2f); composed frame %s the 1-rank frame\n",
+        std::printf("%d ranks (%s), %ux%ux%uspp tracePath%s: rank 0 rendered %llu rays per pass, step %.2f ms (first %.2f); composed frame %s %s\n",
                     star.world, host_collectives ? "collectives over TCP sockets, host-staged" : "RCCL", W, H, spp,
-                    (unsigned long long)(st.rays / 2), ms[1], ms[0], same ? "==" : "DIFFERS FROM");
+                    samples ? ", samples split over the ranks' seeds" : "",
+                    (unsigned long long)(st.rays / 2), ms[1], ms[0], same ? "==" : "DIFFERS FROM",
+                    samples ? "the rank-ordered mean of the shards rendered on one rank" : "the 1-rank frame");
         bad |= !same;
         std::vector<uint8_t> rgba8((size_t)W * H * 4);
         CHECK(trc_upload_accum(ctx, composed.data()));

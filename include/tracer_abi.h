@@ -441,7 +441,10 @@ trc_status trc_tonemap(trc_ctx* ctx, uint8_t* rgba8, float* exposure_out);
  * have come together, when a call arrives that does not continue it, or when ANY other trc_* entry point taking this context is
  * entered (each launches what was kept before it does anything else).  Results, statistics (trc_stats.launches counts
  * calls) and error behaviour of parameter checks are those of launching every call at once; a HIP error of a kept launch
- * is returned by the call that launches it.  Knob "no_coalesce" (trc_debug_set) launches every call at once.
+ * is returned by the call that launches it, and trc_last_error then names the frame range (frame0 .. frame0 + spp - 1) and the
+ * number of trc_render calls whose samples did not run, so that a host can re-issue exactly those.  trc_destroy drops a kept
+ * launch without launching it (nobody could read its frame); call trc_synchronize first to learn its status.  Knob "no_coalesce"
+ * (trc_debug_set) launches every call at once.
  * First launch of a block list (new context, frame size, tile share, scene, camera, integrator), >= 16 samples: run as a
  * head of 8 samples (then passes of 16 and 32 samples where at least four times as many remain) followed by the rest, each
  * pass ordered and split by its predecessor's per-block durations -- the same pixels (a pixel's samples are one chain

@@ -117,6 +117,20 @@ def test_ranks_started_and_composed_without_pytorch(gpu, tmp_path, ranks):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_ranks_sample_sharded_without_pytorch(gpu, tmp_path, ranks):
+    """examples/trc_ranks --samples: the C++ host of the split that scales -- every rank the whole frame with spp / N samples from
+    trc_shard_seed(seed, rank), trc_group_compose_samples over the socket table (all-to-all + gather in C++), and rank 0's own
+    check against the shards folded in rank order on the host.  The ranks are NOT told to use host collectives: they find out
+    from the PCI bus ids that they share one GPU."""
+    log = subprocess.run([RANKS_EXE, "--ranks", str(ranks), "--samples", "--size", "480", "272", "--spp", "16", "--out", str(tmp_path / "s.png")],
+                         text=True, capture_output=True, timeout=600)
+    assert log.returncode == 0, log.stdout + log.stderr
+    assert "ranks share a device" in log.stderr and "collectives over TCP sockets" in log.stdout
+    assert "samples split over the ranks' seeds" in log.stdout and "composed frame == the rank-ordered mean of the shards" in log.stdout
+
+
+@pytest.mark.gpu
 def test_rccl_unique_id_travels_over_the_socket(gpu):
     """the default path of the example with one rank: trc_group_unique_id -> trc_group_init -> ncclReduce, no Python involved"""
     log = subprocess.run([RANKS_EXE, "--ranks", "1", "--size", "320", "200", "--spp", "8", "--out", "/dev/null"], text=True,

@@ -383,6 +383,23 @@ def test_quadric_tessellations_lie_on_their_surfaces(quadrics_pbrt):
     assert scene.tree_depth() > 3
 
 
+def test_a_paraboloid_from_its_apex_has_no_zero_area_triangles(tmp_path):
+    """with zmin = 0 (pbrt's default) row 0 of the grid is the apex, ONE point: its cells are one triangle each, like
+    the cone's apex cells -- not a second, zero-area triangle that becomes a leaf nothing can ever hit"""
+    p = tmp_path / "apex.pbrt"
+    p.write_text(QUADRICS.replace('"float radius" 3 "float zmin" 1 "float zmax" 4', '"float radius" 3 "float zmax" 4'))
+    scene, cam, info, shapes = host.HostScene.from_pbrt(str(p))
+    par = shapes[1]
+    assert par.kind == abi.PBRT_SHAPE_PARABOLOID and par.zmin == 0.0 and par.n_vertices == 65 * 17
+    assert par.n_indices == 3 * 64 * (2 * 16 - 1)                     # the apex row: one triangle per cell
+    v = scene.view
+    verts = np.ctypeslib.as_array(C.cast(v.triList, C.POINTER(C.c_float)), shape=(v.n_vertex, 8))[:, :3].astype(np.float64)
+    idx = np.ctypeslib.as_array(v.idxList, shape=(v.n_index,)).reshape(-1, 3)
+    a, b, c = verts[idx[:, 0]], verts[idx[:, 1]], verts[idx[:, 2]]
+    area = 0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1)
+    assert (area > 1e-6).all()
+
+
 INSTANCED = '''
 LookAt 278 278 -800  278 278 0  0 1 0
 Camera "perspective" "float fov" 40

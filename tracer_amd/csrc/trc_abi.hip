@@ -1030,8 +1030,10 @@ trc_status trc_create(int device, trc_ctx** out) {
 }
 
 void trc_destroy(trc_ctx* ctx) {
-    if (ctx) (void)trc_flush(ctx);
     if (!ctx) return;
+    // nobody can read the frame of a kept launch after this call: it is dropped, not launched (trc_synchronize, a download or
+    // trc_get_stats before trc_destroy launches it and reports its status)
+    ctx->has_deferred = false;
     if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
     if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -1311,6 +1313,12 @@ trc_status trc_flush(trc_ctx* ctx) {
     const uint64_t calls = ctx->deferred_calls;
     const trc_status st = render_pass(ctx, &q, false);
     if (st == TRC_OK && calls > 1) ctx->launches += calls - 1;        // trc_stats.launches counts trc_render calls
+    if (st != TRC_OK) {
+        // the calls that were kept have already returned TRC_OK: the error of their launch surfaces in whatever entry point
+        // flushes it, so it says WHICH samples did not run (trc_last_error) -- a host can re-issue exactly those
+        ctx->error = "kept launch of " + std::to_string(calls) + " trc_render call(s), frames " + std::to_string(q.frame0) + " .. " +
+                     std::to_string(q.frame0 + q.spp - 1) + " (" + std::to_string(q.spp) + " samples per pixel), did not run: " + ctx->error;
+    }
     return st;
 }
 extern "C" {

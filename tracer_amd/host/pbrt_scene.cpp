@@ -52,6 +52,7 @@ struct GfxState {                       // what AttributeBegin / End save (pbrt-
 };
 struct NamedTexture { int32_t kind; float tex1[3], tex2[3]; };
 constexpr uint32_t kQuadricSegments = 64;     // steps of phi over a full turn
+constexpr size_t kMaxInstancedTriangles = size_t(1) << 24;   // ObjectInstance copies stop here (16.7 M triangles: 1.9 GB of device scene)
 
 const PbrtParam* find(const std::vector<PbrtParam>& ps, const char* name) {
     for (const PbrtParam& p : ps) if (p.name == name) return &p;
@@ -248,6 +249,9 @@ extern "C" trc_status trc_host_scene_load_pbrt(const char* path, trc_host_scene*
                 const InstanceRef& in = instances[next_instance++];
                 auto it = objects.find(in.name);
                 if (it == objects.end()) { inf.n_unsupported_shapes++; continue; }       // an instance of nothing
+                // every instance is a flat copy of its template (the reference's scene has no instancing either): bounded, so that
+                // a file with 10^5 instances of a mesh ends as "unsupported" and not as an out-of-memory kill
+                if (s->indices.size() / 3 >= kMaxInstancedTriangles) { inf.n_unsupported_shapes++; continue; }
                 lx.i = it->second.body; ctm = it->second.ctm; g = it->second.g;
                 tstack.clear(); gstack.clear(); object_depth = 0;
                 inst_prefix = in.to_world; replaying = true; again = true;
@@ -499,8 +503,10 @@ extern "C" trc_status trc_host_scene_load_pbrt(const char* path, trc_host_scene*
                         for (uint32_t r = 0; r < rows; ++r) {
                             const uint32_t a = k * (rows + 1) + r, b = a + 1, c2 = a + rows + 1, d2 = c2 + 1;
                             const bool apex = q == QCone && r + 1 == rows;                 // b and d2 are the apex: one triangle
+                            // a paraboloid that starts at z = 0 has its apex in row 0: a and c2 are that one point
+                            const bool apex0 = q == QParaboloid && r == 0 && ds.zmin == 0.0f;
                             if (!apex) { idx.push_back(a); idx.push_back(b); idx.push_back(d2); }
-                            idx.push_back(a); idx.push_back(d2); idx.push_back(c2);
+                            if (!apex0) { idx.push_back(a); idx.push_back(d2); idx.push_back(c2); }
                         }
                 }
                 const size_t nv = Po.size() / 3;
