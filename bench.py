@@ -176,13 +176,17 @@ def valu_roofline(p, kernel_ms=None, source=None, lib_hash=None):
     (MI355X_MICROARCH.md), so a launch of `cyc` shader cycles can issue at most N_SIMD * cyc / 2 of them.
     achieved / peak in wave-instructions per launch, from a PMC summary `p` (tools/pmc_summary.py)."""
     cyc = p["GRBM_GUI_ACTIVE"] / 8.0                       # summed over the 8 XCDs
-    traffic = int(p["hbm_bytes_per_launch"]) if p.get("hbm_bytes_per_launch") is not None else None
+    # bytes the L2s moved to / from the fabric per launch (tools/pmc_summary.py: sized TCC_EA0 request counters; Infinity-Cache
+    # hits INCLUDED, so an upper bound of the HBM bytes that equals them only for working sets far beyond 256 MiB)
+    t = p.get("l2_miss_bytes_per_launch", p.get("hbm_bytes_per_launch"))
+    traffic = int(t) if t is not None else None
     ms = kernel_ms if kernel_ms is not None else p.get("kernel_ms")
     return {
         "bound": "valu-issue", "achieved": int(p["SQ_INSTS_VALU"]), "peak": int(N_SIMD * cyc / 2.0),
         "unit": "VALU wave-instructions/launch", "frac": round(p["SQ_INSTS_VALU"] * 2.0 / (N_SIMD * cyc), 4),
         "traffic": traffic,
-        "hbm_physical_frac": None if traffic is None or not ms else round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+        "traffic_what": "L2-miss bytes per launch, reads (32 / 64 / 128 B x TCC_EA0_RDREQ_*) + writes (WRITE_SIZE); fabric side: Infinity-Cache hits included",
+        "l2_miss_traffic_frac_of_hbm_peak": None if traffic is None or not ms else round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
         "lane_utilisation": round(p["SQ_THREAD_CYCLES_VALU"] / (64.0 * p["SQ_INSTS_VALU"]), 4),
         "useful_lane_frac": round(p["SQ_THREAD_CYCLES_VALU"] / 64.0 * 2.0 / (N_SIMD * cyc), 4),
         "kernel": p["kernel"], "shader_cycles_per_launch": int(cyc), "pmc_kernel_ms": p.get("kernel_ms"),
@@ -662,7 +666,7 @@ def main(argv=None):
             "roofline": roof,
             # the north_star's figure: bytes the REFERENCE's access pattern would move for this work over the
             # kernel time.  Not a bound here -- the scene is LDS-resident, so it can exceed the HBM peak; physical traffic
-            # is roofline.traffic / roofline.hbm_physical_frac
+            # is roofline.traffic / roofline.l2_miss_traffic_frac_of_hbm_peak
             "roofline_hbm_algorithmic": {
                 "bound": "hbm (algorithmic bytes, not a physical bound)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "kernel": "k_render", "kernel_ms": round(kernel_ms, 3),

@@ -38,7 +38,7 @@ def test_cpu_rt_weekend_leg_schema():
 
 
 def test_roofline_only_from_a_summary_of_the_running_library(tmp_path, monkeypatch):
-    """The line's `roofline` (the binding VALU-issue bound, with traffic / hbm_physical_frac) comes from a committed PMC
+    """The line's `roofline` (the binding VALU-issue bound, with traffic / l2_miss_traffic_frac_of_hbm_peak) comes from a committed PMC
     summary and ONLY if it was collected on the library that is running (source hash + kernel name); a stale or missing
     summary yields an object without numbers that says why.  frac is a fraction of a real peak: never above 1."""
     mine = bench.lib_source_hash()
@@ -46,7 +46,7 @@ def test_roofline_only_from_a_summary_of_the_running_library(tmp_path, monkeypat
             "GRBM_GUI_ACTIVE": 8 * 52.7e6, "SQ_INSTS_VALU": 17.1e9, "SQ_THREAD_CYCLES_VALU": 17.1e9 * 16, "kernel_ms": 22.0}
     monkeypatch.setattr(bench, "pmc_summary", lambda: dict(good, _file="profiles/rXX/pmc_config2.json"))
     r = bench.roofline_from_pmc(22.0)
-    assert r["bound"] == "valu-issue" and r["traffic"] == 140000000 and abs(r["hbm_physical_frac"] - 140e6 / 22e-3 / 8e12) < 1e-6
+    assert r["bound"] == "valu-issue" and r["traffic"] == 140000000 and abs(r["l2_miss_traffic_frac_of_hbm_peak"] - 140e6 / 22e-3 / 8e12) < 1e-6
     assert abs(r["frac"] - 17.1e9 * 2 / (1024 * 52.7e6)) < 1e-3 and abs(r["lane_utilisation"] - 0.25) < 1e-9
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["frac"] <= 1.0
     assert abs(r["useful_lane_frac"] - r["frac"] * 0.25) < 1e-3 and r["lib_source_hash"] == mine

@@ -27,7 +27,14 @@ for c in 3 4 volume; do python3 tools/config_bench.py --config $c --warmup 8 2> 
 python3 tools/config_bench.py --config 5 2> $O/config5.err >> $O/configs_as_named.jsonl
 python3 bench.py > $O/bench_line_n1.json 2> $O/bench_n1.err
 python3 bench.py --gpus 2 --steps 2 > $O/bench_line_n2_one_gpu_plumbing.json 2> $O/bench_n2.err
-python3 bench.py --gpus 8 --steps 2 --no-other-scaling > $O/bench_line_n8_one_gpu_plumbing.json 2> $O/bench_n8.err
+python3 bench.py --gpus 8 --steps 2 > $O/bench_line_n8_one_gpu_plumbing.json 2> $O/bench_n8.err
+python3 bench.py --gpus 8 --steps 2 --scaling samples --no-other-scaling > $O/bench_line_n8_samples_one_gpu_plumbing.json 2> $O/bench_n8s.err
+# round 5: throughput across the LDS / L2 / Infinity-Cache / HBM boundaries, the 4 M-triangle operating point under the counters, and
+# what FETCH_SIZE / TCC_EA0_RDREQ* count for this path's gathers (tools/probe/gather_probe.hip)
+python3 tools/size_sweep.py > $O/size_sweep.txt 2> $O/size_sweep.err
+bash tools/pmc_collect.sh ${R}_hbm python3 tools/size_sweep.py --k 16 --integrators path --json --steps 4
+python3 tools/pmc_summary.py ${R}_hbm "k_render_pwg<0, false>" $O/pmc_hbm_point.json 4 > $O/pmc_hbm_point.txt 2>&1
+bash tools/fetch_size_calibration.sh $O > $O/fetch_size_calibration.txt 2>&1
 python3 tools/tools_profile.py spheres > $O/cycle_profile_config2.txt 2>&1
 python3 tools/spp_sweep.py > $O/spp_sweep.txt 2>&1
 for c in 2 4 5; do python3 tools/tile_balance.py --config $c > $O/tile_balance_config$c.txt 2> $O/tile_balance_config$c.err; done
