@@ -326,6 +326,8 @@ def main(argv=None):
                     help="which N > 1 workload fills the top-level fields (the others go to other_scaling)")
     ap.add_argument("--sample-groups", type=int, default=0,
                     help="--scaling samples: number of seeds S the 64 samples are split over (default N); N / S tile ranks share each seed's frame")
+    ap.add_argument("--other-timeout", type=float, default=600.0,
+                    help="seconds an optional leg (other_scaling) may take before the line goes out without it")
     ap.add_argument("--rccl-timeout", type=float, default=300.0,
                     help="seconds a rank waits inside the RCCL bring-up before it exits non-zero (a peer that died would leave it there for ever)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -620,12 +622,9 @@ def main(argv=None):
 
     primary = measure(args.scaling, args.steps, args.warmup)
     others = {}
-    if world > 1 and not args.no_other_scaling:
-        for m in ("strong", "weak", "samples"):
-            if m != args.scaling:
-                others[m] = measure(m, args.steps, args.warmup)
 
-    if rank == 0:
+    def emit(primary, others):
+        """rank 0's ONE JSON line (also called by the watchdog of an optional leg: the headline must not die with it)"""
         kernel_ms = primary["kernel_ms"]
         achieved = primary["bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
         roof = roofline_from_pmc(kernel_ms) if world == 1 else None
@@ -683,15 +682,43 @@ def main(argv=None):
         if world > 1:
             line["per_rank"] = primary["per_rank"]
             if others:
-                line["other_scaling"] = {m: {k: o[k] for k in ("mode", "metric", "value", "ms_per_step", "rays_per_step", "frame",
-                                                               "vary_seed", "cold", "per_rank", "sample_groups", "tile_ranks")}
-                                         for m, o in others.items()}
+                keys = ("mode", "metric", "value", "ms_per_step", "rays_per_step", "frame", "vary_seed", "cold", "per_rank",
+                        "sample_groups", "tile_ranks", "skipped")
+                line["other_scaling"] = {m: {k: o[k] for k in keys if k in o} for m, o in others.items()}
         if world == 1 and not args.no_fast_math:
             line["fast_math_variant"] = fast_math_leg(scene, cam, args.steps)
         if not args.no_cpu_baseline and world == 1:      # CPU baselines: rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(scene, cam)
             line["cpu_rt_weekend"] = cpu_rt_weekend()
         print(json.dumps(line), flush=True)
+
+    if world > 1 and not args.no_other_scaling:
+        # The other workloads are optional legs of the line.  Over RCCL a collective that never completes (a transport problem
+        # that only the sample shards' ncclSend / ncclRecv exchange meets, say) would take the finished primary measurement
+        # down with it: each leg runs under a watchdog that lets rank 0 print the line WITHOUT the leg and ends the process.
+        import threading
+        for m in ("strong", "weak", "samples"):
+            if m == args.scaling:
+                continue
+            finished = threading.Event()
+
+            def bail(mode=m, finished=finished):
+                if finished.is_set():
+                    return
+                if rank == 0:
+                    emit(primary, dict(others, **{mode: {"mode": mode, "skipped": f"did not finish within {args.other_timeout:.0f} s; the line goes out without it"}}))
+                    sys.stdout.flush()
+                os._exit(0)
+            dog = threading.Timer(args.other_timeout, bail)
+            dog.daemon = True
+            dog.start()
+            try:
+                others[m] = measure(m, args.steps, args.warmup)
+            finally:
+                finished.set()
+                dog.cancel()
+    if rank == 0:
+        emit(primary, others)
     sys.stdout.flush()
 
     def teardown():

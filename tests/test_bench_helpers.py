@@ -183,6 +183,25 @@ def test_two_rank_bench_path_on_one_gpu(launcher):
 
 
 @pytest.mark.gpu
+def test_an_optional_leg_that_never_finishes_does_not_take_the_headline_with_it():
+    """the other_scaling legs run under a watchdog: when one does not finish in time (here: at once -- a stand-in for a collective
+    that never completes) rank 0 still prints the ONE line with the finished primary measurement, the leg marked skipped, and
+    every rank exits 0"""
+    import json, subprocess, sys
+    env = dict(os.environ, TRC_BENCH_NO_RCCL="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--other-timeout", "0.05"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["rays_per_step"] == 219978393 and line["value"] > 0
+    assert "did not finish" in line["other_scaling"]["weak"]["skipped"] and "samples" not in line["other_scaling"]
+
+
+@pytest.mark.gpu
 def test_a_failing_rccl_communicator_does_not_end_the_run():
     """The RCCL compose path has never run with N > 1 on hardware.  Here it FAILS for real (two ranks forced onto RCCL with one
     device: ncclCommInitRank refuses): every rank hears of it, all compose through the socket table, the line says so."""
