@@ -229,10 +229,10 @@ int main(int argc, char** argv) {
     trc_Camera cam;
     trc_host_prepare_camera(&cam, (float)W, (float)H);
 
-    // one GPU per rank when there are enough of them, else the ranks share (host collectives only)
+    // one GPU per rank when there are enough of them, else the ranks share -- which the bus ids below find out
     int device = 0;
-    for (int d = star.rank; d >= 0; --d) { if (trc_create(d, &ctx) == TRC_OK) { device = d; break; } ctx = nullptr; if (!host_collectives) break; }
-    if (!ctx) { std::fprintf(stderr, "rank %d: no GPU for this rank (RCCL needs one per rank; --host-collectives shares)\n", star.rank); return 1; }
+    for (int d = star.rank; d >= 0; --d) { if (trc_create(d, &ctx) == TRC_OK) { device = d; break; } ctx = nullptr; }
+    if (!ctx) { std::fprintf(stderr, "rank %d: no GPU\n", star.rank); return 1; }
     CHECK(trc_upload_scene(ctx, &scene));
     CHECK(trc_set_camera(ctx, &cam));
     CHECK(trc_resize(ctx, W, H));
