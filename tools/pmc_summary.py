@@ -94,6 +94,10 @@ if "SQ_WAVE_CYCLES" in res:
 try:
     last = [l for l in open(f"gpurun_out/{tag}/trace.log").read().splitlines() if l.startswith("{")][-1]
     res["workload_line"] = json.loads(last)
+    # the program's own `roofline` objects quote whichever PMC summary was committed when it ran -- an older library's, by
+    # construction, while THIS summary is being collected: not part of what was measured here
+    for k in ("roofline", "roofline_per_pass"):
+        res["workload_line"].pop(k, None)
 except Exception:
     res["workload_line"] = None
 json.dump(res, open(out_path, "w"), indent=1, sort_keys=True)
