@@ -79,6 +79,36 @@ def main():
         if rank == 0:
             out["sppm"] = t.download_accum()
         out["calls"] = np.array([coll.calls[k] for k in ("reduce", "allreduce", "allgather", "alltoall", "gather")])
+    elif case == "ragged":
+        # a frame whose pixel count the ranks do not divide (97 x 61 = 5917: the last pixel slice is short), and a table that
+        # cannot compose sample shards
+        W, H = 97, 61
+        scene = host.HostScene(abi.SCENE_CORNELL_SPHERES)
+        t.upload_scene(scene.view); t.set_camera(host.prepare_camera(W, H)); t.set_environment((0.1, 0.2, 0.3)); t.resize(W, H)
+        t.set_collectives(coll, world, rank)
+        t.clear_accum(); t.seed(abi.shard_seed(5, rank)); t.render(spp=16 // world)
+        t.group_compose_samples(0)
+        if rank == 0:
+            out["sync"] = t.download_composed()
+        t.group_compose_samples_async(0, world)
+        if rank == 0:
+            out["async"] = t.download_composed()
+        t.synchronize(); t.clear_accum(); t.seed(abi.shard_seed(5, rank)); t.render(spp=16 // world)
+        t.group_allreduce_mean_accum()
+        out["mean"] = t.download_accum()
+        # the same ranks with a table that has no alltoall / gather: tiles still compose, sample shards say so
+        import ctypes as C
+        from tracer_amd import device
+        coll.table.alltoall = C.cast(None, type(coll.table.alltoall))
+        t.set_collectives(coll, world, rank)
+        try:
+            t.group_compose_samples(0)
+            out["refused"] = np.array(0)
+        except device.TracerError as e:
+            out["refused"] = np.array(e.status)
+        t.clear_accum(); t.seed(6); t.render(spp=2, tile_rank=rank, tile_nranks=world); t.group_reduce_accum(0)
+        if rank == 0:
+            out["tiles"] = t.download_accum()
     elif case in ("samples2", "samples4"):
         # the split that scales, at the named size: every rank the WHOLE 1920x1080 frame, 64 / N samples from seed
         # trc_shard_seed(seed, rank), composed by trc_group_compose_samples_async (the bench's --scaling samples step)

@@ -155,6 +155,24 @@ def test_config5_sppm_as_an_n_rank_split_at_1080p(gpu, tmp_path, world):
 
 
 @pytest.mark.parametrize("world", [2, 8])
+def test_sample_shards_of_a_frame_the_ranks_do_not_divide(gpu, tmp_path, world):
+    """97 x 61 = 5917 pixels over 2 / 8 ranks: the last pixel slice is short (and with 8 ranks three pixels short of the others);
+    root, pipelined and every-rank compose == the oracle.  A table without alltoall / gather composes tiles and refuses sample
+    shards with TRC_ERR_UNSUPPORTED instead of calling a null pointer."""
+    res = run_ranks("ragged", world, tmp_path / f"ragged{world}")
+    W, H = 97, 61
+    scene = host.HostScene(abi.SCENE_CORNELL_SPHERES)
+    cam = host.prepare_camera(W, H)
+    want, _ = po.render_sample_sharded(scene.view, cam, W, H, [host.fill_rng(po.shard_seed(5, g), W, H) for g in range(world)], 16, env=(0.1, 0.2, 0.3))
+    assert np.array_equal(bits(res[0]["sync"]), bits(want)) and np.array_equal(bits(res[0]["async"]), bits(want))
+    for r in range(world):
+        assert np.array_equal(bits(res[r]["mean"]), bits(want)), r
+        assert int(res[r]["refused"]) == abi.ERR_UNSUPPORTED, r
+    tiles, _ = po.render(scene.view, cam, W, H, host.fill_rng(6, W, H), spp=2, env=(0.1, 0.2, 0.3))
+    assert np.array_equal(bits(res[0]["tiles"]), bits(tiles))
+
+
+@pytest.mark.parametrize("world", [2, 8])
 def test_config2_sample_sharded_at_1080p_is_the_oracle_s_frame(gpu, tmp_path, world):
     """bench.py --scaling samples, step for step: N ranks, each the WHOLE 1920x1080 frame with 64 / N samples from seed
     trc_shard_seed(0x5EED0000, rank), composed on rank 0 == the oracle rendering that definition, every pixel"""
