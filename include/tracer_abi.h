@@ -538,8 +538,11 @@ uint64_t   trc_shard_seed(uint64_t seed, uint32_t sample_group);   /* seed + sam
 /* on the context stream; the composed frame is read with trc_download_composed (root only).  sample_groups == 0: nranks
  * (every rank its own group, no tile split) */
 trc_status trc_group_compose_samples(trc_ctx* ctx, int root, uint32_t sample_groups);
-/* pipelined like trc_group_reduce_accum_async: the exchange runs on the communication stream once the work queued so far
- * has finished, the context switches to its other accumulator, the next trc_clear_accum / trc_seed / trc_render overlap */
+/* pipelined: the exchange runs on the communication stream once the work queued so far has finished, on a SNAPSHOT of the
+ * accumulator taken in render-stream order (a device copy of the frame, ~20 us at 1080p) -- the compose only reads, so unlike
+ * trc_group_reduce_accum_async the context keeps its accumulator: the next trc_render overlaps with the exchange AND may go on
+ * accumulating (frame0 continuing); a progressive host calls this after every trc_render and never clears.
+ * trc_download_composed (root) waits for the exchange */
 trc_status trc_group_compose_samples_async(trc_ctx* ctx, int root, uint32_t sample_groups);
 /* the same compose with sample_groups = nranks, delivered into EVERY rank's accumulator (all-gather instead of the gather).
  * Until ABI 4 this was ncclAllReduce(sum) / nranks, whose sum order is the ring's; it is the rank-ordered sum now. */

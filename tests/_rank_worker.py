@@ -67,6 +67,16 @@ def main():
                 t.group_compose_samples_async(0, S)
                 if rank == 0:
                     out[f"hybrid{step}"] = t.download_composed()
+        # a progressive host: 4 samples, compose, 4 more ON TOP (frame0 continuing), compose -- pipelined, never cleared: the
+        # pipelined compose works on a snapshot and leaves the accumulator to the renderer
+        t.synchronize(); t.clear_accum(); t.seed(abi.shard_seed(300, rank))
+        t.render(spp=4); t.group_compose_samples_async(0)
+        t.render(spp=4, frame0=4); t.group_compose_samples_async(0)
+        if rank == 0:
+            out["prog8"] = t.download_composed()
+        t.render(spp=2, frame0=8); t.group_compose_samples_async(0)
+        if rank == 0:
+            out["prog10"] = t.download_composed()
         # SPPM: bound keys all-reduced, photon records all-gathered, frame composed
         t.synchronize(); t.clear_accum(); t.seed(8); t.sppm_init(9); t.sppm_frames(3)
         cam, pho, mark, count, cx = t.sppm_download()

@@ -96,6 +96,10 @@ def test_every_group_call_with_n_ranks_on_one_gpu(gpu, tmp_path, world):
         for step in range(2):
             want, _ = po.render_sample_sharded(scene.view, cam, W, H, [host.fill_rng(po.shard_seed(200 + step, g), W, H) for g in range(S)], 16)
             assert np.array_equal(bits(res[0][f"hybrid{step}"]), bits(want)), step
+    # progressive + pipelined: samples 0..7 and then 8..9 of every group accumulated in place, composed after each launch
+    for name, per_group in (("prog8", 8), ("prog10", 10)):
+        want, _ = po.render_sample_sharded(scene.view, cam, W, H, [host.fill_rng(po.shard_seed(300, g), W, H) for g in range(world)], per_group * world)
+        assert np.array_equal(bits(res[0][name]), bits(want)), name
     # SPPM
     gpu.clear_accum(); gpu.seed(8); gpu.sppm_init(9); gpu.sppm_frames(3)
     cam, pho, mark, count, cx = gpu.sppm_download()
@@ -113,7 +117,7 @@ def test_every_group_call_with_n_ranks_on_one_gpu(gpu, tmp_path, world):
         # 40-byte wire records + the whole records at the download + the every-rank sample compose; one all-to-all per sample
         # compose (root, every rank, 2 pipelined hybrids), one gather per compose to a root
         hybrid = 2 if world >= 4 else 0
-        assert list(res[r]["calls"]) == [5, 2, 5, 2 + hybrid, 1 + hybrid]
+        assert list(res[r]["calls"]) == [5, 2, 5, 2 + hybrid + 3, 1 + hybrid + 3]                  # + the three progressive composes
 
 
 @pytest.mark.parametrize("world", [2, 8])

@@ -1046,7 +1046,8 @@ void trc_destroy(trc_ctx* ctx) {
     (void)hipFree(ctx->d_block_cost); (void)hipFree(ctx->d_order_hist); (void)hipFree(ctx->d_split); (void)hipFree(ctx->d_whole); (void)hipFree(ctx->d_cost_est); (void)hipFree(ctx->d_qsplit); (void)hipFree(ctx->d_qwhole); (void)hipFree(ctx->d_launch); (void)hipFree(ctx->d_plan); (void)hipFree(ctx->d_plan_gather); (void)hipFree(ctx->d_cost_scratch);
     for (int k = 0; k < 2; ++k) { (void)hipFree(ctx->d_order_keys[k]); (void)hipFree(ctx->d_order_vals[k]); }
     (void)hipFree(ctx->d_accum_alt); (void)hipFree(ctx->d_stack_ovf); (void)hipFree(ctx->d_queue);
-    (void)hipFree(ctx->d_shard_in); (void)hipFree(ctx->d_shard_out);
+    (void)hipFree(ctx->d_shard_in); (void)hipFree(ctx->d_shard_out); (void)hipFree(ctx->d_shard_src);
+    if (ctx->ev_snapshot_free) (void)hipEventDestroy(ctx->ev_snapshot_free);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     if (ctx->h_readback) (void)hipHostFree(ctx->h_readback);
     for (hipEvent_t e : {ctx->ev_rendered, ctx->ev_busy, ctx->ev_busy_alt}) if (e) (void)hipEventDestroy(e);
@@ -1169,8 +1170,8 @@ trc_status trc_resize(trc_ctx* ctx, uint32_t width, uint32_t height) {
     if (ctx->comm_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->comm_stream));
     (void)hipFree(ctx->d_rng); (void)hipFree(ctx->d_accum); (void)hipFree(ctx->d_accum_alt); (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_reduce_recv);
     ctx->d_rng = nullptr; ctx->d_accum = nullptr; ctx->d_accum_alt = nullptr; ctx->d_composed = nullptr; ctx->d_tiles = nullptr; ctx->d_reduce_recv = nullptr;
-    (void)hipFree(ctx->d_shard_in); (void)hipFree(ctx->d_shard_out);
-    ctx->d_shard_in = ctx->d_shard_out = nullptr; ctx->shard_px = 0; ctx->shard_nranks = 0;
+    (void)hipFree(ctx->d_shard_in); (void)hipFree(ctx->d_shard_out); (void)hipFree(ctx->d_shard_src);
+    ctx->d_shard_in = ctx->d_shard_out = ctx->d_shard_src = nullptr; ctx->shard_px = 0; ctx->shard_nranks = 0; ctx->snapshot_busy = false;
     ctx->busy = ctx->busy_alt = false;
     trc_sppm_release(ctx);          // per-pixel camera records depend on the frame size
     ctx->n_tiles = 0; ctx->tiles_nranks = 0;
@@ -2063,10 +2064,27 @@ trc_status trc_group_compose_samples_async(trc_ctx* ctx, int root, uint32_t samp
     if (sample_groups == 0) sample_groups = (uint32_t)ctx->nranks;
     { trc_status cs = check_compose(ctx, root, sample_groups, "trc_group_compose_samples_async"); if (cs != TRC_OK) return cs; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    float* frame = ctx->d_accum;
-    trc_status s = compose_async(ctx, [&] { return compose_samples(ctx, frame, root, sample_groups, ctx->comm_stream, "compose of the sample shards"); });
-    if (s == TRC_OK) ctx->d_composed = ctx->d_shard_out;
-    return s;
+    // Unlike the tile reduce (which composes IN the accumulator and therefore switches to the other one), the sample compose only
+    // reads: it works on a SNAPSHOT of the accumulator (a 33 MB device copy: ~20 us) taken in render-stream order, so the rank
+    // goes on accumulating in place -- a progressive host calls this after every trc_render and never clears.
+    const size_t bytes = (size_t)ctx->width * ctx->height * 16;
+    if (!ctx->comm_stream) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_rendered, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_busy, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_busy_alt, hipEventDisableTiming));
+    }
+    if (!ctx->ev_snapshot_free) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_snapshot_free, hipEventDisableTiming));
+    if (!ctx->d_shard_src) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_shard_src, bytes));
+    if (ctx->snapshot_busy) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_snapshot_free, 0));      // the previous compose still reads it
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_shard_src, ctx->d_accum, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_rendered, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_rendered, 0));
+    { trc_status cs = compose_samples(ctx, ctx->d_shard_src, root, sample_groups, ctx->comm_stream, "compose of the sample shards"); if (cs != TRC_OK) return cs; }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_snapshot_free, ctx->comm_stream));
+    ctx->snapshot_busy = true;
+    ctx->d_composed = ctx->d_shard_out;
+    return TRC_OK;
 }
 
 trc_status trc_download_composed(trc_ctx* ctx, float* rgba) {

@@ -207,6 +207,8 @@ struct trc_ctx {
     bool busy = false, busy_alt = false;
     // sample-sharded compose (trc_group_compose_samples): the slices received from the ranks, and the composed slices
     float* d_shard_in = nullptr; float* d_shard_out = nullptr; size_t shard_px = 0; int shard_nranks = 0;
+    // ... and the pipelined form's snapshot of the accumulator (trc_group_compose_samples_async), free again at ev_snapshot_free
+    float* d_shard_src = nullptr; hipEvent_t ev_snapshot_free = nullptr; bool snapshot_busy = false;
 
     SppmState* sppm = nullptr;       // trc_sppm.hip
 
