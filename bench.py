@@ -633,12 +633,13 @@ def main(argv=None):
         compose = "none"
         sharded = primary["mode"] == "samples"
         if grouped:
-            what = (f"sample shards: all-to-all of the accumulators' {world} pixel slices (ncclSend / ncclRecv), rank-ordered fold, gather "
-                    f"to rank 0" if sharded else f"ncclReduce(sum) of the {W}x{FH} RGBA32F frame to rank 0")
-            compose = (f"{what} on a second stream, overlapped with the "
-                       f"next step" if use_rccl else
-                       f"reduce(sum) of the {W}x{FH} frame through trc_group_set_collectives (host-staged, TCP sockets): {compose_fallback}" if compose_fallback else
-                       f"PLUMBING RUN, NOT A MEASUREMENT: {world} ranks share {n_dev} GPU(s); reduce(sum) of the {W}x{FH} frame "
+            rccl_what = (f"sample shards: all-to-all of the accumulators' {world} pixel slices (ncclSend / ncclRecv), rank-ordered fold, gather "
+                         f"to rank 0" if sharded else f"ncclReduce(sum) of the {W}x{FH} RGBA32F frame to rank 0")
+            table_what = (f"sample shards ({world} pixel slices: alltoall, rank-ordered fold, gather to rank 0)" if sharded
+                          else f"reduce(sum) of the {W}x{FH} frame")
+            compose = (f"{rccl_what} on a second stream, overlapped with the next step" if use_rccl else
+                       f"{table_what} through trc_group_set_collectives (host-staged, TCP sockets): {compose_fallback}" if compose_fallback else
+                       f"PLUMBING RUN, NOT A MEASUREMENT: {world} ranks share {n_dev} GPU(s); {table_what} "
                        f"through trc_group_set_collectives (host-staged, TCP sockets) because RCCL refuses two ranks on one device")
         line = {
             "metric": primary["metric"], "value": primary["value"], "unit": "Mrays/s",
