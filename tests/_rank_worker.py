@@ -3,7 +3,7 @@ supplied through trc_group_set_collectives (host-staged, gloo between the proces
 ranks on one device.  Started by tests/test_gpu_shared_gpu_ranks.py; not a test module itself.
 
 env: RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT, TRC_ROOT, TRC_OUT (directory),
-     TRC_CASE = small | config4 | config5 | samples2 | samples4 (sample sharding at 1080p on BASELINE configs 2 / 4)
+     TRC_CASE = small | ragged | config4 | config5 | samples2 | samples3 | samples4 (sample sharding at 1080p on BASELINE configs 2 / 3 / 4)
 """
 import hashlib
 import os
@@ -119,19 +119,22 @@ def main():
         t.clear_accum(); t.seed(6); t.render(spp=2, tile_rank=rank, tile_nranks=world); t.group_reduce_accum(0)
         if rank == 0:
             out["tiles"] = t.download_accum()
-    elif case in ("samples2", "samples4"):
+    elif case in ("samples2", "samples3", "samples4"):
         # the split that scales, at the named size: every rank the WHOLE 1920x1080 frame, 64 / N samples from seed
         # trc_shard_seed(seed, rank), composed by trc_group_compose_samples_async (the bench's --scaling samples step)
         W, H, total = 1920, 1080, 64
+        integ = abi.INTEGRATOR_PATH
         if case == "samples2":
             scene, seed = host.HostScene(abi.SCENE_CORNELL_SPHERES), 0x5EED0000
+        elif case == "samples3":                            # BASELINE config 3's scene and integrator: coatball.obj, traceMIS
+            scene, seed, integ = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.golden("coatball")), 0x5EED0003, abi.INTEGRATOR_MIS
         else:
             scene, seed = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.golden("teapot").replicate(8, 80.0)), 0x5EED0004
         t.upload_scene(scene.view); t.set_camera(host.prepare_camera(W, H)); t.set_environment((0.0, 0.0, 0.0)); t.resize(W, H)
         t.set_collectives(coll, world, rank)
         for launch in range(2):                              # the second launch runs in adaptive order, on the other accumulator
             t.reset_stats()
-            t.clear_accum(); t.seed(abi.shard_seed(seed, rank)); t.render(spp=total // world)
+            t.clear_accum(); t.seed(abi.shard_seed(seed, rank)); t.render(spp=total // world, integrator=integ)
             t.group_compose_samples_async(0, world)
         st = t.stats()
         out["rays"] = np.uint64(st.rays); out["paths"] = np.uint64(st.paths)

@@ -192,16 +192,20 @@ def test_config2_sample_sharded_at_1080p_is_the_oracle_s_frame(gpu, tmp_path, wo
     assert (want[..., 3] == 1).all()
 
 
-@pytest.mark.parametrize("world", [2, 8])
-def test_config4_sample_sharded_at_1080p_is_the_oracle_s_frame(gpu, tmp_path, world):
-    """the same on BASELINE config 4's scene (teapot.obj x 64, 1 005 056 triangles, the tree read from memory): 64 / N samples
-    per rank through the persistent-workgroup kernel; 1 tile in 64 of the composed frame re-rendered by the oracle"""
-    res = run_ranks("samples4", world, tmp_path / f"s4_{world}", timeout=1500)
+@pytest.mark.parametrize("world,case", [(2, "samples4"), (8, "samples4"), (8, "samples3")])
+def test_mesh_configs_sample_sharded_at_1080p_are_the_oracle_s_frame(gpu, tmp_path, world, case):
+    """the same on BASELINE config 4's scene (teapot.obj x 64, 1 005 056 triangles, the tree read from memory; tracePath) and config 3's
+    (coatball.obj, traceMIS): 64 / N samples per rank through the persistent-workgroup kernels; 1 tile in 64 of the composed frame
+    re-rendered by the oracle"""
+    res = run_ranks(case, world, tmp_path / f"{case}_{world}", timeout=1500)
     W, H = 1920, 1080
-    scene = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.golden("teapot").replicate(8, 80.0))
+    if case == "samples4":
+        scene, seed, integ = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.golden("teapot").replicate(8, 80.0)), 0x5EED0004, abi.INTEGRATOR_PATH
+    else:
+        scene, seed, integ = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.golden("coatball")), 0x5EED0003, abi.INTEGRATOR_MIS
     want, _ = po.render_sample_sharded(scene.view, host.prepare_camera(W, H), W, H,
-                                       [host.fill_rng(po.shard_seed(0x5EED0004, g), W, H) for g in range(world)], 64,
-                                       tile_rank=0, tile_nranks=64)
+                                       [host.fill_rng(po.shard_seed(seed, g), W, H) for g in range(world)], 64,
+                                       tile_rank=0, tile_nranks=64, integrator=integ)
     mine = owner_mask(W, H, 64, 0)
     got = res[0]["frame"]
     assert mine.sum() > 5000 and np.array_equal(bits(got[mine]), bits(want[mine]))
