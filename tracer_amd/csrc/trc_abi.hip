@@ -732,9 +732,8 @@ static void plan_launch_lds(const trc_ctx* ctx, DScene& sc, uint32_t waves_per_s
 
 // LDS plan of a persistent-workgroup launch (k_render_pwg): `waves` wavefronts share one staged prefix; the workgroup's
 // share of the CU's 160 KB minus the wavefronts' stacks is all node prefix.  False when even one node does not fit.
-constexpr uint32_t kPwgStackLdsLevels = 16;      // 4 / 8 / 16 entries per lane in LDS: 33.5 / 31.1 / 30.8 ms on the 1 M-triangle scene
-static bool plan_pwg_lds(const trc_ctx* ctx, DScene& sc, uint32_t waves, uint32_t per_cu, bool hybrid) {
-    const uint32_t levels = ctx->knobs.stack_lds_levels > 0 ? (uint32_t)ctx->knobs.stack_lds_levels : kPwgStackLdsLevels;
+static bool plan_pwg_lds(const trc_ctx* ctx, DScene& sc, uint32_t waves, uint32_t per_cu, bool hybrid, uint32_t default_levels) {
+    const uint32_t levels = ctx->knobs.stack_lds_levels > 0 ? (uint32_t)ctx->knobs.stack_lds_levels : default_levels;      // trc_render_config.hpp
     DScene t = sc;
     if (hybrid) t.stack_lds = std::min(t.stack_depth, levels);
     const uint32_t per_wg = ((160u * 1024u / 4u) / per_cu) & ~127u;
@@ -1550,7 +1549,7 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
         if (!ctx->knobs.no_pwg && !strip && ctx->lds_prefix_ok) {                       // no_pwg: A/B knob
             pwg_waves_n = (uint32_t)pwg_waves((int)p->integrator);
             const uint32_t per_cu = (uint32_t)pwg_per_cu((int)p->integrator);
-            pwg = plan_pwg_lds(ctx, kp.ks.sc, pwg_waves_n, per_cu, hybrid);
+            pwg = plan_pwg_lds(ctx, kp.ks.sc, pwg_waves_n, per_cu, hybrid, pwg_stack_lds_levels((int)p->integrator));
             pwg_grid = std::min((uint32_t)ctx->cu_count * per_cu, (grid_cap + pwg_waves_n - 1) / pwg_waves_n);   // small frames: no idle workgroups
         }
         if (!pwg) {

@@ -44,8 +44,15 @@ constexpr bool hybrid_stack(int integrator) {
 #ifndef TRC_DENSE_MIN_BLOCKS_PER_SLOT
 #define TRC_DENSE_MIN_BLOCKS_PER_SLOT 4
 #endif
+// tracePath on a tree read from memory: SEVEN waves per SIMD (72 registers: 90 spilled values and 160 B of scratch per lane where 64
+// registers spill 116 / 200 B).  Round 4 had found seven slower than eight because a workgroup of 14 wavefronts does not pack -- the
+// dispatcher deals a workgroup's wavefronts to the SIMDs from SIMD 0 on, 14 = 4 + 4 + 3 + 3, and the second workgroup would put an eighth
+// wavefront on a SIMD whose registers hold seven, so only ONE was resident (41.6 ms).  Four-wavefront workgroups, seven per CU, pack
+// (1 + 1 + 1 + 1 each).  Round 5, alternating builds (profiles/r05/ab_shapes_config*.txt, shapes_validate.txt): config 4 23.25 -> 22.87 ms
+// per 32-spp launch, teapot x 1 / x 16 / x 256 16.80 / 22.38 / 20.68 -> 16.33 / 22.04 / 18.92 ms (the scene beyond the Infinity Cache
+// gains most: -8.5 %), 168.5 against 169.6 ms as named; 4 x 8, 8 x 4 at eight waves and 4 x 6 at six are slower (23.66 / 23.36 / 26.73).
 #ifndef TRC_PATH_WAVES_GLOBAL
-#define TRC_PATH_WAVES_GLOBAL 8
+#define TRC_PATH_WAVES_GLOBAL 7
 #endif
 #ifndef TRC_MIS_WAVES
 #define TRC_MIS_WAVES 8              // traceMIS on a tree read from memory (latency-bound: occupancy pays, round 4)
@@ -58,10 +65,10 @@ constexpr bool hybrid_stack(int integrator) {
 #endif
 // persistent workgroups (k_render_pwg): wavefronts per workgroup x workgroups per CU = the waves per CU above
 #ifndef TRC_PWG_WAVES_PATH
-#define TRC_PWG_WAVES_PATH 16
+#define TRC_PWG_WAVES_PATH 4
 #endif
 #ifndef TRC_PWG_PER_CU_PATH
-#define TRC_PWG_PER_CU_PATH 2
+#define TRC_PWG_PER_CU_PATH 7
 #endif
 #ifndef TRC_PWG_WAVES_MIS
 #define TRC_PWG_WAVES_MIS 16
@@ -79,6 +86,11 @@ constexpr bool hybrid_stack(int integrator) {
 #define TRC_STRIP_PATH_WAVES 4
 #endif
 constexpr int pwg_waves(int integrator) { return integrator == TRC_INTEGRATOR_PATH ? TRC_PWG_WAVES_PATH : (integrator == TRC_INTEGRATOR_MIS ? TRC_PWG_WAVES_MIS : TRC_PWG_WAVES_VOLUME); }
+// entries of a lane's traversal stack that live in LDS in a persistent-workgroup launch (deeper ones: global rows, dev_intersect.hpp
+// stack_put); what the stacks leave of the workgroup's LDS share is node prefix.  tracePath 16 (4 / 8 / 16: 33.5 / 31.1 / 30.8 ms in round
+// 2; 12 / 16 alike now); traceMIS 8 (6 / 8 / 10 / 12 / 16: 41.7 / 40.1 / 40.2 / 40.4 / 41.0 ms per 32-spp launch of config 3, 294.4
+// against 300.5 ms as named: its shadow rays walk with one entry per level and its 16 x 2 workgroups get 48 KB of prefix instead of 16)
+constexpr uint32_t pwg_stack_lds_levels(int integrator) { return integrator == TRC_INTEGRATOR_MIS ? 8u : 16u; }
 constexpr int pwg_per_cu(int integrator) { return integrator == TRC_INTEGRATOR_PATH ? TRC_PWG_PER_CU_PATH : (integrator == TRC_INTEGRATOR_MIS ? TRC_PWG_PER_CU_MIS : TRC_PWG_PER_CU_VOLUME); }
 
 // The kernels themselves (trc_render_kernels.hpp) are instantiated in two translation units, so that each family can be compiled

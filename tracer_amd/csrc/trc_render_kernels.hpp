@@ -182,8 +182,9 @@ __global__ void __launch_bounds__(kBlock, STATS ? 1 : (INTEGRATOR == TRC_INTEGRA
 // blocks from a device-wide queue in the launch order (longest first) until it is empty, so no wavefront slot waits
 // for a sibling (what cost the 4-wavefront workgroups of docs/HISTORY.md section 9 their 20 %).  Same blocks, same arithmetic per
 // lane.  Measured (profiles/r02/persistent_workgroups.txt): 2.4-3 % on configs 3 / 4 and the traceVolume scene -- most
-// of a mesh ray's steps are deep in the tree, below any prefix.  Workgroup shapes: tracePath 12 wavefronts x 2 per CU (10
-// x 2 leaves the SIMDs 3+3+2+2 and only one workgroup fits: 48 ms; 8 x 3: 36.8 against 31.1), the others 16 x 1 (8 x 2: +0.5 %).
+// of a mesh ray's steps are deep in the tree, below any prefix.  Workgroup shapes (trc_render_config.hpp): tracePath 4 wavefronts x 7
+// per CU -- seven waves per SIMD at 72 registers, the one shape of 28 wavefronts that packs (round 5; rounds 2-4 ran 12 x 2 and 16 x 2) --,
+// traceMIS 16 x 2 with 8 stack entries per lane in LDS, traceVolume 16 x 1.
 template <int INTEGRATOR, bool SOBOL>
 __global__ void __launch_bounds__(64 * pwg_waves(INTEGRATOR), pwg_waves(INTEGRATOR) * pwg_per_cu(INTEGRATOR) / 4) k_render_pwg(const KRender kp) {
     const DScene& sc = kp.ks.sc;
