@@ -68,6 +68,7 @@ struct SceneRef {
     uint32_t stack_lds;       // traversal-stack entries per lane that live in LDS ...
     uint32_t stack_cap;       // ... of stack_cap in all (the tree's depth)
     uint32_t* ovf;            // ... deeper ones in this lane's column of the workgroup's overflow rows (global memory)
+    uint32_t descend_min;     // DScene::descend_min
 };
 TRC_DEV float4 ld4(const uint32_t* p) { return *reinterpret_cast<const float4*>(p); }
 // The same 16-byte load with the address space spelled out.  Where a lane reads either the LDS copy or the blob, the
@@ -586,16 +587,14 @@ TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const flo
 #ifndef TRC_DESCEND_MIN_LDS
 #define TRC_DESCEND_MIN_LDS 1
 #endif
-#ifndef TRC_DESCEND_MIN_GLOBAL
-#define TRC_DESCEND_MIN_GLOBAL 12     // 8 until the loop lost its done flag; with the leaner step: 8 / 12 / 16 / 24 / 32 = 23.54 / 23.22 / 23.32 / 23.63 / 24.07 ms (config 4), 40.85 / 40.49 / 40.56 / 40.90 / 41.19 (config 3)
-#endif
-    constexpr int kDescendMin = ALL_LDS ? TRC_DESCEND_MIN_LDS : TRC_DESCEND_MIN_GLOBAL;
+    // LDS-resident trees: the plain round (a compile-time 1); trees read from memory: the scene's threshold, wave-uniform
+    const uint32_t kDescendMin = ALL_LDS ? (uint32_t)TRC_DESCEND_MIN_LDS : S.descend_min;
     for (;;) {
         const bool interior = (tv.tag >> kTagIndexBits) == kTagInterior;
-        if (!STATS && kDescendMin > 1) {
+        if (!STATS && (!ALL_LDS || TRC_DESCEND_MIN_LDS > 1)) {
             const unsigned long long m = __ballot(interior);
             if (m == 0ull) break;
-            if (__popcll(m) < kDescendMin && __ballot((tv.tag >> kTagIndexBits) < kTagInterior) != 0ull) break;      // somebody waits with a leaf
+            if ((uint32_t)__popcll(m) < kDescendMin && __ballot((tv.tag >> kTagIndexBits) < kTagInterior) != 0ull) break;      // somebody waits with a leaf
             if (!interior) continue;
         } else if (!interior) break;
         float4 q0, q1, q2, q3;

@@ -1367,6 +1367,7 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
 
     KRender kp{};
     kp.ks = ctx->ks;
+    if (ctx->knobs.descend_min > 0) kp.ks.sc.descend_min = (uint32_t)ctx->knobs.descend_min;      // A/B knob
     kp.cam = ctx->cam;
     kp.ambient[0] = ctx->ambient[0]; kp.ambient[1] = ctx->ambient[1]; kp.ambient[2] = ctx->ambient[2];
     kp.env_rgb = ctx->d_envmap; kp.env_w = ctx->env_w; kp.env_h = ctx->env_h;
@@ -2134,7 +2135,7 @@ trc_status trc_debug_set(trc_ctx* ctx, const char* knob, int value) {
               : k == "sppm_serial_camera" ? &ctx->knobs.sppm_serial_camera : k == "sppm_timing" ? &ctx->knobs.sppm_timing
               : k == "force_blk_shift" ? &ctx->knobs.force_blk_shift : k == "no_split" ? &ctx->knobs.no_split : k == "no_cost_filter" ? &ctx->knobs.no_cost_filter
               : k == "no_cold_probe" ? &ctx->knobs.no_cold_probe : k == "probe_spp" ? &ctx->knobs.probe_spp
-              : k == "no_plan_reuse" ? &ctx->knobs.no_plan_reuse : k == "no_coalesce" ? &ctx->knobs.no_coalesce : k == "no_dense" ? &ctx->knobs.no_dense : k == "head_stages" ? &ctx->knobs.head_stages : nullptr;
+              : k == "no_plan_reuse" ? &ctx->knobs.no_plan_reuse : k == "no_coalesce" ? &ctx->knobs.no_coalesce : k == "no_dense" ? &ctx->knobs.no_dense : k == "head_stages" ? &ctx->knobs.head_stages : k == "descend_min" ? &ctx->knobs.descend_min : nullptr;
     if (!slot) return fail(ctx, TRC_ERR_INVALID_ARG, "trc_debug_set: unknown knob " + k);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // a launch in flight keeps the plan it was made with

@@ -94,6 +94,7 @@ __device__ __forceinline__ SceneRef make_scene_ref(const DScene& sc, const uint3
     S.stack_lds = sc.stack_lds;
     S.stack_cap = sc.stack_depth;
     S.ovf = nullptr;
+    S.descend_min = sc.descend_min;
     return S;
 }
 
@@ -221,7 +222,7 @@ struct trc_ctx {
 
     // A/B and test knobs, per context: defaults from the environment at trc_create (TRC_NO_LDS_FIT, TRC_STACK_LDS_LEVELS,
     // TRC_STRIP_LEN, TRC_NO_PWG, TRC_SPPM_SERIAL_CAMERA), changed through trc_debug_set
-    struct Knobs { int no_lds_fit = 0, stack_lds_levels = 0, strip_len = 0, no_pwg = 0, sppm_serial_camera = 0, sppm_timing = 0, force_blk_shift = 0, no_split = 0, no_cost_filter = 0, no_cold_probe = 0, probe_spp = 0, no_plan_reuse = 0, no_coalesce = 0, no_dense = 0, head_stages = 0; } knobs;
+    struct Knobs { int no_lds_fit = 0, stack_lds_levels = 0, strip_len = 0, no_pwg = 0, sppm_serial_camera = 0, sppm_timing = 0, force_blk_shift = 0, no_split = 0, no_cost_filter = 0, no_cold_probe = 0, probe_spp = 0, no_plan_reuse = 0, no_coalesce = 0, no_dense = 0, head_stages = 0, descend_min = 0; } knobs;
     // k_render_pwg instantiations that were granted > 64 KB of dynamic LDS on THIS context's device (bit = integrator * 2 +
     // sobol): hipFuncSetAttribute applies to the current device only, so the grant is per context, not per process
     uint32_t pwg_lds_granted = 0;

@@ -58,6 +58,12 @@ inline trc_status validate_leaf(trc_ctx* ctx, const trc_scene* s, const trc_BVH&
     return TRC_OK;
 }
 
+#ifndef TRC_DESCEND_MIN_GLOBAL
+#define TRC_DESCEND_MIN_GLOBAL 12     // 8 until the loop lost its done flag; with the leaner step: 8 / 12 / 16 / 24 / 32 = 23.54 / 23.22 / 23.32 / 23.63 / 24.07 ms (config 4), 40.85 / 40.49 / 40.56 / 40.90 / 41.19 (config 3)
+#endif
+#ifndef TRC_DESCEND_MIN_BEYOND_CACHE
+#define TRC_DESCEND_MIN_BEYOND_CACHE 6
+#endif
 // blob offsets for `n_interior` fat nodes (see dev_scene.hpp)
 inline trc_status layout_scene(trc_ctx* ctx, const trc_scene* s, uint32_t n_interior, DScene& sc, uint64_t& total_dwords) {
     const uint32_t n_tri = s->n_index / 3;
@@ -76,6 +82,11 @@ inline trc_status layout_scene(trc_ctx* ctx, const trc_scene* s, uint32_t n_inte
     sc.off_triattr = sc.off_tripos + n_tri * kTriPosDwords;
     sc.n_nodes = n_interior; sc.n_spheres = s->n_sphere; sc.n_squares = s->n_square; sc.n_cubes = s->n_cube;
     sc.n_materials = s->n_material; sc.n_triangles = n_tri;
+    // Descent threshold of the production walk (trav_iter): a scene beyond the 256 MiB Infinity Cache pays HBM latency for most
+    // box steps, and a wavefront whose few remaining descenders keep everybody else waiting pays it once per step -- leaving the
+    // descent earlier wins there (teapot x 256, 708 MB: 19.3 / 18.3 / 17.9 / 17.9 ms per launch at 12 / 8 / 6 / 4), while the scenes that
+    // fit prefer 12 (config 4: 22.83 / 22.88 / 23.08 / 24.02; config 3: 40.06 / 40.29 / 40.72 / 41.51; profiles/r05/ab_descend*.txt).
+    sc.descend_min = total_dwords * 4ull > (256ull << 20) ? TRC_DESCEND_MIN_BEYOND_CACHE : TRC_DESCEND_MIN_GLOBAL;
     return TRC_OK;
 }
 
