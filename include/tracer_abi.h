@@ -598,7 +598,8 @@ trc_status trc_group_set_collectives(trc_ctx* ctx, const trc_collectives* table,
  * "no_split" (no cost-adaptive block size), "no_cost_filter" (launch order and plan from the last launch's durations instead of
  * the shortest seen lately), "force_blk_shift" (k + 1 forces 2^k x 2^k pixel blocks per wavefront, k = 0..3: measurement only), and
  * "sppm_timing" (event pairs around an SPPM frame's photon pass and its hash / table / refine passes, added to
- * trc_stats.kernel_ms; one `launch` per frame).  They change scheduling / bookkeeping only, never a pixel.  Unknown name: TRC_ERR_INVALID_ARG. */
+ * trc_stats.kernel_ms; one `launch` per frame), "descend_min" (n > 0: on trees read from memory the box-step loop of a wavefront goes on
+ * while at least n lanes are still descending and others wait with a leaf; 0 = the scene's own value, 12, or 6 beyond 256 MiB).  They change scheduling / bookkeeping only, never a pixel.  Unknown name: TRC_ERR_INVALID_ARG. */
 trc_status trc_debug_set(trc_ctx* ctx, const char* knob, int value);
 
 /* ------------------------------------------------------------------ */

@@ -401,3 +401,28 @@ def test_small_pixel_blocks_render_the_same_frame(gpu, cornell_spheres, W, H, sp
         assert a[2] == b[2] and np.array_equal(a[1], b[1]) and np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
     ref, rst = po.render(cornell_spheres.view, cam, W, H, host.fill_rng(99, W, H), spp=spp, integrator=integrator, env=(0.2, 0.3, 0.4))
     assert rst.rays == out[2][2] and np.array_equal(out[2][0].view(np.uint32), ref.view(np.uint32))
+
+
+def test_the_descent_threshold_is_scheduling_only(gpu, ball_mesh_scene):
+    """knob descend_min (DScene::descend_min: how many lanes of a wavefront must still be descending for the box-step loop to go on
+    while others wait with a leaf; 12 by default, 6 for scenes beyond the Infinity Cache): every lane performs its own sequence of
+    the reference's steps whatever the interleaving -- the frame, the RNG texture and the ray count do not move"""
+    W, H, spp = 256, 160, 8
+    cam = host.prepare_camera(W, H)
+    gpu.upload_scene(ball_mesh_scene.view); gpu.set_camera(cam); gpu.set_environment((0.0, 0.0, 0.0)); gpu.resize(W, H)
+    frames = []
+    try:
+        for integ in (abi.INTEGRATOR_PATH, abi.INTEGRATOR_MIS):
+            for n in (0, 1, 2, 6, 24, 64):
+                gpu.debug_set("descend_min", n)
+                gpu.seed(99); gpu.clear_accum(); gpu.reset_stats(); gpu.render(spp=spp, integrator=integ)
+                frames.append((integ, n, gpu.download_accum(), gpu.download_rng(), gpu.stats().rays))
+    finally:
+        gpu.debug_set("descend_min", 0)
+    for integ in (abi.INTEGRATOR_PATH, abi.INTEGRATOR_MIS):
+        mine = [f for f in frames if f[0] == integ]
+        ref, _ = po.render(ball_mesh_scene.view, cam, W, H, host.fill_rng(99, W, H), spp=spp, integrator=integ)
+        for _, n, acc, rng, rays in mine:
+            assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32)), (integ, n)
+            assert np.array_equal(rng, mine[0][3]) and rays == mine[0][4], (integ, n)
+
