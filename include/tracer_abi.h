@@ -530,6 +530,9 @@ trc_status trc_group_reduce_accum(trc_ctx* ctx, int root);
  *   - composed pixel = (((A_0 + A_1) + A_2) + ... + A_{nranks-1}) / (float)S per channel in binary32, A_r = rank r's
  *     accumulator texel: a rank-ORDERED sum (zeros of the other tile ranks are exact identities), one IEEE division.
  * Every group must have rendered the same number of samples (the mean of running means is the running mean only then).
+ * Defined for the PCG sampler: under TRC_FLAG_SOBOL a sample's Sobol' point is a function of (frame, pixel) alone, so groups that all
+ * count their frames from 0 draw the SAME points and differ only in the PCG draws (light pick, Russian roulette) -- legal, bit-defined
+ * the same way, and statistically worth little more than one group.
  * How it moves: each rank owns the r-th of nranks equal pixel slices; an all-to-all brings that slice of every rank's
  * accumulator (ncclSend / ncclRecv in one group call; at N = 8 and 1080p 29 MB in and out per rank, every pair on its own
  * xGMI link), a small kernel folds them in rank order, and a gather (root >= 0) brings the N slices (4 MB each) to the
