@@ -419,6 +419,12 @@ TRC_DEV bool mis_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, T
     const float _tr = 1.0f;
     const float _dis = length(_dir);
     const Ray _ray = make_ray(_origin, _nor);
+    // what the light sample contributes if the shadow ray gets through, reduced to four values BEFORE the walk (the same expressions
+    // on the same operands, :345-352): the sample itself (point, normal, material, area pdf) does not have to survive the walk
+    float cosOnLight = fabsf(dot(lsr.n, -_nor));
+    F3 light_term = mat_albedo(cx.sh, lsr.material) * cosOnLight;
+    float liPDF = (_dis * _dis) * lsr.areaPDF / cosOnLight;
+    TRC_PIN(light_term.x); TRC_PIN(light_term.y); TRC_PIN(light_term.z); TRC_PIN(liPDF);
     n_rays++;
     bool blocked;
     if (STATS) {                                  // the reference's walk (the exact counters are defined on it)
@@ -436,11 +442,7 @@ TRC_DEV bool mis_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, T
         float bxPDF = 0;
         n_shaded++;
         F3 weight = material_F(mtype, base_color, wo, wi, uu, bxPDF);
-        float cosOnLight = fabsf(dot(lsr.n, -_nor));
-        F3 Li = mat_albedo(cx.sh, lsr.material);
-        weight = weight * (Li * cosOnLight);
-        float dist2 = _dis * _dis;
-        float liPDF = dist2 * lsr.areaPDF / cosOnLight;
+        weight = weight * light_term;
         weight = weight * power_heuristic(1, liPDF, 1, bxPDF);
         ps.color = ps.color + _tr * ps.ratio * weight / liPDF;
     }

@@ -4,6 +4,13 @@
 //   dot = x*x' + y*y' + z*z' (left to right), length = sqrt(dot), normalize(v) = v * (1/length),
 //   IEEE-754 binary32 everywhere, no FMA contraction (-ffp-contract=off), NaN-ignoring min/max.
 #pragma once
+// a value the compiler must have computed HERE (it may not sink the computation behind a loop that follows): an empty asm that
+// claims to read and write the register
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TRC_PIN(x) asm volatile("" : "+v"(x))
+#else
+#define TRC_PIN(x) ((void)0)
+#endif
 
 #include <hip/hip_runtime.h>
 #include <float.h>
