@@ -151,6 +151,13 @@ def lib_source_hash():
     for f in files:
         h.update(f.encode())
         h.update(_code_only(open(os.path.join(ROOT, f), "r", errors="replace").read()).encode())
+    # ... and the options it is compiled with (the Makefile's flag lines, per-translation-unit ones included)
+    try:
+        for ln in open(os.path.join(ROOT, "Makefile"), "r", errors="replace"):
+            if ln.split(":=")[0].strip() in ("HIPFLAGS",) or ln.startswith("EXTRA_") or ln.lstrip().startswith("-Wall -Wno-unused-function"):
+                h.update(" ".join(ln.split()).encode())
+    except OSError:
+        pass
     return h.hexdigest()[:16]
 
 

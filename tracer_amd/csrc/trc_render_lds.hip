@@ -1,6 +1,8 @@
-// trc_render_lds.hip -- the render kernels of scenes whose whole tree is staged in LDS (the Cornell scenes: BASELINE config 2,
-// SPPM's scene), instantiated with the guard-free reciprocal / square root of dev_vec.hpp (TRC_FAST_UNARY, bit-identical:
-// tests/test_gpu_unary.py).  Definitions: trc_render_kernels.hpp; launched from trc_abi.hip.
+// trc_render_lds.hip -- tracePath on scenes whose whole tree is staged in LDS (the Cornell scenes: BASELINE config 2 -- the bench's
+// kernel), instantiated with the guard-free reciprocal / square root of dev_vec.hpp (TRC_FAST_UNARY, bit-identical:
+// tests/test_gpu_unary.py).  traceMIS / traceVolume on such scenes: trc_render_lds_mis.hip -- two translation units since round 5
+// because this one is compiled with -mllvm -amdgpu-use-amdgpu-trackers (Makefile: EXTRA_trc_render_lds; config 2 16.64 -> 16.50 ms,
+// traceMIS on the same scene would lose 1.6 %: profiles/r05/ab_flags*.txt).  Definitions: trc_render_kernels.hpp; launched from trc_abi.hip.
 #ifndef TRC_FAST_UNARY
 #define TRC_FAST_UNARY 1
 #endif
@@ -15,8 +17,4 @@ __global__ void __launch_bounds__(kBlock, TRC_PATH_WAVES_DENSE) k_render_dense(c
 #define TRC_INST_STRIP(I, B) template __global__ void k_render_strip<true, I, B>(const KRender)
 // exactly the instantiations launch_render<> picks from (trc_abi.hip)
 TRC_INST_RENDER(false, TRC_INTEGRATOR_PATH, false);   TRC_INST_RENDER(true, TRC_INTEGRATOR_PATH, false);   TRC_INST_RENDER(false, TRC_INTEGRATOR_PATH, true);
-TRC_INST_RENDER(false, TRC_INTEGRATOR_MIS, false);    TRC_INST_RENDER(true, TRC_INTEGRATOR_MIS, false);    TRC_INST_RENDER(false, TRC_INTEGRATOR_MIS, true);
-TRC_INST_RENDER(false, TRC_INTEGRATOR_VOLUME, false); TRC_INST_RENDER(true, TRC_INTEGRATOR_VOLUME, false);
 TRC_INST_STRIP(TRC_INTEGRATOR_PATH, false);  TRC_INST_STRIP(TRC_INTEGRATOR_PATH, true);
-TRC_INST_STRIP(TRC_INTEGRATOR_MIS, false);   TRC_INST_STRIP(TRC_INTEGRATOR_MIS, true);
-TRC_INST_STRIP(TRC_INTEGRATOR_VOLUME, false);
