@@ -1536,6 +1536,8 @@ struct CamRec {     // Photon.hh:30-53
     uint32_t photonCount = 0;
     void reset() { ratio = v3(1); position = v3(0); direction = v3(0); valid = false; flux = v3(0); radius = 0; photonCount = 0; }
 };
+inline float canon_nan(float x) { uint32_t q = 0x7FC00000u; float n; std::memcpy(&n, &q, 4); return x != x ? n : x; }
+inline V3 canon_nan(V3 v) { return v3(canon_nan(v.x), canon_nan(v.y), canon_nan(v.z)); }
 struct PhoRec {     // Photon.hh:12-28
     V3 flux = v3(1), normal = v3(0), position = v3(0), direction = v3(0);
     uint8_t step = 0;
@@ -1603,11 +1605,15 @@ void tracePhotonRecord(Ray& ray, RandomSampler& xsampler, PhoRec& pr, const Env&
         if (xsampler.random() > p) { pr.reset(); return; }
         ratio = ratio * (1.0f / p);
     }
-    V3 pn = hitRecord.sn * copysignf(1.0f, wi.z);
+    // A degenerate BSDF sample leaves wi = NaN (bxPDF NaN passes `<= 0`, Photon.metal:268-272), and the SIGN of a NaN is nobody's to
+    // define: x86 generates negative ones, gfx950 positive ones, Metal whatever the GPU does, and each propagates operand signs its own
+    // way.  The record exposes it twice -- copysign(1, wi.z) picks the side of the surface, and direction / flux are stored raw -- so
+    // both restatements fix it the same way: a NaN counts as positive, and a stored NaN is the canonical 0x7FC00000 (declared: DESIGN 6).
+    V3 pn = hitRecord.sn * (std::isnan(wi.z) ? 1.0f : copysignf(1.0f, wi.z));
     pr.position = offset_ray(hitRecord.p, pn);
     pr.normal = pn;
-    pr.direction = (nx * wi.x + ny * wi.y) + hitRecord.sn * wi.z;
-    pr.flux = pr.flux * ratio;
+    pr.direction = canon_nan((nx * wi.x + ny * wi.y) + hitRecord.sn * wi.z);
+    pr.flux = canon_nan(pr.flux * ratio);
     pr.step += 1;
     pr.active = !material.specular;
 }

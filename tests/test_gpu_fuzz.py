@@ -186,7 +186,12 @@ def max_leaf_depth(nodes):
     return int(depth.max())
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+_SPPM_SEEDS = os.environ.get("TRC_FUZZ_SPPM_SEEDS", "1:5").split(":")
+
+
+# 77, 534, 673: scenes of a 1 000-seed campaign in which a photon's BSDF sample is NaN -- copysign(1, NaN) and the stored NaNs took the
+# platform's sign (x86 / gfx950 differ) until both sides fixed it (oracle.cpp tracePhotonRecord)
+@pytest.mark.parametrize("seed", list(range(int(_SPPM_SEEDS[0]), int(_SPPM_SEEDS[1]))) + ([77, 534, 673] if _SPPM_SEEDS == ["1", "5"] else []))
 def test_generated_scene_sppm(gpu, seed):
     """the SPPM pass (Photon.metal) on generated scenes: accumulator, canvas RNG, photon and camera records, hash grids"""
     rs = np.random.RandomState(3000 + seed)
@@ -202,8 +207,12 @@ def test_generated_scene_sppm(gpu, seed):
     ocam, opho, omark, ocount, ocx = o.download()
     assert np.array_equal(drng, rng) and np.array_equal(dacc.view(np.uint32), acc.view(np.uint32))
     assert np.array_equal(dcount, ocount) and np.array_equal(dmark, omark)
-    for f in ("flux", "normal", "position", "direction", "step", "active"):
-        assert bytes(memoryview(np.ascontiguousarray(dpho[f]))) == bytes(memoryview(np.ascontiguousarray(opho[f]))), f
-    for f in ("ratio", "position", "direction", "valid", "alternative", "flux", "radius", "photonCount"):
-        assert bytes(memoryview(np.ascontiguousarray(dcam[f]))) == bytes(memoryview(np.ascontiguousarray(ocam[f]))), f
+    for what, got, ref, fields in (("photon", dpho, opho, ("flux", "normal", "position", "direction", "step", "active")),
+                                   ("camera", dcam, ocam, ("ratio", "position", "direction", "valid", "alternative", "flux", "radius", "photonCount"))):
+        for f in fields:
+            a, b = np.ascontiguousarray(got[f]), np.ascontiguousarray(ref[f])
+            if bytes(memoryview(a)) != bytes(memoryview(b)):
+                bad = np.flatnonzero((a.reshape(len(a), -1).view(np.uint8) != b.reshape(len(b), -1).view(np.uint8)).any(axis=1))
+                raise AssertionError(f"seed {seed}: {what} record field {f} differs in {len(bad)} records, first {bad[:4]}: "
+                                     f"gpu {got[bad[0]]} oracle {ref[bad[0]]}")
     assert dcx.frame_count == ocx.frame_count and dcx.totalPhotonSum == ocx.totalPhotonSum

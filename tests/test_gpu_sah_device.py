@@ -1,6 +1,7 @@
 """BVH::buildTree on the device (trc_upload_scene_sah, tracer_amd/csrc/trc_sah_build.hpp) against the two CPU statements of
 the reference's SAH build (RT_Metal/Metal/BVH.hh:35-269): oracle/oracle_sah.cpp (serial recursion on the reference's growing
 list) and the host builder of libtrc_host (parallel, slots assigned up front).  All 2n-1 records, bit for bit."""
+import os
 import ctypes as C
 
 import numpy as np
@@ -126,7 +127,8 @@ def fuzz_boxes(seed):
     return list(zip(lo, hi))
 
 
-@pytest.mark.parametrize("seed", range(48))
+# TRC_FUZZ_SAH_SEEDS="a:b": a longer campaign by hand (profiles/r05/fuzz_campaign.txt)
+@pytest.mark.parametrize("seed", range(*[int(x) for x in os.environ.get("TRC_FUZZ_SAH_SEEDS", "0:48").split(":")]))
 def test_fuzzed_leaf_sets(gpu, seed):
     sc = host.HostScene(abi.SCENE_CORNELL_SPHERES)
     boxes = fuzz_boxes(seed)

@@ -13,6 +13,7 @@ primitive that is tested although the reference would already have culled its bo
     reference's traversal order),
   * flat primitives lying IN a face of their box (computed t within an ulp of the box entry).
 """
+import os
 import ctypes as C
 
 import numpy as np
@@ -243,7 +244,7 @@ def adversarial_rays(rs, targets, per_target=24):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("seed", range(*[int(x) for x in os.environ.get("TRC_FUZZ_ADV_SEEDS", "1:7").split(":")]))
 def test_adversarial_batches(gpu, seed):
     rs = np.random.RandomState(7000 + seed)
     sv, keep, targets = adversarial_scene(rs)

@@ -184,6 +184,8 @@ TRC_DEV float fmax3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 TRC_DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 TRC_DEV bool is_inf(float x) { return fabsf(x) == __builtin_inff(); }
 TRC_DEV bool is_nan(float x) { return x != x; }
+TRC_DEV float canon_nan(float x) { return x != x ? __uint_as_float(0x7FC00000u) : x; }       // stored NaNs: one bit pattern (trc_sppm.hip)
+TRC_DEV F3 canon_nan(F3 v) { F3 r; r.x = canon_nan(v.x); r.y = canon_nan(v.y); r.z = canon_nan(v.z); return r; }
 
 // ---------------------------------------------------------------- a / b for several a's and one b, same bits as `/`
 // hipcc's correctly rounded binary32 division is 11 instructions: v_div_scale x 2 (bring the operands into a range where

@@ -342,11 +342,13 @@ __global__ void __launch_bounds__(kBlock, TRC_SPPM_PHOTON_WAVES) k_sppm_photon(c
         }
         if (!alive) { flux = f3(1); step = 0; active = false; }      // reset()
         else {
-            F3 pn = rec.sn * copysignf(1.0f, wi.z);
+            // a NaN wi (degenerate BSDF sample) counts as positive and is stored canonical: the sign of a NaN is platform business
+            // (oracle.cpp tracePhotonRecord)
+            F3 pn = rec.sn * (is_nan(wi.z) ? 1.0f : copysignf(1.0f, wi.z));
             position = offset_ray(rec.p, pn);
             normal = pn;
-            direction = (nx * wi.x + ny * wi.y) + rec.sn * wi.z;
-            flux = flux * ratio;
+            direction = canon_nan((nx * wi.x + ny * wi.y) + rec.sn * wi.z);
+            flux = canon_nan(flux * ratio);
             step = (step + 1) & 0xFFu;
             active = !mat_specular(cx.sh, rec.material);
         }
