@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Differential campaign beyond tests/test_gpu_fuzz.py's small frames: generated scenes (its generator) at frame sizes, sample counts
+and launch sequences that bring the adaptive machinery in -- cost-ordered launches, the split plan, persistent workgroups with
+overflow stacks, coalesced 1-sample calls, progressive accumulation over several calls -- GPU against the oracle, bit for bit.
+    python3 tools/fuzz_frames.py <first seed> <last seed>"""
+import math, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+os.environ.setdefault("TRC_FUZZ_SEEDS", "1:2")
+import test_gpu_fuzz as tf
+from oracle import pyoracle as po
+from tracer_amd import abi, host
+from tracer_amd.device import Tracer
+
+gpu = Tracer(0)
+bad = 0
+a, b = int(sys.argv[1]), int(sys.argv[2])
+for seed in range(a, b):
+    rs = np.random.RandomState(50000 + seed)
+    big = seed % 2 == 0
+    sv, keep = tf.random_scene(rs, n_spheres=int(rs.randint(3, 20)), n_cubes=int(rs.randint(1, 6)),
+                               n_tris=int(rs.randint(900, 4000)) if big else int(rs.randint(5, 60)))
+    W, H = int(rs.randint(40, 330)), int(rs.randint(40, 210))
+    integ = int(rs.randint(3))
+    calls = [int(rs.choice([1, 1, 2, 3, 8, 9, 16, 24, 33])) for _ in range(int(rs.randint(1, 6)))]
+    depth = int(rs.randint(1, 9))
+    look_from = rs.uniform(-150, 150, 3); look_from[2] = -170.0
+    if seed % 4 == 3: look_from = rs.uniform(-35, 35, 3)            # a camera INSIDE the scene: rays start within boxes, media, next to surfaces
+    cam = host.make_camera(tuple(look_from), tuple(rs.uniform(-10, 10, 3)), (0, 1, 0), float(rs.uniform(0.0, 3.0)), W / H, math.radians(55), 170.0)
+    grid = rs.rand(6, 7, 8).astype(np.float32) * (rs.rand(6, 7, 8) > 0.4)
+    info = host.density_info(np.ascontiguousarray(grid), sigma_a=0.02, sigma_s=0.05, g=0.3)
+    env = (0.3, 0.4, 0.6) if seed % 3 else (0.0, 0.0, 0.0)
+    gpu.upload_scene(sv); gpu.set_camera(cam); gpu.set_environment(env); gpu.resize(W, H)
+    gpu.upload_density(info, np.ascontiguousarray(grid)); po.set_density(info, np.ascontiguousarray(grid))
+    ok = True
+    for rep in range(2):                     # the second pass runs on the first one's block costs (cost order, split plan)
+        rng = host.fill_rng(70 + seed, W, H)
+        gpu.upload_rng(rng); gpu.clear_accum(); gpu.reset_stats()
+        f0 = 0
+        for c in calls:
+            gpu.render(spp=c, integrator=integ, max_depth=depth, frame0=f0); f0 += c
+        got, got_rng, st = gpu.download_accum(), gpu.download_rng(), gpu.stats()
+        if rep == 0:
+            ref_rng = rng.copy()
+            ref, rst = po.render(sv, cam, W, H, ref_rng, spp=sum(calls), integrator=integ, max_depth=depth, env=env)
+        if not (np.array_equal(got.view(np.uint32), ref.view(np.uint32)) and np.array_equal(got_rng, ref_rng) and st.rays == rst.rays):
+            ok = False
+            print(f"MISMATCH seed {seed} pass {rep}: {W}x{H} integrator {integ} calls {calls} depth {depth} big {big}: "
+                  f"{int((got.view(np.uint32) != ref.view(np.uint32)).any(axis=2).sum())} pixels, rays {st.rays} / {rst.rays}", flush=True)
+    bad += not ok
+    po.set_density(None, None); gpu.upload_density(None, None)
+print(f"seeds {a}..{b - 1}: {b - a - bad} passed, {bad} FAILED")
