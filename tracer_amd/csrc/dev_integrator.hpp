@@ -8,6 +8,12 @@
 #include "dev_intersect.hpp"
 #include "trc_sobol.h"
 
+// traceVolume: steps of the GridDensity medium's delta tracker a lane takes per iteration of the render loop before the other lanes
+// get their next Scene::hit (dev_integrator.hpp grid_sample); 0 = the whole tracker at once
+#ifndef TRC_TRACK_SLICE
+#define TRC_TRACK_SLICE 20
+#endif
+
 namespace trcdev {
 
 // ---------------------------------------------------------------- PCG32 (Random.metal:3-26)
@@ -124,6 +130,9 @@ struct PathState {
     bool primary;            // the ray in flight is the camera ray
     int medium;              // traceVolume: Ray::medium (Ray.hh:18) of the ray in flight
     bool from_bsdf;          // traceVolume: the ray in flight left the BSDF-sampling branch (Render.metal:255-271 applies)
+    bool tracking;           // traceVolume, TRC_TRACK_SLICE: the delta tracker of the GridDensity medium is part-way (grid_sample_slice)
+    float trk_t;
+    int trk_step;
     uint64_t sobol_index;    // TRC_FLAG_SOBOL: mSobolIndex of this sample and the next dimension (SobolSampler.hh:37-41)
     uint32_t sobol_dim;
 };
@@ -182,6 +191,7 @@ TRC_DEV void path_begin(PathState& ps, const Ray& camera_ray, uint32_t max_depth
     ps.primary = true;
     ps.medium = TRC_MEDIUM_NIL;
     ps.from_bsdf = false;
+    ps.tracking = false; ps.trk_t = 0.0f; ps.trk_step = 0;
 }
 
 // What happens between two Scene::hit calls of tracePath (Render.metal:432-489).  Returns true when the
@@ -309,12 +319,18 @@ TRC_DEV float grid_density(const trc_GridDensityInfo& info, const float* density
     return lerp_f(d.z, d0, d1);
 }
 constexpr int kGridSampleMaxSteps = 1 << 16;      // same bound as oracle/oracle.cpp (the reference loop is unbounded)
-TRC_DEV float grid_sample(const PathCtx& cx, const HitRec& rec, MediumHit& mi, Pcg& rng) {
+// The tracker in SLICES of at most `budget` steps (budget < 0: to the end): t and the step count live in the path state, a slice that
+// runs out returns kTrackMore and the lane comes back for the next one WITHOUT a Scene::hit in between (trc_render_kernels.hpp) --
+// the lanes that are not in the cloud go on with their paths instead of waiting for ~100 steps of somebody else's.  The lane's own
+// sequence of operations (and its RNG stream) is the unsliced loop's.
+constexpr float kTrackMore = -1.0f;
+TRC_DEV float grid_sample(const PathCtx& cx, const HitRec& rec, MediumHit& mi, Pcg& rng, float& t, int& step, int budget) {
     if (!cx.density) return 1.0f;
     const trc_GridDensityInfo& info = cx.dinfo;
     const float tMax = rec.vol_t;
-    float t = 0;
-    for (int step = 0; step < kGridSampleMaxSteps; ++step) {
+    for (; step < kGridSampleMaxSteps; ++step) {
+        if (budget == 0) return kTrackMore;
+        --budget;
         t -= dm_logf(1 - pcg_float(rng)) * info.invMaxDensity / info.sigma_t;
         if (t >= tMax) break;
         const F3 p = rec.vol_o + rec.vol_d * t;
@@ -356,6 +372,8 @@ template <bool ALL_LDS, bool STATS, bool VOLUME = false, bool SOBOL = false, boo
 TRC_DEV bool mis_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, TravCounters& cnt, uint32_t& n_rays,
                       uint32_t& n_shaded, F3& result) {
     HitRec& rec = ps.rec;
+    const bool resume = VOLUME && TRC_TRACK_SLICE > 0 && ps.tracking;      // back for the next slice of the delta tracker: nothing below was left undone
+    if (!resume) {
     if (!ps.primary) {
         if ((!VOLUME || ps.from_bsdf) && hitted && mat_type(cx.sh, rec.material) == kMatDiffuse) {   // MIS-weighted emitter hit, :390-404
             F3 Li = mat_albedo(cx.sh, rec.material);
@@ -372,8 +390,9 @@ TRC_DEV bool mis_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, T
     }
     ps.primary = false;
     if (!hitted) { result = ps.color + ps.ratio * env_radiance(cx.env, cx.ambient, ps.ray.d); return true; }
+    }
     const int mtype = mat_type(cx.sh, rec.material);
-    if (mtype == kMatDiffuse) {
+    if (!resume && mtype == kMatDiffuse) {
         F3 le = mat_albedo(cx.sh, rec.material);
         float w = dot(-ps.ray.d, -rec.gn);
         result = ps.ratio * le * fabsf(w);
@@ -382,8 +401,16 @@ TRC_DEV bool mis_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, T
     if (VOLUME) {                                                    // Render.metal:114-158
         MediumHit mi;
         mi.p = f3(0); mi.phaseG = 0; mi.sampled = false;
-        if (ps.medium == TRC_MEDIUM_HOMOGENEOUS) ps.ratio = ps.ratio * homogeneous_sample(ps.ray, rec, mi, rng);
-        else if (ps.medium == TRC_MEDIUM_GRIDDENSITY) ps.ratio = ps.ratio * f3(grid_sample(cx, rec, mi, rng));
+        if (!resume && ps.medium == TRC_MEDIUM_HOMOGENEOUS) ps.ratio = ps.ratio * homogeneous_sample(ps.ray, rec, mi, rng);
+        else if (ps.medium == TRC_MEDIUM_GRIDDENSITY) {
+            if (!resume) { ps.trk_t = 0.0f; ps.trk_step = 0; }
+            const float beam = grid_sample(cx, rec, mi, rng, ps.trk_t, ps.trk_step, TRC_TRACK_SLICE > 0 ? TRC_TRACK_SLICE : -1);
+            if (TRC_TRACK_SLICE > 0) {
+                ps.tracking = beam == kTrackMore;
+                if (ps.tracking) return false;
+            }
+            ps.ratio = ps.ratio * f3(beam);
+        }
         if (mi.sampled) {                                            // scatter inside the medium
             F2 u2; u2.x = pcg_float(rng); u2.y = pcg_float(rng);
             F3 wi;

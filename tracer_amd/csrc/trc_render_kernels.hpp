@@ -104,11 +104,14 @@ __device__ __forceinline__ void render_block(const KRender& kp, const DScene& sc
         // flat loop: one Scene::hit per iteration; a finished path immediately regenerates the next sample
         while (alive) {
             ProfScope<STATS> loop_scope(cnt, kProfLoop);
-            n_rays++;
             constexpr bool kVolume = INTEGRATOR == TRC_INTEGRATOR_VOLUME;
             constexpr int kDefer = STATS ? 0 : (LDS ? TRC_DEFER_LDS : TRC_DEFER_GLOBAL);      // dev_intersect.hpp: trav_test_leaf
-            const bool hitted = scene_hit<LDS, STATS, false, false, kVolume, HYB, kDefer>(cx.S, cx.root_min, cx.root_max, ps.ray, ps.rec, FLT_MAX,
-                                                                        cx.stack, cx.lvstack, cnt);
+            bool hitted = true;
+            if (!(kVolume && TRC_TRACK_SLICE > 0 && ps.tracking)) {       // a lane between two slices of its delta tracker has no ray to trace
+                n_rays++;
+                hitted = scene_hit<LDS, STATS, false, false, kVolume, HYB, kDefer>(cx.S, cx.root_min, cx.root_max, ps.ray, ps.rec, FLT_MAX,
+                                                                                  cx.stack, cx.lvstack, cnt);
+            }
             F3 color;
             const bool finished = (INTEGRATOR == TRC_INTEGRATOR_PATH)
                                       ? path_step<STATS, SOBOL>(cx, ps, hitted, rng, cnt, n_shaded, color)
@@ -332,11 +335,14 @@ __global__ void __launch_bounds__(kBlock, INTEGRATOR == TRC_INTEGRATOR_VOLUME ? 
         deal_pixels();
         if (__ballot(alive || want) == 0ull) break;
         if (alive) {
-            n_rays++;
             constexpr bool kVolume = INTEGRATOR == TRC_INTEGRATOR_VOLUME;
             constexpr int kDefer = LDS ? TRC_DEFER_LDS : TRC_DEFER_GLOBAL;
-            const bool hitted = scene_hit<LDS, false, false, false, kVolume, kHybridStack, kDefer>(cx.S, cx.root_min, cx.root_max, ps.ray, ps.rec, FLT_MAX,
-                                                                      cx.stack, cx.lvstack, cnt);
+            bool hitted = true;
+            if (!(kVolume && TRC_TRACK_SLICE > 0 && ps.tracking)) {       // render_block's loop above
+                n_rays++;
+                hitted = scene_hit<LDS, false, false, false, kVolume, kHybridStack, kDefer>(cx.S, cx.root_min, cx.root_max, ps.ray, ps.rec, FLT_MAX,
+                                                                          cx.stack, cx.lvstack, cnt);
+            }
             F3 color;
             const bool finished = (INTEGRATOR == TRC_INTEGRATOR_PATH)
                                       ? path_step<false, SOBOL>(cx, ps, hitted, rng, cnt, n_shaded, color)
