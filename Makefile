@@ -19,10 +19,11 @@ HIPFLAGS  := -std=c++17 -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-s
 
 HOST_SRC  := tracer_amd/host/bvh_builder.cpp tracer_amd/host/scene.cpp tracer_amd/host/mesh.cpp tracer_amd/host/pbrt_scene.cpp
 HOST_HDR  := tracer_amd/host/host_math.hpp tracer_amd/host/host_scene.hpp tracer_amd/host/pbrt_text.hpp include/tracer_abi.h include/trc_sobol.h
-HIP_SRC   := tracer_amd/csrc/trc_abi.hip tracer_amd/csrc/trc_render_lds.hip tracer_amd/csrc/trc_render_lds_mis.hip tracer_amd/csrc/trc_render_mem.hip tracer_amd/csrc/trc_render_mem_path.hip tracer_amd/csrc/trc_sppm.hip tracer_amd/csrc/trc_lbvh.hip
+HIP_SRC   := tracer_amd/csrc/trc_abi.hip tracer_amd/csrc/trc_render_lds.hip tracer_amd/csrc/trc_render_lds_mis.hip tracer_amd/csrc/trc_render_mem.hip tracer_amd/csrc/trc_render_mem_path.hip tracer_amd/csrc/trc_render_mem_volume.hip tracer_amd/csrc/trc_sppm.hip tracer_amd/csrc/trc_lbvh.hip
 # per translation unit: backend options that pay for ONE kernel family (profiles/r05/ab_flags*.txt: eight scheduler / sinking / LICM options
 # tried on configs 2 / 3 / 4; everything else is within +-1 % or worse).  Scheduling only: the parity suites run on this build.
 EXTRA_trc_render_mem_path := -mllvm -disable-machine-sink
+EXTRA_trc_render_mem_volume := -mllvm -disable-machine-sink
 EXTRA_trc_render_lds      := -mllvm -amdgpu-use-amdgpu-trackers
 HIP_HDR   := $(wildcard tracer_amd/csrc/*.hpp) include/tracer_abi.h include/tracer_test_hooks.h include/trc_detmath.h include/trc_sobol.h
 

@@ -93,12 +93,13 @@ constexpr int pwg_waves(int integrator) { return integrator == TRC_INTEGRATOR_PA
 constexpr uint32_t pwg_stack_lds_levels(int integrator) { return integrator == TRC_INTEGRATOR_MIS ? 8u : 16u; }
 constexpr int pwg_per_cu(int integrator) { return integrator == TRC_INTEGRATOR_PATH ? TRC_PWG_PER_CU_PATH : (integrator == TRC_INTEGRATOR_MIS ? TRC_PWG_PER_CU_MIS : TRC_PWG_PER_CU_VOLUME); }
 
-// The kernels themselves (trc_render_kernels.hpp) are instantiated in four translation units -- by tree residence and integrator family,
+// The kernels themselves (trc_render_kernels.hpp) are instantiated in five translation units -- by tree residence and integrator family,
 // so that each can be compiled with the backend options that pay for it (Makefile: EXTRA_*), and in parallel:
 //   trc_render_lds.hip        tracePath, whole tree staged in LDS (Cornell scenes; the bench's kernel)       -amdgpu-use-amdgpu-trackers
 //   trc_render_lds_mis.hip    traceMIS / traceVolume, whole tree staged in LDS
 //   trc_render_mem_path.hip   tracePath, trees read from memory (mesh scenes)                                 -disable-machine-sink
-//   trc_render_mem.hip        traceMIS / traceVolume, trees read from memory
+//   trc_render_mem.hip        traceMIS, trees read from memory
+//   trc_render_mem_volume.hip traceVolume, trees read from memory                                             -disable-machine-sink
 template <bool LDS, bool STATS, int INTEGRATOR, bool SOBOL = false>
 __global__ void k_render(const KRender kp);
 __global__ void k_render_dense(const KRender kp);      // trc_render_lds.hip
