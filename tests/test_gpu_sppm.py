@@ -58,6 +58,37 @@ def test_sppm_bit_exact(gpu, cornell_spheres, n_frames):
     assert oacc[..., :3].max() > 0
 
 
+def test_a_frame_without_any_visible_point(gpu, cornell_spheres):
+    """The camera looks AWAY from the box: no pixel records a visible point, every pixel contributes {FLT_MAX, -FLT_MAX} to the bound
+    (Photon.metal:157-161), and kernelPhotonParams turns that into box size -inf, radius -inf, hash scale -0 (:357-372).  Found by
+    tools/fuzz_sppm.py in round 5 (cameras inside objects): the device started its min / max keys at the ends of the key range and
+    decoded NaN.  Everything, the Complex block included, equals the oracle."""
+    import struct
+    W, H = 64, 40
+    cam = host.make_camera((278, 278, -800), (278, 278, -2000), (0, 1, 0), 0.0, W / H, np.radians(40.0), 10.0)
+    gpu.upload_scene(cornell_spheres.view); gpu.set_camera(cam); gpu.set_environment((0.0, 0.0, 0.0)); gpu.resize(W, H)
+    gpu.seed(3); gpu.sppm_init(9); gpu.sppm_frames(3)
+    dcam, dpho, dmark, dcount, dcx = gpu.sppm_download()
+    dacc, drng = gpu.download_accum(), gpu.download_rng()
+    rng = host.fill_rng(3, W, H); acc = np.zeros((H, W, 4), np.float32)
+    s = po.Sppm(W, H, 9); s.frames(cornell_spheres.view, cam, rng, acc, 3)
+    ocam, opho, omark, ocount, ocx = s.download()
+    assert not ocam["valid"].any()
+    bits = lambda x: struct.unpack("<I", struct.pack("<f", x))[0]
+    assert ocx.photonInitialRadius == -np.inf and bits(ocx.photonHashScale) == 0x80000000
+    for f in ["frame_count", "photonInitialRadius", "photonHashScale", "totalPhotonSum", "framePhotonSum"]:
+        assert bits(float(getattr(dcx, f))) == bits(float(getattr(ocx, f))), f
+    for ax in "xyz":
+        assert getattr(dcx.photonBox.mini, ax) == getattr(ocx.photonBox.mini, ax) == np.inf
+        assert getattr(dcx.photonBox.maxi, ax) == getattr(ocx.photonBox.maxi, ax) == -np.inf
+    for f in PHO_FIELDS:
+        assert bits_equal(dpho[f], opho[f]), f"photon {f}"
+    for f in CAM_FIELDS:
+        assert bits_equal(dcam[f], ocam[f]), f"camera record {f}"
+    assert np.array_equal(dcount, ocount) and np.array_equal(dmark, omark) and np.array_equal(drng, rng)
+    assert np.array_equal(dacc.view(np.uint32), acc.view(np.uint32))
+
+
 def test_sppm_mesh_scene(gpu, ball_mesh_scene):
     (dcam, dpho, dmark, dcount, dcx), dacc, drng, (ocam, opho, omark, ocount, ocx), oacc, orng = run_both(
         gpu, ball_mesh_scene, 64, 40, 2)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Differential campaign beyond tests/test_gpu_fuzz.py's small frames: generated scenes (its generator) at frame sizes, sample counts
 and launch sequences that bring the adaptive machinery in -- cost-ordered launches, the split plan, persistent workgroups with
-overflow stacks, coalesced 1-sample calls, progressive accumulation over several calls -- GPU against the oracle, bit for bit.
+overflow stacks, coalesced 1-sample calls, progressive accumulation over several calls, the Sobol' sampler, one tile rank of several,
+stacked views -- GPU against the oracle, bit for bit.
     python3 tools/fuzz_frames.py <first seed> <last seed>"""
 import math, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,9 +26,16 @@ for seed in range(a, b):
     integ = int(rs.randint(3))
     calls = [int(rs.choice([1, 1, 2, 3, 8, 9, 16, 24, 33])) for _ in range(int(rs.randint(1, 6)))]
     depth = int(rs.randint(1, 9))
+    # every fifth case through the Sobol' sampler (tracePath / traceMIS), every seventh as one tile rank of 2..5, every ninth as stacked views
+    sobol = seed % 5 == 4 and integ != 2
+    nranks = int(rs.randint(2, 6)) if seed % 7 == 6 else 1
+    trank = int(rs.randint(nranks))
+    views = int(rs.randint(2, 4)) if seed % 9 == 8 else 1
+    if views > 1: H = (H // views) * views
+    vh = H // views
     look_from = rs.uniform(-150, 150, 3); look_from[2] = -170.0
     if seed % 4 == 3: look_from = rs.uniform(-35, 35, 3)            # a camera INSIDE the scene: rays start within boxes, media, next to surfaces
-    cam = host.make_camera(tuple(look_from), tuple(rs.uniform(-10, 10, 3)), (0, 1, 0), float(rs.uniform(0.0, 3.0)), W / H, math.radians(55), 170.0)
+    cam = host.make_camera(tuple(look_from), tuple(rs.uniform(-10, 10, 3)), (0, 1, 0), float(rs.uniform(0.0, 3.0)), W / vh, math.radians(55), 170.0)
     grid = rs.rand(6, 7, 8).astype(np.float32) * (rs.rand(6, 7, 8) > 0.4)
     info = host.density_info(np.ascontiguousarray(grid), sigma_a=0.02, sigma_s=0.05, g=0.3)
     env = (0.3, 0.4, 0.6) if seed % 3 else (0.0, 0.0, 0.0)
@@ -39,14 +47,15 @@ for seed in range(a, b):
         gpu.upload_rng(rng); gpu.clear_accum(); gpu.reset_stats()
         f0 = 0
         for c in calls:
-            gpu.render(spp=c, integrator=integ, max_depth=depth, frame0=f0); f0 += c
+            gpu.render(spp=c, integrator=integ, max_depth=depth, frame0=f0, sobol=sobol, tile_rank=trank, tile_nranks=nranks, view_height=vh if views > 1 else 0); f0 += c
         got, got_rng, st = gpu.download_accum(), gpu.download_rng(), gpu.stats()
         if rep == 0:
             ref_rng = rng.copy()
-            ref, rst = po.render(sv, cam, W, H, ref_rng, spp=sum(calls), integrator=integ, max_depth=depth, env=env)
+            ref, rst = po.render(sv, cam, W, H, ref_rng, spp=sum(calls), integrator=integ, max_depth=depth, env=env, sobol=sobol,
+                                  tile_rank=trank, tile_nranks=nranks, view_height=vh if views > 1 else 0)
         if not (np.array_equal(got.view(np.uint32), ref.view(np.uint32)) and np.array_equal(got_rng, ref_rng) and st.rays == rst.rays):
             ok = False
-            print(f"MISMATCH seed {seed} pass {rep}: {W}x{H} integrator {integ} calls {calls} depth {depth} big {big}: "
+            print(f"MISMATCH seed {seed} pass {rep}: {W}x{H} integrator {integ} calls {calls} depth {depth} big {big} sobol {sobol} rank {trank}/{nranks} views {views}: "
                   f"{int((got.view(np.uint32) != ref.view(np.uint32)).any(axis=2).sum())} pixels, rays {st.rays} / {rst.rays}", flush=True)
     bad += not ok
     po.set_density(None, None); gpu.upload_density(None, None)

@@ -253,10 +253,13 @@ __global__ void __launch_bounds__(kBlock, TRC_SPPM_CAMERA_WAVES) k_sppm_camera(c
     if (first) { kp.vp.flux_radius[pix] = make_float4(0, 0, 0, 0); kp.vp.count[pix] = 0u; }
     reinterpret_cast<uint4*>(kp.canvas_rng)[pix] = ex_rng(rng);
 
-    if (kp.frame_count == 0 && valid) {         // cameraAABB + kernelCameraReducing: exact min/max of the valid positions
-        atomicMin(&kp.cx->key_min[0], f2key(cr_position.x)); atomicMax(&kp.cx->key_max[0], f2key(cr_position.x));
-        atomicMin(&kp.cx->key_min[1], f2key(cr_position.y)); atomicMax(&kp.cx->key_max[1], f2key(cr_position.y));
-        atomicMin(&kp.cx->key_min[2], f2key(cr_position.z)); atomicMax(&kp.cx->key_max[2], f2key(cr_position.z));
+    // cameraAABB + kernelCameraReducing (Photon.metal:157-161,169-218): exact min / max of the valid positions over the {FLT_MAX, -FLT_MAX}
+    // every other pixel contributes -- the keys start there (trc_sppm_init), so a frame without ANY visible point ends like the reference's
+    // (box size -inf, radius -inf, hash scale -0), and a NaN component is skipped as min / max skip it
+    if (kp.frame_count == 0 && valid) {
+        const float c[3] = {cr_position.x, cr_position.y, cr_position.z};
+        for (int k = 0; k < 3; ++k)
+            if (c[k] == c[k]) { atomicMin(&kp.cx->key_min[k], f2key(c[k])); atomicMax(&kp.cx->key_max[k], f2key(c[k])); }
     }
     }
     const uint32_t r = wave_sum(n_rays);
@@ -662,7 +665,7 @@ trc_status trc_sppm_init(trc_ctx* ctx, uint64_t photon_seed) {
     HIP_TRY(ctx, hipMemsetAsync(s->d_count, 0, nph * 4, ctx->stream));
     DComplex h;
     std::memset(&h, 0, sizeof h);
-    for (int k = 0; k < 3; ++k) { h.key_min[k] = 0xFFFFFFFFu; h.key_max[k] = 0u; }
+    for (int k = 0; k < 3; ++k) { h.key_min[k] = 0xFF7FFFFFu; h.key_max[k] = 0x00800000u; }      // f2key(FLT_MAX), f2key(-FLT_MAX): k_sppm_camera
     HIP_TRY(ctx, hipMemcpyAsync(s->d_cx, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // `h` is a stack temporary
     hipLaunchKernelGGL(k_sppm_seed, dim3((unsigned)((nph + 255) / 256)), dim3(256), 0, ctx->stream, s->d_photon_rng,
