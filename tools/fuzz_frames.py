@@ -2,7 +2,7 @@
 """Differential campaign beyond tests/test_gpu_fuzz.py's small frames: generated scenes (its generator) at frame sizes, sample counts
 and launch sequences that bring the adaptive machinery in -- cost-ordered launches, the split plan, persistent workgroups with
 overflow stacks, coalesced 1-sample calls, progressive accumulation over several calls, the Sobol' sampler, one tile rank of several,
-stacked views -- GPU against the oracle, bit for bit.
+stacked views, equirectangular environment maps -- GPU against the oracle, bit for bit.
     python3 tools/fuzz_frames.py <first seed> <last seed>"""
 import math, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -39,6 +39,9 @@ for seed in range(a, b):
     grid = rs.rand(6, 7, 8).astype(np.float32) * (rs.rand(6, 7, 8) > 0.4)
     info = host.density_info(np.ascontiguousarray(grid), sigma_a=0.02, sigma_s=0.05, g=0.3)
     env = (0.3, 0.4, 0.6) if seed % 3 else (0.0, 0.0, 0.0)
+    # every fourth case (offset 1) under an equirectangular environment map of odd sizes, 1 x 1 included (the open scenes let most rays out)
+    envmap = rs.uniform(0.0, 3.0, (int(rs.randint(1, 40)), int(rs.randint(1, 70)), 3)).astype(np.float32) if seed % 4 == 1 else None
+    gpu.set_environment_map(envmap); po.set_environment_map(envmap)
     gpu.upload_scene(sv); gpu.set_camera(cam); gpu.set_environment(env); gpu.resize(W, H)
     gpu.upload_density(info, np.ascontiguousarray(grid)); po.set_density(info, np.ascontiguousarray(grid))
     ok = True
@@ -59,4 +62,5 @@ for seed in range(a, b):
                   f"{int((got.view(np.uint32) != ref.view(np.uint32)).any(axis=2).sum())} pixels, rays {st.rays} / {rst.rays}", flush=True)
     bad += not ok
     po.set_density(None, None); gpu.upload_density(None, None)
+    if envmap is not None: gpu.set_environment_map(None); po.set_environment_map(None)
 print(f"seeds {a}..{b - 1}: {b - a - bad} passed, {bad} FAILED")
