@@ -131,6 +131,19 @@ def test_ranks_sample_sharded_without_pytorch(gpu, tmp_path, ranks):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ranks,W,H", [(4, 9, 31), (8, 4, 5), (4, 27, 21)])
+def test_more_ranks_than_tiles(gpu, ranks, W, H):
+    """A frame so small that some ranks own NO tile (one, two, four tiles of 16 x 16 for 4 / 8 / 4 ranks): such a rank still bounces its
+    photon range and takes part in the all-reduce of the bound keys and the all-gather of the photon records.  Up to round 5 it returned
+    from trc_sppm_frames at once and the others waited for it (found by tools/fuzz_ranks.sh).  The program compares the composed frame
+    and the SPPM frame with the 1-rank results itself."""
+    log = subprocess.run([RANKS_EXE, "--ranks", str(ranks), "--host-collectives", "--size", str(W), str(H), "--spp", "6", "--sppm", "3",
+                          "--out", "/dev/null"], text=True, capture_output=True, timeout=600)
+    assert log.returncode == 0, log.stdout + log.stderr
+    assert "composed frame == the 1-rank frame" in log.stdout and f"the {ranks}-rank frame == the 1-rank frame" in log.stdout
+
+
+@pytest.mark.gpu
 def test_rccl_unique_id_travels_over_the_socket(gpu):
     """the default path of the example with one rank: trc_group_unique_id -> trc_group_init -> ncclReduce, no Python involved"""
     log = subprocess.run([RANKS_EXE, "--ranks", "1", "--size", "320", "200", "--spp", "8", "--out", "/dev/null"], text=True,

@@ -695,7 +695,10 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
     if (nph % (nranks * kBlock)) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "512*512 photons must split evenly over the ranks");
     const uint32_t chunk = nph / nranks;
     { trc_status ts = trc_ensure_tiles(ctx, nranks, rank); if (ts != TRC_OK) return ts; }
-    if (ctx->n_tiles == 0) return TRC_OK;
+    // A rank that owns no tile of a small frame still bounces ITS photon range and takes part in every collective (it returned early
+    // here up to round 5 and left the others waiting in the all-reduce: tools/fuzz_ranks.sh); only its camera and refine launches are empty.
+    if (ctx->n_tiles == 0 && !grouped) return TRC_OK;
+    const bool has_tiles = ctx->n_tiles != 0;
 
     KSppm kp{};
     kp.ks = ctx->ks; kp.cam = ctx->cam;
@@ -717,6 +720,7 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
         return st;
     };
     auto camera_launch = [&](const KSppm& k, hipStream_t st) {
+        if (!has_tiles) return;
         if (all_lds) hipLaunchKernelGGL((k_sppm_camera<true>), dim3(ctx->n_tiles), dim3(kBlock), lds, st, k);
         else hipLaunchKernelGGL((k_sppm_camera<false>), dim3(ctx->n_tiles), dim3(kBlock), lds, st, k);
     };
@@ -791,7 +795,7 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
             s->cur ^= 1; s->cam_ahead = 0;
             kp.vp = kp.vp_prev = s->vp[s->cur];
         }
-        hipLaunchKernelGGL(k_sppm_refine, dim3(ctx->n_tiles), dim3(kBlock), 0, ctx->stream, kp);
+        if (has_tiles) hipLaunchKernelGGL(k_sppm_refine, dim3(ctx->n_tiles), dim3(kBlock), 0, ctx->stream, kp);
         hipLaunchKernelGGL(k_sppm_end_frame, dim3(1), dim3(64), 0, ctx->stream, s->d_cx);
         if (timing) (void)hipEventRecord(seg[3], ctx->stream);
         { const hipError_t le = hipGetLastError(); if (le != hipSuccess) return frame_failed(trc_fail(ctx, TRC_ERR_HIP, std::string("SPPM frame: ") + hipGetErrorString(le))); }
