@@ -22,17 +22,20 @@ for seed in range(a, b):
                                n_tris=int(rs.randint(900, 2500)) if seed % 4 == 0 else int(rs.randint(5, 80)))
     W, H = int(rs.randint(32, 201)), int(rs.randint(24, 141))
     calls = [int(rs.randint(1, 5)) for _ in range(int(rs.randint(1, 4)))]
+    if seed % 13 == 12: W, H = int(rs.randint(300, 500)), int(rs.randint(200, 320)); calls = [int(rs.randint(1, 8)) for _ in range(int(rs.randint(1, 4)))]
     inside = seed % 5 == 4
     eye = tuple(rs.uniform(-30, 30, 3)) if inside else (rs.uniform(-100, 100), rs.uniform(-60, 60), -160.0)
     cam = host.make_camera(eye, (0, 0, 0), (0, 1, 0), 0.0, W / H, math.radians(50), 160.0)
-    gpu.upload_scene(sv); gpu.set_camera(cam); gpu.set_environment((0.0, 0.0, 0.0)); gpu.resize(W, H)
+    env = tuple(float(x) for x in rs.uniform(0, 1, 3)) if seed % 3 == 1 else (0.0, 0.0, 0.0)          # every third case under a constant environment
+    serial = int(seed % 7 == 3)                                                                       # knob: the camera pass without its frame of lead
+    gpu.upload_scene(sv); gpu.set_camera(cam); gpu.set_environment(env); gpu.resize(W, H); gpu.debug_set("sppm_serial_camera", serial)
     gpu.seed(8 + seed); gpu.clear_accum(); gpu.sppm_init(40 + seed)
     for c in calls:
         gpu.sppm_frames(c)
     dcam, dpho, dmark, dcount, dcx = gpu.sppm_download()
     dacc, drng = gpu.download_accum(), gpu.download_rng()
     rng = host.fill_rng(8 + seed, W, H); acc = np.zeros((H, W, 4), np.float32)
-    o = po.Sppm(W, H, 40 + seed); o.frames(sv, cam, rng, acc, sum(calls))
+    o = po.Sppm(W, H, 40 + seed); o.frames(sv, cam, rng, acc, sum(calls), env=env)
     ocam, opho, omark, ocount, ocx = o.download()
     why = []
     if not np.array_equal(drng, rng): why.append("canvas rng")
@@ -46,5 +49,5 @@ for seed in range(a, b):
     if dcx.frame_count != ocx.frame_count or dcx.totalPhotonSum != ocx.totalPhotonSum: why.append("complex")
     if why:
         bad += 1
-        print(f"MISMATCH seed {seed}: {W}x{H} calls {calls} inside {inside}: {why}", flush=True)
+        print(f"MISMATCH seed {seed}: {W}x{H} calls {calls} inside {inside} env {env} serial {serial}: {why}", flush=True)
 print(f"seeds {a}..{b - 1}: {b - a - bad} passed, {bad} FAILED")
