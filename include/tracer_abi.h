@@ -499,7 +499,14 @@ trc_status trc_device_pci_bus_id(trc_ctx* ctx, char* out, size_t out_len);
 trc_status trc_sppm_init(trc_ctx* ctx, uint64_t photon_seed);
 /* n_frames x `photon:` (AAPLRenderer.mm:1077-1086): frame 0 runs photonPrepare (camera records, their
  * bounding box, hash scale, initial radius), every frame photonWork (odd frames re-run the camera pass,
- * photon bounce, hashing, mark/count grid, photon sum, progressive refine into the accumulator) */
+ * photon bounce, hashing, mark/count grid, photon sum, progressive refine into the accumulator).
+ * In a group (trc_group_init / trc_group_set_collectives) EVERY rank calls it: rank r traces and refines the pixels of its tiles and
+ * bounces its 512*512 / nranks photons (the count must split evenly: TRC_ERR_INVALID_ARG otherwise), the bound of the visible points
+ * is all-reduced and the photon records all-gathered each frame; a rank that owns no tile of a small frame still takes part.
+ * Two corners are fixed as the reference's arithmetic has them: a frame in which no pixel records a visible point ends with the
+ * bound {FLT_MAX, -FLT_MAX}, i.e. radius -inf and hash scale -0 (Photon.metal:157-161,357-372); a photon whose BSDF sample is NaN
+ * counts the NaN as positive where copysign(1, wi.z) picks the side of the surface, and its stored direction / flux NaNs are the
+ * canonical 0x7FC00000 (the sign of a NaN is the platform's: DESIGN.md 2). */
 trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames);
 /* any pointer may be NULL.  mark: 4 floats per cell as texturePhotonMark (x, y of the winning photon,
  * cell x, y; -1 when empty), count: 1 float per cell as texturePhotonCount.
