@@ -10,7 +10,7 @@
 set -u
 cd "$(dirname "$0")/.."
 N=${1:-3000}
-ROUND=${2:-r04}
+ROUND=${2:-r05}
 OUT=profiles/$ROUND/sanitizers.txt
 LOGS=build/sanitize_logs
 mkdir -p "profiles/$ROUND" "$LOGS"
