@@ -15,6 +15,7 @@ from tracer_amd import abi, host
 from tracer_amd.device import Tracer
 
 gpu = Tracer(0)
+VOLUME = os.environ.get("TRC_FUZZ_VOLUME") == "1"
 BIG = os.environ.get("TRC_FUZZ_BIG") == "1"        # TRC_FUZZ_BIG=1: 1200..1920 x 700..1080 frames, knobs on every case
 bad = 0
 a, b = int(sys.argv[1]), int(sys.argv[2])
@@ -30,7 +31,7 @@ for seed in range(a, b):
     if BIG: calls = [int(rs.choice([1, 3, 8, 9, 16])) for _ in range(int(rs.randint(1, 4)))]
     depth = int(rs.randint(1, 9))
     # every fifth case through the Sobol' sampler (tracePath / traceMIS), every seventh as one tile rank of 2..5, every ninth as stacked views
-    sobol = seed % 5 == 4 and integ != 2
+    sobol = seed % 5 == 4 and integ != 2 and not VOLUME
     nranks = int(rs.randint(2, 6)) if seed % 7 == 6 else 1
     trank = int(rs.randint(nranks))
     views = int(rs.randint(2, 4)) if seed % 9 == 8 else 1
@@ -41,6 +42,16 @@ for seed in range(a, b):
     cam = host.make_camera(tuple(look_from), tuple(rs.uniform(-10, 10, 3)), (0, 1, 0), float(rs.uniform(0.0, 3.0)), W / vh, math.radians(55), 170.0)
     grid = rs.rand(6, 7, 8).astype(np.float32) * (rs.rand(6, 7, 8) > 0.4)
     info = host.density_info(np.ascontiguousarray(grid), sigma_a=0.02, sigma_s=0.05, g=0.3)
+    if VOLUME:          # TRC_FUZZ_VOLUME=1: traceVolume only, under hostile media -- grids of 1..12 cells a side (sparse, empty, spiked, negative, NaN, -0),
+        integ = 2       # coefficients from 0 to large, forward and backward phase functions
+        dims = tuple(int(x) for x in rs.randint(1, 13, 3))
+        grid = (rs.rand(*dims) * (rs.rand(*dims) > rs.uniform(0.1, 0.95))).astype(np.float32)
+        kind = seed % 6
+        if kind == 1: grid[:] = 0
+        if kind == 2: grid[tuple(rs.randint(0, d) for d in dims)] = 1e3
+        if kind == 3: grid.reshape(-1)[rs.randint(0, grid.size, max(1, grid.size // 10))] = rs.choice(np.array([-1.0, -0.0, np.nan, np.inf], np.float32), max(1, grid.size // 10))
+        sa, ss = [(0.02, 0.05), (0.0, 0.3), (0.5, 0.0), (2.0, 8.0), (1e-4, 1e-4), (0.0, 0.0)][int(rs.randint(6))]
+        info = host.density_info(np.ascontiguousarray(grid), sigma_a=sa, sigma_s=ss, g=float(rs.uniform(-0.9, 0.9)))
     env = (0.3, 0.4, 0.6) if seed % 3 else (0.0, 0.0, 0.0)
     # every fourth case (offset 1) under an equirectangular environment map of odd sizes, 1 x 1 included (the open scenes let most rays out)
     envmap = rs.uniform(0.0, 3.0, (int(rs.randint(1, 40)), int(rs.randint(1, 70)), 3)).astype(np.float32) if seed % 4 == 1 else None
