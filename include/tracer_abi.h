@@ -501,7 +501,8 @@ trc_status trc_sppm_init(trc_ctx* ctx, uint64_t photon_seed);
  * bounding box, hash scale, initial radius), every frame photonWork (odd frames re-run the camera pass,
  * photon bounce, hashing, mark/count grid, photon sum, progressive refine into the accumulator).
  * In a group (trc_group_init / trc_group_set_collectives) EVERY rank calls it: rank r traces and refines the pixels of its tiles and
- * bounces its 512*512 / nranks photons (the count must split evenly: TRC_ERR_INVALID_ARG otherwise), the bound of the visible points
+ * bounces its share of the 512*512 photons (whole wavefronts of 64, the last non-empty share shorter when the ranks do not divide them;
+ * at most 64 ranks), the bound of the visible points
  * is all-reduced and the photon records all-gathered each frame; a rank that owns no tile of a small frame still takes part.
  * Two corners are fixed as the reference's arithmetic has them: a frame in which no pixel records a visible point ends with the
  * bound {FLT_MAX, -FLT_MAX}, i.e. radius -inf and hash scale -0 (Photon.metal:157-161,357-372); a photon whose BSDF sample is NaN

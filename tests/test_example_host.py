@@ -131,7 +131,7 @@ def test_ranks_sample_sharded_without_pytorch(gpu, tmp_path, ranks):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ranks,W,H", [(4, 9, 31), (8, 4, 5), (4, 27, 21)])
+@pytest.mark.parametrize("ranks,W,H", [(4, 9, 31), (8, 4, 5), (4, 27, 21), (3, 200, 120), (7, 20, 12)])      # the last two: rank counts that do not divide the photons
 def test_more_ranks_than_tiles(gpu, ranks, W, H):
     """A frame so small that some ranks own NO tile (one, two, four tiles of 16 x 16 for 4 / 8 / 4 ranks): such a rank still bounces its
     photon range and takes part in the all-reduce of the bound keys and the all-gather of the photon records.  Up to round 5 it returned

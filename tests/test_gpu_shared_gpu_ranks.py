@@ -139,7 +139,7 @@ def test_config4_as_an_n_rank_tile_split_at_1080p(gpu, tmp_path, world):
     assert np.array_equal(bits(res[0]["frame8"]), bits(gpu.download_accum()))
 
 
-@pytest.mark.parametrize("world", [2, 8])
+@pytest.mark.parametrize("world", [2, 3, 8])         # 3: the 4 096 wavefronts of photons do not divide -- chunks of 1 366, 1 366, 1 364 wavefronts, padded all-gathers
 def test_config5_sppm_as_an_n_rank_split_at_1080p(gpu, tmp_path, world):
     res = run_ranks("config5", world, tmp_path / f"c5_{world}", timeout=1500)
     W, H, frames = 1920, 1080, 4

@@ -66,6 +66,7 @@ struct KSppm {
     unsigned long long* stats;   // ctx counters: rays += Scene::hit calls of the camera and photon passes
 };
 
+constexpr uint32_t kPhotonSlack = 64u * kBlock;      // records past the 512 x 512 photons in the buffers the ranks all-gather into: an uneven split pads its last chunks
 // order-preserving float <-> uint mapping for atomicMin/atomicMax
 __device__ __forceinline__ uint32_t f2key(float f) { uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
 __device__ __forceinline__ float key2f(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
@@ -654,13 +655,13 @@ trc_status trc_sppm_init(trc_ctx* ctx, uint64_t photon_seed) {
     }
     HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_main, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventCreateWithFlags(&s->ev_cam, hipEventDisableTiming));
-    HIP_TRY(ctx, hipMalloc((void**)&s->d_pho, nph * sizeof(trc_PhotonRecord)));
+    HIP_TRY(ctx, hipMalloc((void**)&s->d_pho, (nph + kPhotonSlack) * sizeof(trc_PhotonRecord)));      // + the padding of an uneven split over ranks
     HIP_TRY(ctx, hipMalloc((void**)&s->d_mark, nph * 4));
     HIP_TRY(ctx, hipMalloc((void**)&s->d_count, nph * 4));
     HIP_TRY(ctx, hipMalloc((void**)&s->d_cells, (nph + 1) * 3 * sizeof(float4)));
     HIP_TRY(ctx, hipMalloc((void**)&s->d_cx, sizeof(DComplex)));
     HIP_TRY(ctx, hipMemsetAsync(s->d_vp, 0, vp_bytes, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(s->d_pho, 0, nph * sizeof(trc_PhotonRecord), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(s->d_pho, 0, (nph + kPhotonSlack) * sizeof(trc_PhotonRecord), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(s->d_mark, 0, nph * 4, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(s->d_count, 0, nph * 4, ctx->stream));
     DComplex h;
@@ -692,8 +693,11 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
     const bool grouped = ctx->grouped();
     const uint32_t nranks = grouped ? (uint32_t)ctx->nranks : 1u, rank = grouped ? (uint32_t)ctx->rank : 0u;
     const uint32_t np = s->W * s->H, nph = kHashN * kHashN;
-    if (nph % (nranks * kBlock)) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "512*512 photons must split evenly over the ranks");
-    const uint32_t chunk = nph / nranks;
+    // rank r bounces photons [r * chunk, r * chunk + mine): chunks of whole wavefronts, the last non-empty one shorter when the ranks do not
+    // divide the 4 096 wavefronts of photons; the all-gathers move `chunk` records per rank into buffers padded by kPhotonSlack records
+    if (nranks > kPhotonSlack / kBlock) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "the grouped SPPM pass splits its photons over at most 64 ranks");
+    const uint32_t chunk = (nph / kBlock + nranks - 1) / nranks * kBlock;
+    const uint32_t first = std::min(nph, rank * chunk), mine = std::min(chunk, nph - first);
     { trc_status ts = trc_ensure_tiles(ctx, nranks, rank); if (ts != TRC_OK) return ts; }
     // A rank that owns no tile of a small frame still bounces ITS photon range and takes part in every collective (it returned early
     // here up to round 5 and left the others waiting in the all-reduce: tools/fuzz_ranks.sh); only its camera and refine launches are empty.
@@ -705,7 +709,7 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
     kp.ambient[0] = ctx->ambient[0]; kp.ambient[1] = ctx->ambient[1]; kp.ambient[2] = ctx->ambient[2];
     kp.env_rgb = ctx->d_envmap; kp.env_w = ctx->env_w; kp.env_h = ctx->env_h;
     kp.W = s->W; kp.H = s->H;
-    kp.photon_first = rank * chunk;
+    kp.photon_first = first;
     kp.tiles = ctx->d_tiles;
     kp.canvas_rng = ctx->d_rng; kp.accum = ctx->d_accum; kp.photon_rng = s->d_photon_rng;
     kp.vp = kp.vp_prev = s->vp[s->cur]; kp.pho_rec = s->d_pho; kp.mark = s->d_mark; kp.count = s->d_count; kp.cells = s->d_cells; kp.cx = s->d_cx;
@@ -772,14 +776,15 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
             ctx->launches++;
             (void)hipEventRecord(seg[0], ctx->stream);
         }
-        if (all_lds) hipLaunchKernelGGL((k_sppm_photon<true>), dim3(chunk / kBlock), dim3(kBlock), lds, ctx->stream, kp);
-        else hipLaunchKernelGGL((k_sppm_photon<false>), dim3(chunk / kBlock), dim3(kBlock), lds, ctx->stream, kp);
+        if (mine == 0) {}
+        else if (all_lds) hipLaunchKernelGGL((k_sppm_photon<true>), dim3(mine / kBlock), dim3(kBlock), lds, ctx->stream, kp);
+        else hipLaunchKernelGGL((k_sppm_photon<false>), dim3(mine / kBlock), dim3(kBlock), lds, ctx->stream, kp);
         if (timing) (void)hipEventRecord(seg[1], ctx->stream);
         PhotonView pv{s->d_pho, nullptr};
         if (grouped) {                                  // every rank needs every photon for hashing + refine: 40 bytes of each
-            if (!s->d_wire && hipMalloc((void**)&s->d_wire, (size_t)nph * sizeof(PhotonWire)) != hipSuccess)
+            if (!s->d_wire && hipMalloc((void**)&s->d_wire, (size_t)(nph + kPhotonSlack) * sizeof(PhotonWire)) != hipSuccess)
                 return frame_failed(trc_fail(ctx, TRC_ERR_OOM, "hipMalloc photon wire records"));
-            hipLaunchKernelGGL(k_sppm_pack_wire, dim3((chunk + 255) / 256), dim3(256), 0, ctx->stream, s->d_pho, s->d_wire, kp.photon_first, chunk);
+            if (mine) hipLaunchKernelGGL(k_sppm_pack_wire, dim3((mine + 255) / 256), dim3(256), 0, ctx->stream, s->d_pho, s->d_wire, kp.photon_first, mine);
             trc_status cs = trc_coll_allgather(ctx, s->d_wire, (size_t)chunk * sizeof(PhotonWire), ctx->stream, "allgather of the photon wire records");
             if (cs != TRC_OK) return frame_failed(cs);
             pv = PhotonView{nullptr, s->d_wire};
@@ -844,7 +849,7 @@ trc_status trc_sppm_download(trc_ctx* ctx, trc_CameraRecord* cam, trc_PhotonReco
     }
     if (pho) {
         if (s->pho_partial && ctx->grouped()) {           // the per-frame gather moves 40 bytes per photon: the whole records, now (collective)
-            const size_t chunk = nph / (size_t)ctx->nranks;
+            const size_t chunk = (nph / kBlock + (size_t)ctx->nranks - 1) / (size_t)ctx->nranks * kBlock;      // trc_sppm_frames' split
             trc_status cs = trc_coll_allgather(ctx, s->d_pho, chunk * sizeof(trc_PhotonRecord), ctx->stream, "allgather of the photon records (download)");
             if (cs != TRC_OK) return cs;
             s->pho_partial = false;
