@@ -3,9 +3,9 @@
 the library), camera moves, environment changes, reseeding, clearing, RNG / accumulator uploads and downloads, tone mapping, stats, scene
 swaps, resizes -- mirrored step by step on the oracle.  Every download along the way and the final accumulator, RNG texture and ray count must be
 the oracle's, bit for bit: a kept launch must be flushed by exactly the calls that would observe or invalidate it, with the state it was
-issued under.          python3 tools/fuzz_api.py <a> <b>"""
+issued under.          python3 tests/campaigns/fuzz_api.py <a> <b>"""
 import math, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 os.environ.setdefault("TRC_FUZZ_SEEDS", "1:2")

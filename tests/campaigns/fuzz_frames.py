@@ -3,9 +3,9 @@
 and launch sequences that bring the adaptive machinery in -- cost-ordered launches, the split plan, persistent workgroups with
 overflow stacks, coalesced 1-sample calls, progressive accumulation over several calls, the Sobol' sampler, one tile rank of several,
 stacked views, equirectangular environment maps, random scheduling knobs and launch flags -- GPU against the oracle, bit for bit.
-    python3 tools/fuzz_frames.py <first seed> <last seed>"""
+    python3 tests/campaigns/fuzz_frames.py <first seed> <last seed>"""
 import math, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 os.environ.setdefault("TRC_FUZZ_SEEDS", "1:2")

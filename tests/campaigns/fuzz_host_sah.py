@@ -1,5 +1,9 @@
-import sys, ctypes as C, numpy as np
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+#!/usr/bin/env python3
+"""CPU campaign: libtrc_host.so's SAH builder against oracle/oracle_sah.cpp, record for record, on random leaf sets of 2..9 000 boxes -- uniform, on a
+grid (equal centroids), flat, clustered, denormal-sized, zero-extent.        python3 tests/campaigns/fuzz_host_sah.py <a> <b>"""
+import os, sys, ctypes as C, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import pyoracle as po
 from tracer_amd import abi, host
 def rec(nodes,n):

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Output stage campaign: random accumulators -- ordinary radiance, zeros, denormals, huge values, negatives, NaN, +-inf, in frames of
 1 x 1 .. 400 x 300 -- through trc_upload_accum + trc_tonemap against oracle/pyoracle.tonemap (fragmentShader's auto-exposure from exact
-fixed-point sums + ACES, Render.metal:29-75): the exposure's bits and every output byte.      python3 tools/fuzz_output.py <a> <b>"""
+fixed-point sums + ACES, Render.metal:29-75): the exposure's bits and every output byte.      python3 tests/campaigns/fuzz_output.py <a> <b>"""
 import os, struct, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from oracle import pyoracle as po

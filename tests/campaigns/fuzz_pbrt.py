@@ -3,9 +3,9 @@
 directives in random order and nesting (Translate / Scale / Rotate / LookAt / Transform / ConcatTransform / Identity, TransformBegin/End,
 AttributeBegin/End, CoordinateSystem / CoordSysTransform), the seven shape classes with random parameters, materials with colours, area
 lights, camera and film -- through libtrc_host.so's loader and through the reference's own minipbrt: kind, shape-to-world matrix, parameters,
-material, colour, emitter, camera matrix / fov / film, shape for shape.        python3 tools/fuzz_pbrt.py <a> <b>"""
+material, colour, emitter, camera matrix / fov / film, shape for shape.        python3 tests/campaigns/fuzz_pbrt.py <a> <b>"""
 import os, sys, tempfile
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from tracer_amd import abi, host

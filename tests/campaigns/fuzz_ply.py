@@ -3,9 +3,9 @@
 order with random extra scalar and list properties of every PLY type; positions as float or double; normals and uv present or not, uv
 spelled u v / s t / texture_u texture_v; faces of 3..4 vertices under count types uchar / ushort / uint and index types of every integer
 width, named vertex_indices or vertex_index, with other list properties before and after -- through trc_host_mesh_load_ply and the
-reference's minipbrt (as `Shape "plymesh"`): positions, normals, uv and the triangle list, bit for bit.   python3 tools/fuzz_ply.py <a> <b>"""
+reference's minipbrt (as `Shape "plymesh"`): positions, normals, uv and the triangle list, bit for bit.   python3 tests/campaigns/fuzz_ply.py <a> <b>"""
 import os, struct, sys, tempfile
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from tracer_amd import host
@@ -47,7 +47,7 @@ with tempfile.TemporaryDirectory() as d:
         fname = "vertex_indices" if rs.rand() < 0.7 else "vertex_index"
         pre, post = rs.rand() < 0.4, rs.rand() < 0.4
         tn = (lambda t: ALIASES[t]) if alias else (lambda t: t)
-        head = ["ply", f"format {fmt} 1.0", "comment tools/fuzz_ply.py", f"element vertex {nv}"] + [f"property {tn(t)} {n}" for n, t, _ in full]
+        head = ["ply", f"format {fmt} 1.0", "comment tests/campaigns/fuzz_ply.py", f"element vertex {nv}"] + [f"property {tn(t)} {n}" for n, t, _ in full]
         if vlist: head.append(f"property list uchar {tn('short')} vl")
         head.append(f"element face {nf}")
         if pre: head.append(f"property {tn('uchar')} flag")

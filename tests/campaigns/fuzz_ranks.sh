@@ -1,7 +1,7 @@
 #!/bin/bash
 # N-rank campaign on ONE GPU through examples/trc_ranks (no Python in the ranks): random rank counts, ragged and tiny frames (fewer pixels
 # than ranks: empty slices), both splits, with and without the grouped SPPM pass; the program checks its composed frame against the 1-rank
-# frame (tiles) or the rank-ordered mean of the shards (samples) itself and exits non-zero otherwise.   usage: bash tools/fuzz_ranks.sh <a> <b>
+# frame (tiles) or the rank-ordered mean of the shards (samples) itself and exits non-zero otherwise.   usage: bash tests/campaigns/fuzz_ranks.sh <a> <b>
 A=${1:-0}; B=${2:-40}; bad=0
 [ -x examples/trc_ranks ] || make example > /dev/null
 for ((s=A; s<B; s++)); do

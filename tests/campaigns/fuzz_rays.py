@@ -2,9 +2,9 @@
 """Scene::hit campaign with rays the random batches of tests/ never contain: axis-parallel directions (one or two components exactly +-0),
 origins exactly ON surfaces (the hit points of a first batch) and on box faces, directions at triangle vertices and along edges, unnormalised /
 tiny / huge directions, NaN and +-inf components, tmax of 0 / tiny / inf / NaN / negative -- closest and any-hit with counters, and the
-production walks, GPU against the oracle, every field bit for bit (NaN fields: both NaN).      python3 tools/fuzz_rays.py <a> <b>"""
+production walks, GPU against the oracle, every field bit for bit (NaN fields: both NaN).      python3 tests/campaigns/fuzz_rays.py <a> <b>"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 os.environ.setdefault("TRC_FUZZ_SEEDS", "1:2")

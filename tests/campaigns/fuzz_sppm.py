@@ -2,9 +2,9 @@
 """SPPM campaign beyond tests/test_gpu_fuzz.py::test_generated_scene_sppm (64x48, 3 frames in one call): generated scenes at canvas sizes
 32..200 x 24..140, 1..11 frames split over 1..3 trc_sppm_frames calls (the camera pass of an odd frame runs a frame ahead on its own
 stream WITHIN a call: the call boundaries move where that happens), GPU against the oracle -- accumulator, canvas RNG, photon and
-camera records, hash grids, the Complex block -- bit for bit.      python3 tools/fuzz_sppm.py <first seed> <last seed>"""
+camera records, hash grids, the Complex block -- bit for bit.      python3 tests/campaigns/fuzz_sppm.py <first seed> <last seed>"""
 import math, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 os.environ.setdefault("TRC_FUZZ_SEEDS", "1:2")

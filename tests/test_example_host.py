@@ -135,7 +135,7 @@ def test_ranks_sample_sharded_without_pytorch(gpu, tmp_path, ranks):
 def test_more_ranks_than_tiles(gpu, ranks, W, H):
     """A frame so small that some ranks own NO tile (one, two, four tiles of 16 x 16 for 4 / 8 / 4 ranks): such a rank still bounces its
     photon range and takes part in the all-reduce of the bound keys and the all-gather of the photon records.  Up to round 5 it returned
-    from trc_sppm_frames at once and the others waited for it (found by tools/fuzz_ranks.sh).  The program compares the composed frame
+    from trc_sppm_frames at once and the others waited for it (found by tests/campaigns/fuzz_ranks.sh).  The program compares the composed frame
     and the SPPM frame with the 1-rank results itself."""
     log = subprocess.run([RANKS_EXE, "--ranks", str(ranks), "--host-collectives", "--size", str(W), str(H), "--spp", "6", "--sppm", "3",
                           "--out", "/dev/null"], text=True, capture_output=True, timeout=600)

@@ -61,7 +61,7 @@ def test_sppm_bit_exact(gpu, cornell_spheres, n_frames):
 def test_a_frame_without_any_visible_point(gpu, cornell_spheres):
     """The camera looks AWAY from the box: no pixel records a visible point, every pixel contributes {FLT_MAX, -FLT_MAX} to the bound
     (Photon.metal:157-161), and kernelPhotonParams turns that into box size -inf, radius -inf, hash scale -0 (:357-372).  Found by
-    tools/fuzz_sppm.py in round 5 (cameras inside objects): the device started its min / max keys at the ends of the key range and
+    tests/campaigns/fuzz_sppm.py in round 5 (cameras inside objects): the device started its min / max keys at the ends of the key range and
     decoded NaN.  Everything, the Complex block included, equals the oracle."""
     import struct
     W, H = 64, 40

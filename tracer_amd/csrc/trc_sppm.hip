@@ -700,7 +700,7 @@ trc_status trc_sppm_frames(trc_ctx* ctx, uint32_t n_frames) {
     const uint32_t first = std::min(nph, rank * chunk), mine = std::min(chunk, nph - first);
     { trc_status ts = trc_ensure_tiles(ctx, nranks, rank); if (ts != TRC_OK) return ts; }
     // A rank that owns no tile of a small frame still bounces ITS photon range and takes part in every collective (it returned early
-    // here up to round 5 and left the others waiting in the all-reduce: tools/fuzz_ranks.sh); only its camera and refine launches are empty.
+    // here up to round 5 and left the others waiting in the all-reduce: tests/campaigns/fuzz_ranks.sh); only its camera and refine launches are empty.
     if (ctx->n_tiles == 0 && !grouped) return TRC_OK;
     const bool has_tiles = ctx->n_tiles != 0;
 
