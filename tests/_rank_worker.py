@@ -3,7 +3,7 @@ supplied through trc_group_set_collectives (host-staged, gloo between the proces
 ranks on one device.  Started by tests/test_gpu_shared_gpu_ranks.py; not a test module itself.
 
 env: RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT, TRC_ROOT, TRC_OUT (directory),
-     TRC_CASE = small | ragged | config4 | config5 | samples2 | samples3 | samples4 (sample sharding at 1080p on BASELINE configs 2 / 3 / 4)
+     TRC_CASE = small | sppm_small | ragged | config4 | config5 | samples2 | samples3 | samples4 (sample sharding at 1080p on BASELINE configs 2 / 3 / 4)
 """
 import hashlib
 import os
@@ -89,6 +89,21 @@ def main():
         if rank == 0:
             out["sppm"] = t.download_accum()
         out["calls"] = np.array([coll.calls[k] for k in ("reduce", "allreduce", "allgather", "alltoall", "gather")])
+    elif case == "sppm_small":
+        # a canvas of 3 x 2 tiles under more ranks than tiles, and rank counts that do not divide the photons: records, grids and frame
+        W, H, frames = 40, 24, 4
+        scene = host.HostScene(abi.SCENE_CORNELL_SPHERES)
+        t.upload_scene(scene.view); t.set_camera(host.prepare_camera(W, H)); t.set_environment((0.0, 0.0, 0.0)); t.resize(W, H)
+        t.set_collectives(coll, world, rank)
+        t.clear_accum(); t.seed(8); t.sppm_init(9); t.sppm_frames(frames)
+        cam, pho, mark, count, cx = t.sppm_download()
+        t.group_reduce_accum(0)
+        own = owner_mask(W, H, world, rank).ravel()
+        out["cam_own"] = cam[own].view(np.uint8)
+        out["pho"] = pho.view(np.uint8); out["mark"] = mark; out["count"] = count
+        out["total"] = np.float32(cx.totalPhotonSum); out["radius"] = np.float32(cx.photonInitialRadius)
+        if rank == 0:
+            out["sppm"] = t.download_accum()
     elif case == "ragged":
         # a frame whose pixel count the ranks do not divide (97 x 61 = 5917: the last pixel slice is short), and a table that
         # cannot compose sample shards

@@ -158,6 +158,30 @@ def test_config5_sppm_as_an_n_rank_split_at_1080p(gpu, tmp_path, world):
         assert list(res[r]["calls"]) == [1, 2, frames + 1, 0, 0]
 
 
+@pytest.mark.parametrize("world", [5, 8])
+def test_sppm_with_more_ranks_than_tiles_record_for_record(gpu, tmp_path, world):
+    """A 40 x 24 canvas is 3 x 2 tiles: with 8 ranks four of them own none, with 5 one does and the 4 096 wavefronts of photons do not divide either
+    (chunks of 820, ..., 816).  Every rank's camera records of its own pixels, all photon records (gathered at the download through the
+    padded buffers), both hash grids, the photon sum, the radius and the composed frame equal the one-rank pass (round 5: a rank without a
+    tile used to leave trc_sppm_frames before its collectives, and uneven photon splits were refused)."""
+    res = run_ranks("sppm_small", world, tmp_path / f"ss{world}")
+    W, H, frames = 40, 24, 4
+    scene = host.HostScene(abi.SCENE_CORNELL_SPHERES)
+    gpu.upload_scene(scene.view); gpu.set_camera(host.prepare_camera(W, H)); gpu.set_environment((0.0, 0.0, 0.0)); gpu.resize(W, H)
+    gpu.clear_accum(); gpu.seed(8); gpu.sppm_init(9); gpu.sppm_frames(frames)
+    cam, pho, mark, count, cx = gpu.sppm_download()
+    assert np.array_equal(bits(res[0]["sppm"]), bits(gpu.download_accum()))
+    empty = 0
+    for r in range(world):
+        own = owner_mask(W, H, world, r).ravel()
+        empty += not own.any()
+        assert np.array_equal(res[r]["cam_own"], cam[own].view(np.uint8)), r
+        assert np.array_equal(res[r]["pho"], pho.view(np.uint8)) and np.array_equal(res[r]["count"], count), r
+        assert np.array_equal(bits(res[r]["mark"]), bits(mark)), r
+        assert res[r]["total"] == np.float32(cx.totalPhotonSum) and res[r]["radius"] == np.float32(cx.photonInitialRadius), r
+    assert empty == (4 if world == 8 else 1)          # (tx + ty) % world over 3 x 2 tiles
+
+
 @pytest.mark.parametrize("world", [2, 8])
 def test_sample_shards_of_a_frame_the_ranks_do_not_divide(gpu, tmp_path, world):
     """97 x 61 = 5917 pixels over 2 / 8 ranks: the last pixel slice is short (and with 8 ranks three pixels short of the others);
