@@ -25,4 +25,16 @@ for integ, calls in ((abi.INTEGRATOR_PATH, [1, 9]), (abi.INTEGRATOR_MIS, [3])):
     same = np.array_equal(got.view(np.uint32), ref.view(np.uint32)) and np.array_equal(got_rng, rng) and st.rays == rst.rays
     ok &= same
     print(f"{W}x{H} integrator {integ} calls {calls}: {'equal' if same else 'MISMATCH'} ({st.rays} rays, kernels {st.kernel_ms:.1f} ms)", flush=True)
+# ... and the SPPM pass on the same canvas: 3 frames (visible points, bound, hash, refine) -- every record, both grids, the frame
+gpu.seed(5); gpu.clear_accum(); gpu.sppm_init(6); gpu.sppm_frames(3)
+dcam, dpho, dmark, dcount, dcx = gpu.sppm_download()
+dacc, drng = gpu.download_accum(), gpu.download_rng()
+rng = host.fill_rng(5, W, H); acc = np.zeros((H, W, 4), np.float32)
+o = po.Sppm(W, H, 6); o.frames(sc.view, cam, rng, acc, 3)
+ocam, opho, omark, ocount, ocx = o.download()
+same = (np.array_equal(drng, rng) and np.array_equal(dacc.view(np.uint32), acc.view(np.uint32)) and np.array_equal(dcount, ocount) and np.array_equal(dmark, omark)
+        and all(bytes(memoryview(np.ascontiguousarray(dpho[f]))) == bytes(memoryview(np.ascontiguousarray(opho[f]))) for f in ("flux", "normal", "position", "direction", "step", "active"))
+        and all(bytes(memoryview(np.ascontiguousarray(dcam[f]))) == bytes(memoryview(np.ascontiguousarray(ocam[f]))) for f in ("ratio", "position", "direction", "valid", "alternative", "flux", "radius", "photonCount")))
+ok &= same
+print(f"{W}x{H} SPPM, 3 frames: {'equal' if same else 'MISMATCH'}", flush=True)
 sys.exit(0 if ok else 1)
