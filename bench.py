@@ -104,6 +104,152 @@ def cpu_rt_weekend():
                       f"box 400x400x16spp: {r['rays']} rays in {r['seconds']:.2f} s, {r['mpaths_per_s']} Mpaths/s"}
 
 
+def load_goldens():
+    """tests/golden/bench_goldens.json: the ORACLE's ray counts and frame CRC32s at the sizes BASELINE.json names
+    (tests/golden/make_bench_goldens.py) -- what this script holds its own frames to, outside the timed regions."""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "bench_goldens.json")) as f:
+            return json.load(f)
+    except OSError:
+        return {}
+
+
+def frame_crc(a):
+    import zlib
+    import numpy as np
+    return zlib.crc32(np.ascontiguousarray(a).view(np.uint8).tobytes()) & 0xFFFFFFFF
+
+
+def check_against(gold, key, crc=None, rays=None, extra=None):
+    """{"golden": key, "crc_ok": ..., "rays_ok": ...}: None where the committed file has no such entry"""
+    g = gold.get(key)
+    out = {"golden": key if g else None}
+    if g is None:
+        out["missing"] = f"tests/golden/bench_goldens.json has no '{key}' (tests/golden/make_bench_goldens.py)"
+        return out
+    if crc is not None:
+        out["crc_ok"] = bool(g.get("crc_accum") == crc)
+    if rays is not None and "rays" in g:
+        out["rays_ok"] = bool(int(g["rays"]) == int(rays))
+    for k, v in (extra or {}).items():
+        out[k + "_ok"] = bool(g.get(k) == v)
+    return out
+
+
+def config_roofline(name, kernel_prefix, kernel_ms=None):
+    """the VALU-issue roofline of another configuration's kernel from its newest committed PMC summary
+    (profiles/rNN/pmc_<name>.json), under the same rule as the headline's: only when collected on the running library"""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_{name}.json")),
+                   key=lambda f: int(re.search(r"r(\d+)$", os.path.basename(os.path.dirname(f))).group(1)))
+    mine = lib_source_hash()
+    none = {"bound": "valu-issue", "achieved": None, "peak": None, "unit": "VALU wave-instructions/launch", "frac": None, "traffic": None,
+            "lib_source_hash": mine}
+    if not files:
+        return dict(none, stale=f"no profiles/r*/pmc_{name}.json"), None
+    pm = json.load(open(files[-1]))
+    rel = os.path.relpath(files[-1], ROOT)
+    if pm.get("lib_source_hash") != mine or not str(pm.get("kernel", "")).startswith(kernel_prefix):
+        return dict(none, stale=f"{rel} was collected on library {pm.get('lib_source_hash')} / kernel {pm.get('kernel')!r}; running {mine} / {kernel_prefix!r}"), None
+    r = valu_roofline(pm, None, rel, mine)
+    r["pmc_launch"] = f"{pm.get('workload_line', {}).get('spp')} spp per launch"
+    return r, pm
+
+
+OTHER_CONFIGS = ("config3", "config4", "config5_sppm", "volume", "hbm_point")
+
+
+def other_config_leg(key, device, steps=2):
+    """One of BASELINE's other configurations (or the HBM operating point) on a context of its own: `steps` timed steps after the
+    launch order has settled, the frame held to the oracle's committed ray count / CRC (tests/golden/bench_goldens.json)."""
+    import numpy as np
+    from tracer_amd import abi, host
+    from tracer_amd.device import Tracer
+    gold = load_goldens()
+    cam = host.prepare_camera(W, H)
+    t = Tracer(device)
+    try:
+        if key == "config5_sppm":
+            scene = host.HostScene(abi.SCENE_CORNELL_SPHERES)
+            t.upload_scene(scene.view); t.set_camera(cam); t.set_environment((0.0, 0.0, 0.0)); t.resize(W, H)
+            frames, wall, rays = 64, [], 0
+            for i in range(steps + 1):                           # the first pass is the warm-up
+                t.clear_accum(); t.seed(1); t.sppm_init(2); t.synchronize(); t.reset_stats()
+                t0 = time.perf_counter()
+                t.sppm_frames(frames); t.synchronize()
+                if i:
+                    wall.append(time.perf_counter() - t0)
+                rays = t.stats().rays
+            cx = t.sppm_download()[4]
+            ms = sum(wall) / len(wall) * 1e3
+            roofs = {k: config_roofline("config5_" + k, k)[0] for k in ("k_sppm_refine", "k_sppm_camera", "k_sppm_photon", "k_sppm_table")}
+            return {"config": "BASELINE config 5: SPPM photon pass, Cornell + 12 spheres, 512^2 photons per frame, 64 frames at 1920x1080",
+                    "value": round(rays / ms / 1e3, 1), "unit": "Mrays/s", "ms_per_step": round(ms, 3), "ms_per_frame": round(ms / frames, 4),
+                    "rays_per_step": int(rays), "steps": steps, "frames_per_step": frames,
+                    "oracle_check": check_against(gold, key, crc=frame_crc(t.download_accum()),
+                                                  extra={"totalPhotonSum": int(cx.totalPhotonSum), "frame_count": int(cx.frame_count)}),
+                    "roofline": roofs["k_sppm_refine"], "roofline_per_pass": roofs}
+        density = None
+        if key == "config3":
+            scene, integ, spp = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.golden("coatball")), abi.INTEGRATOR_MIS, 256
+            what, pmc, kern = "BASELINE config 3: Cornell + coatball.obj (46 816 triangles), traceMIS, 1920x1080x256spp", "config3", "k_render_pwg<1, false>"
+        elif key == "config4":
+            scene, integ, spp = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.golden("teapot").replicate(8, 80.0)), abi.INTEGRATOR_PATH, 256
+            what, pmc, kern = "BASELINE config 4: Cornell + teapot.obj x 64 (1 005 056 triangles), tracePath, 1920x1080x256spp", "config4", "k_render_pwg<0, false>"
+        elif key == "volume":
+            scene, integ, spp = host.HostScene(abi.SCENE_CORNELL_VOLUME, host.Mesh.golden("coatball")), abi.INTEGRATOR_VOLUME, 64
+            density = host.make_cloud()
+            what, pmc, kern = "traceVolume (SURVEY 8f-3): Cornell + cloud container (100x100x40 grid) + coatball.obj as glass, 1920x1080x64spp", "volume", "k_render_pwg<2, false>"
+        else:                                                     # the operating point where HBM is the memory (DESIGN 4.4)
+            scene = host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.golden("teapot").replicate(16, 80.0), analytic_leaves_only=True)
+            integ, spp = abi.INTEGRATOR_PATH, 32
+            what, pmc, kern = "Cornell + teapot.obj x 256 (4 020 224 triangles, 708 MB: beyond the 256 MiB Infinity Cache), tracePath, 1920x1080x32spp", "hbm_point", "k_render_pwg<0, false>"
+        if key == "hbm_point":
+            t.upload_scene_device(scene.view, abi.TREE_SAH | abi.TREE_TRIANGLE_LEAVES)
+        else:
+            t.upload_scene(scene.view)
+        if density is not None:
+            t.upload_density(host.density_info(density), density)
+        t.set_camera(cam); t.set_environment((0.0, 0.0, 0.0)); t.resize(W, H)
+
+        def step(n):
+            t.seed(SEED); t.clear_accum(); t.render(spp=n, max_depth=DEPTH, integrator=integ)
+        # the launch order and split plan settle on per-SAMPLE costs (DESIGN 4.1), so short launches settle them: 8 x 32 spp, then
+        # one launch of the named length, then the timed ones
+        for _ in range(SETTLE_LAUNCHES):
+            step(min(32, spp))
+        step(spp)
+        t.synchronize(); t.reset_stats()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(spp)
+        t.synchronize()
+        wall = (time.perf_counter() - t0) / steps * 1e3
+        st = t.stats()
+        rays, kernel_ms = st.rays // steps, st.kernel_ms / max(1, st.launches)
+        out = {"config": what, "value": round(rays / wall / 1e3, 1), "unit": "Mrays/s", "ms_per_step": round(wall, 3), "kernel_ms": round(kernel_ms, 3),
+               "rays_per_step": int(rays), "steps": steps, "spp": spp, "kernel": kern,
+               "mpaths_per_s": round(W * H * spp / wall / 1e3, 1), "triangles": int(scene.view.n_index // 3)}
+        roof, pm = config_roofline(pmc, kern)
+        out["roofline"] = roof
+        if key == "hbm_point":
+            # north_star's ">= 40 % of the HBM roofline" can only be asked here (the other scenes live in LDS / L2 / Infinity Cache)
+            frac = None if pm is None else pm.get("l2_miss_frac_of_hbm_peak")
+            share = None if pm is None or not pm.get("l2_miss_bytes_per_launch") else round(pm["l2_miss_write_bytes_per_launch"] / pm["l2_miss_bytes_per_launch"], 3)
+            out["hbm"] = {"mrays": out["value"], "l2_miss_frac_of_hbm_peak": frac, "spill_share": share, "target_frac": 0.40,
+                          "target_met": None if frac is None else bool(frac >= 0.40),
+                          "what": "L2-miss traffic of the 4 M-triangle scene (all of it HBM: 708 MB against a 256 MiB Infinity Cache) over 8 TB/s, from the "
+                                  "committed PMC summary; spill_share = its write half, which is register spills (the frame's own writes are 66 MB). "
+                                  "north_star's >= 40 % is NOT met and is not what bounds this path: dependent 64-byte gathers at full occupancy are "
+                                  "latency-bound (DESIGN 4.4)"}
+        else:
+            out["oracle_check"] = check_against(gold, key, crc=frame_crc(t.download_accum()), rays=rays)
+        return out
+    finally:
+        t.close()
+
+
 def fast_math_leg(scene, cam, steps):
     """The same K steps on libtracer_amd_fast.so (the sources under fast-math rules, like the reference's MTL_FAST_MATH
     shaders).  Reported beside the headline, never as it: only the exact build is comparable with the oracle."""
@@ -339,6 +485,8 @@ def main(argv=None):
                     help="seconds a rank waits inside the RCCL bring-up before it exits non-zero (a peer that died would leave it there for ever)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-scaling", action="store_true", help="N > 1: measure only the primary workload")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="N = 1: skip the other_configs legs (configs 3 / 4 / 5, traceVolume, the HBM point; profiling runs)")
     ap.add_argument("--no-fast-math", action="store_true",
                     help="skip the fast_math_variant leg (profiling runs: both builds name their kernels alike)")
     ap.add_argument("--no-cold", action="store_true",
@@ -482,6 +630,8 @@ def main(argv=None):
         trc.set_collectives(coll, world, rank)
     composing = use_rccl or plumbing
 
+    goldens = load_goldens()
+
     def barrier():
         trc.synchronize()                      # hipStreamSynchronize on the render and the compose stream of this rank's device
         if group is not None:
@@ -499,6 +649,8 @@ def main(argv=None):
             raise SystemExit(f"--sample-groups {S}: must divide both the {world} ranks and the {SPP} samples")
         T = world // S if sharded else world
         group_of, tile_rank = (rank // T, rank % T) if sharded else (0, rank)
+        if sharded and os.environ.get("TRC_BENCH_REVERSE_GROUPS") == "1":     # test hook: the same shards folded in another rank order --
+            group_of = S - 1 - group_of                                       # a composed frame the committed CRC must reject (S >= 3)
         spp_rank = SPP // S
 
         def step(seed=SEED, collect_stats=False):
@@ -570,6 +722,18 @@ def main(argv=None):
         schedule_ms = st.schedule_ms / max(1, st.launches)      # ... and around the launch-list kernels (order, sort, plan), averaged
         shape = trc.launch_shape()                               # the two bounds no schedule of this rank's share can beat
 
+        # SELF-VALIDATION (outside the timed region): the frame the last timed step composed, against the oracle's CRC32 of the
+        # same frame (tests/golden/bench_goldens.json).  Tiles compose the one-GPU frame bit for bit; sample shards and stacked
+        # views have their own committed CRCs.  False = the numbers above belong to a wrong frame: the run exits non-zero.
+        crc_check = None
+        if rank == 0:
+            key = f"config2_samples_S{S}" if sharded else (f"config2_weak_N{world}" if stacked else "config2")
+            frame = trc.download_composed() if composing else trc.download_accum()
+            crc_check = check_against(goldens, key, crc=frame_crc(frame),
+                                      rays=None if world > 1 else rays_per_launch)
+            if os.environ.get("TRC_BENCH_EXPECT_GOLDEN"):           # test hook: hold the frame to another entry (a wrong one must fail)
+                crc_check = check_against(goldens, os.environ["TRC_BENCH_EXPECT_GOLDEN"], crc=frame_crc(frame))
+
         # the same K steps with a DIFFERENT seed each (a progressive renderer never replays a frame: the adaptive
         # launch order then works from the previous frame's costs, not from this frame's own)
         barrier()
@@ -625,17 +789,17 @@ def main(argv=None):
                           "what": "the same K steps with a different RNG seed per step (frame k's block costs order frame k+1)"},
             "per_rank": per_rank, "kernel_ms": kernel_ms, "bytes_per_launch": bytes_per_launch, "cold": cold,
             "rays_per_launch": rays_per_launch, "sample_groups": S, "tile_ranks": T,
+            "oracle_check": crc_check, "composed_crc_ok": None if crc_check is None else crc_check.get("crc_ok"),
         }
 
     primary = measure(args.scaling, args.steps, args.warmup)
-    others = {}
+    info = trc.device_info()                   # before any optional leg: the watchdog thread must never touch the context
 
-    def emit(primary, others):
-        """rank 0's ONE JSON line (also called by the watchdog of an optional leg: the headline must not die with it)"""
+    def build_line(primary):
+        """rank 0's line without the optional legs (they are added as they finish)"""
         kernel_ms = primary["kernel_ms"]
         achieved = primary["bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
         roof = roofline_from_pmc(kernel_ms) if world == 1 else None
-        info = trc.device_info()
         FH = primary["frame"][1]
         compose = "none"
         sharded = primary["mode"] == "samples"
@@ -664,6 +828,8 @@ def main(argv=None):
                        "paths_per_step": primary["paths_per_step"], "mpaths_per_s": primary["mpaths_per_s"],
                        "tiles": f"16x16 px, owner (tx+ty)%{primary['tile_ranks'] if world > 1 else 1}", "device": info["name"], "compose": compose,
                        "settle_launches": SETTLE_LAUNCHES},
+            # the composed frame of the timed steps against the oracle's committed CRC32 (false: the run exits non-zero)
+            "composed_crc_ok": primary["composed_crc_ok"], "oracle_check": primary["oracle_check"],
             "vary_seed": primary["vary_seed"],
             "cold": primary["cold"], "first_launch_ms": primary["cold"]["first_launch_ms"],
             # parity-imposed bounds of the timed launches on rank 0 (every rank's under per_rank at N > 1)
@@ -689,55 +855,106 @@ def main(argv=None):
             line["transport"] = "rccl" if use_rccl else "table"
         if world > 1:
             line["per_rank"] = primary["per_rank"]
-            if others:
-                keys = ("mode", "metric", "value", "ms_per_step", "rays_per_step", "frame", "vary_seed", "cold", "per_rank",
-                        "sample_groups", "tile_ranks", "skipped")
-                line["other_scaling"] = {m: {k: o[k] for k in keys if k in o} for m, o in others.items()}
         if world == 1 and not args.no_fast_math:
             line["fast_math_variant"] = fast_math_leg(scene, cam, args.steps)
         if not args.no_cpu_baseline and world == 1:      # CPU baselines: rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(scene, cam)
             line["cpu_rt_weekend"] = cpu_rt_weekend()
-        print(json.dumps(line), flush=True)
+        return line
+
+    # The headline is complete HERE; everything below is an optional leg that must never take it down.  Each leg runs under a
+    # watchdog and inside try / except; its result (or why it was skipped) is added to the line, which goes out exactly once.
+    import threading
+    line = build_line(primary) if rank == 0 else None
+    out_lock = threading.Lock()
+    state = {"printed": False, "group_ok": True}
+
+    def print_line():
+        with out_lock:
+            if state["printed"] or rank != 0:
+                return
+            state["printed"] = True
+            print(json.dumps(line), flush=True)
+
+    def run_leg(container, name, fn, timeout_s):
+        """fn() under a watchdog.  Rank 0 alone decides a bail: it prints the line without the leg and ends the process; the peers
+        wait a grace period (rank 0's exit closes their sockets first) and leave quietly.  An exception inside the leg is a skip;
+        the ranks then agree on it, and a group that can no longer agree runs no further leg."""
+        if not state["group_ok"]:
+            if rank == 0:
+                line.setdefault(container, {})[name] = {"skipped": "an earlier leg left the ranks out of step"}
+            return
+        finished = threading.Event()
+
+        def bail():
+            if finished.is_set():
+                return
+            if rank == 0:
+                with out_lock:
+                    if finished.is_set():
+                        return
+                    line.setdefault(container, {})[name] = {"skipped": f"did not finish within {timeout_s:.0f} s; the line goes out without it"}
+                print_line()
+                sys.stdout.flush()
+                os._exit(0)
+            time.sleep(30.0)
+            os._exit(0)
+        dog = threading.Timer(timeout_s, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            res = fn()
+        except BaseException as e:                       # SystemExit of a sanity check included: the headline still goes out
+            res = {"skipped": f"{type(e).__name__}: {e}"}
+        finally:
+            with out_lock:
+                finished.set()
+            dog.cancel()
+        if group is not None:
+            try:
+                everybody = group.allreduce_scalar(0 if (isinstance(res, dict) and "skipped" in res) else 1, "MIN") >= 1
+            except Exception as e:                       # a peer is gone or out of step: no further collective is safe
+                everybody, state["group_ok"] = False, False
+                res = {"skipped": f"the ranks lost step ({type(e).__name__}: {e})"}
+            if not everybody and not (isinstance(res, dict) and "skipped" in res):
+                res = {"skipped": "skipped on another rank"}
+        if rank == 0:
+            line.setdefault(container, {})[name] = res
 
     if world > 1 and not args.no_other_scaling:
-        # The other workloads are optional legs of the line.  Over RCCL a collective that never completes (a transport problem
-        # that only the sample shards' ncclSend / ncclRecv exchange meets, say) would take the finished primary measurement
-        # down with it: each leg runs under a watchdog that lets rank 0 print the line WITHOUT the leg and ends the process.
-        import threading
+        keys = ("mode", "metric", "value", "ms_per_step", "rays_per_step", "frame", "vary_seed", "cold", "per_rank",
+                "sample_groups", "tile_ranks", "skipped", "composed_crc_ok", "oracle_check")
         for m in ("strong", "weak", "samples"):
-            if m == args.scaling:
-                continue
-            finished = threading.Event()
-
-            def bail(mode=m, finished=finished):
-                if finished.is_set():
-                    return
-                if rank == 0:
-                    emit(primary, dict(others, **{mode: {"mode": mode, "skipped": f"did not finish within {args.other_timeout:.0f} s; the line goes out without it"}}))
-                    sys.stdout.flush()
-                os._exit(0)
-            dog = threading.Timer(args.other_timeout, bail)
-            dog.daemon = True
-            dog.start()
-            try:
-                others[m] = measure(m, args.steps, args.warmup)
-            finally:
-                finished.set()
-                dog.cancel()
-    if rank == 0:
-        emit(primary, others)
+            if m != args.scaling:
+                run_leg("other_scaling", m, lambda m=m: {k: v for k, v in measure(m, args.steps, args.warmup).items() if k in keys}, args.other_timeout)
+    if world == 1 and not args.no_other_configs:
+        # every other BASELINE configuration + the HBM operating point, witnessed by the same run (each on a context of its own)
+        for key in OTHER_CONFIGS:
+            run_leg("other_configs", key, lambda key=key: other_config_leg(key, device), args.other_timeout)
+        if rank == 0 and "hbm_point" in line.get("other_configs", {}) and "hbm" in line["other_configs"]["hbm_point"]:
+            line["hbm_point"] = line["other_configs"]["hbm_point"]["hbm"]
+    print_line()
     sys.stdout.flush()
+    crc_bad = rank == 0 and (line.get("composed_crc_ok") is False or
+                             any(isinstance(o, dict) and o.get("composed_crc_ok") is False for o in line.get("other_scaling", {}).values()))
 
     def teardown():
         if grouped:
-            if composing:
-                trc.group_finalize()
-            group.barrier()
+            try:
+                if composing:
+                    trc.group_finalize()
+                if state["group_ok"]:
+                    group.barrier()
+            except Exception as e:
+                sys.stderr.write(f"bench.py: rank {rank}: teardown: {e}\n")
             group.close()
         trc.close()
     _with_c_stdout_on_stderr(teardown)
     os.dup2(2, 1)       # anything native code still prints at exit goes to stderr, after the JSON line
+    if crc_bad:
+        sys.stderr.write("bench.py: the composed frame does NOT match the oracle's committed CRC32 (composed_crc_ok false): the numbers of "
+                         "this line belong to a wrong frame\n")
+        sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -56,6 +56,12 @@ def main():
         t.group_compose_samples(0)
         if rank == 0:
             out["samples"] = t.download_composed()
+        else:                                    # the composed frame exists on the root only: the others are told so, not handed stale slices
+            try:
+                t.download_composed()
+                out["nonroot_refused"] = np.array(False)
+            except Exception as e:
+                out["nonroot_refused"] = np.array(getattr(e, "status", None) == abi.ERR_NO_FRAME)
         out["untouched"] = np.array(np.array_equal(mine.view(np.uint32), t.download_accum().view(np.uint32)))   # a progressive host renders on
         t.group_allreduce_mean_accum()
         out["mean"] = t.download_accum()

@@ -173,6 +173,55 @@ def test_two_rank_bench_path_on_one_gpu(launcher):
     assert abs(smp["rays_per_step"] / 219978393 - 1) < 0.01             # another sample set of the same frame: the same work to 1 %
     assert all(r["compose_ms"] is not None for r in smp["per_rank"])
     assert line["plumbing"] is True and "PLUMBING" in line["config"]["compose"]
+    # every workload's composed frame was held to the oracle's committed CRC32 (tests/golden/bench_goldens.json)
+    assert line["composed_crc_ok"] is True and line["oracle_check"]["golden"] == "config2"       # tiles: the one-GPU frame, bit for bit
+    assert weak["composed_crc_ok"] is True and weak["oracle_check"]["golden"] == "config2_weak_N2"
+    assert smp["composed_crc_ok"] is True and smp["oracle_check"]["golden"] == "config2_samples_S2"
+
+
+def _run_bench(args, env_extra=None, timeout=900):
+    import json, subprocess, sys
+    env = dict(os.environ, TRC_BENCH_NO_RCCL="1", **(env_extra or {}))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stderr[-2000:]
+    return out.returncode, json.loads(lines[0]), out.stderr
+
+
+@pytest.mark.gpu
+def test_a_wrong_fold_order_fails_the_run():
+    """bench.py validates what it timed: 4 ranks on one GPU, sample shards.  Folded in rank order the composed frame has the CRC32 the
+    oracle's statement of the definition has (render_sample_sharded, committed); the same four shards folded in the reverse order
+    (test hook: rank r renders group 3 - r) is another frame -- float addition does not associate -- and the run exits non-zero."""
+    rc, line, err = _run_bench(["--gpus", "4", "--steps", "1", "--warmup", "0", "--scaling", "samples", "--no-other-scaling", "--no-cold"])
+    assert rc == 0 and line["composed_crc_ok"] is True and line["oracle_check"]["golden"] == "config2_samples_S4", err[-1500:]
+    rc, line, err = _run_bench(["--gpus", "4", "--steps", "1", "--warmup", "0", "--scaling", "samples", "--no-other-scaling", "--no-cold"],
+                               {"TRC_BENCH_REVERSE_GROUPS": "1"})
+    assert rc == 4 and line["composed_crc_ok"] is False and "does NOT match" in err
+    # ... and a frame held to the wrong golden fails likewise (the tile split against the sample-sharded CRC)
+    rc, line, err = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-other-scaling", "--no-cold"], {"TRC_BENCH_EXPECT_GOLDEN": "config2_samples_S2"})
+    assert rc == 4 and line["composed_crc_ok"] is False
+
+
+@pytest.mark.gpu
+def test_the_one_gpu_line_witnesses_every_baseline_config():
+    """N = 1: the headline frame and every other BASELINE configuration are held to the oracle's committed ray counts and CRC32s, and
+    the HBM operating point says that north_star's 40 % is not met"""
+    rc, line, err = _run_bench(["--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--no-fast-math", "--no-cold"], timeout=1500)
+    assert rc == 0, err[-2000:]
+    assert line["composed_crc_ok"] is True and line["oracle_check"]["rays_ok"] is True
+    oc = line["other_configs"]
+    assert set(oc) == {"config3", "config4", "config5_sppm", "volume", "hbm_point"}
+    for k in ("config3", "config4", "volume"):
+        assert "skipped" not in oc[k], oc[k]
+        assert oc[k]["oracle_check"]["crc_ok"] is True and oc[k]["oracle_check"]["rays_ok"] is True, (k, oc[k]["oracle_check"])
+        assert oc[k]["value"] > 1000 and oc[k]["steps"] == 2
+    s5 = oc["config5_sppm"]
+    assert s5["oracle_check"]["crc_ok"] is True and s5["oracle_check"]["totalPhotonSum_ok"] is True and s5["frames_per_step"] == 64
+    assert line["hbm_point"]["target_frac"] == 0.40 and line["hbm_point"]["mrays"] > 1000
+    assert line["hbm_point"]["target_met"] in (False, None)
     assert line["transport"] == "table" and len(line["devices"]) == 2 and line["devices"][0] == line["devices"][1]   # one GPU, seen by both ranks
     assert all(r["compose_ms"] is not None for r in line["per_rank"])   # the reduce really ran (host-staged)
     # the cold leg and the parity-imposed bounds ride along for every rank

@@ -18,6 +18,7 @@ def _launch(gpu, seed, **kw):
     frame, rng, rays = gpu.download_accum(), gpu.download_rng(), gpu.stats().rays
     _, costs, _ = gpu.block_costs()
     _launch.sixteenths = int(((costs >> 30) & 1).sum())          # blocks some of whose quarters ran as 2x2 sixteenths
+    _launch.pixels = int(((costs >> 29) & 1).sum())              # ... and some of those as single pixels
     return frame, rng, rays, int((costs >> 31).sum()), len(costs)
 
 
@@ -69,6 +70,40 @@ def test_sixteenths_where_wavefront_slots_are_idle(gpu, cornell_spheres):
     assert deep[0] == 0 and max(deep) > 0, deep       # launch 1 is all quarters; sixteenths need a measured quarter first
     ref, st = po.render(cornell_spheres.view, cam, W, H, host.fill_rng(9, W, H), spp=spp, env=(0.2, 0.3, 0.4))
     assert st.rays == plain[2] and np.array_equal(plain[0].view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("scene_kind,integrator", [("spheres", abi.INTEGRATOR_PATH), ("mesh", abi.INTEGRATOR_PATH), ("mesh", abi.INTEGRATOR_MIS)])
+def test_single_pixels_where_a_share_ends_on_one_sixteenth(gpu, cornell_spheres, scene_kind, integrator):
+    """third level of the plan (round 6): a share with far fewer entries than wavefront slots ends on its slowest 2x2 sixteenths -- four
+    divergent sample chains on one wavefront; those run as four single pixels (one lane each: the chain floor) from the launch after
+    they were measured.  Same frame, RNG texture and ray count whatever the plan picks, on the LDS-resident kernels and on the
+    persistent workgroups of a tree read from memory."""
+    W, H, spp = 480, 272, 32
+    scene = cornell_spheres if scene_kind == "spheres" else host.HostScene(abi.SCENE_CORNELL_MESH, host.Mesh.golden("teapot"))
+    cam = host.prepare_camera(W, H)
+    gpu.upload_scene(scene.view); gpu.set_camera(cam); gpu.set_environment((0.2, 0.3, 0.4)); gpu.resize(W, H)
+    gpu.debug_set("no_split", 0)
+    kw = dict(spp=spp, integrator=integrator, tile_rank=1, tile_nranks=2)          # 1 020 blocks for 4 096+ wavefront slots
+    plain = _launch(gpu, 13, small_blocks=False, fixed_order=True, **kw)
+    gpu.debug_set("no_split", 0)
+    gpu.debug_set("no_plan_reuse", 1)               # re-plan before every launch
+    try:
+        pixels, sixteenths = [], []
+        for k in range(9):
+            r = _launch(gpu, 13, **kw)
+            pixels.append(_launch.pixels); sixteenths.append(_launch.sixteenths)
+            assert _same(r, plain), (k, pixels)
+    finally:
+        gpu.debug_set("no_plan_reuse", 0)
+    assert max(sixteenths) > 0 and max(pixels) > 0, (sixteenths, pixels)
+    first = next(k for k, v in enumerate(pixels) if v)
+    assert sixteenths[first - 1] > 0, (sixteenths, pixels)          # a sixteenth is measured as one before it becomes pixels
+    if scene_kind == "spheres":
+        ref, st = po.render(scene.view, cam, W, H, host.fill_rng(13, W, H), spp=spp, env=(0.2, 0.3, 0.4), tile_rank=1, tile_nranks=2, integrator=integrator)
+        mine = np.zeros((H, W), bool)
+        ty, tx = np.meshgrid(np.arange(H) // 16, np.arange(W) // 16, indexing="ij")
+        mine[(tx + ty) % 2 == 1] = True
+        assert st.rays == plain[2] and np.array_equal(plain[0][mine].view(np.uint32), ref[mine].view(np.uint32))
 
 
 @pytest.mark.parametrize("integrator", [abi.INTEGRATOR_PATH, abi.INTEGRATOR_MIS])

@@ -82,6 +82,7 @@ def test_every_group_call_with_n_ranks_on_one_gpu(gpu, tmp_path, world):
     assert np.array_equal(bits(res[0]["samples"]), bits(want))
     for r in range(world):
         assert np.array_equal(bits(res[r]["mean"]), bits(want)) and bool(res[r]["untouched"]), r
+        assert r == 0 or bool(res[r]["nonroot_refused"]), r
     # ... and against this GPU rendering the shards one after the other (the seeds are the documented function of the rank)
     shards = []
     for g in range(world):

@@ -28,6 +28,12 @@ TRC_DEV uint32_t pcg_next(Pcg& r) {
 // randomF: ldexp(float(u32), -32); float(u32) rounds to nearest-even so 1.0f is reachable (B-4)
 TRC_DEV float pcg_float(Pcg& r) { return ldexpf((float)pcg_next(r), -32); }
 
+// Work counters of a lane (rays, shaded hits): a register, or -- in the kernels that park per-pixel state in LDS
+// (trc_render_kernels.hpp: PARK) -- a word of the lane's LDS column bumped by one ds_add_u32, which costs no register at all.
+struct LdsCount { uint32_t* p; };
+TRC_DEV void bump(uint32_t& c) { c++; }
+TRC_DEV void bump(LdsCount& c) { (void)__hip_atomic_fetch_add(c.p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+
 struct Shade {            // what the integrators need from the material table
     const uint32_t* mats; // kMaterialDwords per material: type, texType, albedo.rgb
 };
@@ -196,8 +202,8 @@ TRC_DEV void path_begin(PathState& ps, const Ray& camera_ray, uint32_t max_depth
 
 // What happens between two Scene::hit calls of tracePath (Render.metal:432-489).  Returns true when the
 // path is finished; `result` is then the sample's radiance.
-template <bool STATS, bool SOBOL = false>
-TRC_DEV bool path_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, TravCounters& cnt, uint32_t& n_shaded, F3& result) {
+template <bool STATS, bool SOBOL = false, class COUNT = uint32_t>
+TRC_DEV bool path_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, TravCounters& cnt, COUNT& n_shaded, F3& result) {
     if (!ps.primary) {                                               // } while ((--depth) > 0), :489
         if (--ps.depth_left <= 0) { result = ps.color; return true; }
     }
@@ -220,7 +226,7 @@ TRC_DEV bool path_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, 
     F3 wo = f3(dot(nx, minus_d), dot(ny, minus_d), dot(rec.sn, minus_d));   // wts * (-dir)
     F3 wi = f3(0);
     float bxPDF = 0;                                                 // uninitialised in the reference (B-3)
-    n_shaded++;
+    bump(n_shaded);
     prof<STATS>(cnt, kProfShade);
     F3 attenuation = material_S_F<STATS>(mtype, hit_color(cx.S, cx.sh, rec), wo, wi, uu, bxPDF, cnt);
     if (bxPDF <= 0) { result = ps.color; return true; }
@@ -368,9 +374,9 @@ TRC_DEV float grid_sample(const PathCtx& cx, const HitRec& rec, MediumHit& mi, P
 // Same for traceMIS (Render.metal:298-406) and, with VOLUME, traceVolume (Render.metal:78-275 = traceMIS + the
 // medium block :114-158).  Lights are literally squareList[5] and [6] (:320-324, B-12).
 // The shadow ray (any-hit Scene::hit) is traced here, inside the step.
-template <bool ALL_LDS, bool STATS, bool VOLUME = false, bool SOBOL = false, bool HYB = false>
-TRC_DEV bool mis_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, TravCounters& cnt, uint32_t& n_rays,
-                      uint32_t& n_shaded, F3& result) {
+template <bool ALL_LDS, bool STATS, bool VOLUME = false, bool SOBOL = false, bool HYB = false, class COUNT = uint32_t>
+TRC_DEV bool mis_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, TravCounters& cnt, COUNT& n_rays,
+                      COUNT& n_shaded, F3& result) {
     HitRec& rec = ps.rec;
     const bool resume = VOLUME && TRC_TRACK_SLICE > 0 && ps.tracking;      // back for the next slice of the delta tracker: nothing below was left undone
     if (!resume) {
@@ -452,7 +458,7 @@ TRC_DEV bool mis_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, T
     F3 light_term = mat_albedo(cx.sh, lsr.material) * cosOnLight;
     float liPDF = (_dis * _dis) * lsr.areaPDF / cosOnLight;
     TRC_PIN(light_term.x); TRC_PIN(light_term.y); TRC_PIN(light_term.z); TRC_PIN(liPDF);
-    n_rays++;
+    bump(n_rays);
     bool blocked;
     if (STATS) {                                  // the reference's walk (the exact counters are defined on it)
         HitRec shr;
@@ -467,7 +473,7 @@ TRC_DEV bool mis_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, T
         F3 wo = f3(dot(nx, minus_d), dot(ny, minus_d), dot(rec.sn, minus_d));
         F3 wi = f3(dot(nx, _ray.d), dot(ny, _ray.d), dot(rec.sn, _ray.d));
         float bxPDF = 0;
-        n_shaded++;
+        bump(n_shaded);
         F3 weight = material_F(mtype, base_color, wo, wi, uu, bxPDF);
         weight = weight * light_term;
         weight = weight * power_heuristic(1, liPDF, 1, bxPDF);
@@ -477,7 +483,7 @@ TRC_DEV bool mis_step(const PathCtx& cx, PathState& ps, bool hitted, Pcg& rng, T
     F3 wi = f3(0);
     float bxPDF = 0;
     F3 wo = f3(dot(nx, minus_d), dot(ny, minus_d), dot(rec.sn, minus_d));
-    n_shaded++;
+    bump(n_shaded);
     ps.scat_attenuation = material_S_F(mtype, base_color, wo, wi, uu, bxPDF);
     ps.scat_bxPDF = bxPDF;
     if (bxPDF <= 0) { result = ps.color; return true; }

@@ -440,24 +440,25 @@ struct Trav {
 
 // pops the next deferred sibling, or ends the traversal; `ret_start` = level at which the reference's first
 // upward ("came from child") iteration would run -- only counted, never executed
-// Entry e of a lane's stack.  A ray rarely has more than a dozen siblings pending, but the stack must hold the tree's
-// depth.  HYB (the tracePath render kernels on trees read from memory, whose registers allow 5 waves/SIMD if LDS does):
-// the first S.stack_lds entries live in LDS, deeper ones in the workgroup's rows in global memory.  The other kernels
-// keep the whole stack in LDS (measured: the second level costs traceMIS / traceVolume 2.7 % and buys them nothing at 4
-// waves/SIMD).
-// Almost every access of a wavefront is below stack_lds in all of its lanes: ONE wave-uniform test (a ballot) keeps the
-// per-lane if / else -- six scalar mask instructions and two branches per access -- out of the box-step loop.
+// A lane's stack.  A ray rarely has more than a dozen siblings pending, but the stack must hold the tree's depth.  HYB (the render
+// kernels on trees read from memory, whose registers allow more wavefronts than whole stacks in LDS would): the first S.stack_lds
+// entries live in LDS, deeper ones in the wavefront's rows in global memory.  The other kernels keep the whole stack in LDS.
+// Almost every access of a wavefront is below stack_lds in all of its lanes: ONE wave-uniform test (a ballot) keeps the per-lane
+// if / else -- six scalar mask instructions and two branches per access -- out of the box-step loop.
+// (Round 6 tried the LDS entries as the TOP of the stack instead -- a ring of 2^k slots that moves its oldest entry to the global row
+// when it is full: profiles/r06/exp_stack_ring.patch.  Nothing at 8 entries, -14 % at 4, and traceMIS loses 5 %: a lane that is deep
+// keeps pushing and popping around the ring's edge, and every such step then costs an eviction AND a refill.)
 template <bool HYB>
-TRC_DEV void stack_put(const SceneRef& S, uint32_t* stack, uint32_t e, uint32_t v) {
-    if (!HYB || (__builtin_expect(__builtin_amdgcn_ballot_w64(e >= S.stack_lds) == 0ull, 1))) { stack[e * kBlock] = v; return; }
-    if (e < S.stack_lds) stack[e * kBlock] = v;
-    else st1_global(S.ovf + (e - S.stack_lds) * kBlock, v);
+TRC_DEV void stack_push(const SceneRef& S, uint32_t* stack, uint32_t& sp, uint32_t v) {
+    if (!HYB || __builtin_expect(__builtin_amdgcn_ballot_w64(sp >= S.stack_lds) == 0ull, 1) || sp < S.stack_lds) stack[sp * kBlock] = v;
+    else st1_global(S.ovf + (sp - S.stack_lds) * kBlock, v);
+    sp++;
 }
 template <bool HYB>
-TRC_DEV uint32_t stack_get(const SceneRef& S, const uint32_t* stack, uint32_t e) {
-    if (!HYB || (__builtin_expect(__builtin_amdgcn_ballot_w64(e >= S.stack_lds) == 0ull, 1))) return stack[e * kBlock];
-    if (e < S.stack_lds) return stack[e * kBlock];
-    return ld1_global(S.ovf + (e - S.stack_lds) * kBlock);
+TRC_DEV uint32_t stack_pop(const SceneRef& S, const uint32_t* stack, uint32_t& sp) {      // sp > 0
+    sp--;
+    if (!HYB || __builtin_expect(__builtin_amdgcn_ballot_w64(sp >= S.stack_lds) == 0ull, 1) || sp < S.stack_lds) return stack[sp * kBlock];
+    return ld1_global(S.ovf + (sp - S.stack_lds) * kBlock);
 }
 
 template <bool HYB, bool STATS>
@@ -467,8 +468,7 @@ TRC_DEV void trav_pop_or_finish(const SceneRef& S, Trav& tv, int32_t ret_start, 
         tv.finish();
         return;
     }
-    tv.sp--;
-    tv.tag = stack_get<HYB>(S, stack, tv.sp);
+    tv.tag = stack_pop<HYB>(S, stack, tv.sp);
     if (STATS) {
         const int32_t ls = (int32_t)lvstack[tv.sp * kBlock];
         cnt.n_return += (uint32_t)(ret_start - ls + 1);
@@ -608,9 +608,8 @@ TRC_DEV void trav_iter(const SceneRef& S, const Ray& ray, HitRec& rec, const flo
             const uint32_t tagL = __float_as_uint(q3.z), tagR = __float_as_uint(q3.w);
             const bool left_first = t_left < t_right;            // Render.hh:174 (literal, also when only one hit)
             if (left_test && right_test) {
-                stack_put<HYB>(S, stack, tv.sp, left_first ? tagR : tagL);    // Render.hh:171-172: visit the other one later
                 if (STATS) lvstack[tv.sp * kBlock] = (uint32_t)tv.level;
-                tv.sp++;
+                stack_push<HYB>(S, stack, tv.sp, left_first ? tagR : tagL);    // Render.hh:171-172: visit the other one later
             }
             tv.tag = left_first ? tagL : tagR;
             if (STATS && (tv.tag >> kTagIndexBits) == kTagInterior) tv.level += 1;
@@ -674,8 +673,10 @@ TRC_DEV uint32_t scene_occluded_free(const SceneRef& S, const F3 root_min, const
     auto give = [&](uint32_t tag) {               // a box that passed: into the hand, else onto the stack
         if (restarted) return;
         if (cur0 == kTagNone) cur0 = tag;
-        else if (sp < stack_cap) { stack_put<HYB>(S, stack, sp, tag); sp++; }
-        else { restarted = true; sp = 0; cur0 = kRoot; }                                      // cannot happen on a tree of the depth the stack is sized for
+        else if (sp < stack_cap) stack_push<HYB>(S, stack, sp, tag);
+        // cannot happen on a tree of the depth the stack is sized for (one pending entry per level at most); if it does -- a tree
+        // uploaded with a wrong depth -- an identical rewalk would fill the stack again and spin: the reference's walk answers
+        else { restarted = true; sp = 0; cur0 = kTagNone; found = true; ask_reference = true; }
     };
 #ifndef TRC_OCCL_DESCEND_MIN
 #define TRC_OCCL_DESCEND_MIN 1      // plain round: shadow rays of a wavefront walk left-first, i.e. together (1 / 4 / 8 / 16 / 32: 50.9 / 50.9 / 51.3 / 52.1 / 53.1 ms on config 3)
@@ -708,7 +709,7 @@ TRC_DEV uint32_t scene_occluded_free(const SceneRef& S, const F3 root_min, const
             expand(a0, a1, a2, a3);
             // refill the hand from the stack (deepest pending subtree first)
             if (restarted) continue;
-            if (cur0 == kTagNone && sp > 0u) { sp--; cur0 = stack_get<HYB>(S, stack, sp); }
+            if (cur0 == kTagNone && sp > 0u) cur0 = stack_pop<HYB>(S, stack, sp);
         }
         // ---- primitive test: the leaf in hand
         if (!found && is_leaf(cur0)) {
@@ -721,7 +722,7 @@ TRC_DEV uint32_t scene_occluded_free(const SceneRef& S, const F3 root_min, const
             cur0 = kTagNone;
         }
         if (found) { cur0 = kTagNone; sp = 0; }
-        if (cur0 == kTagNone && sp > 0u) { sp--; cur0 = stack_get<HYB>(S, stack, sp); }
+        if (cur0 == kTagNone && sp > 0u) cur0 = stack_pop<HYB>(S, stack, sp);
         if (__ballot(cur0 != kTagNone) == 0ull) break;
     }
     return ask_reference ? kOccludedAskReference : (found ? kOccludedYes : kOccludedNo);

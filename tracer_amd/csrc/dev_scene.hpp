@@ -54,6 +54,7 @@ struct DScene {
     uint32_t n_nodes, n_spheres, n_squares, n_cubes, n_materials, n_triangles;
     uint32_t stack_depth;     // max pending siblings = tree depth (checked <= TRC_MAX_BVH_DEPTH)
     uint32_t stack_lds;       // stack entries per lane kept in LDS (= stack_depth unless a launch provides overflow rows)
+    uint32_t stack_ovf_rows;  // rows of 64 entries per wavefront in global memory behind them (0: the stack is all LDS)
     uint32_t descend_min;     // trees read from memory: lanes that must still be descending for the box-step loop to go on while others
                               // wait with a leaf (dev_intersect.hpp trav_iter); chosen by where the scene lives (trc_scene_prep.hpp)
 };

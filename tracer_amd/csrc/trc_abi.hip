@@ -129,15 +129,25 @@ constexpr float kQuarterCost = 0.85f;        // a quarter's duration relative to
                                              // a block it has not split yet (measured: 0.8-0.9 for the blocks that matter)
 constexpr float kQuarterEstimate = 0.65f;
 constexpr float kSixteenthTier = 0.8f;       // quarters within this factor of the launch's longest part go on to 2x2 blocks
-// the slowest part of block i that the last launch ran (quarters, or the sixteenths of the quarters that were split again)
+// qsplit[4 i + q]: bit 0 = quarter q of block i ran as four sixteenths in the last launch, bits 4..7 = sixteenth s of it ran as four
+// single pixels (round 6).  for_each_part visits the cost slot of every part block i ran as (trc_ctx.hpp: slot = launch code - 1).
+constexpr uint32_t kPixelBit = 4u;
+template <class F>
+__host__ __device__ __forceinline__ void for_each_part(const uint32_t* qsplit, uint32_t i, F&& f) {
+    for (uint32_t q = 0; q < 4u; ++q) {
+        const uint32_t m = qsplit[4u * i + q];
+        if (!(m & 1u)) { f(q); continue; }
+        for (uint32_t s4 = 0; s4 < 4u; ++s4) {
+            if ((m >> (kPixelBit + s4)) & 1u) { for (uint32_t p4 = 0; p4 < 4u; ++p4) f(20u + 16u * q + 4u * s4 + p4); }
+            else f(4u + 4u * q + s4);
+        }
+    }
+}
+// the slowest part of block i that the last launch ran (quarters, the sixteenths of the quarters that were split again, their pixels)
 __device__ __forceinline__ uint32_t slowest_part(const uint32_t* cost, const uint32_t* qsplit, uint32_t i) {
     const uint32_t* c = cost + (size_t)i * kCostSlots;
     uint32_t m = 0u;
-#pragma unroll
-    for (uint32_t q = 0; q < 4u; ++q) {
-        if (qsplit[4u * i + q]) { const uint32_t* s = c + 4u + 4u * q; m = max(m, max(max(s[0], s[1]), max(s[2], s[3]))); }
-        else m = max(m, c[q]);
-    }
+    for_each_part(qsplit, i, [&](uint32_t slot) { m = max(m, c[slot]); });
     return m;
 }
 // What a block's duration says about the block.  A SIMD issues from its oldest wavefronts first (tools/probe/age_probe.hip:
@@ -158,11 +168,7 @@ __device__ __forceinline__ void filter_block_costs(const uint32_t* cost, const u
         filt[at] = (f && !fresh) ? min(f + (f >> 6) + 1u, c) : c;
     };
     if (stride != kCostSlots || !split[i]) { slot(0u); return; }
-#pragma unroll
-    for (uint32_t q = 0; q < 4u; ++q) {
-        if (qsplit[4u * i + q]) { for (uint32_t s4 = 0; s4 < 4u; ++s4) slot(4u + 4u * q + s4); }
-        else slot(q);
-    }
+    for_each_part(qsplit, i, slot);
     // What the block cost when it last ran WHOLE ranks it for as long as it runs in parts (a value measured under the same
     // conditions as its unsplit neighbours': re-estimating it from the parts every launch made the plan settle elsewhere,
     // config 3 329 -> 344-366 ms).  It only follows the parts DOWN when they say the block is no longer what it was (a camera
@@ -203,7 +209,7 @@ __global__ void __launch_bounds__(256) k_order_keys(const uint32_t* raw, uint32_
 // it ran whole (else -1), quart[4 r + q] = quarter q's cost when the block ran in parts and that quarter ran as ONE (else 0;
 // 0xFFFFFFFF: it already ran as sixteenths)
 __global__ void __launch_bounds__(256) k_plan_gather(const uint32_t* vals, const uint32_t* split, const uint32_t* cost, const uint32_t* qsplit,
-                                                     const uint32_t* raw, uint32_t n, uint32_t* part, float* rawv, uint32_t* quart) {
+                                                     const uint32_t* raw, uint32_t n, uint32_t* part, float* rawv, uint32_t* quart, uint32_t* sixt) {
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
     if (r >= n) return;
     const uint32_t i = vals[r];
@@ -211,8 +217,14 @@ __global__ void __launch_bounds__(256) k_plan_gather(const uint32_t* vals, const
     part[r] = sp ? slowest_part(cost, qsplit, i) : 0u;
     rawv[r] = sp ? -1.0f : (float)raw[(size_t)i * kCostSlots];
 #pragma unroll
-    for (uint32_t q = 0; q < 4u; ++q)
-        quart[4u * r + q] = !sp ? 0u : (qsplit[4u * i + q] ? 0xFFFFFFFFu : cost[(size_t)i * kCostSlots + q]);
+    for (uint32_t q = 0; q < 4u; ++q) {
+        const uint32_t m = sp ? qsplit[4u * i + q] : 0u;
+        quart[4u * r + q] = !sp ? 0u : ((m & 1u) ? 0xFFFFFFFFu : cost[(size_t)i * kCostSlots + q]);
+        // third level: sixteenth s of a quarter that ran as sixteenths -- its cost as ONE sixteenth (0xFFFFFFFF: it already ran as
+        // pixels; 0: its quarter ran whole, nothing is known about it)
+        for (uint32_t s4 = 0; s4 < 4u; ++s4)
+            sixt[16u * r + 4u * q + s4] = !(m & 1u) ? 0u : (((m >> (kPixelBit + s4)) & 1u) ? 0xFFFFFFFFu : cost[(size_t)i * kCostSlots + 4u + 4u * q + s4]);
+    }
 }
 // exclusive prefix sum over the 1024 threads of the workgroup (wave shuffles, then the 16 wave totals); returns the total
 __device__ __forceinline__ double block_scan_1024(double v, double* s_wave /* [16] */, double& total) {
@@ -229,8 +241,8 @@ __device__ __forceinline__ double block_scan_1024(double v, double* s_wave /* [1
     total = tot;
     return base + inc - v;
 }
-__global__ void __launch_bounds__(1024) k_plan_split(const uint32_t* keys, const uint32_t* part, const float* rawv, const uint32_t* quart, uint32_t n,
-                                                     uint32_t k_max, const uint32_t slots, const uint32_t max_entries, uint32_t* plan, uint32_t* launch) {
+__global__ void __launch_bounds__(1024) k_plan_split(const uint32_t* keys, const uint32_t* part, const float* rawv, const uint32_t* quart, const uint32_t* sixt,
+                                                     uint32_t n, uint32_t k_max, const uint32_t slots, const uint32_t max_entries, uint32_t* plan, uint32_t* launch) {
     __shared__ double s_wave[16];
     __shared__ float s_best[1024];
     __shared__ uint32_t s_k[1024], s_q[1024], s_first[1024];
@@ -317,49 +329,85 @@ __global__ void __launch_bounds__(1024) k_plan_split(const uint32_t* keys, const
     uint32_t K2 = s_k[0] + s_q[0], use_tier = tier, keep = 1u;
     if (12u * K2 > room) { K2 = s_k[0]; use_tier = 0xFFFFFFFFu; }                 // no new ones
     if (12u * K2 > room) { K2 = 0u; keep = 0u; }                                  // not even the old ones: back to quarters
+    __syncthreads();
+    // third level (round 6): the sixteenths of quarters that were sixteenths last launch too and lasted at least `tier` run as four
+    // single pixels -- one lane, the floor of a pixel's sample chain -- under the same condition (the launch ends on its longest
+    // part while wavefront slots are idle) and out of what room the second level left
+    uint32_t have3 = 0u, want3 = 0u;
+    if (keep) for (uint32_t j = t; j < 16u * K; j += 1024u) {
+        const uint32_t cs = sixt[j];
+        if (cs == 0u) continue;
+        if (cs == 0xFFFFFFFFu) have3++;
+        else if (cs >= tier) want3++;
+    }
+    s_k[t] = have3; s_q[t] = want3;
+    __syncthreads();
+    for (uint32_t off = 512u; off > 0u; off >>= 1) { if (t < off) { s_k[t] += s_k[t + off]; s_q[t] += s_q[t + off]; } __syncthreads(); }
+    const uint32_t room3 = room - 12u * K2;
+    uint32_t K3 = s_k[0] + s_q[0], tier3 = tier, keep3 = 1u;
+    if (3u * K3 > room3) { K3 = s_k[0]; tier3 = 0xFFFFFFFFu; }
+    if (3u * K3 > room3) { K3 = 0u; keep3 = 0u; }
     if (t == 0) {
         plan[0] = K; plan[3] = use_tier; plan[4] = K2; plan[7] = keep;
         plan[5] = 0u;                                                  // k_build_launch's cursor into the part region
         plan[6] = K;
-        plan[1] = entries1 + 12u * K2;
+        plan[8] = tier3; plan[9] = K3; plan[10] = keep3;
+        plan[1] = entries1 + 12u * K2 + 3u * K3;
     }
-    // the part region is sized for more sixteenths than k_build_launch may make: entries it does not claim name no pixels
-    for (uint32_t j = t; j < 4u * K + 12u * K2; j += 1024u) launch[j] = kLaunchIndexMask;
+    // the part region is sized for more parts than k_build_launch may make: entries it does not claim name no pixels
+    for (uint32_t j = t; j < 4u * K + 12u * K2 + 3u * K3; j += 1024u) launch[j] = kLaunchIndexMask;
 }
 // the launch list of a plan: first the parts of ranks 0 .. K-1 (the longest blocks: quarters, or sixteenths of the quarters
 // the second level picked), then the other blocks whole, longest first.  The parts take their places with an atomic cursor
 // (any order will do among them: they all start in the first round of wavefronts); a part region sized for more sixteenths
 // than were made is padded with entries that name no pixels.
 __global__ void __launch_bounds__(256) k_build_launch(const uint32_t* keys, const uint32_t* vals, uint32_t* cost, uint32_t n, uint32_t* plan,
-                                                      uint32_t* launch, uint32_t* split, uint32_t* whole, uint32_t* qsplit, uint32_t* qwhole, const bool filtered) {
+                                                      uint32_t* launch, uint32_t* split, uint32_t* whole, uint32_t* qsplit, uint32_t* qwhole, uint32_t* swhole, const bool filtered) {
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
     if (r >= n) return;
-    const uint32_t K = plan[0], tier = plan[3], region = 4u * K + 12u * plan[4], keep = plan[7], i = vals[r];
+    const uint32_t K = plan[0], tier = plan[3], keep = plan[7], tier3 = plan[8], keep3 = plan[10], i = vals[r];
+    const uint32_t region = 4u * K + 12u * plan[4] + 3u * plan[9];
     if (r < K) {
         const bool was_split = split[i] != 0u;
-        uint32_t codes[16], n_parts = 0u;          // per quarter: 1 entry or 4
-#pragma unroll
+        uint32_t codes[64], n_parts = 0u;          // per quarter: 1 entry, or per sixteenth 1 or 4
+        uint32_t* c = cost + (size_t)i * kCostSlots;
         for (uint32_t q = 0; q < 4u; ++q) {
             bool again = false;
+            const uint32_t m = was_split ? qsplit[4u * i + q] : 0u;
+            const bool was = (m & 1u) != 0u;
             if (was_split) {
-                const bool was = qsplit[4u * i + q] != 0u;
-                const uint32_t cq = was ? qwhole[4u * i + q] : cost[(size_t)i * kCostSlots + q];
+                const uint32_t cq = was ? qwhole[4u * i + q] : c[q];
                 again = was ? keep != 0u : cq >= tier;
                 if (again && !was) {
                     qwhole[4u * i + q] = max(1u, cq);
-                    if (filtered) for (uint32_t s4 = 0; s4 < 4u; ++s4) cost[(size_t)i * kCostSlots + 4u + 4u * q + s4] = 0u;   // nothing known yet
-                } else if (!again && was && filtered) cost[(size_t)i * kCostSlots + q] = qwhole[4u * i + q];    // back to one quarter: what it took as one
-
+                    if (filtered) for (uint32_t s4 = 0; s4 < 4u; ++s4) c[4u + 4u * q + s4] = 0u;   // nothing known yet
+                } else if (!again && was && filtered) c[q] = qwhole[4u * i + q];    // back to one quarter: what it took as one
             }
-            qsplit[4u * i + q] = again ? 1u : 0u;
-            if (again) { for (uint32_t s4 = 0; s4 < 4u; ++s4) codes[n_parts++] = 5u + 4u * q + s4; }
-            else codes[n_parts++] = 1u + q;
+            uint32_t mnew = again ? 1u : 0u;
+            if (!again) { codes[n_parts++] = 1u + q; qsplit[4u * i + q] = 0u; continue; }
+            for (uint32_t s4 = 0; s4 < 4u; ++s4) {
+                // a sixteenth goes on to pixels only once it has been MEASURED as a sixteenth (its quarter ran as sixteenths before)
+                const uint32_t at16 = 16u * i + 4u * q + s4;
+                const bool was3 = was && ((m >> (kPixelBit + s4)) & 1u);
+                bool again3 = false;
+                if (was) {
+                    const uint32_t cs = was3 ? swhole[at16] : c[4u + 4u * q + s4];
+                    again3 = was3 ? keep3 != 0u : cs >= tier3;
+                    if (again3 && !was3) {
+                        swhole[at16] = max(1u, cs);
+                        if (filtered) for (uint32_t p4 = 0; p4 < 4u; ++p4) c[20u + 16u * q + 4u * s4 + p4] = 0u;
+                    } else if (!again3 && was3 && filtered) c[4u + 4u * q + s4] = swhole[at16];     // back to one sixteenth
+                }
+                if (again3) { mnew |= 1u << (kPixelBit + s4); for (uint32_t p4 = 0; p4 < 4u; ++p4) codes[n_parts++] = 21u + 16u * q + 4u * s4 + p4; }
+                else codes[n_parts++] = 5u + 4u * q + s4;
+            }
+            qsplit[4u * i + q] = mnew;
         }
         const uint32_t at = atomicAdd(&plan[5], n_parts);
         for (uint32_t j = 0; j < n_parts; ++j) if (at + j < region) launch[at + j] = i | (codes[j] << kLaunchCodeShift);
         if (!was_split) {
             whole[i] = max(1u, 0xFFFFFFu - keys[r]);     // what it cost as one block, for as long as it runs in parts
-            if (filtered) for (uint32_t k = 0; k < 4u; ++k) cost[(size_t)i * kCostSlots + k] = 0u;               // the quarters: nothing known yet
+            if (filtered) for (uint32_t k = 0; k < 4u; ++k) c[k] = 0u;               // the quarters: nothing known yet
         }
         split[i] = 1u;
     } else {
@@ -373,7 +421,8 @@ __global__ void __launch_bounds__(256) k_build_launch(const uint32_t* keys, cons
 // every block as four quarters (a first launch of few blocks: nothing is known about their costs yet)
 __global__ void __launch_bounds__(256) k_build_launch_all_quarters(uint32_t n, uint32_t* plan, uint32_t* launch, uint32_t* split, uint32_t* whole, uint32_t* qsplit) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i == 0) { plan[0] = n; plan[1] = 4u * n; plan[2] = 0u; plan[3] = 0xFFFFFFFFu; plan[4] = 0u; plan[5] = 4u * n; plan[6] = 0xFFFFFFFFu; plan[7] = 1u; }
+    if (i == 0) { plan[0] = n; plan[1] = 4u * n; plan[2] = 0u; plan[3] = 0xFFFFFFFFu; plan[4] = 0u; plan[5] = 4u * n; plan[6] = 0xFFFFFFFFu; plan[7] = 1u;
+                  plan[8] = 0xFFFFFFFFu; plan[9] = 0u; plan[10] = 1u; }
     if (i >= n) return;
 #pragma unroll
     for (uint32_t j = 0; j < 4u; ++j) { launch[4u * i + j] = i | ((j + 1u) << kLaunchCodeShift); qsplit[4u * i + j] = 0u; }
@@ -717,10 +766,15 @@ size_t trc_dyn_lds_bytes(const trc_ctx* ctx, bool stats) { return dyn_lds_bytes(
 // Measured on the 1 M-triangle scene (depth 27: 6.9 KB of stack): the tracePath kernel (5 waves/SIMD by registers) was
 // held at 4 by LDS; 34.9 -> 32.8 ms per 32-spp launch once it fits.
 constexpr uint32_t kStackLdsLevels = 16;
+// LDS entries of a two-level stack when `levels` are wanted, and the global rows behind them
+static void set_hybrid_stack(DScene& sc, uint32_t levels) {
+    sc.stack_lds = std::min(sc.stack_depth, std::max(1u, levels));
+    sc.stack_ovf_rows = sc.stack_depth - sc.stack_lds;
+}
 static void plan_launch_lds(const trc_ctx* ctx, DScene& sc, uint32_t waves_per_simd, bool hybrid) {
-    if (ctx->knobs.no_lds_fit) return;                                                 // A/B knobs (trc_debug_set)
     const uint32_t levels = ctx->knobs.stack_lds_levels > 0 ? (uint32_t)ctx->knobs.stack_lds_levels : kStackLdsLevels;
-    if (hybrid) sc.stack_lds = std::min(sc.stack_depth, levels);
+    if (hybrid) set_hybrid_stack(sc, ctx->knobs.no_lds_fit ? std::max(levels, sc.stack_depth) : levels);      // (knob: the whole stack in LDS)
+    if (ctx->knobs.no_lds_fit) return;                                                 // A/B knobs (trc_debug_set)
     if (!ctx->lds_prefix_ok) return;                                                   // all or nothing was decided at upload
     const uint32_t per_wg = ((160u * 1024u / 4u) / (4u * waves_per_simd)) & ~127u;     // dwords; LDS is granted in 512-byte units
     const uint32_t stack = sc.stack_lds * kBlock;
@@ -732,23 +786,29 @@ static void plan_launch_lds(const trc_ctx* ctx, DScene& sc, uint32_t waves_per_s
 
 // LDS plan of a persistent-workgroup launch (k_render_pwg): `waves` wavefronts share one staged prefix; the workgroup's
 // share of the CU's 160 KB minus the wavefronts' stacks is all node prefix.  False when even one node does not fit.
-static bool plan_pwg_lds(const trc_ctx* ctx, DScene& sc, uint32_t waves, uint32_t per_cu, bool hybrid, uint32_t default_levels) {
-    const uint32_t levels = ctx->knobs.stack_lds_levels > 0 ? (uint32_t)ctx->knobs.stack_lds_levels : default_levels;      // trc_render_config.hpp
-    DScene t = sc;
-    if (hybrid) t.stack_lds = std::min(t.stack_depth, levels);
+static bool plan_pwg_lds(const trc_ctx* ctx, DScene& sc, uint32_t waves, uint32_t per_cu, bool hybrid, uint32_t default_levels, uint32_t park_rows) {
+    uint32_t levels = ctx->knobs.stack_lds_levels > 0 ? (uint32_t)ctx->knobs.stack_lds_levels : default_levels;      // trc_render_config.hpp
     const uint32_t per_wg = ((160u * 1024u / 4u) / per_cu) & ~127u;
-    const uint32_t stacks = waves * t.stack_lds * kBlock;
-    if (per_wg < stacks + t.off_nodes + kNodeDwords) return false;
-    t.n_lds_nodes = std::min(t.n_nodes, (per_wg - stacks - t.off_nodes) / kNodeDwords);
-    t.lds_dwords = t.off_nodes + t.n_lds_nodes * kNodeDwords;
-    sc = t;
-    return true;
+    for (;; --levels) {
+        DScene t = sc;
+        if (hybrid) set_hybrid_stack(t, levels);
+        const uint32_t stacks = waves * (t.stack_lds + park_rows) * kBlock;       // per wavefront: its stack rows, then its park rows (k_render_pwg)
+        if (per_wg >= stacks + t.off_nodes + kNodeDwords) {
+            t.n_lds_nodes = std::min(t.n_nodes, (per_wg - stacks - t.off_nodes) / kNodeDwords);
+            t.lds_dwords = t.off_nodes + t.n_lds_nodes * kNodeDwords;
+            sc = t;
+            return true;
+        }
+        // a scene with many analytic primitives / materials: fewer stack entries in LDS before giving the persistent workgroups up
+        if (!hybrid || levels <= 6u || ctx->knobs.stack_lds_levels > 0) return false;
+    }
 }
 
 trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32_t view_height, uint32_t blk_shift) {
     if (ctx->d_tiles && ctx->d_block_cost && ctx->tiles_nranks == nranks && ctx->tiles_rank == rank &&
         ctx->tiles_view_height == view_height && ctx->tiles_blk_shift == blk_shift) return TRC_OK;
     std::vector<uint32_t> tiles = make_tiles(ctx->width, ctx->height, nranks, rank, view_height, blk_shift);
+    if (tiles.size() > (size_t)kLaunchIndexMask) return trc_fail(ctx, TRC_ERR_UNSUPPORTED, "frame too large: more pixel blocks than a launch-list entry can name");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     // the cache key (tiles_nranks ...) is written LAST: a failed allocation below leaves the list invalid, so the next
     // call rebuilds it instead of launching with a null block_cost / order buffer
@@ -762,6 +822,7 @@ trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32
     (void)hipFree(ctx->d_cost_est); ctx->d_cost_est = nullptr;
     (void)hipFree(ctx->d_qsplit); ctx->d_qsplit = nullptr;
     (void)hipFree(ctx->d_qwhole); ctx->d_qwhole = nullptr;
+    (void)hipFree(ctx->d_swhole); ctx->d_swhole = nullptr;
     (void)hipFree(ctx->d_launch); ctx->d_launch = nullptr;
     (void)hipFree(ctx->d_plan_gather); ctx->d_plan_gather = nullptr;
     (void)hipFree(ctx->d_cost_scratch); ctx->d_cost_scratch = nullptr;
@@ -776,11 +837,12 @@ trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_cost_est, tiles.size() * 4 * kCostSlots));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_qsplit, tiles.size() * 16));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_qwhole, tiles.size() * 16));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_swhole, tiles.size() * 64));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_launch, tiles.size() * 4 * kCostSlots));
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_plan_gather, tiles.size() * 4 * 6));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->d_plan_gather, tiles.size() * 4 * 22));     // k_plan_gather: part, raw, 4 quarters, 16 sixteenths per rank
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_cost_scratch, tiles.size() * 4 * kCostSlots));   // where instrumented launches leave their durations      // k_plan_gather: part, raw, 4 quarters per rank
-        if (!ctx->d_plan) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_plan, 8 * sizeof(uint32_t)));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_plan, 0, 8 * sizeof(uint32_t), ctx->stream));
+        if (!ctx->d_plan) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_plan, kPlanWords * sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_plan, 0, kPlanWords * sizeof(uint32_t), ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_split, 0, tiles.size() * 4, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_qsplit, 0, tiles.size() * 16, ctx->stream));
         ctx->launch_cap = (uint32_t)tiles.size() * kCostSlots;
@@ -1042,7 +1104,7 @@ void trc_destroy(trc_ctx* ctx) {
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     (void)hipFree(ctx->d_blob); (void)hipFree(ctx->d_bvh_ref); (void)hipFree(ctx->d_density); (void)hipFree(ctx->d_occupancy); (void)hipFree(ctx->d_envmap); (void)hipFree(ctx->d_sobol32); (void)hipFree(ctx->d_sobol_vdc); (void)hipFree(ctx->d_rng); (void)hipFree(ctx->d_accum);
     (void)hipFree(ctx->d_tiles); (void)hipFree(ctx->d_stats); (void)hipFree(ctx->d_stats_sum); (void)hipFree(ctx->d_reduce_recv);
-    (void)hipFree(ctx->d_block_cost); (void)hipFree(ctx->d_order_hist); (void)hipFree(ctx->d_split); (void)hipFree(ctx->d_whole); (void)hipFree(ctx->d_cost_est); (void)hipFree(ctx->d_qsplit); (void)hipFree(ctx->d_qwhole); (void)hipFree(ctx->d_launch); (void)hipFree(ctx->d_plan); (void)hipFree(ctx->d_plan_gather); (void)hipFree(ctx->d_cost_scratch);
+    (void)hipFree(ctx->d_block_cost); (void)hipFree(ctx->d_order_hist); (void)hipFree(ctx->d_split); (void)hipFree(ctx->d_whole); (void)hipFree(ctx->d_cost_est); (void)hipFree(ctx->d_qsplit); (void)hipFree(ctx->d_qwhole); (void)hipFree(ctx->d_swhole); (void)hipFree(ctx->d_launch); (void)hipFree(ctx->d_plan); (void)hipFree(ctx->d_plan_gather); (void)hipFree(ctx->d_cost_scratch);
     for (int k = 0; k < 2; ++k) { (void)hipFree(ctx->d_order_keys[k]); (void)hipFree(ctx->d_order_vals[k]); }
     (void)hipFree(ctx->d_accum_alt); (void)hipFree(ctx->d_stack_ovf); (void)hipFree(ctx->d_queue);
     (void)hipFree(ctx->d_shard_in); (void)hipFree(ctx->d_shard_out); (void)hipFree(ctx->d_shard_src);
@@ -1484,12 +1546,13 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
             uint32_t* g_part = ctx->d_plan_gather;
             float* g_raw = reinterpret_cast<float*>(ctx->d_plan_gather + n);
             uint32_t* g_quart = ctx->d_plan_gather + 2 * (size_t)n;
+            uint32_t* g_sixt = ctx->d_plan_gather + 6 * (size_t)n;
             hipLaunchKernelGGL(k_plan_gather, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_order_vals[res], ctx->d_split, costs, ctx->d_qsplit,
-                               ctx->d_block_cost, n, g_part, g_raw, g_quart);
-            hipLaunchKernelGGL(k_plan_split, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_order_keys[res], g_part, g_raw, g_quart, n, k_max, wave_slots,
+                               ctx->d_block_cost, n, g_part, g_raw, g_quart, g_sixt);
+            hipLaunchKernelGGL(k_plan_split, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_order_keys[res], g_part, g_raw, g_quart, g_sixt, n, k_max, wave_slots,
                                max_entries, ctx->d_plan, ctx->d_launch);
             hipLaunchKernelGGL(k_build_launch, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_order_keys[res], ctx->d_order_vals[res], costs, n,
-                               ctx->d_plan, ctx->d_launch, ctx->d_split, ctx->d_whole, ctx->d_qsplit, ctx->d_qwhole, filtered);
+                               ctx->d_plan, ctx->d_launch, ctx->d_split, ctx->d_whole, ctx->d_qsplit, ctx->d_qwhole, ctx->d_swhole, filtered);
             kp.order = ctx->d_launch;
             kp.n_launch = ctx->d_plan + 1;
             grid_cap = max_entries;
@@ -1542,7 +1605,7 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
     }
 
     bool pwg = false;
-    uint32_t pwg_waves_n = 0, pwg_grid = 0;
+    uint32_t pwg_waves_n = 0, pwg_grid = 0, pwg_park_rows = 0;
     if (!stats && !ctx->lds_scene) {
         const bool strip = kp.strip > 1;
         const bool is_path = p->integrator == TRC_INTEGRATOR_PATH;
@@ -1550,7 +1613,8 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
         if (!ctx->knobs.no_pwg && !strip && ctx->lds_prefix_ok) {                       // no_pwg: A/B knob
             pwg_waves_n = (uint32_t)pwg_waves((int)p->integrator);
             const uint32_t per_cu = (uint32_t)pwg_per_cu((int)p->integrator);
-            pwg = plan_pwg_lds(ctx, kp.ks.sc, pwg_waves_n, per_cu, hybrid, pwg_stack_lds_levels((int)p->integrator));
+            pwg_park_rows = pwg_park((int)p->integrator) ? kParkRows : 0u;
+            pwg = plan_pwg_lds(ctx, kp.ks.sc, pwg_waves_n, per_cu, hybrid, pwg_stack_lds_levels((int)p->integrator), pwg_park_rows);
             pwg_grid = std::min((uint32_t)ctx->cu_count * per_cu, (grid_cap + pwg_waves_n - 1) / pwg_waves_n);   // small frames: no idle workgroups
         }
         if (!pwg) {
@@ -1558,7 +1622,7 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
                                  : p->integrator == TRC_INTEGRATOR_MIS ? (strip ? 4 : TRC_MIS_WAVES) : (strip ? 3 : TRC_VOLUME_WAVES);
             plan_launch_lds(ctx, kp.ks.sc, waves, hybrid);
         }
-        const size_t rows = kp.ks.sc.stack_depth - kp.ks.sc.stack_lds;
+        const size_t rows = kp.ks.sc.stack_ovf_rows;
         const size_t need = rows * kBlock * sizeof(uint32_t) * (pwg ? (size_t)pwg_grid * pwg_waves_n : (size_t)grid_cap);   // rows per wavefront
         if (need > ctx->stack_ovf_bytes) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1569,7 +1633,7 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
         }
         kp.stack_ovf = ctx->d_stack_ovf;
     }
-    const size_t lds = pwg ? ((size_t)kp.ks.sc.lds_dwords + (size_t)pwg_waves_n * kp.ks.sc.stack_lds * kBlock) * 4 : dyn_lds_bytes(kp.ks.sc, stats);
+    const size_t lds = pwg ? ((size_t)kp.ks.sc.lds_dwords + (size_t)pwg_waves_n * (kp.ks.sc.stack_lds + pwg_park_rows) * kBlock) * 4 : dyn_lds_bytes(kp.ks.sc, stats);
     if (pwg) {
         if (!ctx->d_queue && hipMalloc((void**)&ctx->d_queue, sizeof(uint32_t)) != hipSuccess) return fail(ctx, TRC_ERR_OOM, "hipMalloc block queue");
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(uint32_t), ctx->stream));
@@ -1705,10 +1769,7 @@ trc_status trc_debug_launch_shape(trc_ctx* ctx, trc_launch_shape* out) {
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t* q = &c[(size_t)i * stride];
         if (!sp[i]) { item(q[0]); continue; }
-        for (uint32_t k = 0; k < 4u; ++k) {
-            if (qs[4u * i + k]) { for (uint32_t s4 = 0; s4 < 4u; ++s4) item(q[4u + 4u * k + s4]); }
-            else item(q[k]);
-        }
+        for_each_part(qs.data(), i, [&](uint32_t slot) { item(q[slot]); });
     }
     const double to_ms = (double)ctx->last_cost_div / ((double)khz);      // cost units -> shader clocks -> ms
     out->entries = entries;
@@ -1741,11 +1802,8 @@ trc_status trc_debug_block_costs(trc_ctx* ctx, uint32_t* tiles, uint32_t* costs,
         for (uint32_t i = 0; i < n; ++i) {        // a block that ran in parts: its slowest part, bit 31 set (bit 30: some of them 2x2)
             const uint32_t* q = &c[(size_t)i * stride];
             if (!sp[i]) { costs[i] = q[0]; continue; }
-            uint32_t m = 0u, deep = 0u;
-            for (uint32_t k = 0; k < 4u; ++k) {
-                if (qs[4u * i + k]) { deep = 0x40000000u; for (uint32_t s4 = 0; s4 < 4u; ++s4) m = std::max(m, q[4u + 4u * k + s4]); }
-                else m = std::max(m, q[k]);
-            }
+            uint32_t m = 0u, deep = 0u;      // bit 30: some of its quarters ran as 2x2 sixteenths; bit 29: some of those as single pixels
+            for_each_part(qs.data(), i, [&](uint32_t slot) { m = std::max(m, q[slot]); if (slot >= 4u) deep |= 0x40000000u; if (slot >= 20u) deep |= 0x20000000u; });
             costs[i] = std::min(m, 0xFFFFFFu) | 0x80000000u | deep;
         }
     }
@@ -1902,7 +1960,9 @@ trc_status compose_samples(trc_ctx* ctx, const float* src, int root, uint32_t gr
     if (!ctx->d_shard_in || ctx->shard_px != slice_px || ctx->shard_nranks != N) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->comm_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->comm_stream));
+        if (ctx->d_composed == ctx->d_shard_out) ctx->d_composed = nullptr;     // never leave it pointing at freed memory (a failed hipMalloc below returns)
         (void)hipFree(ctx->d_shard_in); (void)hipFree(ctx->d_shard_out); ctx->d_shard_in = ctx->d_shard_out = nullptr;
+        ctx->shard_px = 0; ctx->shard_nranks = 0;
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_shard_in, total_bytes));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_shard_out, total_bytes));
         // zero-filled in stream order with the first use (hipMemset runs on the NULL stream, which the context's
@@ -1993,7 +2053,7 @@ trc_status trc_group_compose_samples(trc_ctx* ctx, int root, uint32_t sample_gro
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->comm_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->comm_stream));    // an earlier pipelined compose still owns the slice buffers
     { trc_status cs = compose_samples(ctx, ctx->d_accum, root, sample_groups, ctx->stream, "compose of the sample shards"); if (cs != TRC_OK) return cs; }
-    ctx->d_composed = ctx->d_shard_out;
+    ctx->d_composed = ctx->rank == root ? ctx->d_shard_out : nullptr;      // the composed frame exists on the root only
     return TRC_OK;
 }
 
@@ -2083,7 +2143,7 @@ trc_status trc_group_compose_samples_async(trc_ctx* ctx, int root, uint32_t samp
     { trc_status cs = compose_samples(ctx, ctx->d_shard_src, root, sample_groups, ctx->comm_stream, "compose of the sample shards"); if (cs != TRC_OK) return cs; }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_snapshot_free, ctx->comm_stream));
     ctx->snapshot_busy = true;
-    ctx->d_composed = ctx->d_shard_out;
+    ctx->d_composed = ctx->rank == root ? ctx->d_shard_out : nullptr;      // the composed frame exists on the root only
     return TRC_OK;
 }
 

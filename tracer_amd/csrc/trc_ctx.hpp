@@ -19,13 +19,16 @@ using namespace trcdev;
 // ======================================================================= kernels
 extern __shared__ __attribute__((aligned(16))) uint32_t trc_smem[];
 
-// launch-list entries (KRender::order): index into the block list | part code << 27.  Code 0: the whole block; 1..4: its 4x4
-// quarter code - 1 (x fastest) on 16 lanes; 5..20: the 2x2 sixteenth (code - 5) & 3 of quarter (code - 5) >> 2 on 4 lanes.
-constexpr uint32_t kLaunchCodeShift = 27u;
+// launch-list entries (KRender::order): index into the block list | part code << 25.  Code 0: the whole block; 1..4: its 4x4
+// quarter code - 1 (x fastest) on 16 lanes; 5..20: the 2x2 sixteenth (code - 5) & 3 of quarter (code - 5) >> 2 on 4 lanes;
+// 21..84 (round 6): ONE pixel on one lane -- pixel (code - 21) & 3 of sixteenth ((code - 21) >> 2) & 3 of quarter (code - 21) >> 4:
+// the floor of a pixel's sample chain, for the shares of a frame that end on a single 4-lane wavefront.
+constexpr uint32_t kLaunchCodeShift = 25u;
 constexpr uint32_t kLaunchIndexMask = (1u << kLaunchCodeShift) - 1u;
 // duration slots per 8x8 block of a list that may be split (KRender::cost_stride): 0..3 the quarters (0 also the whole
-// block), 4..19 the sixteenths
-constexpr uint32_t kCostSlots = 20u;
+// block), 4..19 the sixteenths, 20..83 the pixels -- slot = code - 1
+constexpr uint32_t kCostSlots = 84u;
+constexpr uint32_t kPlanWords = 12u;          // trc_abi.hip k_plan_split
 
 struct KScene {
     DScene sc;
@@ -167,6 +170,7 @@ struct trc_ctx {
     uint32_t* d_cost_est = nullptr;     // per cost slot: the shortest duration seen lately (k_filter_costs)
     uint32_t* d_qsplit = nullptr;       // [4 n] quarter q of block i ran as four sixteenths in the last launch ...
     uint32_t* d_qwhole = nullptr;       // [4 n] ... and what it cost when it last ran as one quarter
+    uint32_t* d_swhole = nullptr;       // [16 n] what a sixteenth cost when it last ran as one (while it runs as four pixels: bits 4..7 of qsplit)
     uint32_t* d_launch = nullptr;
     uint32_t* d_plan = nullptr;
     uint32_t* d_cost_scratch = nullptr;  // durations of instrumented launches (never read)

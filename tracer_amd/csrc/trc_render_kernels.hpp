@@ -10,22 +10,29 @@
 // and accumulator read and written once.  `slot` = position of the block in the launch order; `stack` / `lvstack` / `ovf` =
 // this lane's columns of the wavefront's traversal stack.  Shared by k_render (one block per one-wavefront workgroup) and
 // k_render_pwg (wavefronts of a persistent workgroup pulling blocks from a queue).
-template <bool LDS, bool STATS, int INTEGRATOR, bool SOBOL, bool HYB>
+//
+// PARK (k_render_pwg on trees read from memory): the values a lane touches only where a sample begins or ends -- the running mean,
+// (u, v), the pixel's coordinates, the sample counter -- and the two work counters live in kParkRows words of the lane's LDS column
+// `park` (row r at park[r * kBlock]) instead of registers: ten values fewer to carry through the walk and the shading code of every
+// iteration, i.e. fewer spills to scratch -- which on a mesh scene streams through the L2 the node fetches live in.
+// Same loads, same arithmetic, same stores per lane; the LDS rows are paid for with traversal-stack entries (trc_render_config.hpp).
+template <bool LDS, bool STATS, int INTEGRATOR, bool SOBOL, bool HYB, bool PARK = false, class COUNT = uint32_t>
 __device__ __forceinline__ void render_block(const KRender& kp, const DScene& sc, const uint32_t* small_base, uint32_t* stack, uint32_t* lvstack,
-                                             uint32_t* ovf, const uint32_t slot, const uint32_t lane,
-                                             uint32_t& n_rays, uint32_t& n_shaded, uint32_t& n_paths, TravCounters& cnt) {
+                                             uint32_t* ovf, uint32_t* park, const uint32_t slot, const uint32_t lane,
+                                             COUNT& n_rays, COUNT& n_shaded, uint32_t& n_paths, TravCounters& cnt) {
     const uint64_t t_start = clock64();          // this wavefront's own duration = the next launch's sort key
     const uint32_t entry = kp.order ? kp.order[slot] : slot;     // adaptive launch order / cost-adaptive block size (trc_render)
     const uint32_t index = entry & kLaunchIndexMask, code = entry >> kLaunchCodeShift;
     if (index >= kp.n_tiles) return;                            // padding of the launch list's part region (k_pad_launch)
     const uint32_t tile = kp.tiles[index];                      // pixel block: x | y << 16 in units of the block edge
-    // 3: 8x8 pixels, all 64 lanes; 2: 4x4 pixels, lanes 0..15; 1: 2x2 pixels, lanes 0..3 -- the whole list (kp.blk_shift), or a part
-    // of an 8x8 block whose previous launch ran long: quarter code - 1, or sixteenth (code - 5) & 3 of quarter (code - 5) >> 2
-    const uint32_t part = code >= 5u ? code - 5u : 0u;
+    // 3: 8x8 pixels, all 64 lanes; 2: 4x4 pixels, lanes 0..15; 1: 2x2 pixels, lanes 0..3; 0: one pixel, lane 0 -- the whole list
+    // (kp.blk_shift), or a part of an 8x8 block whose previous launch ran long (trc_ctx.hpp: launch codes)
+    const uint32_t part = code >= 21u ? (code - 21u) >> 2 : (code >= 5u ? code - 5u : 0u);      // sixteenth 0..15
     const uint32_t quarter = code >= 5u ? part >> 2 : (code ? code - 1u : 0u);
-    const uint32_t bs = code >= 5u ? 1u : (code ? 2u : kp.blk_shift);
-    const uint32_t qx = code ? ((quarter & 1u) << 2) + (code >= 5u ? (part & 1u) << 1 : 0u) : 0u;
-    const uint32_t qy = code ? ((quarter >> 1) << 2) + (code >= 5u ? ((part >> 1) & 1u) << 1 : 0u) : 0u;
+    const uint32_t bs = code >= 21u ? 0u : (code >= 5u ? 1u : (code ? 2u : kp.blk_shift));
+    const uint32_t pixel = code >= 21u ? (code - 21u) & 3u : 0u;
+    const uint32_t qx = code ? ((quarter & 1u) << 2) + (code >= 5u ? (part & 1u) << 1 : 0u) + (pixel & 1u) : 0u;
+    const uint32_t qy = code ? ((quarter >> 1) << 2) + (code >= 5u ? ((part >> 1) & 1u) << 1 : 0u) + (pixel >> 1) : 0u;
     const uint32_t px = ((tile & 0xFFFFu) << kp.blk_shift) + qx + (lane & ((1u << bs) - 1u));
     const uint32_t py = ((tile >> 16) << kp.blk_shift) + qy + (lane >> bs);
     const uint32_t W = kp.fr.width, H = kp.fr.height;
@@ -53,19 +60,36 @@ __device__ __forceinline__ void render_block(const KRender& kp, const DScene& sc
             cx.sobol_xy[0] = px; cx.sobol_xy[1] = py % kp.view_height;
         }
 
-        const size_t pix = (size_t)py * W + px;
-        uint4 texel = reinterpret_cast<const uint4*>(kp.fr.rng)[pix];       // r, g, b, a
-        float4 acc = reinterpret_cast<const float4*>(kp.fr.accum)[pix];
-        F3 cached = f3(acc.x, acc.y, acc.z);
-        const float u = (float)px / (float)W;                               // no sub-pixel jitter (B-2)
-        const float v = (float)(py % kp.view_height) / (float)kp.view_height;      // one view: view_height == H
+        // the values that are touched only where a sample begins or ends: registers, or (PARK) rows of the lane's LDS column
+        F3 cached_r = f3(0);
+        float u_r = 0, v_r = 0;
+        uint32_t s_r = 0;
+        size_t pix_r = 0;
+        auto row_f = [&](uint32_t r) { return __uint_as_float(park[r * kBlock]); };
+        auto put_f = [&](uint32_t r, float x) { park[r * kBlock] = __float_as_uint(x); };
+        auto get_cached = [&]() { if constexpr (PARK) return f3(row_f(kParkCachedX), row_f(kParkCachedY), row_f(kParkCachedZ)); else return cached_r; };
+        auto set_cached = [&](F3 c) { if constexpr (PARK) { put_f(kParkCachedX, c.x); put_f(kParkCachedY, c.y); put_f(kParkCachedZ, c.z); } else cached_r = c; };
+        auto get_sample = [&]() { if constexpr (PARK) return park[kParkSample * kBlock]; else return s_r; };
+        auto set_sample = [&](uint32_t s) { if constexpr (PARK) park[kParkSample * kBlock] = s; else s_r = s; };
+        uint4 texel;
+        {
+            const size_t pix = (size_t)py * W + px;
+            texel = reinterpret_cast<const uint4*>(kp.fr.rng)[pix];       // r, g, b, a
+            const float4 acc = reinterpret_cast<const float4*>(kp.fr.accum)[pix];
+            const float u = (float)px / (float)W;                               // no sub-pixel jitter (B-2)
+            const float v = (float)(py % kp.view_height) / (float)kp.view_height;      // one view: view_height == H
+            set_cached(f3(acc.x, acc.y, acc.z));
+            set_sample(0u);
+            if constexpr (PARK) { put_f(kParkU, u); put_f(kParkV, v); park[kParkPx * kBlock] = px; park[kParkPy * kBlock] = py; }
+            else { u_r = u; v_r = v; pix_r = pix; }
+        }
 
         PathState ps;
         Pcg rng;
-        uint32_t s = 0;
         uint64_t state_after_cast = 0;       // SOBOL: the sampler draws from a copy, the texel keeps this (SobolSampler.hh:50)
         // castRay, then (SOBOL) the sampler of this frame: Render.metal:527-530
-        auto begin_sample = [&]() {
+        auto begin_sample = [&](uint32_t s) {
+            const float u = PARK ? row_f(kParkU) : u_r, v = PARK ? row_f(kParkV) : v_r;
             path_begin(ps, cast_ray(kp.cam, u, v, rng), kp.max_depth);
             if (SOBOL) {
                 state_after_cast = rng.state;
@@ -79,7 +103,7 @@ __device__ __forceinline__ void render_block(const KRender& kp, const DScene& sc
             // words trade roles every frame (Render.metal:516-519,545-557, B-1)
             rng.state = ((uint64_t)texel.z << 32) | texel.w;
             rng.inc = ((uint64_t)texel.x << 32) | texel.y;
-            begin_sample();
+            begin_sample(0u);
         }
         // end of a sample: accumulate, hand the RNG words back to the texel, start the next sample (or stop)
         auto finish_sample = [&](F3 color) {
@@ -87,18 +111,27 @@ __device__ __forceinline__ void render_block(const KRender& kp, const DScene& sc
             const bool bad = is_inf(color.x) || is_nan(color.x) || is_inf(color.y) || is_nan(color.y) ||
                              is_inf(color.z) || is_nan(color.z);
             if (bad) color = f3(0);                                         // :537-538
+            uint32_t s = get_sample();
             const uint32_t frame = kp.frame0 + s;
-            cached = div_shared(cached * (float)frame + color, (float)(frame + 1));  // running mean, :540-541
+            set_cached(div_shared(get_cached() * (float)frame + color, (float)(frame + 1)));  // running mean, :540-541
             if (SOBOL) rng.state = state_after_cast;
-            texel.y = (uint32_t)rng.state; texel.x = (uint32_t)(rng.state >> 32);
-            texel.w = (uint32_t)rng.inc;   texel.z = (uint32_t)(rng.inc >> 32);
-            n_paths++;
-            if (++s == kp.spp) {
+            // PARK: the texel is not carried through the loop -- the last sample's write-back is the RNG's own words (below)
+            if constexpr (!PARK) {
+                texel.y = (uint32_t)rng.state; texel.x = (uint32_t)(rng.state >> 32);
+                texel.w = (uint32_t)rng.inc;   texel.z = (uint32_t)(rng.inc >> 32);
+                n_paths++;
+            }
+            ++s;
+            set_sample(s);
+            if (s == kp.spp) {
                 alive = false;
             } else {
-                rng.state = ((uint64_t)texel.z << 32) | texel.w;
-                rng.inc = ((uint64_t)texel.x << 32) | texel.y;
-                begin_sample();
+                if constexpr (PARK) { const uint64_t t = rng.state; rng.state = rng.inc; rng.inc = t; }      // the words trade roles (B-1)
+                else {
+                    rng.state = ((uint64_t)texel.z << 32) | texel.w;
+                    rng.inc = ((uint64_t)texel.x << 32) | texel.y;
+                }
+                begin_sample(s);
             }
         };
         // flat loop: one Scene::hit per iteration; a finished path immediately regenerates the next sample
@@ -108,9 +141,11 @@ __device__ __forceinline__ void render_block(const KRender& kp, const DScene& sc
             constexpr int kDefer = STATS ? 0 : (LDS ? TRC_DEFER_LDS : TRC_DEFER_GLOBAL);      // dev_intersect.hpp: trav_test_leaf
             bool hitted = true;
             if (!(kVolume && TRC_TRACK_SLICE > 0 && ps.tracking)) {       // a lane between two slices of its delta tracker has no ray to trace
-                n_rays++;
+                bump(n_rays);
+                if constexpr (PARK && TRC_PARK_WALK) { put_f(kParkRatioX, ps.ratio.x); put_f(kParkRatioX + 1, ps.ratio.y); put_f(kParkRatioX + 2, ps.ratio.z); }
                 hitted = scene_hit<LDS, STATS, false, false, kVolume, HYB, kDefer>(cx.S, cx.root_min, cx.root_max, ps.ray, ps.rec, FLT_MAX,
                                                                                   cx.stack, cx.lvstack, cnt);
+                if constexpr (PARK && TRC_PARK_WALK) ps.ratio = f3(row_f(kParkRatioX), row_f(kParkRatioX + 1), row_f(kParkRatioX + 2));
             }
             F3 color;
             const bool finished = (INTEGRATOR == TRC_INTEGRATOR_PATH)
@@ -118,6 +153,13 @@ __device__ __forceinline__ void render_block(const KRender& kp, const DScene& sc
                                       : mis_step<LDS, STATS, kVolume, SOBOL, HYB>(cx, ps, hitted, rng, cnt, n_rays, n_shaded, color);
             if (finished) finish_sample(color);
         }
+        if constexpr (PARK) {       // the loop is left by the last finish_sample only (trc_render launches spp >= 1): what that one would
+            n_paths += kp.spp;      // have put into the texel, and one finished sample per call of it
+            texel.y = (uint32_t)rng.state; texel.x = (uint32_t)(rng.state >> 32);
+            texel.w = (uint32_t)rng.inc;   texel.z = (uint32_t)(rng.inc >> 32);
+        }
+        const F3 cached = get_cached();
+        const size_t pix = PARK ? (size_t)park[kParkPy * kBlock] * W + park[kParkPx * kBlock] : pix_r;
         float4 out; out.x = cached.x; out.y = cached.y; out.z = cached.z; out.w = 1.0f;
         reinterpret_cast<float4*>(kp.fr.accum)[pix] = out;
         reinterpret_cast<uint4*>(kp.fr.rng)[pix] = texel;
@@ -141,8 +183,8 @@ __device__ __forceinline__ void render_workgroup(const KRender& kp) {
     TravCounters cnt;
     counters_zero(cnt);
     constexpr bool kHybridStack = !LDS && !STATS && hybrid_stack(INTEGRATOR);     // plan_launch_lds
-    uint32_t* ovf = kHybridStack ? kp.stack_ovf + (size_t)blockIdx.x * (sc.stack_depth - sc.stack_lds) * kBlock + lane : nullptr;
-    render_block<LDS, STATS, INTEGRATOR, SOBOL, kHybridStack>(kp, sc, small_base, stack, lvstack, ovf, blockIdx.x, lane, n_rays, n_shaded, n_paths, cnt);
+    uint32_t* ovf = kHybridStack ? kp.stack_ovf + (size_t)blockIdx.x * sc.stack_ovf_rows * kBlock + lane : nullptr;
+    render_block<LDS, STATS, INTEGRATOR, SOBOL, kHybridStack>(kp, sc, small_base, stack, lvstack, ovf, nullptr, blockIdx.x, lane, n_rays, n_shaded, n_paths, cnt);
 
     // exact work counters: wave reduction, one 64-bit atomic per wave and counter
     uint32_t r_paths = wave_sum(n_paths), r_rays = wave_sum(n_rays), r_shaded = wave_sum(n_shaded);
@@ -200,20 +242,39 @@ __global__ void __launch_bounds__(64 * pwg_waves(INTEGRATOR), pwg_waves(INTEGRAT
     }
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     constexpr bool kHybridStack = hybrid_stack(INTEGRATOR);
-    uint32_t* stack = trc_smem + sc.lds_dwords + wave * sc.stack_lds * kBlock + lane;
-    uint32_t* ovf = kHybridStack ? kp.stack_ovf + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * (sc.stack_depth - sc.stack_lds) * kBlock + lane : nullptr;
-    uint32_t n_rays = 0, n_shaded = 0, n_paths = 0;
+    constexpr bool kPark = pwg_park(INTEGRATOR);
+    constexpr uint32_t kRows = kPark ? kParkRows : 0u;          // a wavefront's LDS: stack_lds stack rows, then the park rows (render_block)
+    uint32_t* stack = trc_smem + sc.lds_dwords + wave * (sc.stack_lds + kRows) * kBlock + lane;
+    uint32_t* park = stack + sc.stack_lds * kBlock;
+    uint32_t* ovf = kHybridStack ? kp.stack_ovf + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * sc.stack_ovf_rows * kBlock + lane : nullptr;
+    uint32_t n_paths = 0;
     TravCounters cnt;
     counters_zero(cnt);
     const uint32_t n_entries = kp.n_launch ? *kp.n_launch : kp.n_tiles;
-    for (;;) {
-        uint32_t slot = 0;
-        if (lane == 0) slot = atomicAdd(kp.queue, 1u);
-        slot = __builtin_amdgcn_readfirstlane(slot);
-        if (slot >= n_entries) break;
-        render_block<false, false, INTEGRATOR, SOBOL, kHybridStack>(kp, sc, trc_smem, stack, nullptr, ovf, slot, lane, n_rays, n_shaded, n_paths, cnt);
+    uint32_t r_rays, r_shaded;
+    if constexpr (kPark) {
+        park[kParkRays * kBlock] = 0u; park[kParkShaded * kBlock] = 0u;
+        LdsCount n_rays{park + kParkRays * kBlock}, n_shaded{park + kParkShaded * kBlock};
+        for (;;) {
+            uint32_t slot = 0;
+            if (lane == 0) slot = atomicAdd(kp.queue, 1u);
+            slot = __builtin_amdgcn_readfirstlane(slot);
+            if (slot >= n_entries) break;
+            render_block<false, false, INTEGRATOR, SOBOL, kHybridStack, true>(kp, sc, trc_smem, stack, nullptr, ovf, park, slot, lane, n_rays, n_shaded, n_paths, cnt);
+        }
+        r_rays = wave_sum(park[kParkRays * kBlock]); r_shaded = wave_sum(park[kParkShaded * kBlock]);
+    } else {
+        uint32_t n_rays = 0, n_shaded = 0;
+        for (;;) {
+            uint32_t slot = 0;
+            if (lane == 0) slot = atomicAdd(kp.queue, 1u);
+            slot = __builtin_amdgcn_readfirstlane(slot);
+            if (slot >= n_entries) break;
+            render_block<false, false, INTEGRATOR, SOBOL, kHybridStack>(kp, sc, trc_smem, stack, nullptr, ovf, nullptr, slot, lane, n_rays, n_shaded, n_paths, cnt);
+        }
+        r_rays = wave_sum(n_rays); r_shaded = wave_sum(n_shaded);
     }
-    uint32_t r_paths = wave_sum(n_paths), r_rays = wave_sum(n_rays), r_shaded = wave_sum(n_shaded);
+    const uint32_t r_paths = wave_sum(n_paths);
     if (lane == 0) {
         unsigned long long* const stats = stat_row(kp.stats, blockIdx.x * (blockDim.x >> 6) + wave);
         atomicAdd(&stats[kStatPaths], (unsigned long long)r_paths);
@@ -251,7 +312,7 @@ __global__ void __launch_bounds__(kBlock, INTEGRATOR == TRC_INTEGRATOR_VOLUME ? 
     PathCtx cx;
     cx.S = make_scene_ref(sc, small_base);
     constexpr bool kHybridStack = !LDS && hybrid_stack(INTEGRATOR);
-    if (kHybridStack) cx.S.ovf = kp.stack_ovf + (size_t)blockIdx.x * (sc.stack_depth - sc.stack_lds) * kBlock + lane;
+    if (kHybridStack) cx.S.ovf = kp.stack_ovf + (size_t)blockIdx.x * sc.stack_ovf_rows * kBlock + lane;
     cx.root_min = f3(kp.ks.root_box[0], kp.ks.root_box[1], kp.ks.root_box[2]);
     cx.root_max = f3(kp.ks.root_box[3], kp.ks.root_box[4], kp.ks.root_box[5]);
     cx.sh.mats = small_base + sc.off_materials;

@@ -106,6 +106,7 @@ inline void plan_lds(DScene& sc, uint32_t max_leaf_depth, bool prefix_ok) {
     sc.lds_dwords = sc.off_nodes + sc.n_lds_nodes * kNodeDwords;
     sc.stack_depth = std::max(1u, max_leaf_depth);
     sc.stack_lds = sc.stack_depth;
+    sc.stack_ovf_rows = 0;
 }
 
 // analytic primitives and materials into the blob (the fat nodes are written by the caller, the triangle records on the

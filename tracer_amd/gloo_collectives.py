@@ -30,6 +30,10 @@ class GlooCollectives:
                     ALLTOALL_FN(self._alltoall), GATHER_FN(self._gather))
         self.table = Collectives(None, 1, 0, *self._cb)
 
+    def _global(self, root):
+        """torch.distributed's dst= / src= are GLOBAL ranks; the table speaks of ranks of ITS group"""
+        return root if self._group is None else self._dist.get_global_rank(self._group, root)
+
     def _view(self, buf, count, dtype):
         return np.ctypeslib.as_array(C.cast(buf, C.POINTER(np.ctypeslib.as_ctypes_type(_NP[dtype]))), shape=(count,))
 
@@ -47,7 +51,7 @@ class GlooCollectives:
         try:
             a = self._view(buf, count, dtype)
             t, widened = self._tensor(a)
-            self._dist.reduce(t, dst=root, op=self._op(op), group=self._group)
+            self._dist.reduce(t, dst=self._global(root), op=self._op(op), group=self._group)
             if widened and self.rank == root:
                 a[:] = t.numpy().astype(a.dtype)
             self.calls["reduce"] += 1
@@ -88,15 +92,15 @@ class GlooCollectives:
             a = self._view(buf, bytes_per_rank * self.world, abi.DT_U8)
             send = [self._torch.from_numpy(a[r * bytes_per_rank:(r + 1) * bytes_per_rank].copy()) for r in range(self.world)]
             recv = [self._torch.empty(bytes_per_rank, dtype=self._torch.uint8) for _ in range(self.world)]
-            # gloo has no all_to_all: one all_gather per destination slice would move N times the data; pairwise send / recv
-            # in a fixed order (lower rank sends first) cannot deadlock
+            # gloo has no all_to_all: one all_gather per destination slice would move N times the data; every pair's send and
+            # receive are POSTED (isend / irecv) before anything is waited for, so no order of the ranks can deadlock
             reqs = []
             for p in range(self.world):
                 if p == self.rank:
                     recv[p] = send[p]
                     continue
-                reqs.append(self._dist.isend(send[p], dst=p, group=self._group))
-                reqs.append(self._dist.irecv(recv[p], src=p, group=self._group))
+                reqs.append(self._dist.isend(send[p], dst=self._global(p), group=self._group))
+                reqs.append(self._dist.irecv(recv[p], src=self._global(p), group=self._group))
             for q in reqs:
                 q.wait()
             for r, t in enumerate(recv):
@@ -112,7 +116,7 @@ class GlooCollectives:
             a = self._view(buf, bytes_per_rank * self.world, abi.DT_U8)
             mine = self._torch.from_numpy(a[self.rank * bytes_per_rank:(self.rank + 1) * bytes_per_rank].copy())
             parts = [self._torch.empty(bytes_per_rank, dtype=self._torch.uint8) for _ in range(self.world)] if self.rank == root else None
-            self._dist.gather(mine, parts, dst=root, group=self._group)
+            self._dist.gather(mine, parts, dst=self._global(root), group=self._group)
             if self.rank == root:
                 for r, t in enumerate(parts):
                     a[r * bytes_per_rank:(r + 1) * bytes_per_rank] = t.numpy()

@@ -174,16 +174,21 @@ class SocketGroup:
                     port, token_hex = read_published(self._file).split()
                     token = bytes.fromhex(token_hex)
                     s = socket.create_connection(("127.0.0.1", int(port)), timeout=5.0)
-                    s.settimeout(timeout_s)
+                    # the handshake gets seconds: a stale port file may name a port an unrelated listener holds by now, and a
+                    # wrong listener must cost one retry (the file is read again), not the run's whole timeout
+                    s.settimeout(10.0)
                     s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     theirs = bytes(_recv_exact(s, 16))
                     mine = secrets.token_bytes(16)
                     head = struct.pack("<8sII16s", _MAGIC, self.rank, self.world, mine)
                     s.sendall(head + _mac(token, head, theirs))
                     proof = bytes(_recv_exact(s, 32))
-                    if hmac.compare_digest(proof, _mac(token, b"rank0", mine)) and _recv(s) == b"go":
-                        self._hub = s
-                        break
+                    if hmac.compare_digest(proof, _mac(token, b"rank0", mine)):
+                        s.settimeout(max(10.0, deadline - time.monotonic()))      # rank 0 says "go" when EVERY rank has been admitted
+                        if _recv(s) == b"go":
+                            s.settimeout(timeout_s)
+                            self._hub = s
+                            break
                     s.close()
                 except (OSError, ValueError, ConnectionError):
                     if s is not None:
