@@ -38,8 +38,11 @@ extern "C" {
  *    no_cold_probe / probe_spp (the first launch of a block list runs as an 8-sample head + the rest, trc_render)
  * 5: sample sharding with a bit-level definition: trc_shard_seed, trc_group_compose_samples[_async]; trc_collectives grew
  *    (alltoall, gather); trc_group_allreduce_mean_accum is that compose delivered to every rank (rank-ordered sum, no longer an
- *    all-reduce); trc_device_pci_bus_id; the test hooks moved to include/tracer_test_hooks.h and libtracer_amd_hooks.so */
-#define TRC_ABI_VERSION 5
+ *    all-reduce); trc_device_pci_bus_id; the test hooks moved to include/tracer_test_hooks.h and libtracer_amd_hooks.so
+ * 6: launch lists may hold single-pixel parts (trc_debug_block_costs: bit 29; trc_launch_shape counts them as items); knob
+ *    camera_policy; trc_download_composed on a non-root rank of a sample-sharded compose returns TRC_ERR_NO_FRAME (it used to
+ *    hand out that rank's partial slices) */
+#define TRC_ABI_VERSION 6
 
 /* ------------------------------------------------------------------ */
 /* vector / matrix PODs (Apple simd layout)                            */
@@ -468,11 +471,12 @@ trc_status trc_reset_stats(trc_ctx* ctx);
 /* developer diagnostic: the pixel blocks of the last trc_render (x | y << 16, in units of the block edge 1 << *blk_shift)
  * and the duration each one's wavefront measured per sample (shader clocks / (4 spp) -- the sort key of the adaptive launch order); with
  * strips (spp < 8) the costs are per strip; a block that ran in parts (four 4x4 quarters, some of them as four 2x2
- * sixteenths) reports its slowest part with bit 31 set, and bit 30 when it had sixteenths.  Any pointer may be NULL; at most `capacity` entries are written. */
+ * sixteenths, some of those as four single pixels) reports its slowest part with bit 31 set, bit 30 when it had sixteenths and bit 29 when it
+ * had single pixels.  Any pointer may be NULL; at most `capacity` entries are written. */
 trc_status trc_debug_block_costs(trc_ctx* ctx, uint32_t* tiles, uint32_t* costs, uint32_t capacity, uint32_t* n_blocks, uint32_t* blk_shift);
 /* developer diagnostic: the two lower bounds of the last trc_render's kernel time that no schedule can beat.  A pixel's samples
  * are one chain through its RNG texel (Render.metal:545-557), so a launch lasts at least as long as its slowest wavefront-sized
- * item (a whole 8x8 block, or a 4x4 / 2x2 part of one) -- the bound a strong-scaled share of a frame runs into -- and at least
+ * item (a whole 8x8 block, or a 4x4 / 2x2 / single-pixel part of one) -- the bound a strong-scaled share of a frame runs into -- and at least
  * the items' summed durations over the wavefront slots of the GPU.  Durations are the wavefronts' own measurements (shader
  * clocks), converted with the device's nominal shader clock. */
 typedef struct trc_launch_shape {
@@ -610,7 +614,9 @@ trc_status trc_group_set_collectives(trc_ctx* ctx, const trc_collectives* table,
  * the shortest seen lately), "force_blk_shift" (k + 1 forces 2^k x 2^k pixel blocks per wavefront, k = 0..3: measurement only), and
  * "sppm_timing" (event pairs around an SPPM frame's photon pass and its hash / table / refine passes, added to
  * trc_stats.kernel_ms; one `launch` per frame), "descend_min" (n > 0: on trees read from memory the box-step loop of a wavefront goes on
- * while at least n lanes are still descending and others wait with a leaf; 0 = the scene's own value, 12, or 6 beyond 256 MiB).  They change scheduling / bookkeeping only, never a pixel.  Unknown name: TRC_ERR_INVALID_ARG. */
+ * while at least n lanes are still descending and others wait with a leaf; 0 = the scene's own value, 12, or 6 beyond 256 MiB), "camera_policy" (what trc_set_camera does with the recorded block costs: 0 = keeps them when the camera moved a little -- the view turned by
+ * at most 5 degrees and the eye moved by at most 5 % of the scene's diagonal: the next launch is one pass ordered by the last launch's raw durations -- and forgets them
+ * otherwise -- the next launch runs as a head + the rest; 1 always forgets, 2 always keeps the filtered costs, 3 always keeps and takes the raw durations: tools/moving_camera.py).  They change scheduling / bookkeeping only, never a pixel.  Unknown name: TRC_ERR_INVALID_ARG. */
 trc_status trc_debug_set(trc_ctx* ctx, const char* knob, int value);
 
 /* ------------------------------------------------------------------ */

@@ -177,6 +177,13 @@ def test_two_rank_bench_path_on_one_gpu(launcher):
     assert line["composed_crc_ok"] is True and line["oracle_check"]["golden"] == "config2"       # tiles: the one-GPU frame, bit for bit
     assert weak["composed_crc_ok"] is True and weak["oracle_check"]["golden"] == "config2_weak_N2"
     assert smp["composed_crc_ok"] is True and smp["oracle_check"]["golden"] == "config2_samples_S2"
+    assert line["transport"] == "table" and len(line["devices"]) == 2 and line["devices"][0] == line["devices"][1]   # one GPU, seen by both ranks
+    assert all(r["compose_ms"] is not None for r in line["per_rank"])   # the reduce really ran (host-staged)
+    # the cold leg and the parity-imposed bounds ride along for every rank
+    assert line["cold"]["settle_launches"] == 0 and line["first_launch_ms"] == line["cold"]["first_launch_ms"] > 0
+    assert line["config"]["settle_launches"] == 8
+    for r in line["per_rank"]:
+        assert 0 < r["longest_chain_ms"] and 0 < r["work_over_slots_ms"] and r["launch_entries"] >= 32400 // 2
 
 
 def _run_bench(args, env_extra=None, timeout=900):
@@ -222,13 +229,6 @@ def test_the_one_gpu_line_witnesses_every_baseline_config():
     assert s5["oracle_check"]["crc_ok"] is True and s5["oracle_check"]["totalPhotonSum_ok"] is True and s5["frames_per_step"] == 64
     assert line["hbm_point"]["target_frac"] == 0.40 and line["hbm_point"]["mrays"] > 1000
     assert line["hbm_point"]["target_met"] in (False, None)
-    assert line["transport"] == "table" and len(line["devices"]) == 2 and line["devices"][0] == line["devices"][1]   # one GPU, seen by both ranks
-    assert all(r["compose_ms"] is not None for r in line["per_rank"])   # the reduce really ran (host-staged)
-    # the cold leg and the parity-imposed bounds ride along for every rank
-    assert line["cold"]["settle_launches"] == 0 and line["first_launch_ms"] == line["cold"]["first_launch_ms"] > 0
-    assert line["config"]["settle_launches"] == 8
-    for r in line["per_rank"]:
-        assert 0 < r["longest_chain_ms"] and 0 < r["work_over_slots_ms"] and r["launch_entries"] >= 32400 // 2
 
 
 @pytest.mark.gpu

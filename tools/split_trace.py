@@ -22,5 +22,7 @@ for N in [int(x) for x in a.ranks.split(",")]:
             t.seed(0x5EED0000 + (i if a.vary_seed else 0)); t.reset_stats()
             t.render(spp=spp, integrator=wl["integrator"], tile_rank=0, tile_nranks=N); t.synchronize()
             _, costs, _ = t.block_costs()
-            out.append(f"{t.stats().kernel_ms:.2f}/{int((costs >> 31).sum())}/{int(((costs >> 30) & 1).sum())}")
-        print(f"N={N} {mode}: {len(costs)} blocks; kernel ms / blocks run in parts / of those with 2x2 sixteenths, per launch: " + " ".join(out))
+            sh = t.launch_shape()
+            out.append(f"{t.stats().kernel_ms:.2f}/{int((costs >> 31).sum())}/{int(((costs >> 30) & 1).sum())}/{int(((costs >> 29) & 1).sum())}"
+                       f"[{sh['entries']}:{sh['longest_entry_ms']:.1f}]")
+        print(f"N={N} {mode}: {len(costs)} blocks; kernel ms / blocks run in parts / of those with 2x2 sixteenths / with single pixels [items : longest item ms], per launch: " + " ".join(out))

@@ -7,7 +7,7 @@ Triangle,Texture,Material,Camera}.hh (see the header for file:line).
 """
 import ctypes as C
 
-TRC_ABI_VERSION = 5
+TRC_ABI_VERSION = 6
 TRC_TILE = 16
 TRC_MAX_BVH_DEPTH = 64
 TREE_SAH, TREE_TRIANGLE_LEAVES = 1, 2

@@ -341,7 +341,10 @@ TRC_DEV float grid_sample(const PathCtx& cx, const HitRec& rec, MediumHit& mi, P
         if (t >= tMax) break;
         const F3 p = rec.vol_o + rec.vol_d * t;
         // empty-space shortcut: a lookup whose 2x2x2 footprint lies in an all-zero brick interpolates zeros to +0 (a
-        // majorant-only "null collision"), so the 8 gathers and 7 lerps are skipped; the random number is still drawn
+        // majorant-only "null collision"), so the 8 gathers and 7 lerps are skipped; the random number is still drawn.
+        // (Round 6 also skipped the LOOKUP for the steps a ray certainly stays inside an empty brick -- exit distance worked out
+        // once per brick: profiles/r06/exp_empty_runs.patch.  Same bits, +1.6 .. +4.8 %: the brick byte is an L1 hit, the extra
+        // divergent branch and the exit arithmetic are not free.  Removed.)
         float dens = 0.0f;
         {
             const int ix = grid_to_int(floorf(p.x * (float)info.nx - 0.5f)), iy = grid_to_int(floorf(p.y * (float)info.ny - 0.5f)),

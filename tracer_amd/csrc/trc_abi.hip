@@ -1193,7 +1193,35 @@ trc_status trc_set_camera(trc_ctx* ctx, const trc_Camera* c) {
     d.lenRadius = c->lenRadius;
     // another view: the blocks' recorded costs are another picture's (the next launch measures afresh: trc_render's head)
     // (the old view's launch order survives as a PRIOR for the head of the next launch: a camera usually moves a little)
-    if (!ctx->has_camera || std::memcmp(&before, &d, sizeof d) != 0) { if (ctx->cost_valid) ctx->d_stale_order = ctx->d_last_order; ctx->cost_valid = false; ctx->d_last_order = nullptr; }
+    // Round 6 (tools/moving_camera.py, profiles/r06/moving_camera.txt): a camera that moves a LITTLE -- a drag, frame after frame -- keeps the
+    // recorded costs: the next launch is ordered and planned by them as one pass, taking the last launch's RAW durations (the filter follows
+    // a block that got heavier by 1.6 % per launch only).  Under a camera that moves 0.5 degrees per frame that costs 4-8 % over a settled
+    // launch where forgetting the costs (head + rest on every view) costs 8-24 %.  A camera that JUMPS -- the view direction turns by more
+    // than 5 degrees or the eye moves by more than 5 % of the scene's diagonal -- looks at another picture: the costs are forgotten as before.
+    // Knob camera_policy: 0 = this rule, 1 = always forget, 2 = always keep (filtered costs), 3 = always keep (raw durations).
+    if (!ctx->has_camera || std::memcmp(&before, &d, sizeof d) != 0) {
+        auto centre = [](const DCamera& c, float out[3]) {      // direction of the view's centre ray
+            float n = 0.0f;
+            for (int k = 0; k < 3; ++k) { out[k] = c.cornerLowLeft[k] + 0.5f * c.horizontal[k] + 0.5f * c.vertical[k] - c.lookFrom[k]; n += out[k] * out[k]; }
+            n = n > 0.0f ? 1.0f / std::sqrt(n) : 0.0f;
+            for (int k = 0; k < 3; ++k) out[k] *= n;
+        };
+        bool small = false;
+        if (ctx->has_camera && ctx->has_scene) {
+            float a[3], b[3], cosang = 0.0f, shift = 0.0f, diag = 0.0f;
+            centre(before, a); centre(d, b);
+            for (int k = 0; k < 3; ++k) {
+                cosang += a[k] * b[k];
+                shift += (d.lookFrom[k] - before.lookFrom[k]) * (d.lookFrom[k] - before.lookFrom[k]);
+                diag += (ctx->ks.root_box[3 + k] - ctx->ks.root_box[k]) * (ctx->ks.root_box[3 + k] - ctx->ks.root_box[k]);
+            }
+            small = cosang >= 0.9961947f /* cos 5 degrees */ && shift <= 0.0025f * diag;
+        }
+        const int policy = ctx->knobs.camera_policy;
+        const bool keep = ctx->cost_valid && (policy == 0 ? small : policy >= 2);
+        if (keep) { ctx->plan_streak = 0; ctx->cost_fresh_next = policy != 2; }
+        else { if (ctx->cost_valid) ctx->d_stale_order = ctx->d_last_order; ctx->cost_valid = false; ctx->d_last_order = nullptr; }
+    }
     ctx->has_camera = true;
     return TRC_OK;
 }
@@ -1532,7 +1560,8 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
         hipEvent_t s0 = get_event(ctx), s1 = get_event(ctx);
         if (s0) (void)hipEventRecord(s0, ctx->stream);
         hipLaunchKernelGGL(k_order_keys, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_block_cost, costs, ctx->d_split, ctx->d_whole, ctx->d_qsplit,
-                           kp.cost_stride, n, ctx->d_order_keys[0], ctx->d_order_vals[0], filtered, ctx->cost_head_age == 2);
+                           kp.cost_stride, n, ctx->d_order_keys[0], ctx->d_order_vals[0], filtered, ctx->cost_head_age == 2 || ctx->cost_fresh_next);
+        ctx->cost_fresh_next = false;
         int res = 0;
         trc_sort_pairs24(ctx->stream, ctx->d_order_keys, ctx->d_order_vals, ctx->d_order_hist, ctx->d_order_hist + trc_sort_hist_words(n), n, &res);
         kp.order = ctx->d_order_vals[res];
@@ -2195,7 +2224,8 @@ trc_status trc_debug_set(trc_ctx* ctx, const char* knob, int value) {
               : k == "sppm_serial_camera" ? &ctx->knobs.sppm_serial_camera : k == "sppm_timing" ? &ctx->knobs.sppm_timing
               : k == "force_blk_shift" ? &ctx->knobs.force_blk_shift : k == "no_split" ? &ctx->knobs.no_split : k == "no_cost_filter" ? &ctx->knobs.no_cost_filter
               : k == "no_cold_probe" ? &ctx->knobs.no_cold_probe : k == "probe_spp" ? &ctx->knobs.probe_spp
-              : k == "no_plan_reuse" ? &ctx->knobs.no_plan_reuse : k == "no_coalesce" ? &ctx->knobs.no_coalesce : k == "no_dense" ? &ctx->knobs.no_dense : k == "head_stages" ? &ctx->knobs.head_stages : k == "descend_min" ? &ctx->knobs.descend_min : nullptr;
+              : k == "no_plan_reuse" ? &ctx->knobs.no_plan_reuse : k == "no_coalesce" ? &ctx->knobs.no_coalesce : k == "no_dense" ? &ctx->knobs.no_dense : k == "head_stages" ? &ctx->knobs.head_stages : k == "descend_min" ? &ctx->knobs.descend_min
+              : k == "camera_policy" ? &ctx->knobs.camera_policy : nullptr;
     if (!slot) return fail(ctx, TRC_ERR_INVALID_ARG, "trc_debug_set: unknown knob " + k);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // a launch in flight keeps the plan it was made with

@@ -183,6 +183,7 @@ struct trc_ctx {
     uint32_t last_cost_div = 0, last_wave_slots = 0;     // of the last render launch (trc_debug_launch_shape)
     trc_params deferred{}; bool has_deferred = false; uint64_t deferred_calls = 0;   // a launch of few samples kept for coalescing (trc_render)
     int cost_head_age = 0;                    // 1: the costs are a cold head's (trc_render), 2: the launch after it ran on them
+    bool cost_fresh_next = false;             // the next ordered launch takes the last launch's raw durations as its costs (trc_set_camera, policy 2)
     uint32_t cost_integrator = 0xFFFFFFFFu;   // integrator the recorded costs belong to
     const uint32_t* d_stale_order = nullptr;     // the launch order of the view before the camera moved: the next cold pass's prior
     const uint32_t* d_last_order = nullptr; uint32_t order_age = 0;     // most recent sorted order (short launches reuse it)
@@ -226,7 +227,7 @@ struct trc_ctx {
 
     // A/B and test knobs, per context: defaults from the environment at trc_create (TRC_NO_LDS_FIT, TRC_STACK_LDS_LEVELS,
     // TRC_STRIP_LEN, TRC_NO_PWG, TRC_SPPM_SERIAL_CAMERA), changed through trc_debug_set
-    struct Knobs { int no_lds_fit = 0, stack_lds_levels = 0, strip_len = 0, no_pwg = 0, sppm_serial_camera = 0, sppm_timing = 0, force_blk_shift = 0, no_split = 0, no_cost_filter = 0, no_cold_probe = 0, probe_spp = 0, no_plan_reuse = 0, no_coalesce = 0, no_dense = 0, head_stages = 0, descend_min = 0; } knobs;
+    struct Knobs { int no_lds_fit = 0, stack_lds_levels = 0, strip_len = 0, no_pwg = 0, sppm_serial_camera = 0, sppm_timing = 0, force_blk_shift = 0, no_split = 0, no_cost_filter = 0, no_cold_probe = 0, probe_spp = 0, no_plan_reuse = 0, no_coalesce = 0, no_dense = 0, head_stages = 0, descend_min = 0, camera_policy = 0; } knobs;
     // k_render_pwg instantiations that were granted > 64 KB of dynamic LDS on THIS context's device (bit = integrator * 2 +
     // sobol): hipFuncSetAttribute applies to the current device only, so the grant is per context, not per process
     uint32_t pwg_lds_granted = 0;

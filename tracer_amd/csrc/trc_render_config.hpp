@@ -87,18 +87,14 @@ constexpr bool hybrid_stack(int integrator) {
 #endif
 constexpr int pwg_waves(int integrator) { return integrator == TRC_INTEGRATOR_PATH ? TRC_PWG_WAVES_PATH : (integrator == TRC_INTEGRATOR_MIS ? TRC_PWG_WAVES_MIS : TRC_PWG_WAVES_VOLUME); }
 // entries of a lane's traversal stack that live in LDS in a persistent-workgroup launch (deeper ones: global rows, dev_intersect.hpp
-// stack_put); what the stacks leave of the workgroup's LDS share is node prefix.  tracePath 16 (4 / 8 / 16: 33.5 / 31.1 / 30.8 ms in round
-// 2; 12 / 16 alike now); traceMIS 8 (6 / 8 / 10 / 12 / 16: 41.7 / 40.1 / 40.2 / 40.4 / 41.0 ms per 32-spp launch of config 3, 294.4
+// stack_push); what the stacks leave of the workgroup's LDS share is node prefix.  tracePath 10 beside its park rows (round 6: 6 / 8 / 10:
+// 23.2 / 22.1 / 21.9 ms per 32-spp launch of config 4; 16 without park rows: 22.6); traceMIS 8 (6 / 8 / 10 / 12 / 16: 41.7 / 40.1 / 40.2 / 40.4 / 41.0 ms per 32-spp launch of config 3, 294.4
 // against 300.5 ms as named: its shadow rays walk with one entry per level and its 16 x 2 workgroups get 48 KB of prefix instead of 16)
 // PARK (round 6, trc_render_kernels.hpp::render_block): kParkRows words of a lane's LDS column hold the values that are touched only
 // where a sample begins or ends (running mean, (u, v), pixel coordinates, sample counter) and the two work counters, so that they are
 // not carried -- and spilled to scratch -- through the walk and the shading code of every iteration.  Paid for with stack entries:
 // tracePath keeps 10 instead of 16 in LDS (deeper ones: the global rows) and most of its node prefix goes (profiles/r06/ab_park_*.txt).
-#ifndef TRC_PARK_WALK
-#define TRC_PARK_WALK 0      // A/B: the path's throughput (3 values) also leaves the registers for the duration of the walk
-#endif
-enum : uint32_t { kParkCachedX = 0, kParkCachedY, kParkCachedZ, kParkU, kParkV, kParkPx, kParkPy, kParkSample, kParkRays, kParkShaded,
-                  kParkRatioX, kParkRows = TRC_PARK_WALK ? kParkRatioX + 3 : kParkRatioX };
+enum : uint32_t { kParkCachedX = 0, kParkCachedY, kParkCachedZ, kParkU, kParkV, kParkPx, kParkPy, kParkSample, kParkRays, kParkShaded, kParkRows };
 #ifndef TRC_PARK_PATH
 #define TRC_PARK_PATH 1
 #endif

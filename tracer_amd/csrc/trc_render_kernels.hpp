@@ -142,10 +142,8 @@ __device__ __forceinline__ void render_block(const KRender& kp, const DScene& sc
             bool hitted = true;
             if (!(kVolume && TRC_TRACK_SLICE > 0 && ps.tracking)) {       // a lane between two slices of its delta tracker has no ray to trace
                 bump(n_rays);
-                if constexpr (PARK && TRC_PARK_WALK) { put_f(kParkRatioX, ps.ratio.x); put_f(kParkRatioX + 1, ps.ratio.y); put_f(kParkRatioX + 2, ps.ratio.z); }
                 hitted = scene_hit<LDS, STATS, false, false, kVolume, HYB, kDefer>(cx.S, cx.root_min, cx.root_max, ps.ray, ps.rec, FLT_MAX,
                                                                                   cx.stack, cx.lvstack, cnt);
-                if constexpr (PARK && TRC_PARK_WALK) ps.ratio = f3(row_f(kParkRatioX), row_f(kParkRatioX + 1), row_f(kParkRatioX + 2));
             }
             F3 color;
             const bool finished = (INTEGRATOR == TRC_INTEGRATOR_PATH)
