@@ -33,6 +33,14 @@ are reported under "other_scaling"):
       tile ranks.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the roofline definitions).
+
+Self-validation (round 6): the frame the timed steps rendered / composed is downloaded once, OUTSIDE the timed region, and its CRC32 (at
+N = 1 also the ray count) is held to the CPU oracle's committed value for that frame (tests/golden/bench_goldens.json, written by
+tests/golden/make_bench_goldens.py): `composed_crc_ok`; false ends the run non-zero after the line.  At N = 1 the line also carries
+`other_configs` -- BASELINE configs 3, 4, 5, the traceVolume scene and the 4 M-triangle HBM operating point, two timed steps each on a
+context of its own, each frame checked the same way, each with the roofline of its kernel's committed PMC summary -- and `hbm_point`
+(north_star's ">= 40 % of the HBM roofline" at the one operating point where it can be asked: not met).  Optional legs never take the
+headline down: each runs inside try / except and under a watchdog.
 """
 import argparse
 import hashlib

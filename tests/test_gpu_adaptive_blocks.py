@@ -174,3 +174,30 @@ def test_filtered_costs_change_the_schedule_not_the_pixels(gpu, cornell_spheres)
         gpu.debug_set("no_cost_filter", 0)
     with pytest.raises(Exception):
         gpu.debug_set("no_such_knob", 1)
+
+
+@pytest.mark.parametrize("policy", [0, 1, 2, 3])
+def test_a_moving_camera_changes_the_schedule_not_the_pixels(gpu, cornell_spheres, policy):
+    """trc_set_camera keeps the recorded block costs when the camera moved a little (knob camera_policy 0: the shipped rule; 1 always
+    forgets, 2 / 3 always keep: tools/moving_camera.py) -- the next launch is then ordered and split by another view's costs.  Small
+    steps, a jump, small steps again: every frame equals the plain launch of the same view, RNG texture and ray count included."""
+    import math
+    W, H, spp = 640, 360, 16
+    gpu.upload_scene(cornell_spheres.view); gpu.set_environment((0.2, 0.3, 0.4)); gpu.resize(W, H)
+    gpu.debug_set("camera_policy", policy)
+    try:
+        def view(deg):
+            r = math.radians(deg)
+            eye = (278 + 1078 * math.sin(r), 278, 278 - 1078 * math.cos(r))
+            gpu.set_camera(host.make_camera(eye, (278, 278, 278), (0, 1, 0), 0.0, W / H, math.radians(45), 10.0))
+        view(0.0)
+        for k in range(3):
+            _launch(gpu, 40 + k, spp=spp)                       # costs of the first view settle
+        for k, deg in enumerate([0.5, 1.0, 1.5, 40.0, 40.5, 41.0]):      # drags, a jump, drags
+            view(deg)
+            got = _launch(gpu, 50 + k, spp=spp)
+            view(deg)                                           # (the same camera again: nothing is forgotten, nothing changes)
+            plain = _launch(gpu, 50 + k, spp=spp, small_blocks=False, fixed_order=True)
+            assert _same(got, plain), (policy, deg)
+    finally:
+        gpu.debug_set("camera_policy", 0)

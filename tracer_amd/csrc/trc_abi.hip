@@ -100,8 +100,8 @@ trc_status trc_repack_triangles(trc_ctx* ctx, const trc_scene* s, const DScene& 
     if (hipMalloc((void**)&d_idx, (size_t)s->n_index * 4) != hipSuccess) { (void)hipFree(d_verts); return trc_fail(ctx, TRC_ERR_OOM, "hipMalloc triangle indices"); }
     trc_status st = TRC_OK;
     do {
-        if (hipMemcpyAsync(d_verts, s->triList, (size_t)s->n_vertex * sizeof(trc_TriangleVertex), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-            hipMemcpyAsync(d_idx, s->idxList, (size_t)s->n_index * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { st = trc_fail(ctx, TRC_ERR_HIP, "H2D triangles"); break; }
+        if (trc_copy_to_device(ctx, d_verts, s->triList, (size_t)s->n_vertex * sizeof(trc_TriangleVertex), ctx->stream) != TRC_OK ||
+            trc_copy_to_device(ctx, d_idx, s->idxList, (size_t)s->n_index * 4, ctx->stream) != TRC_OK) { st = trc_fail(ctx, TRC_ERR_HIP, "H2D triangles"); break; }
         hipLaunchKernelGGL(k_repack_triangles, dim3((n_tri + 255) / 256), dim3(256), 0, ctx->stream, d_verts, d_idx, n_tri,
                            reinterpret_cast<float4*>(d_blob + sc.off_tripos), reinterpret_cast<float4*>(d_blob + sc.off_triattr));
         if (d_tri_leaves) hipLaunchKernelGGL(k_triangle_leaves, dim3((n_tri + 255) / 256), dim3(256), 0, ctx->stream, d_verts, d_idx, n_tri, d_tri_leaves);
@@ -751,6 +751,49 @@ bool trc_load_rccl(std::string& err) {
     return true;
 }
 
+// ----------------------------------------------------------------------- transfers through pinned staging (trc_ctx.hpp)
+static trc_status xfer_ready(trc_ctx* ctx) {
+    if (ctx->h_xfer) return TRC_OK;
+    HIP_TRY(ctx, hipHostMalloc((void**)&ctx->h_xfer, 2 * kXferChunk, hipHostMallocDefault));
+    for (hipEvent_t& e : ctx->ev_xfer) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return TRC_OK;
+}
+trc_status trc_copy_to_host(trc_ctx* ctx, void* host, const void* dev, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return TRC_OK;
+    { const trc_status rs = xfer_ready(ctx); if (rs != TRC_OK) return rs; }
+    size_t prev_off = 0, prev_n = 0;
+    int slot = 0;
+    for (size_t off = 0; off < bytes; off += kXferChunk, slot ^= 1) {
+        const size_t n = std::min(kXferChunk, bytes - off);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_xfer + slot * kXferChunk, static_cast<const char*>(dev) + off, n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_xfer[slot], st));
+        if (prev_n) {                                     // the chunk before, while this one is on its way
+            HIP_TRY(ctx, hipEventSynchronize(ctx->ev_xfer[slot ^ 1]));
+            std::memcpy(static_cast<char*>(host) + prev_off, ctx->h_xfer + (slot ^ 1) * kXferChunk, prev_n);
+        }
+        prev_off = off; prev_n = n;
+    }
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev_xfer[slot ^ 1]));
+    std::memcpy(static_cast<char*>(host) + prev_off, ctx->h_xfer + (slot ^ 1) * kXferChunk, prev_n);
+    return TRC_OK;
+}
+trc_status trc_copy_to_device(trc_ctx* ctx, void* dev, const void* host, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return TRC_OK;
+    { const trc_status rs = xfer_ready(ctx); if (rs != TRC_OK) return rs; }
+    int slot = 0;
+    bool used[2] = {false, false};
+    for (size_t off = 0; off < bytes; off += kXferChunk, slot ^= 1) {
+        const size_t n = std::min(kXferChunk, bytes - off);
+        if (used[slot]) HIP_TRY(ctx, hipEventSynchronize(ctx->ev_xfer[slot]));       // the copy that last read this half has finished
+        std::memcpy(ctx->h_xfer + slot * kXferChunk, static_cast<const char*>(host) + off, n);
+        HIP_TRY(ctx, hipMemcpyAsync(static_cast<char*>(dev) + off, ctx->h_xfer + slot * kXferChunk, n, hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_xfer[slot], st));
+        used[slot] = true;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return TRC_OK;
+}
+
 static size_t dyn_lds_bytes(const DScene& sc, bool stats) {
     size_t dwords = sc.lds_dwords + (size_t)sc.stack_lds * kBlock * (stats ? 2u : 1u);
     return dwords * 4;
@@ -851,7 +894,7 @@ trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32
             HIP_TRY(ctx, hipMalloc((void**)&ctx->d_order_vals[k], tiles.size() * 4));
         }
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_order_hist, (trc_sort_hist_words(ctx->n_tiles) + 256) * 4));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_tiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        { const trc_status cs = trc_copy_to_device(ctx, ctx->d_tiles, tiles.data(), tiles.size() * 4, ctx->stream); if (cs != TRC_OK) return cs; }
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     ctx->tiles_nranks = nranks; ctx->tiles_rank = rank; ctx->tiles_view_height = view_height; ctx->tiles_blk_shift = blk_shift;
@@ -866,7 +909,7 @@ trc_status ensure_sobol_tables(trc_ctx* ctx, uint32_t m) {
         std::vector<uint32_t> m32(TRC_SOBOL_DIMS * TRC_SOBOL_MATRIX_SIZE);
         trc_sobol_matrices32(m32.data());
         if (!ctx->d_sobol32) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_sobol32, m32.size() * sizeof(uint32_t)));
-        HIP_TRY(ctx, hipMemcpy(ctx->d_sobol32, m32.data(), m32.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        { const trc_status cs = trc_copy_to_device(ctx, ctx->d_sobol32, m32.data(), m32.size() * sizeof(uint32_t), ctx->stream); if (cs != TRC_OK) return cs; }
         HIP_TRY(ctx, hipMalloc((void**)&ctx->d_sobol_vdc, 2 * TRC_SOBOL_MATRIX_SIZE * sizeof(uint64_t)));
         ctx->sobol_m = ~0u;
     }
@@ -1110,6 +1153,8 @@ void trc_destroy(trc_ctx* ctx) {
     (void)hipFree(ctx->d_shard_in); (void)hipFree(ctx->d_shard_out); (void)hipFree(ctx->d_shard_src);
     if (ctx->ev_snapshot_free) (void)hipEventDestroy(ctx->ev_snapshot_free);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    if (ctx->h_xfer) (void)hipHostFree(ctx->h_xfer);
+    for (hipEvent_t e : ctx->ev_xfer) if (e) (void)hipEventDestroy(e);
     if (ctx->h_readback) (void)hipHostFree(ctx->h_readback);
     for (hipEvent_t e : {ctx->ev_rendered, ctx->ev_busy, ctx->ev_busy_alt}) if (e) (void)hipEventDestroy(e);
     if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
@@ -1133,7 +1178,7 @@ trc_status trc_upload_scene(trc_ctx* ctx, const trc_scene* scene) {
     ctx->has_scene = false;
     ctx->blob_bytes = (size_t)blob_total * 4;
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_blob, ctx->blob_bytes));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_blob, blob.data(), blob.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    { const trc_status cs = trc_copy_to_device(ctx, ctx->d_blob, blob.data(), blob.size() * 4, ctx->stream); if (cs != TRC_OK) return cs; }
     { trc_status rs = trc_repack_triangles(ctx, scene, ks.sc, ctx->d_blob, nullptr); if (rs != TRC_OK) return rs; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ks.sc.blob = ctx->d_blob;
@@ -1158,7 +1203,7 @@ trc_status trc_upload_density(trc_ctx* ctx, const trc_GridDensityInfo* info, con
     const uint64_t count = (uint64_t)info->nx * info->ny * info->nz;
     if (count > (1ull << 31)) return fail(ctx, TRC_ERR_UNSUPPORTED, "trc_upload_density: more than 2^31 cells");
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_density, count * sizeof(float)));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_density, density, count * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    { const trc_status cs = trc_copy_to_device(ctx, ctx->d_density, density, count * sizeof(float), ctx->stream); if (cs != TRC_OK) return cs; }
     // occupancy of 4x4x4 bricks: brick b covers lookups whose base cell i = floor(p*n - 0.5) has (i + 1) >> 2 == b, i.e.
     // the cells 4b-1 .. 4b+3 and their +1 neighbours; nonzero = any of them holds a value other than +0
     const int nx = (int)info->nx, ny = (int)info->ny, nz = (int)info->nz;
@@ -1176,7 +1221,7 @@ trc_status trc_upload_density(trc_ctx* ctx, const trc_GridDensityInfo* info, con
                         for (int bx = x >> 2; bx <= (x + 1) >> 2; ++bx) occ[((size_t)bz * nby + by) * nbx + bx] = 1;
             }
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_occupancy, occ.size()));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_occupancy, occ.data(), occ.size(), hipMemcpyHostToDevice, ctx->stream));
+    { const trc_status cs = trc_copy_to_device(ctx, ctx->d_occupancy, occ.data(), occ.size(), ctx->stream); if (cs != TRC_OK) return cs; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->dinfo = *info;
     return TRC_OK;
@@ -1243,7 +1288,7 @@ trc_status trc_set_environment_map(trc_ctx* ctx, uint32_t w, uint32_t h, const f
     if (w == 0 || h == 0 || (uint64_t)w * h > (1ull << 28)) return fail(ctx, TRC_ERR_INVALID_ARG, "trc_set_environment_map: bad size");
     const size_t bytes = (size_t)w * h * 3 * sizeof(float);
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_envmap, bytes));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_envmap, rgb, bytes, hipMemcpyHostToDevice, ctx->stream));
+    { const trc_status cs = trc_copy_to_device(ctx, ctx->d_envmap, rgb, bytes, ctx->stream); if (cs != TRC_OK) return cs; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->env_w = w; ctx->env_h = h;
     return TRC_OK;
@@ -1293,8 +1338,7 @@ static trc_status copy_frame(trc_ctx* ctx, void* dev, void* host, bool to_device
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t bytes = (size_t)ctx->width * ctx->height * 16;
     trc_sppm_order_after_camera(ctx);
-    if (to_device) HIP_TRY(ctx, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
-    else HIP_TRY(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    { const trc_status cs = to_device ? trc_copy_to_device(ctx, dev, host, bytes, ctx->stream) : trc_copy_to_host(ctx, host, dev, bytes, ctx->stream); if (cs != TRC_OK) return cs; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     collect_events(ctx);
     return TRC_OK;
@@ -1341,7 +1385,7 @@ trc_status trc_tonemap(trc_ctx* ctx, uint8_t* rgba8, float* exposure_out) {
         if (exposure_out) *exposure_out = expose;
         hipLaunchKernelGGL(k_tonemap, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, reinterpret_cast<const float4*>(ctx->d_accum),
                            ctx->width, ctx->height, expose, d_out);
-        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(rgba8, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        if (hipGetLastError() != hipSuccess || trc_copy_to_host(ctx, rgba8, d_out, (size_t)n * 4, ctx->stream) != TRC_OK ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) { st = fail(ctx, TRC_ERR_HIP, "tonemap kernel"); break; }
     } while (0);
     (void)hipFree(d_sums); (void)hipFree(d_out);
@@ -1528,7 +1572,7 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
     // a whole frame's worth of blocks per wavefront slot: the LDS-resident tracePath kernel at one more wavefront per SIMD
     const bool dense = ctx->lds_scene && p->integrator == TRC_INTEGRATOR_PATH && !stats && !sobol && kp.strip == 1 && !ctx->knobs.no_dense &&
                        ctx->n_tiles >= (uint32_t)TRC_DENSE_MIN_BLOCKS_PER_SLOT * (uint32_t)ctx->cu_count * 4u * TRC_PATH_WAVES_DENSE &&
-                       dyn_lds_bytes(kp.ks.sc, false) * 4u * TRC_PATH_WAVES_DENSE <= 160u * 1024u;
+                       ((dyn_lds_bytes(kp.ks.sc, false) + (size_t)TRC_PARK_DENSE * kBlock * 4u + 511u) & ~(size_t)511u) * 4u * TRC_PATH_WAVES_DENSE <= 160u * 1024u;
     const uint32_t waves_per_simd = dense ? TRC_PATH_WAVES_DENSE : p->integrator == TRC_INTEGRATOR_PATH ? (ctx->lds_scene ? TRC_PATH_WAVES : TRC_PATH_WAVES_GLOBAL)
                                   : p->integrator == TRC_INTEGRATOR_MIS ? (ctx->lds_scene ? TRC_MIS_WAVES_LDS : TRC_MIS_WAVES) : TRC_VOLUME_WAVES;
     const uint32_t wave_slots = (uint32_t)ctx->cu_count * 4u * waves_per_simd;
@@ -1634,7 +1678,7 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
     }
 
     bool pwg = false;
-    uint32_t pwg_waves_n = 0, pwg_grid = 0, pwg_park_rows = 0;
+    uint32_t pwg_waves_n = 0, pwg_grid = 0, park_rows = dense ? (uint32_t)TRC_PARK_DENSE : 0u;      // LDS rows of parked per-pixel state (render_block)
     if (!stats && !ctx->lds_scene) {
         const bool strip = kp.strip > 1;
         const bool is_path = p->integrator == TRC_INTEGRATOR_PATH;
@@ -1642,8 +1686,9 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
         if (!ctx->knobs.no_pwg && !strip && ctx->lds_prefix_ok) {                       // no_pwg: A/B knob
             pwg_waves_n = (uint32_t)pwg_waves((int)p->integrator);
             const uint32_t per_cu = (uint32_t)pwg_per_cu((int)p->integrator);
-            pwg_park_rows = pwg_park((int)p->integrator) ? kParkRows : 0u;
-            pwg = plan_pwg_lds(ctx, kp.ks.sc, pwg_waves_n, per_cu, hybrid, pwg_stack_lds_levels((int)p->integrator), pwg_park_rows);
+            park_rows = pwg_park_rows((int)p->integrator);
+            pwg = plan_pwg_lds(ctx, kp.ks.sc, pwg_waves_n, per_cu, hybrid, pwg_stack_lds_levels((int)p->integrator), park_rows);
+            if (!pwg) park_rows = 0u;
             pwg_grid = std::min((uint32_t)ctx->cu_count * per_cu, (grid_cap + pwg_waves_n - 1) / pwg_waves_n);   // small frames: no idle workgroups
         }
         if (!pwg) {
@@ -1662,7 +1707,8 @@ static trc_status render_pass(trc_ctx* ctx, const trc_params* p, bool inner) {
         }
         kp.stack_ovf = ctx->d_stack_ovf;
     }
-    const size_t lds = pwg ? ((size_t)kp.ks.sc.lds_dwords + (size_t)pwg_waves_n * (kp.ks.sc.stack_lds + pwg_park_rows) * kBlock) * 4 : dyn_lds_bytes(kp.ks.sc, stats);
+    const size_t lds = pwg ? ((size_t)kp.ks.sc.lds_dwords + (size_t)pwg_waves_n * (kp.ks.sc.stack_lds + park_rows) * kBlock) * 4
+                           : dyn_lds_bytes(kp.ks.sc, stats) + (dense ? (size_t)park_rows * kBlock * 4 : 0u);
     if (pwg) {
         if (!ctx->d_queue && hipMalloc((void**)&ctx->d_queue, sizeof(uint32_t)) != hipSuccess) return fail(ctx, TRC_ERR_OOM, "hipMalloc block queue");
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(uint32_t), ctx->stream));
@@ -1710,7 +1756,7 @@ trc_status trc_trace_rays(trc_ctx* ctx, const trc_ray* rays, size_t n, trc_hit* 
     if (hipMalloc((void**)&d_hits, n * sizeof(trc_hit)) != hipSuccess) { (void)hipFree(d_rays); return fail(ctx, TRC_ERR_OOM, "hipMalloc hits"); }
     trc_status st = TRC_OK;
     do {
-        if (hipMemcpyAsync(d_rays, rays, n * sizeof(trc_ray), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { st = fail(ctx, TRC_ERR_HIP, "H2D rays"); break; }
+        if (trc_copy_to_device(ctx, d_rays, rays, n * sizeof(trc_ray), ctx->stream) != TRC_OK) { st = fail(ctx, TRC_ERR_HIP, "H2D rays"); break; }
         KTrace kp{};
         kp.ks = ctx->ks; kp.rays = d_rays; kp.hits = d_hits; kp.n = (uint32_t)n;
         const size_t lds = trc_dyn_lds_bytes(ctx, true);
@@ -1727,7 +1773,7 @@ trc_status trc_trace_rays(trc_ctx* ctx, const trc_ray* rays, size_t n, trc_hit* 
 #undef TRC_LAUNCH_TRACE
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { st = fail(ctx, TRC_ERR_HIP, std::string("k_trace launch: ") + hipGetErrorString(e)); break; }
-        if (hipMemcpyAsync(out, d_hits, n * sizeof(trc_hit), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { st = fail(ctx, TRC_ERR_HIP, "D2H hits"); break; }
+        if (trc_copy_to_host(ctx, out, d_hits, n * sizeof(trc_hit), ctx->stream) != TRC_OK) { st = fail(ctx, TRC_ERR_HIP, "D2H hits"); break; }
         e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { st = fail(ctx, TRC_ERR_HIP, std::string("k_trace: ") + hipGetErrorString(e)); break; }
     } while (0);
@@ -1787,10 +1833,10 @@ trc_status trc_debug_launch_shape(trc_ctx* ctx, trc_launch_shape* out) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t stride = ctx->cost_quarters ? kCostSlots : 1u;
     std::vector<uint32_t> c((size_t)n * stride), sp(n, 0u), qs((size_t)n * 4u, 0u);
-    HIP_TRY(ctx, hipMemcpy(c.data(), ctx->d_block_cost, c.size() * 4, hipMemcpyDeviceToHost));
+    { const trc_status cs = trc_copy_to_host(ctx, c.data(), ctx->d_block_cost, c.size() * 4, ctx->stream); if (cs != TRC_OK) return cs; }
     if (stride != 1u && ctx->split_live) {
-        HIP_TRY(ctx, hipMemcpy(sp.data(), ctx->d_split, (size_t)n * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(ctx, hipMemcpy(qs.data(), ctx->d_qsplit, (size_t)n * 16, hipMemcpyDeviceToHost));
+        { const trc_status cs = trc_copy_to_host(ctx, sp.data(), ctx->d_split, (size_t)n * 4, ctx->stream); if (cs != TRC_OK) return cs; }
+        { const trc_status cs = trc_copy_to_host(ctx, qs.data(), ctx->d_qsplit, (size_t)n * 16, ctx->stream); if (cs != TRC_OK) return cs; }
     }
     uint64_t sum = 0, longest = 0;
     uint32_t entries = 0;
@@ -1819,14 +1865,14 @@ trc_status trc_debug_block_costs(trc_ctx* ctx, uint32_t* tiles, uint32_t* costs,
     const uint32_t n = std::min(capacity, ctx->n_tiles);
     if (n == 0 || !ctx->d_tiles) return TRC_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (tiles) HIP_TRY(ctx, hipMemcpy(tiles, ctx->d_tiles, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (tiles) { const trc_status cs = trc_copy_to_host(ctx, tiles, ctx->d_tiles, (size_t)n * 4, ctx->stream); if (cs != TRC_OK) return cs; }
     if (costs) {
         const uint32_t stride = ctx->cost_quarters ? kCostSlots : 1u;
         std::vector<uint32_t> c((size_t)n * stride), sp(n, 0u), qs((size_t)n * 4u, 0u);
-        HIP_TRY(ctx, hipMemcpy(c.data(), ctx->d_block_cost, c.size() * 4, hipMemcpyDeviceToHost));
+        { const trc_status cs = trc_copy_to_host(ctx, c.data(), ctx->d_block_cost, c.size() * 4, ctx->stream); if (cs != TRC_OK) return cs; }
         if (stride != 1u) {
-            HIP_TRY(ctx, hipMemcpy(sp.data(), ctx->d_split, (size_t)n * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(ctx, hipMemcpy(qs.data(), ctx->d_qsplit, (size_t)n * 16, hipMemcpyDeviceToHost));
+            { const trc_status cs = trc_copy_to_host(ctx, sp.data(), ctx->d_split, (size_t)n * 4, ctx->stream); if (cs != TRC_OK) return cs; }
+            { const trc_status cs = trc_copy_to_host(ctx, qs.data(), ctx->d_qsplit, (size_t)n * 16, ctx->stream); if (cs != TRC_OK) return cs; }
         }
         for (uint32_t i = 0; i < n; ++i) {        // a block that ran in parts: its slowest part, bit 31 set (bit 30: some of them 2x2)
             const uint32_t* q = &c[(size_t)i * stride];
@@ -1848,18 +1894,18 @@ trc_status trc_div_by_test(trc_ctx* ctx, const float* a, const float* b, size_t 
     float* d = nullptr;
     HIP_TRY(ctx, hipMalloc((void**)&d, n * 8 * sizeof(float)));
     float *d_a = d, *d_b = d + n, *d_fast = d + 2 * n, *d_plain = d + 5 * n;
-    hipError_t e = hipMemcpyAsync(d_a, a, n * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_b, b, n * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) {
+    trc_status ts = trc_copy_to_device(ctx, d_a, a, n * 4, ctx->stream);
+    if (ts == TRC_OK) ts = trc_copy_to_device(ctx, d_b, b, n * 4, ctx->stream);
+    if (ts == TRC_OK) {
         hipLaunchKernelGGL(k_div_by_test, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_a, d_b, (uint32_t)n, d_fast, d_plain);
-        e = hipGetLastError();
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) ts = fail(ctx, TRC_ERR_HIP, std::string("trc_div_by_test: ") + hipGetErrorString(e));
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(fast, d_fast, n * 12, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(plain, d_plain, n * 12, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream); else (void)hipStreamSynchronize(ctx->stream);
+    if (ts == TRC_OK) ts = trc_copy_to_host(ctx, fast, d_fast, n * 12, ctx->stream);
+    if (ts == TRC_OK) ts = trc_copy_to_host(ctx, plain, d_plain, n * 12, ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(d);
-    if (e != hipSuccess) return fail(ctx, TRC_ERR_HIP, std::string("trc_div_by_test: ") + hipGetErrorString(e));
-    return TRC_OK;
+    return ts;
 }
 
 trc_status trc_unary_test(trc_ctx* ctx, uint32_t op, uint32_t first_bits, uint64_t count, uint64_t* n_mismatch, uint32_t* first_mismatch) {
@@ -2183,7 +2229,7 @@ trc_status trc_download_composed(trc_ctx* ctx, float* rgba) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->comm_stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->comm_stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(rgba, ctx->d_composed, (size_t)ctx->width * ctx->height * 16, hipMemcpyDeviceToHost));
+    { const trc_status cs = trc_copy_to_host(ctx, rgba, ctx->d_composed, (size_t)ctx->width * ctx->height * 16, ctx->stream); if (cs != TRC_OK) return cs; }
     return TRC_OK;
 }
 

@@ -224,6 +224,8 @@ struct trc_ctx {
     void* h_stage = nullptr;            // pinned staging buffer of host-staged collectives
     size_t h_stage_bytes = 0;
     uint32_t* h_readback = nullptr;     // 1 KB of pinned host memory for the per-level counter read-back of trc_upload_scene_sah
+    char* h_xfer = nullptr;             // 2 x kXferChunk bytes of pinned host memory: every transfer to / from caller memory goes through it (trc_copy_*)
+    hipEvent_t ev_xfer[2] = {nullptr, nullptr};
 
     // A/B and test knobs, per context: defaults from the environment at trc_create (TRC_NO_LDS_FIT, TRC_STACK_LDS_LEVELS,
     // TRC_STRIP_LEN, TRC_NO_PWG, TRC_SPPM_SERIAL_CAMERA), changed through trc_debug_set
@@ -276,6 +278,17 @@ constexpr int kNcclUint8 = 1, kNcclUint32 = 3, kNcclFloat = 7, kNcclSum = 0, kNc
 trc_status trc_coll_reduce(trc_ctx* ctx, void* buf, size_t count, int dtype, int op, int root, hipStream_t st, const char* what);
 trc_status trc_coll_allreduce(trc_ctx* ctx, void* buf, size_t count, int dtype, int op, hipStream_t st, const char* what);
 trc_status trc_coll_allgather(trc_ctx* ctx, void* buf, size_t bytes_per_rank, hipStream_t st, const char* what);
+
+// Transfers between device memory and memory the CALLER (or a std::vector of ours) owns.  They do not hand the host pointer to the HIP
+// runtime: a copy to / from pageable memory makes the runtime pin the caller's pages in place, and under many processes sharing the GPU a
+// D2H copy into freshly mapped pages was seen to leave whole ranges of the destination untouched -- zeros where the device buffer,
+// downloaded again, had the data (round 6: tests/campaigns/sppm_stress.py reproduced round 5's "unwritten photon records" 380 times in
+// 9 000 scenes, every one of them a transfer, none a kernel).  So the bytes go through the context's own pinned
+// buffer, two chunks of kXferChunk in flight, and are copied to / from the caller's memory by the CPU.  Synchronous: on return the
+// transfer is complete (`st` is synchronised up to it).
+constexpr size_t kXferChunk = 4u << 20;
+trc_status trc_copy_to_host(trc_ctx* ctx, void* host, const void* dev, size_t bytes, hipStream_t st);
+trc_status trc_copy_to_device(trc_ctx* ctx, void* dev, const void* host, size_t bytes, hipStream_t st);
 
 // tiles owned by `rank` of `nranks` (XCD-aware order) uploaded into ctx->d_tiles; shared by render and SPPM
 trc_status trc_ensure_tiles(trc_ctx* ctx, uint32_t nranks, uint32_t rank, uint32_t view_height = 0, uint32_t blk_shift = 3);

@@ -537,11 +537,11 @@ static trc_status upload_device_tree(trc_ctx* ctx, const trc_scene* s, bool sah,
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_blob, ctx->blob_bytes));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_bvh_ref, sizeof(trc_BVH) * n_nodes));
     hipStream_t st = ctx->stream;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_blob, blob.get(), (size_t)sc.off_nodes * 4, hipMemcpyHostToDevice, st));
+    { const trc_status cs = trc_copy_to_device(ctx, ctx->d_blob, blob.get(), (size_t)sc.off_nodes * 4, st); if (cs != TRC_OK) return cs; }
     // the caller's leaf records go straight to slots 1..n of the reference-layout array (BVH.hh:246-269), the triangles' behind them
     { trc_status rs = trc_repack_triangles(ctx, s, sc, ctx->d_blob, triangle_leaves ? ctx->d_bvh_ref + 1 + n_given : nullptr); if (rs != TRC_OK) return rs; }
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_bvh_ref, 0, sizeof(trc_BVH), st));
-    if (n_given) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_bvh_ref + 1, s->bvhList, sizeof(trc_BVH) * n_given, hipMemcpyHostToDevice, st));
+    if (n_given) { const trc_status cs = trc_copy_to_device(ctx, ctx->d_bvh_ref + 1, s->bvhList, sizeof(trc_BVH) * n_given, st); if (cs != TRC_OK) return cs; }
 
     Buffers buf;
     DLeaf* d_leaves; uint32_t *d_keys[2], *d_vals[2], *d_hist, *d_bounds, *d_height, *d_arrived;
@@ -686,7 +686,7 @@ trc_status trc_download_bvh(trc_ctx* ctx, trc_BVH* out, uint32_t capacity, uint3
     if (!out) return TRC_OK;
     if (capacity < ctx->n_bvh_ref) return trc_fail(ctx, TRC_ERR_INVALID_ARG, "trc_download_bvh: capacity too small");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_bvh_ref, sizeof(trc_BVH) * ctx->n_bvh_ref, hipMemcpyDeviceToHost, ctx->stream));
+    { const trc_status cs = trc_copy_to_host(ctx, out, ctx->d_bvh_ref, sizeof(trc_BVH) * ctx->n_bvh_ref, ctx->stream); if (cs != TRC_OK) return cs; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TRC_OK;
 }

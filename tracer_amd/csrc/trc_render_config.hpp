@@ -90,23 +90,30 @@ constexpr int pwg_waves(int integrator) { return integrator == TRC_INTEGRATOR_PA
 // stack_push); what the stacks leave of the workgroup's LDS share is node prefix.  tracePath 10 beside its park rows (round 6: 6 / 8 / 10:
 // 23.2 / 22.1 / 21.9 ms per 32-spp launch of config 4; 16 without park rows: 22.6); traceMIS 8 (6 / 8 / 10 / 12 / 16: 41.7 / 40.1 / 40.2 / 40.4 / 41.0 ms per 32-spp launch of config 3, 294.4
 // against 300.5 ms as named: its shadow rays walk with one entry per level and its 16 x 2 workgroups get 48 KB of prefix instead of 16)
-// PARK (round 6, trc_render_kernels.hpp::render_block): kParkRows words of a lane's LDS column hold the values that are touched only
-// where a sample begins or ends (running mean, (u, v), pixel coordinates, sample counter) and the two work counters, so that they are
-// not carried -- and spilled to scratch -- through the walk and the shading code of every iteration.  Paid for with stack entries:
-// tracePath keeps 10 instead of 16 in LDS (deeper ones: the global rows) and most of its node prefix goes (profiles/r06/ab_park_*.txt).
-enum : uint32_t { kParkCachedX = 0, kParkCachedY, kParkCachedZ, kParkU, kParkV, kParkPx, kParkPy, kParkSample, kParkRays, kParkShaded, kParkRows };
+// PARK (round 6, trc_render_kernels.hpp::render_block): words of a lane's LDS column hold the values that are touched only where a sample
+// begins or ends (running mean, (u, v), sample counter) and the two work counters, so that they are not carried -- and spilled to scratch
+// -- through the walk and the shading code of every iteration.  8 rows, or 10 with the pixel's coordinates (with 8 they are worked out
+// again at the end from the launch entry, read once more).  Paid for with stack entries / node prefix; per kernel family, each measured
+// (profiles/r06/ab_park_*.txt): 0 = off.
+enum : uint32_t { kParkCachedX = 0, kParkCachedY, kParkCachedZ, kParkU, kParkV, kParkSample, kParkRays, kParkShaded, kParkPx, kParkPy };
 #ifndef TRC_PARK_PATH
-#define TRC_PARK_PATH 1
+#define TRC_PARK_PATH 8          // 8 rows + 12 stack entries against 10 + 10: -0.6 % on config 4 and on the 4 M-triangle scene (ab_park_rows_config4.txt)
 #endif
 #ifndef TRC_PARK_MIS
 #define TRC_PARK_MIS 0
 #endif
 #ifndef TRC_PARK_VOLUME
-#define TRC_PARK_VOLUME 1
+#define TRC_PARK_VOLUME 10       // (8: +3 %, ab_park_rows_volume.txt)
 #endif
-constexpr bool pwg_park(int integrator) { return integrator == TRC_INTEGRATOR_PATH ? TRC_PARK_PATH != 0 : (integrator == TRC_INTEGRATOR_MIS ? TRC_PARK_MIS != 0 : TRC_PARK_VOLUME != 0); }
+#ifndef TRC_PARK_DENSE
+#define TRC_PARK_DENSE 0         // k_render_dense (the headline kernel: tracePath, whole tree in LDS): 8 rows are what six waves per SIMD leave, and they
+#endif                           // take its scratch from 88 to 32 bytes per lane -- and its time from 16.57 to 17.19 ms (ab_park_dense_config2.txt):
+                                 // the kernel is bound by issue, and an LDS access is an issued instruction + a wait where the spill was one too.  Off.
+constexpr uint32_t pwg_park_rows(int integrator) { return integrator == TRC_INTEGRATOR_PATH ? TRC_PARK_PATH : (integrator == TRC_INTEGRATOR_MIS ? TRC_PARK_MIS : TRC_PARK_VOLUME); }
+static_assert((TRC_PARK_PATH == 0 || TRC_PARK_PATH == 8 || TRC_PARK_PATH == 10) && (TRC_PARK_MIS == 0 || TRC_PARK_MIS == 8 || TRC_PARK_MIS == 10) &&
+              (TRC_PARK_VOLUME == 0 || TRC_PARK_VOLUME == 8 || TRC_PARK_VOLUME == 10) && (TRC_PARK_DENSE == 0 || TRC_PARK_DENSE == 8 || TRC_PARK_DENSE == 10), "park rows: 0, 8 or 10");
 #ifndef TRC_PWG_STACK_LDS_PATH
-#define TRC_PWG_STACK_LDS_PATH (TRC_PARK_PATH ? 10 : 16)
+#define TRC_PWG_STACK_LDS_PATH (TRC_PARK_PATH == 10 ? 10 : (TRC_PARK_PATH == 8 ? 12 : 16))
 #endif
 #ifndef TRC_PWG_STACK_LDS_MIS
 #define TRC_PWG_STACK_LDS_MIS 8

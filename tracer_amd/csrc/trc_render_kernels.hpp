@@ -11,12 +11,12 @@
 // this lane's columns of the wavefront's traversal stack.  Shared by k_render (one block per one-wavefront workgroup) and
 // k_render_pwg (wavefronts of a persistent workgroup pulling blocks from a queue).
 //
-// PARK (k_render_pwg on trees read from memory): the values a lane touches only where a sample begins or ends -- the running mean,
-// (u, v), the pixel's coordinates, the sample counter -- and the two work counters live in kParkRows words of the lane's LDS column
-// `park` (row r at park[r * kBlock]) instead of registers: ten values fewer to carry through the walk and the shading code of every
-// iteration, i.e. fewer spills to scratch -- which on a mesh scene streams through the L2 the node fetches live in.
-// Same loads, same arithmetic, same stores per lane; the LDS rows are paid for with traversal-stack entries (trc_render_config.hpp).
-template <bool LDS, bool STATS, int INTEGRATOR, bool SOBOL, bool HYB, bool PARK = false, class COUNT = uint32_t>
+// PARK = 8 | 10 (k_render_pwg on trees read from memory, k_render_dense): the values a lane touches only where a sample begins or ends
+// -- the running mean, (u, v), the sample counter, with 10 rows the pixel's coordinates -- and the two work counters live in PARK words
+// of the lane's LDS column `park` (row r at park[r * kBlock]) instead of registers: that many values fewer to carry through the walk and
+// the shading code of every iteration, i.e. fewer spills to scratch -- which on a mesh scene streams through the L2 the node fetches
+// live in, and on the LDS-resident headline scene are issue slots.  Same loads, same arithmetic, same stores per lane.
+template <bool LDS, bool STATS, int INTEGRATOR, bool SOBOL, bool HYB, int PARK = 0, class COUNT = uint32_t>
 __device__ __forceinline__ void render_block(const KRender& kp, const DScene& sc, const uint32_t* small_base, uint32_t* stack, uint32_t* lvstack,
                                              uint32_t* ovf, uint32_t* park, const uint32_t slot, const uint32_t lane,
                                              COUNT& n_rays, COUNT& n_shaded, uint32_t& n_paths, TravCounters& cnt) {
@@ -80,7 +80,8 @@ __device__ __forceinline__ void render_block(const KRender& kp, const DScene& sc
             const float v = (float)(py % kp.view_height) / (float)kp.view_height;      // one view: view_height == H
             set_cached(f3(acc.x, acc.y, acc.z));
             set_sample(0u);
-            if constexpr (PARK) { put_f(kParkU, u); put_f(kParkV, v); park[kParkPx * kBlock] = px; park[kParkPy * kBlock] = py; }
+            if constexpr (PARK) { put_f(kParkU, u); put_f(kParkV, v); }
+            if constexpr (PARK >= 10) { park[kParkPx * kBlock] = px; park[kParkPy * kBlock] = py; }
             else { u_r = u; v_r = v; pix_r = pix; }
         }
 
@@ -157,7 +158,22 @@ __device__ __forceinline__ void render_block(const KRender& kp, const DScene& sc
             texel.w = (uint32_t)rng.inc;   texel.z = (uint32_t)(rng.inc >> 32);
         }
         const F3 cached = get_cached();
-        const size_t pix = PARK ? (size_t)park[kParkPy * kBlock] * W + park[kParkPx * kBlock] : pix_r;
+        size_t pix = pix_r;
+        if constexpr (PARK >= 10) pix = (size_t)park[kParkPy * kBlock] * W + park[kParkPx * kBlock];
+        else if constexpr (PARK != 0) {
+            // 8 rows: the pixel's coordinates are not carried at all -- the launch entry is read once more (volatile: a second load, not
+            // a value kept alive through the loop) and decoded as at the top
+            const uint32_t entry2 = kp.order ? *reinterpret_cast<const volatile uint32_t*>(kp.order + slot) : slot;
+            const uint32_t code2 = entry2 >> kLaunchCodeShift;
+            const uint32_t tile2 = *reinterpret_cast<const volatile uint32_t*>(kp.tiles + (entry2 & kLaunchIndexMask));
+            const uint32_t part2 = code2 >= 21u ? (code2 - 21u) >> 2 : (code2 >= 5u ? code2 - 5u : 0u);
+            const uint32_t quarter2 = code2 >= 5u ? part2 >> 2 : (code2 ? code2 - 1u : 0u);
+            const uint32_t bs2 = code2 >= 21u ? 0u : (code2 >= 5u ? 1u : (code2 ? 2u : kp.blk_shift));
+            const uint32_t pixel2 = code2 >= 21u ? (code2 - 21u) & 3u : 0u;
+            const uint32_t qx2 = code2 ? ((quarter2 & 1u) << 2) + (code2 >= 5u ? (part2 & 1u) << 1 : 0u) + (pixel2 & 1u) : 0u;
+            const uint32_t qy2 = code2 ? ((quarter2 >> 1) << 2) + (code2 >= 5u ? ((part2 >> 1) & 1u) << 1 : 0u) + (pixel2 >> 1) : 0u;
+            pix = (size_t)(((tile2 >> 16) << kp.blk_shift) + qy2 + (lane >> bs2)) * W + ((tile2 & 0xFFFFu) << kp.blk_shift) + qx2 + (lane & ((1u << bs2) - 1u));
+        }
         float4 out; out.x = cached.x; out.y = cached.y; out.z = cached.z; out.w = 1.0f;
         reinterpret_cast<float4*>(kp.fr.accum)[pix] = out;
         reinterpret_cast<uint4*>(kp.fr.rng)[pix] = texel;
@@ -168,7 +184,7 @@ __device__ __forceinline__ void render_block(const KRender& kp, const DScene& sc
 }
 
 // the body of k_render (one one-wavefront workgroup = one entry of the launch list)
-template <bool LDS, bool STATS, int INTEGRATOR, bool SOBOL>
+template <bool LDS, bool STATS, int INTEGRATOR, bool SOBOL, int PARK = 0>
 __device__ __forceinline__ void render_workgroup(const KRender& kp) {
     if (kp.n_launch && blockIdx.x >= *kp.n_launch) return;      // the grid is sized for the most quarters a plan may splice in
     const DScene& sc = kp.ks.sc;
@@ -182,6 +198,13 @@ __device__ __forceinline__ void render_workgroup(const KRender& kp) {
     counters_zero(cnt);
     constexpr bool kHybridStack = !LDS && !STATS && hybrid_stack(INTEGRATOR);     // plan_launch_lds
     uint32_t* ovf = kHybridStack ? kp.stack_ovf + (size_t)blockIdx.x * sc.stack_ovf_rows * kBlock + lane : nullptr;
+    if constexpr (PARK != 0) {                  // the park rows follow the stack rows of this one-wavefront workgroup (trc_abi.hip: dense_lds_bytes)
+        uint32_t* park = stack + sc.stack_lds * kBlock;
+        park[kParkRays * kBlock] = 0u; park[kParkShaded * kBlock] = 0u;
+        LdsCount c_rays{park + kParkRays * kBlock}, c_shaded{park + kParkShaded * kBlock};
+        render_block<LDS, STATS, INTEGRATOR, SOBOL, kHybridStack, PARK>(kp, sc, small_base, stack, lvstack, ovf, park, blockIdx.x, lane, c_rays, c_shaded, n_paths, cnt);
+        n_rays = park[kParkRays * kBlock]; n_shaded = park[kParkShaded * kBlock];
+    } else
     render_block<LDS, STATS, INTEGRATOR, SOBOL, kHybridStack>(kp, sc, small_base, stack, lvstack, ovf, nullptr, blockIdx.x, lane, n_rays, n_shaded, n_paths, cnt);
 
     // exact work counters: wave reduction, one 64-bit atomic per wave and counter
@@ -240,8 +263,8 @@ __global__ void __launch_bounds__(64 * pwg_waves(INTEGRATOR), pwg_waves(INTEGRAT
     }
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     constexpr bool kHybridStack = hybrid_stack(INTEGRATOR);
-    constexpr bool kPark = pwg_park(INTEGRATOR);
-    constexpr uint32_t kRows = kPark ? kParkRows : 0u;          // a wavefront's LDS: stack_lds stack rows, then the park rows (render_block)
+    constexpr uint32_t kRows = pwg_park_rows(INTEGRATOR);       // a wavefront's LDS: stack_lds stack rows, then the park rows (render_block)
+    constexpr bool kPark = kRows != 0u;
     uint32_t* stack = trc_smem + sc.lds_dwords + wave * (sc.stack_lds + kRows) * kBlock + lane;
     uint32_t* park = stack + sc.stack_lds * kBlock;
     uint32_t* ovf = kHybridStack ? kp.stack_ovf + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * sc.stack_ovf_rows * kBlock + lane : nullptr;
@@ -258,7 +281,7 @@ __global__ void __launch_bounds__(64 * pwg_waves(INTEGRATOR), pwg_waves(INTEGRAT
             if (lane == 0) slot = atomicAdd(kp.queue, 1u);
             slot = __builtin_amdgcn_readfirstlane(slot);
             if (slot >= n_entries) break;
-            render_block<false, false, INTEGRATOR, SOBOL, kHybridStack, true>(kp, sc, trc_smem, stack, nullptr, ovf, park, slot, lane, n_rays, n_shaded, n_paths, cnt);
+            render_block<false, false, INTEGRATOR, SOBOL, kHybridStack, (int)kRows>(kp, sc, trc_smem, stack, nullptr, ovf, park, slot, lane, n_rays, n_shaded, n_paths, cnt);
         }
         r_rays = wave_sum(park[kParkRays * kBlock]); r_shaded = wave_sum(park[kParkShaded * kBlock]);
     } else {

@@ -10,7 +10,7 @@
 
 // tracePath on an LDS-resident tree at one more wavefront per SIMD, for launch lists many times the wavefront slots (trc_render_config.hpp)
 __global__ void __launch_bounds__(kBlock, TRC_PATH_WAVES_DENSE) k_render_dense(const KRender kp) {
-    render_workgroup<true, false, TRC_INTEGRATOR_PATH, false>(kp);
+    render_workgroup<true, false, TRC_INTEGRATOR_PATH, false, TRC_PARK_DENSE>(kp);      // + per-pixel state parked in LDS rows (render_block)
 }
 
 #define TRC_INST_RENDER(S, I, B) template __global__ void k_render<true, S, I, B>(const KRender)

@@ -818,16 +818,16 @@ trc_status trc_sppm_hash_cells(trc_ctx* ctx, const float* cells, size_t n, float
     float *d_in = nullptr, *d_out = nullptr;
     HIP_TRY(ctx, hipMalloc((void**)&d_in, n * 12));
     if (hipMalloc((void**)&d_out, n * 4) != hipSuccess) { (void)hipFree(d_in); return trc_fail(ctx, TRC_ERR_OOM, "hipMalloc"); }
-    hipError_t e = hipMemcpyAsync(d_in, cells, n * 12, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) {
+    trc_status ts = trc_copy_to_device(ctx, d_in, cells, n * 12, ctx->stream);
+    if (ts == TRC_OK) {
         hipLaunchKernelGGL(k_sppm_hash_cells, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_in, (uint32_t)n, hash_scale, d_out);
-        e = hipGetLastError();
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) ts = trc_fail(ctx, TRC_ERR_HIP, std::string("trc_sppm_hash_cells: ") + hipGetErrorString(e));
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * 4, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream); else (void)hipStreamSynchronize(ctx->stream);
+    if (ts == TRC_OK) ts = trc_copy_to_host(ctx, out, d_out, n * 4, ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_in); (void)hipFree(d_out);
-    if (e != hipSuccess) return trc_fail(ctx, TRC_ERR_HIP, std::string("trc_sppm_hash_cells: ") + hipGetErrorString(e));
-    return TRC_OK;
+    return ts;
 }
 #endif  // TRC_TEST_HOOKS
 
@@ -842,10 +842,10 @@ trc_status trc_sppm_download(trc_ctx* ctx, trc_CameraRecord* cam, trc_PhotonReco
     if (cam) {
         HIP_TRY(ctx, hipMalloc((void**)&d_packed, np * sizeof(trc_CameraRecord)));
         hipLaunchKernelGGL(k_sppm_pack_records, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, s->vp[s->cur], d_packed, (uint32_t)np);
-        hipError_t ce = hipMemcpyAsync(cam, d_packed, np * sizeof(trc_CameraRecord), hipMemcpyDeviceToHost, ctx->stream);
-        if (ce == hipSuccess) ce = hipStreamSynchronize(ctx->stream);
+        const trc_status cs = trc_copy_to_host(ctx, cam, d_packed, np * sizeof(trc_CameraRecord), ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
         (void)hipFree(d_packed);
-        if (ce != hipSuccess) return trc_fail(ctx, TRC_ERR_HIP, std::string("trc_sppm_download: camera records: ") + hipGetErrorString(ce));
+        if (cs != TRC_OK) return cs;
     }
     if (pho) {
         if (s->pho_partial && ctx->grouped()) {           // the per-frame gather moves 40 bytes per photon: the whole records, now (collective)
@@ -854,11 +854,11 @@ trc_status trc_sppm_download(trc_ctx* ctx, trc_CameraRecord* cam, trc_PhotonReco
             if (cs != TRC_OK) return cs;
             s->pho_partial = false;
         }
-        HIP_TRY(ctx, hipMemcpyAsync(pho, s->d_pho, nph * sizeof(trc_PhotonRecord), hipMemcpyDeviceToHost, ctx->stream));
+        { const trc_status cs = trc_copy_to_host(ctx, pho, s->d_pho, nph * sizeof(trc_PhotonRecord), ctx->stream); if (cs != TRC_OK) return cs; }
     }
     std::vector<uint32_t> hm, hc;
-    if (mark) { hm.resize(nph); HIP_TRY(ctx, hipMemcpyAsync(hm.data(), s->d_mark, nph * 4, hipMemcpyDeviceToHost, ctx->stream)); }
-    if (count) { hc.resize(nph); HIP_TRY(ctx, hipMemcpyAsync(hc.data(), s->d_count, nph * 4, hipMemcpyDeviceToHost, ctx->stream)); }
+    if (mark) { hm.resize(nph); const trc_status cs = trc_copy_to_host(ctx, hm.data(), s->d_mark, nph * 4, ctx->stream); if (cs != TRC_OK) return cs; }
+    if (count) { hc.resize(nph); const trc_status cs = trc_copy_to_host(ctx, hc.data(), s->d_count, nph * 4, ctx->stream); if (cs != TRC_OK) return cs; }
     DComplex h;
     HIP_TRY(ctx, hipMemcpyAsync(&h, s->d_cx, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
