@@ -223,11 +223,12 @@ def other_config_leg(key, device, steps=2):
 
         def step(n):
             t.seed(SEED); t.clear_accum(); t.render(spp=n, max_depth=DEPTH, integrator=integ)
-        # the launch order and split plan settle on per-SAMPLE costs, so short launches settle them: 8 x 32 spp, then
-        # one launch of the named length, then the timed ones
+        # the launch order and split plan settle on per-SAMPLE costs, so short launches do most of it: 8 x 32 spp, then
+        # three launches of the named length (the split plan's K keeps ramping for a few launches on config 3), then the timed ones
         for _ in range(SETTLE_LAUNCHES):
             step(min(32, spp))
-        step(spp)
+        for _ in range(3):
+            step(spp)
         t.synchronize(); t.reset_stats()
         t0 = time.perf_counter()
         for _ in range(steps):
