@@ -288,6 +288,20 @@ def parse_functions():
     gm = body_after(micro, r"struct\s+GlassMaterial\s*")
     fn["GlassMaterial.kr_kt_ratio"] = literals(gm[:gm.index("GlassMaterial(")].replace("MicrofacetReflection", " ").replace("MicrofacetTransmission", " "))
     fn["rgb_to_y"] = literals(re.search(r"(0\.212671f[^;]*;)", spectrum).group(1)) if "0.212671f" in spectrum else []
+    # round 6, second batch: the output stage, the checker texture, the media, the photon emission, the path depth
+    render_hh = strip_comments(read("RT_Metal/Metal/Render.hh"))
+    render_metal = strip_comments(read("RT_Metal/Metal/Render.metal"))
+    texture_hh = strip_comments(read("RT_Metal/Metal/Texture.hh"))
+    fn["ACESTone"] = literals(body_after(render_hh, r"inline\s+float3\s+ACESTone\s*\("))
+    chk = re.search(r"case\s+TextureType::Checker\s*:\s*\{(.*?)\}", texture_hh, re.S).group(1)
+    fn["Texture::Checker"] = literals(chk, floats_only=False)
+    fn["HomogeneousMedium.args"] = [eval_expr(a) for a in call_args(render_metal, "HomogeneousMedium")[0]]
+    kp = body_after(render_metal, r"kernel\s+void\s*\n?\s*kernelPathTracing\s*\(")
+    fn["kernelPathTracing.depth"] = [float(re.search(r"=\s*trace(?:Path|MIS|Volume)\s*\(\s*(\d+)\s*,", kp).group(1))]
+    pr = body_after(photon_metal, r"kernel\s+void\s*\n?\s*kernelPhotonRecording\s*\(")
+    fn["kernelPhotonRecording.origin"] = vec(re.search(r"auto\s+_origin\s*=\s*(float3\s*\([^)]*\))", pr).group(1))
+    fn["kernelPhotonRecording.flux_scale"] = [eval_expr(re.search(r"albedo\s*\*\s*([\d.]+)\s*;", pr).group(1))]
+    fn["kernelPhotonRecording.light_squares"] = [float(x) for x in re.findall(r"squareList\[(\d+)\]\.sample", pr)]
     m = re.search(r"#define\s+PHOTON_HASHN\s+(\d+)", common)
     fn["PHOTON_HASHN"] = [float(m.group(1))]
     m = re.search(r"const\s+float\s+alpha\s*=\s*([\d.]+)\s*;", photon_metal)
@@ -298,7 +312,7 @@ def parse_functions():
 def main():
     files = ["RT_Metal/Tracer/Tracer.mm", "RT_Metal/Tracer/AAPLRenderer.mm", "RT_Metal/Metal/Math.hh", "RT_Metal/Metal/MicrofacetBXDF.h",
              "RT_Metal/Metal/BXDF.metal", "RT_Metal/Metal/Photon.hh", "RT_Metal/Metal/Photon.metal", "RT_Metal/Metal/Common.hh",
-             "RT_Metal/Metal/Square.hh", "RT_Metal/Metal/Spectrum.hh"]
+             "RT_Metal/Metal/Square.hh", "RT_Metal/Metal/Spectrum.hh", "RT_Metal/Metal/Render.hh", "RT_Metal/Metal/Render.metal", "RT_Metal/Metal/Texture.hh"]
     doc = {"about": "numbers parsed out of the reference's sources by tests/golden/make_reference_constants.py (data, not source text)",
            "sources_sha256": {f: hashlib.sha256(open(os.path.join(REF, f), "rb").read()).hexdigest()[:16] for f in files},
            "scene": parse_scene(), "functions": parse_functions()}

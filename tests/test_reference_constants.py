@@ -11,6 +11,7 @@ import importlib.util
 import json
 import math
 import os
+import re
 import struct
 
 import numpy as np
@@ -320,3 +321,41 @@ def test_photon_hash_follows_the_parsed_constants(ref):
         want = F(np.floor(F(fract * F(n_hash * n_hash))))
         got = L.orc_photon_hash((C.c_float * 3)(*idx), hs)
         assert got == want, (idx, hs)
+
+
+def test_output_stage_texture_media_and_photon_emission_constants(ref):
+    """second batch (round 6): ACESTone's five coefficients, the checker texture's frequencies, the homogeneous medium as
+    Render.metal:118 constructs it, the path depth, and the photon emission (origin, flux scale, light squares) -- the reference's text
+    against the oracle's and the kernels' spelling of them, and against what the library does with them where an entry point shows it"""
+    fn = ref["functions"]
+    o = src("oracle/oracle.cpp")
+    i = o.index("const float A =")
+    assert mk.literals(o[i:i + 90]) == fn["ACESTone"]                                        # orc_tonemap's copy
+    abi_hip = src("tracer_amd/csrc/trc_abi.hip")
+    i = abi_hip.index("const float A =")
+    assert mk.literals(abi_hip[i:i + 90]) == fn["ACESTone"]                                  # k_tonemap's copy
+    # the checker: sin(8 pi u) * cos(pi / 2 + 4 pi v), 0.5 * step(0, .) + 0.5
+    assert fn["Texture::Checker"] == [8.0, 2.0, 4.0, 0.5, 0.0, 0.5]
+    for text, a, b in ((o, "m_sin(8 * PI_F * uv.x)", "m_cos(PI_F / 2 + 4 * PI_F * uv.y)"),
+                       (src("tracer_amd/csrc/dev_bsdf.hpp"), "8 * kPi * uv.x", "kPi / 2 + 4 * kPi * uv.y")):
+        assert a in text and b in text
+    # media, depth, photon emission
+    assert fn["HomogeneousMedium.args"] == [0.02, 0.08, 0.5]
+    for text in (o, src("tracer_amd/csrc/dev_integrator.hpp")):
+        i = text.index("sigma_a = ")
+        assert [v for v in mk.literals(text[i:i + 260]) if v in (0.02, 0.08, 0.5)][:2] == [0.02, 0.08] and "0.5f" in text[i:i + 900]
+    assert fn["kernelPathTracing.depth"] == [8.0] and abi.Params().max_depth in (0, 8)
+    assert fn["kernelPhotonRecording.origin"] == [450.0, 250.0, 250.0] and fn["kernelPhotonRecording.flux_scale"] == [100000.0]
+    assert fn["kernelPhotonRecording.light_squares"] == [5.0, 6.0]
+    for text in (o, src("tracer_amd/csrc/trc_sppm.hip")):
+        assert re.search(r"\(450, 250, 250\)", text) and re.search(r"\* 100000\.0f", text)
+        assert re.search(r"square_sample\(cx\.S, 5,|squareList\[5\]|sample_square\(.*5", text)
+    # what the tone mapper does with the five coefficients: one grey pixel through orc_tonemap against a float64 evaluation
+    acc = np.zeros((4, 4, 4), np.float32); acc[..., :3] = 0.18; acc[..., 3] = 1.0
+    img, exposure = pyoracle.tonemap(acc)
+    A, B, Cc, D, E = fn["ACESTone"]
+    c = 0.18 * exposure
+    want = (c * (A * c + B)) / (c * (Cc * c + D) + E)
+    assert abs(int(img[0, 0, 0]) - int(min(max(want, 0.0), 1.0) * 255.0 + 0.5)) <= 1 and 20 < int(img[0, 0, 0]) < 250
+    bad = (A + 0.3, B, Cc, D, E)                                     # teeth: a digit of the first coefficient moves the pixel
+    assert abs(int(img[0, 0, 0]) - int(min((c * (bad[0] * c + B)) / (c * (Cc * c + D) + E), 1.0) * 255.0 + 0.5)) > 1
