@@ -1,7 +1,7 @@
 #!/bin/bash
 # The sanitizer recipe:
 #   make asan tsan            builds tools/sanitize/driver.cpp + the host / oracle sources under ASan+UBSan and under TSan
-#   bash tools/run_sanitizers.sh [fuzz iterations per reader, default 3000] [round directory, default r05]
+#   bash tools/run_sanitizers.sh [fuzz iterations per reader, default 3000] [round directory, default r06]
 # runs (1) the ASan+UBSan driver, (2) the TSan driver, (3) the Python CPU test files that exercise the host library and the
 # oracle against the ASan+UBSan shared libraries (the sanitizer runtime preloaded into python).
 # Every leg's FULL output goes to build/sanitize_logs/<leg>.log and is what the report patterns are searched in (a
@@ -10,7 +10,7 @@
 set -u
 cd "$(dirname "$0")/.."
 N=${1:-3000}
-ROUND=${2:-r05}
+ROUND=${2:-r06}
 OUT=profiles/$ROUND/sanitizers.txt
 LOGS=build/sanitize_logs
 mkdir -p "profiles/$ROUND" "$LOGS"
