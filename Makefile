@@ -27,7 +27,7 @@ EXTRA_trc_render_mem_volume := -mllvm -disable-machine-sink
 EXTRA_trc_render_lds      := -mllvm -amdgpu-use-amdgpu-trackers
 HIP_HDR   := $(wildcard tracer_amd/csrc/*.hpp) include/tracer_abi.h include/tracer_test_hooks.h include/trc_detmath.h include/trc_sobol.h
 
-.PHONY: all host hip hip_fast hip_hooks oracle example clean variant asan tsan sanitize
+.PHONY: all host hip hip_fast hip_hooks oracle example clean variant asan tsan sanitize design_table
 all: host hip hip_fast hip_hooks oracle example
 
 host: $(LIBDIR)/libtrc_host.so
@@ -117,3 +117,6 @@ sanitize:
 clean:
 	rm -f $(LIBDIR)/*.so examples/trc_render examples/trc_ranks
 	$(MAKE) -C oracle clean
+
+design_table:
+	python3 tools/design_table.py --write

@@ -4,6 +4,8 @@
 # The PMC summaries carry the source hash of the library they were collected on; bench.py quotes pmc_config2.json only when
 # that hash is the running library's, so the bench line and the as-named lines are taken in a SECOND call, after the summaries
 # have been committed:  gpurun -- 'bash tools/regen_profiles.sh r04 lines'
+# Round 6: `... r06 pmc` = the PMC set alone; after `lines`, copy gpurun_out/<round>/{bench_line_*.json,configs_as_named.jsonl,pmc_*.json,*_kernel_stats.csv}
+# into profiles/<round>/ and run  python3 tools/design_table.py --round <round> --write  -- the ONE table of numbers in DESIGN.md section 8 is generated from them.
 R=${1:-r06}; O=gpurun_out/$R; mkdir -p $O
 export TMPDIR=/tmp
 if [ "$2" = "lines" ]; then      # second call, after the PMC summaries of the first have been copied to profiles/<round>/ and committed
