@@ -111,6 +111,41 @@ def test_self_launch_does_not_hang_when_a_rank_dies():
     assert "a rank failed" in out.stderr and not out.stdout.strip()
 
 
+def test_the_committed_goldens_cover_every_frame_bench_holds_itself_to():
+    """tests/golden/bench_goldens.json (the oracle at the named sizes, make_bench_goldens.py): one entry per frame bench.py checks --
+    the headline, the sample-sharded and stacked-view composes for N = 2, 4, 8, the other configurations -- and check_against's verdicts"""
+    g = bench.load_goldens()
+    for k in ["config2", "config3", "config4", "volume", "config5_sppm"] + [f"config2_samples_S{n}" for n in (2, 4, 8)] + [f"config2_weak_N{n}" for n in (2, 4, 8)]:
+        assert k in g and isinstance(g[k]["crc_accum"], int) and 0 <= g[k]["crc_accum"] < 2**32, k
+    assert g["config2"]["rays"] == 219978393 and g["config3"]["rays"] == 1677111408 and g["config4"]["rays"] == 938746169 and g["volume"]["rays"] == 445116398
+    assert g["config2_weak_N2"]["rays"] > 2 * 0.99 * g["config2"]["rays"] and g["config5_sppm"]["frame_count"] == 64
+    assert len({g[f"config2_samples_S{n}"]["crc_accum"] for n in (2, 4, 8)} | {g["config2"]["crc_accum"]}) == 4       # four different sample sets
+    ok = bench.check_against(g, "config2", crc=g["config2"]["crc_accum"], rays=219978393)
+    assert ok == {"golden": "config2", "crc_ok": True, "rays_ok": True}
+    bad = bench.check_against(g, "config2", crc=g["config2"]["crc_accum"] ^ 1, rays=219978392)
+    assert bad["crc_ok"] is False and bad["rays_ok"] is False
+    none = bench.check_against(g, "config2_samples_S3", crc=1)
+    assert none["golden"] is None and "crc_ok" not in none and "make_bench_goldens" in none["missing"]
+    s5 = bench.check_against(g, "config5_sppm", crc=g["config5_sppm"]["crc_accum"], extra={"totalPhotonSum": g["config5_sppm"]["totalPhotonSum"], "frame_count": 63})
+    assert s5["crc_ok"] and s5["totalPhotonSum_ok"] is True and s5["frame_count_ok"] is False
+    assert bench.frame_crc(np.zeros((2, 2, 4), np.float32)) == 0x758D6336                       # zlib.crc32 of 64 zero bytes
+
+
+def test_other_config_rooflines_follow_the_source_hash_rule(monkeypatch):
+    """a leg's `roofline` comes from profiles/rNN/pmc_<config>.json only when that summary was collected on the running library"""
+    roof, pm = bench.config_roofline("config4", "k_render_pwg<0, false>")
+    mine = bench.lib_source_hash()
+    if pm is not None:
+        assert pm["lib_source_hash"] == mine and 0 < roof["frac"] <= 1 and roof["bound"] == "valu-issue" and "spp" in roof["pmc_launch"]
+    else:
+        assert roof["frac"] is None and "stale" in roof
+    monkeypatch.setattr(bench, "lib_source_hash", lambda: "0123456789abcdef")
+    roof, pm = bench.config_roofline("config4", "k_render_pwg<0, false>")
+    assert pm is None and roof["frac"] is None and "was collected on library" in roof["stale"]
+    roof, pm = bench.config_roofline("no_such_config", "k")
+    assert pm is None and "no profiles" in roof["stale"]
+
+
 def test_gpu_count_probe_does_not_touch_hip():
     assert isinstance(bench.visible_gpus(), int) and bench.visible_gpus() >= 0
 
