@@ -864,6 +864,12 @@ def main(argv=None):
             line["transport"] = "rccl" if use_rccl else "table"
         if world > 1:
             line["per_rank"] = primary["per_rank"]
+            # how to read an N-GPU curve of this line: the tile split renders the ONE frame BASELINE names, bit for bit, and a
+            # pixel's samples are one sequential chain -- a share ends on its slowest item however few it owns (one GPU emulating a rank:
+            # 39 / 26 / 22 % efficiency at N = 8 on configs 2 / 3 / 4, profiles/r06/share_bounds.txt); the split that scales (84 / 92 / 93 %
+            # there) is the sample-sharded one, measured in the same run under other_scaling.samples
+            line["scaling_note"] = ("strong = tile split of the named frame (bit-identical to one GPU; chain-bound: per_rank[].longest_chain_ms vs "
+                                    "work_over_slots_ms); the split that scales is other_scaling.samples (sample shards, bit-defined)")
         if world == 1 and not args.no_fast_math:
             line["fast_math_variant"] = fast_math_leg(scene, cam, args.steps)
         if not args.no_cpu_baseline and world == 1:      # CPU baselines: rank 0 at N = 1 only
