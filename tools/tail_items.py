@@ -21,7 +21,7 @@ for i in range(a.launches):
 ms = t.stats().kernel_ms
 shape = t.launch_shape()
 tiles, costs, bs = t.block_costs()
-c = (costs & 0x3FFFFFFF).astype(np.float64)
+c = (costs & 0xFFFFFF).astype(np.float64)          # bits 31 / 30 / 29: ran in parts / some as 2x2 sixteenths / some as single pixels
 parts, deep = (costs >> 31) & 1, (costs >> 30) & 1
 scale = shape["longest_entry_ms"] / c.max()
 d = c * scale
